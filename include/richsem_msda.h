@@ -1,0 +1,136 @@
+/*
+ * richsem_msda.h -- C ABI of the MI355X (gfx950) multi-scale deformable attention library
+ * (librichsem_msda.so, built from richsem_amd/csrc by hipcc --offload-arch=gfx950).
+ *
+ * This is the drop-in boundary for the reference's native extension
+ * `MultiScaleDeformableAttention` (reference models/richsem/ops/src/vision.cpp:13-16):
+ *
+ *   reference (pybind11 / ATen)                                   this library (extern "C")
+ *   ------------------------------------------------------------  ---------------------------
+ *   ms_deform_attn_forward   src/ms_deform_attn.h:20-39            msda_forward_{f32,f64}
+ *     -> ms_deform_attn_cuda_forward  src/cuda/ms_deform_attn_cuda.cu:20-80
+ *   ms_deform_attn_backward  src/ms_deform_attn.h:41-61            msda_backward_{f32,f64}
+ *     -> ms_deform_attn_cuda_backward src/cuda/ms_deform_attn_cuda.cu:83-153
+ *
+ * Plain pointers and sizes only; no torch / ATen types.  All data pointers are DEVICE pointers
+ * to contiguous row-major tensors with the reference's layouts
+ * (src/cuda/ms_deform_attn_cuda.cu:40-48):
+ *
+ *   value          (N, S, M, D)            S = sum_l H_l*W_l
+ *   spatial_shapes (L, 2) int64            (H_l, W_l)                        [device]
+ *   level_start    (L)    int64            start row of level l inside S     [device]
+ *   sampling_loc   (N, Lq, M, L, P, 2)     (x, y) normalised to [0,1] over the padded map
+ *   attn_weight    (N, Lq, M, L, P)
+ *   out / grad_out (N, Lq, M*D)
+ *   grad_value, grad_sampling_loc, grad_attn_weight: shaped like value / sampling_loc / attn_weight
+ *
+ * Differences from the reference binding, all on the ownership side:
+ *   - outputs are caller-allocated; they need NOT be zero-filled (the reference allocates them
+ *     with at::zeros, ms_deform_attn_cuda.cu:54,121-123; here the library zero-fills what its
+ *     kernels accumulate into, on `stream`);
+ *   - the HIP stream is an explicit argument (the reference takes the current stream,
+ *     ms_deform_attn_cuda.cu:65,135); work is enqueued, never synchronised;
+ *   - `shapes_host` / `level_start_host` are optional HOST mirrors of the two int64 tensors.
+ *     The launch geometry and the argument checks need the level sizes on the host; when the
+ *     mirrors are NULL the library copies them from the device, which synchronises `stream`
+ *     (correct, slower; a training loop should pass the mirrors, as the Python shim does);
+ *   - errors are returned (and described by msda_last_error()), never only printed as in
+ *     ms_deform_im2col_cuda.cuh:948-952.
+ *
+ * `im2col_step` keeps the reference's contract (N % min(N, im2col_step) == 0, otherwise
+ * MSDA_ERR_IM2COL_STEP; ms_deform_attn_cuda.cu:50-52).  Images are independent, so the
+ * library processes the whole batch in one launch whatever the step is; results are identical.
+ *
+ * Thread safety: entry points keep no global mutable state except the option table set by
+ * msda_set_option(); they may be called concurrently on different streams (forward thread
+ * and autograd thread).
+ */
+#ifndef RICHSEM_MSDA_H
+#define RICHSEM_MSDA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RICHSEM_MSDA_ABI_VERSION 1
+
+/* Return codes: 0 = success; negative = argument error detected on the host (nothing was
+ * launched); positive = hipError_t reported by the runtime. */
+enum {
+    MSDA_OK = 0,
+    MSDA_ERR_NULL_POINTER = -1,
+    MSDA_ERR_BAD_DIMS = -2,      /* non-positive dimension, sum H*W != S, bad level_start   */
+    MSDA_ERR_IM2COL_STEP = -3,   /* N % min(N, im2col_step) != 0                            */
+    MSDA_ERR_TOO_LARGE = -4,     /* a tensor has >= 2^31 elements (32-bit index math, as the */
+                                 /* reference: ms_deform_im2col_cuda.cuh:255-263)           */
+    MSDA_ERR_MISALIGNED = -5,    /* a data pointer is not aligned to its element size        */
+    MSDA_ERR_NO_DEVICE = -6,     /* no gfx950 device / code object not loadable              */
+    MSDA_ERR_BAD_OPTION = -7
+};
+
+typedef void *msda_stream_t; /* hipStream_t; NULL = the default stream */
+
+int msda_abi_version(void);
+
+/* Text of the last error on the calling thread ("" if none). */
+const char *msda_last_error(void);
+
+/* Tuning / test hooks.  Keys:
+ *   "fwd_variant"  0 = auto, 1 = direct gather kernel, 2 = LDS-window kernel (when applicable)
+ *   "bwd_variant"  0 = auto, 1 = global-atomic kernel, 2 = LDS-accumulation kernel
+ * Unknown key -> MSDA_ERR_BAD_OPTION. */
+int msda_set_option(const char *key, int value);
+int msda_get_option(const char *key, int *value);
+
+/* ---- launch profiler (measurement aid; off by default) ------------------------------------
+ * When enabled, every forward/backward call brackets its MAIN kernel (not the zero-fill) with
+ * a pair of pre-created HIP events recorded on the stream the kernel is launched on.
+ * msda_profile_collect() synchronises those events and returns one record per call, oldest
+ * first, then clears the log.  No allocation happens on the launch path. */
+typedef struct {
+    int kind;        /* 0 = forward, 1 = backward                                  */
+    int variant;     /* 1 = direct kernel, 2 = tiled kernel                        */
+    int dtype_bytes; /* 4 or 8                                                     */
+    int N, S, M, D, L, Lq, P;
+    float kernel_ms; /* elapsed time of the main kernel                            */
+} msda_profile_record;
+
+int msda_profile_enable(int capacity);  /* capacity = max calls to log; 0 disables and frees   */
+int msda_profile_collect(msda_profile_record *records, int max_records, int *n_records);
+
+/* ---- forward:  replaces ms_deform_attn_forward (src/ms_deform_attn.h:20-39) ---------------- */
+int msda_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                     const float *sampling_loc, const float *attn_weight,
+                     int N, int S, int M, int D, int L, int Lq, int P, int im2col_step,
+                     float *out,
+                     const int64_t *shapes_host, const int64_t *level_start_host,
+                     msda_stream_t stream);
+
+int msda_forward_f64(const double *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                     const double *sampling_loc, const double *attn_weight,
+                     int N, int S, int M, int D, int L, int Lq, int P, int im2col_step,
+                     double *out,
+                     const int64_t *shapes_host, const int64_t *level_start_host,
+                     msda_stream_t stream);
+
+/* ---- backward: replaces ms_deform_attn_backward (src/ms_deform_attn.h:41-61) --------------- */
+int msda_backward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                      const float *sampling_loc, const float *attn_weight, const float *grad_out,
+                      int N, int S, int M, int D, int L, int Lq, int P, int im2col_step,
+                      float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
+                      const int64_t *shapes_host, const int64_t *level_start_host,
+                      msda_stream_t stream);
+
+int msda_backward_f64(const double *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                      const double *sampling_loc, const double *attn_weight, const double *grad_out,
+                      int N, int S, int M, int D, int L, int Lq, int P, int im2col_step,
+                      double *grad_value, double *grad_sampling_loc, double *grad_attn_weight,
+                      const int64_t *shapes_host, const int64_t *level_start_host,
+                      msda_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RICHSEM_MSDA_H */

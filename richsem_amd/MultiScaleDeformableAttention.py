@@ -1,0 +1,128 @@
+"""Drop-in for the reference's compiled extension module ``MultiScaleDeformableAttention``.
+
+The reference builds a pybind11 module of that name from models/richsem/ops/src (setup.py:55)
+with exactly two functions (src/vision.cpp:13-16), imported at
+models/richsem/ops/functions/ms_deform_attn_func.py:18.  This module exposes the same two
+functions with the same argument order, shapes, dtypes and error behaviour, and forwards to
+the C ABI of librichsem_msda.so (include/richsem_msda.h) -- hand-written gfx950 HIP kernels.
+
+    ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+        -> output (N, Lq, M*D)                                   (src/ms_deform_attn.h:20-39)
+    ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                            grad_output, im2col_step)
+        -> [grad_value, grad_sampling_loc, grad_attn_weight]     (src/ms_deform_attn.h:41-61)
+
+Like the reference there is no CPU implementation: CPU tensors raise
+``RuntimeError("Not implemented on the CPU")`` (src/ms_deform_attn.h:38,60).
+"""
+import weakref
+
+import numpy as np
+import torch
+
+from . import _lib
+
+__all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward"]
+
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+
+# Host mirrors of (spatial_shapes, level_start_index).  The launch geometry needs the level sizes on
+# the host; reading them back costs a stream synchronisation, so it is done once per tensor OBJECT
+# (the transformer passes the same two tensors to all 12 attention calls of a step, and autograd
+# hands the same objects back to backward).  Keyed by id() and validated by a weak reference plus
+# the version counter, so a recycled id or an in-place edit can never return a stale mirror.
+_mirrors = {}
+_MIRROR_CAP = 64
+
+
+def _host_mirror(shapes, lsi):
+    key = (id(shapes), id(lsi))
+    hit = _mirrors.get(key)
+    if hit is not None:
+        ref_s, ref_l, ver_s, ver_l, arrays = hit
+        if ref_s() is shapes and ref_l() is lsi and ver_s == shapes._version and ver_l == lsi._version:
+            return arrays
+    arrays = (np.ascontiguousarray(shapes.detach().cpu().numpy(), dtype=np.int64),
+              np.ascontiguousarray(lsi.detach().cpu().numpy(), dtype=np.int64))
+    if len(_mirrors) >= _MIRROR_CAP:
+        _mirrors.clear()
+    _mirrors[key] = (weakref.ref(shapes), weakref.ref(lsi), shapes._version, lsi._version, arrays)
+    return arrays
+
+
+def _check_inputs(named, fn):
+    """The reference's AT_ASSERTM preconditions (ms_deform_attn_cuda.cu:28-38, 93-105)."""
+    value = named[0][1]
+    if not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
+    for name, t in named:
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor")
+        if t.device != value.device:
+            raise RuntimeError(f"{name} must be on the same device as value")
+    if value.dtype not in _SUFFIX:
+        raise RuntimeError(f'"{fn}" not implemented for \'{str(value.dtype).replace("torch.", "")}\'')
+    for name, t in named:
+        if name in ("spatial_shapes", "level_start_index"):
+            if t.dtype != torch.int64:
+                raise RuntimeError(f"{name} must be an int64 tensor")
+        elif t.dtype != value.dtype:
+            raise RuntimeError(f"{name} must have the dtype of value ({value.dtype}), got {t.dtype}")
+
+
+def _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5 or spatial_shapes.dim() != 2:
+        raise RuntimeError("expected value (N,S,M,D), spatial_shapes (L,2), sampling_loc (N,Lq,M,L,P,2), "
+                           "attn_weight (N,Lq,M,L,P)")
+    N, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Lq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+    if (tuple(sampling_loc.shape) != (N, Lq, M, L, P, 2) or tuple(attn_weight.shape) != (N, Lq, M, L, P)
+            or tuple(spatial_shapes.shape) != (L, 2) or tuple(level_start_index.shape) != (L,)):
+        raise RuntimeError(
+            f"inconsistent shapes: value {tuple(value.shape)}, spatial_shapes {tuple(spatial_shapes.shape)}, "
+            f"level_start_index {tuple(level_start_index.shape)}, sampling_loc {tuple(sampling_loc.shape)}, "
+            f"attn_weight {tuple(attn_weight.shape)}")
+    return N, S, M, D, L, Lq, P
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)], "ms_deform_attn_forward_cuda")
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    lib = _lib.load()
+    sh, ls = _host_mirror(spatial_shapes, level_start_index)
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = getattr(lib, "msda_forward_" + _SUFFIX[value.dtype])(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+            attn_weight.data_ptr(), N, S, M, D, L, Lq, P, int(im2col_step), out.data_ptr(),
+            sh.ctypes.data, ls.ctypes.data, stream)
+    _lib.check(rc)
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            im2col_step):
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)],
+                  "ms_deform_attn_backward_cuda")
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    if grad_output.numel() != N * Lq * M * D:
+        raise RuntimeError(f"grad_output has {grad_output.numel()} elements, expected {N * Lq * M * D}")
+    lib = _lib.load()
+    sh, ls = _host_mirror(spatial_shapes, level_start_index)
+    grad_value = torch.empty_like(value)            # zero-filled by the library, on the same stream
+    grad_loc = torch.empty_like(sampling_loc)       # written exactly once per element by the kernel
+    grad_aw = torch.empty_like(attn_weight)
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = getattr(lib, "msda_backward_" + _SUFFIX[value.dtype])(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+            attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L, Lq, P, int(im2col_step),
+            grad_value.data_ptr(), grad_loc.data_ptr(), grad_aw.data_ptr(), sh.ctypes.data, ls.ctypes.data, stream)
+    _lib.check(rc)
+    return [grad_value, grad_loc, grad_aw]

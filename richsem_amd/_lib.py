@@ -1,0 +1,112 @@
+"""ctypes binding of librichsem_msda.so (C ABI: include/richsem_msda.h).
+
+There is no CPU fallback: if the library cannot be loaded the import of anything that needs
+it raises, and CPU tensors are rejected exactly like the reference does
+(reference models/richsem/ops/src/ms_deform_attn.h:38 "Not implemented on the CPU").
+"""
+import ctypes
+import os
+
+from . import _build
+
+_lib = None
+
+ERR_NAMES = {
+    -1: "MSDA_ERR_NULL_POINTER", -2: "MSDA_ERR_BAD_DIMS", -3: "MSDA_ERR_IM2COL_STEP",
+    -4: "MSDA_ERR_TOO_LARGE", -5: "MSDA_ERR_MISALIGNED", -6: "MSDA_ERR_NO_DEVICE", -7: "MSDA_ERR_BAD_OPTION",
+}
+
+ABI_VERSION = 1
+
+# every symbol include/richsem_msda.h declares
+SYMBOLS = [
+    "msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option",
+    "msda_profile_enable", "msda_profile_collect",
+    "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64",
+]
+
+
+class ProfileRecord(ctypes.Structure):
+    """msda_profile_record (include/richsem_msda.h)"""
+    _fields_ = [("kind", ctypes.c_int), ("variant", ctypes.c_int), ("dtype_bytes", ctypes.c_int),
+                ("N", ctypes.c_int), ("S", ctypes.c_int), ("M", ctypes.c_int), ("D", ctypes.c_int),
+                ("L", ctypes.c_int), ("Lq", ctypes.c_int), ("P", ctypes.c_int), ("kernel_ms", ctypes.c_float)]
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -m richsem_amd._build` (hipcc --offload-arch=gfx950). "
+            "richsem_amd has no CPU or PyTorch fallback for MSDeformAttn.")
+    import torch  # noqa: F401  -- make torch's libamdhip64 (same SONAME) the one HIP runtime of this process
+    L = ctypes.CDLL(path)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    L.msda_abi_version.restype = ci
+    L.msda_last_error.restype = ctypes.c_char_p
+    L.msda_set_option.argtypes = [ctypes.c_char_p, ci]
+    L.msda_set_option.restype = ci
+    L.msda_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ci)]
+    L.msda_get_option.restype = ci
+    L.msda_profile_enable.argtypes = [ci]
+    L.msda_profile_enable.restype = ci
+    L.msda_profile_collect.argtypes = [ctypes.POINTER(ProfileRecord), ci, ctypes.POINTER(ci)]
+    L.msda_profile_collect.restype = ci
+    for sfx in ("f32", "f64"):
+        f = getattr(L, "msda_forward_" + sfx)
+        f.argtypes = [vp] * 5 + [ci] * 8 + [vp, vp, vp, vp]
+        f.restype = ci
+        g = getattr(L, "msda_backward_" + sfx)
+        g.argtypes = [vp] * 6 + [ci] * 8 + [vp, vp, vp, vp, vp, vp]
+        g.restype = ci
+    if L.msda_abi_version() != ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {L.msda_abi_version()} != expected {ABI_VERSION}; rebuild")
+    _lib = L
+    return L
+
+
+def last_error():
+    return load().msda_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Turn a C-ABI return code into a RuntimeError (the reference raises RuntimeError via AT_ASSERTM)."""
+    if rc == 0:
+        return
+    name = ERR_NAMES.get(rc, f"hipError {rc}" if rc > 0 else f"error {rc}")
+    raise RuntimeError(f"richsem_msda: {last_error()} [{name}]")
+
+
+def set_option(key, value):
+    check(load().msda_set_option(key.encode(), int(value)))
+
+
+def get_option(key):
+    v = ctypes.c_int(0)
+    check(load().msda_get_option(key.encode(), ctypes.byref(v)))
+    return v.value
+
+
+def profile_enable(capacity):
+    """Log up to `capacity` calls (0 = off): HIP events around each call's main kernel, on its stream."""
+    check(load().msda_profile_enable(int(capacity)))
+
+
+def profile_collect(max_records=65536):
+    """Synchronise the logged events; returns a list of dicts (kind 'fwd'/'bwd', variant, dims, kernel_ms)."""
+    buf = (ProfileRecord * max_records)()
+    n = ctypes.c_int(0)
+    check(load().msda_profile_collect(buf, max_records, ctypes.byref(n)))
+    out = []
+    for r in buf[:n.value]:
+        out.append(dict(kind="bwd" if r.kind else "fwd", variant=r.variant, dtype_bytes=r.dtype_bytes, N=r.N, S=r.S,
+                        M=r.M, D=r.D, L=r.L, Lq=r.Lq, P=r.P, kernel_ms=float(r.kernel_ms)))
+    return out

@@ -1,0 +1,358 @@
+// msda_api.hip -- the C ABI of librichsem_msda.so (declared in include/richsem_msda.h).
+//
+// Host side of the drop-in for the reference's ms_deform_attn_cuda_forward / _backward
+// (reference models/richsem/ops/src/cuda/ms_deform_attn_cuda.cu:20-80, 83-153): argument checks,
+// launch geometry, zero-fill of the accumulated output, kernel selection.  No torch types.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/richsem_msda.h"
+#include "msda_direct.h"
+#include "msda_tiled.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s (hipError %d)", what, hipGetErrorString(e), (int)e);
+    return (int)e;
+}
+
+std::atomic<int> g_fwd_variant{0}, g_bwd_variant{0};
+
+// ---- launch profiler: pre-created event pairs, one per logged call -----------------------------
+struct ProfileSlot {
+    hipEvent_t start, stop;
+    msda_profile_record rec;
+};
+std::mutex g_prof_mutex;
+std::vector<ProfileSlot> g_prof_slots;
+int g_prof_used = 0;
+std::atomic<bool> g_prof_on{false};
+
+// RAII bracket around the main kernel launch of one call
+struct ProfileScope {
+    ProfileSlot *slot = nullptr;
+    hipStream_t stream;
+    ProfileScope(int kind, int variant, int dtype_bytes, int N, int S, int M, int D, int L, int Lq, int P,
+                 hipStream_t st)
+        : stream(st)
+    {
+        if (!g_prof_on.load(std::memory_order_relaxed)) return;
+        std::lock_guard<std::mutex> lock(g_prof_mutex);
+        if (g_prof_used >= (int)g_prof_slots.size()) return;
+        slot = &g_prof_slots[g_prof_used++];
+        slot->rec = msda_profile_record{kind, variant, dtype_bytes, N, S, M, D, L, Lq, P, 0.f};
+        (void)hipEventRecord(slot->start, stream);
+    }
+    ~ProfileScope()
+    {
+        if (slot) (void)hipEventRecord(slot->stop, stream);
+    }
+};
+
+struct Problem {
+    int N, S, M, D, L, Lq, P;
+    std::vector<int64_t> shapes, lsi;  // host mirrors
+};
+
+bool is_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// Argument checks shared by forward and backward.  Mirrors the reference's preconditions
+// (ms_deform_attn_cuda.cu:28-52) and adds the bounds the kernels rely on.
+int check_problem(Problem &pb, const int64_t *shapes_dev, const int64_t *lsi_dev, const int64_t *shapes_host,
+                  const int64_t *lsi_host, int im2col_step, hipStream_t stream)
+{
+    if (pb.N <= 0 || pb.S <= 0 || pb.M <= 0 || pb.D <= 0 || pb.L <= 0 || pb.Lq <= 0 || pb.P <= 0)
+        return fail(MSDA_ERR_BAD_DIMS, "non-positive dimension (N=%d S=%d M=%d D=%d L=%d Lq=%d P=%d)", pb.N, pb.S,
+                    pb.M, pb.D, pb.L, pb.Lq, pb.P);
+    if (im2col_step <= 0) return fail(MSDA_ERR_IM2COL_STEP, "im2col_step(%d) must be positive", im2col_step);
+    const int step = pb.N < im2col_step ? pb.N : im2col_step;
+    if (pb.N % step != 0) return fail(MSDA_ERR_IM2COL_STEP, "batch(%d) must divide im2col_step(%d)", pb.N, step);
+
+    const int64_t lim = (int64_t)1 << 31;
+    const int64_t n_value = (int64_t)pb.N * pb.S * pb.M * pb.D;
+    const int64_t n_out = (int64_t)pb.N * pb.Lq * pb.M * pb.D;
+    const int64_t n_loc = (int64_t)pb.N * pb.Lq * pb.M * pb.L * pb.P * 2;
+    if (n_value >= lim || n_out >= lim || n_loc >= lim)
+        return fail(MSDA_ERR_TOO_LARGE, "tensor with >= 2^31 elements (value %lld, out %lld, loc %lld)",
+                    (long long)n_value, (long long)n_out, (long long)n_loc);
+
+    pb.shapes.resize(2 * (size_t)pb.L);
+    pb.lsi.resize((size_t)pb.L);
+    if (shapes_host && lsi_host) {
+        memcpy(pb.shapes.data(), shapes_host, sizeof(int64_t) * 2 * pb.L);
+        memcpy(pb.lsi.data(), lsi_host, sizeof(int64_t) * pb.L);
+    } else {  // slow path: synchronises the stream
+        hipError_t e = hipMemcpyAsync(pb.shapes.data(), shapes_dev, sizeof(int64_t) * 2 * pb.L, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(pb.lsi.data(), lsi_dev, sizeof(int64_t) * pb.L, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return hip_fail(e, "copying spatial_shapes / level_start_index to the host");
+    }
+    int64_t total = 0;
+    for (int l = 0; l < pb.L; ++l) {
+        const int64_t H = pb.shapes[2 * l], W = pb.shapes[2 * l + 1], st = pb.lsi[l];
+        if (H <= 0 || W <= 0 || H >= lim || W >= lim || H * W > pb.S)
+            return fail(MSDA_ERR_BAD_DIMS, "level %d: bad spatial shape (%lld, %lld)", l, (long long)H, (long long)W);
+        if (st < 0 || st + H * W > pb.S)
+            return fail(MSDA_ERR_BAD_DIMS, "level %d: level_start_index %lld + %lld*%lld exceeds S=%d", l, (long long)st,
+                        (long long)H, (long long)W, pb.S);
+        total += H * W;
+    }
+    if (total != pb.S)
+        return fail(MSDA_ERR_BAD_DIMS, "sum of H*W over levels (%lld) != S (%d)", (long long)total, pb.S);
+    return MSDA_OK;
+}
+
+int floor_log2(int x)
+{
+    int r = 0;
+    while ((1 << (r + 1)) <= x) ++r;
+    return r;
+}
+
+// Channels per lane for the direct kernels: the widest access (<= 16 B) that D and every data
+// pointer allow.
+template <typename T>
+int pick_channels_per_lane(int D, std::initializer_list<const void *> ptrs)
+{
+    int c = (int)(16 / sizeof(T));
+    for (; c > 1; c >>= 1) {
+        bool ok = D % c == 0;
+        for (const void *p : ptrs) ok = ok && is_aligned(p, sizeof(T) * c);
+        if (ok) break;
+    }
+    return c;
+}
+
+msda::DirectGeom direct_geom(const Problem &pb, int C)
+{
+    msda::DirectGeom g{};
+    g.N = pb.N; g.S = pb.S; g.M = pb.M; g.D = pb.D; g.L = pb.L; g.Lq = pb.Lq; g.P = pb.P;
+    const int lanes = (pb.D + C - 1) / C;
+    int G = 1;
+    while (G < lanes && G < msda::kWave) G <<= 1;
+    g.G = G;
+    g.logG = floor_log2(G);
+    g.nchunks = (lanes + G - 1) / G;
+    const int per_iter = msda::kDirectWaves * (msda::kWave / G);
+    g.qtile = per_iter * 2 > 64 ? per_iter * 2 : 64;   // >= 2 passes per block amortise the level table
+    g.ntiles = (pb.Lq + g.qtile - 1) / g.qtile;
+    return g;
+}
+
+int direct_grid(const msda::DirectGeom &g)
+{
+    const int pairs = g.N * g.M;
+    return msda::kXcds * ((pairs + msda::kXcds - 1) / msda::kXcds) * g.ntiles;
+}
+
+template <typename T>
+int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc, const T *aw, int N, int S,
+                 int M, int D, int L, int Lq, int P, int im2col_step, T *out, const int64_t *shapes_host,
+                 const int64_t *lsi_host, msda_stream_t stream_)
+{
+    g_err[0] = 0;
+    if (!value || !shapes || !lsi || !loc || !aw || !out) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Problem pb{N, S, M, D, L, Lq, P, {}, {}};
+    if (int rc = check_problem(pb, shapes, lsi, shapes_host, lsi_host, im2col_step, stream)) return rc;
+    if (!is_aligned(value, sizeof(T)) || !is_aligned(out, sizeof(T)) || !is_aligned(aw, sizeof(T)) ||
+        !is_aligned(loc, 2 * sizeof(T)) || !is_aligned(shapes, 8) || !is_aligned(lsi, 8))
+        return fail(MSDA_ERR_MISALIGNED, "misaligned pointer (sampling_loc needs 2*sizeof(T))");
+
+    const int variant = g_fwd_variant.load();
+    if (variant != 1 && msda::tiled_fwd_applicable<T>(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(),
+                                                     pb.lsi.data(), value, out)) {
+        hipError_t e;
+        {
+            ProfileScope prof(0, 2, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
+            e = msda::launch_fwd_tiled<T>(value, shapes, lsi, loc, aw, out, pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P,
+                                          pb.shapes.data(), pb.lsi.data(), stream);
+        }
+        if (e != hipSuccess) return hip_fail(e, "launch of the tiled forward kernel");
+        return MSDA_OK;
+    }
+
+    const int C = pick_channels_per_lane<T>(D, {value, out});
+    const msda::DirectGeom g = direct_geom(pb, C);
+    const size_t lds = msda::direct_lds_bytes<T>(g);
+    const dim3 grid(direct_grid(g)), block(msda::kDirectThreads);
+    ProfileScope prof(0, 1, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
+    switch (C) {
+        case 4: hipLaunchKernelGGL((msda::fwd_direct_kernel<T, (sizeof(T) == 4 ? 4 : 2)>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g); break;
+        case 2: hipLaunchKernelGGL((msda::fwd_direct_kernel<T, 2>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g); break;
+        default: hipLaunchKernelGGL((msda::fwd_direct_kernel<T, 1>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch of the direct forward kernel");
+    return MSDA_OK;
+}
+
+template <typename T>
+int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc, const T *aw,
+                  const T *grad_out, int N, int S, int M, int D, int L, int Lq, int P, int im2col_step, T *grad_value,
+                  T *grad_loc, T *grad_aw, const int64_t *shapes_host, const int64_t *lsi_host, msda_stream_t stream_)
+{
+    g_err[0] = 0;
+    if (!value || !shapes || !lsi || !loc || !aw || !grad_out || !grad_value || !grad_loc || !grad_aw)
+        return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Problem pb{N, S, M, D, L, Lq, P, {}, {}};
+    if (int rc = check_problem(pb, shapes, lsi, shapes_host, lsi_host, im2col_step, stream)) return rc;
+    if (!is_aligned(value, sizeof(T)) || !is_aligned(grad_out, sizeof(T)) || !is_aligned(aw, sizeof(T)) ||
+        !is_aligned(grad_value, sizeof(T)) || !is_aligned(grad_aw, sizeof(T)) || !is_aligned(loc, 2 * sizeof(T)) ||
+        !is_aligned(grad_loc, 2 * sizeof(T)) || !is_aligned(shapes, 8) || !is_aligned(lsi, 8))
+        return fail(MSDA_ERR_MISALIGNED, "misaligned pointer (sampling_loc / grad_sampling_loc need 2*sizeof(T))");
+
+    // grad_value is accumulated into (the reference gets it from at::zeros_like, ms_deform_attn_cuda.cu:121)
+    hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(T) * (size_t)N * S * M * D, stream);
+    if (e != hipSuccess) return hip_fail(e, "zero-fill of grad_value");
+
+    const int variant = g_bwd_variant.load();
+    if (variant != 1 && msda::tiled_bwd_applicable<T>(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(),
+                                                     pb.lsi.data(), value, grad_out, grad_value)) {
+        {
+            ProfileScope prof(1, 2, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
+            e = msda::launch_bwd_tiled<T>(value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw, pb.N,
+                                          pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(), pb.lsi.data(), stream);
+        }
+        if (e != hipSuccess) return hip_fail(e, "launch of the tiled backward kernel");
+        return MSDA_OK;
+    }
+
+    const int C = pick_channels_per_lane<T>(D, {value, grad_out});
+    const msda::DirectGeom g = direct_geom(pb, C);
+    const size_t lds = msda::direct_lds_bytes<T>(g);
+    const dim3 grid(direct_grid(g)), block(msda::kDirectThreads);
+    ProfileScope prof(1, 1, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
+    switch (C) {
+        case 4: hipLaunchKernelGGL((msda::bwd_direct_kernel<T, (sizeof(T) == 4 ? 4 : 2)>), grid, block, lds, stream, value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw, g); break;
+        case 2: hipLaunchKernelGGL((msda::bwd_direct_kernel<T, 2>), grid, block, lds, stream, value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw, g); break;
+        default: hipLaunchKernelGGL((msda::bwd_direct_kernel<T, 1>), grid, block, lds, stream, value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw, g); break;
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch of the direct backward kernel");
+    return MSDA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msda_abi_version(void) { return RICHSEM_MSDA_ABI_VERSION; }
+
+const char *msda_last_error(void) { return g_err; }
+
+int msda_set_option(const char *key, int value)
+{
+    if (key && !strcmp(key, "fwd_variant") && value >= 0 && value <= 2) { g_fwd_variant = value; return MSDA_OK; }
+    if (key && !strcmp(key, "bwd_variant") && value >= 0 && value <= 2) { g_bwd_variant = value; return MSDA_OK; }
+    return fail(MSDA_ERR_BAD_OPTION, "unknown option or value: %s=%d", key ? key : "(null)", value);
+}
+
+int msda_get_option(const char *key, int *value)
+{
+    if (!value) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    if (key && !strcmp(key, "fwd_variant")) { *value = g_fwd_variant; return MSDA_OK; }
+    if (key && !strcmp(key, "bwd_variant")) { *value = g_bwd_variant; return MSDA_OK; }
+    return fail(MSDA_ERR_BAD_OPTION, "unknown option: %s", key ? key : "(null)");
+}
+
+int msda_profile_enable(int capacity)
+{
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof_on = false;
+    for (auto &s : g_prof_slots) {
+        (void)hipEventDestroy(s.start);
+        (void)hipEventDestroy(s.stop);
+    }
+    g_prof_slots.clear();
+    g_prof_used = 0;
+    if (capacity <= 0) return MSDA_OK;
+    g_prof_slots.resize((size_t)capacity);
+    for (auto &s : g_prof_slots) {
+        hipError_t e = hipEventCreate(&s.start);
+        if (e == hipSuccess) e = hipEventCreate(&s.stop);
+        if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+    }
+    g_prof_on = true;
+    return MSDA_OK;
+}
+
+int msda_profile_collect(msda_profile_record *records, int max_records, int *n_records)
+{
+    if (!records || !n_records) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    int n = 0;
+    for (int i = 0; i < g_prof_used && n < max_records; ++i) {
+        ProfileSlot &s = g_prof_slots[i];
+        hipError_t e = hipEventSynchronize(s.stop);
+        if (e == hipSuccess) e = hipEventElapsedTime(&s.rec.kernel_ms, s.start, s.stop);
+        if (e != hipSuccess) return hip_fail(e, "reading profile events");
+        records[n++] = s.rec;
+    }
+    *n_records = n;
+    g_prof_used = 0;
+    return MSDA_OK;
+}
+
+int msda_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                     const float *sampling_loc, const float *attn_weight, int N, int S, int M, int D, int L, int Lq,
+                     int P, int im2col_step, float *out, const int64_t *shapes_host, const int64_t *level_start_host,
+                     msda_stream_t stream)
+{
+    return forward_impl<float>(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D, L, Lq, P,
+                               im2col_step, out, shapes_host, level_start_host, stream);
+}
+
+int msda_forward_f64(const double *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                     const double *sampling_loc, const double *attn_weight, int N, int S, int M, int D, int L, int Lq,
+                     int P, int im2col_step, double *out, const int64_t *shapes_host, const int64_t *level_start_host,
+                     msda_stream_t stream)
+{
+    return forward_impl<double>(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D, L, Lq, P,
+                                im2col_step, out, shapes_host, level_start_host, stream);
+}
+
+int msda_backward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                      const float *sampling_loc, const float *attn_weight, const float *grad_out, int N, int S, int M,
+                      int D, int L, int Lq, int P, int im2col_step, float *grad_value, float *grad_sampling_loc,
+                      float *grad_attn_weight, const int64_t *shapes_host, const int64_t *level_start_host,
+                      msda_stream_t stream)
+{
+    return backward_impl<float>(value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_out, N, S, M, D, L,
+                                Lq, P, im2col_step, grad_value, grad_sampling_loc, grad_attn_weight, shapes_host,
+                                level_start_host, stream);
+}
+
+int msda_backward_f64(const double *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                      const double *sampling_loc, const double *attn_weight, const double *grad_out, int N, int S,
+                      int M, int D, int L, int Lq, int P, int im2col_step, double *grad_value,
+                      double *grad_sampling_loc, double *grad_attn_weight, const int64_t *shapes_host,
+                      const int64_t *level_start_host, msda_stream_t stream)
+{
+    return backward_impl<double>(value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_out, N, S, M, D, L,
+                                 Lq, P, im2col_step, grad_value, grad_sampling_loc, grad_attn_weight, shapes_host,
+                                 level_start_host, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,249 @@
+// msda_direct.h -- "direct" MSDeformAttn kernels for gfx950: every shape, every D.
+//
+// Work decomposition (both kernels)
+//   item   = one (image b, query q, head m): D output channels, L*P sampling points.
+//   group  = G lanes (power of two, 1..64) holding one item; lane j owns channels
+//            [(chunk*G + j)*C, +C) with C = channels per lane (one 16-B / 8-B / 4-B access).
+//            D=32 f32: C=4, G=8 -> a wave works on 8 items at once and every value access is a
+//            1 KiB wave-instruction made of eight 128-B rows (the widest gather shape there is).
+//   block  = 4 waves; all items of a block belong to ONE (b,m) pair and to one tile of
+//            `qtile` consecutive queries; pairs are pinned to XCDs (decode_block).
+//   points = resolved ONCE per item (lane j resolves points j, j+G, ...), parked in LDS as
+//            PointRec and re-read by the item's lanes as LDS broadcasts -- instead of every
+//            channel-thread re-deriving all L*P points from global memory, which is what the
+//            reference's one-thread-per-output-scalar layout does (ms_deform_im2col_cuda.cuh:255-297).
+//
+// Forward  (spec: reference ms_deform_im2col_cuda.cuh:237-299): out = sum_points attn * bilinear.
+// Backward (spec: reference ms_deform_im2col_cuda.cuh:87-159, 301-403): grad_value by global
+//          float atomics shaped as G*C*sizeof(T)-byte row segments; grad_loc / grad_attn reduced
+//          across the group's lanes with wave shuffles (no LDS tree, no barriers, no serial
+//          thread-0 loop) and written exactly once -> no zero-fill needed for them.
+#pragma once
+
+#include "msda_common.h"
+
+namespace msda {
+
+struct DirectGeom {
+    int N, S, M, D, L, Lq, P;
+    int G, logG, nchunks;  // lanes per item, log2, channel chunks per lane
+    int qtile, ntiles;     // queries per block, tiles per (b,m) pair
+};
+
+constexpr int kDirectThreads = 256;
+constexpr int kDirectWaves = kDirectThreads / kWave;
+// records of one item; +1 record of padding so that the 8 items a wave reads together (LDS
+// broadcast per item) start on different banks
+constexpr int kSlotStride = kPointBatch + 1;
+
+// LDS: [L x LevelGeom][waves x items-per-wave x kPointBatch x PointRec<T>]
+template <typename T>
+inline size_t direct_lds_bytes(const DirectGeom &g)
+{
+    const int ipw = kWave / g.G;
+    return sizeof(LevelGeom) * g.L + sizeof(PointRec<T>) * kDirectWaves * ipw * kSlotStride;
+}
+
+__device__ __forceinline__ void load_levels(LevelGeom *lv, const int64_t *shapes, const int64_t *lsi, int L)
+{
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        lv[l].H = (int)shapes[2 * l];
+        lv[l].W = (int)shapes[2 * l + 1];
+        lv[l].start = (int)lsi[l];
+        lv[l].pad = 0;
+    }
+    __syncthreads();
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(kDirectThreads) void fwd_direct_kernel(
+    const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
+    const T *__restrict__ loc, const T *__restrict__ aw, T *__restrict__ out, const DirectGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LevelGeom *lv = reinterpret_cast<LevelGeom *>(smem);
+    PointRec<T> *recs = reinterpret_cast<PointRec<T> *>(smem + sizeof(LevelGeom) * g.L);
+
+    int pair, tile;
+    if (!decode_block(blockIdx.x, g.N * g.M, g.ntiles, pair, tile)) return;  // block-uniform
+    load_levels(lv, shapes, lsi, g.L);
+
+    const int b = pair / g.M, m = pair - b * g.M;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int ipw = kWave >> g.logG;              // items per wave
+    const int j = lane & (g.G - 1);               // lane within the group
+    const int slot = wave * ipw + (lane >> g.logG);
+    const int LP = g.L * g.P;
+    const int row_elems = g.M * g.D;
+    PointRec<T> *my = recs + slot * kSlotStride;
+
+    const int q_end = min((tile + 1) * g.qtile, g.Lq);
+    for (int q0 = tile * g.qtile; q0 < q_end; q0 += kDirectWaves * ipw) {   // block-uniform trip count
+        const int q = q0 + slot;
+        const bool live = q < q_end;
+        const int item = (b * g.Lq + q) * g.M + m;
+        for (int ch = 0; ch < g.nchunks; ++ch) {
+            const int c0 = (ch * g.G + j) * C;
+            const bool has_c = live && c0 < g.D;
+            T acc[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = (T)0;
+            for (int p0 = 0; p0 < LP; p0 += kPointBatch) {
+                const int np = min(kPointBatch, LP - p0);
+                // (1) resolve this batch of points, one point per lane, into the item's LDS slot
+                if (live) {
+                    for (int pt = j; pt < np; pt += g.G) {
+                        const int gp = p0 + pt, l = gp / g.P;
+                        const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + ((int64_t)item * LP + gp) * 2);
+                        const T a = aw[(int64_t)item * LP + gp];
+                        const LevelGeom G_ = lv[l];
+                        PointRec<T> r;
+                        T lh, lw;
+                        resolve_point<T>(xy.v[0], xy.v[1], G_.H, G_.W, (b * g.S + G_.start) * row_elems + m * g.D,
+                                         row_elems, r.o, lh, lw);
+                        const T hh = (T)1 - lh, hw = (T)1 - lw;
+                        r.f[0] = hh * hw * a;
+                        r.f[1] = hh * lw * a;
+                        r.f[2] = lh * hw * a;
+                        r.f[3] = lh * lw * a;
+                        my[pt] = r;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is in order; stop compiler motion
+                // (2) gather: every lane walks the item's points, C channels each
+                if (has_c) {
+#pragma unroll 4
+                    for (int pt = 0; pt < np; ++pt) {
+                        const PointRec<T> r = my[pt];
+                        Pack<T, C> v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (r.o[k] >= 0) {
+                                v[k] = *reinterpret_cast<const Pack<T, C> *>(value + r.o[k] + c0);
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < C; ++c) v[k].v[c] = (T)0;
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+                            acc[c] += r.f[0] * v[0].v[c] + r.f[1] * v[1].v[c] + r.f[2] * v[2].v[c] + r.f[3] * v[3].v[c];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (has_c) {
+                Pack<T, C> o;
+#pragma unroll
+                for (int c = 0; c < C; ++c) o.v[c] = acc[c];
+                *reinterpret_cast<Pack<T, C> *>(out + (int64_t)item * g.D + c0) = o;
+            }
+        }
+    }
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(kDirectThreads) void bwd_direct_kernel(
+    const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
+    const T *__restrict__ loc, const T *__restrict__ aw, const T *__restrict__ grad_out,
+    T *__restrict__ grad_value, T *__restrict__ grad_loc, T *__restrict__ grad_aw, const DirectGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LevelGeom *lv = reinterpret_cast<LevelGeom *>(smem);
+    PointRec<T> *recs = reinterpret_cast<PointRec<T> *>(smem + sizeof(LevelGeom) * g.L);
+
+    int pair, tile;
+    if (!decode_block(blockIdx.x, g.N * g.M, g.ntiles, pair, tile)) return;
+    load_levels(lv, shapes, lsi, g.L);
+
+    const int b = pair / g.M, m = pair - b * g.M;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int ipw = kWave >> g.logG;
+    const int j = lane & (g.G - 1);
+    const int slot = wave * ipw + (lane >> g.logG);
+    const int LP = g.L * g.P;
+    const int row_elems = g.M * g.D;
+    PointRec<T> *my = recs + slot * kSlotStride;
+
+    const int q_end = min((tile + 1) * g.qtile, g.Lq);
+    for (int q0 = tile * g.qtile; q0 < q_end; q0 += kDirectWaves * ipw) {
+        const int q = q0 + slot;
+        const bool live = q < q_end;
+        const int item = (b * g.Lq + q) * g.M + m;
+        // grad_out of this lane's first channel chunk stays in registers (the only chunk when D <= 64*C)
+        Pack<T, C> g0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) g0.v[c] = (T)0;
+        if (live && j * C < g.D) g0 = *reinterpret_cast<const Pack<T, C> *>(grad_out + (int64_t)item * g.D + j * C);
+
+        for (int p0 = 0; p0 < LP; p0 += kPointBatch) {
+            const int np = min(kPointBatch, LP - p0);
+            if (live) {
+                for (int pt = j; pt < np; pt += g.G) {
+                    const int gp = p0 + pt, l = gp / g.P;
+                    const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + ((int64_t)item * LP + gp) * 2);
+                    const LevelGeom G_ = lv[l];
+                    PointRec<T> r;
+                    resolve_point<T>(xy.v[0], xy.v[1], G_.H, G_.W, (b * g.S + G_.start) * row_elems + m * g.D,
+                                     row_elems, r.o, r.f[0], r.f[1]);
+                    r.f[2] = aw[(int64_t)item * LP + gp];
+                    r.f[3] = (T)0;
+                    my[pt] = r;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int pt = 0; pt < np; ++pt) {           // wave-uniform trip count (shuffles inside)
+                const PointRec<T> r = my[pt];
+                const T lh = r.f[0], lw = r.f[1], a = r.f[2];
+                const T hh = (T)1 - lh, hw = (T)1 - lw;
+                const T w[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+                T s_a = (T)0, s_w = (T)0, s_h = (T)0;
+                for (int ch = 0; ch < g.nchunks; ++ch) {
+                    const int c0 = (ch * g.G + j) * C;
+                    if (!(live && c0 < g.D)) continue;
+                    Pack<T, C> tg = g0;
+                    if (ch > 0) tg = *reinterpret_cast<const Pack<T, C> *>(grad_out + (int64_t)item * g.D + c0);
+                    Pack<T, C> v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (r.o[k] >= 0) {
+                            v[k] = *reinterpret_cast<const Pack<T, C> *>(value + r.o[k] + c0);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < C; ++c) v[k].v[c] = (T)0;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const T tgv = tg.v[c] * a;
+                        const T v1 = v[0].v[c], v2 = v[1].v[c], v3 = v[2].v[c], v4 = v[3].v[c];
+                        s_a += tg.v[c] * (w[0] * v1 + w[1] * v2 + w[2] * v3 + w[3] * v4);
+                        s_w += (hh * (v2 - v1) + lh * (v4 - v3)) * tgv;
+                        s_h += (hw * (v3 - v1) + lw * (v4 - v2)) * tgv;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (r.o[k] >= 0) atomicAdd(grad_value + r.o[k] + c0 + c, w[k] * tgv);
+                    }
+                }
+                // sum the per-lane partials over the item's G lanes
+                for (int s = 1; s < g.G; s <<= 1) {
+                    s_a += shfl_xor_t(s_a, s);
+                    s_w += shfl_xor_t(s_w, s);
+                    s_h += shfl_xor_t(s_h, s);
+                }
+                if (live && j == 0) {
+                    const int gp = p0 + pt;
+                    const LevelGeom G_ = lv[gp / g.P];
+                    grad_aw[(int64_t)item * LP + gp] = s_a;
+                    Pack<T, 2> gl;
+                    gl.v[0] = (T)G_.W * s_w;
+                    gl.v[1] = (T)G_.H * s_h;
+                    *reinterpret_cast<Pack<T, 2> *>(grad_loc + ((int64_t)item * LP + gp) * 2) = gl;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+}  // namespace msda

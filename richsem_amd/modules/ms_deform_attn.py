@@ -1,0 +1,94 @@
+"""``MSDeformAttn`` -- host-side mirror of the reference module
+(reference models/richsem/ops/modules/ms_deform_attn.py:30-115), built on the gfx950 operator.
+
+Kept identical to the reference so released checkpoints load and callers run unchanged
+(deformable_transformer.py:840,902,925 construct it; :870,:1017 call it):
+  * constructor ``MSDeformAttn(d_model=256, n_levels=4, n_heads=8, n_points=4)``, ``im2col_step = 64``
+  * parameter names ``sampling_offsets``, ``attention_weights``, ``value_proj``, ``output_proj``
+  * initialisation (``_reset_parameters``, reference :62-76): zero offset weights, offset bias = the
+    n_heads compass directions scaled to max-norm 1 times (point index + 1); zero attention
+    weights; Xavier-uniform value/output projections with zero bias
+  * ``forward(query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+    input_padding_mask=None)`` with 2-d (x, y) or 4-d (x, y, w, h) reference points (reference :78-115)
+"""
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..functions import MSDeformAttnFunction
+
+
+def _is_power_of_2(n):
+    if not isinstance(n, int) or n < 0:
+        raise ValueError(f"invalid input for _is_power_of_2: {n} (type: {type(n)})")
+    return n != 0 and (n & (n - 1)) == 0
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError(f"d_model must be divisible by n_heads, but got {d_model} and {n_heads}")
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("MSDeformAttn: a per-head dimension that is a power of 2 (32 in RichSem) selects the "
+                          "fastest gfx950 kernels; other sizes run on the generic kernels.")
+        self.im2col_step = 64
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        H, L, P = self.n_heads, self.n_levels, self.n_points
+        angle = torch.arange(H, dtype=torch.float32) * (2.0 * math.pi / H)
+        direction = torch.stack([angle.cos(), angle.sin()], dim=-1)
+        direction = direction / direction.abs().max(dim=-1, keepdim=True)[0]          # max-norm 1
+        steps = torch.arange(1, P + 1, dtype=torch.float32).view(1, 1, P, 1)
+        bias = direction.view(H, 1, 1, 2).expand(H, L, P, 2) * steps
+        with torch.no_grad():
+            self.sampling_offsets.weight.zero_()
+            self.sampling_offsets.bias = nn.Parameter(bias.reshape(-1).clone())
+            self.attention_weights.weight.zero_()
+            self.attention_weights.bias.zero_()
+            nn.init.xavier_uniform_(self.value_proj.weight)
+            self.value_proj.bias.zero_()
+            nn.init.xavier_uniform_(self.output_proj.weight)
+            self.output_proj.bias.zero_()
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        """query (N, Lq, C); reference_points (N, Lq, L, 2|4) in [0,1] incl. padding; input_flatten (N, S, C);
+        input_spatial_shapes (L, 2) = (H_l, W_l); input_level_start_index (L,); input_padding_mask (N, S) bool,
+        True on padding.  Returns (N, Lq, C)."""
+        N, Lq, _ = query.shape
+        S = input_flatten.shape[1]
+        H, L, P = self.n_heads, self.n_levels, self.n_points
+        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == S
+
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, S, H, self.d_model // H)
+
+        offsets = self.sampling_offsets(query).view(N, Lq, H, L, P, 2)
+        weights = F.softmax(self.attention_weights(query).view(N, Lq, H, L * P), -1).view(N, Lq, H, L, P)
+
+        ref = reference_points[:, :, None, :, None, :]                                   # (N, Lq, 1, L, 1, 2|4)
+        if reference_points.shape[-1] == 2:
+            wh = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)   # (L, 2) = (W, H)
+            locations = ref + offsets / wh[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            locations = ref[..., :2] + offsets / P * ref[..., 2:] * 0.5
+        else:
+            raise ValueError(
+                f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
+
+        out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index, locations, weights,
+                                         self.im2col_step)
+        return self.output_proj(out)

@@ -1,0 +1,136 @@
+"""Synthetic MSDeformAttn workloads at the shapes of BASELINE.json's configs, and the algorithmic
+byte counts the roofline is quoted on.
+
+Shapes (R50 4-scale, 1333x800 padded to 800x1344; reference util/misc.py:410-414, richsem.py:304-308):
+levels 100x168, 50x84, 25x42, 13x21 -> S = 22323; N = 2 images per GPU, M = 8 heads, D = 32, L = P = 4.
+  E   encoder self-attention call   Lq = S = 22323          (deformable_transformer.py:870)
+  Dd  decoder cross-attention call  Lq = 1092 = 900 + 192   (deformable_transformer.py:1017)
+  Em  ImageNet-LVIS mosaic step     1280x1280 -> 160^2, 80^2, 40^2, 20^2, S = Lq = 34000
+One training step runs 6 E and 6 Dd calls forward and backward (6 encoder + 6 decoder layers,
+config/RichSem/baseline_4scale.py:36-37).
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+
+
+def pyramid_shapes(height, width, n_levels=4):
+    """Feature-map sizes of the R50 4-scale pyramid for a padded (height, width) image: strides 8/16/32
+    (ceil), then each extra level is a 3x3 stride-2 pad-1 conv of the previous one (richsem.py:304-308)."""
+    shapes = [(math.ceil(height / s), math.ceil(width / s)) for s in (8, 16, 32)][:n_levels]
+    while len(shapes) < n_levels:
+        h, w = shapes[-1]
+        shapes.append(((h - 1) // 2 + 1, (w - 1) // 2 + 1))
+    return shapes
+
+
+@dataclass
+class Call:
+    name: str
+    N: int
+    M: int
+    D: int
+    P: int
+    shapes: list          # [(H, W)] per level
+    Lq: int
+    encoder: bool         # queries are the pixels of the pyramid (Lq == S)
+
+    @property
+    def L(self):
+        return len(self.shapes)
+
+    @property
+    def S(self):
+        return sum(h * w for h, w in self.shapes)
+
+    def bytes_fwd(self, e_v=4, e_s=4):
+        """Algorithmic bytes of one forward call: value read once, out written once, loc + attn read."""
+        return e_v * (self.N * self.S * self.M * self.D + self.N * self.Lq * self.M * self.D) \
+            + e_s * 3 * self.N * self.Lq * self.M * self.L * self.P
+
+    def bytes_bwd(self, e_v=4, e_s=4):
+        """Algorithmic bytes of one backward call: value read + grad_value written, grad_out read,
+        loc + attn read, grad_loc + grad_attn written."""
+        return e_v * (2 * self.N * self.S * self.M * self.D + self.N * self.Lq * self.M * self.D) \
+            + e_s * 6 * self.N * self.Lq * self.M * self.L * self.P
+
+
+def call_E(N=2):
+    sh = pyramid_shapes(800, 1344)
+    return Call("E", N, 8, 32, 4, sh, sum(h * w for h, w in sh), True)
+
+
+def call_Dd(N=2, Lq=1092):
+    return Call("Dd", N, 8, 32, 4, pyramid_shapes(800, 1344), Lq, False)
+
+
+def call_Em(N=2):
+    sh = pyramid_shapes(1280, 1280)
+    return Call("Em", N, 8, 32, 4, sh, sum(h * w for h, w in sh), True)
+
+
+def shrunk(call, factor):
+    """The same call on a pyramid `factor` times smaller per side (parity-test sizes)."""
+    sh = [(max(1, round(h / factor)), max(1, round(w / factor))) for h, w in call.shapes]
+    S = sum(h * w for h, w in sh)
+    return Call(call.name + f"/{factor}", call.N, call.M, call.D, call.P, sh, S if call.encoder else
+                max(8, call.Lq // (factor * factor)), call.encoder)
+
+
+def level_tensors(call, device="cpu"):
+    shapes = torch.as_tensor(call.shapes, dtype=torch.long, device=device)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    return shapes, lsi
+
+
+def encoder_reference_points(call, dtype=torch.float32):
+    """Pixel centres of every level, normalised (x, y); valid_ratio = 1 (deformable_transformer.py:512-525)."""
+    refs = []
+    for H, W in call.shapes:
+        ys = (torch.arange(H, dtype=dtype) + 0.5) / H
+        xs = (torch.arange(W, dtype=dtype) + 0.5) / W
+        gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+        refs.append(torch.stack((gx.reshape(-1), gy.reshape(-1)), -1))
+    return torch.cat(refs, 0)
+
+
+def make_inputs(call, loc_mode="init", seed=0, dtype=torch.float32, device="cpu", jitter_px=1.0):
+    """Seeded inputs for one call: value ~ N(0,1); attn = softmax(N(0,1)) over the L*P points;
+    grad_out ~ N(0,1); sampling locations in one of two distributions:
+      "init"    reference points (encoder: pixel centres; decoder: U(0.1,0.9)^2 box centres) + the module's
+                initial offsets (head h: direction (cos,sin)(2 pi h/M)/max|.|, times k = 1..P pixels of the
+                sampled level; ops/modules/ms_deform_attn.py:62-76) + N(0, jitter_px) pixels -- local pattern
+      "uniform" U[0,1)^2 as in ops/test.py:34 -- worst-case locality
+    Generated on the CPU generator (reproducible everywhere), then moved to `device`.
+    Returns dict(value, shapes, lsi, loc, aw, grad_out)."""
+    g = torch.Generator().manual_seed(seed)
+    N, M, D, L, P, S, Lq = call.N, call.M, call.D, call.L, call.P, call.S, call.Lq
+    value = torch.randn(N, S, M, D, generator=g, dtype=dtype)
+    aw = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g, dtype=dtype), -1).view(N, Lq, M, L, P)
+    grad_out = torch.randn(N, Lq, M * D, generator=g, dtype=dtype)
+    if loc_mode == "uniform":
+        loc = torch.rand(N, Lq, M, L, P, 2, generator=g, dtype=dtype)
+    elif loc_mode == "init":
+        if call.encoder:
+            ref = encoder_reference_points(call, dtype)[None].expand(N, Lq, 2)
+        else:
+            ref = torch.rand(N, Lq, 2, generator=g, dtype=dtype) * 0.8 + 0.1
+        th = torch.arange(M, dtype=dtype) * (2.0 * math.pi / M)
+        d = torch.stack([th.cos(), th.sin()], -1)
+        d = d / d.abs().max(-1, keepdim=True)[0]
+        k = torch.arange(1, P + 1, dtype=dtype)
+        off = (d[:, None, None, :] * k[None, None, :, None]).expand(M, L, P, 2)
+        off = off[None, None] + jitter_px * torch.randn(N, Lq, M, L, P, 2, generator=g, dtype=dtype)
+        wh = torch.tensor([[w, h] for h, w in call.shapes], dtype=dtype)
+        loc = ref[:, :, None, None, None, :] + off / wh[None, None, None, :, None, :]
+    else:
+        raise ValueError(loc_mode)
+    shapes, lsi = level_tensors(call)
+    t = dict(value=value, shapes=shapes, lsi=lsi, loc=loc.contiguous(), aw=aw.contiguous(), grad_out=grad_out)
+    return {k: v.to(device) for k, v in t.items()}
+
+
+# one training step of the hot path: (call, repetitions)
+def training_step_calls(N=2):
+    return [(call_E(N), 6), (call_Dd(N), 6)]

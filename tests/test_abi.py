@@ -1,0 +1,101 @@
+"""CPU: the C-ABI library builds for gfx950, loads, exports every symbol include/richsem_msda.h declares,
+and rejects bad arguments on the host (no kernel is launched in this file)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from richsem_amd import _build, _lib
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "richsem_msda.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(msda_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _build.build()
+    return _lib.load()
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.lib_path()], text=True)
+    exported = set(line.split()[-1] for line in out.splitlines() if line.strip())
+    for sym in declared_symbols():
+        assert sym in exported, sym
+        assert getattr(lib, sym) is not None
+
+
+def test_library_contains_gfx950_code_object():
+    blob = open(_lib.lib_path(), "rb").read()
+    assert b"gfx950" in blob and b"fwd_direct_kernel" in blob and b"bwd_direct_kernel" in blob
+
+
+def test_abi_version(lib):
+    assert lib.msda_abi_version() == _lib.ABI_VERSION
+    m = re.search(r"#define RICHSEM_MSDA_ABI_VERSION (\d+)", open(HEADER).read())
+    assert int(m.group(1)) == _lib.ABI_VERSION
+
+
+def test_options_roundtrip(lib):
+    for key in ("fwd_variant", "bwd_variant"):
+        old = _lib.get_option(key)
+        _lib.set_option(key, 1)
+        assert _lib.get_option(key) == 1
+        _lib.set_option(key, old)
+    with pytest.raises(RuntimeError, match="MSDA_ERR_BAD_OPTION"):
+        _lib.set_option("no_such_option", 1)
+    with pytest.raises(RuntimeError, match="MSDA_ERR_BAD_OPTION"):
+        _lib.set_option("fwd_variant", 99)
+
+
+def _call_forward(lib, dims, shapes, lsi, im2col_step=64, null=None, ptr=0x1000):
+    """Forward entry with fake (never dereferenced) device pointers: every check below fails on the host,
+    before anything touches a device."""
+    N, S, M, D, L, Lq, P = dims
+    sh = np.asarray(shapes, dtype=np.int64)
+    ls = np.asarray(lsi, dtype=np.int64)
+    p = [ptr] * 5
+    if null is not None:
+        p[null] = None
+    return lib.msda_forward_f32(p[0], p[1], p[2], p[3], p[4], N, S, M, D, L, Lq, P, im2col_step, ptr,
+                                sh.ctypes.data, ls.ctypes.data, None)
+
+
+def test_argument_errors_are_reported_not_printed(lib):
+    good = (2, 30, 2, 4, 2, 5, 2)
+    shapes, lsi = [[6, 4], [3, 2]], [0, 24]
+    assert _call_forward(lib, good, shapes, lsi, null=0) == -1                      # MSDA_ERR_NULL_POINTER
+    assert _call_forward(lib, (2, 30, 2, 0, 2, 5, 2), shapes, lsi) == -2            # non-positive D
+    assert _call_forward(lib, (2, 31, 2, 4, 2, 5, 2), shapes, lsi) == -2            # sum H*W != S
+    assert "!= S" in _lib.last_error()
+    assert _call_forward(lib, good, shapes, [0, 25]) == -2                          # level runs past S
+    assert _call_forward(lib, good, [[6, 4], [0, 2]], lsi) == -2                    # empty level
+    assert _call_forward(lib, (3, 30, 2, 4, 2, 5, 2), shapes, lsi, im2col_step=2) == -3   # 3 % min(3,2) != 0
+    assert "must divide im2col_step" in _lib.last_error()
+    assert _call_forward(lib, good, shapes, lsi, im2col_step=0) == -3
+    assert _call_forward(lib, (4, 1 << 20, 8, 64, 1, 5, 2), [[1024, 1024]], [0]) == -4   # >= 2^31 elements
+    assert _call_forward(lib, good, shapes, lsi, ptr=0x1002) == -5                  # misaligned pointers
+    with pytest.raises(RuntimeError, match="MSDA_ERR_MISALIGNED"):
+        _lib.check(-5)
+
+
+def test_im2col_step_contract_matches_reference(lib):
+    """reference ms_deform_attn_cuda.cu:48-52: step' = min(N, step); N % step' must be 0."""
+    shapes, lsi = [[6, 4], [3, 2]], [0, 24]
+    for N, step in [(6, 4), (5, 2), (7, 3), (64 * 3 + 1, 64)]:
+        assert _call_forward(lib, (N, 30, 2, 4, 2, 5, 2), shapes, lsi, im2col_step=step) == -3
+        assert f"batch({N}) must divide im2col_step({min(N, step)})" in _lib.last_error()

@@ -1,0 +1,267 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (via the drop-in module), against
+  (1) the committed golden vectors made from the reference's own implementation,
+  (2) the oracle (oracle/msda_oracle.c) on seeded inputs, for every kernel variant and channel count the
+      reference's test covers (ops/test.py:85: D in 30, 32, 64, 71, 1025, 2048, 3096),
+  (3) size-independent properties at BASELINE.json's full sizes.
+Tolerances: fp64 1e-10 relative to the tensor's max (summation order differs, float atomics in backward);
+fp32 2e-5 for forward and 2e-4 for gradients (sums of up to Lq*16 atomically-added terms) -- far inside
+north_star's 1e-3 and the reference's own rtol 1e-2 / atol 1e-3 (ops/test.py:56)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import msda_oracle as O
+from richsem_amd import _lib, workload as W
+from richsem_amd import MultiScaleDeformableAttention as MSDA
+from richsem_amd.functions import MSDeformAttnFunction
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+VARIANTS = [1, 2]   # 1 = direct kernels, 2 = tiled kernels where applicable (else falls back to direct)
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def rel_err(a, b):
+    a = a.detach().cpu().numpy() if hasattr(a, "detach") else a
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+
+
+def tols(dtype):
+    return (1e-10, 1e-10) if dtype in (np.float64, torch.float64) else (2e-5, 2e-4)
+
+
+@pytest.fixture(autouse=True)
+def _restore_variants():
+    yield
+    _lib.set_option("fwd_variant", 0)
+    _lib.set_option("bwd_variant", 0)
+
+
+def run_gpu(z, variant=0):
+    _lib.set_option("fwd_variant", variant)
+    _lib.set_option("bwd_variant", variant)
+    v, sh, ls, loc, aw, go = (dev(z[k]) for k in ("value", "shapes", "lsi", "loc", "aw", "grad_out"))
+    out = MSDA.ms_deform_attn_forward(v, sh, ls, loc, aw, 64)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, ls, loc, aw, go.contiguous(), 64)
+    torch.cuda.synchronize()
+    return out, gv, gl, ga
+
+
+def test_hip_library_is_the_loaded_path():
+    lib = _lib.load()
+    assert lib.msda_abi_version() == _lib.ABI_VERSION
+    maps = open("/proc/self/maps").read()
+    assert "librichsem_msda.so" in maps
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("case", CASES)
+def test_golden_vectors(case, variant):
+    z = np.load(os.path.join(GOLDEN, case + ".npz"))
+    out, gv, gl, ga = run_gpu(z, variant)
+    tf, tg = tols(z["value"].dtype)
+    assert rel_err(out, z["out"]) < tf
+    assert rel_err(gv, z["grad_value"]) < tg
+    assert rel_err(ga, z["grad_aw"]) < tg
+    if case == "border_exact_fwd":   # see tests/test_oracle_golden.py: kernel semantics on the exact border
+        ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
+        assert rel_err(gl, ogl) < tg
+    else:
+        assert rel_err(gl, z["grad_loc"]) < tg
+
+
+def test_reference_test_recipe_tolerances():
+    """ops/test.py:31-60 acceptance: fp64 default allclose, fp32 rtol 1e-2 / atol 1e-3."""
+    z = np.load(os.path.join(GOLDEN, "ref_test_fwd_double.npz"))
+    out, *_ = run_gpu(z)
+    assert np.allclose(out.cpu().numpy(), z["out"])
+    z = np.load(os.path.join(GOLDEN, "ref_test_fwd_float.npz"))
+    out, *_ = run_gpu(z)
+    assert np.allclose(out.cpu().numpy(), z["out"], rtol=1e-2, atol=1e-3)
+
+
+def _recipe(N, S, M, D, Lq, L, P, gen, dtype):
+    value = torch.rand(N, S, M, D, generator=gen, dtype=dtype) * 0.01
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=gen, dtype=dtype)
+    aw = torch.rand(N, Lq, M, L, P, generator=gen, dtype=dtype) + 1e-5
+    aw /= aw.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    go = torch.randn(N, Lq, M * D, generator=gen, dtype=dtype)
+    return value, loc, aw, go
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("D", [30, 32, 64, 71, 1025, 2048, 3096, 1, 2, 4, 6, 20, 128, 256, 260])
+def test_every_channel_count_against_oracle(D, dtype):
+    """The reference test's channel list (one per backward-kernel variant there) plus odd sizes that exercise
+    each channels-per-lane / lanes-per-item combination of the direct kernels."""
+    N, M, Lq, L, P = 1, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long)
+    lsi = torch.as_tensor([0, 24])
+    gen = torch.Generator().manual_seed(1000 + D)
+    value, loc, aw, go = _recipe(N, 30, M, D, Lq, L, P, gen, dtype)
+    z = dict(value=value.numpy(), shapes=shapes.numpy(), lsi=lsi.numpy(), loc=loc.numpy(), aw=aw.numpy(),
+             grad_out=go.numpy())
+    out, gv, gl, ga = run_gpu(z)
+    oo = O.forward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"])
+    ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
+    tf, tg = tols(dtype)
+    assert rel_err(out, oo) < tf
+    assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("loc_mode", ["init", "uniform"])
+@pytest.mark.parametrize("which", ["E", "Dd", "Em"])
+def test_shrunk_baseline_calls_against_oracle(which, loc_mode, variant):
+    """BASELINE configs at 1/4 scale per side (sizes the oracle finishes in about a second), N = 2, M = 8, D = 32."""
+    call = W.shrunk({"E": W.call_E, "Dd": W.call_Dd, "Em": W.call_Em}[which](2), 4)
+    t = W.make_inputs(call, loc_mode, seed=7)
+    z = {k: v.numpy() for k, v in t.items()}
+    out, gv, gl, ga = run_gpu(z, variant)
+    oo = O.forward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"])
+    ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
+    tf, tg = tols(np.float32)
+    assert rel_err(out, oo) < tf
+    assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg
+
+
+@pytest.mark.parametrize("dims", [
+    dict(N=3, M=3, D=32, L=1, P=1, shapes=[(5, 7)], Lq=11),          # pairs not a multiple of 8, single level/point
+    dict(N=1, M=1, D=32, L=3, P=5, shapes=[(9, 3), (1, 1), (2, 8)], Lq=1),     # 1x1 level, one query
+    dict(N=2, M=16, D=8, L=2, P=3, shapes=[(4, 4), (2, 2)], Lq=70),  # more pairs than XCDs
+    dict(N=1, M=2, D=16, L=5, P=9, shapes=[(3, 3)] * 5, Lq=67),      # L*P = 45 > one point batch (32)
+])
+def test_ragged_geometries_against_oracle(dims):
+    call = W.Call("r", dims["N"], dims["M"], dims["D"], dims["P"], dims["shapes"], dims["Lq"], False)
+    t = W.make_inputs(call, "uniform", seed=5, dtype=torch.float64)
+    t["loc"] = t["loc"] * 1.5 - 0.25      # includes partially and fully outside samples
+    z = {k: v.numpy() for k, v in t.items()}
+    out, gv, gl, ga = run_gpu(z)
+    oo = O.forward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"])
+    ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
+    assert rel_err(out, oo) < 1e-10
+    assert rel_err(gv, ogv) < 1e-10 and rel_err(gl, ogl) < 1e-10 and rel_err(ga, oga) < 1e-10
+
+
+def test_all_samples_outside_gives_zeros():
+    call = W.Call("o", 1, 2, 32, 2, [(6, 4), (3, 2)], 9, False)
+    t = W.make_inputs(call, "uniform", seed=2)
+    t["loc"] = t["loc"] + 5.0
+    out, gv, gl, ga = run_gpu({k: v.numpy() for k, v in t.items()})
+    assert float(out.abs().max()) == 0 and float(gv.abs().max()) == 0
+    assert float(gl.abs().max()) == 0 and float(ga.abs().max()) == 0
+
+
+def test_outputs_do_not_depend_on_stale_output_memory():
+    """Outputs are caller-allocated and NOT pre-zeroed (include/richsem_msda.h): poison them first."""
+    call = W.shrunk(W.call_E(2), 8)
+    t = {k: v.cuda() for k, v in W.make_inputs(call, "init", seed=9).items()}
+    lib = _lib.load()
+    N, S, M, D, L, Lq, P = call.N, call.S, call.M, call.D, call.L, call.Lq, call.P
+    sh, ls = t["shapes"].cpu().numpy(), t["lsi"].cpu().numpy()
+    outs = []
+    for poison in (float("nan"), 123.0):
+        out = torch.full((N, Lq, M * D), poison, device="cuda")
+        gv = torch.full_like(t["value"], poison)
+        gl = torch.full_like(t["loc"], poison)
+        ga = torch.full_like(t["aw"], poison)
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.msda_forward_f32(t["value"].data_ptr(), t["shapes"].data_ptr(), t["lsi"].data_ptr(),
+                                        t["loc"].data_ptr(), t["aw"].data_ptr(), N, S, M, D, L, Lq, P, 64,
+                                        out.data_ptr(), sh.ctypes.data, ls.ctypes.data, s))
+        _lib.check(lib.msda_backward_f32(t["value"].data_ptr(), t["shapes"].data_ptr(), t["lsi"].data_ptr(),
+                                         t["loc"].data_ptr(), t["aw"].data_ptr(), t["grad_out"].data_ptr(), N, S, M, D,
+                                         L, Lq, P, 64, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), sh.ctypes.data,
+                                         ls.ctypes.data, s))
+        torch.cuda.synchronize()
+        outs.append((out, gv, gl, ga))
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all()
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_host_mirror_is_optional():
+    """NULL host mirrors: the library reads the level sizes back itself (synchronising) and gives the same result."""
+    z = np.load(os.path.join(GOLDEN, "decoder_n2m8_f64.npz"))
+    v, sh, ls, loc, aw = (dev(z[k]) for k in ("value", "shapes", "lsi", "loc", "aw"))
+    N, S, M, D = v.shape
+    L, Lq, P = sh.shape[0], loc.shape[1], loc.shape[4]
+    out = torch.empty(N, Lq, M * D, dtype=torch.float64, device="cuda")
+    _lib.check(_lib.load().msda_forward_f64(v.data_ptr(), sh.data_ptr(), ls.data_ptr(), loc.data_ptr(), aw.data_ptr(),
+                                            N, S, M, D, L, Lq, P, 64, out.data_ptr(), None, None,
+                                            torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rel_err(out, z["out"]) < 1e-10
+
+
+def test_shim_errors_match_reference_preconditions():
+    z = np.load(os.path.join(GOLDEN, "decoder_n2m8_f64.npz"))
+    v, sh, ls, loc, aw = (dev(z[k]) for k in ("value", "shapes", "lsi", "loc", "aw"))
+    with pytest.raises(RuntimeError, match="value tensor has to be contiguous"):
+        MSDA.ms_deform_attn_forward(v.transpose(0, 1), sh, ls, loc, aw, 64)
+    with pytest.raises(RuntimeError, match="spatial_shapes must be a CUDA tensor"):
+        MSDA.ms_deform_attn_forward(v, sh.cpu(), ls, loc, aw, 64)
+    with pytest.raises(RuntimeError, match="not implemented for 'Half'"):
+        MSDA.ms_deform_attn_forward(v.half(), sh, ls, loc.half(), aw.half(), 64)
+    with pytest.raises(RuntimeError, match="must divide im2col_step"):
+        MSDA.ms_deform_attn_forward(v.repeat(3, 1, 1, 1)[:3], sh, ls, loc.repeat(3, 1, 1, 1, 1, 1)[:3].contiguous(),
+                                    aw.repeat(3, 1, 1, 1, 1)[:3].contiguous(), 2)
+
+
+def test_autograd_function_gradcheck_like_reference():
+    """ops/test.py:63-78 runs torch.autograd.gradcheck in fp64 on all three differentiable inputs."""
+    N, M, D, Lq, L, P = 1, 2, 4, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long).cuda()
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    gen = torch.Generator().manual_seed(3)
+    value, loc, aw, _ = _recipe(N, 30, M, D, Lq, L, P, gen, torch.float64)
+    value, loc, aw = (t.cuda().requires_grad_(True) for t in (value, loc, aw))
+    assert torch.autograd.gradcheck(MSDeformAttnFunction.apply, (value, shapes, lsi, loc, aw, 2))
+
+
+@pytest.mark.parametrize("which", ["E", "Dd"])
+def test_full_size_properties(which):
+    """BASELINE.json's full sizes, checked through properties that need no oracle run:
+    linearity in value, the adjoint identity <out(v), g> = <v, grad_value(g)>, constant-field reproduction,
+    and agreement of the two kernel variants."""
+    call = {"E": W.call_E, "Dd": W.call_Dd}[which](2)
+    t = {k: v.cuda() for k, v in W.make_inputs(call, "init", seed=0).items()}
+    f = lambda v: MSDA.ms_deform_attn_forward(v, t["shapes"], t["lsi"], t["loc"], t["aw"], 64)
+    out = f(t["value"])
+    v2 = torch.randn_like(t["value"])
+    lin = f(2.0 * t["value"] - 3.0 * v2)
+    assert torch.allclose(lin, 2.0 * out - 3.0 * f(v2), rtol=1e-4, atol=1e-4)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64)
+    lhs = (out.double() * t["grad_out"].double()).sum()
+    rhs = (t["value"].double() * gv.double()).sum()
+    assert abs(float(lhs - rhs)) < 1e-4 * max(1.0, abs(float(lhs)))
+    # grad_attn is the sampled value dotted with grad_out: sum_p attn * grad_attn == <out, grad_out> per (b,q,m)
+    per_head = (out.view(call.N, call.Lq, call.M, call.D) * t["grad_out"].view(call.N, call.Lq, call.M, call.D)).sum(-1)
+    assert torch.allclose((t["aw"] * ga).sum((-1, -2)), per_head, rtol=1e-3, atol=1e-3)
+    # a constant field is reproduced wherever all four corners of all samples are inside the map
+    ones = torch.ones_like(t["value"])
+    o1 = f(ones).view(call.N, call.Lq, call.M, call.D)
+    H = t["shapes"][:, 0].float()[None, None, None, :, None]
+    Wd = t["shapes"][:, 1].float()[None, None, None, :, None]
+    x, y = t["loc"][..., 0] * Wd - 0.5, t["loc"][..., 1] * H - 0.5
+    inside = ((x >= 0) & (x <= Wd - 1) & (y >= 0) & (y <= H - 1)).all(-1).all(-1)
+    assert inside.float().mean() > 0.3
+    assert torch.allclose(o1[inside], torch.ones_like(o1[inside]), atol=1e-5)
+    # kernel variants agree
+    res = {}
+    for variant in VARIANTS:
+        _lib.set_option("fwd_variant", variant)
+        _lib.set_option("bwd_variant", variant)
+        res[variant] = (f(t["value"]),) + tuple(MSDA.ms_deform_attn_backward(
+            t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64))
+    for a, b in zip(res[1], res[2]):
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-3)

@@ -1,0 +1,91 @@
+"""CPU: host-side logic of the drop-in (argument checks of the shim, workload geometry, byte counts)."""
+import sys
+
+import pytest
+import torch
+
+import richsem_amd
+from richsem_amd import workload as W
+from richsem_amd import MultiScaleDeformableAttention as MSDA
+from richsem_amd.functions import MSDeformAttnFunction
+from richsem_amd.modules import MSDeformAttn
+
+
+def small_inputs(dtype=torch.float32):
+    call = W.Call("t", 1, 2, 4, 2, [(6, 4), (3, 2)], 5, False)
+    return call, W.make_inputs(call, "uniform", seed=1, dtype=dtype)
+
+
+def test_cpu_tensors_are_rejected_like_the_reference():
+    """reference src/ms_deform_attn.h:38,60: AT_ERROR("Not implemented on the CPU") -- and no silent fallback."""
+    _, t = small_inputs()
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        MSDA.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], 64)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        MSDA.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        MSDeformAttnFunction.apply(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], 64)
+
+
+def test_dropin_module_name():
+    shim = richsem_amd.install_dropin()
+    import MultiScaleDeformableAttention as ref_name
+    assert hasattr(ref_name, "ms_deform_attn_forward") and hasattr(ref_name, "ms_deform_attn_backward")
+    assert sys.modules["MultiScaleDeformableAttention"] is not None
+    assert shim.ms_deform_attn_forward is MSDA.ms_deform_attn_forward
+
+
+def test_module_state_dict_keys_and_init_match_reference():
+    """reference ops/modules/ms_deform_attn.py:50-76: parameter names and the initial sampling pattern."""
+    m = MSDeformAttn(256, 4, 8, 4)
+    assert sorted(m.state_dict().keys()) == sorted(
+        f"{n}.{p}" for n in ("sampling_offsets", "attention_weights", "value_proj", "output_proj")
+        for p in ("weight", "bias"))
+    assert m.im2col_step == 64
+    assert m.sampling_offsets.weight.abs().max() == 0 and m.attention_weights.weight.abs().max() == 0
+    assert m.attention_weights.bias.abs().max() == 0 and m.value_proj.bias.abs().max() == 0
+    b = m.sampling_offsets.bias.detach().view(8, 4, 4, 2)
+    # head 0 points along +x, head 2 along +y; point k is k+1 steps out; same for every level
+    assert torch.allclose(b[0, :, :, 0], torch.tensor([1., 2., 3., 4.]).expand(4, 4))
+    assert torch.allclose(b[0, :, :, 1], torch.zeros(4, 4), atol=1e-6)
+    assert torch.allclose(b[2, :, :, 1], torch.tensor([1., 2., 3., 4.]).expand(4, 4))
+    assert torch.allclose(b[1, 0, 0], torch.tensor([1., 1.]), atol=1e-6)      # diagonal, max-norm 1
+    assert torch.equal(b[:, 0], b[:, 3])
+    with pytest.raises(ValueError):
+        MSDeformAttn(250, 4, 8, 4)
+
+
+def test_module_rejects_bad_reference_points_before_the_op():
+    m = MSDeformAttn(32, 2, 4, 2)
+    q = torch.zeros(1, 5, 32)
+    src = torch.zeros(1, 30, 32)
+    shapes = torch.tensor([[6, 4], [3, 2]])
+    lsi = torch.tensor([0, 24])
+    with pytest.raises(ValueError, match="Last dim of reference_points must be 2 or 4"):
+        m(q, torch.zeros(1, 5, 2, 3), src, shapes, lsi)
+
+
+def test_pyramid_shapes_and_algorithmic_bytes():
+    """SURVEY.md section 8 / BASELINE.md section 3 figures."""
+    E, Dd, Em = W.call_E(), W.call_Dd(), W.call_Em()
+    assert E.shapes == [(100, 168), (50, 84), (25, 42), (13, 21)] and E.S == 22323 and E.Lq == 22323
+    assert Em.shapes == [(160, 160), (80, 80), (40, 40), (20, 20)] and Em.S == 34000
+    assert (E.bytes_fwd(), E.bytes_bwd()) == (160011264, 274305024)
+    assert (Dd.bytes_fwd(), Dd.bytes_bwd()) == (51308544, 100380672)
+    step = sum(r * (c.bytes_fwd() + c.bytes_bwd()) for c, r in W.training_step_calls())
+    assert abs(step - 3.52e9) < 0.01e9
+    sh, lsi = W.level_tensors(E)
+    assert lsi.tolist() == [0, 16800, 21000, 22050]
+
+
+def test_make_inputs_is_seeded_and_well_formed():
+    call = W.shrunk(W.call_E(1), 8)
+    a = W.make_inputs(call, "init", seed=3)
+    b = W.make_inputs(call, "init", seed=3)
+    c = W.make_inputs(call, "init", seed=4)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert not torch.equal(a["loc"], c["loc"])
+    assert a["loc"].shape == (1, call.Lq, 8, 4, 4, 2) and a["loc"].is_contiguous()
+    assert torch.allclose(a["aw"].sum((-1, -2)), torch.ones(1, call.Lq, 8), atol=1e-5)
+    u = W.make_inputs(call, "uniform", seed=3)
+    assert 0 <= float(u["loc"].min()) and float(u["loc"].max()) < 1

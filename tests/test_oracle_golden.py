@@ -1,0 +1,93 @@
+"""CPU: the oracle (oracle/msda_oracle.c) against the golden vectors made from the reference's own
+pure-PyTorch path (tests/golden/make_golden.py).  This is what pins the oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import msda_oracle as O
+
+from conftest import GOLDEN
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+
+
+def tol_for(dtype):
+    # fp64: rounding-order differences only; fp32: same, at single precision
+    return 1e-12 if dtype == np.float64 else 2e-5
+
+
+def test_cases_present():
+    assert len(CASES) >= 11, CASES
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_matches_reference(case):
+    z = np.load(os.path.join(GOLDEN, case + ".npz"))
+    out = O.forward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"])
+    assert out.dtype == z["out"].dtype and out.shape == z["out"].shape
+    assert rel_err(out, z["out"]) < tol_for(out.dtype)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_backward_matches_reference_autograd(case):
+    z = np.load(os.path.join(GOLDEN, case + ".npz"))
+    gv, gl, ga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
+    tol = tol_for(gv.dtype)
+    assert rel_err(gv, z["grad_value"]) < tol
+    assert rel_err(ga, z["grad_aw"]) < tol
+    if case == "border_exact_fwd":
+        # Samples EXACTLY on the acceptance border (h_im == -1, h_im == H, same for w): the reference CUDA
+        # kernel drops them (ms_deform_im2col_cuda.cuh:285 uses strict inequalities) so their location gradient
+        # is 0, while grid_sample keeps them with zero weight and a one-sided derivative.  Measure-zero set;
+        # the oracle follows the kernel.  Everywhere else the location gradients must agree.
+        H = z["shapes"][:, 0].astype(np.float64)[None, None, None, :, None]
+        W = z["shapes"][:, 1].astype(np.float64)[None, None, None, :, None]
+        h_im = z["loc"][..., 1] * H - 0.5
+        w_im = z["loc"][..., 0] * W - 0.5
+        on_border = (h_im == -1) | (h_im == H) | (w_im == -1) | (w_im == W)
+        assert on_border.any() and not on_border.all()
+        assert np.all(gl[on_border] == 0)
+        keep = ~on_border
+        assert np.abs(gl[keep] - z["grad_loc"][keep]).max() / np.abs(z["grad_loc"]).max() < tol
+    else:
+        assert rel_err(gl, z["grad_loc"]) < tol
+
+
+def test_reference_test_tolerances():
+    """The reference's own acceptance criteria (ops/test.py:40 default allclose in fp64; :56 rtol 1e-2, atol 1e-3
+    in fp32) hold for the oracle on the reference's own inputs."""
+    z = np.load(os.path.join(GOLDEN, "ref_test_fwd_double.npz"))
+    assert np.allclose(O.forward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"]), z["out"])
+    z = np.load(os.path.join(GOLDEN, "ref_test_fwd_float.npz"))
+    assert np.allclose(O.forward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"]), z["out"], rtol=1e-2, atol=1e-3)
+
+
+def test_threads_do_not_change_results():
+    z = np.load(os.path.join(GOLDEN, "pyramid_encoder_f32.npz"))
+    args = (z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"])
+    O.set_threads(1)
+    o1 = O.forward(*args)
+    g1 = O.backward(*args, z["grad_out"])
+    O.set_threads(4)
+    o4 = O.forward(*args)
+    g4 = O.backward(*args, z["grad_out"])
+    O.set_threads(1)
+    assert np.array_equal(o1, o4)
+    for a, b in zip(g1, g4):
+        assert np.array_equal(a, b)
+
+
+def test_oracle_adjoint_identity():
+    """<out(value), g> == <value, grad_value(g)>: forward is linear in value and backward is its adjoint."""
+    z = np.load(os.path.join(GOLDEN, "decoder_n2m8_f64.npz"))
+    out = O.forward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"])
+    gv, _, _ = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
+    lhs = float((out * z["grad_out"]).sum())
+    rhs = float((z["value"] * gv).sum())
+    assert abs(lhs - rhs) < 1e-10 * max(1.0, abs(lhs))
