@@ -62,8 +62,9 @@ def _check_inputs(named, fn):
             raise RuntimeError(f"{name} must be a CUDA tensor")
         if t.device != value.device:
             raise RuntimeError(f"{name} must be on the same device as value")
-    if value.dtype not in _SUFFIX:
-        raise RuntimeError(f'"{fn}" not implemented for \'{str(value.dtype).replace("torch.", "")}\'')
+    if value.dtype not in _SUFFIX:   # AT_DISPATCH_FLOATING_TYPES: float and double only (ms_deform_attn_cuda.cu:64,134)
+        aten = {torch.float16: "Half", torch.bfloat16: "BFloat16", torch.int64: "Long", torch.int32: "Int"}
+        raise RuntimeError(f'"{fn}" not implemented for \'{aten.get(value.dtype, str(value.dtype))}\'')
     for name, t in named:
         if name in ("spatial_shapes", "level_start_index"):
             if t.dtype != torch.int64:

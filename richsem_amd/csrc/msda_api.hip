@@ -35,7 +35,7 @@ int hip_fail(hipError_t e, const char *what)
     return (int)e;
 }
 
-std::atomic<int> g_fwd_variant{0}, g_bwd_variant{0};
+std::atomic<int> g_fwd_variant{0}, g_bwd_variant{0}, g_bwd_cpl{0};
 
 // ---- launch profiler: pre-created event pairs, one per logged call -----------------------------
 struct ProfileSlot {
@@ -148,7 +148,7 @@ msda::DirectGeom direct_geom(const Problem &pb, int C)
     msda::DirectGeom g{};
     g.N = pb.N; g.S = pb.S; g.M = pb.M; g.D = pb.D; g.L = pb.L; g.Lq = pb.Lq; g.P = pb.P;
     const int lanes = (pb.D + C - 1) / C;
-    int G = 1;
+    int G = msda::kMinGroup;
     while (G < lanes && G < msda::kWave) G <<= 1;
     g.G = G;
     g.logG = floor_log2(G);
@@ -156,6 +156,8 @@ msda::DirectGeom direct_geom(const Problem &pb, int C)
     const int per_iter = msda::kDirectWaves * (msda::kWave / G);
     g.qtile = per_iter * 2 > 64 ? per_iter * 2 : 64;   // >= 2 passes per block amortise the level table
     g.ntiles = (pb.Lq + g.qtile - 1) / g.qtile;
+    const int LP = pb.L * pb.P;
+    g.pbatch = LP < msda::kPointBatch ? LP : msda::kPointBatch;
     return g;
 }
 
@@ -195,6 +197,7 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
     const int C = pick_channels_per_lane<T>(D, {value, out});
     const msda::DirectGeom g = direct_geom(pb, C);
     const size_t lds = msda::direct_lds_bytes<T>(g);
+    if (lds > 64 * 1024) return fail(MSDA_ERR_BAD_DIMS, "too many levels (L=%d) for the level table in LDS", L);
     const dim3 grid(direct_grid(g)), block(msda::kDirectThreads);
     ProfileScope prof(0, 1, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
     switch (C) {
@@ -239,9 +242,14 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         return MSDA_OK;
     }
 
-    const int C = pick_channels_per_lane<T>(D, {value, grad_out});
+    // Float atomics run at full rate only as >= 128-B row segments (one dword per lane): with 32 or more
+    // channels put ONE channel on a lane, so that a wave-instruction adds two whole 128-B rows.
+    int C = pick_channels_per_lane<T>(D, {value, grad_out});
+    if (g_bwd_cpl.load() > 0) C = g_bwd_cpl.load() <= C ? g_bwd_cpl.load() : C;
+    else if (D * (int)sizeof(T) >= 128) C = 1;
     const msda::DirectGeom g = direct_geom(pb, C);
     const size_t lds = msda::direct_lds_bytes<T>(g);
+    if (lds > 64 * 1024) return fail(MSDA_ERR_BAD_DIMS, "too many levels (L=%d) for the level table in LDS", L);
     const dim3 grid(direct_grid(g)), block(msda::kDirectThreads);
     ProfileScope prof(1, 1, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
     switch (C) {
@@ -266,6 +274,7 @@ int msda_set_option(const char *key, int value)
 {
     if (key && !strcmp(key, "fwd_variant") && value >= 0 && value <= 2) { g_fwd_variant = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_variant") && value >= 0 && value <= 2) { g_bwd_variant = value; return MSDA_OK; }
+    if (key && !strcmp(key, "bwd_direct_cpl") && (value == 0 || value == 1 || value == 2 || value == 4)) { g_bwd_cpl = value; return MSDA_OK; }
     return fail(MSDA_ERR_BAD_OPTION, "unknown option or value: %s=%d", key ? key : "(null)", value);
 }
 
@@ -274,6 +283,7 @@ int msda_get_option(const char *key, int *value)
     if (!value) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
     if (key && !strcmp(key, "fwd_variant")) { *value = g_fwd_variant; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_variant")) { *value = g_bwd_variant; return MSDA_OK; }
+    if (key && !strcmp(key, "bwd_direct_cpl")) { *value = g_bwd_cpl; return MSDA_OK; }
     return fail(MSDA_ERR_BAD_OPTION, "unknown option: %s", key ? key : "(null)");
 }
 

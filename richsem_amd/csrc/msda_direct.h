@@ -28,20 +28,20 @@ struct DirectGeom {
     int N, S, M, D, L, Lq, P;
     int G, logG, nchunks;  // lanes per item, log2, channel chunks per lane
     int qtile, ntiles;     // queries per block, tiles per (b,m) pair
+    int pbatch;            // sampling points staged in LDS per pass: min(L*P, kPointBatch)
 };
 
 constexpr int kDirectThreads = 256;
 constexpr int kDirectWaves = kDirectThreads / kWave;
-// records of one item; +1 record of padding so that the 8 items a wave reads together (LDS
-// broadcast per item) start on different banks
-constexpr int kSlotStride = kPointBatch + 1;
+constexpr int kMinGroup = 8;   // lanes per item are never fewer: bounds the items (LDS slots) per wave
 
-// LDS: [L x LevelGeom][waves x items-per-wave x kPointBatch x PointRec<T>]
+// LDS: [L x LevelGeom][waves x items-per-wave x (pbatch + 1) x PointRec<T>]; the +1 record of padding
+// makes the items a wave reads together (one LDS broadcast per item) start on different banks.
 template <typename T>
 inline size_t direct_lds_bytes(const DirectGeom &g)
 {
     const int ipw = kWave / g.G;
-    return sizeof(LevelGeom) * g.L + sizeof(PointRec<T>) * kDirectWaves * ipw * kSlotStride;
+    return sizeof(LevelGeom) * g.L + sizeof(PointRec<T>) * kDirectWaves * ipw * (g.pbatch + 1);
 }
 
 __device__ __forceinline__ void load_levels(LevelGeom *lv, const int64_t *shapes, const int64_t *lsi, int L)
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kDirectThreads) void fwd_direct_kernel(
     const int slot = wave * ipw + (lane >> g.logG);
     const int LP = g.L * g.P;
     const int row_elems = g.M * g.D;
-    PointRec<T> *my = recs + slot * kSlotStride;
+    PointRec<T> *my = recs + slot * (g.pbatch + 1);
 
     const int q_end = min((tile + 1) * g.qtile, g.Lq);
     for (int q0 = tile * g.qtile; q0 < q_end; q0 += kDirectWaves * ipw) {   // block-uniform trip count
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(kDirectThreads) void fwd_direct_kernel(
             T acc[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[c] = (T)0;
-            for (int p0 = 0; p0 < LP; p0 += kPointBatch) {
-                const int np = min(kPointBatch, LP - p0);
+            for (int p0 = 0; p0 < LP; p0 += g.pbatch) {
+                const int np = min(g.pbatch, LP - p0);
                 // (1) resolve this batch of points, one point per lane, into the item's LDS slot
                 if (live) {
                     for (int pt = j; pt < np; pt += g.G) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kDirectThreads) void bwd_direct_kernel(
     const int slot = wave * ipw + (lane >> g.logG);
     const int LP = g.L * g.P;
     const int row_elems = g.M * g.D;
-    PointRec<T> *my = recs + slot * kSlotStride;
+    PointRec<T> *my = recs + slot * (g.pbatch + 1);
 
     const int q_end = min((tile + 1) * g.qtile, g.Lq);
     for (int q0 = tile * g.qtile; q0 < q_end; q0 += kDirectWaves * ipw) {
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(kDirectThreads) void bwd_direct_kernel(
         for (int c = 0; c < C; ++c) g0.v[c] = (T)0;
         if (live && j * C < g.D) g0 = *reinterpret_cast<const Pack<T, C> *>(grad_out + (int64_t)item * g.D + j * C);
 
-        for (int p0 = 0; p0 < LP; p0 += kPointBatch) {
-            const int np = min(kPointBatch, LP - p0);
+        for (int p0 = 0; p0 < LP; p0 += g.pbatch) {
+            const int np = min(g.pbatch, LP - p0);
             if (live) {
                 for (int pt = j; pt < np; pt += g.G) {
                     const int gp = p0 + pt, l = gp / g.P;
