@@ -78,11 +78,25 @@ int msda_abi_version(void);
 const char *msda_last_error(void);
 
 /* Tuning / test hooks.  Keys:
- *   "fwd_variant"  0 = auto, 1 = direct gather kernel, 2 = LDS-window kernel (when applicable)
- *   "bwd_variant"  0 = auto, 1 = global-atomic kernel, 2 = LDS-accumulation kernel
- * Unknown key -> MSDA_ERR_BAD_OPTION. */
+ *   "fwd_variant"     0 = auto, 1 = direct gather kernel, 2 = LDS-window kernel (when applicable)
+ *   "bwd_variant"     0 = auto, 1 = global-atomic kernel, 2 = LDS-accumulation kernels (when applicable)
+ *   "bwd_direct_cpl"  channels per lane of the direct backward kernel (0 = auto, 1, 2, 4)
+ *   "tile_region"     side of an LDS-window region, in pixels of the finest level (default 16)
+ *   "tile_margin"     window margin around a region, in pixels of the sampled level (default 6)
+ * Unknown key or value out of range -> MSDA_ERR_BAD_OPTION.  Options change speed, never results. */
 int msda_set_option(const char *key, int value);
 int msda_get_option(const char *key, int *value);
+
+/* Host-only: the launch plan the LDS-window kernels would use for a problem (no device access).
+ * info[0] = 1 if the window kernels apply (fp32, D = 32, L <= 4, Lq == S, levels contiguous), else 0;
+ * info[1], info[2] = region grid (rows, cols); info[3] = LDS phases; info[4] = LDS bytes per workgroup;
+ * info[5] = workgroups; info[6] = margin; info[7] = largest number of queries in one region. */
+int msda_tiled_plan(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
+                    const int64_t *level_start_host, int info[8]);
+
+/* Diagnostic: when `device_buffer` is non-NULL the LDS-window kernels write shader-clock stamps into it, 16 x 8 bytes
+ * per workgroup (buffer >= workgroups x 128 bytes), one per kernel stage; NULL (default) switches it off. */
+int msda_debug_stamps(void *device_buffer);
 
 /* ---- launch profiler (measurement aid; off by default) ------------------------------------
  * When enabled, every forward/backward call brackets its MAIN kernel (not the zero-fill) with

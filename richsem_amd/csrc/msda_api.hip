@@ -275,6 +275,9 @@ int msda_set_option(const char *key, int value)
     if (key && !strcmp(key, "fwd_variant") && value >= 0 && value <= 2) { g_fwd_variant = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_variant") && value >= 0 && value <= 2) { g_bwd_variant = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_direct_cpl") && (value == 0 || value == 1 || value == 2 || value == 4)) { g_bwd_cpl = value; return MSDA_OK; }
+    if (key && !strcmp(key, "tile_region") && value >= 4 && value <= 64) { msda::tiled_options().region_px = value; return MSDA_OK; }
+    if (key && !strcmp(key, "tile_margin") && value >= 0 && value <= 32) { msda::tiled_options().margin = value; return MSDA_OK; }
+    if (key && !strcmp(key, "tile_debug") && value >= 0 && value <= 255) { msda::tiled_options().dbg = value; return MSDA_OK; }
     return fail(MSDA_ERR_BAD_OPTION, "unknown option or value: %s=%d", key ? key : "(null)", value);
 }
 
@@ -284,7 +287,44 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "fwd_variant")) { *value = g_fwd_variant; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_variant")) { *value = g_bwd_variant; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_direct_cpl")) { *value = g_bwd_cpl; return MSDA_OK; }
+    if (key && !strcmp(key, "tile_region")) { *value = msda::tiled_options().region_px; return MSDA_OK; }
+    if (key && !strcmp(key, "tile_margin")) { *value = msda::tiled_options().margin; return MSDA_OK; }
     return fail(MSDA_ERR_BAD_OPTION, "unknown option: %s", key ? key : "(null)");
+}
+
+int msda_tiled_plan(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
+                    const int64_t *level_start_host, int *info)
+{
+    if (!shapes_host || !level_start_host || !info) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    if (L < 1 || L > 64) return fail(MSDA_ERR_BAD_DIMS, "bad L=%d", L);
+    const msda::TiledPlan pl = msda::plan_tiled(N, S, M, D, L, Lq, P, shapes_host, level_start_host,
+                                                msda::tiled_options().region_px, msda::tiled_options().margin);
+    info[0] = pl.ok ? 1 : 0;
+    info[1] = pl.g.GY;
+    info[2] = pl.g.GX;
+    info[3] = pl.g.nphases;
+    info[4] = (int)pl.lds_bytes;
+    info[5] = pl.grid;
+    info[6] = pl.g.margin;
+    info[7] = 0;
+    if (pl.ok) {   // largest number of queries any region holds
+        for (int gy = 0; gy < pl.g.GY; ++gy)
+            for (int gx = 0; gx < pl.g.GX; ++gx) {
+                int nq = 0;
+                for (int l = 0; l < L; ++l) {
+                    const msda::LevelRect r = msda::level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin);
+                    nq += r.qnr * r.qnc;
+                }
+                info[7] = nq > info[7] ? nq : info[7];
+            }
+    }
+    return MSDA_OK;
+}
+
+int msda_debug_stamps(void *device_buffer)
+{
+    msda::tiled_options().stamps = static_cast<unsigned long long *>(device_buffer);
+    return MSDA_OK;
 }
 
 int msda_profile_enable(int capacity)

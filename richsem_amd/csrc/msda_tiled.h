@@ -1,15 +1,687 @@
-// msda_tiled.h -- LDS-window MSDeformAttn kernels for gfx950 (encoder-shaped calls, D = 32).
-// Placeholder: the tiled kernels are not enabled yet; the direct kernels serve every call.
+// msda_tiled.h -- LDS-window MSDeformAttn kernels for gfx950, for encoder-shaped calls
+// (queries = the pixels of the pyramid, Lq == S; D = 32 fp32; L <= 4): the shape that carries
+// >95 % of the path's bytes (call "E").
+//
+// Why: in an encoder call every query samples around its own position, at every level.  The direct
+// kernels fetch each of the 64 bilinear corners of a (query, head) from L2 (2.9 GB of 128-B row
+// requests per call, L2-rate bound at ~180 us) and add each corner's gradient with a global float
+// atomic (2.9 GB of atomics, chip-rate bound at ~2.3 ms).  Here a workgroup owns ONE image REGION
+// of ONE (image, head) pair:
+//   * its queries are the pixels of every level whose centre falls in the region (~16x16 level-0
+//     pixels -> ~340 queries), so they share their sampling neighbourhoods;
+//   * per level it stages the window (region footprint +- margin) of the value slice in LDS --
+//     128 B per pixel, filled with whole-row 16-B loads -- and gathers the corners from LDS;
+//   * backward accumulates grad_value into an LDS window with LDS float atomics and flushes each
+//     touched pixel ONCE per region with a 128-B-row global atomic, instead of once per corner.
+// The window is only a cache: every corner is tested against it and corners outside (large learned
+// offsets, samples near the map border) fall back to global loads / global atomics, so results
+// are exact for ARBITRARY sampling locations; only speed depends on locality.
+// The query <-> region assignment is pure geometry on the level sizes; it needs the call to be
+// encoder-shaped only to be profitable, never to be correct.
+//
+// Semantics: identical to msda_direct.h (spec: reference ms_deform_im2col_cuda.cuh:33-159, 237-403).
 #pragma once
 
 #include "msda_common.h"
 
 namespace msda {
 
+constexpr int kTL = 4;               // levels supported by the tiled kernels
+constexpr int kTiledThreads = 1024;  // 16 waves, one workgroup per CU (the LDS window is the limiter)
+constexpr int kTD = 32;              // channels per head
+constexpr int kGatherQPG = 4;        // queries per 8-lane group   (128 groups -> <= 512 queries per region)
+constexpr int kGatherBatch = 2;      // queries whose operand loads are issued together
+constexpr int kMaxRegionQueries = 512;
+constexpr int kSD = 16;              // channels per scatter workgroup (two workgroups per region: channel halves)
+constexpr int kScatterGroups = kTiledThreads / kSD;   // 16-lane groups, one query each
+// LDS per workgroup (160 KiB): header + windows (128 B per pixel: 32 x f32 when gathering, 16 x f64 when
+// accumulating) + the scatter kernel's per-group sampling-point records
+constexpr int kLdsBudgetBytes = 124 * 1024;
+
+struct TiledGeom {
+    int N, S, M, Lq, L, P;
+    int GY, GX;            // region grid over the normalised image plane
+    int margin;            // window margin, in pixels of the sampled level
+    int H[kTL], W[kTL], start[kTL];
+    int phase[kTL];        // levels are processed in phases; the windows of one phase share the LDS
+    int nphases;
+    unsigned long long *stamps;   // diagnostic builds of a run only: per-workgroup s_memtime stamps (16 per workgroup), or null
+    int dbg;               // timing experiments only (results become wrong): 1 = plain LDS add instead of atomic,
+                           // 2 = no flush, 4 = no global fallback atomics, 8 = no LDS accumulation at all
+};
+
+// ---- region geometry (host and device) --------------------------------------------------------------
+// Level-l pixel row r belongs to region row gy iff its centre (r+0.5)/H lies in [gy/GY, (gy+1)/GY):
+// first row of region gy:
+__host__ __device__ inline int region_first(int H, int gy, int GY) { return (2 * H * gy + GY - 1) / (2 * GY); }
+
+__host__ __device__ inline int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+struct LevelRect {
+    int qr0, qc0, qnr, qnc;   // queries of this level inside the region
+    int wr0, wc0, nwr, nwc;   // window (inclusive origin, size) of this level
+};
+
+__host__ __device__ inline LevelRect level_rect(int H, int W, int gy, int gx, int GY, int GX, int margin)
+{
+    LevelRect r;
+    r.qr0 = region_first(H, gy, GY);
+    r.qnr = region_first(H, gy + 1, GY) - r.qr0;
+    r.qc0 = region_first(W, gx, GX);
+    r.qnc = region_first(W, gx + 1, GX) - r.qc0;
+    // reference positions of the region, in level pixel coordinates: [g*H/G - 0.5, (g+1)*H/G - 0.5)
+    int lo = floor_div(2 * gy * H - GY, 2 * GY) - margin;
+    int hi = floor_div(2 * (gy + 1) * H - GY, 2 * GY) + 1 + margin;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > H - 1 ? H - 1 : hi;
+    r.wr0 = lo;
+    r.nwr = hi - lo + 1;
+    lo = floor_div(2 * gx * W - GX, 2 * GX) - margin;
+    hi = floor_div(2 * (gx + 1) * W - GX, 2 * GX) + 1 + margin;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > W - 1 ? W - 1 : hi;
+    r.wc0 = lo;
+    r.nwc = hi - lo + 1;
+    return r;
+}
+
+// Per-workgroup header at the start of LDS: the region's geometry and its query list.  Kept in LDS (not in
+// registers) so that the level loop can stay a run-time loop; fields are re-read as wave-uniform scalars.
+struct TileHeader {
+    LevelRect r[kTL];
+    int qpre[kTL + 1];   // prefix sums of the per-level query counts
+    int lds_px[kTL];     // first LDS pixel of the level's window inside its phase
+    int H[kTL], W[kTL], start[kTL], phase[kTL];
+    int pad[3];
+    int qid[kMaxRegionQueries];   // global query index of the region's i-th query
+};
+static_assert(sizeof(TileHeader) % 16 == 0, "windows must stay 16-byte aligned behind the header");
+
+struct TiledOptions {
+    int region_px = 16;
+    int margin = 6;
+    int dbg = 0;
+    unsigned long long *stamps = nullptr;
+};
+inline TiledOptions &tiled_options()
+{
+    static TiledOptions o;
+    return o;
+}
+
+// ---- host planner ------------------------------------------------------------------------------------
+struct TiledPlan {
+    bool ok = false;
+    TiledGeom g{};
+    size_t lds_bytes = 0;
+    int grid = 0;
+};
+
+inline TiledPlan plan_tiled(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi,
+                            int region_px, int margin)
+{
+    TiledPlan pl;
+    if (D != kTD || L > kTL || L < 1 || Lq != S || P < 1 || L * P > 16) return pl;
+    int64_t pre = 0;
+    for (int l = 0; l < L; ++l) {   // queries must be exactly the pixels: levels tile [0,S) in order
+        if (lsi[l] != pre) return pl;
+        pre += shapes[2 * l] * shapes[2 * l + 1];
+    }
+    if (pre != S) return pl;
+    TiledGeom &g = pl.g;
+    g.N = N; g.S = S; g.M = M; g.Lq = Lq; g.L = L; g.P = P;
+    g.margin = margin;
+    g.dbg = tiled_options().dbg;
+    g.stamps = tiled_options().stamps;
+    int Hmax = 0, Wmax = 0;
+    for (int l = 0; l < L; ++l) {
+        g.H[l] = (int)shapes[2 * l];
+        g.W[l] = (int)shapes[2 * l + 1];
+        g.start[l] = (int)lsi[l];
+        Hmax = g.H[l] > Hmax ? g.H[l] : Hmax;
+        Wmax = g.W[l] > Wmax ? g.W[l] : Wmax;
+    }
+    const int cap_px = kLdsBudgetBytes / (kTD * (int)sizeof(float));
+    // region grid: ~region_px pixels of the finest level per side; refine until queries and windows fit
+    for (int rp = region_px; rp >= 4; rp -= 2) {
+        g.GY = (Hmax + rp - 1) / rp;
+        g.GX = (Wmax + rp - 1) / rp;
+        int max_q = 0, max_win[kTL] = {0, 0, 0, 0};
+        for (int gy = 0; gy < g.GY; ++gy)
+            for (int gx = 0; gx < g.GX; ++gx) {
+                int nq = 0;
+                for (int l = 0; l < L; ++l) {
+                    const LevelRect r = level_rect(g.H[l], g.W[l], gy, gx, g.GY, g.GX, margin);
+                    nq += r.qnr * r.qnc;
+                    const int w = r.nwr * r.nwc;
+                    max_win[l] = w > max_win[l] ? w : max_win[l];
+                }
+                max_q = nq > max_q ? nq : max_q;
+            }
+        bool fits = max_q <= kMaxRegionQueries;
+        for (int l = 0; l < L; ++l) fits = fits && max_win[l] <= cap_px;
+        if (!fits) continue;
+        // greedy phases: consecutive levels share the LDS while their worst-case windows fit together
+        int ph = 0, used = 0, max_phase_px = 0;
+        for (int l = 0; l < L; ++l) {
+            if (used + max_win[l] > cap_px) { ++ph; used = 0; }
+            g.phase[l] = ph;
+            used += max_win[l];
+            max_phase_px = used > max_phase_px ? used : max_phase_px;
+        }
+        for (int l = L; l < kTL; ++l) { g.phase[l] = -1; g.H[l] = g.W[l] = 1; g.start[l] = 0; }
+        g.nphases = ph + 1;
+        pl.lds_bytes = sizeof(TileHeader) + (size_t)max_phase_px * kTD * sizeof(float);
+        pl.grid = kXcds * ((N * M + kXcds - 1) / kXcds) * g.GY * g.GX;
+        pl.ok = true;
+        return pl;
+    }
+    return pl;
+}
+
+// ---- device helpers -------------------------------------------------------------------------------------
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Diagnostic only (g.stamps is null in normal runs): slot i of this workgroup's stamp row <- shader clock.
+template <int KERNEL>   // 1 = scatter, 2 = gather; dbg bits 4..5 select one kernel (0 = all)
+__device__ __forceinline__ void stamp(const TiledGeom &g, int i)
+{
+    if (g.stamps && threadIdx.x == 0 && (((g.dbg >> 4) & 3) == 0 || ((g.dbg >> 4) & 3) == KERNEL)) {
+        const unsigned long long wg = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + (unsigned long long)gridDim.y * blockIdx.z);
+        g.stamps[wg * 16 + i] = __builtin_amdgcn_s_memtime();
+    }
+}
+
+// Builds the header (all threads of the workgroup must call it).  Returns the number of queries.
+__device__ __forceinline__ int build_header(TileHeader *h, const TiledGeom &g, int gy, int gx)
+{
+    const int l = threadIdx.x;
+    if (l < kTL) {   // one lane per level: the integer divisions of level_rect run side by side
+        int H = 1, W = 1, st = 0, ph = -1;
+#pragma unroll
+        for (int i = 0; i < kTL; ++i)
+            if (i == l) { H = g.H[i]; W = g.W[i]; st = g.start[i]; ph = g.phase[i]; }
+        LevelRect r = LevelRect{0, 0, 0, 1, 0, 0, 0, 1};
+        if (l < g.L) r = level_rect(H, W, gy, gx, g.GY, g.GX, g.margin);
+        h->r[l] = r;
+        h->H[l] = H;
+        h->W[l] = W;
+        h->start[l] = st;
+        h->phase[l] = l < g.L ? ph : -1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        h->qpre[0] = 0;
+        int used = 0, cur = 0;
+        for (int i = 0; i < kTL; ++i) {
+            h->qpre[i + 1] = h->qpre[i] + (i < g.L ? h->r[i].qnr * h->r[i].qnc : 0);
+            if (i < g.L && h->phase[i] != cur) { cur = h->phase[i]; used = 0; }
+            h->lds_px[i] = used;
+            if (i < g.L) used += h->r[i].nwr * h->r[i].nwc;
+        }
+    }
+    __syncthreads();
+    const int nq = h->qpre[kTL];
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) {   // level-major, row-major inside the level
+        int q = -1;
+        for (int lv = 0; lv < kTL; ++lv) {
+            if (i >= h->qpre[lv] && i < h->qpre[lv + 1]) {
+                const int k = i - h->qpre[lv];
+                const int qnc = h->r[lv].qnc;
+                const int rr = k / qnc, cc = k - rr * qnc;
+                q = h->start[lv] + (h->r[lv].qr0 + rr) * h->W[lv] + h->r[lv].qc0 + cc;
+            }
+        }
+        h->qid[i] = q;
+    }
+    __syncthreads();
+    return uni(nq);
+}
+
+// DPP quad broadcast: every lane of a quad receives the value held by lane `SRC` of its quad.
+template <int SRC>
+__device__ __forceinline__ int quad_bcast_i(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, SRC | (SRC << 2) | (SRC << 4) | (SRC << 6), 0xF, 0xF, true);
+}
+template <int SRC>
+__device__ __forceinline__ float quad_bcast_f(float v)
+{
+    return __int_as_float(quad_bcast_i<SRC>(__float_as_int(v)));
+}
+
+// Wave-uniform description of one sampled level inside the current region.
+struct LevelCtx {
+    int H, W, wr0, wc0, nwr, nwc, lds_base /* float index of the window */, base_row /* element offset of value[b, start, m, 0] */;
+};
+
+// ---- forward, and the location / attention gradients of backward ------------------------------------------
+// 8 lanes x 4 channels per query; lane i of each quad resolves sampling point pc+i and the quad shares it by
+// DPP broadcast.  BWD = false: out.  BWD = true: grad_loc, grad_attn (grad_value is the scatter kernel's job).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Sum over the 8 lanes of a query with DPP only (no LDS crossbar): quad butterflies, then the other quad of the
+// 8-lane half-row through row_half_mirror (every lane of a quad already holds the quad's sum).
+__device__ __forceinline__ float group8_sum(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    return v;
+}
+
+// The four corner rows of one sampling point for this lane's 4 channels.
+//   mode >= 0: all corners valid and inside the window (LDS float index of corner (h_low, w_low))
+//   mode = -2: general point: corners fetched from global memory, zero outside the map
+__device__ __forceinline__ void load_corners(const float *__restrict__ value, const float *win, const LevelCtx &lc,
+                                             int row_elems, int j, int mode, float px_, float py_, float4 &v1, float4 &v2,
+                                             float4 &v3, float4 &v4)
+{
+    if (mode >= 0) {
+        const float *p = win + mode + 4 * j;
+        v1 = *reinterpret_cast<const float4 *>(p);
+        v2 = *reinterpret_cast<const float4 *>(p + kTD);
+        v3 = *reinterpret_cast<const float4 *>(p + lc.nwc * kTD);
+        v4 = *reinterpret_cast<const float4 *>(p + lc.nwc * kTD + kTD);
+    } else {
+        int o[4];
+        float lh2, lw2;
+        resolve_point<float>(px_, py_, lc.H, lc.W, lc.base_row, row_elems, o, lh2, lw2);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        v1 = o[0] >= 0 ? *reinterpret_cast<const float4 *>(value + o[0] + 4 * j) : z;
+        v2 = o[1] >= 0 ? *reinterpret_cast<const float4 *>(value + o[1] + 4 * j) : z;
+        v3 = o[2] >= 0 ? *reinterpret_cast<const float4 *>(value + o[2] + 4 * j) : z;
+        v4 = o[3] >= 0 ? *reinterpret_cast<const float4 *>(value + o[3] + 4 * j) : z;
+    }
+}
+
+// Forward: acc += sum_k wk * vk  (wk already holds bilinear weight x attention weight), packed two channels wide.
+__device__ __forceinline__ void fwd_point(const float *__restrict__ value, const float *win, const LevelCtx &lc,
+                                          int row_elems, int j, int mode, float w1, float w2, float w3, float w4,
+                                          float px_, float py_, v2f &acc_lo, v2f &acc_hi)
+{
+    if (mode == -1) return;
+    float4 v1, v2, v3, v4;
+    load_corners(value, win, lc, row_elems, j, mode, px_, py_, v1, v2, v3, v4);
+    acc_lo += w1 * (v2f){v1.x, v1.y} + w2 * (v2f){v2.x, v2.y} + w3 * (v2f){v3.x, v3.y} + w4 * (v2f){v4.x, v4.y};
+    acc_hi += w1 * (v2f){v1.z, v1.w} + w2 * (v2f){v2.z, v2.w} + w3 * (v2f){v3.z, v3.w} + w4 * (v2f){v4.z, v4.w};
+}
+
+// Backward (location / attention gradients) of one point; gq = grad_out of the query for this lane's channels.
+__device__ __forceinline__ void bwd_point(const float *__restrict__ value, const float *win, const LevelCtx &lc,
+                                          int row_elems, int j, int mode, float lh, float lw, float pa, float px_,
+                                          float py_, const float4 &gq, float *__restrict__ grad_loc_pt,
+                                          float *__restrict__ grad_aw_pt)
+{
+    float s_a = 0.f, s_w = 0.f, s_h = 0.f;
+    if (mode != -1) {
+        float4 v1, v2, v3, v4;
+        load_corners(value, win, lc, row_elems, j, mode, px_, py_, v1, v2, v3, v4);
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        // per channel: d/dlw of the bilinear value = hh*(v2-v1) + lh*(v4-v3); d/dlh = hw*(v3-v1) + lw*(v4-v2);
+        // the value itself = v1 + lw*(v2-v1) + lh*((v3-v1) + lw*((v4-v3)-(v2-v1)))
+        const v2f gl = {gq.x, gq.y}, gh = {gq.z, gq.w};
+        const v2f a1 = {v1.x, v1.y}, a2 = {v2.x, v2.y}, a3 = {v3.x, v3.y}, a4 = {v4.x, v4.y};
+        const v2f b1 = {v1.z, v1.w}, b2 = {v2.z, v2.w}, b3 = {v3.z, v3.w}, b4 = {v4.z, v4.w};
+        const v2f dwa = hh * (a2 - a1) + lh * (a4 - a3), dwb = hh * (b2 - b1) + lh * (b4 - b3);
+        const v2f dha = hw * (a3 - a1) + lw * (a4 - a2), dhb = hw * (b3 - b1) + lw * (b4 - b2);
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        const v2f va = w1 * a1 + w2 * a2 + w3 * a3 + w4 * a4, vb = w1 * b1 + w2 * b2 + w3 * b3 + w4 * b4;
+        const v2f ta = gl * va + gh * vb, tw = gl * dwa + gh * dwb, th = gl * dha + gh * dhb;
+        s_a = ta.x + ta.y;
+        s_w = tw.x + tw.y;
+        s_h = th.x + th.y;
+    }
+    // uniform over the 8 lanes of the query (mode is), so the DPP partners are always active
+    s_a = group8_sum(s_a);
+    s_w = group8_sum(s_w);
+    s_h = group8_sum(s_h);
+    if (j == 0) {
+        *grad_aw_pt = s_a;
+        *reinterpret_cast<float2 *>(grad_loc_pt) = make_float2((float)lc.W * s_w * pa, (float)lc.H * s_h * pa);
+    }
+}
+
+// One sampled level for the kGatherQPG queries of an 8-lane group.  The operand loads of kGatherBatch queries are
+// issued before any of them is used (queries without a slot read a valid address and are masked by mode = -1).
+template <bool BWD>
+__device__ __forceinline__ void gather_level(const float *__restrict__ value, const float *__restrict__ loc,
+                                             const float *__restrict__ aw, const float *win, const LevelCtx &lc,
+                                             int row_elems, int P, int j, const unsigned (&pt0)[kGatherQPG],
+                                             const bool (&live)[kGatherQPG], v2f (&acc_lo)[kGatherQPG],
+                                             v2f (&acc_hi)[kGatherQPG], const float *__restrict__ grad_out,
+                                             const unsigned (&item)[kGatherQPG], float *__restrict__ grad_loc,
+                                             float *__restrict__ grad_aw)
+{
+    for (int pc = 0; pc < P; pc += 4) {
+        const int myp = pc + (j & 3);
+        const bool pv = myp < P;
+        const unsigned mp = pv ? myp : 0;
+#pragma unroll
+        for (int k0 = 0; k0 < kGatherQPG; k0 += kGatherBatch) {
+            float2 xy[kGatherBatch];
+            float a[kGatherBatch];
+            float4 gq[kGatherBatch];   // backward: grad_out of the query (re-read per level: L2-resident, saves registers)
+#pragma unroll
+            for (int u = 0; u < kGatherBatch; ++u) {
+                xy[u] = *reinterpret_cast<const float2 *>(loc + 2u * (pt0[k0 + u] + mp));
+                a[u] = aw[pt0[k0 + u] + mp];
+                if (BWD) gq[u] = *reinterpret_cast<const float4 *>(grad_out + item[k0 + u] * (unsigned)kTD + 4u * j);
+            }
+#pragma unroll
+            for (int u = 0; u < kGatherBatch; ++u) {
+                const int k = k0 + u;
+                int mode = -1;
+                float lh = 0.f, lw = 0.f;
+                const float h_im = xy[u].y * (float)lc.H - 0.5f, w_im = xy[u].x * (float)lc.W - 0.5f;
+                if (pv && live[k] && h_im > -1.f && w_im > -1.f && h_im < (float)lc.H && w_im < (float)lc.W) {
+                    const float hf = floorf(h_im), wf = floorf(w_im);
+                    lh = h_im - hf;
+                    lw = w_im - wf;
+                    const int rr = (int)hf - lc.wr0, cc = (int)wf - lc.wc0;
+                    // inside the window implies inside the map: the window is clamped to the map
+                    const bool inside = rr >= 0 && rr + 1 < lc.nwr && cc >= 0 && cc + 1 < lc.nwc;
+                    mode = inside ? lc.lds_base + (rr * lc.nwc + cc) * kTD : -2;
+                }
+                if (!live[k]) continue;   // uniform over the 8-lane group
+                if (!BWD) {
+                    const float hh = 1.f - lh, hw = 1.f - lw;
+                    const float w1 = hh * hw * a[u], w2 = hh * lw * a[u], w3 = lh * hw * a[u], w4 = lh * lw * a[u];
+#define MSDA_FWD_ONE(I)                                                                                               \
+    if (pc + I < P)                                                                                                    \
+        fwd_point(value, win, lc, row_elems, j, quad_bcast_i<I>(mode), quad_bcast_f<I>(w1), quad_bcast_f<I>(w2),     \
+                  quad_bcast_f<I>(w3), quad_bcast_f<I>(w4), quad_bcast_f<I>(xy[u].x), quad_bcast_f<I>(xy[u].y),      \
+                  acc_lo[k], acc_hi[k]);
+                    MSDA_FWD_ONE(0)
+                    MSDA_FWD_ONE(1)
+                    MSDA_FWD_ONE(2)
+                    MSDA_FWD_ONE(3)
+#undef MSDA_FWD_ONE
+                } else {
+#define MSDA_BWD_ONE(I)                                                                                               \
+    if (pc + I < P)                                                                                                    \
+        bwd_point(value, win, lc, row_elems, j, quad_bcast_i<I>(mode), quad_bcast_f<I>(lh), quad_bcast_f<I>(lw),     \
+                  quad_bcast_f<I>(a[u]), quad_bcast_f<I>(xy[u].x), quad_bcast_f<I>(xy[u].y), gq[u],                   \
+                  grad_loc + 2u * (pt0[k] + pc + I), grad_aw + pt0[k] + pc + I);
+                    MSDA_BWD_ONE(0)
+                    MSDA_BWD_ONE(1)
+                    MSDA_BWD_ONE(2)
+                    MSDA_BWD_ONE(3)
+#undef MSDA_BWD_ONE
+                }
+            }
+        }
+    }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(kTiledThreads) void tiled_gather_kernel(
+    const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ aw,
+    const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
+    float *__restrict__ grad_aw, const TiledGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TileHeader *hdr = reinterpret_cast<TileHeader *>(smem);
+    float *win = reinterpret_cast<float *>(smem + sizeof(TileHeader));
+
+    int pair, region;
+    if (!decode_block(blockIdx.x, g.N * g.M, g.GY * g.GX, pair, region)) return;
+    const int b = pair / g.M, m = pair - b * g.M;
+    const int gy = region / g.GX, gx = region - gy * g.GX;
+    stamp<2>(g, 0);
+    const int nq = build_header(hdr, g, gy, gx);
+    stamp<2>(g, 1);
+
+    const int tid = threadIdx.x;
+    const int j = tid & 7, grp = tid >> 3;
+    constexpr int ngroups = kTiledThreads / 8;
+    const int row_elems = g.M * kTD;
+    const int LP = g.L * g.P;
+
+    bool live[kGatherQPG];
+    unsigned item[kGatherQPG];            // (b*Lq + q)*M + m; every element offset derived from it fits 32 bits (host-checked)
+    v2f acc_lo[kGatherQPG], acc_hi[kGatherQPG];   // forward: output accumulators of the group's queries
+#pragma unroll
+    for (int k = 0; k < kGatherQPG; ++k) {
+        const int i = grp + k * ngroups;
+        live[k] = i < nq;
+        item[k] = (unsigned)((b * g.Lq + hdr->qid[live[k] ? i : 0]) * g.M + m);
+        acc_lo[k] = acc_hi[k] = (v2f){0.f, 0.f};
+    }
+
+    // forward accumulates over the phases in registers; backward writes per-point results, so there the phases of a
+    // region are independent workgroups (blockIdx.y)
+    const int ph_begin = BWD ? (int)blockIdx.y : 0, ph_end = BWD ? ph_begin + 1 : g.nphases;
+    for (int ph = ph_begin; ph < ph_end; ++ph) {
+        // ---- stage this phase's windows: whole 128-B pixel rows, 16 B per lane -------------------------------
+        for (int l = 0; l < g.L; ++l) {
+            if (uni(hdr->phase[l]) != ph) continue;
+            const int wr0 = uni(hdr->r[l].wr0), wc0 = uni(hdr->r[l].wc0), nwc = uni(hdr->r[l].nwc);
+            const int npx = uni(hdr->r[l].nwr) * nwc, Wl = uni(hdr->W[l]);
+            const float *src = value + ((int64_t)(b * g.S + uni(hdr->start[l])) * g.M + m) * kTD + 4 * j;
+            float *dst = win + (int64_t)uni(hdr->lds_px[l]) * kTD + 4 * j;
+            // eight independent row loads in flight per lane before the first LDS store
+            for (int px0 = grp; px0 < npx; px0 += 8 * ngroups) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int px = min(px0 + u * ngroups, npx - 1);   // clamped: always a valid row, stored only if in range
+                    const int rr = px / nwc, cc = px - rr * nwc;
+                    v[u] = *reinterpret_cast<const float4 *>(src + (int64_t)((wr0 + rr) * Wl + wc0 + cc) * row_elems);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int px = px0 + u * ngroups;
+                    if (px < npx) *reinterpret_cast<float4 *>(dst + px * kTD) = v[u];
+                }
+            }
+        }
+        __syncthreads();
+        stamp<2>(g, 2 + 2 * (ph - ph_begin));
+
+        // ---- gather -------------------------------------------------------------------------------------
+        for (int l = 0; l < g.L; ++l) {
+            if (uni(hdr->phase[l]) != ph) continue;
+            LevelCtx lc;
+            lc.H = uni(hdr->H[l]);
+            lc.W = uni(hdr->W[l]);
+            lc.wr0 = uni(hdr->r[l].wr0);
+            lc.wc0 = uni(hdr->r[l].wc0);
+            lc.nwr = uni(hdr->r[l].nwr);
+            lc.nwc = uni(hdr->r[l].nwc);
+            lc.lds_base = uni(hdr->lds_px[l]) * kTD;
+            lc.base_row = (b * g.S + uni(hdr->start[l])) * row_elems + m * kTD;
+            unsigned pt0[kGatherQPG];
+#pragma unroll
+            for (int k = 0; k < kGatherQPG; ++k) pt0[k] = item[k] * (unsigned)LP + (unsigned)(l * g.P);
+            gather_level<BWD>(value, loc, aw, win, lc, row_elems, g.P, j, pt0, live, acc_lo, acc_hi, grad_out, item,
+                              grad_loc, grad_aw);
+        }
+        __syncthreads();   // the next phase overwrites the windows
+        stamp<2>(g, 3 + 2 * (ph - ph_begin));
+    }
+
+    if (!BWD) {
+#pragma unroll
+        for (int k = 0; k < kGatherQPG; ++k)
+            if (live[k])
+                *reinterpret_cast<float4 *>(out + item[k] * (unsigned)kTD + 4u * j) =
+                    make_float4(acc_lo[k].x, acc_lo[k].y, acc_hi[k].x, acc_hi[k].y);
+    }
+}
+
+// ---- backward: grad_value ---------------------------------------------------------------------------------
+// gfx950 facts this kernel is built on (measured, tools/lds_atomic_bench.hip): the LDS float atomic ds_add_f32 is
+// serialised (120-190 CU cycles per wave-instruction) while ds_add_f64 is native (about 5), and global float atomics
+// run at ~1.3 TB/s only as whole row segments.  So the window accumulates in f64 (which also makes the in-window sum
+// exact to f32 precision whatever the order), a workgroup takes one CHANNEL HALF of a region (16 channels x 8 B =
+// 128 B per pixel, the same LDS geometry as the gather kernels) and every touched pixel is flushed once.
+// 16 lanes per query: lane j resolves sampling point j (L*P <= 16) and owns channel j of the half; the resolved
+// points are parked in LDS records and replayed to the group as LDS broadcasts.
+struct alignas(16) ScatterRec {
+    int t[4];     // per corner: >= 0 LDS f64 index of (pixel, channel 0); < -1: -(global element offset) - 2; -1: none;
+                  // t[1] = -3: all four corners inside the window, t[0] is the base of corner (h_low, w_low)
+    float w[4];   // bilinear weight x attention weight
+};
+
+__global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
+    const float *__restrict__ loc, const float *__restrict__ aw, const float *__restrict__ grad_out,
+    float *__restrict__ grad_value, const TiledGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TileHeader *hdr = reinterpret_cast<TileHeader *>(smem);
+    ScatterRec *recs = reinterpret_cast<ScatterRec *>(smem + sizeof(TileHeader));
+    double *win = reinterpret_cast<double *>(smem + sizeof(TileHeader) + sizeof(ScatterRec) * kScatterGroups * 16);
+
+    int pair, region;
+    if (!decode_block(blockIdx.x, g.N * g.M, g.GY * g.GX, pair, region)) return;
+    const int half = blockIdx.y;   // channel half; gridDim.x is a multiple of 8, so both halves share the pair's XCD
+    const int b = pair / g.M, m = pair - b * g.M;
+    const int gy = region / g.GX, gx = region - gy * g.GX;
+    stamp<1>(g, 0);
+    const int nq = build_header(hdr, g, gy, gx);
+    stamp<1>(g, 1);
+
+    const int tid = threadIdx.x;
+    const int j = tid & (kSD - 1), grp = tid / kSD;
+    const int row_elems = g.M * kTD;
+    const int LP = g.L * g.P;
+    const int ch0 = m * kTD + half * kSD;   // first channel of this workgroup inside a pixel row
+    ScatterRec *my = recs + grp * 16;
+
+    // this lane's sampling point: level constants (lane-varying, read once)
+    const int lj = j < LP ? j / g.P : 0;
+    const int Hj = hdr->H[lj], Wj = hdr->W[lj];
+    const int wr0 = hdr->r[lj].wr0, wc0 = hdr->r[lj].wc0, nwr = hdr->r[lj].nwr, nwc = hdr->r[lj].nwc;
+    const int ldsj = hdr->lds_px[lj], phj = j < LP ? hdr->phase[lj] : -1;
+    const int basej = (b * g.S + hdr->start[lj]) * row_elems + ch0;
+
+    {
+        const int ph = blockIdx.z;   // one LDS phase per workgroup: the phases of a region are independent here
+        // ---- clear this phase's accumulation windows ---------------------------------------------------------
+        int phase_px = 0;
+        for (int l = 0; l < g.L; ++l)
+            if (uni(hdr->phase[l]) == ph) phase_px = uni(hdr->lds_px[l]) + uni(hdr->r[l].nwr) * uni(hdr->r[l].nwc);
+        for (int i = tid; i < phase_px * (kSD / 2); i += kTiledThreads)
+            reinterpret_cast<double2 *>(win)[i] = make_double2(0.0, 0.0);
+        __syncthreads();
+        stamp<1>(g, 2);
+
+        // ---- accumulate: one query per 16-lane group, next query's operands prefetched --------------------------
+        const int jp = j < LP ? j : 0;
+        float2 n_xy = make_float2(0.f, 0.f);
+        float n_a = 0.f, n_g = 0.f;
+        if (grp < nq) {
+            const int64_t item = (int64_t)(b * g.Lq + hdr->qid[grp]) * g.M + m;
+            n_xy = *reinterpret_cast<const float2 *>(loc + (item * LP + jp) * 2);
+            n_a = aw[item * LP + jp];
+            n_g = grad_out[item * kTD + half * kSD + j];
+        }
+        for (int i = grp; i < nq; i += kScatterGroups) {
+            const float2 xy = n_xy;
+            const float a = n_a, gk = n_g;
+            if (i + kScatterGroups < nq) {
+                const int64_t item = (int64_t)(b * g.Lq + hdr->qid[i + kScatterGroups]) * g.M + m;
+                n_xy = *reinterpret_cast<const float2 *>(loc + (item * LP + jp) * 2);
+                n_a = aw[item * LP + jp];
+                n_g = grad_out[item * kTD + half * kSD + j];
+            }
+            if (phj == ph) {   // resolve my point of this query
+                ScatterRec r;
+                r.t[0] = r.t[1] = r.t[2] = r.t[3] = -1;
+                r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0.f;
+                const float h_im = xy.y * (float)Hj - 0.5f, w_im = xy.x * (float)Wj - 0.5f;
+                if (h_im > -1.f && w_im > -1.f && h_im < (float)Hj && w_im < (float)Wj) {
+                    const float hf = floorf(h_im), wf = floorf(w_im);
+                    const int h_low = (int)hf, w_low = (int)wf;
+                    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+                    r.w[0] = hh * hw * a;
+                    r.w[1] = hh * lw * a;
+                    r.w[2] = lh * hw * a;
+                    r.w[3] = lh * lw * a;
+                    const bool top = h_low >= 0, bot = h_low + 1 <= Hj - 1, lef = w_low >= 0, rig = w_low + 1 <= Wj - 1;
+                    const int rr = h_low - wr0, cc = w_low - wc0;
+                    const bool r0 = rr >= 0 && rr < nwr, r1 = rr + 1 >= 0 && rr + 1 < nwr;
+                    const bool c0 = cc >= 0 && cc < nwc, c1 = cc + 1 >= 0 && cc + 1 < nwc;
+                    const int lbase = (ldsj + rr * nwc + cc) * kSD;
+                    const int gbase = basej + (h_low * Wj + w_low) * row_elems;
+                    if (top && bot && lef && rig && r0 && r1 && c0 && c1) {
+                        r.t[0] = lbase;   // all four corners inside the window: one base, fixed strides
+                        r.t[1] = -3;
+                    } else {
+                        if (top && lef) r.t[0] = (r0 && c0) ? lbase : -gbase - 2;
+                        if (top && rig) r.t[1] = (r0 && c1) ? lbase + kSD : -(gbase + row_elems) - 2;
+                        if (bot && lef) r.t[2] = (r1 && c0) ? lbase + nwc * kSD : -(gbase + Wj * row_elems) - 2;
+                        if (bot && rig) r.t[3] = (r1 && c1) ? lbase + nwc * kSD + kSD : -(gbase + Wj * row_elems + row_elems) - 2;
+                    }
+                }
+                my[j] = r;
+            }
+            __builtin_amdgcn_wave_barrier();   // a group lives inside one wave; same-wave LDS traffic is in order
+            for (int l = 0; l < g.L; ++l) {
+                if (uni(hdr->phase[l]) != ph) continue;
+                const int row2 = uni(hdr->r[l].nwc) * kSD;   // f64 elements between vertically adjacent window pixels
+                for (int p = 0; p < g.P; ++p) {
+                    const ScatterRec r = my[l * g.P + p];
+                    if (r.t[1] == -3) {   // uniform over the 16-lane group
+                        double *p0 = win + r.t[0] + j, *p1 = p0 + row2;
+                        if (!(g.dbg & 8)) {
+                            atomicAdd(p0, (double)(r.w[0] * gk));
+                            atomicAdd(p0 + kSD, (double)(r.w[1] * gk));
+                            atomicAdd(p1, (double)(r.w[2] * gk));
+                            atomicAdd(p1 + kSD, (double)(r.w[3] * gk));
+                        }
+                    } else {
+#pragma unroll
+                        for (int cn = 0; cn < 4; ++cn) {
+                            const int t = r.t[cn];
+                            const float v = r.w[cn] * gk;
+                            if (t >= 0) {
+                                if (!(g.dbg & 8)) atomicAdd(win + t + j, (double)v);
+                            } else if (t < -1) {
+                                if (!(g.dbg & 4)) atomicAdd(grad_value + (-(t + 2)) + j, v);
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        stamp<1>(g, 3);
+
+        // ---- flush: every touched pixel once, 64-B row segments of global float atomics --------------------------------
+        for (int l = 0; l < g.L; ++l) {
+            if (uni(hdr->phase[l]) != ph) continue;
+            const int fr0 = uni(hdr->r[l].wr0), fc0 = uni(hdr->r[l].wc0), fnc = uni(hdr->r[l].nwc);
+            const int npx = uni(hdr->r[l].nwr) * fnc, Wl = uni(hdr->W[l]);
+            float *dst = grad_value + (int64_t)(b * g.S + uni(hdr->start[l])) * row_elems + ch0 + j;
+            const double *src = win + (int64_t)uni(hdr->lds_px[l]) * kSD + j;
+            for (int px = grp; px < npx; px += kScatterGroups) {
+                const float v = (float)src[px * kSD];
+                if (v != 0.f && !(g.dbg & 2)) {
+                    const int rr = px / fnc, cc = px - rr * fnc;
+                    atomicAdd(dst + (int64_t)((fr0 + rr) * Wl + fc0 + cc) * row_elems, v);
+                }
+            }
+        }
+        __syncthreads();
+        stamp<1>(g, 4);
+    }
+}
+
+// ---- host entry points ----------------------------------------------------------------------------------------------
 template <typename T>
 bool tiled_fwd_applicable(int, int, int, int, int, int, int, const int64_t *, const int64_t *, const T *, const T *)
 {
     return false;
+}
+template <>
+inline bool tiled_fwd_applicable<float>(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes,
+                                        const int64_t *lsi, const float *value, const float *out)
+{
+    if ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(out)) & 15) return false;
+    return plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin).ok;
 }
 
 template <typename T>
@@ -18,6 +690,21 @@ bool tiled_bwd_applicable(int, int, int, int, int, int, int, const int64_t *, co
 {
     return false;
 }
+template <>
+inline bool tiled_bwd_applicable<float>(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes,
+                                        const int64_t *lsi, const float *value, const float *grad_out,
+                                        const float *grad_value)
+{
+    if ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(grad_out) |
+         reinterpret_cast<uintptr_t>(grad_value)) & 15)
+        return false;
+    return plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin).ok;
+}
+
+inline hipError_t set_lds_limit(const void *fn, size_t bytes)
+{
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 
 template <typename T>
 hipError_t launch_fwd_tiled(const T *, const int64_t *, const int64_t *, const T *, const T *, T *, int, int, int, int,
@@ -25,12 +712,47 @@ hipError_t launch_fwd_tiled(const T *, const int64_t *, const int64_t *, const T
 {
     return hipErrorNotSupported;
 }
+template <>
+inline hipError_t launch_fwd_tiled<float>(const float *value, const int64_t *, const int64_t *, const float *loc,
+                                          const float *aw, float *out, int N, int S, int M, int D, int L, int Lq, int P,
+                                          const int64_t *shapes_h, const int64_t *lsi_h, hipStream_t stream)
+{
+    const TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes_h, lsi_h, tiled_options().region_px, tiled_options().margin);
+    if (!pl.ok) return hipErrorInvalidValue;
+    hipError_t e = set_lds_limit(reinterpret_cast<const void *>(&tiled_gather_kernel<false>), pl.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tiled_gather_kernel<false>, dim3(pl.grid), dim3(kTiledThreads), pl.lds_bytes, stream, value, loc, aw,
+                       (const float *)nullptr, out, (float *)nullptr, (float *)nullptr, pl.g);
+    return hipGetLastError();
+}
 
 template <typename T>
 hipError_t launch_bwd_tiled(const T *, const int64_t *, const int64_t *, const T *, const T *, const T *, T *, T *, T *,
                             int, int, int, int, int, int, int, const int64_t *, const int64_t *, hipStream_t)
 {
     return hipErrorNotSupported;
+}
+template <>
+inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, const int64_t *, const float *loc,
+                                          const float *aw, const float *grad_out, float *grad_value, float *grad_loc,
+                                          float *grad_aw, int N, int S, int M, int D, int L, int Lq, int P,
+                                          const int64_t *shapes_h, const int64_t *lsi_h, hipStream_t stream)
+{
+    const TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes_h, lsi_h, tiled_options().region_px, tiled_options().margin);
+    if (!pl.ok) return hipErrorInvalidValue;
+    const size_t lds_scatter = pl.lds_bytes + sizeof(ScatterRec) * kScatterGroups * 16;
+    hipError_t e = set_lds_limit(reinterpret_cast<const void *>(&tiled_gather_kernel<true>), pl.lds_bytes);
+    if (e == hipSuccess) e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_kernel), lds_scatter);
+    if (e != hipSuccess) return e;
+    // grad_value (pre-zeroed by the caller of this function): LDS accumulation + one flush per touched pixel
+    hipLaunchKernelGGL(tiled_scatter_kernel, dim3(pl.grid, kTD / kSD, pl.g.nphases), dim3(kTiledThreads), lds_scatter,
+                       stream, loc, aw, grad_out, grad_value, pl.g);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // grad_sampling_loc, grad_attn_weight: gather from LDS windows of value
+    hipLaunchKernelGGL(tiled_gather_kernel<true>, dim3(pl.grid, pl.g.nphases), dim3(kTiledThreads), pl.lds_bytes, stream,
+                       value, loc, aw, grad_out, (float *)nullptr, grad_loc, grad_aw, pl.g);
+    return hipGetLastError();
 }
 
 }  // namespace msda

@@ -89,3 +89,41 @@ def test_make_inputs_is_seeded_and_well_formed():
     assert torch.allclose(a["aw"].sum((-1, -2)), torch.ones(1, call.Lq, 8), atol=1e-5)
     u = W.make_inputs(call, "uniform", seed=3)
     assert 0 <= float(u["loc"].min()) and float(u["loc"].max()) < 1
+
+
+def test_tiled_plan_geometry():
+    """Host-only launch plan of the LDS-window kernels (msda_tiled_plan): applicability and LDS budget."""
+    from richsem_amd import _lib
+    E = W.call_E()
+    sh, lsi = W.level_tensors(E)
+    p = _lib.tiled_plan(E.N, E.S, E.M, E.D, E.L, E.Lq, E.P, sh.tolist(), lsi.tolist())
+    assert p["applicable"] == 1
+    assert p["GY"] * p["GX"] >= 24 and p["max_region_queries"] <= 512
+    assert p["lds_bytes"] <= 160 * 1024 and p["phases"] >= 1
+    assert p["grid"] == 8 * 2 * p["GY"] * p["GX"]          # 16 (image, head) pairs over 8 XCDs
+    Em = W.call_Em()
+    sh, lsi = W.level_tensors(Em)
+    assert _lib.tiled_plan(Em.N, Em.S, Em.M, Em.D, Em.L, Em.Lq, Em.P, sh.tolist(), lsi.tolist())["applicable"] == 1
+    # decoder-shaped (Lq != S), other channel counts, or levels not laid out back to back: direct kernels
+    Dd = W.call_Dd()
+    sh, lsi = W.level_tensors(Dd)
+    assert _lib.tiled_plan(Dd.N, Dd.S, Dd.M, Dd.D, Dd.L, Dd.Lq, Dd.P, sh.tolist(), lsi.tolist())["applicable"] == 0
+    sh, lsi = W.level_tensors(E)
+    assert _lib.tiled_plan(E.N, E.S, E.M, 64, E.L, E.Lq, E.P, sh.tolist(), lsi.tolist())["applicable"] == 0
+    bad = lsi.tolist()
+    bad[1], bad[2] = bad[2], bad[1]
+    assert _lib.tiled_plan(E.N, E.S, E.M, E.D, E.L, E.Lq, E.P, sh.tolist(), bad)["applicable"] == 0
+
+
+def test_region_partition_covers_every_query_once():
+    """The region <-> query assignment of the LDS-window kernels (richsem_amd/csrc/msda_tiled.h, region_first):
+    pixel row r of a level with H rows belongs to region row g iff (2r+1)*G // (2H) == g."""
+    def region_first(H, g, G):
+        return (2 * H * g + G - 1) // (2 * G)
+    for H in (1, 2, 3, 13, 21, 25, 42, 50, 84, 100, 168, 160):
+        for G in (1, 2, 7, 11, 13, 21):
+            owner = [(2 * r + 1) * G // (2 * H) for r in range(H)]
+            for g in range(G):
+                lo, hi = region_first(H, g, G), region_first(H, g + 1, G)
+                assert [r for r in range(H) if owner[r] == g] == list(range(lo, hi))
+            assert region_first(H, 0, G) == 0 and region_first(H, G, G) == H
