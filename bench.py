@@ -53,6 +53,34 @@ def parse_args():
     return ap.parse_args()
 
 
+def shard_batch(tensors, rank, world):
+    """Data-parallel sharding of one call's tensors: rank r owns images [r*n, (r+1)*n) of the global batch; the
+    level geometry is shared.  No data-path collective: images are independent."""
+    n_total = tensors["value"].shape[0]
+    if n_total % world:
+        raise ValueError(f"global batch {n_total} is not divisible by world size {world}")
+    n = n_total // world
+    out = {}
+    for k, v in tensors.items():
+        out[k] = v if k in ("shapes", "lsi") else v[rank * n:(rank + 1) * n].contiguous()
+    return out
+
+
+def reduce_elapsed(elapsed, dist):
+    """Step time of the job = the slowest rank's (MAX all-reduce); `dist` is torch.distributed or None."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return elapsed
+    import torch as _t
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = _t.tensor([elapsed], dtype=_t.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def total_images(images_per_gpu, world):
+    return images_per_gpu * world
+
+
 def cpu_baseline(calls, loc_mode, n_images):
     """Oracle timed on the host: one forward+backward of each distinct call, scaled by its repetitions."""
     from oracle import msda_oracle as O
@@ -136,14 +164,11 @@ def main():
     records = _lib.profile_collect()
     _lib.profile_enable(0)
 
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = reduce_elapsed(elapsed, dist)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        total_images = n_img * world
+        n_total = total_images(n_img, world)
         # per-kernel statistics from the library's event log (this rank)
         by = {}
         for r in records:
@@ -153,17 +178,19 @@ def main():
             call = next(c for c, _ in calls if c.Lq == Lq)
             nbytes = call.bytes_bwd() if kind == "bwd" else call.bytes_fwd()
             avg = sum(ms) / len(ms)
-            kernels.append({"kernel": f"msda_{kind}_{'direct' if variant == 1 else 'tiled'}[{call.name}]",
+            hip = {("fwd", 1): "fwd_direct_kernel", ("bwd", 1): "bwd_direct_kernel", ("fwd", 2): "tiled_gather_kernel<false>",
+                   ("bwd", 2): "tiled_scatter_kernel + tiled_gather_kernel<true>"}[(kind, variant)]
+            kernels.append({"kernel": f"msda_{kind}_{'direct' if variant == 1 else 'tiled'}[{call.name}]", "hip_kernels": hip,
                             "launches": len(ms), "avg_us": round(avg * 1e3, 2), "total_ms": round(sum(ms), 3),
                             "alg_bytes": nbytes, "GBps": round(nbytes / (avg * 1e-3) / 1e9, 1)})
         dom = max(kernels, key=lambda k: k["total_ms"])
-        roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": dom["kernel"], "hip_kernels": dom["hip_kernels"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
                     "alg_bytes_per_launch": dom["alg_bytes"], "avg_launch_us": dom["avg_us"]}
         line = {
             "metric": "training images/sec, RichSem R50 4-scale 1333x800 (MSDeformAttn hot path: 12 fwd + 12 bwd "
                       "calls per step)",
-            "value": round(total_images / (elapsed / args.steps), 3), "unit": "img/s",
+            "value": round(n_total / (elapsed / args.steps), 3), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: R50 4-scale 800x1344 (S=22323), bs={n_img}/GPU, M=8 D=32 L=P=4; "

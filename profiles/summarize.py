@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 CSVs collected by tools/collect_profiles.sh into the committed summary profiles/<tag>_summary.md.
+
+    python profiles/summarize.py gpurun_out/r01 r01
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def kernel_stats(d):
+    f = glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv"))
+    rows = list(csv.DictReader(open(f[0]))) if f else []
+    return [(r["Name"], int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, float(r["Percentage"]))
+            for r in rows]
+
+
+def per_grid(d):
+    """Average duration per (kernel, grid size): separates the E and Dd launches of the direct kernels."""
+    f = glob.glob(os.path.join(d, "trace", "*", "*_kernel_trace.csv"))
+    acc = collections.defaultdict(list)
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            name = r["Kernel_Name"].split("(")[0]
+            grid = (r.get("Grid_Size_X") or r.get("Grid_Size") or "?", r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""))
+            acc[(name, grid)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return acc
+
+
+def pmc(d, sub, counter):
+    f = glob.glob(os.path.join(d, sub, "*", "*_counter_collection.csv"))
+    acc = collections.defaultdict(list)
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            if r["Counter_Name"] == counter:
+                acc[(r["Kernel_Name"].split("(")[0], r["Grid_Size"])].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    d, tag = sys.argv[1], sys.argv[2]
+    out = [f"# rocprofv3 summary {tag}", ""]
+    try:
+        line = json.loads(open(os.path.join(d, "bench.json")).read().strip().splitlines()[-1])
+        out += ["## bench.py line (un-profiled run)", "", "```json", json.dumps(line, indent=1), "```", ""]
+    except Exception as e:  # pragma: no cover
+        out += [f"(no bench line: {e})", ""]
+    out += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline`", "",
+            "| kernel | calls | avg µs | total ms | % |", "|---|---|---|---|---|"]
+    for name, calls, avg, tot, pct in kernel_stats(d):
+        out.append(f"| `{name[:90]}` | {calls} | {avg:.1f} | {tot:.2f} | {pct:.1f} |")
+    out += ["", "### per (kernel, grid): E and Dd launches of the same kernel separated", "",
+            "| kernel | grid (threads) | launches | avg µs |", "|---|---|---|---|"]
+    for (name, grid), v in sorted(per_grid(d).items()):
+        out.append(f"| `{name[:70]}` | {'x'.join(g for g in grid if g)} | {len(v)} | {sum(v) / len(v):.1f} |")
+    fetch, write = pmc(d, "pmc_fetch", "FETCH_SIZE"), pmc(d, "pmc_write", "WRITE_SIZE")
+    out += ["", "## HBM traffic per launch (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes)", "",
+            "FETCH_SIZE / WRITE_SIZE are in KiB. Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950",
+            "reports half the bytes of a wide coalesced stream, so the read side is doubled below; WRITE_SIZE is exact for",
+            "16-B-per-lane stores and float atomics. Other access widths are uncalibrated, so treat the sum as an estimate.", "",
+            "| kernel | grid | FETCH_SIZE KiB | WRITE_SIZE KiB | est. HBM MB = (2·fetch + write)·1024/1e6 |", "|---|---|---|---|---|"]
+    for key in sorted(set(fetch) | set(write)):
+        f = sum(fetch.get(key, [0])) / max(1, len(fetch.get(key, [0])))
+        w = sum(write.get(key, [0])) / max(1, len(write.get(key, [0])))
+        out.append(f"| `{key[0][:60]}` | {key[1]} | {f:.0f} | {w:.0f} | {(2 * f + w) * 1024 / 1e6:.1f} |")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{tag}_summary.md")
+    open(path, "w").write("\n".join(out) + "\n")
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()

@@ -30,8 +30,8 @@ constexpr int kTL = 4;               // levels supported by the tiled kernels
 constexpr int kTiledThreads = 1024;  // 16 waves, one workgroup per CU (the LDS window is the limiter)
 constexpr int kTD = 32;              // channels per head
 constexpr int kGatherQPG = 4;        // queries per 8-lane group   (128 groups -> <= 512 queries per region)
-constexpr int kGatherBatch = 2;      // queries whose operand loads are issued together
 constexpr int kMaxRegionQueries = 512;
+constexpr int kMaxGrid = 24;         // region rows / columns covered by the host-made geometry tables
 constexpr int kSD = 16;              // channels per scatter workgroup (two workgroups per region: channel halves)
 constexpr int kScatterGroups = kTiledThreads / kSD;   // 16-lane groups, one query each
 // LDS per workgroup (160 KiB): header + windows (128 B per pixel: 32 x f32 when gathering, 16 x f64 when
@@ -45,6 +45,10 @@ struct TiledGeom {
     int H[kTL], W[kTL], start[kTL];
     int phase[kTL];        // levels are processed in phases; the windows of one phase share the LDS
     int nphases;
+    // per level and region row / column, precomputed on the host (level_rect): first query row, window origin, window
+    // extent -- the workgroup's header is table look-ups instead of ~30 integer divisions
+    short rq0[kTL][kMaxGrid + 1], rw0[kTL][kMaxGrid], rwn[kTL][kMaxGrid];
+    short cq0[kTL][kMaxGrid + 1], cw0[kTL][kMaxGrid], cwn[kTL][kMaxGrid];
     unsigned long long *stamps;   // diagnostic builds of a run only: per-workgroup s_memtime stamps (16 per workgroup), or null
     int dbg;               // timing experiments only (results become wrong): 1 = plain LDS add instead of atomic,
                            // 2 = no flush, 4 = no global fallback atomics, 8 = no LDS accumulation at all
@@ -146,6 +150,7 @@ inline TiledPlan plan_tiled(int N, int S, int M, int D, int L, int Lq, int P, co
     for (int rp = region_px; rp >= 4; rp -= 2) {
         g.GY = (Hmax + rp - 1) / rp;
         g.GX = (Wmax + rp - 1) / rp;
+        if (g.GY > kMaxGrid || g.GX > kMaxGrid || Hmax >= 32768 || Wmax >= 32768) return pl;
         int max_q = 0, max_win[kTL] = {0, 0, 0, 0};
         for (int gy = 0; gy < g.GY; ++gy)
             for (int gx = 0; gx < g.GX; ++gx) {
@@ -171,6 +176,18 @@ inline TiledPlan plan_tiled(int N, int S, int M, int D, int L, int Lq, int P, co
         }
         for (int l = L; l < kTL; ++l) { g.phase[l] = -1; g.H[l] = g.W[l] = 1; g.start[l] = 0; }
         g.nphases = ph + 1;
+        for (int l = 0; l < kTL; ++l) {
+            for (int gy = 0; gy <= g.GY; ++gy) {
+                const LevelRect r = level_rect(g.H[l], g.W[l], gy < g.GY ? gy : g.GY - 1, 0, g.GY, g.GX, margin);
+                g.rq0[l][gy] = (short)(gy < g.GY ? r.qr0 : r.qr0 + r.qnr);
+                if (gy < g.GY) { g.rw0[l][gy] = (short)r.wr0; g.rwn[l][gy] = (short)r.nwr; }
+            }
+            for (int gx = 0; gx <= g.GX; ++gx) {
+                const LevelRect r = level_rect(g.H[l], g.W[l], 0, gx < g.GX ? gx : g.GX - 1, g.GY, g.GX, margin);
+                g.cq0[l][gx] = (short)(gx < g.GX ? r.qc0 : r.qc0 + r.qnc);
+                if (gx < g.GX) { g.cw0[l][gx] = (short)r.wc0; g.cwn[l][gx] = (short)r.nwc; }
+            }
+        }
         pl.lds_bytes = sizeof(TileHeader) + (size_t)max_phase_px * kTD * sizeof(float);
         pl.grid = kXcds * ((N * M + kXcds - 1) / kXcds) * g.GY * g.GX;
         pl.ok = true;
@@ -196,13 +213,23 @@ __device__ __forceinline__ void stamp(const TiledGeom &g, int i)
 __device__ __forceinline__ int build_header(TileHeader *h, const TiledGeom &g, int gy, int gx)
 {
     const int l = threadIdx.x;
-    if (l < kTL) {   // one lane per level: the integer divisions of level_rect run side by side
+    if (l < kTL) {   // one lane per level; geometry comes from the host-made tables (uniform row / column index)
         int H = 1, W = 1, st = 0, ph = -1;
+        LevelRect r = LevelRect{0, 0, 0, 1, 0, 0, 0, 1};
 #pragma unroll
         for (int i = 0; i < kTL; ++i)
-            if (i == l) { H = g.H[i]; W = g.W[i]; st = g.start[i]; ph = g.phase[i]; }
-        LevelRect r = LevelRect{0, 0, 0, 1, 0, 0, 0, 1};
-        if (l < g.L) r = level_rect(H, W, gy, gx, g.GY, g.GX, g.margin);
+            if (i == l) {
+                H = g.H[i]; W = g.W[i]; st = g.start[i]; ph = g.phase[i];
+                r.qr0 = g.rq0[i][gy];
+                r.qnr = g.rq0[i][gy + 1] - r.qr0;
+                r.qc0 = g.cq0[i][gx];
+                r.qnc = g.cq0[i][gx + 1] - r.qc0;
+                r.wr0 = g.rw0[i][gy];
+                r.nwr = g.rwn[i][gy];
+                r.wc0 = g.cw0[i][gx];
+                r.nwc = g.cwn[i][gx];
+            }
+        if (l >= g.L) r = LevelRect{0, 0, 0, 1, 0, 0, 0, 1};
         h->r[l] = r;
         h->H[l] = H;
         h->W[l] = W;
@@ -342,15 +369,33 @@ __device__ __forceinline__ void bwd_point(const float *__restrict__ value, const
     }
 }
 
-// One sampled level for the kGatherQPG queries of an 8-lane group.  The operand loads of kGatherBatch queries are
-// issued before any of them is used (queries without a slot read a valid address and are masked by mode = -1).
+// This lane's sampling point (point (j & 3) of the level's first four) for each of the group's queries.  Loaded one
+// level AHEAD of its use, so the global-memory latency hides behind the window fill / the previous level's gather.
+struct LevelOps {
+    float2 xy[kGatherQPG];
+    float a[kGatherQPG];
+};
+
+__device__ __forceinline__ void load_level_ops(const float *__restrict__ loc, const float *__restrict__ aw,
+                                               const unsigned (&item)[kGatherQPG], unsigned LP, unsigned lvl_pt0, int P,
+                                               int j, LevelOps &o)
+{
+    const unsigned mp = lvl_pt0 + ((j & 3) < P ? (j & 3) : 0);
+#pragma unroll
+    for (int k = 0; k < kGatherQPG; ++k) {   // queries without a slot read a valid address and are masked later
+        o.xy[k] = *reinterpret_cast<const float2 *>(loc + 2u * (item[k] * LP + mp));
+        o.a[k] = aw[item[k] * LP + mp];
+    }
+}
+
+// One sampled level for the kGatherQPG queries of an 8-lane group.
 template <bool BWD>
 __device__ __forceinline__ void gather_level(const float *__restrict__ value, const float *__restrict__ loc,
                                              const float *__restrict__ aw, const float *win, const LevelCtx &lc,
                                              int row_elems, int P, int j, const unsigned (&pt0)[kGatherQPG],
-                                             const bool (&live)[kGatherQPG], v2f (&acc_lo)[kGatherQPG],
-                                             v2f (&acc_hi)[kGatherQPG], const float *__restrict__ grad_out,
-                                             const unsigned (&item)[kGatherQPG], float *__restrict__ grad_loc,
+                                             const bool (&live)[kGatherQPG], const LevelOps &pre,
+                                             v2f (&acc_lo)[kGatherQPG], v2f (&acc_hi)[kGatherQPG],
+                                             const float4 (&gq)[kGatherQPG], float *__restrict__ grad_loc,
                                              float *__restrict__ grad_aw)
 {
     for (int pc = 0; pc < P; pc += 4) {
@@ -358,57 +403,50 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
         const bool pv = myp < P;
         const unsigned mp = pv ? myp : 0;
 #pragma unroll
-        for (int k0 = 0; k0 < kGatherQPG; k0 += kGatherBatch) {
-            float2 xy[kGatherBatch];
-            float a[kGatherBatch];
-            float4 gq[kGatherBatch];   // backward: grad_out of the query (re-read per level: L2-resident, saves registers)
-#pragma unroll
-            for (int u = 0; u < kGatherBatch; ++u) {
-                xy[u] = *reinterpret_cast<const float2 *>(loc + 2u * (pt0[k0 + u] + mp));
-                a[u] = aw[pt0[k0 + u] + mp];
-                if (BWD) gq[u] = *reinterpret_cast<const float4 *>(grad_out + item[k0 + u] * (unsigned)kTD + 4u * j);
+        for (int k = 0; k < kGatherQPG; ++k) {
+            float2 xy = pre.xy[k];
+            float a = pre.a[k];
+            if (pc > 0) {   // more than four points per level: the rest is loaded in place (uniform branch)
+                xy = *reinterpret_cast<const float2 *>(loc + 2u * (pt0[k] + mp));
+                a = aw[pt0[k] + mp];
             }
-#pragma unroll
-            for (int u = 0; u < kGatherBatch; ++u) {
-                const int k = k0 + u;
-                int mode = -1;
-                float lh = 0.f, lw = 0.f;
-                const float h_im = xy[u].y * (float)lc.H - 0.5f, w_im = xy[u].x * (float)lc.W - 0.5f;
-                if (pv && live[k] && h_im > -1.f && w_im > -1.f && h_im < (float)lc.H && w_im < (float)lc.W) {
-                    const float hf = floorf(h_im), wf = floorf(w_im);
-                    lh = h_im - hf;
-                    lw = w_im - wf;
-                    const int rr = (int)hf - lc.wr0, cc = (int)wf - lc.wc0;
-                    // inside the window implies inside the map: the window is clamped to the map
-                    const bool inside = rr >= 0 && rr + 1 < lc.nwr && cc >= 0 && cc + 1 < lc.nwc;
-                    mode = inside ? lc.lds_base + (rr * lc.nwc + cc) * kTD : -2;
-                }
-                if (!live[k]) continue;   // uniform over the 8-lane group
-                if (!BWD) {
-                    const float hh = 1.f - lh, hw = 1.f - lw;
-                    const float w1 = hh * hw * a[u], w2 = hh * lw * a[u], w3 = lh * hw * a[u], w4 = lh * lw * a[u];
+            int mode = -1;
+            float lh = 0.f, lw = 0.f;
+            const float h_im = xy.y * (float)lc.H - 0.5f, w_im = xy.x * (float)lc.W - 0.5f;
+            if (pv && live[k] && h_im > -1.f && w_im > -1.f && h_im < (float)lc.H && w_im < (float)lc.W) {
+                const float hf = floorf(h_im), wf = floorf(w_im);
+                lh = h_im - hf;
+                lw = w_im - wf;
+                const int rr = (int)hf - lc.wr0, cc = (int)wf - lc.wc0;
+                // inside the window implies inside the map: the window is clamped to the map
+                const bool inside = rr >= 0 && rr + 1 < lc.nwr && cc >= 0 && cc + 1 < lc.nwc;
+                mode = inside ? lc.lds_base + (rr * lc.nwc + cc) * kTD : -2;
+            }
+            if (!live[k]) continue;   // uniform over the 8-lane group
+            if (!BWD) {
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const float w1 = hh * hw * a, w2 = hh * lw * a, w3 = lh * hw * a, w4 = lh * lw * a;
 #define MSDA_FWD_ONE(I)                                                                                               \
     if (pc + I < P)                                                                                                    \
         fwd_point(value, win, lc, row_elems, j, quad_bcast_i<I>(mode), quad_bcast_f<I>(w1), quad_bcast_f<I>(w2),     \
-                  quad_bcast_f<I>(w3), quad_bcast_f<I>(w4), quad_bcast_f<I>(xy[u].x), quad_bcast_f<I>(xy[u].y),      \
-                  acc_lo[k], acc_hi[k]);
-                    MSDA_FWD_ONE(0)
-                    MSDA_FWD_ONE(1)
-                    MSDA_FWD_ONE(2)
-                    MSDA_FWD_ONE(3)
+                  quad_bcast_f<I>(w3), quad_bcast_f<I>(w4), quad_bcast_f<I>(xy.x), quad_bcast_f<I>(xy.y), acc_lo[k],  \
+                  acc_hi[k]);
+                MSDA_FWD_ONE(0)
+                MSDA_FWD_ONE(1)
+                MSDA_FWD_ONE(2)
+                MSDA_FWD_ONE(3)
 #undef MSDA_FWD_ONE
-                } else {
+            } else {
 #define MSDA_BWD_ONE(I)                                                                                               \
     if (pc + I < P)                                                                                                    \
         bwd_point(value, win, lc, row_elems, j, quad_bcast_i<I>(mode), quad_bcast_f<I>(lh), quad_bcast_f<I>(lw),     \
-                  quad_bcast_f<I>(a[u]), quad_bcast_f<I>(xy[u].x), quad_bcast_f<I>(xy[u].y), gq[u],                   \
+                  quad_bcast_f<I>(a), quad_bcast_f<I>(xy.x), quad_bcast_f<I>(xy.y), gq[k],                            \
                   grad_loc + 2u * (pt0[k] + pc + I), grad_aw + pt0[k] + pc + I);
-                    MSDA_BWD_ONE(0)
-                    MSDA_BWD_ONE(1)
-                    MSDA_BWD_ONE(2)
-                    MSDA_BWD_ONE(3)
+                MSDA_BWD_ONE(0)
+                MSDA_BWD_ONE(1)
+                MSDA_BWD_ONE(2)
+                MSDA_BWD_ONE(3)
 #undef MSDA_BWD_ONE
-                }
             }
         }
     }
@@ -424,8 +462,12 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_gather_kernel(
     TileHeader *hdr = reinterpret_cast<TileHeader *>(smem);
     float *win = reinterpret_cast<float *>(smem + sizeof(TileHeader));
 
-    int pair, region;
-    if (!decode_block(blockIdx.x, g.N * g.M, g.GY * g.GX, pair, region)) return;
+    // backward: the phases of a region are independent workgroups; they are the fastest-varying part of the
+    // XCD-local index so that they run back to back on one XCD and share loc / attn / grad_out in its L2
+    const int nsub = BWD ? g.nphases : 1;
+    int pair, rs;
+    if (!decode_block(blockIdx.x, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) return;
+    const int region = rs / nsub, sub = rs - region * nsub;
     const int b = pair / g.M, m = pair - b * g.M;
     const int gy = region / g.GX, gx = region - gy * g.GX;
     stamp<2>(g, 0);
@@ -448,11 +490,22 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_gather_kernel(
         item[k] = (unsigned)((b * g.Lq + hdr->qid[live[k] ? i : 0]) * g.M + m);
         acc_lo[k] = acc_hi[k] = (v2f){0.f, 0.f};
     }
+    float4 gq[kGatherQPG];   // backward: grad_out of the group's queries, this lane's 4 channels
+#pragma unroll
+    for (int k = 0; k < kGatherQPG; ++k)
+        gq[k] = BWD ? *reinterpret_cast<const float4 *>(grad_out + item[k] * (unsigned)kTD + 4u * j)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
 
     // forward accumulates over the phases in registers; backward writes per-point results, so there the phases of a
-    // region are independent workgroups (blockIdx.y)
-    const int ph_begin = BWD ? (int)blockIdx.y : 0, ph_end = BWD ? ph_begin + 1 : g.nphases;
+    // region are independent workgroups (`sub`)
+    const int ph_begin = BWD ? sub : 0, ph_end = BWD ? ph_begin + 1 : g.nphases;
     for (int ph = ph_begin; ph < ph_end; ++ph) {
+        // levels of this phase are consecutive: [lb, le)
+        int lb = g.L, le = 0;
+        for (int l = 0; l < g.L; ++l)
+            if (uni(hdr->phase[l]) == ph) { lb = l < lb ? l : lb; le = l + 1; }
+        LevelOps nxt;
+        load_level_ops(loc, aw, item, (unsigned)LP, (unsigned)(lb * g.P), g.P, j, nxt);   // in flight during the fill
         // ---- stage this phase's windows: whole 128-B pixel rows, 16 B per lane -------------------------------
         for (int l = 0; l < g.L; ++l) {
             if (uni(hdr->phase[l]) != ph) continue;
@@ -480,8 +533,9 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_gather_kernel(
         stamp<2>(g, 2 + 2 * (ph - ph_begin));
 
         // ---- gather -------------------------------------------------------------------------------------
-        for (int l = 0; l < g.L; ++l) {
-            if (uni(hdr->phase[l]) != ph) continue;
+        for (int l = lb; l < le; ++l) {
+            const LevelOps cur = nxt;
+            if (l + 1 < le) load_level_ops(loc, aw, item, (unsigned)LP, (unsigned)((l + 1) * g.P), g.P, j, nxt);
             LevelCtx lc;
             lc.H = uni(hdr->H[l]);
             lc.W = uni(hdr->W[l]);
@@ -494,8 +548,8 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_gather_kernel(
             unsigned pt0[kGatherQPG];
 #pragma unroll
             for (int k = 0; k < kGatherQPG; ++k) pt0[k] = item[k] * (unsigned)LP + (unsigned)(l * g.P);
-            gather_level<BWD>(value, loc, aw, win, lc, row_elems, g.P, j, pt0, live, acc_lo, acc_hi, grad_out, item,
-                              grad_loc, grad_aw);
+            gather_level<BWD>(value, loc, aw, win, lc, row_elems, g.P, j, pt0, live, cur, acc_lo, acc_hi, gq, grad_loc,
+                              grad_aw);
         }
         __syncthreads();   // the next phase overwrites the windows
         stamp<2>(g, 3 + 2 * (ph - ph_begin));
@@ -533,9 +587,13 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
     ScatterRec *recs = reinterpret_cast<ScatterRec *>(smem + sizeof(TileHeader));
     double *win = reinterpret_cast<double *>(smem + sizeof(TileHeader) + sizeof(ScatterRec) * kScatterGroups * 16);
 
-    int pair, region;
-    if (!decode_block(blockIdx.x, g.N * g.M, g.GY * g.GX, pair, region)) return;
-    const int half = blockIdx.y;   // channel half; gridDim.x is a multiple of 8, so both halves share the pair's XCD
+    // (channel half, phase) of a region = the fastest-varying part of the XCD-local index: the workgroups of one
+    // region run back to back on one XCD and share loc / attn / grad_out in its L2
+    const int nsub = (kTD / kSD) * g.nphases;
+    int pair, rs;
+    if (!decode_block(blockIdx.x, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) return;
+    const int region = rs / nsub, sub = rs - region * nsub;
+    const int half = sub % (kTD / kSD);
     const int b = pair / g.M, m = pair - b * g.M;
     const int gy = region / g.GX, gx = region - gy * g.GX;
     stamp<1>(g, 0);
@@ -557,7 +615,7 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
     const int basej = (b * g.S + hdr->start[lj]) * row_elems + ch0;
 
     {
-        const int ph = blockIdx.z;   // one LDS phase per workgroup: the phases of a region are independent here
+        const int ph = sub / (kTD / kSD);   // one LDS phase per workgroup: the phases of a region are independent here
         // ---- clear this phase's accumulation windows ---------------------------------------------------------
         int phase_px = 0;
         for (int l = 0; l < g.L; ++l)
@@ -745,12 +803,12 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
     if (e == hipSuccess) e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_kernel), lds_scatter);
     if (e != hipSuccess) return e;
     // grad_value (pre-zeroed by the caller of this function): LDS accumulation + one flush per touched pixel
-    hipLaunchKernelGGL(tiled_scatter_kernel, dim3(pl.grid, kTD / kSD, pl.g.nphases), dim3(kTiledThreads), lds_scatter,
+    hipLaunchKernelGGL(tiled_scatter_kernel, dim3(pl.grid * (kTD / kSD) * pl.g.nphases), dim3(kTiledThreads), lds_scatter,
                        stream, loc, aw, grad_out, grad_value, pl.g);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // grad_sampling_loc, grad_attn_weight: gather from LDS windows of value
-    hipLaunchKernelGGL(tiled_gather_kernel<true>, dim3(pl.grid, pl.g.nphases), dim3(kTiledThreads), pl.lds_bytes, stream,
+    hipLaunchKernelGGL(tiled_gather_kernel<true>, dim3(pl.grid * pl.g.nphases), dim3(kTiledThreads), pl.lds_bytes, stream,
                        value, loc, aw, grad_out, (float *)nullptr, grad_loc, grad_aw, pl.g);
     return hipGetLastError();
 }

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): bench line + rocprofv3 kernel trace + HBM traffic counters, into gpurun_out/<tag>/.
+#   tools/collect_profiles.sh r01
+# rocprofv3 is given the program itself after `--` (python3 bench.py ...), never a wrapper; --pmc runs are separate passes
+# with kernel tracing only, as the pool requires.
+set -e -o pipefail
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 python3 $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+tail -c 600 $OUT/bench.json; echo
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace.err
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+echo collected $OUT
