@@ -74,16 +74,19 @@ __host__ __device__ inline LevelRect level_rect(int H, int W, int gy, int gx, in
     r.qc0 = region_first(W, gx, GX);
     r.qnc = region_first(W, gx + 1, GX) - r.qc0;
     // reference positions of the region, in level pixel coordinates: [g*H/G - 0.5, (g+1)*H/G - 0.5)
+    // The window may reach one pixel beyond the map on every side (rows -1 and H, columns -1 and W): that apron is
+    // zero-filled, so a sample whose corners straddle the map border -- frequent on the coarse levels -- still takes
+    // the in-window path and reads the zero the bilinear kernel prescribes for outside corners.
     int lo = floor_div(2 * gy * H - GY, 2 * GY) - margin;
     int hi = floor_div(2 * (gy + 1) * H - GY, 2 * GY) + 1 + margin;
-    lo = lo < 0 ? 0 : lo;
-    hi = hi > H - 1 ? H - 1 : hi;
+    lo = lo < -1 ? -1 : lo;
+    hi = hi > H ? H : hi;
     r.wr0 = lo;
     r.nwr = hi - lo + 1;
     lo = floor_div(2 * gx * W - GX, 2 * GX) - margin;
     hi = floor_div(2 * (gx + 1) * W - GX, 2 * GX) + 1 + margin;
-    lo = lo < 0 ? 0 : lo;
-    hi = hi > W - 1 ? W - 1 : hi;
+    lo = lo < -1 ? -1 : lo;
+    hi = hi > W ? W : hi;
     r.wc0 = lo;
     r.nwc = hi - lo + 1;
     return r;
@@ -297,76 +300,55 @@ __device__ __forceinline__ float group8_sum(float v)
     return v;
 }
 
-// The four corner rows of one sampling point for this lane's 4 channels.
-//   mode >= 0: all corners valid and inside the window (LDS float index of corner (h_low, w_low))
-//   mode = -2: general point: corners fetched from global memory, zero outside the map
-__device__ __forceinline__ void load_corners(const float *__restrict__ value, const float *win, const LevelCtx &lc,
-                                             int row_elems, int j, int mode, float px_, float py_, float4 &v1, float4 &v2,
-                                             float4 &v3, float4 &v4)
+// The four corner rows of an IN-WINDOW sampling point for this lane's 4 channels: straight-line LDS reads.
+__device__ __forceinline__ void lds_corners(const float *win, int nwc, int j, int mode, float4 &v1, float4 &v2, float4 &v3,
+                                            float4 &v4)
 {
-    if (mode >= 0) {
-        const float *p = win + mode + 4 * j;
-        v1 = *reinterpret_cast<const float4 *>(p);
-        v2 = *reinterpret_cast<const float4 *>(p + kTD);
-        v3 = *reinterpret_cast<const float4 *>(p + lc.nwc * kTD);
-        v4 = *reinterpret_cast<const float4 *>(p + lc.nwc * kTD + kTD);
-    } else {
-        int o[4];
-        float lh2, lw2;
-        resolve_point<float>(px_, py_, lc.H, lc.W, lc.base_row, row_elems, o, lh2, lw2);
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        v1 = o[0] >= 0 ? *reinterpret_cast<const float4 *>(value + o[0] + 4 * j) : z;
-        v2 = o[1] >= 0 ? *reinterpret_cast<const float4 *>(value + o[1] + 4 * j) : z;
-        v3 = o[2] >= 0 ? *reinterpret_cast<const float4 *>(value + o[2] + 4 * j) : z;
-        v4 = o[3] >= 0 ? *reinterpret_cast<const float4 *>(value + o[3] + 4 * j) : z;
-    }
+    const float *p = win + mode + 4 * j;
+    v1 = *reinterpret_cast<const float4 *>(p);
+    v2 = *reinterpret_cast<const float4 *>(p + kTD);
+    v3 = *reinterpret_cast<const float4 *>(p + nwc * kTD);
+    v4 = *reinterpret_cast<const float4 *>(p + nwc * kTD + kTD);
 }
 
-// Forward: acc += sum_k wk * vk  (wk already holds bilinear weight x attention weight), packed two channels wide.
-__device__ __forceinline__ void fwd_point(const float *__restrict__ value, const float *win, const LevelCtx &lc,
-                                          int row_elems, int j, int mode, float w1, float w2, float w3, float w4,
-                                          float px_, float py_, v2f &acc_lo, v2f &acc_hi)
+// General point (a corner outside the window): corners from global memory, zero outside the map.
+__device__ __forceinline__ void global_corners(const float *__restrict__ value, const LevelCtx &lc, int row_elems, int j,
+                                               float x, float y, float4 &v1, float4 &v2, float4 &v3, float4 &v4)
 {
-    if (mode == -1) return;
-    float4 v1, v2, v3, v4;
-    load_corners(value, win, lc, row_elems, j, mode, px_, py_, v1, v2, v3, v4);
+    int o[4];
+    float lh2, lw2;
+    resolve_point<float>(x, y, lc.H, lc.W, lc.base_row, row_elems, o, lh2, lw2);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    v1 = o[0] >= 0 ? *reinterpret_cast<const float4 *>(value + o[0] + 4 * j) : z;
+    v2 = o[1] >= 0 ? *reinterpret_cast<const float4 *>(value + o[1] + 4 * j) : z;
+    v3 = o[2] >= 0 ? *reinterpret_cast<const float4 *>(value + o[2] + 4 * j) : z;
+    v4 = o[3] >= 0 ? *reinterpret_cast<const float4 *>(value + o[3] + 4 * j) : z;
+}
+
+__device__ __forceinline__ void fwd_accumulate(float w1, float w2, float w3, float w4, const float4 &v1, const float4 &v2,
+                                               const float4 &v3, const float4 &v4, v2f &acc_lo, v2f &acc_hi)
+{
     acc_lo += w1 * (v2f){v1.x, v1.y} + w2 * (v2f){v2.x, v2.y} + w3 * (v2f){v3.x, v3.y} + w4 * (v2f){v4.x, v4.y};
     acc_hi += w1 * (v2f){v1.z, v1.w} + w2 * (v2f){v2.z, v2.w} + w3 * (v2f){v3.z, v3.w} + w4 * (v2f){v4.z, v4.w};
 }
 
-// Backward (location / attention gradients) of one point; gq = grad_out of the query for this lane's channels.
-__device__ __forceinline__ void bwd_point(const float *__restrict__ value, const float *win, const LevelCtx &lc,
-                                          int row_elems, int j, int mode, float lh, float lw, float pa, float px_,
-                                          float py_, const float4 &gq, float *__restrict__ grad_loc_pt,
-                                          float *__restrict__ grad_aw_pt)
+// Per-lane partial sums of the location / attention gradients of one point (this lane's 4 channels).
+//   d value / d lw = hh*(v2-v1) + lh*(v4-v3);  d value / d lh = hw*(v3-v1) + lw*(v4-v2)
+__device__ __forceinline__ void bwd_partials(float lh, float lw, const float4 &gq, const float4 &v1, const float4 &v2,
+                                             const float4 &v3, const float4 &v4, float &s_a, float &s_w, float &s_h)
 {
-    float s_a = 0.f, s_w = 0.f, s_h = 0.f;
-    if (mode != -1) {
-        float4 v1, v2, v3, v4;
-        load_corners(value, win, lc, row_elems, j, mode, px_, py_, v1, v2, v3, v4);
-        const float hh = 1.f - lh, hw = 1.f - lw;
-        // per channel: d/dlw of the bilinear value = hh*(v2-v1) + lh*(v4-v3); d/dlh = hw*(v3-v1) + lw*(v4-v2);
-        // the value itself = v1 + lw*(v2-v1) + lh*((v3-v1) + lw*((v4-v3)-(v2-v1)))
-        const v2f gl = {gq.x, gq.y}, gh = {gq.z, gq.w};
-        const v2f a1 = {v1.x, v1.y}, a2 = {v2.x, v2.y}, a3 = {v3.x, v3.y}, a4 = {v4.x, v4.y};
-        const v2f b1 = {v1.z, v1.w}, b2 = {v2.z, v2.w}, b3 = {v3.z, v3.w}, b4 = {v4.z, v4.w};
-        const v2f dwa = hh * (a2 - a1) + lh * (a4 - a3), dwb = hh * (b2 - b1) + lh * (b4 - b3);
-        const v2f dha = hw * (a3 - a1) + lw * (a4 - a2), dhb = hw * (b3 - b1) + lw * (b4 - b2);
-        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-        const v2f va = w1 * a1 + w2 * a2 + w3 * a3 + w4 * a4, vb = w1 * b1 + w2 * b2 + w3 * b3 + w4 * b4;
-        const v2f ta = gl * va + gh * vb, tw = gl * dwa + gh * dwb, th = gl * dha + gh * dhb;
-        s_a = ta.x + ta.y;
-        s_w = tw.x + tw.y;
-        s_h = th.x + th.y;
-    }
-    // uniform over the 8 lanes of the query (mode is), so the DPP partners are always active
-    s_a = group8_sum(s_a);
-    s_w = group8_sum(s_w);
-    s_h = group8_sum(s_h);
-    if (j == 0) {
-        *grad_aw_pt = s_a;
-        *reinterpret_cast<float2 *>(grad_loc_pt) = make_float2((float)lc.W * s_w * pa, (float)lc.H * s_h * pa);
-    }
+    const float hh = 1.f - lh, hw = 1.f - lw;
+    const v2f gl = {gq.x, gq.y}, gh = {gq.z, gq.w};
+    const v2f a1 = {v1.x, v1.y}, a2 = {v2.x, v2.y}, a3 = {v3.x, v3.y}, a4 = {v4.x, v4.y};
+    const v2f b1 = {v1.z, v1.w}, b2 = {v2.z, v2.w}, b3 = {v3.z, v3.w}, b4 = {v4.z, v4.w};
+    const v2f dwa = hh * (a2 - a1) + lh * (a4 - a3), dwb = hh * (b2 - b1) + lh * (b4 - b3);
+    const v2f dha = hw * (a3 - a1) + lw * (a4 - a2), dhb = hw * (b3 - b1) + lw * (b4 - b2);
+    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+    const v2f va = w1 * a1 + w2 * a2 + w3 * a3 + w4 * a4, vb = w1 * b1 + w2 * b2 + w3 * b3 + w4 * b4;
+    const v2f ta = gl * va + gh * vb, tw = gl * dwa + gh * dwb, th = gl * dha + gh * dhb;
+    s_a = ta.x + ta.y;
+    s_w = tw.x + tw.y;
+    s_h = th.x + th.y;
 }
 
 // This lane's sampling point (point (j & 3) of the level's first four) for each of the group's queries.  Loaded one
@@ -388,71 +370,117 @@ __device__ __forceinline__ void load_level_ops(const float *__restrict__ loc, co
     }
 }
 
-// One sampled level for the kGatherQPG queries of an 8-lane group.
-template <bool BWD>
+// One sampled level for the kGatherQPG queries of an 8-lane group.  P4 = the level has exactly 4 points (RichSem):
+// no point-count checks in the unrolled body.  Hot path = in-window points: one wave-divergent branch per point and
+// straight-line LDS reads + packed FMAs.  Points with a corner outside the window are rare; they are handled
+// afterwards in ONE run-time loop per query (not unrolled), with shuffles instead of DPP.
+template <bool BWD, bool P4>
 __device__ __forceinline__ void gather_level(const float *__restrict__ value, const float *__restrict__ loc,
                                              const float *__restrict__ aw, const float *win, const LevelCtx &lc,
-                                             int row_elems, int P, int j, const unsigned (&pt0)[kGatherQPG],
+                                             int row_elems, int P_, int j, const unsigned (&pt0)[kGatherQPG],
                                              const bool (&live)[kGatherQPG], const LevelOps &pre,
                                              v2f (&acc_lo)[kGatherQPG], v2f (&acc_hi)[kGatherQPG],
                                              const float4 (&gq)[kGatherQPG], float *__restrict__ grad_loc,
                                              float *__restrict__ grad_aw)
 {
+    const int P = P4 ? 4 : P_;
     for (int pc = 0; pc < P; pc += 4) {
         const int myp = pc + (j & 3);
-        const bool pv = myp < P;
+        const bool pv = P4 || myp < P;
         const unsigned mp = pv ? myp : 0;
 #pragma unroll
         for (int k = 0; k < kGatherQPG; ++k) {
+            if (!live[k]) continue;   // uniform over the 8-lane group
             float2 xy = pre.xy[k];
             float a = pre.a[k];
-            if (pc > 0) {   // more than four points per level: the rest is loaded in place (uniform branch)
+            if (!P4 && pc > 0) {   // more than four points per level: the rest is loaded in place (uniform branch)
                 xy = *reinterpret_cast<const float2 *>(loc + 2u * (pt0[k] + mp));
                 a = aw[pt0[k] + mp];
             }
+            // resolve this lane's point.  mode >= 0: LDS float index of corner (h_low, w_low), all corners in the window
+            // (the window's apron beyond the map holds zeros, so border samples qualify too); -1: dropped; -2: general
             int mode = -1;
             float lh = 0.f, lw = 0.f;
             const float h_im = xy.y * (float)lc.H - 0.5f, w_im = xy.x * (float)lc.W - 0.5f;
-            if (pv && live[k] && h_im > -1.f && w_im > -1.f && h_im < (float)lc.H && w_im < (float)lc.W) {
+            if (pv && h_im > -1.f && w_im > -1.f && h_im < (float)lc.H && w_im < (float)lc.W) {
                 const float hf = floorf(h_im), wf = floorf(w_im);
                 lh = h_im - hf;
                 lw = w_im - wf;
                 const int rr = (int)hf - lc.wr0, cc = (int)wf - lc.wc0;
-                // inside the window implies inside the map: the window is clamped to the map
                 const bool inside = rr >= 0 && rr + 1 < lc.nwr && cc >= 0 && cc + 1 < lc.nwc;
                 mode = inside ? lc.lds_base + (rr * lc.nwc + cc) * kTD : -2;
             }
-            if (!live[k]) continue;   // uniform over the 8-lane group
-            if (!BWD) {
-                const float hh = 1.f - lh, hw = 1.f - lw;
-                const float w1 = hh * hw * a, w2 = hh * lw * a, w3 = lh * hw * a, w4 = lh * lw * a;
-#define MSDA_FWD_ONE(I)                                                                                               \
-    if (pc + I < P)                                                                                                    \
-        fwd_point(value, win, lc, row_elems, j, quad_bcast_i<I>(mode), quad_bcast_f<I>(w1), quad_bcast_f<I>(w2),     \
-                  quad_bcast_f<I>(w3), quad_bcast_f<I>(w4), quad_bcast_f<I>(xy.x), quad_bcast_f<I>(xy.y), acc_lo[k],  \
-                  acc_hi[k]);
-                MSDA_FWD_ONE(0)
-                MSDA_FWD_ONE(1)
-                MSDA_FWD_ONE(2)
-                MSDA_FWD_ONE(3)
-#undef MSDA_FWD_ONE
-            } else {
-#define MSDA_BWD_ONE(I)                                                                                               \
-    if (pc + I < P)                                                                                                    \
-        bwd_point(value, win, lc, row_elems, j, quad_bcast_i<I>(mode), quad_bcast_f<I>(lh), quad_bcast_f<I>(lw),     \
-                  quad_bcast_f<I>(a), quad_bcast_f<I>(xy.x), quad_bcast_f<I>(xy.y), gq[k],                            \
-                  grad_loc + 2u * (pt0[k] + pc + I), grad_aw + pt0[k] + pc + I);
-                MSDA_BWD_ONE(0)
-                MSDA_BWD_ONE(1)
-                MSDA_BWD_ONE(2)
-                MSDA_BWD_ONE(3)
-#undef MSDA_BWD_ONE
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            // forward broadcasts finished weights; backward needs lh, lw and the attention weight separately
+            const float w1 = hh * hw * a, w2 = hh * lw * a, w3 = lh * hw * a, w4 = lh * lw * a;
+            bool any_slow = false;
+#define MSDA_POINT(I)                                                                                                 \
+    if (P4 || pc + I < P) {                                                                                            \
+        const int m_ = quad_bcast_i<I>(mode);                                                                          \
+        any_slow |= m_ == -2;                                                                                          \
+        if (!BWD) {                                                                                                    \
+            if (m_ >= 0) {                                                                                             \
+                float4 v1, v2, v3, v4;                                                                                 \
+                lds_corners(win, lc.nwc, j, m_, v1, v2, v3, v4);                                                       \
+                fwd_accumulate(quad_bcast_f<I>(w1), quad_bcast_f<I>(w2), quad_bcast_f<I>(w3), quad_bcast_f<I>(w4), v1, \
+                               v2, v3, v4, acc_lo[k], acc_hi[k]);                                                      \
+            }                                                                                                          \
+        } else {                                                                                                       \
+            float s_a = 0.f, s_w = 0.f, s_h = 0.f;                                                                     \
+            if (m_ >= 0) {                                                                                             \
+                float4 v1, v2, v3, v4;                                                                                 \
+                lds_corners(win, lc.nwc, j, m_, v1, v2, v3, v4);                                                       \
+                bwd_partials(quad_bcast_f<I>(lh), quad_bcast_f<I>(lw), gq[k], v1, v2, v3, v4, s_a, s_w, s_h);          \
+            }                                                                                                          \
+            s_a = group8_sum(s_a);                                                                                     \
+            s_w = group8_sum(s_w);                                                                                     \
+            s_h = group8_sum(s_h);                                                                                     \
+            const float pa_ = quad_bcast_f<I>(a);                                                                      \
+            if (j == 0) { /* dropped / general points get zeros here; general ones are rewritten below */             \
+                grad_aw[pt0[k] + pc + I] = s_a;                                                                        \
+                *reinterpret_cast<float2 *>(grad_loc + 2u * (pt0[k] + pc + I)) =                                       \
+                    make_float2((float)lc.W * s_w * pa_, (float)lc.H * s_h * pa_);                                     \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+            MSDA_POINT(0)
+            MSDA_POINT(1)
+            MSDA_POINT(2)
+            MSDA_POINT(3)
+#undef MSDA_POINT
+            if (any_slow) {   // uniform over the quad's query; rare
+                const int lane0 = (threadIdx.x & (kWave - 1)) & ~3;
+                for (int i = 0; i < 4; ++i) {
+                    const int m_ = __shfl(mode, lane0 + i, kWave);
+                    const float x_ = __shfl(xy.x, lane0 + i, kWave), y_ = __shfl(xy.y, lane0 + i, kWave);
+                    const float lh_ = __shfl(lh, lane0 + i, kWave), lw_ = __shfl(lw, lane0 + i, kWave);
+                    const float a_ = __shfl(a, lane0 + i, kWave);
+                    if (m_ != -2) continue;   // uniform over the 8 lanes of the query
+                    float4 v1, v2, v3, v4;
+                    global_corners(value, lc, row_elems, j, x_, y_, v1, v2, v3, v4);
+                    if (!BWD) {
+                        const float hh_ = 1.f - lh_, hw_ = 1.f - lw_;
+                        fwd_accumulate(hh_ * hw_ * a_, hh_ * lw_ * a_, lh_ * hw_ * a_, lh_ * lw_ * a_, v1, v2, v3, v4,
+                                       acc_lo[k], acc_hi[k]);
+                    } else {
+                        float s_a, s_w, s_h;
+                        bwd_partials(lh_, lw_, gq[k], v1, v2, v3, v4, s_a, s_w, s_h);
+                        s_a = group8_sum(s_a);
+                        s_w = group8_sum(s_w);
+                        s_h = group8_sum(s_h);
+                        if (j == 0) {
+                            grad_aw[pt0[k] + pc + i] = s_a;
+                            *reinterpret_cast<float2 *>(grad_loc + 2u * (pt0[k] + pc + i)) =
+                                make_float2((float)lc.W * s_w * a_, (float)lc.H * s_h * a_);
+                        }
+                    }
+                }
             }
         }
     }
 }
 
-template <bool BWD>
+template <bool BWD, bool P4>
 __global__ __launch_bounds__(kTiledThreads) void tiled_gather_kernel(
     const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ aw,
     const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
@@ -510,7 +538,7 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_gather_kernel(
         for (int l = 0; l < g.L; ++l) {
             if (uni(hdr->phase[l]) != ph) continue;
             const int wr0 = uni(hdr->r[l].wr0), wc0 = uni(hdr->r[l].wc0), nwc = uni(hdr->r[l].nwc);
-            const int npx = uni(hdr->r[l].nwr) * nwc, Wl = uni(hdr->W[l]);
+            const int npx = uni(hdr->r[l].nwr) * nwc, Wl = uni(hdr->W[l]), Hl = uni(hdr->H[l]);
             const float *src = value + ((int64_t)(b * g.S + uni(hdr->start[l])) * g.M + m) * kTD + 4 * j;
             float *dst = win + (int64_t)uni(hdr->lds_px[l]) * kTD + 4 * j;
             // eight independent row loads in flight per lane before the first LDS store
@@ -520,7 +548,11 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_gather_kernel(
                 for (int u = 0; u < 8; ++u) {
                     const int px = min(px0 + u * ngroups, npx - 1);   // clamped: always a valid row, stored only if in range
                     const int rr = px / nwc, cc = px - rr * nwc;
-                    v[u] = *reinterpret_cast<const float4 *>(src + (int64_t)((wr0 + rr) * Wl + wc0 + cc) * row_elems);
+                    const int row = wr0 + rr, col = wc0 + cc;
+                    const bool in_map = row >= 0 && row < Hl && col >= 0 && col < Wl;   // else: the zero apron
+                    const int rowc = min(max(row, 0), Hl - 1), colc = min(max(col, 0), Wl - 1);
+                    const float4 t = *reinterpret_cast<const float4 *>(src + (int64_t)(rowc * Wl + colc) * row_elems);
+                    v[u] = in_map ? t : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -548,8 +580,8 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_gather_kernel(
             unsigned pt0[kGatherQPG];
 #pragma unroll
             for (int k = 0; k < kGatherQPG; ++k) pt0[k] = item[k] * (unsigned)LP + (unsigned)(l * g.P);
-            gather_level<BWD>(value, loc, aw, win, lc, row_elems, g.P, j, pt0, live, cur, acc_lo, acc_hi, gq, grad_loc,
-                              grad_aw);
+            gather_level<BWD, P4>(value, loc, aw, win, lc, row_elems, g.P, j, pt0, live, cur, acc_lo, acc_hi, gq,
+                                  grad_loc, grad_aw);
         }
         __syncthreads();   // the next phase overwrites the windows
         stamp<2>(g, 3 + 2 * (ph - ph_begin));
@@ -663,7 +695,7 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
                     const bool c0 = cc >= 0 && cc < nwc, c1 = cc + 1 >= 0 && cc + 1 < nwc;
                     const int lbase = (ldsj + rr * nwc + cc) * kSD;
                     const int gbase = basej + (h_low * Wj + w_low) * row_elems;
-                    if (top && bot && lef && rig && r0 && r1 && c0 && c1) {
+                    if (r0 && r1 && c0 && c1) {   // incl. corners on the window's apron beyond the map: never flushed
                         r.t[0] = lbase;   // all four corners inside the window: one base, fixed strides
                         r.t[1] = -3;
                     } else {
@@ -715,12 +747,13 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
             const int npx = uni(hdr->r[l].nwr) * fnc, Wl = uni(hdr->W[l]);
             float *dst = grad_value + (int64_t)(b * g.S + uni(hdr->start[l])) * row_elems + ch0 + j;
             const double *src = win + (int64_t)uni(hdr->lds_px[l]) * kSD + j;
+            const int Hl = uni(hdr->H[l]);
             for (int px = grp; px < npx; px += kScatterGroups) {
                 const float v = (float)src[px * kSD];
-                if (v != 0.f && !(g.dbg & 2)) {
-                    const int rr = px / fnc, cc = px - rr * fnc;
-                    atomicAdd(dst + (int64_t)((fr0 + rr) * Wl + fc0 + cc) * row_elems, v);
-                }
+                const int rr = px / fnc, cc = px - rr * fnc;
+                const int row = fr0 + rr, col = fc0 + cc;
+                if (v != 0.f && row >= 0 && row < Hl && col >= 0 && col < Wl && !(g.dbg & 2))
+                    atomicAdd(dst + (int64_t)(row * Wl + col) * row_elems, v);
             }
         }
         __syncthreads();
@@ -777,9 +810,10 @@ inline hipError_t launch_fwd_tiled<float>(const float *value, const int64_t *, c
 {
     const TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes_h, lsi_h, tiled_options().region_px, tiled_options().margin);
     if (!pl.ok) return hipErrorInvalidValue;
-    hipError_t e = set_lds_limit(reinterpret_cast<const void *>(&tiled_gather_kernel<false>), pl.lds_bytes);
+    auto kern = P == 4 ? &tiled_gather_kernel<false, true> : &tiled_gather_kernel<false, false>;
+    hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pl.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tiled_gather_kernel<false>, dim3(pl.grid), dim3(kTiledThreads), pl.lds_bytes, stream, value, loc, aw,
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(kTiledThreads), pl.lds_bytes, stream, value, loc, aw,
                        (const float *)nullptr, out, (float *)nullptr, (float *)nullptr, pl.g);
     return hipGetLastError();
 }
@@ -799,7 +833,8 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
     const TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes_h, lsi_h, tiled_options().region_px, tiled_options().margin);
     if (!pl.ok) return hipErrorInvalidValue;
     const size_t lds_scatter = pl.lds_bytes + sizeof(ScatterRec) * kScatterGroups * 16;
-    hipError_t e = set_lds_limit(reinterpret_cast<const void *>(&tiled_gather_kernel<true>), pl.lds_bytes);
+    auto kern = P == 4 ? &tiled_gather_kernel<true, true> : &tiled_gather_kernel<true, false>;
+    hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pl.lds_bytes);
     if (e == hipSuccess) e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_kernel), lds_scatter);
     if (e != hipSuccess) return e;
     // grad_value (pre-zeroed by the caller of this function): LDS accumulation + one flush per touched pixel
@@ -808,8 +843,8 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // grad_sampling_loc, grad_attn_weight: gather from LDS windows of value
-    hipLaunchKernelGGL(tiled_gather_kernel<true>, dim3(pl.grid * pl.g.nphases), dim3(kTiledThreads), pl.lds_bytes, stream,
-                       value, loc, aw, grad_out, (float *)nullptr, grad_loc, grad_aw, pl.g);
+    hipLaunchKernelGGL(kern, dim3(pl.grid * pl.g.nphases), dim3(kTiledThreads), pl.lds_bytes, stream, value, loc, aw, grad_out,
+                       (float *)nullptr, grad_loc, grad_aw, pl.g);
     return hipGetLastError();
 }
 
