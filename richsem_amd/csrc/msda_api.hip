@@ -297,14 +297,13 @@ int msda_tiled_plan(int N, int S, int M, int D, int L, int Lq, int P, const int6
 {
     if (!shapes_host || !level_start_host || !info) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
     if (L < 1 || L > 64) return fail(MSDA_ERR_BAD_DIMS, "bad L=%d", L);
-    const msda::TiledPlan pl = msda::plan_tiled(N, S, M, D, L, Lq, P, shapes_host, level_start_host,
-                                                msda::tiled_options().region_px, msda::tiled_options().margin);
+    const msda::TiledPlan pl = msda::plan_gather(N, S, M, D, L, Lq, P, shapes_host, level_start_host);
     info[0] = pl.ok ? 1 : 0;
     info[1] = pl.g.GY;
     info[2] = pl.g.GX;
     info[3] = pl.g.nphases;
     info[4] = (int)pl.lds_bytes;
-    info[5] = pl.grid;
+    info[5] = pl.grid * (msda::kTD / msda::kFwdGC);
     info[6] = pl.g.margin;
     info[7] = 0;
     if (pl.ok) {   // largest number of queries any region holds

@@ -27,16 +27,24 @@
 namespace msda {
 
 constexpr int kTL = 4;               // levels supported by the tiled kernels
-constexpr int kTiledThreads = 1024;  // 16 waves, one workgroup per CU (the LDS window is the limiter)
 constexpr int kTD = 32;              // channels per head
-constexpr int kGatherQPG = 4;        // queries per 8-lane group   (128 groups -> <= 512 queries per region)
 constexpr int kMaxRegionQueries = 512;
 constexpr int kMaxGrid = 24;         // region rows / columns covered by the host-made geometry tables
+// Gather kernels (forward; backward location / attention gradients): a workgroup works on ONE CHANNEL HALF at a time
+// -- 16 channels = 64 B per window pixel -- so that its LDS stays under half a CU's and two workgroups share a CU: one
+// waits on its window fill (HBM-paced) while the other gathers.
+constexpr int kFwdGC = 16;           // forward: channels per workgroup (a channel half), 4 lanes per query, 512 threads
+constexpr int kFwdLdsBudget = 76 * 1024;
+// Backward location / attention gradients need all 32 channels of a sample at once: 8 lanes per query, 1024 threads,
+// one workgroup per CU (two 16-channel passes with a read-modify-write of the per-point results measured slower).
+constexpr int kBwdGC = 32;
+constexpr int kBwdLdsBudget = 124 * 1024;   // three phases = three independent workgroups per region (measured faster than two)
+constexpr int kGatherQPG = 4;        // queries per lane group (128 groups -> <= 512 queries per region)
+// Scatter kernel (backward grad_value): 16 channels x f64 = 128 B per window pixel, one workgroup per CU.
+constexpr int kTiledThreads = 1024;
 constexpr int kSD = 16;              // channels per scatter workgroup (two workgroups per region: channel halves)
 constexpr int kScatterGroups = kTiledThreads / kSD;   // 16-lane groups, one query each
-// LDS per workgroup (160 KiB): header + windows (128 B per pixel: 32 x f32 when gathering, 16 x f64 when
-// accumulating) + the scatter kernel's per-group sampling-point records
-constexpr int kLdsBudgetBytes = 124 * 1024;
+constexpr int kLdsBudgetBytes = 124 * 1024;           // windows; header and per-group point records take the rest
 
 struct TiledGeom {
     int N, S, M, Lq, L, P;
@@ -125,7 +133,7 @@ struct TiledPlan {
 };
 
 inline TiledPlan plan_tiled(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi,
-                            int region_px, int margin)
+                            int region_px, int margin, int budget_bytes, int px_bytes)
 {
     TiledPlan pl;
     if (D != kTD || L > kTL || L < 1 || Lq != S || P < 1 || L * P > 16) return pl;
@@ -148,7 +156,7 @@ inline TiledPlan plan_tiled(int N, int S, int M, int D, int L, int Lq, int P, co
         Hmax = g.H[l] > Hmax ? g.H[l] : Hmax;
         Wmax = g.W[l] > Wmax ? g.W[l] : Wmax;
     }
-    const int cap_px = kLdsBudgetBytes / (kTD * (int)sizeof(float));
+    const int cap_px = budget_bytes / px_bytes;
     // region grid: ~region_px pixels of the finest level per side; refine until queries and windows fit
     for (int rp = region_px; rp >= 4; rp -= 2) {
         g.GY = (Hmax + rp - 1) / rp;
@@ -191,7 +199,7 @@ inline TiledPlan plan_tiled(int N, int S, int M, int D, int L, int Lq, int P, co
                 if (gx < g.GX) { g.cw0[l][gx] = (short)r.wc0; g.cwn[l][gx] = (short)r.nwc; }
             }
         }
-        pl.lds_bytes = sizeof(TileHeader) + (size_t)max_phase_px * kTD * sizeof(float);
+        pl.lds_bytes = sizeof(TileHeader) + (size_t)max_phase_px * px_bytes;
         pl.grid = kXcds * ((N * M + kXcds - 1) / kXcds) * g.GY * g.GX;
         pl.ok = true;
         return pl;
@@ -290,39 +298,48 @@ struct LevelCtx {
 // DPP broadcast.  BWD = false: out.  BWD = true: grad_loc, grad_attn (grad_value is the scatter kernel's job).
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// Sum over the 8 lanes of a query with DPP only (no LDS crossbar): quad butterflies, then the other quad of the
-// 8-lane half-row through row_half_mirror (every lane of a quad already holds the quad's sum).
-__device__ __forceinline__ float group8_sum(float v)
+// Sum over the 4 lanes of a query (one quad) with DPP only: no LDS crossbar, no barrier.
+__device__ __forceinline__ float quad_sum(float v)
 {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
     return v;
 }
 
 // The four corner rows of an IN-WINDOW sampling point for this lane's 4 channels: straight-line LDS reads.
+template <int GC>
 __device__ __forceinline__ void lds_corners(const float *win, int nwc, int j, int mode, float4 &v1, float4 &v2, float4 &v3,
                                             float4 &v4)
 {
     const float *p = win + mode + 4 * j;
     v1 = *reinterpret_cast<const float4 *>(p);
-    v2 = *reinterpret_cast<const float4 *>(p + kTD);
-    v3 = *reinterpret_cast<const float4 *>(p + nwc * kTD);
-    v4 = *reinterpret_cast<const float4 *>(p + nwc * kTD + kTD);
+    v2 = *reinterpret_cast<const float4 *>(p + GC);
+    v3 = *reinterpret_cast<const float4 *>(p + nwc * GC);
+    v4 = *reinterpret_cast<const float4 *>(p + nwc * GC + GC);
+}
+
+// Sum over the GC/4 lanes of a query: the quad, plus the neighbouring quad (row_half_mirror) when a query spans 8 lanes.
+template <int GC>
+__device__ __forceinline__ float query_sum(float v)
+{
+    v = quad_sum(v);
+    if (GC == 32) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+    return v;
 }
 
 // General point (a corner outside the window): corners from global memory, zero outside the map.
-__device__ __forceinline__ void global_corners(const float *__restrict__ value, const LevelCtx &lc, int row_elems, int j,
+// `chan` = first channel of this lane inside the head (channel half * 16 + 4 * lane).
+__device__ __forceinline__ void global_corners(const float *__restrict__ value, const LevelCtx &lc, int row_elems, int chan,
                                                float x, float y, float4 &v1, float4 &v2, float4 &v3, float4 &v4)
 {
     int o[4];
     float lh2, lw2;
     resolve_point<float>(x, y, lc.H, lc.W, lc.base_row, row_elems, o, lh2, lw2);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    v1 = o[0] >= 0 ? *reinterpret_cast<const float4 *>(value + o[0] + 4 * j) : z;
-    v2 = o[1] >= 0 ? *reinterpret_cast<const float4 *>(value + o[1] + 4 * j) : z;
-    v3 = o[2] >= 0 ? *reinterpret_cast<const float4 *>(value + o[2] + 4 * j) : z;
-    v4 = o[3] >= 0 ? *reinterpret_cast<const float4 *>(value + o[3] + 4 * j) : z;
+    v1 = o[0] >= 0 ? *reinterpret_cast<const float4 *>(value + o[0] + chan) : z;
+    v2 = o[1] >= 0 ? *reinterpret_cast<const float4 *>(value + o[1] + chan) : z;
+    v3 = o[2] >= 0 ? *reinterpret_cast<const float4 *>(value + o[2] + chan) : z;
+    v4 = o[3] >= 0 ? *reinterpret_cast<const float4 *>(value + o[3] + chan) : z;
 }
 
 __device__ __forceinline__ void fwd_accumulate(float w1, float w2, float w3, float w4, const float4 &v1, const float4 &v2,
@@ -351,8 +368,9 @@ __device__ __forceinline__ void bwd_partials(float lh, float lw, const float4 &g
     s_h = th.x + th.y;
 }
 
-// This lane's sampling point (point (j & 3) of the level's first four) for each of the group's queries.  Loaded one
-// level AHEAD of its use, so the global-memory latency hides behind the window fill / the previous level's gather.
+// This lane's sampling point (lane i of the quad holds point i of the level's first four) for each of the quad's
+// queries.  Loaded one level AHEAD of its use, so the global-memory latency hides behind the window fill / the
+// previous level's gather.
 struct LevelOps {
     float2 xy[kGatherQPG];
     float a[kGatherQPG];
@@ -370,14 +388,32 @@ __device__ __forceinline__ void load_level_ops(const float *__restrict__ loc, co
     }
 }
 
-// One sampled level for the kGatherQPG queries of an 8-lane group.  P4 = the level has exactly 4 points (RichSem):
-// no point-count checks in the unrolled body.  Hot path = in-window points: one wave-divergent branch per point and
+// backward: a per-point result of this channel half; the second half adds to what the first half stored (same lane,
+// same address, program order).
+template <bool ACC>
+__device__ __forceinline__ void store_point_grads(float *__restrict__ grad_loc, float *__restrict__ grad_aw, unsigned pt,
+                                                  float s_a, float gx, float gy)
+{
+    float2 *pl = reinterpret_cast<float2 *>(grad_loc + 2u * pt);
+    if (ACC) {
+        const float2 o = *pl;
+        grad_aw[pt] += s_a;
+        *pl = make_float2(o.x + gx, o.y + gy);
+    } else {
+        grad_aw[pt] = s_a;
+        *pl = make_float2(gx, gy);
+    }
+}
+
+// One sampled level for the kGatherQPG queries of a quad.  P4 = the level has exactly 4 points (RichSem): no
+// point-count checks in the unrolled body.  Hot path = in-window points: one wave-divergent branch per point and
 // straight-line LDS reads + packed FMAs.  Points with a corner outside the window are rare; they are handled
 // afterwards in ONE run-time loop per query (not unrolled), with shuffles instead of DPP.
-template <bool BWD, bool P4>
+// ACC (backward, second channel half): add to the stored per-point results instead of overwriting them.
+template <bool BWD, bool P4, bool ACC, int GC>
 __device__ __forceinline__ void gather_level(const float *__restrict__ value, const float *__restrict__ loc,
                                              const float *__restrict__ aw, const float *win, const LevelCtx &lc,
-                                             int row_elems, int P_, int j, const unsigned (&pt0)[kGatherQPG],
+                                             int row_elems, int P_, int j, int chan, const unsigned (&pt0)[kGatherQPG],
                                              const bool (&live)[kGatherQPG], const LevelOps &pre,
                                              v2f (&acc_lo)[kGatherQPG], v2f (&acc_hi)[kGatherQPG],
                                              const float4 (&gq)[kGatherQPG], float *__restrict__ grad_loc,
@@ -390,7 +426,7 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
         const unsigned mp = pv ? myp : 0;
 #pragma unroll
         for (int k = 0; k < kGatherQPG; ++k) {
-            if (!live[k]) continue;   // uniform over the 8-lane group
+            if (!live[k]) continue;   // uniform over the quad
             float2 xy = pre.xy[k];
             float a = pre.a[k];
             if (!P4 && pc > 0) {   // more than four points per level: the rest is loaded in place (uniform branch)
@@ -408,7 +444,7 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
                 lw = w_im - wf;
                 const int rr = (int)hf - lc.wr0, cc = (int)wf - lc.wc0;
                 const bool inside = rr >= 0 && rr + 1 < lc.nwr && cc >= 0 && cc + 1 < lc.nwc;
-                mode = inside ? lc.lds_base + (rr * lc.nwc + cc) * kTD : -2;
+                mode = inside ? lc.lds_base + (rr * lc.nwc + cc) * GC : -2;
             }
             const float hh = 1.f - lh, hw = 1.f - lw;
             // forward broadcasts finished weights; backward needs lh, lw and the attention weight separately
@@ -421,7 +457,7 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
         if (!BWD) {                                                                                                    \
             if (m_ >= 0) {                                                                                             \
                 float4 v1, v2, v3, v4;                                                                                 \
-                lds_corners(win, lc.nwc, j, m_, v1, v2, v3, v4);                                                       \
+                lds_corners<GC>(win, lc.nwc, j, m_, v1, v2, v3, v4);                                                       \
                 fwd_accumulate(quad_bcast_f<I>(w1), quad_bcast_f<I>(w2), quad_bcast_f<I>(w3), quad_bcast_f<I>(w4), v1, \
                                v2, v3, v4, acc_lo[k], acc_hi[k]);                                                      \
             }                                                                                                          \
@@ -429,18 +465,16 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
             float s_a = 0.f, s_w = 0.f, s_h = 0.f;                                                                     \
             if (m_ >= 0) {                                                                                             \
                 float4 v1, v2, v3, v4;                                                                                 \
-                lds_corners(win, lc.nwc, j, m_, v1, v2, v3, v4);                                                       \
+                lds_corners<GC>(win, lc.nwc, j, m_, v1, v2, v3, v4);                                                       \
                 bwd_partials(quad_bcast_f<I>(lh), quad_bcast_f<I>(lw), gq[k], v1, v2, v3, v4, s_a, s_w, s_h);          \
             }                                                                                                          \
-            s_a = group8_sum(s_a);                                                                                     \
-            s_w = group8_sum(s_w);                                                                                     \
-            s_h = group8_sum(s_h);                                                                                     \
-            const float pa_ = quad_bcast_f<I>(a);                                                                      \
-            if (j == 0) { /* dropped / general points get zeros here; general ones are rewritten below */             \
-                grad_aw[pt0[k] + pc + I] = s_a;                                                                        \
-                *reinterpret_cast<float2 *>(grad_loc + 2u * (pt0[k] + pc + I)) =                                       \
-                    make_float2((float)lc.W * s_w * pa_, (float)lc.H * s_h * pa_);                                     \
-            }                                                                                                          \
+            s_a = query_sum<GC>(s_a);                                                                                  \
+            s_w = query_sum<GC>(s_w);                                                                                  \
+            s_h = query_sum<GC>(s_h);                                                                                  \
+            /* lane I of the quad stores point I (dropped / general points: zeros here, general ones redone below) */ \
+            if (j == I)                                                                                                \
+                store_point_grads<ACC>(grad_loc, grad_aw, pt0[k] + pc + I, s_a, (float)lc.W * s_w * a,                 \
+                                       (float)lc.H * s_h * a);                                                         \
         }                                                                                                              \
     }
             MSDA_POINT(0)
@@ -448,16 +482,16 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
             MSDA_POINT(2)
             MSDA_POINT(3)
 #undef MSDA_POINT
-            if (any_slow) {   // uniform over the quad's query; rare
+            if (any_slow) {   // uniform over the quad; rare
                 const int lane0 = (threadIdx.x & (kWave - 1)) & ~3;
                 for (int i = 0; i < 4; ++i) {
                     const int m_ = __shfl(mode, lane0 + i, kWave);
                     const float x_ = __shfl(xy.x, lane0 + i, kWave), y_ = __shfl(xy.y, lane0 + i, kWave);
                     const float lh_ = __shfl(lh, lane0 + i, kWave), lw_ = __shfl(lw, lane0 + i, kWave);
                     const float a_ = __shfl(a, lane0 + i, kWave);
-                    if (m_ != -2) continue;   // uniform over the 8 lanes of the query
+                    if (m_ != -2) continue;   // uniform over the quad
                     float4 v1, v2, v3, v4;
-                    global_corners(value, lc, row_elems, j, x_, y_, v1, v2, v3, v4);
+                    global_corners(value, lc, row_elems, chan, x_, y_, v1, v2, v3, v4);
                     if (!BWD) {
                         const float hh_ = 1.f - lh_, hw_ = 1.f - lw_;
                         fwd_accumulate(hh_ * hw_ * a_, hh_ * lw_ * a_, lh_ * hw_ * a_, lh_ * lw_ * a_, v1, v2, v3, v4,
@@ -465,14 +499,13 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
                     } else {
                         float s_a, s_w, s_h;
                         bwd_partials(lh_, lw_, gq[k], v1, v2, v3, v4, s_a, s_w, s_h);
-                        s_a = group8_sum(s_a);
-                        s_w = group8_sum(s_w);
-                        s_h = group8_sum(s_h);
-                        if (j == 0) {
-                            grad_aw[pt0[k] + pc + i] = s_a;
-                            *reinterpret_cast<float2 *>(grad_loc + 2u * (pt0[k] + pc + i)) =
-                                make_float2((float)lc.W * s_w * a_, (float)lc.H * s_h * a_);
-                        }
+                        s_a = query_sum<GC>(s_a);
+                        s_w = query_sum<GC>(s_w);
+                        s_h = query_sum<GC>(s_h);
+                        // the fast pass stored zeros (ACC: left the first half's value) for this point: add ours on top
+                        if (j == i)
+                            store_point_grads<true>(grad_loc, grad_aw, pt0[k] + pc + i, s_a, (float)lc.W * s_w * a_,
+                                                    (float)lc.H * s_h * a_);
                     }
                 }
             }
@@ -480,8 +513,11 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
     }
 }
 
-template <bool BWD, bool P4>
-__global__ __launch_bounds__(kTiledThreads) void tiled_gather_kernel(
+// Forward (BWD = false): workgroup = (image, head, region, channel half); accumulates over the LDS phases in registers.
+// Backward (BWD = true): workgroup = (image, head, region, LDS phase); runs the two channel halves one after the other
+// (the per-point gradients are sums over all 32 channels).
+template <bool BWD, bool P4, int GC>
+__global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled_gather_kernel(
     const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ aw,
     const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
     float *__restrict__ grad_aw, const TiledGeom g)
@@ -490,9 +526,13 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_gather_kernel(
     TileHeader *hdr = reinterpret_cast<TileHeader *>(smem);
     float *win = reinterpret_cast<float *>(smem + sizeof(TileHeader));
 
-    // backward: the phases of a region are independent workgroups; they are the fastest-varying part of the
-    // XCD-local index so that they run back to back on one XCD and share loc / attn / grad_out in its L2
-    const int nsub = BWD ? g.nphases : 1;
+    // the sub-workgroups of a region are the fastest-varying part of the XCD-local index: they run back to back on one
+    // XCD and share loc / attn / grad_out (and the value windows) in its L2
+    constexpr int GL = GC / 4;                              // lanes per query
+    constexpr int kThreads = GC == 16 ? 512 : 1024;
+    constexpr int kGroups = kThreads / GL;                   // 128 queries in flight per pass over k
+    constexpr int kHalves = kTD / GC;                        // channel passes per region
+    const int nsub = BWD ? g.nphases : kHalves;
     int pair, rs;
     if (!decode_block(blockIdx.x, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) return;
     const int region = rs / nsub, sub = rs - region * nsub;
@@ -503,95 +543,101 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_gather_kernel(
     stamp<2>(g, 1);
 
     const int tid = threadIdx.x;
-    const int j = tid & 7, grp = tid >> 3;
-    constexpr int ngroups = kTiledThreads / 8;
+    const int j = tid & (GL - 1), grp = tid / GL;
     const int row_elems = g.M * kTD;
     const int LP = g.L * g.P;
 
     bool live[kGatherQPG];
-    unsigned item[kGatherQPG];            // (b*Lq + q)*M + m; every element offset derived from it fits 32 bits (host-checked)
-    v2f acc_lo[kGatherQPG], acc_hi[kGatherQPG];   // forward: output accumulators of the group's queries
+    unsigned item[kGatherQPG];   // (b*Lq + q)*M + m; every element offset derived from it fits 32 bits (host-checked)
+    v2f acc_lo[kGatherQPG], acc_hi[kGatherQPG];   // forward: output accumulators of the quad's queries
 #pragma unroll
     for (int k = 0; k < kGatherQPG; ++k) {
-        const int i = grp + k * ngroups;
+        const int i = grp + k * kGroups;
         live[k] = i < nq;
         item[k] = (unsigned)((b * g.Lq + hdr->qid[live[k] ? i : 0]) * g.M + m);
         acc_lo[k] = acc_hi[k] = (v2f){0.f, 0.f};
     }
-    float4 gq[kGatherQPG];   // backward: grad_out of the group's queries, this lane's 4 channels
-#pragma unroll
-    for (int k = 0; k < kGatherQPG; ++k)
-        gq[k] = BWD ? *reinterpret_cast<const float4 *>(grad_out + item[k] * (unsigned)kTD + 4u * j)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // forward accumulates over the phases in registers; backward writes per-point results, so there the phases of a
-    // region are independent workgroups (`sub`)
     const int ph_begin = BWD ? sub : 0, ph_end = BWD ? ph_begin + 1 : g.nphases;
-    for (int ph = ph_begin; ph < ph_end; ++ph) {
-        // levels of this phase are consecutive: [lb, le)
-        int lb = g.L, le = 0;
-        for (int l = 0; l < g.L; ++l)
-            if (uni(hdr->phase[l]) == ph) { lb = l < lb ? l : lb; le = l + 1; }
-        LevelOps nxt;
-        load_level_ops(loc, aw, item, (unsigned)LP, (unsigned)(lb * g.P), g.P, j, nxt);   // in flight during the fill
-        // ---- stage this phase's windows: whole 128-B pixel rows, 16 B per lane -------------------------------
-        for (int l = 0; l < g.L; ++l) {
-            if (uni(hdr->phase[l]) != ph) continue;
-            const int wr0 = uni(hdr->r[l].wr0), wc0 = uni(hdr->r[l].wc0), nwc = uni(hdr->r[l].nwc);
-            const int npx = uni(hdr->r[l].nwr) * nwc, Wl = uni(hdr->W[l]), Hl = uni(hdr->H[l]);
-            const float *src = value + ((int64_t)(b * g.S + uni(hdr->start[l])) * g.M + m) * kTD + 4 * j;
-            float *dst = win + (int64_t)uni(hdr->lds_px[l]) * kTD + 4 * j;
-            // eight independent row loads in flight per lane before the first LDS store
-            for (int px0 = grp; px0 < npx; px0 += 8 * ngroups) {
-                float4 v[8];
+    const int half_begin = BWD ? 0 : sub, half_end = BWD ? kHalves : sub + 1;
+    int st = 2;
+    for (int half = half_begin; half < half_end; ++half) {
+        const int chan = half * GC + 4 * j;   // this lane's first channel inside the head
+        float4 gq[kGatherQPG];                 // backward: grad_out of the quad's queries, this lane's 4 channels
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int px = min(px0 + u * ngroups, npx - 1);   // clamped: always a valid row, stored only if in range
-                    const int rr = px / nwc, cc = px - rr * nwc;
-                    const int row = wr0 + rr, col = wc0 + cc;
-                    const bool in_map = row >= 0 && row < Hl && col >= 0 && col < Wl;   // else: the zero apron
-                    const int rowc = min(max(row, 0), Hl - 1), colc = min(max(col, 0), Wl - 1);
-                    const float4 t = *reinterpret_cast<const float4 *>(src + (int64_t)(rowc * Wl + colc) * row_elems);
-                    v[u] = in_map ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+        for (int k = 0; k < kGatherQPG; ++k)
+            gq[k] = BWD ? *reinterpret_cast<const float4 *>(grad_out + item[k] * (unsigned)kTD + chan)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ph = ph_begin; ph < ph_end; ++ph) {
+            // levels of this phase are consecutive: [lb, le)
+            int lb = g.L, le = 0;
+            for (int l = 0; l < g.L; ++l)
+                if (uni(hdr->phase[l]) == ph) { lb = l < lb ? l : lb; le = l + 1; }
+            LevelOps nxt;
+            load_level_ops(loc, aw, item, (unsigned)LP, (unsigned)(lb * g.P), g.P, j, nxt);   // in flight during the fill
+            // ---- stage this phase's windows: 64-B pixel half-rows, 16 B per lane -------------------------------------
+            for (int l = lb; l < le; ++l) {
+                const int wr0 = uni(hdr->r[l].wr0), wc0 = uni(hdr->r[l].wc0), nwc = uni(hdr->r[l].nwc);
+                const int npx = uni(hdr->r[l].nwr) * nwc, Wl = uni(hdr->W[l]), Hl = uni(hdr->H[l]);
+                const float *src = value + ((int64_t)(b * g.S + uni(hdr->start[l])) * g.M + m) * kTD + chan;
+                float *dst = win + (int64_t)uni(hdr->lds_px[l]) * GC + 4 * j;
+                // eight independent loads in flight per lane before the first LDS store
+                for (int px0 = grp; px0 < npx; px0 += 8 * kGroups) {
+                    float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int px = px0 + u * ngroups;
-                    if (px < npx) *reinterpret_cast<float4 *>(dst + px * kTD) = v[u];
+                    for (int u = 0; u < 8; ++u) {
+                        const int px = min(px0 + u * kGroups, npx - 1);   // clamped; stored only if in range
+                        const int rr = px / nwc, cc = px - rr * nwc;
+                        const int row = wr0 + rr, col = wc0 + cc;
+                        const bool in_map = row >= 0 && row < Hl && col >= 0 && col < Wl;   // else: the zero apron
+                        const int rowc = min(max(row, 0), Hl - 1), colc = min(max(col, 0), Wl - 1);
+                        const float4 t = *reinterpret_cast<const float4 *>(src + (int64_t)(rowc * Wl + colc) * row_elems);
+                        v[u] = in_map ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int px = px0 + u * kGroups;
+                        if (px < npx) *reinterpret_cast<float4 *>(dst + px * GC) = v[u];
+                    }
                 }
             }
-        }
-        __syncthreads();
-        stamp<2>(g, 2 + 2 * (ph - ph_begin));
+            __syncthreads();
+            stamp<2>(g, st++);
 
-        // ---- gather -------------------------------------------------------------------------------------
-        for (int l = lb; l < le; ++l) {
-            const LevelOps cur = nxt;
-            if (l + 1 < le) load_level_ops(loc, aw, item, (unsigned)LP, (unsigned)((l + 1) * g.P), g.P, j, nxt);
-            LevelCtx lc;
-            lc.H = uni(hdr->H[l]);
-            lc.W = uni(hdr->W[l]);
-            lc.wr0 = uni(hdr->r[l].wr0);
-            lc.wc0 = uni(hdr->r[l].wc0);
-            lc.nwr = uni(hdr->r[l].nwr);
-            lc.nwc = uni(hdr->r[l].nwc);
-            lc.lds_base = uni(hdr->lds_px[l]) * kTD;
-            lc.base_row = (b * g.S + uni(hdr->start[l])) * row_elems + m * kTD;
-            unsigned pt0[kGatherQPG];
+            // ---- gather -------------------------------------------------------------------------------------
+            for (int l = lb; l < le; ++l) {
+                const LevelOps cur = nxt;
+                if (l + 1 < le) load_level_ops(loc, aw, item, (unsigned)LP, (unsigned)((l + 1) * g.P), g.P, j, nxt);
+                LevelCtx lc;
+                lc.H = uni(hdr->H[l]);
+                lc.W = uni(hdr->W[l]);
+                lc.wr0 = uni(hdr->r[l].wr0);
+                lc.wc0 = uni(hdr->r[l].wc0);
+                lc.nwr = uni(hdr->r[l].nwr);
+                lc.nwc = uni(hdr->r[l].nwc);
+                lc.lds_base = uni(hdr->lds_px[l]) * GC;
+                lc.base_row = (b * g.S + uni(hdr->start[l])) * row_elems + m * kTD;
+                unsigned pt0[kGatherQPG];
 #pragma unroll
-            for (int k = 0; k < kGatherQPG; ++k) pt0[k] = item[k] * (unsigned)LP + (unsigned)(l * g.P);
-            gather_level<BWD, P4>(value, loc, aw, win, lc, row_elems, g.P, j, pt0, live, cur, acc_lo, acc_hi, gq,
-                                  grad_loc, grad_aw);
+                for (int k = 0; k < kGatherQPG; ++k) pt0[k] = item[k] * (unsigned)LP + (unsigned)(l * g.P);
+                if (BWD && half > 0)
+                    gather_level<BWD, P4, true, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
+                                                acc_hi, gq, grad_loc, grad_aw);
+                else
+                    gather_level<BWD, P4, false, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
+                                                 acc_hi, gq, grad_loc, grad_aw);
+            }
+            __syncthreads();   // the next fill overwrites the windows
+            stamp<2>(g, st++);
         }
-        __syncthreads();   // the next phase overwrites the windows
-        stamp<2>(g, 3 + 2 * (ph - ph_begin));
     }
 
     if (!BWD) {
+        const int chan = sub * GC + 4 * j;
 #pragma unroll
         for (int k = 0; k < kGatherQPG; ++k)
             if (live[k])
-                *reinterpret_cast<float4 *>(out + item[k] * (unsigned)kTD + 4u * j) =
+                *reinterpret_cast<float4 *>(out + item[k] * (unsigned)kTD + chan) =
                     make_float4(acc_lo[k].x, acc_lo[k].y, acc_hi[k].x, acc_hi[k].y);
     }
 }
@@ -762,6 +808,22 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
 }
 
 // ---- host entry points ----------------------------------------------------------------------------------------------
+inline TiledPlan plan_gather(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
+{
+    return plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin, kFwdLdsBudget,
+                      kFwdGC * (int)sizeof(float));
+}
+inline TiledPlan plan_bwd_gather(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
+{
+    return plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin, kBwdLdsBudget,
+                      kBwdGC * (int)sizeof(float));
+}
+inline TiledPlan plan_scatter(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
+{
+    return plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin, kLdsBudgetBytes,
+                      kSD * (int)sizeof(double));
+}
+
 template <typename T>
 bool tiled_fwd_applicable(int, int, int, int, int, int, int, const int64_t *, const int64_t *, const T *, const T *)
 {
@@ -772,7 +834,7 @@ inline bool tiled_fwd_applicable<float>(int N, int S, int M, int D, int L, int L
                                         const int64_t *lsi, const float *value, const float *out)
 {
     if ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(out)) & 15) return false;
-    return plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin).ok;
+    return plan_gather(N, S, M, D, L, Lq, P, shapes, lsi).ok;
 }
 
 template <typename T>
@@ -789,7 +851,7 @@ inline bool tiled_bwd_applicable<float>(int N, int S, int M, int D, int L, int L
     if ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(grad_out) |
          reinterpret_cast<uintptr_t>(grad_value)) & 15)
         return false;
-    return plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin).ok;
+    return plan_bwd_gather(N, S, M, D, L, Lq, P, shapes, lsi).ok && plan_scatter(N, S, M, D, L, Lq, P, shapes, lsi).ok;
 }
 
 inline hipError_t set_lds_limit(const void *fn, size_t bytes)
@@ -808,12 +870,12 @@ inline hipError_t launch_fwd_tiled<float>(const float *value, const int64_t *, c
                                           const float *aw, float *out, int N, int S, int M, int D, int L, int Lq, int P,
                                           const int64_t *shapes_h, const int64_t *lsi_h, hipStream_t stream)
 {
-    const TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes_h, lsi_h, tiled_options().region_px, tiled_options().margin);
+    const TiledPlan pl = plan_gather(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
     if (!pl.ok) return hipErrorInvalidValue;
-    auto kern = P == 4 ? &tiled_gather_kernel<false, true> : &tiled_gather_kernel<false, false>;
+    auto kern = P == 4 ? &tiled_gather_kernel<false, true, kFwdGC> : &tiled_gather_kernel<false, false, kFwdGC>;
     hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pl.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(kTiledThreads), pl.lds_bytes, stream, value, loc, aw,
+    hipLaunchKernelGGL(kern, dim3(pl.grid * (kTD / kFwdGC)), dim3(kFwdGC == 16 ? 512 : 1024), pl.lds_bytes, stream, value, loc, aw,
                        (const float *)nullptr, out, (float *)nullptr, (float *)nullptr, pl.g);
     return hipGetLastError();
 }
@@ -830,21 +892,22 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
                                           float *grad_aw, int N, int S, int M, int D, int L, int Lq, int P,
                                           const int64_t *shapes_h, const int64_t *lsi_h, hipStream_t stream)
 {
-    const TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes_h, lsi_h, tiled_options().region_px, tiled_options().margin);
-    if (!pl.ok) return hipErrorInvalidValue;
-    const size_t lds_scatter = pl.lds_bytes + sizeof(ScatterRec) * kScatterGroups * 16;
-    auto kern = P == 4 ? &tiled_gather_kernel<true, true> : &tiled_gather_kernel<true, false>;
-    hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pl.lds_bytes);
+    const TiledPlan pg = plan_bwd_gather(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
+    const TiledPlan ps = plan_scatter(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
+    if (!pg.ok || !ps.ok) return hipErrorInvalidValue;
+    const size_t lds_scatter = ps.lds_bytes + sizeof(ScatterRec) * kScatterGroups * 16;
+    auto kern = P == 4 ? &tiled_gather_kernel<true, true, kBwdGC> : &tiled_gather_kernel<true, false, kBwdGC>;
+    hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pg.lds_bytes);
     if (e == hipSuccess) e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_kernel), lds_scatter);
     if (e != hipSuccess) return e;
     // grad_value (pre-zeroed by the caller of this function): LDS accumulation + one flush per touched pixel
-    hipLaunchKernelGGL(tiled_scatter_kernel, dim3(pl.grid * (kTD / kSD) * pl.g.nphases), dim3(kTiledThreads), lds_scatter,
-                       stream, loc, aw, grad_out, grad_value, pl.g);
+    hipLaunchKernelGGL(tiled_scatter_kernel, dim3(ps.grid * (kTD / kSD) * ps.g.nphases), dim3(kTiledThreads), lds_scatter,
+                       stream, loc, aw, grad_out, grad_value, ps.g);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // grad_sampling_loc, grad_attn_weight: gather from LDS windows of value
-    hipLaunchKernelGGL(kern, dim3(pl.grid * pl.g.nphases), dim3(kTiledThreads), pl.lds_bytes, stream, value, loc, aw, grad_out,
-                       (float *)nullptr, grad_loc, grad_aw, pl.g);
+    hipLaunchKernelGGL(kern, dim3(pg.grid * pg.g.nphases), dim3(kBwdGC == 16 ? 512 : 1024), pg.lds_bytes, stream, value, loc, aw, grad_out,
+                       (float *)nullptr, grad_loc, grad_aw, pg.g);
     return hipGetLastError();
 }
 

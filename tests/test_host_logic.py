@@ -100,7 +100,8 @@ def test_tiled_plan_geometry():
     assert p["applicable"] == 1
     assert p["GY"] * p["GX"] >= 24 and p["max_region_queries"] <= 512
     assert p["lds_bytes"] <= 160 * 1024 and p["phases"] >= 1
-    assert p["grid"] == 8 * 2 * p["GY"] * p["GX"]          # 16 (image, head) pairs over 8 XCDs
+    assert p["grid"] == 8 * 2 * p["GY"] * p["GX"] * 2      # 16 (image, head) pairs over 8 XCDs, two channel halves
+    assert p["lds_bytes"] <= 80 * 1024                     # two gather workgroups share a CU
     Em = W.call_Em()
     sh, lsi = W.level_tensors(Em)
     assert _lib.tiled_plan(Em.N, Em.S, Em.M, Em.D, Em.L, Em.Lq, Em.P, sh.tolist(), lsi.tolist())["applicable"] == 1
