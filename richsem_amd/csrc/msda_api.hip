@@ -278,6 +278,7 @@ int msda_set_option(const char *key, int value)
     if (key && !strcmp(key, "tile_region") && value >= 4 && value <= 64) { msda::tiled_options().region_px = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_margin") && value >= 0 && value <= 32) { msda::tiled_options().margin = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_debug") && value >= 0 && value <= 255) { msda::tiled_options().dbg = value; return MSDA_OK; }
+    if (key && !strcmp(key, "tile_accum") && (value == 0 || value == 1)) { msda::tiled_options().accum = value; return MSDA_OK; }
     return fail(MSDA_ERR_BAD_OPTION, "unknown option or value: %s=%d", key ? key : "(null)", value);
 }
 
@@ -289,6 +290,7 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "bwd_direct_cpl")) { *value = g_bwd_cpl; return MSDA_OK; }
     if (key && !strcmp(key, "tile_region")) { *value = msda::tiled_options().region_px; return MSDA_OK; }
     if (key && !strcmp(key, "tile_margin")) { *value = msda::tiled_options().margin; return MSDA_OK; }
+    if (key && !strcmp(key, "tile_accum")) { *value = msda::tiled_options().accum; return MSDA_OK; }
     return fail(MSDA_ERR_BAD_OPTION, "unknown option: %s", key ? key : "(null)");
 }
 

@@ -34,7 +34,7 @@ constexpr int kMaxGrid = 24;         // region rows / columns covered by the hos
 // -- 16 channels = 64 B per window pixel -- so that its LDS stays under half a CU's and two workgroups share a CU: one
 // waits on its window fill (HBM-paced) while the other gathers.
 constexpr int kFwdGC = 16;           // forward: channels per workgroup (a channel half), 4 lanes per query, 512 threads
-constexpr int kFwdLdsBudget = 76 * 1024;
+constexpr int kFwdLdsBudget = 75 * 1024;   // + header < 80 KiB: two workgroups per CU
 // Backward location / attention gradients need all 32 channels of a sample at once: 8 lanes per query, 1024 threads,
 // one workgroup per CU (two 16-channel passes with a read-modify-write of the per-point results measured slower).
 constexpr int kBwdGC = 32;
@@ -109,12 +109,14 @@ struct TileHeader {
     int H[kTL], W[kTL], start[kTL], phase[kTL];
     int pad[3];
     int qid[kMaxRegionQueries];   // global query index of the region's i-th query
+    float gmax[kMaxRegionQueries];   // integer-accumulation scatter: max_c |grad_out[q, c]| of the region's i-th query
 };
 static_assert(sizeof(TileHeader) % 16 == 0, "windows must stay 16-byte aligned behind the header");
 
 struct TiledOptions {
     int region_px = 16;
     int margin = 6;
+    int accum = 0;   // grad_value window: 0 = f64 LDS atomics (exact), 1 = per-pixel block floating point on int32 atomics
     int dbg = 0;
     unsigned long long *stamps = nullptr;
 };
@@ -248,23 +250,43 @@ __device__ __forceinline__ int build_header(TileHeader *h, const TiledGeom &g, i
         h->phase[l] = l < g.L ? ph : -1;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        h->qpre[0] = 0;
-        int used = 0, cur = 0;
+    // every thread derives the prefix sums from one batch of (pipelined) LDS reads -- a single thread walking the levels
+    // with dependent LDS round trips cost ~3k cycles per workgroup
+    int qpre[kTL + 1], ldspx[kTL];
+    {
+        int qn[kTL], wn[kTL], phs[kTL];
+#pragma unroll
         for (int i = 0; i < kTL; ++i) {
-            h->qpre[i + 1] = h->qpre[i] + (i < g.L ? h->r[i].qnr * h->r[i].qnc : 0);
-            if (i < g.L && h->phase[i] != cur) { cur = h->phase[i]; used = 0; }
-            h->lds_px[i] = used;
-            if (i < g.L) used += h->r[i].nwr * h->r[i].nwc;
+            qn[i] = h->r[i].qnr * h->r[i].qnc;
+            wn[i] = h->r[i].nwr * h->r[i].nwc;
+            phs[i] = h->phase[i];
+        }
+        qpre[0] = 0;
+        int used = 0, cur = 0;
+#pragma unroll
+        for (int i = 0; i < kTL; ++i) {
+            const bool on = i < g.L;
+            qpre[i + 1] = qpre[i] + (on ? qn[i] : 0);
+            if (on && phs[i] != cur) { cur = phs[i]; used = 0; }
+            ldspx[i] = used;
+            if (on) used += wn[i];
         }
     }
-    __syncthreads();
-    const int nq = h->qpre[kTL];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < kTL; ++i) {
+            h->qpre[i] = qpre[i];
+            h->lds_px[i] = ldspx[i];
+        }
+        h->qpre[kTL] = qpre[kTL];
+    }
+    const int nq = qpre[kTL];
     for (int i = threadIdx.x; i < nq; i += blockDim.x) {   // level-major, row-major inside the level
         int q = -1;
+#pragma unroll
         for (int lv = 0; lv < kTL; ++lv) {
-            if (i >= h->qpre[lv] && i < h->qpre[lv + 1]) {
-                const int k = i - h->qpre[lv];
+            if (i >= qpre[lv] && i < qpre[lv + 1]) {
+                const int k = i - qpre[lv];
                 const int qnc = h->r[lv].qnc;
                 const int rr = k / qnc, cc = k - rr * qnc;
                 q = h->start[lv] + (h->r[lv].qr0 + rr) * h->W[lv] + h->r[lv].qc0 + cc;
@@ -807,6 +829,251 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
     }
 }
 
+// ---- backward: grad_value, integer accumulation ("block floating point per pixel") --------------------------------------
+// ds_add_u32 costs ~2.6 CU cycles per wave instruction against ~13 for ds_add_f64 under this kernel's bank conflicts, and a
+// 32-bit accumulator holds all 32 channels of a pixel in 128 B, so one workgroup serves a whole (region, phase).  To make
+// integer accumulation safe for any input, every window pixel gets ITS OWN scale:
+//   pass 1  per pixel: cnt = number of in-window contributions, maxc = max |bilinear * attn| * max_c |grad_out[q, c]|
+//           (integer max / add LDS atomics on the float bit pattern, one lane per corner)
+//   scale   2^30 / (cnt * maxc): the quantised contributions of a pixel can never overflow 32 bits
+//   pass 2  acc[pixel][channel] += round(contribution * scale)   (ds_add_u32, one channel per lane)
+//   flush   acc / scale, one 128-B row global float atomic per touched pixel
+// Error per pixel-channel <= cnt^2 * maxc / 2^31 (worst case), ~sqrt(cnt) * cnt * maxc * 2^-32 typical: for 64
+// contributions that is 2e-6 / 1e-7 of the pixel's largest contribution -- float32-class, and the result is bitwise
+// reproducible (integer sums do not depend on order).  Contributions outside the window still use global float atomics.
+constexpr int kBfpGroups = kTiledThreads / kTD;          // 32-lane groups, one query each
+constexpr int kBfpPxBytes = kTD * 4 + 8;                 // int32 x 32 channels + {maxc | scale, cnt | 1/scale}
+constexpr int kBfpLdsBudget = 150 * 1024;
+constexpr int kBfpBatch = 4;                              // queries per group whose operands are fetched together
+
+struct BfpPoint {   // one sampling point resolved by one lane of a quad
+    int base;       // >= 0: window pixel index of corner (h_low, w_low), all four corners inside the window (incl. apron)
+                    //   -1: nothing to do;  -2: general point (per-corner window / global handling)
+    int t[4];       // general point only: per corner window pixel index (>= 0), -(global element offset) - 2, or -1
+    float w[4];     // bilinear weight x attention weight
+};
+
+__device__ __forceinline__ BfpPoint bfp_resolve(float x, float y, float a, int H, int W, int wr0, int wc0, int nwr, int nwc,
+                                                int lds_px, int base_row, int row_elems, bool valid)
+{
+    BfpPoint p;
+    p.base = -1;
+    p.t[0] = p.t[1] = p.t[2] = p.t[3] = -1;
+    p.w[0] = p.w[1] = p.w[2] = p.w[3] = 0.f;
+    const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
+    if (!(valid && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) return p;
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const int h_low = (int)hf, w_low = (int)wf;
+    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+    p.w[0] = hh * hw * a;
+    p.w[1] = hh * lw * a;
+    p.w[2] = lh * hw * a;
+    p.w[3] = lh * lw * a;
+    const int rr = h_low - wr0, cc = w_low - wc0;
+    const bool r0 = rr >= 0 && rr < nwr, r1 = rr + 1 >= 0 && rr + 1 < nwr;
+    const bool c0 = cc >= 0 && cc < nwc, c1 = cc + 1 >= 0 && cc + 1 < nwc;
+    const int lbase = lds_px + rr * nwc + cc;
+    if (r0 && r1 && c0 && c1) {
+        p.base = lbase;
+        return p;
+    }
+    p.base = -2;
+    const bool top = h_low >= 0, bot = h_low + 1 <= H - 1, lef = w_low >= 0, rig = w_low + 1 <= W - 1;
+    const int gbase = base_row + (h_low * W + w_low) * row_elems;
+    if (top && lef) p.t[0] = (r0 && c0) ? lbase : -gbase - 2;
+    if (top && rig) p.t[1] = (r0 && c1) ? lbase + 1 : -(gbase + row_elems) - 2;
+    if (bot && lef) p.t[2] = (r1 && c0) ? lbase + nwc : -(gbase + W * row_elems) - 2;
+    if (bot && rig) p.t[3] = (r1 && c1) ? lbase + nwc + 1 : -(gbase + W * row_elems + row_elems) - 2;
+    return p;
+}
+
+__global__ __launch_bounds__(kTiledThreads) void tiled_scatter_bfp_kernel(
+    const float *__restrict__ loc, const float *__restrict__ aw, const float *__restrict__ grad_out,
+    float *__restrict__ grad_value, const TiledGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TileHeader *hdr = reinterpret_cast<TileHeader *>(smem);
+
+    const int nsub = g.nphases;
+    int pair, rs;
+    if (!decode_block(blockIdx.x, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) return;
+    const int region = rs / nsub, ph = rs - region * nsub;
+    const int b = pair / g.M, m = pair - b * g.M;
+    const int gy = region / g.GX, gx = region - gy * g.GX;
+    stamp<1>(g, 0);
+    const int nq = build_header(hdr, g, gy, gx);
+    stamp<1>(g, 1);
+
+    const int tid = threadIdx.x;
+    const int j = tid & (kTD - 1), grp = tid / kTD;
+    const int row_elems = g.M * kTD;
+    const int LP = g.L * g.P;
+
+    int lb = g.L, le = 0, phase_px = 0;
+    for (int l = 0; l < g.L; ++l)
+        if (uni(hdr->phase[l]) == ph) {
+            lb = l < lb ? l : lb;
+            le = l + 1;
+            phase_px = uni(hdr->lds_px[l]) + uni(hdr->r[l].nwr) * uni(hdr->r[l].nwc);
+        }
+    int *acc = reinterpret_cast<int *>(smem + sizeof(TileHeader));            // [phase_px][32]
+    unsigned *maxc = reinterpret_cast<unsigned *>(acc + (size_t)phase_px * kTD);   // pass 1: max bits; then: scale (float)
+    unsigned *cnt = maxc + phase_px;                                           // pass 1: count;    then: 1/scale (float)
+
+    for (int i = tid; i < phase_px * (kTD / 4); i += kTiledThreads) reinterpret_cast<int4 *>(acc)[i] = make_int4(0, 0, 0, 0);
+    for (int i = tid; i < 2 * phase_px; i += kTiledThreads) maxc[i] = 0u;
+    __syncthreads();
+    stamp<1>(g, 2);
+
+    // ---- pass 0: max_c |grad_out[q, c]| of every query (32 lanes = 32 channels; two queries in flight per group) ------
+    for (int i = grp; i < nq; i += 2 * kBfpGroups) {
+        const int i2 = i + kBfpGroups;
+        const unsigned it0 = (unsigned)((b * g.Lq + hdr->qid[i]) * g.M + m);
+        const unsigned it1 = (unsigned)((b * g.Lq + hdr->qid[i2 < nq ? i2 : i]) * g.M + m);
+        float g0 = fabsf(grad_out[it0 * (unsigned)kTD + j]), g1 = fabsf(grad_out[it1 * (unsigned)kTD + j]);
+#pragma unroll
+        for (int sft = 1; sft < kTD; sft <<= 1) {
+            g0 = fmaxf(g0, __shfl_xor(g0, sft, kWave));
+            g1 = fmaxf(g1, __shfl_xor(g1, sft, kWave));
+        }
+        if (j == 0) {
+            hdr->gmax[i] = g0;
+            if (i2 < nq) hdr->gmax[i2] = g1;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 1: per-pixel count and largest possible contribution; one thread per (query, point) ---------------------------
+    // (this kernel runs one level per phase: lb is the level)
+    {
+        const int H = uni(hdr->H[lb]), W = uni(hdr->W[lb]), nwc = uni(hdr->r[lb].nwc);
+        const int wr0 = uni(hdr->r[lb].wr0), wc0 = uni(hdr->r[lb].wc0), nwr = uni(hdr->r[lb].nwr), l0 = uni(hdr->lds_px[lb]);
+        for (int idx = tid; idx < nq * g.P; idx += kTiledThreads) {
+            const int qi = idx / g.P, pp = idx - qi * g.P;
+            const unsigned item = (unsigned)((b * g.Lq + hdr->qid[qi]) * g.M + m);
+            const unsigned pt = item * (unsigned)LP + (unsigned)(lb * g.P + pp);
+            const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
+            const BfpPoint p = bfp_resolve(xy.x, xy.y, aw[pt], H, W, wr0, wc0, nwr, nwc, l0, 0, row_elems, true);
+            if (p.base == -1) continue;
+            const float gm = hdr->gmax[qi];
+#pragma unroll
+            for (int cn = 0; cn < 4; ++cn) {
+                const int t = p.base >= 0 ? p.base + (cn & 1) + (cn >> 1) * nwc : p.t[cn];
+                if (t >= 0) {
+                    atomicMax(maxc + t, __float_as_uint(fabsf(p.w[cn]) * gm));   // non-negative floats order like uints
+                    atomicAdd(cnt + t, 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- per-pixel scale --------------------------------------------------------------------------------------------
+    for (int i = tid; i < phase_px; i += kTiledThreads) {
+        const float bound = (float)cnt[i] * __uint_as_float(maxc[i]);
+        const bool ok = bound > 0.f && bound < 3.0e38f;
+        maxc[i] = __float_as_uint(ok ? 1073741824.f / bound : 0.f);
+        cnt[i] = __float_as_uint(ok ? bound * (1.f / 1073741824.f) : 0.f);
+    }
+    __syncthreads();
+    stamp<1>(g, 3);
+
+    // ---- pass 2: quantise against the pixel's scale and accumulate; one channel per lane, lane i of every quad resolves
+    //      point i; the next query's operands are prefetched --------------------------------------------------------------------
+    {
+        const float *scale = reinterpret_cast<const float *>(maxc);
+        const int H = uni(hdr->H[lb]), W = uni(hdr->W[lb]), nwc = uni(hdr->r[lb].nwc);
+        const int wr0 = uni(hdr->r[lb].wr0), wc0 = uni(hdr->r[lb].wc0), nwr = uni(hdr->r[lb].nwr), l0 = uni(hdr->lds_px[lb]);
+        const int base_row = (b * g.S + uni(hdr->start[lb])) * row_elems + m * kTD;
+        const unsigned jp = (unsigned)(lb * g.P + ((j & 3) < g.P ? (j & 3) : 0));
+        // kBfpBatch queries per group are fetched together: the memory latency is paid once per batch, not per query
+        for (int i0 = grp; i0 < nq; i0 += kBfpBatch * kBfpGroups) {
+            unsigned items[kBfpBatch];
+            float2 xys[kBfpBatch];
+            float as[kBfpBatch], gs[kBfpBatch];
+#pragma unroll
+            for (int u = 0; u < kBfpBatch; ++u) {
+                const int i = i0 + u * kBfpGroups;
+                items[u] = (unsigned)((b * g.Lq + hdr->qid[i < nq ? i : i0]) * g.M + m);   // clamped; masked below
+                xys[u] = *reinterpret_cast<const float2 *>(loc + 2u * (items[u] * (unsigned)LP + jp));
+                as[u] = aw[items[u] * (unsigned)LP + jp];
+                gs[u] = grad_out[items[u] * (unsigned)kTD + j];
+            }
+#pragma unroll
+          for (int u = 0; u < kBfpBatch; ++u) {
+            if (i0 + u * kBfpGroups >= nq) break;   // uniform over the 32-lane group
+            float2 xy = xys[u];
+            float a = as[u];
+            const float gk = gs[u];
+            const unsigned item = items[u];
+            for (int pc = 0; pc < g.P; pc += 4) {
+                const int myp = pc + (j & 3);
+                const bool pv = myp < g.P;
+                if (pc > 0) {   // more than four points per level: loaded in place
+                    const unsigned pt = item * (unsigned)LP + (unsigned)(lb * g.P + (pv ? myp : 0));
+                    xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
+                    a = aw[pt];
+                }
+                BfpPoint p = bfp_resolve(xy.x, xy.y, a, H, W, wr0, wc0, nwr, nwc, l0, base_row, row_elems, pv);
+                // fold the destination pixel's scale into the weight (in-window corners only)
+                float ws[4];
+#pragma unroll
+                for (int cn = 0; cn < 4; ++cn) {
+                    const int t = p.base >= 0 ? p.base + (cn & 1) + (cn >> 1) * nwc : p.t[cn];
+                    ws[cn] = t >= 0 ? p.w[cn] * scale[t] : p.w[cn];
+                }
+#define MSDA_BFP_ONE(I)                                                                                                \
+    if (pc + I < g.P) {                                                                                                 \
+        const int base_ = quad_bcast_i<I>(p.base);                                                                      \
+        const float w0 = quad_bcast_f<I>(ws[0]), w1 = quad_bcast_f<I>(ws[1]);                                           \
+        const float w2 = quad_bcast_f<I>(ws[2]), w3 = quad_bcast_f<I>(ws[3]);                                           \
+        if (base_ >= 0) {                                                                                               \
+            int *a0 = acc + base_ * kTD + j, *a1 = a0 + nwc * kTD;                                                      \
+            atomicAdd(a0, __float2int_rn(w0 * gk));                                                                     \
+            atomicAdd(a0 + kTD, __float2int_rn(w1 * gk));                                                               \
+            atomicAdd(a1, __float2int_rn(w2 * gk));                                                                     \
+            atomicAdd(a1 + kTD, __float2int_rn(w3 * gk));                                                               \
+        } else if (base_ == -2) {                                                                                       \
+            const int tt[4] = {quad_bcast_i<I>(p.t[0]), quad_bcast_i<I>(p.t[1]), quad_bcast_i<I>(p.t[2]),               \
+                               quad_bcast_i<I>(p.t[3])};                                                                \
+            const float ww[4] = {w0, w1, w2, w3};                                                                       \
+            _Pragma("unroll") for (int cn = 0; cn < 4; ++cn)                                                            \
+            {                                                                                                           \
+                if (tt[cn] >= 0)                                                                                        \
+                    atomicAdd(acc + tt[cn] * kTD + j, __float2int_rn(ww[cn] * gk));                                     \
+                else if (tt[cn] < -1)                                                                                   \
+                    atomicAdd(grad_value + (-(tt[cn] + 2)) + j, ww[cn] * gk);                                           \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
+                MSDA_BFP_ONE(0)
+                MSDA_BFP_ONE(1)
+                MSDA_BFP_ONE(2)
+                MSDA_BFP_ONE(3)
+#undef MSDA_BFP_ONE
+            }
+          }
+        }
+    }
+    __syncthreads();
+    stamp<1>(g, 4);
+
+    // ---- flush: de-quantise, one 128-B row of global float atomics per touched in-map pixel ---------------------------------
+    const float *inv = reinterpret_cast<const float *>(cnt);
+    for (int l = lb; l < le; ++l) {
+        const int fr0 = uni(hdr->r[l].wr0), fc0 = uni(hdr->r[l].wc0), fnc = uni(hdr->r[l].nwc);
+        const int npx = uni(hdr->r[l].nwr) * fnc, Wl = uni(hdr->W[l]), Hl = uni(hdr->H[l]), l0 = uni(hdr->lds_px[l]);
+        float *dst = grad_value + (int64_t)(b * g.S + uni(hdr->start[l])) * row_elems + m * kTD + j;
+        for (int px = grp; px < npx; px += kBfpGroups) {
+            const int q = acc[(l0 + px) * kTD + j];
+            const int rr = px / fnc, cc = px - rr * fnc;
+            const int row = fr0 + rr, col = fc0 + cc;
+            if (q != 0 && row >= 0 && row < Hl && col >= 0 && col < Wl)
+                atomicAdd(dst + (int64_t)(row * Wl + col) * row_elems, (float)q * inv[l0 + px]);
+        }
+    }
+    stamp<1>(g, 5);
+}
+
 // ---- host entry points ----------------------------------------------------------------------------------------------
 inline TiledPlan plan_gather(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
 {
@@ -817,6 +1084,16 @@ inline TiledPlan plan_bwd_gather(int N, int S, int M, int D, int L, int Lq, int 
 {
     return plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin, kBwdLdsBudget,
                       kBwdGC * (int)sizeof(float));
+}
+inline TiledPlan plan_scatter_bfp(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
+{
+    TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin,
+                              kBfpLdsBudget, kBfpPxBytes);
+    if (pl.ok) {   // one level per phase = per workgroup: a query needs one operand fetch per workgroup (prefetchable)
+        for (int l = 0; l < L; ++l) pl.g.phase[l] = l;
+        pl.g.nphases = L;
+    }
+    return pl;
 }
 inline TiledPlan plan_scatter(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
 {
@@ -901,8 +1178,16 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
     if (e == hipSuccess) e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_kernel), lds_scatter);
     if (e != hipSuccess) return e;
     // grad_value (pre-zeroed by the caller of this function): LDS accumulation + one flush per touched pixel
-    hipLaunchKernelGGL(tiled_scatter_kernel, dim3(ps.grid * (kTD / kSD) * ps.g.nphases), dim3(kTiledThreads), lds_scatter,
-                       stream, loc, aw, grad_out, grad_value, ps.g);
+    const TiledPlan pb = plan_scatter_bfp(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
+    if (tiled_options().accum == 1 && pb.ok) {
+        e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_bfp_kernel), pb.lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(tiled_scatter_bfp_kernel, dim3(pb.grid * pb.g.nphases), dim3(kTiledThreads), pb.lds_bytes, stream,
+                           loc, aw, grad_out, grad_value, pb.g);
+    } else {
+        hipLaunchKernelGGL(tiled_scatter_kernel, dim3(ps.grid * (kTD / kSD) * ps.g.nphases), dim3(kTiledThreads), lds_scatter,
+                           stream, loc, aw, grad_out, grad_value, ps.g);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // grad_sampling_loc, grad_attn_weight: gather from LDS windows of value
