@@ -116,6 +116,8 @@ static_assert(sizeof(TileHeader) % 16 == 0, "windows must stay 16-byte aligned b
 struct TiledOptions {
     int region_px = 16;
     int margin = 6;
+    int persist = 512;   // 0 = one workgroup per work item; n > 0 = at most n workgroups (n/2 for the 1024-thread kernels)
+                         // walking the items (2 x 256 CUs by default: no per-item launch ramp)
     int accum = 0;   // grad_value window: 0 = f64 LDS atomics (exact), 1 = per-pixel block floating point on int32 atomics
     int dbg = 0;
     unsigned long long *stamps = nullptr;
@@ -555,8 +557,12 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
     constexpr int kGroups = kThreads / GL;                   // 128 queries in flight per pass over k
     constexpr int kHalves = kTD / GC;                        // channel passes per region
     const int nsub = BWD ? g.nphases : kHalves;
+    // Persistent form: the grid may be smaller than the number of work items; a workgroup then walks the items
+    // vb = blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8, so vb keeps the workgroup's XCD).
+    const int n_items = kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.GY * g.GX * nsub;
+    for (int vb = blockIdx.x; vb < n_items; vb += gridDim.x) {
     int pair, rs;
-    if (!decode_block(blockIdx.x, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) return;
+    if (!decode_block(vb, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) continue;
     const int region = rs / nsub, sub = rs - region * nsub;
     const int b = pair / g.M, m = pair - b * g.M;
     const int gy = region / g.GX, gx = region - gy * g.GX;
@@ -662,6 +668,8 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                 *reinterpret_cast<float4 *>(out + item[k] * (unsigned)kTD + chan) =
                     make_float4(acc_lo[k].x, acc_lo[k].y, acc_hi[k].x, acc_hi[k].y);
     }
+    __syncthreads();   // the next item rebuilds the header
+    }
 }
 
 // ---- backward: grad_value ---------------------------------------------------------------------------------
@@ -690,8 +698,10 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
     // (channel half, phase) of a region = the fastest-varying part of the XCD-local index: the workgroups of one
     // region run back to back on one XCD and share loc / attn / grad_out in its L2
     const int nsub = (kTD / kSD) * g.nphases;
+    const int n_items = kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.GY * g.GX * nsub;
+    for (int vb = blockIdx.x; vb < n_items; vb += gridDim.x) {   // persistent form, see tiled_gather_kernel
     int pair, rs;
-    if (!decode_block(blockIdx.x, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) return;
+    if (!decode_block(vb, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) continue;
     const int region = rs / nsub, sub = rs - region * nsub;
     const int half = sub % (kTD / kSD);
     const int b = pair / g.M, m = pair - b * g.M;
@@ -827,6 +837,7 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
         __syncthreads();
         stamp<1>(g, 4);
     }
+    }
 }
 
 // ---- backward: grad_value, integer accumulation ("block floating point per pixel") --------------------------------------
@@ -895,8 +906,10 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_bfp_kernel(
     TileHeader *hdr = reinterpret_cast<TileHeader *>(smem);
 
     const int nsub = g.nphases;
+    const int n_items = kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.GY * g.GX * nsub;
+    for (int vb = blockIdx.x; vb < n_items; vb += gridDim.x) {   // persistent form, see tiled_gather_kernel
     int pair, rs;
-    if (!decode_block(blockIdx.x, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) return;
+    if (!decode_block(vb, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) continue;
     const int region = rs / nsub, ph = rs - region * nsub;
     const int b = pair / g.M, m = pair - b * g.M;
     const int gy = region / g.GX, gx = region - gy * g.GX;
@@ -1072,6 +1085,8 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_bfp_kernel(
         }
     }
     stamp<1>(g, 5);
+    __syncthreads();   // the next item rebuilds the header and clears the window
+    }
 }
 
 // ---- host entry points ----------------------------------------------------------------------------------------------
@@ -1152,7 +1167,9 @@ inline hipError_t launch_fwd_tiled<float>(const float *value, const int64_t *, c
     auto kern = P == 4 ? &tiled_gather_kernel<false, true, kFwdGC> : &tiled_gather_kernel<false, false, kFwdGC>;
     hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pl.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(pl.grid * (kTD / kFwdGC)), dim3(kFwdGC == 16 ? 512 : 1024), pl.lds_bytes, stream, value, loc, aw,
+    int grid = pl.grid * (kTD / kFwdGC);
+    if (tiled_options().persist > 0 && grid > tiled_options().persist) grid = tiled_options().persist / kXcds * kXcds;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdGC == 16 ? 512 : 1024), pl.lds_bytes, stream, value, loc, aw,
                        (const float *)nullptr, out, (float *)nullptr, (float *)nullptr, pl.g);
     return hipGetLastError();
 }
@@ -1182,16 +1199,22 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
     if (tiled_options().accum == 1 && pb.ok) {
         e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_bfp_kernel), pb.lds_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(tiled_scatter_bfp_kernel, dim3(pb.grid * pb.g.nphases), dim3(kTiledThreads), pb.lds_bytes, stream,
-                           loc, aw, grad_out, grad_value, pb.g);
+        int sgrid = pb.grid * pb.g.nphases;
+        if (tiled_options().persist > 0 && sgrid > tiled_options().persist / 2) sgrid = tiled_options().persist / 2 / kXcds * kXcds;
+        hipLaunchKernelGGL(tiled_scatter_bfp_kernel, dim3(sgrid), dim3(kTiledThreads), pb.lds_bytes, stream, loc, aw, grad_out,
+                           grad_value, pb.g);
     } else {
-        hipLaunchKernelGGL(tiled_scatter_kernel, dim3(ps.grid * (kTD / kSD) * ps.g.nphases), dim3(kTiledThreads), lds_scatter,
-                           stream, loc, aw, grad_out, grad_value, ps.g);
+        int sgrid = ps.grid * (kTD / kSD) * ps.g.nphases;
+        if (tiled_options().persist > 0 && sgrid > tiled_options().persist / 2) sgrid = tiled_options().persist / 2 / kXcds * kXcds;
+        hipLaunchKernelGGL(tiled_scatter_kernel, dim3(sgrid), dim3(kTiledThreads), lds_scatter, stream, loc, aw, grad_out,
+                           grad_value, ps.g);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // grad_sampling_loc, grad_attn_weight: gather from LDS windows of value
-    hipLaunchKernelGGL(kern, dim3(pg.grid * pg.g.nphases), dim3(kBwdGC == 16 ? 512 : 1024), pg.lds_bytes, stream, value, loc, aw, grad_out,
+    int ggrid = pg.grid * pg.g.nphases;
+    if (tiled_options().persist > 0 && ggrid > tiled_options().persist / 2) ggrid = tiled_options().persist / 2 / kXcds * kXcds;
+    hipLaunchKernelGGL(kern, dim3(ggrid), dim3(kBwdGC == 16 ? 512 : 1024), pg.lds_bytes, stream, value, loc, aw, grad_out,
                        (float *)nullptr, grad_loc, grad_aw, pg.g);
     return hipGetLastError();
 }
