@@ -81,7 +81,7 @@ const char *msda_last_error(void);
  *   "fwd_variant"     0 = auto, 1 = direct gather kernel, 2 = LDS-window kernel (when applicable)
  *   "bwd_variant"     0 = auto, 1 = global-atomic kernel, 2 = LDS-accumulation kernels (when applicable)
  *   "bwd_direct_cpl"  channels per lane of the direct backward kernel (0 = auto, 1, 2, 4)
- *   "tile_region"     side of an LDS-window region, in pixels of the finest level (default 16)
+ *   "tile_region"     side of an LDS-window region, in pixels of the finest level (default 20)
  *   "tile_margin"     window margin around a region, in pixels of the sampled level (default 6)
  * Unknown key or value out of range -> MSDA_ERR_BAD_OPTION.  Options change speed, never results. */
 int msda_set_option(const char *key, int value);

@@ -44,7 +44,7 @@ constexpr int kGatherQPG = 4;        // queries per lane group (128 groups -> <=
 constexpr int kTiledThreads = 1024;
 constexpr int kSD = 16;              // channels per scatter workgroup (two workgroups per region: channel halves)
 constexpr int kScatterGroups = kTiledThreads / kSD;   // 16-lane groups, one query each
-constexpr int kLdsBudgetBytes = 124 * 1024;           // windows; header and per-group point records take the rest
+constexpr int kLdsBudgetBytes = 122 * 1024;           // windows; header (4.3 KB) and per-group point records (32 KB) take the rest
 
 struct TiledGeom {
     int N, S, M, Lq, L, P;
@@ -114,7 +114,7 @@ struct TileHeader {
 static_assert(sizeof(TileHeader) % 16 == 0, "windows must stay 16-byte aligned behind the header");
 
 struct TiledOptions {
-    int region_px = 16;
+    int region_px = 20;   // finest-level pixels per region side (swept on MI355X: 20 beats 16 by ~15 %; larger does not fit LDS)
     int margin = 6;
     int persist = 512;   // 0 = one workgroup per work item; n > 0 = at most n workgroups (n/2 for the 1024-thread kernels)
                          // walking the items (2 x 256 CUs by default: no per-item launch ramp)
@@ -134,10 +134,12 @@ struct TiledPlan {
     TiledGeom g{};
     size_t lds_bytes = 0;
     int grid = 0;
+    int max_px = 0;   // integer-accumulation scatter: largest single-level window
+    int max_q = 0;    // most queries in one region
 };
 
 inline TiledPlan plan_tiled(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi,
-                            int region_px, int margin, int budget_bytes, int px_bytes)
+                            int region_px, int margin, int budget_bytes, int px_bytes, int per_query_bytes = 0)
 {
     TiledPlan pl;
     if (D != kTD || L > kTL || L < 1 || Lq != S || P < 1 || L * P > 16) return pl;
@@ -160,7 +162,7 @@ inline TiledPlan plan_tiled(int N, int S, int M, int D, int L, int Lq, int P, co
         Hmax = g.H[l] > Hmax ? g.H[l] : Hmax;
         Wmax = g.W[l] > Wmax ? g.W[l] : Wmax;
     }
-    const int cap_px = budget_bytes / px_bytes;
+    int cap_px = budget_bytes / px_bytes;
     // region grid: ~region_px pixels of the finest level per side; refine until queries and windows fit
     for (int rp = region_px; rp >= 4; rp -= 2) {
         g.GY = (Hmax + rp - 1) / rp;
@@ -178,7 +180,8 @@ inline TiledPlan plan_tiled(int N, int S, int M, int D, int L, int Lq, int P, co
                 }
                 max_q = nq > max_q ? nq : max_q;
             }
-        bool fits = max_q <= kMaxRegionQueries;
+        cap_px = (budget_bytes - max_q * per_query_bytes) / px_bytes;   // LDS also holds per-query data in some kernels
+        bool fits = max_q <= kMaxRegionQueries && cap_px > 0;
         for (int l = 0; l < L; ++l) fits = fits && max_win[l] <= cap_px;
         if (!fits) continue;
         // greedy phases: consecutive levels share the LDS while their worst-case windows fit together
@@ -203,7 +206,8 @@ inline TiledPlan plan_tiled(int N, int S, int M, int D, int L, int Lq, int P, co
                 if (gx < g.GX) { g.cw0[l][gx] = (short)r.wc0; g.cwn[l][gx] = (short)r.nwc; }
             }
         }
-        pl.lds_bytes = sizeof(TileHeader) + (size_t)max_phase_px * px_bytes;
+        pl.lds_bytes = sizeof(TileHeader) + (size_t)max_phase_px * px_bytes + (size_t)max_q * per_query_bytes;
+        pl.max_q = max_q;
         pl.grid = kXcds * ((N * M + kXcds - 1) / kXcds) * g.GY * g.GX;
         pl.ok = true;
         return pl;
@@ -842,250 +846,223 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
 
 // ---- backward: grad_value, integer accumulation ("block floating point per pixel") --------------------------------------
 // ds_add_u32 costs ~2.6 CU cycles per wave instruction against ~13 for ds_add_f64 under this kernel's bank conflicts, and a
-// 32-bit accumulator holds all 32 channels of a pixel in 128 B, so one workgroup serves a whole (region, phase).  To make
+// 32-bit accumulator holds all 32 channels of a pixel in 128 B, so one workgroup serves a whole (region, level).  To make
 // integer accumulation safe for any input, every window pixel gets ITS OWN scale:
-//   pass 1  per pixel: cnt = number of in-window contributions, maxc = max |bilinear * attn| * max_c |grad_out[q, c]|
-//           (integer max / add LDS atomics on the float bit pattern, one lane per corner)
-//   scale   2^30 / (cnt * maxc): the quantised contributions of a pixel can never overflow 32 bits
-//   pass 2  acc[pixel][channel] += round(contribution * scale)   (ds_add_u32, one channel per lane)
-//   flush   acc / scale, one 128-B row global float atomic per touched pixel
-// Error per pixel-channel <= cnt^2 * maxc / 2^31 (worst case), ~sqrt(cnt) * cnt * maxc * 2^-32 typical: for 64
-// contributions that is 2e-6 / 1e-7 of the pixel's largest contribution -- float32-class, and the result is bitwise
-// reproducible (integer sums do not depend on order).  Contributions outside the window still use global float atomics.
+//   pass 0  gmax[q] = max_c |grad_out[q, c]| for the region's queries
+//   pass 1  one thread per (query, point): resolve the point once, park it as a record in LDS, and per in-window corner
+//           update cnt[pixel] += 1 and maxc[pixel] = max(maxc, |bilinear * attn| * gmax[q]) with integer LDS atomics
+//           (non-negative floats order like their bit patterns)
+//   scale   2^30 / (cnt * maxc): the quantised contributions of a pixel can never overflow 32 bits; the records'
+//           weights are multiplied by their destination pixel's scale
+//   pass 2  replay: acc[pixel][channel] += round(weight * grad_out[q, channel])   (ds_add_u32, one channel per lane)
+//   flush   acc / scale, one 128-B row global float atomic per touched in-map pixel
+// Error per pixel-channel <= cnt^2 * maxc / 2^31 in the worst case, ~sqrt(cnt) * cnt * maxc * 2^-32 typically: for 64
+// contributions 2e-6 / 1e-7 of the pixel's largest contribution -- float32-class -- and the in-window sum is bitwise
+// reproducible (integer sums do not depend on order).  Points with a corner outside the window use global float atomics.
 constexpr int kBfpGroups = kTiledThreads / kTD;          // 32-lane groups, one query each
 constexpr int kBfpPxBytes = kTD * 4 + 8;                 // int32 x 32 channels + {maxc | scale, cnt | 1/scale}
-constexpr int kBfpLdsBudget = 150 * 1024;
-constexpr int kBfpBatch = 4;                              // queries per group whose operands are fetched together
+constexpr int kBfpBatch = 4;                             // queries per group whose grad_out rows are fetched together
 
-struct BfpPoint {   // one sampling point resolved by one lane of a quad
-    int base;       // >= 0: window pixel index of corner (h_low, w_low), all four corners inside the window (incl. apron)
-                    //   -1: nothing to do;  -2: general point (per-corner window / global handling)
-    int t[4];       // general point only: per corner window pixel index (>= 0), -(global element offset) - 2, or -1
-    float w[4];     // bilinear weight x attention weight
+struct alignas(4) BfpRec {   // one sampling point of one of the region's queries, resolved in pass 1
+    int base;     // >= 0: window pixel of corner (h_low, w_low), all four corners inside the window (incl. apron);
+                  //   -1: nothing to do;  -2: general point, resolved again (per corner) when replayed
+    float w[4];   // bilinear weight x attention weight (x destination pixel scale after the scale step)
 };
 
-__device__ __forceinline__ BfpPoint bfp_resolve(float x, float y, float a, int H, int W, int wr0, int wc0, int nwr, int nwc,
-                                                int lds_px, int base_row, int row_elems, bool valid)
+// Per-corner targets of a general point: window pixel (>= 0), -(global element offset) - 2, or -1.
+__device__ __forceinline__ void bfp_general_targets(float x, float y, int H, int W, int wr0, int wc0, int nwr, int nwc,
+                                                    int lds_px, int base_row, int row_elems, int t[4])
 {
-    BfpPoint p;
-    p.base = -1;
-    p.t[0] = p.t[1] = p.t[2] = p.t[3] = -1;
-    p.w[0] = p.w[1] = p.w[2] = p.w[3] = 0.f;
+    t[0] = t[1] = t[2] = t[3] = -1;
     const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
-    if (!(valid && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) return p;
-    const float hf = floorf(h_im), wf = floorf(w_im);
-    const int h_low = (int)hf, w_low = (int)wf;
-    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-    p.w[0] = hh * hw * a;
-    p.w[1] = hh * lw * a;
-    p.w[2] = lh * hw * a;
-    p.w[3] = lh * lw * a;
+    if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) return;
+    const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
     const int rr = h_low - wr0, cc = w_low - wc0;
     const bool r0 = rr >= 0 && rr < nwr, r1 = rr + 1 >= 0 && rr + 1 < nwr;
     const bool c0 = cc >= 0 && cc < nwc, c1 = cc + 1 >= 0 && cc + 1 < nwc;
-    const int lbase = lds_px + rr * nwc + cc;
-    if (r0 && r1 && c0 && c1) {
-        p.base = lbase;
-        return p;
-    }
-    p.base = -2;
     const bool top = h_low >= 0, bot = h_low + 1 <= H - 1, lef = w_low >= 0, rig = w_low + 1 <= W - 1;
+    const int lbase = lds_px + rr * nwc + cc;
     const int gbase = base_row + (h_low * W + w_low) * row_elems;
-    if (top && lef) p.t[0] = (r0 && c0) ? lbase : -gbase - 2;
-    if (top && rig) p.t[1] = (r0 && c1) ? lbase + 1 : -(gbase + row_elems) - 2;
-    if (bot && lef) p.t[2] = (r1 && c0) ? lbase + nwc : -(gbase + W * row_elems) - 2;
-    if (bot && rig) p.t[3] = (r1 && c1) ? lbase + nwc + 1 : -(gbase + W * row_elems + row_elems) - 2;
-    return p;
+    if (top && lef) t[0] = (r0 && c0) ? lbase : -gbase - 2;
+    if (top && rig) t[1] = (r0 && c1) ? lbase + 1 : -(gbase + row_elems) - 2;
+    if (bot && lef) t[2] = (r1 && c0) ? lbase + nwc : -(gbase + W * row_elems) - 2;
+    if (bot && rig) t[3] = (r1 && c1) ? lbase + nwc + 1 : -(gbase + W * row_elems + row_elems) - 2;
 }
 
+template <bool P4>
 __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_bfp_kernel(
     const float *__restrict__ loc, const float *__restrict__ aw, const float *__restrict__ grad_out,
-    float *__restrict__ grad_value, const TiledGeom g)
+    float *__restrict__ grad_value, const TiledGeom g, const int max_phase_px)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TileHeader *hdr = reinterpret_cast<TileHeader *>(smem);
-
-    const int nsub = g.nphases;
-    const int n_items = kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.GY * g.GX * nsub;
-    for (int vb = blockIdx.x; vb < n_items; vb += gridDim.x) {   // persistent form, see tiled_gather_kernel
-    int pair, rs;
-    if (!decode_block(vb, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) continue;
-    const int region = rs / nsub, ph = rs - region * nsub;
-    const int b = pair / g.M, m = pair - b * g.M;
-    const int gy = region / g.GX, gx = region - gy * g.GX;
-    stamp<1>(g, 0);
-    const int nq = build_header(hdr, g, gy, gx);
-    stamp<1>(g, 1);
+    int *acc = reinterpret_cast<int *>(smem + sizeof(TileHeader));                       // [px][32]
+    unsigned *maxc = reinterpret_cast<unsigned *>(acc + (size_t)max_phase_px * kTD);     // pass 1: max bits; then scale
+    unsigned *cnt = maxc + max_phase_px;                                                  // pass 1: count; then 1/scale
+    BfpRec *recs = reinterpret_cast<BfpRec *>(cnt + max_phase_px);                        // [query][point]
 
     const int tid = threadIdx.x;
     const int j = tid & (kTD - 1), grp = tid / kTD;
     const int row_elems = g.M * kTD;
     const int LP = g.L * g.P;
+    const int nsub = g.nphases;   // one level per phase
+    const int n_items = kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.GY * g.GX * nsub;
+    for (int vb = blockIdx.x; vb < n_items; vb += gridDim.x) {   // persistent form, see tiled_gather_kernel
+        int pair, rs;
+        if (!decode_block(vb, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) continue;
+        const int region = rs / nsub, lv = rs - region * nsub;   // lv: the level this item scatters into
+        const int b = pair / g.M, m = pair - b * g.M;
+        const int gy = region / g.GX, gx = region - gy * g.GX;
+        stamp<1>(g, 0);
+        const int nq = build_header(hdr, g, gy, gx);
+        stamp<1>(g, 1);
 
-    int lb = g.L, le = 0, phase_px = 0;
-    for (int l = 0; l < g.L; ++l)
-        if (uni(hdr->phase[l]) == ph) {
-            lb = l < lb ? l : lb;
-            le = l + 1;
-            phase_px = uni(hdr->lds_px[l]) + uni(hdr->r[l].nwr) * uni(hdr->r[l].nwc);
+        const int H = uni(hdr->H[lv]), W = uni(hdr->W[lv]), nwc = uni(hdr->r[lv].nwc), nwr = uni(hdr->r[lv].nwr);
+        const int wr0 = uni(hdr->r[lv].wr0), wc0 = uni(hdr->r[lv].wc0);
+        const int npx = nwr * nwc;   // the window starts at LDS pixel 0 (one level per phase)
+        const int base_row = (b * g.S + uni(hdr->start[lv])) * row_elems + m * kTD;
+
+        for (int i = tid; i < npx * (kTD / 4); i += kTiledThreads) reinterpret_cast<int4 *>(acc)[i] = make_int4(0, 0, 0, 0);
+        for (int i = tid; i < npx; i += kTiledThreads) { maxc[i] = 0u; cnt[i] = 0u; }
+
+        // ---- pass 0: gmax[q]; 8 lanes x 4 channels per query, 128 queries per sweep -----------------------------------
+        for (int i = tid >> 3; i < nq; i += kTiledThreads / 8) {
+            const unsigned item = (unsigned)((b * g.Lq + hdr->qid[i]) * g.M + m);
+            const float4 v = *reinterpret_cast<const float4 *>(grad_out + item * (unsigned)kTD + 4u * (tid & 7));
+            float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+            mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xF, 0xF, true)));
+            mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x4E, 0xF, 0xF, true)));
+            mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x141, 0xF, 0xF, true)));
+            if ((tid & 7) == 0) hdr->gmax[i] = mx;
         }
-    int *acc = reinterpret_cast<int *>(smem + sizeof(TileHeader));            // [phase_px][32]
-    unsigned *maxc = reinterpret_cast<unsigned *>(acc + (size_t)phase_px * kTD);   // pass 1: max bits; then: scale (float)
-    unsigned *cnt = maxc + phase_px;                                           // pass 1: count;    then: 1/scale (float)
+        __syncthreads();
+        stamp<1>(g, 2);
 
-    for (int i = tid; i < phase_px * (kTD / 4); i += kTiledThreads) reinterpret_cast<int4 *>(acc)[i] = make_int4(0, 0, 0, 0);
-    for (int i = tid; i < 2 * phase_px; i += kTiledThreads) maxc[i] = 0u;
-    __syncthreads();
-    stamp<1>(g, 2);
-
-    // ---- pass 0: max_c |grad_out[q, c]| of every query (32 lanes = 32 channels; two queries in flight per group) ------
-    for (int i = grp; i < nq; i += 2 * kBfpGroups) {
-        const int i2 = i + kBfpGroups;
-        const unsigned it0 = (unsigned)((b * g.Lq + hdr->qid[i]) * g.M + m);
-        const unsigned it1 = (unsigned)((b * g.Lq + hdr->qid[i2 < nq ? i2 : i]) * g.M + m);
-        float g0 = fabsf(grad_out[it0 * (unsigned)kTD + j]), g1 = fabsf(grad_out[it1 * (unsigned)kTD + j]);
-#pragma unroll
-        for (int sft = 1; sft < kTD; sft <<= 1) {
-            g0 = fmaxf(g0, __shfl_xor(g0, sft, kWave));
-            g1 = fmaxf(g1, __shfl_xor(g1, sft, kWave));
-        }
-        if (j == 0) {
-            hdr->gmax[i] = g0;
-            if (i2 < nq) hdr->gmax[i2] = g1;
-        }
-    }
-    __syncthreads();
-
-    // ---- pass 1: per-pixel count and largest possible contribution; one thread per (query, point) ---------------------------
-    // (this kernel runs one level per phase: lb is the level)
-    {
-        const int H = uni(hdr->H[lb]), W = uni(hdr->W[lb]), nwc = uni(hdr->r[lb].nwc);
-        const int wr0 = uni(hdr->r[lb].wr0), wc0 = uni(hdr->r[lb].wc0), nwr = uni(hdr->r[lb].nwr), l0 = uni(hdr->lds_px[lb]);
+        // ---- pass 1: one thread per (query, point): record + per-pixel count / largest possible contribution ---------------------
         for (int idx = tid; idx < nq * g.P; idx += kTiledThreads) {
             const int qi = idx / g.P, pp = idx - qi * g.P;
             const unsigned item = (unsigned)((b * g.Lq + hdr->qid[qi]) * g.M + m);
-            const unsigned pt = item * (unsigned)LP + (unsigned)(lb * g.P + pp);
+            const unsigned pt = item * (unsigned)LP + (unsigned)(lv * g.P + pp);
             const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
-            const BfpPoint p = bfp_resolve(xy.x, xy.y, aw[pt], H, W, wr0, wc0, nwr, nwc, l0, 0, row_elems, true);
-            if (p.base == -1) continue;
-            const float gm = hdr->gmax[qi];
-#pragma unroll
-            for (int cn = 0; cn < 4; ++cn) {
-                const int t = p.base >= 0 ? p.base + (cn & 1) + (cn >> 1) * nwc : p.t[cn];
-                if (t >= 0) {
-                    atomicMax(maxc + t, __float_as_uint(fabsf(p.w[cn]) * gm));   // non-negative floats order like uints
-                    atomicAdd(cnt + t, 1u);
+            const float a = aw[pt];
+            BfpRec r;
+            r.base = -1;
+            r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0.f;
+            const float h_im = xy.y * (float)H - 0.5f, w_im = xy.x * (float)W - 0.5f;
+            if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                const float hf = floorf(h_im), wf = floorf(w_im);
+                const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+                r.w[0] = hh * hw * a;
+                r.w[1] = hh * lw * a;
+                r.w[2] = lh * hw * a;
+                r.w[3] = lh * lw * a;
+                const int rr = (int)hf - wr0, cc = (int)wf - wc0;
+                const bool inside = rr >= 0 && rr + 1 < nwr && cc >= 0 && cc + 1 < nwc;
+                r.base = inside ? rr * nwc + cc : -2;
+                const float gm = hdr->gmax[qi];
+                int t[4];
+                if (inside) {
+                    t[0] = r.base; t[1] = r.base + 1; t[2] = r.base + nwc; t[3] = r.base + nwc + 1;
+                } else {
+                    bfp_general_targets(xy.x, xy.y, H, W, wr0, wc0, nwr, nwc, 0, 0, row_elems, t);
                 }
+#pragma unroll
+                for (int cn = 0; cn < 4; ++cn)
+                    if (t[cn] >= 0) {
+                        atomicMax(maxc + t[cn], __float_as_uint(fabsf(r.w[cn]) * gm));
+                        atomicAdd(cnt + t[cn], 1u);
+                    }
+            }
+            recs[idx] = r;
+        }
+        __syncthreads();
+        // ---- per-pixel scale; a non-finite bound (inf / nan in grad_out or attn) poisons the pixel instead of hiding it ------
+        for (int i = tid; i < npx; i += kTiledThreads) {
+            const float bound = (float)cnt[i] * __uint_as_float(maxc[i]);
+            const bool ok = bound > 0.f && bound < 3.0e38f;
+            maxc[i] = __float_as_uint(ok ? 1073741824.f / bound : 0.f);
+            cnt[i] = __float_as_uint(bound > 0.f || bound != bound ? bound * (1.f / 1073741824.f) : 0.f);
+        }
+        __syncthreads();
+        const float *scale = reinterpret_cast<const float *>(maxc);
+        // fold the destination pixels' scales into the weights of the in-window records
+        for (int idx = tid; idx < nq * g.P; idx += kTiledThreads) {
+            const int base = recs[idx].base;
+            if (base >= 0) {
+                recs[idx].w[0] *= scale[base];
+                recs[idx].w[1] *= scale[base + 1];
+                recs[idx].w[2] *= scale[base + nwc];
+                recs[idx].w[3] *= scale[base + nwc + 1];
             }
         }
-    }
-    __syncthreads();
-    // ---- per-pixel scale --------------------------------------------------------------------------------------------
-    for (int i = tid; i < phase_px; i += kTiledThreads) {
-        const float bound = (float)cnt[i] * __uint_as_float(maxc[i]);
-        const bool ok = bound > 0.f && bound < 3.0e38f;
-        maxc[i] = __float_as_uint(ok ? 1073741824.f / bound : 0.f);
-        cnt[i] = __float_as_uint(ok ? bound * (1.f / 1073741824.f) : 0.f);
-    }
-    __syncthreads();
-    stamp<1>(g, 3);
+        __syncthreads();
+        stamp<1>(g, 3);
 
-    // ---- pass 2: quantise against the pixel's scale and accumulate; one channel per lane, lane i of every quad resolves
-    //      point i; the next query's operands are prefetched --------------------------------------------------------------------
-    {
-        const float *scale = reinterpret_cast<const float *>(maxc);
-        const int H = uni(hdr->H[lb]), W = uni(hdr->W[lb]), nwc = uni(hdr->r[lb].nwc);
-        const int wr0 = uni(hdr->r[lb].wr0), wc0 = uni(hdr->r[lb].wc0), nwr = uni(hdr->r[lb].nwr), l0 = uni(hdr->lds_px[lb]);
-        const int base_row = (b * g.S + uni(hdr->start[lb])) * row_elems + m * kTD;
-        const unsigned jp = (unsigned)(lb * g.P + ((j & 3) < g.P ? (j & 3) : 0));
-        // kBfpBatch queries per group are fetched together: the memory latency is paid once per batch, not per query
+        // ---- pass 2: replay; 32 lanes = 32 channels of one query, kBfpBatch queries' grad_out rows fetched together ------------
         for (int i0 = grp; i0 < nq; i0 += kBfpBatch * kBfpGroups) {
-            unsigned items[kBfpBatch];
-            float2 xys[kBfpBatch];
-            float as[kBfpBatch], gs[kBfpBatch];
+            float gs[kBfpBatch];
 #pragma unroll
             for (int u = 0; u < kBfpBatch; ++u) {
                 const int i = i0 + u * kBfpGroups;
-                items[u] = (unsigned)((b * g.Lq + hdr->qid[i < nq ? i : i0]) * g.M + m);   // clamped; masked below
-                xys[u] = *reinterpret_cast<const float2 *>(loc + 2u * (items[u] * (unsigned)LP + jp));
-                as[u] = aw[items[u] * (unsigned)LP + jp];
-                gs[u] = grad_out[items[u] * (unsigned)kTD + j];
+                const unsigned item = (unsigned)((b * g.Lq + hdr->qid[i < nq ? i : i0]) * g.M + m);
+                gs[u] = grad_out[item * (unsigned)kTD + j];
             }
 #pragma unroll
-          for (int u = 0; u < kBfpBatch; ++u) {
-            if (i0 + u * kBfpGroups >= nq) break;   // uniform over the 32-lane group
-            float2 xy = xys[u];
-            float a = as[u];
-            const float gk = gs[u];
-            const unsigned item = items[u];
-            for (int pc = 0; pc < g.P; pc += 4) {
-                const int myp = pc + (j & 3);
-                const bool pv = myp < g.P;
-                if (pc > 0) {   // more than four points per level: loaded in place
-                    const unsigned pt = item * (unsigned)LP + (unsigned)(lb * g.P + (pv ? myp : 0));
-                    xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
-                    a = aw[pt];
-                }
-                BfpPoint p = bfp_resolve(xy.x, xy.y, a, H, W, wr0, wc0, nwr, nwc, l0, base_row, row_elems, pv);
-                // fold the destination pixel's scale into the weight (in-window corners only)
-                float ws[4];
+            for (int u = 0; u < kBfpBatch; ++u) {
+                const int i = i0 + u * kBfpGroups;
+                if (i >= nq) break;   // uniform over the 32-lane group
+                const float gk = gs[u];
+                const int np = P4 ? 4 : g.P;
+                BfpRec rq[4];
+                if (P4) {   // the four records of the query are read together: one LDS latency per query, not per point
 #pragma unroll
-                for (int cn = 0; cn < 4; ++cn) {
-                    const int t = p.base >= 0 ? p.base + (cn & 1) + (cn >> 1) * nwc : p.t[cn];
-                    ws[cn] = t >= 0 ? p.w[cn] * scale[t] : p.w[cn];
+                    for (int pp = 0; pp < 4; ++pp) rq[pp] = recs[i * 4 + pp];
                 }
-#define MSDA_BFP_ONE(I)                                                                                                \
-    if (pc + I < g.P) {                                                                                                 \
-        const int base_ = quad_bcast_i<I>(p.base);                                                                      \
-        const float w0 = quad_bcast_f<I>(ws[0]), w1 = quad_bcast_f<I>(ws[1]);                                           \
-        const float w2 = quad_bcast_f<I>(ws[2]), w3 = quad_bcast_f<I>(ws[3]);                                           \
-        if (base_ >= 0) {                                                                                               \
-            int *a0 = acc + base_ * kTD + j, *a1 = a0 + nwc * kTD;                                                      \
-            atomicAdd(a0, __float2int_rn(w0 * gk));                                                                     \
-            atomicAdd(a0 + kTD, __float2int_rn(w1 * gk));                                                               \
-            atomicAdd(a1, __float2int_rn(w2 * gk));                                                                     \
-            atomicAdd(a1 + kTD, __float2int_rn(w3 * gk));                                                               \
-        } else if (base_ == -2) {                                                                                       \
-            const int tt[4] = {quad_bcast_i<I>(p.t[0]), quad_bcast_i<I>(p.t[1]), quad_bcast_i<I>(p.t[2]),               \
-                               quad_bcast_i<I>(p.t[3])};                                                                \
-            const float ww[4] = {w0, w1, w2, w3};                                                                       \
-            _Pragma("unroll") for (int cn = 0; cn < 4; ++cn)                                                            \
-            {                                                                                                           \
-                if (tt[cn] >= 0)                                                                                        \
-                    atomicAdd(acc + tt[cn] * kTD + j, __float2int_rn(ww[cn] * gk));                                     \
-                else if (tt[cn] < -1)                                                                                   \
-                    atomicAdd(grad_value + (-(tt[cn] + 2)) + j, ww[cn] * gk);                                           \
-            }                                                                                                           \
-        }                                                                                                               \
-    }
-                MSDA_BFP_ONE(0)
-                MSDA_BFP_ONE(1)
-                MSDA_BFP_ONE(2)
-                MSDA_BFP_ONE(3)
-#undef MSDA_BFP_ONE
+#pragma unroll
+                for (int pp = 0; pp < (P4 ? 4 : 16); ++pp) {
+                    if (!P4 && pp >= np) break;
+                    const BfpRec r = P4 ? rq[pp & 3] : recs[i * g.P + pp];   // same address in all 32 lanes: LDS broadcast
+                    if (r.base >= 0) {
+                        int *a0 = acc + r.base * kTD + j, *a1 = a0 + nwc * kTD;
+                        atomicAdd(a0, __float2int_rn(r.w[0] * gk));
+                        atomicAdd(a0 + kTD, __float2int_rn(r.w[1] * gk));
+                        atomicAdd(a1, __float2int_rn(r.w[2] * gk));
+                        atomicAdd(a1 + kTD, __float2int_rn(r.w[3] * gk));
+                    } else if (r.base == -2) {   // rare: a corner outside the window
+                        const unsigned item = (unsigned)((b * g.Lq + hdr->qid[i]) * g.M + m);
+                        const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * (item * (unsigned)LP + (unsigned)(lv * g.P + pp)));
+                        int t[4];
+                        bfp_general_targets(xy.x, xy.y, H, W, wr0, wc0, nwr, nwc, 0, base_row, row_elems, t);
+#pragma unroll
+                        for (int cn = 0; cn < 4; ++cn) {
+                            if (t[cn] >= 0)
+                                atomicAdd(acc + t[cn] * kTD + j, __float2int_rn(r.w[cn] * scale[t[cn]] * gk));
+                            else if (t[cn] < -1)
+                                atomicAdd(grad_value + (-(t[cn] + 2)) + j, r.w[cn] * gk);
+                        }
+                    }
+                }
             }
-          }
         }
-    }
-    __syncthreads();
-    stamp<1>(g, 4);
+        __syncthreads();
+        stamp<1>(g, 4);
 
-    // ---- flush: de-quantise, one 128-B row of global float atomics per touched in-map pixel ---------------------------------
-    const float *inv = reinterpret_cast<const float *>(cnt);
-    for (int l = lb; l < le; ++l) {
-        const int fr0 = uni(hdr->r[l].wr0), fc0 = uni(hdr->r[l].wc0), fnc = uni(hdr->r[l].nwc);
-        const int npx = uni(hdr->r[l].nwr) * fnc, Wl = uni(hdr->W[l]), Hl = uni(hdr->H[l]), l0 = uni(hdr->lds_px[l]);
-        float *dst = grad_value + (int64_t)(b * g.S + uni(hdr->start[l])) * row_elems + m * kTD + j;
-        for (int px = grp; px < npx; px += kBfpGroups) {
-            const int q = acc[(l0 + px) * kTD + j];
-            const int rr = px / fnc, cc = px - rr * fnc;
-            const int row = fr0 + rr, col = fc0 + cc;
-            if (q != 0 && row >= 0 && row < Hl && col >= 0 && col < Wl)
-                atomicAdd(dst + (int64_t)(row * Wl + col) * row_elems, (float)q * inv[l0 + px]);
+        // ---- flush: de-quantise, one 128-B row of global float atomics per touched in-map pixel ---------------------------------
+        {
+            const float *inv = reinterpret_cast<const float *>(cnt);
+            float *dst = grad_value + (int64_t)(b * g.S + uni(hdr->start[lv])) * row_elems + m * kTD + j;
+            for (int px = grp; px < npx; px += kBfpGroups) {
+                const int q = acc[px * kTD + j];
+                const float iv = inv[px];
+                const int rr = px / nwc, cc = px - rr * nwc;
+                const int row = wr0 + rr, col = wc0 + cc;
+                const bool poisoned = !(iv == iv) || fabsf(iv) > 3.0e38f;   // non-finite bound: keep the result non-finite
+                if ((q != 0 || poisoned) && row >= 0 && row < H && col >= 0 && col < W)
+                    atomicAdd(dst + (int64_t)(row * W + col) * row_elems, poisoned ? iv : (float)q * iv);
+            }
         }
-    }
-    stamp<1>(g, 5);
-    __syncthreads();   // the next item rebuilds the header and clears the window
+        stamp<1>(g, 5);
+        __syncthreads();   // the next item rebuilds the header and clears the window
     }
 }
 
@@ -1102,11 +1079,23 @@ inline TiledPlan plan_bwd_gather(int N, int S, int M, int D, int L, int Lq, int 
 }
 inline TiledPlan plan_scatter_bfp(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
 {
-    TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin,
-                              kBfpLdsBudget, kBfpPxBytes);
-    if (pl.ok) {   // one level per phase = per workgroup: a query needs one operand fetch per workgroup (prefetchable)
+    // LDS: header + window (136 B per pixel) + one 20-B record per (query, point) of the region, within 160 KiB
+    const int budget = 160 * 1024 - (int)sizeof(TileHeader) - 256;
+    TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin, budget,
+                              kBfpPxBytes, P * (int)sizeof(BfpRec));
+    if (pl.ok) {   // one level per phase = per work item; every window starts at LDS pixel 0
+        int max_px = 0;
+        for (int gy = 0; gy < pl.g.GY; ++gy)
+            for (int gx = 0; gx < pl.g.GX; ++gx)
+                for (int l = 0; l < L; ++l) {
+                    const LevelRect r = level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin);
+                    max_px = r.nwr * r.nwc > max_px ? r.nwr * r.nwc : max_px;
+                }
         for (int l = 0; l < L; ++l) pl.g.phase[l] = l;
         pl.g.nphases = L;
+        pl.lds_bytes = sizeof(TileHeader) + (size_t)max_px * kBfpPxBytes + (size_t)pl.max_q * P * sizeof(BfpRec);
+        pl.grid = pl.grid;   // per (pair, region); the launch multiplies by the number of levels
+        pl.max_px = max_px;
     }
     return pl;
 }
@@ -1197,12 +1186,13 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
     // grad_value (pre-zeroed by the caller of this function): LDS accumulation + one flush per touched pixel
     const TiledPlan pb = plan_scatter_bfp(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
     if (tiled_options().accum == 1 && pb.ok) {
-        e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_bfp_kernel), pb.lds_bytes);
+        auto skern = P == 4 ? &tiled_scatter_bfp_kernel<true> : &tiled_scatter_bfp_kernel<false>;
+        e = set_lds_limit(reinterpret_cast<const void *>(skern), pb.lds_bytes);
         if (e != hipSuccess) return e;
         int sgrid = pb.grid * pb.g.nphases;
         if (tiled_options().persist > 0 && sgrid > tiled_options().persist / 2) sgrid = tiled_options().persist / 2 / kXcds * kXcds;
-        hipLaunchKernelGGL(tiled_scatter_bfp_kernel, dim3(sgrid), dim3(kTiledThreads), pb.lds_bytes, stream, loc, aw, grad_out,
-                           grad_value, pb.g);
+        hipLaunchKernelGGL(skern, dim3(sgrid), dim3(kTiledThreads), pb.lds_bytes, stream, loc, aw, grad_out,
+                           grad_value, pb.g, pb.max_px);
     } else {
         int sgrid = ps.grid * (kTD / kSD) * ps.g.nphases;
         if (tiled_options().persist > 0 && sgrid > tiled_options().persist / 2) sgrid = tiled_options().persist / 2 / kXcds * kXcds;

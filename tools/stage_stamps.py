@@ -17,10 +17,14 @@ ap.add_argument("--call", default="E")
 ap.add_argument("--kernel", default="fwd")
 ap.add_argument("--loc", default="init")
 ap.add_argument("--which", type=int, default=0, help="1 = scatter only, 2 = gather only")
+ap.add_argument("--set", action="append", default=[], help="option=value")
 args = ap.parse_args()
 call = {"E": W.call_E, "Em": W.call_Em}[args.call](2)
 t = W.make_inputs(call, args.loc, seed=0, device="cuda")
 lib = _lib.load()
+for kv in args.set:
+    k, v = kv.split('=')
+    _lib.set_option(k, int(v))
 nwg = 20000
 buf = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
 
