@@ -153,8 +153,14 @@ msda::DirectGeom direct_geom(const Problem &pb, int C)
     g.G = G;
     g.logG = floor_log2(G);
     g.nchunks = (lanes + G - 1) / G;
+    // queries per block: whole passes of the block's lane groups; few passes when Lq is small (decoder calls) so that
+    // the grid still fills 256 CUs several times over, more passes (amortising the level table) when Lq is large
     const int per_iter = msda::kDirectWaves * (msda::kWave / G);
-    g.qtile = per_iter * 2 > 64 ? per_iter * 2 : 64;   // >= 2 passes per block amortise the level table
+    const int slots = msda::kXcds * ((pb.N * pb.M + msda::kXcds - 1) / msda::kXcds);
+    const int want_tiles = (4096 + slots - 1) / slots;
+    int passes = pb.Lq / (per_iter * want_tiles);
+    passes = passes < 1 ? 1 : (passes > 8 ? 8 : passes);
+    g.qtile = per_iter * passes;
     g.ntiles = (pb.Lq + g.qtile - 1) / g.qtile;
     const int LP = pb.L * pb.P;
     g.pbatch = LP < msda::kPointBatch ? LP : msda::kPointBatch;
