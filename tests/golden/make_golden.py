@@ -195,3 +195,77 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Module-level vectors: the reference's own nn.Module
+# (models/richsem/ops/modules/ms_deform_attn.py:30-115) run on the CPU.  The module file does
+# `from ..functions import MSDeformAttnFunction`, i.e. it needs its package and the compiled CUDA function; here the
+# module source file is loaded by path into a synthetic package whose `functions.MSDeformAttnFunction.apply`
+# forwards to the reference's own pure-PyTorch core (the function its authors ship "for debug and test"), so every
+# arithmetic step that produces the vectors is the reference's.
+def make_module_vectors():
+    core = load_reference_core()
+    pkg = types.ModuleType("_refops")
+    pkg.__path__ = []
+    fn_mod = types.ModuleType("_refops.functions")
+
+    class MSDeformAttnFunction:   # same call signature as the reference's autograd Function (ms_deform_attn_func.py:23)
+        @staticmethod
+        def apply(value, shapes, lsi, loc, aw, im2col_step):
+            return core(value, shapes, loc, aw)
+
+    fn_mod.MSDeformAttnFunction = MSDeformAttnFunction
+    mods = types.ModuleType("_refops.modules")
+    mods.__path__ = []
+    sys.modules.update({"_refops": pkg, "_refops.functions": fn_mod, "_refops.modules": mods})
+    path = "/root/reference/models/richsem/ops/modules/ms_deform_attn.py"
+    spec = importlib.util.spec_from_file_location("_refops.modules.ms_deform_attn", path)
+    m = importlib.util.module_from_spec(spec)
+    m.__package__ = "_refops.modules"
+    spec.loader.exec_module(m)
+    RefMSDeformAttn = m.MSDeformAttn
+
+    shapes = torch.as_tensor([(9, 14), (5, 7), (3, 4), (2, 2)], dtype=torch.long)
+    lsi = lsi_of(shapes)
+    S = int(shapes.prod(1).sum())
+    N, C, L, H, P = 2, 64, 4, 2, 4     # two heads of 32 channels: small fixture, same per-head width as RichSem
+    for name, ref_dim, Lq in (("module_encoder_ref2d", 2, S), ("module_decoder_ref4d", 4, 37)):
+        torch.manual_seed(20 if ref_dim == 2 else 21)
+        mod = RefMSDeformAttn(C, L, H, P).double()
+        with torch.no_grad():   # move away from the all-zero init so every parameter matters
+            mod.sampling_offsets.weight.normal_(0, 0.02)
+            mod.attention_weights.weight.normal_(0, 0.05)
+            mod.attention_weights.bias.normal_(0, 0.1)
+        gen = torch.Generator().manual_seed(99 + ref_dim)
+        query = torch.randn(N, Lq, C, generator=gen, dtype=torch.float64, requires_grad=True)
+        src = torch.randn(N, S, C, generator=gen, dtype=torch.float64, requires_grad=True)
+        if ref_dim == 2:   # pixel centres, as TransformerEncoder.get_reference_points with valid_ratio 1
+            refs = []
+            for Hh, Ww in shapes.tolist():
+                ry, rx = torch.meshgrid(torch.linspace(0.5, Hh - 0.5, Hh, dtype=torch.float64),
+                                        torch.linspace(0.5, Ww - 0.5, Ww, dtype=torch.float64), indexing="ij")
+                refs.append(torch.stack((rx.reshape(-1) / Ww, ry.reshape(-1) / Hh), -1))
+            rp = torch.cat(refs, 0)[None, :, None, :].expand(N, S, L, 2).contiguous()
+        else:              # boxes (cx, cy, w, h)
+            cxcy = torch.rand(N, Lq, 1, 2, generator=gen, dtype=torch.float64) * 0.8 + 0.1
+            wh = torch.rand(N, Lq, 1, 2, generator=gen, dtype=torch.float64) * 0.4 + 0.05
+            rp = torch.cat((cxcy, wh), -1).expand(N, Lq, L, 4).contiguous()
+        mask = torch.zeros(N, S, dtype=torch.bool)
+        mask[1, lsi[0] + 9:lsi[0] + 14] = True          # padded pixels of image 1
+        mask[1, -1] = True
+        out = mod(query, rp, src, shapes, lsi, mask)
+        go = torch.randn(out.shape, generator=gen, dtype=torch.float64)
+        out.backward(go)
+        sd = {k: v.detach().numpy() for k, v in mod.state_dict().items()}
+        grads = {k + ".grad": p.grad.numpy() for k, p in mod.named_parameters()}
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), query=query.detach().numpy(), src=src.detach().numpy(),
+                            reference_points=rp.numpy(), shapes=shapes.numpy(), lsi=lsi.numpy(), mask=mask.numpy(),
+                            out=out.detach().numpy(), grad_out=go.numpy(), grad_query=query.grad.numpy(),
+                            grad_src=src.grad.numpy(), **{"param." + k: v for k, v in sd.items()},
+                            **{"param." + k: v for k, v in grads.items()})
+        print(f"{name}: query{tuple(query.shape)} src{tuple(src.shape)} ref{tuple(rp.shape)} -> out{tuple(out.shape)}")
+
+
+if __name__ == "__main__":
+    make_module_vectors()

@@ -22,7 +22,8 @@ from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
+               if not os.path.basename(p).startswith("module_"))
 VARIANTS = [1, 2]   # 1 = direct kernels, 2 = tiled kernels where applicable (else falls back to direct)
 
 
