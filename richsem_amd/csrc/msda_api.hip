@@ -286,6 +286,7 @@ int msda_set_option(const char *key, int value)
     if (key && !strcmp(key, "tile_debug") && value >= 0 && value <= 255) { msda::tiled_options().dbg = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_accum") && (value == 0 || value == 1)) { msda::tiled_options().accum = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_persist") && value >= 0 && value <= 65536) { msda::tiled_options().persist = value; return MSDA_OK; }
+    if (key && !strcmp(key, "bwd_gather_halves") && (value == 0 || value == 1)) { msda::tiled_options().bwd_halves = value; return MSDA_OK; }
     return fail(MSDA_ERR_BAD_OPTION, "unknown option or value: %s=%d", key ? key : "(null)", value);
 }
 
@@ -299,6 +300,7 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "tile_margin")) { *value = msda::tiled_options().margin; return MSDA_OK; }
     if (key && !strcmp(key, "tile_accum")) { *value = msda::tiled_options().accum; return MSDA_OK; }
     if (key && !strcmp(key, "tile_persist")) { *value = msda::tiled_options().persist; return MSDA_OK; }
+    if (key && !strcmp(key, "bwd_gather_halves")) { *value = msda::tiled_options().bwd_halves; return MSDA_OK; }
     return fail(MSDA_ERR_BAD_OPTION, "unknown option: %s", key ? key : "(null)");
 }
 

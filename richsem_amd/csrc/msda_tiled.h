@@ -38,7 +38,9 @@ constexpr int kFwdLdsBudget = 75 * 1024;   // + header < 80 KiB: two workgroups 
 // Backward location / attention gradients need all 32 channels of a sample at once: 8 lanes per query, 1024 threads,
 // one workgroup per CU (two 16-channel passes with a read-modify-write of the per-point results measured slower).
 constexpr int kBwdGC = 32;
-constexpr int kBwdLdsBudget = 124 * 1024;   // three phases = three independent workgroups per region (measured faster than two)
+constexpr int kBwdLdsBudget = 124 * 1024;
+// ... alternatively on channel halves like the forward (two workgroups per CU, the first half's per-point results kept
+// in registers): needs one level per work item and P <= 4 (tile option "bwd_gather_halves")   // three phases = three independent workgroups per region (measured faster than two)
 constexpr int kGatherQPG = 4;        // queries per lane group (128 groups -> <= 512 queries per region)
 // Scatter kernel (backward grad_value): 16 channels x f64 = 128 B per window pixel, one workgroup per CU.
 constexpr int kTiledThreads = 1024;
@@ -116,6 +118,7 @@ static_assert(sizeof(TileHeader) % 16 == 0, "windows must stay 16-byte aligned b
 struct TiledOptions {
     int region_px = 20;   // finest-level pixels per region side (swept on MI355X: 20 beats 16 by ~15 %; larger does not fit LDS)
     int margin = 6;
+    int bwd_halves = 0;  // backward location/attention gradients: 0 = 32 channels at once (faster as measured), 1 = two 16-channel passes
     int persist = 512;   // 0 = one workgroup per work item; n > 0 = at most n workgroups (n/2 for the 1024-thread kernels)
                          // walking the items (2 x 256 CUs by default: no per-item launch ramp)
     int accum = 0;   // grad_value window: 0 = f64 LDS atomics (exact), 1 = per-pixel block floating point on int32 atomics
@@ -437,15 +440,16 @@ __device__ __forceinline__ void store_point_grads(float *__restrict__ grad_loc, 
 // point-count checks in the unrolled body.  Hot path = in-window points: one wave-divergent branch per point and
 // straight-line LDS reads + packed FMAs.  Points with a corner outside the window are rare; they are handled
 // afterwards in ONE run-time loop per query (not unrolled), with shuffles instead of DPP.
-// ACC (backward, second channel half): add to the stored per-point results instead of overwriting them.
-template <bool BWD, bool P4, bool ACC, int GC>
+// MODE (backward): 0 = all 32 channels in one pass: store the per-point results; 1 = first channel half: keep them in
+// `part` (lane i of the quad keeps point i); 2 = second channel half: add `part` and store.
+template <bool BWD, bool P4, int MODE, int GC>
 __device__ __forceinline__ void gather_level(const float *__restrict__ value, const float *__restrict__ loc,
                                              const float *__restrict__ aw, const float *win, const LevelCtx &lc,
                                              int row_elems, int P_, int j, int chan, const unsigned (&pt0)[kGatherQPG],
                                              const bool (&live)[kGatherQPG], const LevelOps &pre,
                                              v2f (&acc_lo)[kGatherQPG], v2f (&acc_hi)[kGatherQPG],
-                                             const float4 (&gq)[kGatherQPG], float *__restrict__ grad_loc,
-                                             float *__restrict__ grad_aw)
+                                             const float4 (&gq)[kGatherQPG], float (&part)[kGatherQPG][3],
+                                             float *__restrict__ grad_loc, float *__restrict__ grad_aw)
 {
     const int P = P4 ? 4 : P_;
     for (int pc = 0; pc < P; pc += 4) {
@@ -499,10 +503,18 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
             s_a = query_sum<GC>(s_a);                                                                                  \
             s_w = query_sum<GC>(s_w);                                                                                  \
             s_h = query_sum<GC>(s_h);                                                                                  \
-            /* lane I of the quad stores point I (dropped / general points: zeros here, general ones redone below) */ \
-            if (j == I)                                                                                                \
-                store_point_grads<ACC>(grad_loc, grad_aw, pt0[k] + pc + I, s_a, (float)lc.W * s_w * a,                 \
-                                       (float)lc.H * s_h * a);                                                         \
+            /* lane I of the quad owns point I (dropped / general points: zeros here, general ones redone below) */   \
+            if (j == I) {                                                                                              \
+                const float gx_ = (float)lc.W * s_w * a, gy_ = (float)lc.H * s_h * a;                                  \
+                if (MODE == 1) {                                                                                       \
+                    part[k][0] = s_a;                                                                                  \
+                    part[k][1] = gx_;                                                                                  \
+                    part[k][2] = gy_;                                                                                  \
+                } else {                                                                                               \
+                    store_point_grads<false>(grad_loc, grad_aw, pt0[k] + pc + I, s_a + (MODE == 2 ? part[k][0] : 0.f), \
+                                             gx_ + (MODE == 2 ? part[k][1] : 0.f), gy_ + (MODE == 2 ? part[k][2] : 0.f)); \
+                }                                                                                                      \
+            }                                                                                                          \
         }                                                                                                              \
     }
             MSDA_POINT(0)
@@ -530,10 +542,17 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
                         s_a = query_sum<GC>(s_a);
                         s_w = query_sum<GC>(s_w);
                         s_h = query_sum<GC>(s_h);
-                        // the fast pass stored zeros (ACC: left the first half's value) for this point: add ours on top
-                        if (j == i)
-                            store_point_grads<true>(grad_loc, grad_aw, pt0[k] + pc + i, s_a, (float)lc.W * s_w * a_,
-                                                    (float)lc.H * s_h * a_);
+                        // the fast pass gave this point zeros: add ours on top (first half: in `part`, else in memory)
+                        if (j == i) {
+                            const float gx_ = (float)lc.W * s_w * a_, gy_ = (float)lc.H * s_h * a_;
+                            if (MODE == 1) {
+                                part[k][0] += s_a;
+                                part[k][1] += gx_;
+                                part[k][2] += gy_;
+                            } else {
+                                store_point_grads<true>(grad_loc, grad_aw, pt0[k] + pc + i, s_a, gx_, gy_);
+                            }
+                        }
                     }
                 }
             }
@@ -590,6 +609,11 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
         acc_lo[k] = acc_hi[k] = (v2f){0.f, 0.f};
     }
 
+    // backward on channel halves keeps the first half's per-point results here; it then needs one level per work item and
+    // at most four points per level (host-enforced)
+    float part[kGatherQPG][3];
+#pragma unroll
+    for (int k = 0; k < kGatherQPG; ++k) part[k][0] = part[k][1] = part[k][2] = 0.f;
     const int ph_begin = BWD ? sub : 0, ph_end = BWD ? ph_begin + 1 : g.nphases;
     const int half_begin = BWD ? 0 : sub, half_end = BWD ? kHalves : sub + 1;
     int st = 2;
@@ -652,12 +676,15 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                 unsigned pt0[kGatherQPG];
 #pragma unroll
                 for (int k = 0; k < kGatherQPG; ++k) pt0[k] = item[k] * (unsigned)LP + (unsigned)(l * g.P);
-                if (BWD && half > 0)
-                    gather_level<BWD, P4, true, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                acc_hi, gq, grad_loc, grad_aw);
+                if (!BWD || kHalves == 1)
+                    gather_level<BWD, P4, 0, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
+                                                 acc_hi, gq, part, grad_loc, grad_aw);
+                else if (half == 0)
+                    gather_level<BWD, P4, 1, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
+                                                 acc_hi, gq, part, grad_loc, grad_aw);
                 else
-                    gather_level<BWD, P4, false, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, grad_loc, grad_aw);
+                    gather_level<BWD, P4, 2, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
+                                                 acc_hi, gq, part, grad_loc, grad_aw);
             }
             __syncthreads();   // the next fill overwrites the windows
             stamp<2>(g, st++);
@@ -1074,8 +1101,28 @@ inline TiledPlan plan_gather(int N, int S, int M, int D, int L, int Lq, int P, c
 }
 inline TiledPlan plan_bwd_gather(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
 {
-    return plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin, kBwdLdsBudget,
-                      kBwdGC * (int)sizeof(float));
+    if (tiled_options().bwd_halves && P <= 4) {   // channel halves: forward geometry, one level per work item
+        TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin,
+                                  kFwdLdsBudget, kFwdGC * (int)sizeof(float));
+        if (pl.ok) {
+            int max_px = 0;
+            for (int gy = 0; gy < pl.g.GY; ++gy)
+                for (int gx = 0; gx < pl.g.GX; ++gx)
+                    for (int l = 0; l < L; ++l) {
+                        const LevelRect r = level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin);
+                        max_px = r.nwr * r.nwc > max_px ? r.nwr * r.nwc : max_px;
+                    }
+            for (int l = 0; l < L; ++l) pl.g.phase[l] = l;
+            pl.g.nphases = L;
+            pl.lds_bytes = sizeof(TileHeader) + (size_t)max_px * kFwdGC * sizeof(float);
+            pl.max_px = kFwdGC;   // marks the channel-half configuration
+        }
+        return pl;
+    }
+    TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin, kBwdLdsBudget,
+                              kBwdGC * (int)sizeof(float));
+    pl.max_px = kBwdGC;
+    return pl;
 }
 inline TiledPlan plan_scatter_bfp(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
 {
@@ -1179,7 +1226,9 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
     const TiledPlan ps = plan_scatter(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
     if (!pg.ok || !ps.ok) return hipErrorInvalidValue;
     const size_t lds_scatter = ps.lds_bytes + sizeof(ScatterRec) * kScatterGroups * 16;
-    auto kern = P == 4 ? &tiled_gather_kernel<true, true, kBwdGC> : &tiled_gather_kernel<true, false, kBwdGC>;
+    const bool halves = pg.max_px == kFwdGC;
+    auto kern = halves ? (P == 4 ? &tiled_gather_kernel<true, true, kFwdGC> : &tiled_gather_kernel<true, false, kFwdGC>)
+                       : (P == 4 ? &tiled_gather_kernel<true, true, kBwdGC> : &tiled_gather_kernel<true, false, kBwdGC>);
     hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pg.lds_bytes);
     if (e == hipSuccess) e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_kernel), lds_scatter);
     if (e != hipSuccess) return e;
@@ -1203,8 +1252,9 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
     if (e != hipSuccess) return e;
     // grad_sampling_loc, grad_attn_weight: gather from LDS windows of value
     int ggrid = pg.grid * pg.g.nphases;
-    if (tiled_options().persist > 0 && ggrid > tiled_options().persist / 2) ggrid = tiled_options().persist / 2 / kXcds * kXcds;
-    hipLaunchKernelGGL(kern, dim3(ggrid), dim3(kBwdGC == 16 ? 512 : 1024), pg.lds_bytes, stream, value, loc, aw, grad_out,
+    const int gcap = halves ? tiled_options().persist : tiled_options().persist / 2;
+    if (tiled_options().persist > 0 && ggrid > gcap) ggrid = gcap / kXcds * kXcds;
+    hipLaunchKernelGGL(kern, dim3(ggrid), dim3(halves ? 512 : 1024), pg.lds_bytes, stream, value, loc, aw, grad_out,
                        (float *)nullptr, grad_loc, grad_aw, pg.g);
     return hipGetLastError();
 }

@@ -266,3 +266,53 @@ def test_full_size_properties(which):
             t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64))
     for a, b in zip(res[1], res[2]):
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("opts", [
+    {"tile_accum": 1},                       # integer (block floating point) grad_value accumulator
+    {"tile_persist": 0},                     # one workgroup per work item instead of persistent workgroups
+    {"bwd_gather_halves": 1},                # backward gather on channel halves
+    {"tile_region": 12, "tile_margin": 3},   # small windows: many samples take the general (global) path
+    {"tile_margin": 0},
+])
+@pytest.mark.parametrize("which", ["E", "Em"])
+def test_window_kernel_options_do_not_change_results(which, opts):
+    """Tuning options change speed, never results (include/richsem_msda.h)."""
+    defaults = {k: _lib.get_option(k) for k in opts}
+    try:
+        for k, v in opts.items():
+            _lib.set_option(k, v)
+        call = W.shrunk({"E": W.call_E, "Em": W.call_Em}[which](2), 4)
+        for loc_mode in ("init", "uniform"):
+            t = W.make_inputs(call, loc_mode, seed=21)
+            z = {k: v.numpy() for k, v in t.items()}
+            out, gv, gl, ga = run_gpu(z, 2)
+            oo = O.forward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"])
+            ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
+            tf, tg = tols(np.float32)
+            assert rel_err(out, oo) < tf
+            assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg
+    finally:
+        for k, v in defaults.items():
+            _lib.set_option(k, v)
+
+
+def test_integer_accumulator_error_is_float32_class():
+    """tile_accum=1 (per-pixel block floating point): error of grad_value against the f64 oracle stays within a few
+    float32 ulps of the tensor's scale -- same class as float atomics -- also with a 1000:1 spread of gradient
+    magnitudes between queries."""
+    call = W.shrunk(W.call_E(2), 4)
+    t = W.make_inputs(call, "init", seed=33)
+    scale = torch.ones(call.N, call.Lq, 1)
+    scale[:, ::7] = 1000.0
+    t["grad_out"] = t["grad_out"] * scale
+    z = {k: v.numpy() for k, v in t.items()}
+    ogv, _, _ = O.backward(z["value"].astype(np.float64), z["shapes"], z["lsi"], z["loc"].astype(np.float64),
+                           z["aw"].astype(np.float64), z["grad_out"].astype(np.float64))
+    errs = {}
+    for accum in (0, 1):
+        _lib.set_option("tile_accum", accum)
+        _, gv, _, _ = run_gpu(z, 2)
+        errs[accum] = rel_err(gv, ogv)
+    _lib.set_option("tile_accum", 0)
+    assert errs[0] < 2e-6 and errs[1] < 2e-5, errs
