@@ -81,6 +81,28 @@ def total_images(images_per_gpu, world):
     return images_per_gpu * world
 
 
+def measured_traffic(hip_kernels):
+    """HBM bytes per launch of the given HIP kernels from the latest committed PMC summary (profiles/*_traffic.json,
+    made by profiles/summarize.py from separate rocprofv3 --pmc passes), or None.  The counters cannot be read from
+    inside this process; the number is attached so that it sits next to the algorithmic bytes it is compared with."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=os.path.getmtime)
+    if not files:
+        return None
+    try:
+        table = json.load(open(files[-1]))["kernels"]
+    except Exception:
+        return None
+    total, found = 0, 0
+    for want in hip_kernels.split(" + "):
+        want = want.strip().rstrip(">")   # "tiled_gather_kernel<false" matches "...tiled_gather_kernel<false, true, 16>"
+        hits = [v for k, v in table.items() if want in k and v["hbm_bytes_est"] > 0]
+        if hits:
+            total += max(h["hbm_bytes_est"] for h in hits)   # E-sized launch of that kernel
+            found += 1
+    return total if found else None
+
+
 def cpu_baseline(calls, loc_mode, n_images):
     """Oracle timed on the host: one forward+backward of each distinct call, scaled by its repetitions."""
     from oracle import msda_oracle as O
@@ -185,7 +207,7 @@ def main():
                             "alg_bytes": nbytes, "GBps": round(nbytes / (avg * 1e-3) / 1e9, 1)})
         dom = max(kernels, key=lambda k: k["total_ms"])
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "hip_kernels": dom["hip_kernels"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom["hip_kernels"]),
                     "alg_bytes_per_launch": dom["alg_bytes"], "avg_launch_us": dom["avg_us"]}
         line = {
             "metric": "training images/sec, RichSem R50 4-scale 1333x800 (MSDeformAttn hot path: 12 fwd + 12 bwd "

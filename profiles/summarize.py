@@ -66,6 +66,15 @@ def main():
         f = sum(fetch.get(key, [0])) / max(1, len(fetch.get(key, [0])))
         w = sum(write.get(key, [0])) / max(1, len(write.get(key, [0])))
         out.append(f"| `{key[0][:60]}` | {key[1]} | {f:.0f} | {w:.0f} | {(2 * f + w) * 1024 / 1e6:.1f} |")
+    # machine-readable traffic table for bench.py's roofline.traffic (bytes per launch, corrected as above)
+    traffic = {}
+    for key in sorted(set(fetch) | set(write)):
+        f = sum(fetch.get(key, [0])) / max(1, len(fetch.get(key, [0])))
+        w = sum(write.get(key, [0])) / max(1, len(write.get(key, [0])))
+        traffic[f"{key[0]}|{key[1]}"] = {"fetch_size_kib": f, "write_size_kib": w, "hbm_bytes_est": int((2 * f + w) * 1024)}
+    json.dump({"tag": tag, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; read side doubled "
+               "(gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section)", "kernels": traffic},
+              open(os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{tag}_traffic.json"), "w"), indent=1)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{tag}_summary.md")
     open(path, "w").write("\n".join(out) + "\n")
     print("wrote", path)
