@@ -46,7 +46,8 @@ constexpr int kGatherQPG = 4;        // queries per lane group (128 groups -> <=
 constexpr int kTiledThreads = 1024;
 constexpr int kSD = 16;              // channels per scatter workgroup (two workgroups per region: channel halves)
 constexpr int kScatterGroups = kTiledThreads / kSD;   // 16-lane groups, one query each
-constexpr int kLdsBudgetBytes = 122 * 1024;           // windows; header (4.3 KB) and per-group point records (32 KB) take the rest
+constexpr int kLdsBudgetBytes = 152 * 1024;           // windows; the header takes the rest
+constexpr int kScatterBatch = 2;                      // queries per group whose operands are fetched together
 
 struct TiledGeom {
     int N, S, M, Lq, L, P;
@@ -723,8 +724,7 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TileHeader *hdr = reinterpret_cast<TileHeader *>(smem);
-    ScatterRec *recs = reinterpret_cast<ScatterRec *>(smem + sizeof(TileHeader));
-    double *win = reinterpret_cast<double *>(smem + sizeof(TileHeader) + sizeof(ScatterRec) * kScatterGroups * 16);
+    double *win = reinterpret_cast<double *>(smem + sizeof(TileHeader));
 
     // (channel half, phase) of a region = the fastest-varying part of the XCD-local index: the workgroups of one
     // region run back to back on one XCD and share loc / attn / grad_out in its L2
@@ -746,15 +746,6 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
     const int row_elems = g.M * kTD;
     const int LP = g.L * g.P;
     const int ch0 = m * kTD + half * kSD;   // first channel of this workgroup inside a pixel row
-    ScatterRec *my = recs + grp * 16;
-
-    // this lane's sampling point: level constants (lane-varying, read once)
-    const int lj = j < LP ? j / g.P : 0;
-    const int Hj = hdr->H[lj], Wj = hdr->W[lj];
-    const int wr0 = hdr->r[lj].wr0, wc0 = hdr->r[lj].wc0, nwr = hdr->r[lj].nwr, nwc = hdr->r[lj].nwc;
-    const int ldsj = hdr->lds_px[lj], phj = j < LP ? hdr->phase[lj] : -1;
-    const int basej = (b * g.S + hdr->start[lj]) * row_elems + ch0;
-
     {
         const int ph = sub / (kTD / kSD);   // one LDS phase per workgroup: the phases of a region are independent here
         // ---- clear this phase's accumulation windows ---------------------------------------------------------
@@ -766,85 +757,102 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
         __syncthreads();
         stamp<1>(g, 2);
 
-        // ---- accumulate: one query per 16-lane group, next query's operands prefetched --------------------------
-        const int jp = j < LP ? j : 0;
-        float2 n_xy = make_float2(0.f, 0.f);
-        float n_a = 0.f, n_g = 0.f;
-        if (grp < nq) {
-            const int64_t item = (int64_t)(b * g.Lq + hdr->qid[grp]) * g.M + m;
-            n_xy = *reinterpret_cast<const float2 *>(loc + (item * LP + jp) * 2);
-            n_a = aw[item * LP + jp];
-            n_g = grad_out[item * kTD + half * kSD + j];
-        }
-        for (int i = grp; i < nq; i += kScatterGroups) {
-            const float2 xy = n_xy;
-            const float a = n_a, gk = n_g;
-            if (i + kScatterGroups < nq) {
-                const int64_t item = (int64_t)(b * g.Lq + hdr->qid[i + kScatterGroups]) * g.M + m;
-                n_xy = *reinterpret_cast<const float2 *>(loc + (item * LP + jp) * 2);
-                n_a = aw[item * LP + jp];
-                n_g = grad_out[item * kTD + half * kSD + j];
+        // ---- accumulate: a query = 16 lanes (4 quads); lane i of every quad resolves point i of the current level and the
+        //      quad shares it by DPP broadcast (no LDS records); kScatterBatch queries per group are fetched together ---------
+        for (int i0 = grp; i0 < nq; i0 += kScatterBatch * kScatterGroups) {
+            unsigned items[kScatterBatch];
+            float gks[kScatterBatch];
+#pragma unroll
+            for (int u = 0; u < kScatterBatch; ++u) {
+                const int i = i0 + u * kScatterGroups;
+                items[u] = (unsigned)((b * g.Lq + hdr->qid[i < nq ? i : i0]) * g.M + m);   // clamped; masked below
+                gks[u] = grad_out[items[u] * (unsigned)kTD + half * kSD + j];
             }
-            if (phj == ph) {   // resolve my point of this query
-                ScatterRec r;
-                r.t[0] = r.t[1] = r.t[2] = r.t[3] = -1;
-                r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0.f;
-                const float h_im = xy.y * (float)Hj - 0.5f, w_im = xy.x * (float)Wj - 0.5f;
-                if (h_im > -1.f && w_im > -1.f && h_im < (float)Hj && w_im < (float)Wj) {
-                    const float hf = floorf(h_im), wf = floorf(w_im);
-                    const int h_low = (int)hf, w_low = (int)wf;
-                    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-                    r.w[0] = hh * hw * a;
-                    r.w[1] = hh * lw * a;
-                    r.w[2] = lh * hw * a;
-                    r.w[3] = lh * lw * a;
-                    const bool top = h_low >= 0, bot = h_low + 1 <= Hj - 1, lef = w_low >= 0, rig = w_low + 1 <= Wj - 1;
-                    const int rr = h_low - wr0, cc = w_low - wc0;
-                    const bool r0 = rr >= 0 && rr < nwr, r1 = rr + 1 >= 0 && rr + 1 < nwr;
-                    const bool c0 = cc >= 0 && cc < nwc, c1 = cc + 1 >= 0 && cc + 1 < nwc;
-                    const int lbase = (ldsj + rr * nwc + cc) * kSD;
-                    const int gbase = basej + (h_low * Wj + w_low) * row_elems;
-                    if (r0 && r1 && c0 && c1) {   // incl. corners on the window's apron beyond the map: never flushed
-                        r.t[0] = lbase;   // all four corners inside the window: one base, fixed strides
-                        r.t[1] = -3;
-                    } else {
-                        if (top && lef) r.t[0] = (r0 && c0) ? lbase : -gbase - 2;
-                        if (top && rig) r.t[1] = (r0 && c1) ? lbase + kSD : -(gbase + row_elems) - 2;
-                        if (bot && lef) r.t[2] = (r1 && c0) ? lbase + nwc * kSD : -(gbase + Wj * row_elems) - 2;
-                        if (bot && rig) r.t[3] = (r1 && c1) ? lbase + nwc * kSD + kSD : -(gbase + Wj * row_elems + row_elems) - 2;
-                    }
-                }
-                my[j] = r;
-            }
-            __builtin_amdgcn_wave_barrier();   // a group lives inside one wave; same-wave LDS traffic is in order
             for (int l = 0; l < g.L; ++l) {
                 if (uni(hdr->phase[l]) != ph) continue;
-                const int row2 = uni(hdr->r[l].nwc) * kSD;   // f64 elements between vertically adjacent window pixels
-                for (int p = 0; p < g.P; ++p) {
-                    const ScatterRec r = my[l * g.P + p];
-                    if (r.t[1] == -3) {   // uniform over the 16-lane group
-                        double *p0 = win + r.t[0] + j, *p1 = p0 + row2;
-                        if (!(g.dbg & 8)) {
-                            atomicAdd(p0, (double)(r.w[0] * gk));
-                            atomicAdd(p0 + kSD, (double)(r.w[1] * gk));
-                            atomicAdd(p1, (double)(r.w[2] * gk));
-                            atomicAdd(p1 + kSD, (double)(r.w[3] * gk));
-                        }
-                    } else {
+                const int H = uni(hdr->H[l]), W = uni(hdr->W[l]);
+                const int wr0 = uni(hdr->r[l].wr0), wc0 = uni(hdr->r[l].wc0), nwr = uni(hdr->r[l].nwr), nwc = uni(hdr->r[l].nwc);
+                const int ldsl = uni(hdr->lds_px[l]);
+                const int base_l = (b * g.S + uni(hdr->start[l])) * row_elems + ch0;
+                const int row2 = nwc * kSD;   // f64 elements between vertically adjacent window pixels
+                for (int pc = 0; pc < g.P; pc += 4) {
+                    const int myp = pc + (j & 3);
+                    const bool pv = myp < g.P;
+                    float2 xys[kScatterBatch];
+                    float as[kScatterBatch];
 #pragma unroll
-                        for (int cn = 0; cn < 4; ++cn) {
-                            const int t = r.t[cn];
-                            const float v = r.w[cn] * gk;
-                            if (t >= 0) {
-                                if (!(g.dbg & 8)) atomicAdd(win + t + j, (double)v);
-                            } else if (t < -1) {
-                                if (!(g.dbg & 4)) atomicAdd(grad_value + (-(t + 2)) + j, v);
+                    for (int u = 0; u < kScatterBatch; ++u) {
+                        const unsigned pt = items[u] * (unsigned)LP + (unsigned)(l * g.P + (pv ? myp : 0));
+                        xys[u] = *reinterpret_cast<const float2 *>(loc + 2u * pt);
+                        as[u] = aw[pt];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kScatterBatch; ++u) {
+                        if (i0 + u * kScatterGroups >= nq) break;   // uniform over the 16-lane group
+                        const float gk = gks[u];
+                        // resolve this lane's point: base >= 0: LDS f64 index of corner (h_low, w_low), all four corners in the
+                        // window (apron included); -1: nothing; -2: general point with per-corner targets t[]
+                        int base = -1, t0 = -1, t1 = -1, t2 = -1, t3 = -1;
+                        float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+                        const float h_im = xys[u].y * (float)H - 0.5f, w_im = xys[u].x * (float)W - 0.5f;
+                        if (pv && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                            const float hf = floorf(h_im), wf = floorf(w_im);
+                            const int h_low = (int)hf, w_low = (int)wf;
+                            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+                            w0 = hh * hw * as[u];
+                            w1 = hh * lw * as[u];
+                            w2 = lh * hw * as[u];
+                            w3 = lh * lw * as[u];
+                            const int rr = h_low - wr0, cc = w_low - wc0;
+                            const bool r0 = rr >= 0 && rr < nwr, r1 = rr + 1 >= 0 && rr + 1 < nwr;
+                            const bool c0 = cc >= 0 && cc < nwc, c1 = cc + 1 >= 0 && cc + 1 < nwc;
+                            const int lbase = (ldsl + rr * nwc + cc) * kSD;
+                            if (r0 && r1 && c0 && c1) {
+                                base = lbase;
+                            } else {
+                                base = -2;
+                                const bool top = h_low >= 0, bot = h_low + 1 <= H - 1, lef = w_low >= 0, rig = w_low + 1 <= W - 1;
+                                const int gbase = base_l + (h_low * W + w_low) * row_elems;
+                                if (top && lef) t0 = (r0 && c0) ? lbase : -gbase - 2;
+                                if (top && rig) t1 = (r0 && c1) ? lbase + kSD : -(gbase + row_elems) - 2;
+                                if (bot && lef) t2 = (r1 && c0) ? lbase + row2 : -(gbase + W * row_elems) - 2;
+                                if (bot && rig) t3 = (r1 && c1) ? lbase + row2 + kSD : -(gbase + W * row_elems + row_elems) - 2;
                             }
                         }
+#define MSDA_SC_ONE(I)                                                                                                 \
+    if (pc + I < g.P) {                                                                                                 \
+        const int base_ = quad_bcast_i<I>(base);                                                                        \
+        const float v0 = quad_bcast_f<I>(w0) * gk, v1 = quad_bcast_f<I>(w1) * gk;                                       \
+        const float v2 = quad_bcast_f<I>(w2) * gk, v3 = quad_bcast_f<I>(w3) * gk;                                       \
+        if (base_ >= 0) {                                                                                               \
+            double *p0 = win + base_ + j, *p1 = p0 + row2;                                                              \
+            if (!(g.dbg & 8)) {                                                                                         \
+                atomicAdd(p0, (double)v0);                                                                              \
+                atomicAdd(p0 + kSD, (double)v1);                                                                        \
+                atomicAdd(p1, (double)v2);                                                                              \
+                atomicAdd(p1 + kSD, (double)v3);                                                                        \
+            }                                                                                                           \
+        } else if (base_ == -2) {                                                                                       \
+            const int tt[4] = {quad_bcast_i<I>(t0), quad_bcast_i<I>(t1), quad_bcast_i<I>(t2), quad_bcast_i<I>(t3)};     \
+            const float vv[4] = {v0, v1, v2, v3};                                                                       \
+            _Pragma("unroll") for (int cn = 0; cn < 4; ++cn)                                                            \
+            {                                                                                                           \
+                if (tt[cn] >= 0) {                                                                                      \
+                    if (!(g.dbg & 8)) atomicAdd(win + tt[cn] + j, (double)vv[cn]);                                      \
+                } else if (tt[cn] < -1) {                                                                               \
+                    if (!(g.dbg & 4)) atomicAdd(grad_value + (-(tt[cn] + 2)) + j, vv[cn]);                              \
+                }                                                                                                       \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
+                        MSDA_SC_ONE(0)
+                        MSDA_SC_ONE(1)
+                        MSDA_SC_ONE(2)
+                        MSDA_SC_ONE(3)
+#undef MSDA_SC_ONE
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
         stamp<1>(g, 3);
@@ -1182,6 +1190,18 @@ inline bool tiled_bwd_applicable<float>(int N, int S, int M, int D, int L, int L
     return plan_bwd_gather(N, S, M, D, L, Lq, P, shapes, lsi).ok && plan_scatter(N, S, M, D, L, Lq, P, shapes, lsi).ok;
 }
 
+// Persistent grid size: at most `cap` workgroups, a multiple of 8 (XCD affinity), and with cap/8 coprime to the number of
+// sub-items per region -- otherwise a workgroup's stride through the item list would always land on the same kind of
+// sub-item (e.g. always the three-level phase) and the work would be badly balanced.
+inline int persistent_grid(int total, int cap, int nsub)
+{
+    if (cap <= 0 || total <= cap) return total;
+    auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+    int g8 = cap / kXcds;
+    while (g8 > 1 && gcd(g8, nsub) != 1) --g8;
+    return g8 * kXcds;
+}
+
 inline hipError_t set_lds_limit(const void *fn, size_t bytes)
 {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -1203,8 +1223,7 @@ inline hipError_t launch_fwd_tiled<float>(const float *value, const int64_t *, c
     auto kern = P == 4 ? &tiled_gather_kernel<false, true, kFwdGC> : &tiled_gather_kernel<false, false, kFwdGC>;
     hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pl.lds_bytes);
     if (e != hipSuccess) return e;
-    int grid = pl.grid * (kTD / kFwdGC);
-    if (tiled_options().persist > 0 && grid > tiled_options().persist) grid = tiled_options().persist / kXcds * kXcds;
+    const int grid = persistent_grid(pl.grid * (kTD / kFwdGC), tiled_options().persist, kTD / kFwdGC);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdGC == 16 ? 512 : 1024), pl.lds_bytes, stream, value, loc, aw,
                        (const float *)nullptr, out, (float *)nullptr, (float *)nullptr, pl.g);
     return hipGetLastError();
@@ -1225,7 +1244,7 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
     const TiledPlan pg = plan_bwd_gather(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
     const TiledPlan ps = plan_scatter(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
     if (!pg.ok || !ps.ok) return hipErrorInvalidValue;
-    const size_t lds_scatter = ps.lds_bytes + sizeof(ScatterRec) * kScatterGroups * 16;
+    const size_t lds_scatter = ps.lds_bytes;
     const bool halves = pg.max_px == kFwdGC;
     auto kern = halves ? (P == 4 ? &tiled_gather_kernel<true, true, kFwdGC> : &tiled_gather_kernel<true, false, kFwdGC>)
                        : (P == 4 ? &tiled_gather_kernel<true, true, kBwdGC> : &tiled_gather_kernel<true, false, kBwdGC>);
@@ -1238,22 +1257,20 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
         auto skern = P == 4 ? &tiled_scatter_bfp_kernel<true> : &tiled_scatter_bfp_kernel<false>;
         e = set_lds_limit(reinterpret_cast<const void *>(skern), pb.lds_bytes);
         if (e != hipSuccess) return e;
-        int sgrid = pb.grid * pb.g.nphases;
-        if (tiled_options().persist > 0 && sgrid > tiled_options().persist / 2) sgrid = tiled_options().persist / 2 / kXcds * kXcds;
+        const int sgrid = persistent_grid(pb.grid * pb.g.nphases, tiled_options().persist / 2, pb.g.nphases);
         hipLaunchKernelGGL(skern, dim3(sgrid), dim3(kTiledThreads), pb.lds_bytes, stream, loc, aw, grad_out,
                            grad_value, pb.g, pb.max_px);
     } else {
-        int sgrid = ps.grid * (kTD / kSD) * ps.g.nphases;
-        if (tiled_options().persist > 0 && sgrid > tiled_options().persist / 2) sgrid = tiled_options().persist / 2 / kXcds * kXcds;
+        const int sgrid = persistent_grid(ps.grid * (kTD / kSD) * ps.g.nphases, tiled_options().persist / 2,
+                                          (kTD / kSD) * ps.g.nphases);
         hipLaunchKernelGGL(tiled_scatter_kernel, dim3(sgrid), dim3(kTiledThreads), lds_scatter, stream, loc, aw, grad_out,
                            grad_value, ps.g);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // grad_sampling_loc, grad_attn_weight: gather from LDS windows of value
-    int ggrid = pg.grid * pg.g.nphases;
-    const int gcap = halves ? tiled_options().persist : tiled_options().persist / 2;
-    if (tiled_options().persist > 0 && ggrid > gcap) ggrid = gcap / kXcds * kXcds;
+    const int ggrid = persistent_grid(pg.grid * pg.g.nphases, halves ? tiled_options().persist : tiled_options().persist / 2,
+                                      pg.g.nphases);
     hipLaunchKernelGGL(kern, dim3(ggrid), dim3(halves ? 512 : 1024), pg.lds_bytes, stream, value, loc, aw, grad_out,
                        (float *)nullptr, grad_loc, grad_aw, pg.g);
     return hipGetLastError();
