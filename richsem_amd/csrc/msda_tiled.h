@@ -38,7 +38,7 @@ constexpr int kFwdLdsBudget = 75 * 1024;   // + header < 80 KiB: two workgroups 
 // Backward location / attention gradients need all 32 channels of a sample at once: 8 lanes per query, 1024 threads,
 // one workgroup per CU (two 16-channel passes with a read-modify-write of the per-point results measured slower).
 constexpr int kBwdGC = 32;
-constexpr int kBwdLdsBudget = 124 * 1024;
+constexpr int kBwdLdsBudget = 152 * 1024;   // region 20 fits its finest-level window in one phase
 // ... alternatively on channel halves like the forward (two workgroups per CU, the first half's per-point results kept
 // in registers): needs one level per work item and P <= 4 (tile option "bwd_gather_halves")   // three phases = three independent workgroups per region (measured faster than two)
 constexpr int kGatherQPG = 4;        // queries per lane group (128 groups -> <= 512 queries per region)
