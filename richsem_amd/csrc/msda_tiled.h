@@ -381,23 +381,32 @@ __device__ __forceinline__ void fwd_accumulate(float w1, float w2, float w3, flo
     acc_hi += w1 * (v2f){v1.z, v1.w} + w2 * (v2f){v2.z, v2.w} + w3 * (v2f){v3.z, v3.w} + w4 * (v2f){v4.z, v4.w};
 }
 
-// Per-lane partial sums of the location / attention gradients of one point (this lane's 4 channels).
-//   d value / d lw = hh*(v2-v1) + lh*(v4-v3);  d value / d lh = hw*(v3-v1) + lw*(v4-v2)
-__device__ __forceinline__ void bwd_partials(float lh, float lw, const float4 &gq, const float4 &v1, const float4 &v2,
-                                             const float4 &v3, const float4 &v4, float &s_a, float &s_w, float &s_h)
+// Backward location / attention gradients of one point are three channel sums that are all linear in the four
+// "corner dots"  D_k = sum_c grad_out[c] * v_k[c]:
+//   grad_attn = w1*D1 + w2*D2 + w3*D3 + w4*D4,  d/dlw = hh*(D2-D1) + lh*(D4-D3),  d/dlh = hw*(D3-D1) + lw*(D4-D2)
+// so a lane only forms the four dots over its 4 channels (8 packed FMAs); the dots are summed over the query's lanes and
+// combined with the bilinear coefficients afterwards.
+__device__ __forceinline__ void corner_dots(const float4 &gq, const float4 &v1, const float4 &v2, const float4 &v3,
+                                            const float4 &v4, float &d1, float &d2, float &d3, float &d4)
+{
+    const v2f gl = {gq.x, gq.y}, gh = {gq.z, gq.w};
+    const v2f t1 = gl * (v2f){v1.x, v1.y} + gh * (v2f){v1.z, v1.w};
+    const v2f t2 = gl * (v2f){v2.x, v2.y} + gh * (v2f){v2.z, v2.w};
+    const v2f t3 = gl * (v2f){v3.x, v3.y} + gh * (v2f){v3.z, v3.w};
+    const v2f t4 = gl * (v2f){v4.x, v4.y} + gh * (v2f){v4.z, v4.w};
+    d1 = t1.x + t1.y;
+    d2 = t2.x + t2.y;
+    d3 = t3.x + t3.y;
+    d4 = t4.x + t4.y;
+}
+
+__device__ __forceinline__ void combine_dots(float lh, float lw, float d1, float d2, float d3, float d4, float &s_a,
+                                             float &s_w, float &s_h)
 {
     const float hh = 1.f - lh, hw = 1.f - lw;
-    const v2f gl = {gq.x, gq.y}, gh = {gq.z, gq.w};
-    const v2f a1 = {v1.x, v1.y}, a2 = {v2.x, v2.y}, a3 = {v3.x, v3.y}, a4 = {v4.x, v4.y};
-    const v2f b1 = {v1.z, v1.w}, b2 = {v2.z, v2.w}, b3 = {v3.z, v3.w}, b4 = {v4.z, v4.w};
-    const v2f dwa = hh * (a2 - a1) + lh * (a4 - a3), dwb = hh * (b2 - b1) + lh * (b4 - b3);
-    const v2f dha = hw * (a3 - a1) + lw * (a4 - a2), dhb = hw * (b3 - b1) + lw * (b4 - b2);
-    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-    const v2f va = w1 * a1 + w2 * a2 + w3 * a3 + w4 * a4, vb = w1 * b1 + w2 * b2 + w3 * b3 + w4 * b4;
-    const v2f ta = gl * va + gh * vb, tw = gl * dwa + gh * dwb, th = gl * dha + gh * dhb;
-    s_a = ta.x + ta.y;
-    s_w = tw.x + tw.y;
-    s_h = th.x + th.y;
+    s_a = hh * hw * d1 + hh * lw * d2 + lh * hw * d3 + lh * lw * d4;
+    s_w = hh * (d2 - d1) + lh * (d4 - d3);
+    s_h = hw * (d3 - d1) + lw * (d4 - d2);
 }
 
 // This lane's sampling point (lane i of the quad holds point i of the level's first four) for each of the quad's
@@ -495,15 +504,17 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
                                v2, v3, v4, acc_lo[k], acc_hi[k]);                                                      \
             }                                                                                                          \
         } else {                                                                                                       \
-            float s_a = 0.f, s_w = 0.f, s_h = 0.f;                                                                     \
+            float d1 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f, s_a, s_w, s_h;                                               \
             if (m_ >= 0) {                                                                                             \
                 float4 v1, v2, v3, v4;                                                                                 \
-                lds_corners<GC>(win, lc.nwc, j, m_, v1, v2, v3, v4);                                                       \
-                bwd_partials(quad_bcast_f<I>(lh), quad_bcast_f<I>(lw), gq[k], v1, v2, v3, v4, s_a, s_w, s_h);          \
+                lds_corners<GC>(win, lc.nwc, j, m_, v1, v2, v3, v4);                                                   \
+                corner_dots(gq[k], v1, v2, v3, v4, d1, d2, d3, d4);                                                    \
             }                                                                                                          \
-            s_a = query_sum<GC>(s_a);                                                                                  \
-            s_w = query_sum<GC>(s_w);                                                                                  \
-            s_h = query_sum<GC>(s_h);                                                                                  \
+            d1 = query_sum<GC>(d1);                                                                                    \
+            d2 = query_sum<GC>(d2);                                                                                    \
+            d3 = query_sum<GC>(d3);                                                                                    \
+            d4 = query_sum<GC>(d4);                                                                                    \
+            combine_dots(quad_bcast_f<I>(lh), quad_bcast_f<I>(lw), d1, d2, d3, d4, s_a, s_w, s_h);                     \
             /* lane I of the quad owns point I (dropped / general points: zeros here, general ones redone below) */   \
             if (j == I) {                                                                                              \
                 const float gx_ = (float)lc.W * s_w * a, gy_ = (float)lc.H * s_h * a;                                  \
@@ -538,11 +549,13 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
                         fwd_accumulate(hh_ * hw_ * a_, hh_ * lw_ * a_, lh_ * hw_ * a_, lh_ * lw_ * a_, v1, v2, v3, v4,
                                        acc_lo[k], acc_hi[k]);
                     } else {
-                        float s_a, s_w, s_h;
-                        bwd_partials(lh_, lw_, gq[k], v1, v2, v3, v4, s_a, s_w, s_h);
-                        s_a = query_sum<GC>(s_a);
-                        s_w = query_sum<GC>(s_w);
-                        s_h = query_sum<GC>(s_h);
+                        float d1, d2, d3, d4, s_a, s_w, s_h;
+                        corner_dots(gq[k], v1, v2, v3, v4, d1, d2, d3, d4);
+                        d1 = query_sum<GC>(d1);
+                        d2 = query_sum<GC>(d2);
+                        d3 = query_sum<GC>(d3);
+                        d4 = query_sum<GC>(d4);
+                        combine_dots(lh_, lw_, d1, d2, d3, d4, s_a, s_w, s_h);
                         // the fast pass gave this point zeros: add ours on top (first half: in `part`, else in memory)
                         if (j == i) {
                             const float gx_ = (float)lc.W * s_w * a_, gy_ = (float)lc.H * s_h * a_;
