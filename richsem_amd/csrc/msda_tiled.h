@@ -459,7 +459,7 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
                                              const bool (&live)[kGatherQPG], const LevelOps &pre,
                                              v2f (&acc_lo)[kGatherQPG], v2f (&acc_hi)[kGatherQPG],
                                              const float4 (&gq)[kGatherQPG], float (&part)[kGatherQPG][3],
-                                             float *__restrict__ grad_loc, float *__restrict__ grad_aw)
+                                             float *__restrict__ grad_loc, float *__restrict__ grad_aw, int dbgflags)
 {
     const int P = P4 ? 4 : P_;
     for (int pc = 0; pc < P; pc += 4) {
@@ -492,6 +492,7 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
             // forward broadcasts finished weights; backward needs lh, lw and the attention weight separately
             const float w1 = hh * hw * a, w2 = hh * lw * a, w3 = lh * hw * a, w4 = lh * lw * a;
             bool any_slow = false;
+            float ps_a = 0.f, ps_x = 0.f, ps_y = 0.f;   // backward: this lane's point (lane i <-> point pc + i)
 #define MSDA_POINT(I)                                                                                                 \
     if (P4 || pc + I < P) {                                                                                            \
         const int m_ = quad_bcast_i<I>(mode);                                                                          \
@@ -505,7 +506,7 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
             }                                                                                                          \
         } else {                                                                                                       \
             float d1 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f, s_a, s_w, s_h;                                               \
-            if (m_ >= 0) {                                                                                             \
+            if (m_ >= 0 && !(dbgflags & 128)) {                                                                        \
                 float4 v1, v2, v3, v4;                                                                                 \
                 lds_corners<GC>(win, lc.nwc, j, m_, v1, v2, v3, v4);                                                   \
                 corner_dots(gq[k], v1, v2, v3, v4, d1, d2, d3, d4);                                                    \
@@ -515,17 +516,12 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
             d3 = query_sum<GC>(d3);                                                                                    \
             d4 = query_sum<GC>(d4);                                                                                    \
             combine_dots(quad_bcast_f<I>(lh), quad_bcast_f<I>(lw), d1, d2, d3, d4, s_a, s_w, s_h);                     \
-            /* lane I of the quad owns point I (dropped / general points: zeros here, general ones redone below) */   \
+            /* lane I of the quad keeps point I (dropped / general points: zeros here, general ones redone below); */  \
+            /* the four points are stored together after the loop: one 16-B and one 32-B segment per query */          \
             if (j == I) {                                                                                              \
-                const float gx_ = (float)lc.W * s_w * a, gy_ = (float)lc.H * s_h * a;                                  \
-                if (MODE == 1) {                                                                                       \
-                    part[k][0] = s_a;                                                                                  \
-                    part[k][1] = gx_;                                                                                  \
-                    part[k][2] = gy_;                                                                                  \
-                } else {                                                                                               \
-                    store_point_grads<false>(grad_loc, grad_aw, pt0[k] + pc + I, s_a + (MODE == 2 ? part[k][0] : 0.f), \
-                                             gx_ + (MODE == 2 ? part[k][1] : 0.f), gy_ + (MODE == 2 ? part[k][2] : 0.f)); \
-                }                                                                                                      \
+                ps_a = s_a;                                                                                            \
+                ps_x = (float)lc.W * s_w * a;                                                                          \
+                ps_y = (float)lc.H * s_h * a;                                                                          \
             }                                                                                                          \
         }                                                                                                              \
     }
@@ -534,6 +530,16 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
             MSDA_POINT(2)
             MSDA_POINT(3)
 #undef MSDA_POINT
+            if (BWD && j < 4 && (P4 || pc + j < P) && !(dbgflags & 64)) {
+                if (MODE == 1) {
+                    part[k][0] = ps_a;
+                    part[k][1] = ps_x;
+                    part[k][2] = ps_y;
+                } else {
+                    store_point_grads<false>(grad_loc, grad_aw, pt0[k] + pc + j, ps_a + (MODE == 2 ? part[k][0] : 0.f),
+                                             ps_x + (MODE == 2 ? part[k][1] : 0.f), ps_y + (MODE == 2 ? part[k][2] : 0.f));
+                }
+            }
             if (any_slow) {   // uniform over the quad; rare
                 const int lane0 = (threadIdx.x & (kWave - 1)) & ~3;
                 for (int i = 0; i < 4; ++i) {
@@ -692,13 +698,13 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                 for (int k = 0; k < kGatherQPG; ++k) pt0[k] = item[k] * (unsigned)LP + (unsigned)(l * g.P);
                 if (!BWD || kHalves == 1)
                     gather_level<BWD, P4, 0, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw);
+                                                 acc_hi, gq, part, grad_loc, grad_aw, g.dbg);
                 else if (half == 0)
                     gather_level<BWD, P4, 1, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw);
+                                                 acc_hi, gq, part, grad_loc, grad_aw, g.dbg);
                 else
                     gather_level<BWD, P4, 2, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw);
+                                                 acc_hi, gq, part, grad_loc, grad_aw, g.dbg);
             }
             __syncthreads();   // the next fill overwrites the windows
             stamp<2>(g, st++);
