@@ -61,8 +61,7 @@ struct TiledGeom {
     short rq0[kTL][kMaxGrid + 1], rw0[kTL][kMaxGrid], rwn[kTL][kMaxGrid];
     short cq0[kTL][kMaxGrid + 1], cw0[kTL][kMaxGrid], cwn[kTL][kMaxGrid];
     unsigned long long *stamps;   // diagnostic builds of a run only: per-workgroup s_memtime stamps (16 per workgroup), or null
-    int dbg;               // timing experiments only (results become wrong): 1 = plain LDS add instead of atomic,
-                           // 2 = no flush, 4 = no global fallback atomics, 8 = no LDS accumulation at all
+    int dbg;               // diagnostic: bits 4..5 select the kernel that writes stage stamps (0 = all, 1 = scatter, 2 = gather)
 };
 
 // ---- region geometry (host and device) --------------------------------------------------------------
@@ -459,7 +458,7 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
                                              const bool (&live)[kGatherQPG], const LevelOps &pre,
                                              v2f (&acc_lo)[kGatherQPG], v2f (&acc_hi)[kGatherQPG],
                                              const float4 (&gq)[kGatherQPG], float (&part)[kGatherQPG][3],
-                                             float *__restrict__ grad_loc, float *__restrict__ grad_aw, int dbgflags)
+                                             float *__restrict__ grad_loc, float *__restrict__ grad_aw)
 {
     const int P = P4 ? 4 : P_;
     for (int pc = 0; pc < P; pc += 4) {
@@ -506,7 +505,7 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
             }                                                                                                          \
         } else {                                                                                                       \
             float d1 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f, s_a, s_w, s_h;                                               \
-            if (m_ >= 0 && !(dbgflags & 128)) {                                                                        \
+            if (m_ >= 0) {                                                                                             \
                 float4 v1, v2, v3, v4;                                                                                 \
                 lds_corners<GC>(win, lc.nwc, j, m_, v1, v2, v3, v4);                                                   \
                 corner_dots(gq[k], v1, v2, v3, v4, d1, d2, d3, d4);                                                    \
@@ -530,7 +529,7 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
             MSDA_POINT(2)
             MSDA_POINT(3)
 #undef MSDA_POINT
-            if (BWD && j < 4 && (P4 || pc + j < P) && !(dbgflags & 64)) {
+            if (BWD && j < 4 && (P4 || pc + j < P)) {
                 if (MODE == 1) {
                     part[k][0] = ps_a;
                     part[k][1] = ps_x;
@@ -698,13 +697,13 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                 for (int k = 0; k < kGatherQPG; ++k) pt0[k] = item[k] * (unsigned)LP + (unsigned)(l * g.P);
                 if (!BWD || kHalves == 1)
                     gather_level<BWD, P4, 0, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw, g.dbg);
+                                                 acc_hi, gq, part, grad_loc, grad_aw);
                 else if (half == 0)
                     gather_level<BWD, P4, 1, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw, g.dbg);
+                                                 acc_hi, gq, part, grad_loc, grad_aw);
                 else
                     gather_level<BWD, P4, 2, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw, g.dbg);
+                                                 acc_hi, gq, part, grad_loc, grad_aw);
             }
             __syncthreads();   // the next fill overwrites the windows
             stamp<2>(g, st++);
@@ -729,14 +728,8 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
 // run at ~1.3 TB/s only as whole row segments.  So the window accumulates in f64 (which also makes the in-window sum
 // exact to f32 precision whatever the order), a workgroup takes one CHANNEL HALF of a region (16 channels x 8 B =
 // 128 B per pixel, the same LDS geometry as the gather kernels) and every touched pixel is flushed once.
-// 16 lanes per query: lane j resolves sampling point j (L*P <= 16) and owns channel j of the half; the resolved
-// points are parked in LDS records and replayed to the group as LDS broadcasts.
-struct alignas(16) ScatterRec {
-    int t[4];     // per corner: >= 0 LDS f64 index of (pixel, channel 0); < -1: -(global element offset) - 2; -1: none;
-                  // t[1] = -3: all four corners inside the window, t[0] is the base of corner (h_low, w_low)
-    float w[4];   // bilinear weight x attention weight
-};
-
+// 16 lanes per query (4 quads): lane i of every quad resolves sampling point i of the current level and the quad shares
+// it by DPP broadcast; each lane owns one channel of the half.  Persistent workgroups walk (region, channel half, phase).
 __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
     const float *__restrict__ loc, const float *__restrict__ aw, const float *__restrict__ grad_out,
     float *__restrict__ grad_value, const TiledGeom g)
@@ -845,22 +838,19 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
         const float v2 = quad_bcast_f<I>(w2) * gk, v3 = quad_bcast_f<I>(w3) * gk;                                       \
         if (base_ >= 0) {                                                                                               \
             double *p0 = win + base_ + j, *p1 = p0 + row2;                                                              \
-            if (!(g.dbg & 8)) {                                                                                         \
-                atomicAdd(p0, (double)v0);                                                                              \
-                atomicAdd(p0 + kSD, (double)v1);                                                                        \
-                atomicAdd(p1, (double)v2);                                                                              \
-                atomicAdd(p1 + kSD, (double)v3);                                                                        \
-            }                                                                                                           \
+            atomicAdd(p0, (double)v0);                                                                                  \
+            atomicAdd(p0 + kSD, (double)v1);                                                                            \
+            atomicAdd(p1, (double)v2);                                                                                  \
+            atomicAdd(p1 + kSD, (double)v3);                                                                            \
         } else if (base_ == -2) {                                                                                       \
             const int tt[4] = {quad_bcast_i<I>(t0), quad_bcast_i<I>(t1), quad_bcast_i<I>(t2), quad_bcast_i<I>(t3)};     \
             const float vv[4] = {v0, v1, v2, v3};                                                                       \
             _Pragma("unroll") for (int cn = 0; cn < 4; ++cn)                                                            \
             {                                                                                                           \
-                if (tt[cn] >= 0) {                                                                                      \
-                    if (!(g.dbg & 8)) atomicAdd(win + tt[cn] + j, (double)vv[cn]);                                      \
-                } else if (tt[cn] < -1) {                                                                               \
-                    if (!(g.dbg & 4)) atomicAdd(grad_value + (-(tt[cn] + 2)) + j, vv[cn]);                              \
-                }                                                                                                       \
+                if (tt[cn] >= 0)                                                                                        \
+                    atomicAdd(win + tt[cn] + j, (double)vv[cn]);                                                        \
+                else if (tt[cn] < -1)                                                                                   \
+                    atomicAdd(grad_value + (-(tt[cn] + 2)) + j, vv[cn]);                                                \
             }                                                                                                           \
         }                                                                                                               \
     }
@@ -888,7 +878,7 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
                 const float v = (float)src[px * kSD];
                 const int rr = px / fnc, cc = px - rr * fnc;
                 const int row = fr0 + rr, col = fc0 + cc;
-                if (v != 0.f && row >= 0 && row < Hl && col >= 0 && col < Wl && !(g.dbg & 2))
+                if (v != 0.f && row >= 0 && row < Hl && col >= 0 && col < Wl)
                     atomicAdd(dst + (int64_t)(row * Wl + col) * row_elems, v);
             }
         }

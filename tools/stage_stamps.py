@@ -58,4 +58,4 @@ for i in range(1, 16):
     print(f"stage {i - 1}->{i}: mean {d.mean():9.0f} ticks  median {d.median():9.0f}  (n={int(ok.sum())})")
     prev = cur
 tot = (prev - s[:, 0])
-print(f"total per workgroup: mean {tot.mean():.0f} ticks (s_memtime ticks = 100 MHz? see note) ")
+print(f"total per workgroup (or per last item of a persistent workgroup): mean {tot.mean():.0f} shader cycles")
