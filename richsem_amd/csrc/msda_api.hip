@@ -284,7 +284,7 @@ int msda_set_option(const char *key, int value)
     if (key && !strcmp(key, "tile_region") && value >= 4 && value <= 64) { msda::tiled_options().region_px = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_margin") && value >= 0 && value <= 32) { msda::tiled_options().margin = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_debug") && value >= 0 && value <= 255) { msda::tiled_options().dbg = value; return MSDA_OK; }
-    if (key && !strcmp(key, "tile_accum") && (value == 0 || value == 1)) { msda::tiled_options().accum = value; return MSDA_OK; }
+    if (key && !strcmp(key, "tile_accum") && value >= 0 && value <= 2) { msda::tiled_options().accum = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_persist") && value >= 0 && value <= 65536) { msda::tiled_options().persist = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_gather_halves") && (value == 0 || value == 1)) { msda::tiled_options().bwd_halves = value; return MSDA_OK; }
     return fail(MSDA_ERR_BAD_OPTION, "unknown option or value: %s=%d", key ? key : "(null)", value);

@@ -121,7 +121,7 @@ struct TiledOptions {
     int bwd_halves = 0;  // backward location/attention gradients: 0 = 32 channels at once (faster as measured), 1 = two 16-channel passes
     int persist = 512;   // 0 = one workgroup per work item; n > 0 = at most n workgroups (n/2 for the 1024-thread kernels)
                          // walking the items (2 x 256 CUs by default: no per-item launch ramp)
-    int accum = 0;   // grad_value window: 0 = f64 LDS atomics (exact), 1 = per-pixel block floating point on int32 atomics
+    int accum = 2;   // grad_value: 0 = f64 LDS atomic window, 1 = integer block-floating-point window, 2 = sorted reduction
     int dbg = 0;
     unsigned long long *stamps = nullptr;
 };
@@ -1110,6 +1110,226 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_bfp_kernel(
     }
 }
 
+// ---- backward: grad_value by sorted (segmented) reduction -- no floating-point LDS atomics ---------------------------------------
+// Work item = (image, head, region, LEVEL), all 32 channels.  Instead of adding every corner of every sampling point into an
+// LDS window with a float atomic (the f64 kernel above is bound by the ds_add_f64 issue rate), the points are BUCKETED by the
+// window pixel of their (h_low, w_low) corner with integer LDS atomics -- one lane per point, not per channel -- and every
+// output pixel then sums, in registers, the records of the (up to) four buckets whose points touch it:
+//   A  grad_out rows of the region's queries -> LDS (gcache); histogram cleared
+//   B  one thread per (query, point): resolve; in-window points take a rank in their bucket (ds_add_rtn_u32);
+//      points with a corner outside the window go to a side list
+//   C  exclusive scan of the histogram -> bucket offsets;  D  records written to their sorted slots
+//   E  8 lanes x 4 channels per output pixel: acc += w_k * gcache[q] over the records of buckets p, p-1, p-nwc, p-nwc-1
+//      (corner k = 0..3), then the wave transposes to one channel per lane and adds whole 128-B rows to grad_value
+//   F  side list: 32 lanes per point, row atomics straight to global memory (as the direct kernel)
+// Sums are fp32 like the reference's; their order inside a bucket follows the atomic ranks (run-to-run variation at the
+// rounding level, as with the reference's float atomics).
+constexpr int kSortMaxPx = 1280;            // largest single-level window (pixels) the kernel takes
+constexpr int kSortMaxPts = kMaxRegionQueries * 4;
+
+struct alignas(4) SortRec {
+    int q;        // index of the query inside the region (row of gcache)
+    float w[4];   // bilinear weight x attention weight of the four corners
+};
+
+struct SortLds {   // after the TileHeader
+    float gcache[kMaxRegionQueries * kTD];
+    int offs[kSortMaxPx + 4];               // histogram, then exclusive prefix (offs[npx] = total)
+    SortRec sorted[kSortMaxPts];
+    int genlist[kSortMaxPts];
+    int wave_tot[16];
+    int ngen;
+    int pad[3];
+};
+
+__global__ __launch_bounds__(kTiledThreads) void tiled_scatter_sorted_kernel(
+    const float *__restrict__ loc, const float *__restrict__ aw, const float *__restrict__ grad_out,
+    float *__restrict__ grad_value, const TiledGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TileHeader *hdr = reinterpret_cast<TileHeader *>(smem);
+    SortLds *S = reinterpret_cast<SortLds *>(smem + sizeof(TileHeader));
+
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int row_elems = g.M * kTD;
+    const int LP = g.L * g.P;
+    const int nsub = g.L;   // one level per work item
+    const int n_items = kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.GY * g.GX * nsub;
+    for (int vb = blockIdx.x; vb < n_items; vb += gridDim.x) {   // persistent form, see tiled_gather_kernel
+        int pair, rs;
+        if (!decode_block(vb, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) continue;
+        const int region = rs / nsub, lv = rs - region * nsub;
+        const int b = pair / g.M, m = pair - b * g.M;
+        const int gy = region / g.GX, gx = region - gy * g.GX;
+        stamp<1>(g, 0);
+        const int nq = build_header(hdr, g, gy, gx);
+        stamp<1>(g, 1);
+        const int H = uni(hdr->H[lv]), W = uni(hdr->W[lv]), nwc = uni(hdr->r[lv].nwc), nwr = uni(hdr->r[lv].nwr);
+        const int wr0 = uni(hdr->r[lv].wr0), wc0 = uni(hdr->r[lv].wc0);
+        const int npx = nwr * nwc;
+        const int base_row = (b * g.S + uni(hdr->start[lv])) * row_elems + m * kTD;
+
+        // ---- A: grad_out rows -> LDS; clear the histogram -------------------------------------------------------------
+        for (int i = tid >> 3; i < nq; i += kTiledThreads / 8) {
+            const unsigned item = (unsigned)((b * g.Lq + hdr->qid[i]) * g.M + m);
+            *reinterpret_cast<float4 *>(S->gcache + i * kTD + 4 * (tid & 7)) =
+                *reinterpret_cast<const float4 *>(grad_out + item * (unsigned)kTD + 4u * (tid & 7));
+        }
+        for (int i = tid; i <= npx; i += kTiledThreads) S->offs[i] = 0;
+        if (tid == 0) S->ngen = 0;
+        __syncthreads();
+
+        // ---- B: resolve; rank inside the bucket of the (h_low, w_low) pixel --------------------------------------------
+        int r_pix[2], r_rank[2];
+        SortRec r_rec[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * kTiledThreads;
+            r_pix[u] = -1;
+            r_rank[u] = 0;
+            if (idx < nq * g.P) {
+                const int qi = idx / g.P, pp = idx - qi * g.P;
+                const unsigned item = (unsigned)((b * g.Lq + hdr->qid[qi]) * g.M + m);
+                const unsigned pt = item * (unsigned)LP + (unsigned)(lv * g.P + pp);
+                const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
+                const float a = aw[pt];
+                const float h_im = xy.y * (float)H - 0.5f, w_im = xy.x * (float)W - 0.5f;
+                if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                    const float hf = floorf(h_im), wf = floorf(w_im);
+                    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+                    const int rr = (int)hf - wr0, cc = (int)wf - wc0;
+                    if (rr >= 0 && rr + 1 < nwr && cc >= 0 && cc + 1 < nwc) {   // all four corners in the window (apron incl.)
+                        r_pix[u] = rr * nwc + cc;
+                        r_rec[u].q = qi;
+                        r_rec[u].w[0] = hh * hw * a;
+                        r_rec[u].w[1] = hh * lw * a;
+                        r_rec[u].w[2] = lh * hw * a;
+                        r_rec[u].w[3] = lh * lw * a;
+                        r_rank[u] = atomicAdd(&S->offs[r_pix[u]], 1);
+                    } else {
+                        S->genlist[atomicAdd(&S->ngen, 1)] = idx;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        stamp<1>(g, 2);
+
+        // ---- C: exclusive scan of the histogram (two entries per thread; kSortMaxPx <= 2 * 1024) --------------------------------
+        {
+            const int e0 = 2 * tid, e1 = 2 * tid + 1;
+            const int c0 = e0 < npx ? S->offs[e0] : 0, c1 = e1 < npx ? S->offs[e1] : 0;
+            int incl = c0 + c1;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const int t = __shfl_up(incl, d, kWave);
+                if (lane >= d) incl += t;
+            }
+            if (lane == kWave - 1) S->wave_tot[wave] = incl;
+            __syncthreads();
+            int base = 0;
+#pragma unroll
+            for (int w = 0; w < kTiledThreads / kWave; ++w) base += w < wave ? S->wave_tot[w] : 0;
+            const int excl = base + incl - (c0 + c1);
+            if (e0 <= npx) S->offs[e0] = excl;                 // e0 == npx / e1 == npx write the total (sentinel)
+            if (e1 <= npx) S->offs[e1] = excl + c0;
+        }
+        __syncthreads();
+        // ---- D: records to their sorted slots -----------------------------------------------------------------------------------
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (r_pix[u] >= 0) S->sorted[S->offs[r_pix[u]] + r_rank[u]] = r_rec[u];
+        __syncthreads();
+        stamp<1>(g, 3);
+
+        // ---- E: per output pixel, 8 lanes x 4 channels; then transpose to one channel per lane and add rows ---------------------
+        {
+            const int j8 = lane & 7, grp8 = tid >> 3;
+            for (int px0 = 0; px0 < npx; px0 += kTiledThreads / 8) {   // wave-uniform trip count
+                const int px = px0 + grp8;
+                const int rr = px / nwc, cc = px - rr * nwc;
+                const int row = wr0 + rr, col = wc0 + cc;
+                const bool valid = px < npx && row >= 0 && row < H && col >= 0 && col < W;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int rk = rr - (k >> 1), ck = cc - (k & 1);   // (h_low, w_low) of points whose corner k is this pixel
+                        if (rk < 0 || ck < 0) continue;
+                        const int bin = rk * nwc + ck;
+                        const int e1 = S->offs[bin + 1];
+                        int e = S->offs[bin];
+                        // several records in flight: the record -> gcache row dependency is the latency chain of this loop
+                        for (; e + 3 < e1; e += 4) {
+                            float w[4];
+                            int q[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                w[u] = S->sorted[e + u].w[k];
+                                q[u] = S->sorted[e + u].q;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float4 gv = *reinterpret_cast<const float4 *>(S->gcache + q[u] * kTD + 4 * j8);
+                                acc.x += w[u] * gv.x;
+                                acc.y += w[u] * gv.y;
+                                acc.z += w[u] * gv.z;
+                                acc.w += w[u] * gv.w;
+                            }
+                        }
+                        for (; e < e1; ++e) {
+                            const float w = S->sorted[e].w[k];
+                            const float4 gv = *reinterpret_cast<const float4 *>(S->gcache + S->sorted[e].q * kTD + 4 * j8);
+                            acc.x += w * gv.x;
+                            acc.y += w * gv.y;
+                            acc.z += w * gv.z;
+                            acc.w += w * gv.w;
+                        }
+                    }
+                }
+                const int rowoff = valid ? base_row + (row * W + col) * row_elems : -1;
+                // transpose: in round r the lower / upper half-wave adds the row of pixel slot 2r / 2r+1, one channel per lane
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int src = ((2 * r + (lane >> 5)) << 3) + ((lane & 31) >> 2);
+                    const float vx = __shfl(acc.x, src, kWave), vy = __shfl(acc.y, src, kWave);
+                    const float vz = __shfl(acc.z, src, kWave), vw = __shfl(acc.w, src, kWave);
+                    const int ro = __shfl(rowoff, src, kWave);
+                    const int comp = lane & 3;
+                    const float v = comp == 0 ? vx : (comp == 1 ? vy : (comp == 2 ? vz : vw));
+                    if (ro >= 0 && v != 0.f) atomicAdd(grad_value + ro + (lane & 31), v);
+                }
+            }
+        }
+        stamp<1>(g, 4);
+
+        // ---- F: points with a corner outside the window: row atomics straight to global memory ----------------------------------
+        {
+            const int j = tid & (kTD - 1), grp32 = tid / kTD;
+            const int ngen = S->ngen;
+            for (int gi = grp32; gi < ngen; gi += kTiledThreads / kTD) {
+                const int idx = S->genlist[gi];
+                const int qi = idx / g.P, pp = idx - qi * g.P;
+                const unsigned item = (unsigned)((b * g.Lq + hdr->qid[qi]) * g.M + m);
+                const unsigned pt = item * (unsigned)LP + (unsigned)(lv * g.P + pp);
+                const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
+                const float a = aw[pt];
+                int o[4];
+                float lh, lw;
+                resolve_point<float>(xy.x, xy.y, H, W, base_row, row_elems, o, lh, lw);
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const float gk = S->gcache[qi * kTD + j] * a;
+                const float ww[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+#pragma unroll
+                for (int cn = 0; cn < 4; ++cn)
+                    if (o[cn] >= 0) atomicAdd(grad_value + o[cn] + j, ww[cn] * gk);
+            }
+        }
+        stamp<1>(g, 5);
+        __syncthreads();   // the next item rebuilds the header and the LDS tables
+    }
+}
+
 // ---- host entry points ----------------------------------------------------------------------------------------------
 inline TiledPlan plan_gather(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
 {
@@ -1160,6 +1380,26 @@ inline TiledPlan plan_scatter_bfp(int N, int S, int M, int D, int L, int Lq, int
         pl.lds_bytes = sizeof(TileHeader) + (size_t)max_px * kBfpPxBytes + (size_t)pl.max_q * P * sizeof(BfpRec);
         pl.grid = pl.grid;   // per (pair, region); the launch multiplies by the number of levels
         pl.max_px = max_px;
+    }
+    return pl;
+}
+inline TiledPlan plan_scatter_sorted(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
+{
+    TiledPlan pl;
+    if (P > 4) return pl;   // two (query, point) records per thread
+    pl = plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin, kSortMaxPx * 4, 4);
+    if (pl.ok) {
+        int max_px = 0;
+        for (int gy = 0; gy < pl.g.GY; ++gy)
+            for (int gx = 0; gx < pl.g.GX; ++gx)
+                for (int l = 0; l < L; ++l) {
+                    const LevelRect r = level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin);
+                    max_px = r.nwr * r.nwc > max_px ? r.nwr * r.nwc : max_px;
+                }
+        if (max_px > kSortMaxPx) { pl.ok = false; return pl; }
+        for (int l = 0; l < L; ++l) pl.g.phase[l] = l;
+        pl.g.nphases = L;
+        pl.lds_bytes = sizeof(TileHeader) + sizeof(SortLds);
     }
     return pl;
 }
@@ -1262,7 +1502,14 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
     if (e != hipSuccess) return e;
     // grad_value (pre-zeroed by the caller of this function): LDS accumulation + one flush per touched pixel
     const TiledPlan pb = plan_scatter_bfp(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
-    if (tiled_options().accum == 1 && pb.ok) {
+    const TiledPlan pso = plan_scatter_sorted(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
+    if (tiled_options().accum == 2 && pso.ok) {
+        e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_sorted_kernel), pso.lds_bytes);
+        if (e != hipSuccess) return e;
+        const int sgrid = persistent_grid(pso.grid * pso.g.nphases, tiled_options().persist / 2, pso.g.nphases);
+        hipLaunchKernelGGL(tiled_scatter_sorted_kernel, dim3(sgrid), dim3(kTiledThreads), pso.lds_bytes, stream, loc, aw,
+                           grad_out, grad_value, pso.g);
+    } else if (tiled_options().accum == 1 && pb.ok) {
         auto skern = P == 4 ? &tiled_scatter_bfp_kernel<true> : &tiled_scatter_bfp_kernel<false>;
         e = set_lds_limit(reinterpret_cast<const void *>(skern), pb.lds_bytes);
         if (e != hipSuccess) return e;
