@@ -200,8 +200,10 @@ def main():
             call = next(c for c, _ in calls if c.Lq == Lq)
             nbytes = call.bytes_bwd() if kind == "bwd" else call.bytes_fwd()
             avg = sum(ms) / len(ms)
+            scatter = {0: "tiled_scatter_kernel", 1: "tiled_scatter_bfp_kernel", 2: "tiled_scatter_sorted_kernel"}[
+                _lib.get_option("tile_accum")]
             hip = {("fwd", 1): "fwd_direct_kernel", ("bwd", 1): "bwd_direct_kernel", ("fwd", 2): "tiled_gather_kernel<false>",
-                   ("bwd", 2): "tiled_scatter_kernel + tiled_gather_kernel<true>"}[(kind, variant)]
+                   ("bwd", 2): scatter + " + tiled_gather_kernel<true>"}[(kind, variant)]
             kernels.append({"kernel": f"msda_{kind}_{'direct' if variant == 1 else 'tiled'}[{call.name}]", "hip_kernels": hip,
                             "launches": len(ms), "avg_us": round(avg * 1e3, 2), "total_ms": round(sum(ms), 3),
                             "alg_bytes": nbytes, "GBps": round(nbytes / (avg * 1e-3) / 1e9, 1)})

@@ -83,6 +83,11 @@ const char *msda_last_error(void);
  *   "bwd_direct_cpl"  channels per lane of the direct backward kernel (0 = auto, 1, 2, 4)
  *   "tile_region"     side of an LDS-window region, in pixels of the finest level (default 20)
  *   "tile_margin"     window margin around a region, in pixels of the sampled level (default 6)
+ *   "tile_accum"      grad_value of the window path: 2 = sorted (segmented) reduction, fp32 sums (default);
+ *                     0 = f64 LDS-atomic window; 1 = per-pixel block-floating-point window on 32-bit integer LDS atomics
+ *   "tile_persist"    persistent workgroups walking the work items (default 512 = 2 per CU; 0 = one workgroup per item)
+ *   "bwd_gather_halves"  1 = backward location/attention gradients on channel halves (default 0)
+ *   "tile_debug"      diagnostic bits (stage-stamp kernel selection)
  * Unknown key or value out of range -> MSDA_ERR_BAD_OPTION.  Options change speed, never results. */
 int msda_set_option(const char *key, int value);
 int msda_get_option(const char *key, int *value);
