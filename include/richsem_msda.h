@@ -80,6 +80,14 @@ const char *msda_last_error(void);
 /* Tuning / test hooks.  Keys:
  *   "fwd_variant"     0 = auto, 1 = direct gather kernel, 2 = LDS-window kernel (when applicable)
  *   "bwd_variant"     0 = auto, 1 = global-atomic kernel, 2 = LDS-accumulation kernels (when applicable)
+ *                     auto = window kernels for encoder-shaped fp32 calls while the locality monitor (below) finds the
+ *                     sampling points local enough, the direct kernels otherwise
+ *   "locality_monitor"  1 (default) = in auto mode the window forward kernel counts, on the first 8 calls of a problem
+ *                     shape and on every 64th after, the points that miss their window; the count comes back by an
+ *                     asynchronous copy and is read on a later call (no call waits, nothing is probed during graph
+ *                     capture).  Share > 2 % -> direct forward, share > 25 % -> direct backward (crossovers measured on
+ *                     MI355X).  0 = auto always takes the window kernels when they apply.  Setting it forgets what was
+ *                     learnt.  "locality_share_ppm" (get only): last measured share in parts per million, -1 = none.
  *   "bwd_direct_cpl"  channels per lane of the direct backward kernel (0 = auto, 1, 2, 4)
  *   "tile_region"     side of an LDS-window region, in pixels of the finest level (default 20)
  *   "tile_margin"     window margin around a region, in pixels of the sampled level (default 6)
@@ -102,6 +110,11 @@ int msda_tiled_plan(int N, int S, int M, int D, int L, int Lq, int P, const int6
 /* Diagnostic: when `device_buffer` is non-NULL the LDS-window kernels write shader-clock stamps into it, 16 x 8 bytes
  * per workgroup (buffer >= workgroups x 128 bytes), one per kernel stage; NULL (default) switches it off. */
 int msda_debug_stamps(void *device_buffer);
+
+/* Diagnostic: when `device_counter` (one uint32, caller-zeroed) is non-NULL, the LDS-window FORWARD kernel adds to it
+ * the number of sampling points that missed their window and took the general path, counted once per 16-channel half
+ * (so a call adds at most 2 * N*Lq*M*L*P).  NULL (default) switches it off. */
+int msda_debug_stats(void *device_counter);
 
 /* ---- launch profiler (measurement aid; off by default) ------------------------------------
  * When enabled, every forward/backward call brackets its MAIN kernel (not the zero-fill) with

@@ -21,7 +21,7 @@ ABI_VERSION = 1
 # every symbol include/richsem_msda.h declares
 SYMBOLS = [
     "msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option",
-    "msda_profile_enable", "msda_profile_collect", "msda_tiled_plan", "msda_debug_stamps",
+    "msda_profile_enable", "msda_profile_collect", "msda_tiled_plan", "msda_debug_stamps", "msda_debug_stats",
     "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64",
 ]
 
@@ -60,6 +60,8 @@ def load():
     L.msda_tiled_plan.restype = ci
     L.msda_debug_stamps.argtypes = [vp]
     L.msda_debug_stamps.restype = ci
+    L.msda_debug_stats.argtypes = [vp]
+    L.msda_debug_stats.restype = ci
     L.msda_profile_enable.argtypes = [ci]
     L.msda_profile_enable.restype = ci
     L.msda_profile_collect.argtypes = [ctypes.POINTER(ProfileRecord), ci, ctypes.POINTER(ci)]

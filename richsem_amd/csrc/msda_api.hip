@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/richsem_msda.h"
@@ -67,6 +68,121 @@ struct ProfileScope {
         if (slot) (void)hipEventRecord(slot->stop, stream);
     }
 };
+
+
+// ---- locality monitor -----------------------------------------------------------------------------------
+// The LDS-window kernels win only while most sampling points fall into the window of their query's region; the share
+// that does not ("general share") is a property of the DATA (how far the network's offsets reach).  Measured on MI355X
+// (tools/locality_sweep.sh, call E): the window forward beats the direct forward up to a general share of ~2.5 %, the
+// window backward beats the direct backward up to ~25 %.  In automatic mode the library therefore lets the window
+// forward kernel count its general points now and then (one atomic per wave), brings the count back with an
+// asynchronous copy + event on the caller's stream, and reads it on a LATER call once the event has completed -- no
+// call ever waits.  Nothing is probed while the stream is being captured into a graph.
+constexpr float kFwdShareMax = 0.02f, kBwdShareMax = 0.25f;
+constexpr unsigned kProbeWarmCalls = 8, kProbeEvery = 64;
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_monitor_on{1};
+std::atomic<int> g_last_share_ppm{-1};
+
+struct MonitorEntry {
+    unsigned calls = 0, next_probe = 0, probes = 0;
+    float share = 0.f;
+    bool known = false;
+};
+struct Monitor {
+    std::mutex mu;
+    unsigned *dev = nullptr, *host = nullptr;   // one counter on the device, its pinned host copy
+    hipEvent_t done = nullptr;
+    bool pending = false;
+    uint64_t pending_key = 0;
+    double pending_points = 0;
+    std::unordered_map<uint64_t, MonitorEntry> table;
+};
+Monitor g_monitors[kMaxDevices];
+
+uint64_t problem_key(const int N, const int S, const int M, const int L, const int P, const int64_t *shapes)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+    mix(N); mix(S); mix(M); mix(L); mix(P);
+    for (int l = 0; l < 2 * L; ++l) mix((uint64_t)shapes[l]);
+    return h;
+}
+
+// under mo.mu: fold a finished probe into its entry
+void monitor_poll(Monitor &mo)
+{
+    if (!mo.pending || hipEventQuery(mo.done) != hipSuccess) return;
+    mo.pending = false;
+    MonitorEntry &en = mo.table[mo.pending_key];
+    const float s = (float)((double)*mo.host / mo.pending_points);
+    // the first probes see different layers of the network: keep their worst; later ones track slowly
+    en.share = !en.known ? s : (en.probes <= kProbeWarmCalls ? (s > en.share ? s : en.share) : 0.5f * (en.share + s));
+    en.known = true;
+    g_last_share_ppm = (int)(s * 1e6f);
+}
+
+Monitor *monitor_for_current_device()
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    return &g_monitors[dev];
+}
+
+// Forward, automatic mode, window kernels applicable.  Returns the variant to run (1 direct, 2 window) and, through
+// *probe, the device counter the window kernel should add its general points to (or null).  With *probe set the caller
+// MUST call monitor_finish_probe after its launch.  The monitor's mutex is held from here to monitor_finish_probe.
+int monitor_choose_fwd(Monitor *mo, uint64_t key, hipStream_t stream, unsigned **probe)
+{
+    *probe = nullptr;
+    if (!mo || !g_monitor_on.load()) return 2;
+    mo->mu.lock();
+    monitor_poll(*mo);
+    MonitorEntry &en = mo->table[key];
+    const unsigned call = en.calls++;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
+    bool want = !mo->pending && cap == hipStreamCaptureStatusNone && call >= en.next_probe;
+    if (want && !mo->dev) {   // first probe on this device
+        if (hipMalloc(reinterpret_cast<void **>(&mo->dev), sizeof(unsigned)) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&mo->host), sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&mo->done, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            mo->dev = nullptr;
+            want = false;
+        }
+    }
+    if (want && hipMemsetAsync(mo->dev, 0, sizeof(unsigned), stream) != hipSuccess) want = false;
+    if (want) {
+        *probe = mo->dev;
+        en.next_probe = call + (en.probes < kProbeWarmCalls ? 1 : kProbeEvery);
+        ++en.probes;
+        mo->pending_key = key;
+        return 2;   // a probe IS a window-kernel call; the lock stays held
+    }
+    const int variant = en.known && en.share > kFwdShareMax ? 1 : 2;
+    mo->mu.unlock();
+    return variant;
+}
+
+void monitor_finish_probe(Monitor *mo, double points, hipStream_t stream, bool launched)
+{
+    if (launched && hipMemcpyAsync(mo->host, mo->dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+        hipEventRecord(mo->done, stream) == hipSuccess) {
+        mo->pending = true;
+        mo->pending_points = points;
+    }
+    mo->mu.unlock();
+}
+
+int monitor_choose_bwd(Monitor *mo, uint64_t key)
+{
+    if (!mo || !g_monitor_on.load()) return 2;
+    std::lock_guard<std::mutex> lock(mo->mu);
+    monitor_poll(*mo);
+    const auto it = mo->table.find(key);
+    return it != mo->table.end() && it->second.known && it->second.share > kBwdShareMax ? 1 : 2;
+}
 
 struct Problem {
     int N, S, M, D, L, Lq, P;
@@ -187,17 +303,26 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
         !is_aligned(loc, 2 * sizeof(T)) || !is_aligned(shapes, 8) || !is_aligned(lsi, 8))
         return fail(MSDA_ERR_MISALIGNED, "misaligned pointer (sampling_loc needs 2*sizeof(T))");
 
-    const int variant = g_fwd_variant.load();
+    int variant = g_fwd_variant.load();
     if (variant != 1 && msda::tiled_fwd_applicable<T>(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(),
                                                      pb.lsi.data(), value, out)) {
-        hipError_t e;
-        {
-            ProfileScope prof(0, 2, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
-            e = msda::launch_fwd_tiled<T>(value, shapes, lsi, loc, aw, out, pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P,
-                                          pb.shapes.data(), pb.lsi.data(), stream);
+        unsigned *probe = nullptr;
+        Monitor *mo = nullptr;
+        if (variant == 0) {   // automatic: follow the locality monitor
+            mo = monitor_for_current_device();
+            variant = monitor_choose_fwd(mo, problem_key(N, S, M, L, P, pb.shapes.data()), stream, &probe);
         }
-        if (e != hipSuccess) return hip_fail(e, "launch of the tiled forward kernel");
-        return MSDA_OK;
+        if (variant == 2) {
+            hipError_t e;
+            {
+                ProfileScope prof(0, 2, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
+                e = msda::launch_fwd_tiled<T>(value, shapes, lsi, loc, aw, out, pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P,
+                                              pb.shapes.data(), pb.lsi.data(), probe, stream);
+            }
+            if (probe) monitor_finish_probe(mo, 2.0 * N * Lq * M * L * P, stream, e == hipSuccess);
+            if (e != hipSuccess) return hip_fail(e, "launch of the tiled forward kernel");
+            return MSDA_OK;
+        }
     }
 
     const int C = pick_channels_per_lane<T>(D, {value, out});
@@ -236,16 +361,21 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
     hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(T) * (size_t)N * S * M * D, stream);
     if (e != hipSuccess) return hip_fail(e, "zero-fill of grad_value");
 
-    const int variant = g_bwd_variant.load();
+    int variant = g_bwd_variant.load();
     if (variant != 1 && msda::tiled_bwd_applicable<T>(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(),
                                                      pb.lsi.data(), value, grad_out, grad_value)) {
-        {
-            ProfileScope prof(1, 2, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
-            e = msda::launch_bwd_tiled<T>(value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw, pb.N,
-                                          pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(), pb.lsi.data(), stream);
+        if (variant == 0)   // automatic: the forward calls of this problem measured how local its sampling points are
+            variant = monitor_choose_bwd(monitor_for_current_device(), problem_key(N, S, M, L, P, pb.shapes.data()));
+        if (variant == 2) {
+            {
+                ProfileScope prof(1, 2, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
+                e = msda::launch_bwd_tiled<T>(value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw, pb.N,
+                                              pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(), pb.lsi.data(),
+                                              stream);
+            }
+            if (e != hipSuccess) return hip_fail(e, "launch of the tiled backward kernel");
+            return MSDA_OK;
         }
-        if (e != hipSuccess) return hip_fail(e, "launch of the tiled backward kernel");
-        return MSDA_OK;
     }
 
     // Float atomics run at full rate only as >= 128-B row segments (one dword per lane): with 32 or more
@@ -287,6 +417,15 @@ int msda_set_option(const char *key, int value)
     if (key && !strcmp(key, "tile_accum") && value >= 0 && value <= 2) { msda::tiled_options().accum = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_persist") && value >= 0 && value <= 65536) { msda::tiled_options().persist = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_gather_halves") && (value == 0 || value == 1)) { msda::tiled_options().bwd_halves = value; return MSDA_OK; }
+    if (key && !strcmp(key, "locality_monitor") && (value == 0 || value == 1)) {
+        g_monitor_on = value;
+        for (Monitor &mo : g_monitors) {   // switching it (either way) forgets what was learnt
+            std::lock_guard<std::mutex> lock(mo.mu);
+            mo.table.clear();
+        }
+        g_last_share_ppm = -1;
+        return MSDA_OK;
+    }
     return fail(MSDA_ERR_BAD_OPTION, "unknown option or value: %s=%d", key ? key : "(null)", value);
 }
 
@@ -301,6 +440,8 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "tile_accum")) { *value = msda::tiled_options().accum; return MSDA_OK; }
     if (key && !strcmp(key, "tile_persist")) { *value = msda::tiled_options().persist; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_gather_halves")) { *value = msda::tiled_options().bwd_halves; return MSDA_OK; }
+    if (key && !strcmp(key, "locality_monitor")) { *value = g_monitor_on; return MSDA_OK; }
+    if (key && !strcmp(key, "locality_share_ppm")) { *value = g_last_share_ppm; return MSDA_OK; }   // read-only
     return fail(MSDA_ERR_BAD_OPTION, "unknown option: %s", key ? key : "(null)");
 }
 
@@ -329,6 +470,12 @@ int msda_tiled_plan(int N, int S, int M, int D, int L, int Lq, int P, const int6
                 info[7] = nq > info[7] ? nq : info[7];
             }
     }
+    return MSDA_OK;
+}
+
+int msda_debug_stats(void *device_counter)
+{
+    msda::tiled_options().stats = static_cast<unsigned *>(device_counter);
     return MSDA_OK;
 }
 

@@ -61,6 +61,7 @@ struct TiledGeom {
     short rq0[kTL][kMaxGrid + 1], rw0[kTL][kMaxGrid], rwn[kTL][kMaxGrid];
     short cq0[kTL][kMaxGrid + 1], cw0[kTL][kMaxGrid], cwn[kTL][kMaxGrid];
     unsigned long long *stamps;   // diagnostic builds of a run only: per-workgroup s_memtime stamps (16 per workgroup), or null
+    unsigned *stats;              // forward, optional: stats[0] += points that missed their window (locality monitor), or null
     int dbg;               // diagnostic: bits 4..5 select the kernel that writes stage stamps (0 = all, 1 = scatter, 2 = gather)
 };
 
@@ -124,6 +125,7 @@ struct TiledOptions {
     int accum = 2;   // grad_value: 0 = f64 LDS atomic window, 1 = integer block-floating-point window, 2 = sorted reduction
     int dbg = 0;
     unsigned long long *stamps = nullptr;
+    unsigned *stats = nullptr;   // diagnostic override of the locality counter (msda_debug_stats)
 };
 inline TiledOptions &tiled_options()
 {
@@ -157,6 +159,7 @@ inline TiledPlan plan_tiled(int N, int S, int M, int D, int L, int Lq, int P, co
     g.margin = margin;
     g.dbg = tiled_options().dbg;
     g.stamps = tiled_options().stamps;
+    g.stats = tiled_options().stats;
     int Hmax = 0, Wmax = 0;
     for (int l = 0; l < L; ++l) {
         g.H[l] = (int)shapes[2 * l];
@@ -458,7 +461,7 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
                                              const bool (&live)[kGatherQPG], const LevelOps &pre,
                                              v2f (&acc_lo)[kGatherQPG], v2f (&acc_hi)[kGatherQPG],
                                              const float4 (&gq)[kGatherQPG], float (&part)[kGatherQPG][3],
-                                             float *__restrict__ grad_loc, float *__restrict__ grad_aw)
+                                             float *__restrict__ grad_loc, float *__restrict__ grad_aw, unsigned &n_general)
 {
     const int P = P4 ? 4 : P_;
     for (int pc = 0; pc < P; pc += 4) {
@@ -487,6 +490,7 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
                 const bool inside = rr >= 0 && rr + 1 < lc.nwr && cc >= 0 && cc + 1 < lc.nwc;
                 mode = inside ? lc.lds_base + (rr * lc.nwc + cc) * GC : -2;
             }
+            n_general += (mode == -2 && j < 4) ? 1u : 0u;   // locality monitor (lanes 0..3 of a query hold its four points)
             const float hh = 1.f - lh, hw = 1.f - lw;
             // forward broadcasts finished weights; backward needs lh, lw and the attention weight separately
             const float w1 = hh * hw * a, w2 = hh * lw * a, w3 = lh * hw * a, w4 = lh * lw * a;
@@ -541,7 +545,11 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
             }
             if (any_slow) {   // uniform over the quad; rare
                 const int lane0 = (threadIdx.x & (kWave - 1)) & ~3;
+                // which of the four point slots has a general point anywhere in the wave: the others are skipped
+                // without their shuffles (wave-uniform test)
+                const unsigned long long slow_lanes = __ballot(mode == -2);
                 for (int i = 0; i < 4; ++i) {
+                    if (!(slow_lanes & (0x1111111111111111ull << i))) continue;
                     const int m_ = __shfl(mode, lane0 + i, kWave);
                     const float x_ = __shfl(xy.x, lane0 + i, kWave), y_ = __shfl(xy.y, lane0 + i, kWave);
                     const float lh_ = __shfl(lh, lane0 + i, kWave), lw_ = __shfl(lw, lane0 + i, kWave);
@@ -602,6 +610,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
     // Persistent form: the grid may be smaller than the number of work items; a workgroup then walks the items
     // vb = blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8, so vb keeps the workgroup's XCD).
     const int n_items = kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.GY * g.GX * nsub;
+    unsigned n_general = 0;   // points of this lane that missed their window
     for (int vb = blockIdx.x; vb < n_items; vb += gridDim.x) {
     int pair, rs;
     if (!decode_block(vb, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) continue;
@@ -697,13 +706,13 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                 for (int k = 0; k < kGatherQPG; ++k) pt0[k] = item[k] * (unsigned)LP + (unsigned)(l * g.P);
                 if (!BWD || kHalves == 1)
                     gather_level<BWD, P4, 0, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw);
+                                                 acc_hi, gq, part, grad_loc, grad_aw, n_general);
                 else if (half == 0)
                     gather_level<BWD, P4, 1, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw);
+                                                 acc_hi, gq, part, grad_loc, grad_aw, n_general);
                 else
                     gather_level<BWD, P4, 2, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw);
+                                                 acc_hi, gq, part, grad_loc, grad_aw, n_general);
             }
             __syncthreads();   // the next fill overwrites the windows
             stamp<2>(g, st++);
@@ -719,6 +728,10 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                     make_float4(acc_lo[k].x, acc_lo[k].y, acc_hi[k].x, acc_hi[k].y);
     }
     __syncthreads();   // the next item rebuilds the header
+    }
+    if (g.stats) {   // locality monitor: one atomic per wave (only when the host asked for the count)
+        for (int o = kWave / 2; o > 0; o >>= 1) n_general += __shfl_xor(n_general, o, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0 && n_general) atomicAdd(g.stats, n_general);
     }
 }
 
@@ -1458,17 +1471,19 @@ inline hipError_t set_lds_limit(const void *fn, size_t bytes)
 
 template <typename T>
 hipError_t launch_fwd_tiled(const T *, const int64_t *, const int64_t *, const T *, const T *, T *, int, int, int, int,
-                            int, int, int, const int64_t *, const int64_t *, hipStream_t)
+                            int, int, int, const int64_t *, const int64_t *, unsigned *, hipStream_t)
 {
     return hipErrorNotSupported;
 }
 template <>
 inline hipError_t launch_fwd_tiled<float>(const float *value, const int64_t *, const int64_t *, const float *loc,
                                           const float *aw, float *out, int N, int S, int M, int D, int L, int Lq, int P,
-                                          const int64_t *shapes_h, const int64_t *lsi_h, hipStream_t stream)
+                                          const int64_t *shapes_h, const int64_t *lsi_h, unsigned *general_points,
+                                          hipStream_t stream)
 {
-    const TiledPlan pl = plan_gather(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
+    TiledPlan pl = plan_gather(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
     if (!pl.ok) return hipErrorInvalidValue;
+    if (general_points) pl.g.stats = general_points;   // locality monitor (msda_api.hip); else the diagnostic override
     auto kern = P == 4 ? &tiled_gather_kernel<false, true, kFwdGC> : &tiled_gather_kernel<false, false, kFwdGC>;
     hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pl.lds_bytes);
     if (e != hipSuccess) return e;

@@ -56,6 +56,13 @@ def test_options_roundtrip(lib):
         _lib.set_option(key, 1)
         assert _lib.get_option(key) == 1
         _lib.set_option(key, old)
+    assert _lib.get_option("locality_monitor") == 1          # on by default
+    _lib.set_option("locality_monitor", 0)
+    assert _lib.get_option("locality_monitor") == 0
+    _lib.set_option("locality_monitor", 1)
+    assert _lib.get_option("locality_share_ppm") == -1       # nothing measured (and nothing can be, without a GPU)
+    with pytest.raises(RuntimeError, match="MSDA_ERR_BAD_OPTION"):
+        _lib.set_option("locality_share_ppm", 5)             # read-only
     with pytest.raises(RuntimeError, match="MSDA_ERR_BAD_OPTION"):
         _lib.set_option("no_such_option", 1)
     with pytest.raises(RuntimeError, match="MSDA_ERR_BAD_OPTION"):

@@ -316,3 +316,48 @@ def test_integer_accumulator_error_is_float32_class():
         errs[accum] = rel_err(gv, ogv)
     _lib.set_option("tile_accum", 0)
     assert errs[0] < 2e-6 and errs[1] < 2e-5, errs
+
+
+# ---- locality monitor (automatic kernel choice follows the data) ---------------------------------------------------
+def _variants_of(fn, n=1):
+    _lib.profile_enable(8)
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    recs = _lib.profile_collect()
+    _lib.profile_enable(0)
+    return [r["variant"] for r in recs]
+
+
+@pytest.mark.parametrize("loc_mode,expect", [("init", 2), ("uniform", 1)])
+def test_locality_monitor_picks_kernels_by_data(loc_mode, expect):
+    """Auto mode: the window kernels stay on a local sampling pattern and give way to the direct kernels on a
+    scattered one (after the first probe has come back); results match the oracle either way."""
+    call = W.shrunk(W.call_E(2), 2)
+    z = W.make_inputs(call, loc_mode, seed=11)
+    t = {k: v.cuda() for k, v in z.items()}
+    _lib.set_option("fwd_variant", 0)
+    _lib.set_option("bwd_variant", 0)
+    _lib.set_option("locality_monitor", 1)   # forget earlier tests
+    fwd = lambda: MSDA.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], 64)
+    bwd = lambda: MSDA.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64)
+    assert _variants_of(fwd) == [2]          # the first call is a probe, and a probe is a window-kernel call
+    torch.cuda.synchronize()
+    out = fwd()                               # folds the finished probe in, then chooses
+    share = _lib.get_option("locality_share_ppm") * 1e-6
+    assert (share < 0.02) == (expect == 2), share
+    for _ in range(10):                       # past the warm-up probes
+        fwd()
+        torch.cuda.synchronize()
+    assert _variants_of(fwd) == [expect]
+    assert _variants_of(bwd) == [expect]
+    gv, gl, ga = bwd()
+    zn = {k: v.numpy() for k, v in z.items()}
+    oo = O.forward(zn["value"], zn["shapes"], zn["lsi"], zn["loc"], zn["aw"])
+    ogv, ogl, oga = O.backward(zn["value"], zn["shapes"], zn["lsi"], zn["loc"], zn["aw"], zn["grad_out"])
+    tf, tg = tols(np.float32)
+    assert rel_err(out, oo) < tf
+    assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg
+    _lib.set_option("locality_monitor", 0)
+    assert _variants_of(fwd) == [2] and _variants_of(bwd) == [2]
+    _lib.set_option("locality_monitor", 1)

@@ -22,9 +22,19 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--set", action="append", default=[], help="option=value[,value...] (sweep)")
     ap.add_argument("--only", default="both", choices=["fwd", "bwd", "both"])
+    ap.add_argument("--jitter", type=float, default=1.0, help="sigma (pixels of the sampled level) of the 'init' pattern")
+    ap.add_argument("--stats", action="store_true", help="print the share of points that miss the forward windows")
     args = ap.parse_args()
     call = {"E": W.call_E, "Dd": W.call_Dd, "Em": W.call_Em}[args.call](2)
-    t = W.make_inputs(call, args.loc, seed=0, device="cuda")
+    t = W.make_inputs(call, args.loc, seed=0, device="cuda", jitter_px=args.jitter)
+    if args.stats:
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.load().msda_debug_stats(cnt.data_ptr())
+        _lib.set_option("fwd_variant", 2)    # (in automatic mode the locality monitor's own counter takes precedence)
+        MSDA.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], 64)
+        _lib.load().msda_debug_stats(None)
+        _lib.set_option("fwd_variant", 0)
+        print(f"general-path share: {cnt.item() / (2 * t['aw'].numel()):.4f}", flush=True)
     sweeps = []
     for s in args.set:
         k, v = s.split("=")
