@@ -91,6 +91,10 @@ const char *msda_last_error(void);
  *   "bwd_direct_cpl"  channels per lane of the direct backward kernel (0 = auto, 1, 2, 4)
  *   "tile_region"     side of an LDS-window region, in pixels of the finest level (default 20)
  *   "tile_margin"     window margin around a region, in pixels of the sampled level (default 6)
+ *   "tile_grow"       1 (default) = a window grows into the LDS its phase leaves unused, coarsest level first (per-level
+ *                     margins >= tile_margin); 0 = every level uses exactly tile_margin
+ *   "bwd_levelsum"    1 (default) = direct backward: levels whose whole map fits LDS and that receive >= 2 sampling
+ *                     points per pixel are summed in LDS by their own kernel (no global atomics for them); 0 = off
  *   "tile_accum"      grad_value of the window path: 2 = sorted (segmented) reduction, fp32 sums (default);
  *                     0 = f64 LDS-atomic window; 1 = per-pixel block-floating-point window on 32-bit integer LDS atomics
  *   "tile_persist"    persistent workgroups walking the work items (default 512 = 2 per CU; 0 = one workgroup per item)

@@ -15,6 +15,7 @@
 
 #include "../../include/richsem_msda.h"
 #include "msda_direct.h"
+#include "msda_levelsum.h"
 #include "msda_tiled.h"
 
 namespace {
@@ -36,7 +37,7 @@ int hip_fail(hipError_t e, const char *what)
     return (int)e;
 }
 
-std::atomic<int> g_fwd_variant{0}, g_bwd_variant{0}, g_bwd_cpl{0};
+std::atomic<int> g_fwd_variant{0}, g_bwd_variant{0}, g_bwd_cpl{0}, g_levelsum{1};
 
 // ---- launch profiler: pre-created event pairs, one per logged call -----------------------------
 struct ProfileSlot {
@@ -283,6 +284,29 @@ msda::DirectGeom direct_geom(const Problem &pb, int C)
     return g;
 }
 
+// fp32 only: whole-level LDS sums of grad_value (msda_levelsum.h); `taken` = bit mask of the levels it produced
+template <typename T>
+hipError_t launch_levelsum(const Problem &, const T *, const T *, const T *, T *, hipStream_t, unsigned &taken)
+{
+    taken = 0;
+    return hipSuccess;
+}
+template <>
+hipError_t launch_levelsum<float>(const Problem &pb, const float *loc, const float *aw, const float *grad_out,
+                                  float *grad_value, hipStream_t stream, unsigned &taken)
+{
+    msda::LevelSumGeom lg;
+    size_t lds = 0;
+    taken = msda::plan_levelsum(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(), pb.lsi.data(), lg, lds);
+    if (!taken) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda::bwd_levelsum_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(msda::bwd_levelsum_kernel, dim3(msda::levelsum_grid(lg)), dim3(msda::kLsThreads), lds, stream, loc,
+                       aw, grad_out, grad_value, lg);
+    return hipGetLastError();
+}
+
 int direct_grid(const msda::DirectGeom &g)
 {
     const int pairs = g.N * g.M;
@@ -383,11 +407,16 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
     int C = pick_channels_per_lane<T>(D, {value, grad_out});
     if (g_bwd_cpl.load() > 0) C = g_bwd_cpl.load() <= C ? g_bwd_cpl.load() : C;
     else if (D * (int)sizeof(T) >= 128) C = 1;
-    const msda::DirectGeom g = direct_geom(pb, C);
+    msda::DirectGeom g = direct_geom(pb, C);
     const size_t lds = msda::direct_lds_bytes<T>(g);
     if (lds > 64 * 1024) return fail(MSDA_ERR_BAD_DIMS, "too many levels (L=%d) for the level table in LDS", L);
     const dim3 grid(direct_grid(g)), block(msda::kDirectThreads);
     ProfileScope prof(1, 1, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
+    // small levels that receive many points per pixel: summed whole in LDS, taken away from the atomics below
+    if (g_levelsum.load()) {
+        e = launch_levelsum<T>(pb, loc, aw, grad_out, grad_value, stream, g.gv_skip);
+        if (e != hipSuccess) return hip_fail(e, "launch of the level-sum backward kernel");
+    }
     switch (C) {
         case 4: hipLaunchKernelGGL((msda::bwd_direct_kernel<T, (sizeof(T) == 4 ? 4 : 2)>), grid, block, lds, stream, value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw, g); break;
         case 2: hipLaunchKernelGGL((msda::bwd_direct_kernel<T, 2>), grid, block, lds, stream, value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw, g); break;
@@ -417,6 +446,8 @@ int msda_set_option(const char *key, int value)
     if (key && !strcmp(key, "tile_accum") && value >= 0 && value <= 2) { msda::tiled_options().accum = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_persist") && value >= 0 && value <= 65536) { msda::tiled_options().persist = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_gather_halves") && (value == 0 || value == 1)) { msda::tiled_options().bwd_halves = value; return MSDA_OK; }
+    if (key && !strcmp(key, "bwd_levelsum") && (value == 0 || value == 1)) { g_levelsum = value; return MSDA_OK; }
+    if (key && !strcmp(key, "tile_grow") && (value == 0 || value == 1)) { msda::tiled_options().grow = value; return MSDA_OK; }
     if (key && !strcmp(key, "locality_monitor") && (value == 0 || value == 1)) {
         g_monitor_on = value;
         for (Monitor &mo : g_monitors) {   // switching it (either way) forgets what was learnt
@@ -440,6 +471,8 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "tile_accum")) { *value = msda::tiled_options().accum; return MSDA_OK; }
     if (key && !strcmp(key, "tile_persist")) { *value = msda::tiled_options().persist; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_gather_halves")) { *value = msda::tiled_options().bwd_halves; return MSDA_OK; }
+    if (key && !strcmp(key, "bwd_levelsum")) { *value = g_levelsum; return MSDA_OK; }
+    if (key && !strcmp(key, "tile_grow")) { *value = msda::tiled_options().grow; return MSDA_OK; }
     if (key && !strcmp(key, "locality_monitor")) { *value = g_monitor_on; return MSDA_OK; }
     if (key && !strcmp(key, "locality_share_ppm")) { *value = g_last_share_ppm; return MSDA_OK; }   // read-only
     return fail(MSDA_ERR_BAD_OPTION, "unknown option: %s", key ? key : "(null)");
@@ -464,7 +497,7 @@ int msda_tiled_plan(int N, int S, int M, int D, int L, int Lq, int P, const int6
             for (int gx = 0; gx < pl.g.GX; ++gx) {
                 int nq = 0;
                 for (int l = 0; l < L; ++l) {
-                    const msda::LevelRect r = msda::level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin);
+                    const msda::LevelRect r = msda::level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin_l[l]);
                     nq += r.qnr * r.qnc;
                 }
                 info[7] = nq > info[7] ? nq : info[7];

@@ -15,7 +15,8 @@
 //
 // Forward  (spec: reference ms_deform_im2col_cuda.cuh:237-299): out = sum_points attn * bilinear.
 // Backward (spec: reference ms_deform_im2col_cuda.cuh:87-159, 301-403): grad_value by global
-//          float atomics shaped as G*C*sizeof(T)-byte row segments; grad_loc / grad_attn reduced
+//          float atomics shaped as G*C*sizeof(T)-byte row segments (levels in DirectGeom::gv_skip
+//          excepted: whole small levels are summed in LDS by msda_levelsum.h); grad_loc / grad_attn reduced
 //          across the group's lanes with wave shuffles (no LDS tree, no barriers, no serial
 //          thread-0 loop) and written exactly once -> no zero-fill needed for them.
 #pragma once
@@ -29,6 +30,7 @@ struct DirectGeom {
     int G, logG, nchunks;  // lanes per item, log2, channel chunks per lane
     int qtile, ntiles;     // queries per block, tiles per (b,m) pair
     int pbatch;            // sampling points staged in LDS per pass: min(L*P, kPointBatch)
+    unsigned gv_skip;      // backward: bit l set = grad_value of level l is produced elsewhere (msda_levelsum.h)
 };
 
 constexpr int kDirectThreads = 256;
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(kDirectThreads) void bwd_direct_kernel(
             __builtin_amdgcn_wave_barrier();
             for (int pt = 0; pt < np; ++pt) {           // wave-uniform trip count (shuffles inside)
                 const PointRec<T> r = my[pt];
+                const bool add_gv = !((g.gv_skip >> ((p0 + pt) / g.P)) & 1u);   // wave-uniform (L <= 32 when set)
                 const T lh = r.f[0], lw = r.f[1], a = r.f[2];
                 const T hh = (T)1 - lh, hw = (T)1 - lw;
                 const T w[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(kDirectThreads) void bwd_direct_kernel(
                         s_h += (hw * (v3 - v1) + lw * (v4 - v2)) * tgv;
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            if (r.o[k] >= 0) atomicAdd(grad_value + r.o[k] + c0 + c, w[k] * tgv);
+                            if (add_gv && r.o[k] >= 0) atomicAdd(grad_value + r.o[k] + c0 + c, w[k] * tgv);
                     }
                 }
                 // sum the per-lane partials over the item's G lanes

@@ -1,0 +1,127 @@
+// msda_levelsum.h -- backward grad_value of WHOLE small levels, accumulated in LDS (gfx950, fp32).
+//
+// When a call sends many sampling points into a small map (decoder calls: 1092 queries x 4 points per head hit a
+// 13x21, 25x42 or 50x84 level), the direct backward kernel spends its time in global float atomics that mostly collide
+// on the same few rows.  This kernel takes such a level away from it: one workgroup owns (image, head, level, slice of
+// kLsChan channels), keeps that whole slice of the level as an f64 window in LDS (ds_add_f64 is the native LDS float
+// atomic on gfx950; ds_add_f32 is serialised, tools/lds_atomic_bench.hip), walks ALL queries of the call for that level
+// and writes every pixel of its slice exactly once with plain stores -- no global atomics, no dependence on the
+// zero-fill.  The f64 window also makes the sum exact to fp32 rounding whatever the order.
+// Semantics: reference ms_deform_im2col_cuda.cuh:87-159 (the grad_value part), products formed in fp32 as there.
+#pragma once
+
+#include "msda_common.h"
+
+namespace msda {
+
+constexpr int kLsChan = 4;          // channels per slice = lanes per sampling point
+constexpr int kLsThreads = 1024;
+constexpr int kLsMaxLevels = 8;     // levels one launch can take
+constexpr int kLsUnroll = 4;        // points in flight per lane group
+constexpr int kLsLdsBudget = 150 * 1024;
+
+struct LevelSumGeom {
+    int N, S, M, D, L, Lq, P;
+    int nlev, nslices;
+    int lev[kLsMaxLevels], H[kLsMaxLevels], W[kLsMaxLevels], start[kLsMaxLevels];
+};
+
+// Which levels of a call this kernel should take (bit l of the result), and the launch geometry for them.
+// A level qualifies when its slice window fits LDS and it receives at least two sampling points per pixel (otherwise
+// there is nothing to merge); the per-workgroup walk over Lq*P points is bounded so that one launch stays short.
+inline unsigned plan_levelsum(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes,
+                              const int64_t *lsi, LevelSumGeom &g, size_t &lds_bytes)
+{
+    g = LevelSumGeom{};
+    lds_bytes = 0;
+    if (L > 32 || D > 128 || (int64_t)Lq * P > 65536) return 0;
+    g.N = N; g.S = S; g.M = M; g.D = D; g.L = L; g.Lq = Lq; g.P = P;
+    g.nslices = (D + kLsChan - 1) / kLsChan;
+    unsigned mask = 0;
+    for (int l = 0; l < L && g.nlev < kLsMaxLevels; ++l) {
+        const int64_t px = shapes[2 * l] * shapes[2 * l + 1];
+        const size_t bytes = (size_t)px * kLsChan * sizeof(double);
+        if (bytes > (size_t)kLsLdsBudget || (int64_t)Lq * P < 2 * px) continue;
+        g.lev[g.nlev] = l;
+        g.H[g.nlev] = (int)shapes[2 * l];
+        g.W[g.nlev] = (int)shapes[2 * l + 1];
+        g.start[g.nlev] = (int)lsi[l];
+        ++g.nlev;
+        mask |= 1u << l;
+        lds_bytes = bytes > lds_bytes ? bytes : lds_bytes;
+    }
+    return mask;
+}
+
+inline int levelsum_grid(const LevelSumGeom &g)
+{
+    return kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.nlev * g.nslices;
+}
+
+__global__ __launch_bounds__(kLsThreads) void bwd_levelsum_kernel(const float *__restrict__ loc,
+                                                                  const float *__restrict__ aw,
+                                                                  const float *__restrict__ grad_out,
+                                                                  float *__restrict__ grad_value, const LevelSumGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *win = reinterpret_cast<double *>(smem);
+
+    int pair, t;
+    if (!decode_block(blockIdx.x, g.N * g.M, g.nlev * g.nslices, pair, t)) return;
+    // the slices of one level are neighbours in the XCD-local order: they read the same loc / attn lines
+    const int li = t / g.nslices, slice = t - li * g.nslices;
+    const int b = pair / g.M, m = pair - b * g.M;
+    const int l = g.lev[li], H = g.H[li], W = g.W[li];
+    const int npx = H * W;
+    const int tid = threadIdx.x;
+    const int j = tid & (kLsChan - 1), grp = tid / kLsChan;
+    constexpr int kGroups = kLsThreads / kLsChan;
+    const int ch = slice * kLsChan + j;
+    const bool has_ch = ch < g.D;
+
+    for (int e = tid; e < npx * kLsChan; e += kLsThreads) win[e] = 0.0;
+    __syncthreads();
+
+    const int LP = g.L * g.P;
+    const int npts = g.Lq * g.P;   // sampling points of this (image, head, level)
+    for (int i0 = grp; i0 < npts; i0 += kGroups * kLsUnroll) {
+        float x[kLsUnroll], y[kLsUnroll], ga[kLsUnroll];
+#pragma unroll
+        for (int u = 0; u < kLsUnroll; ++u) {   // all loads of the batch are issued before the first use
+            const int i = i0 + u * kGroups;
+            const bool live = i < npts;
+            const int q = live ? i / g.P : 0, p = live ? i - q * g.P : 0;
+            const unsigned item = (unsigned)((b * g.Lq + q) * g.M + m);
+            const unsigned pt = item * (unsigned)LP + (unsigned)(l * g.P + p);
+            const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
+            const float a = aw[pt];
+            const float go = has_ch ? grad_out[item * (unsigned)g.D + ch] : 0.f;
+            x[u] = xy.x;
+            y[u] = xy.y;
+            ga[u] = live ? go * a : 0.f;          // top_grad * attn_weight (ms_deform_im2col_cuda.cuh:117)
+            if (!live) x[u] = -4.f;               // dropped by the range test below
+        }
+#pragma unroll
+        for (int u = 0; u < kLsUnroll; ++u) {
+            const float h_im = y[u] * (float)H - 0.5f, w_im = x[u] * (float)W - 0.5f;
+            if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) continue;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)hf, w_low = (int)wf;
+            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+            const bool top = h_low >= 0, bot = h_low + 1 <= H - 1, lef = w_low >= 0, rig = w_low + 1 <= W - 1;
+            double *p00 = win + (h_low * W + w_low) * kLsChan + j;
+            if (top && lef) atomicAdd(p00, (double)(hh * hw * ga[u]));
+            if (top && rig) atomicAdd(p00 + kLsChan, (double)(hh * lw * ga[u]));
+            if (bot && lef) atomicAdd(p00 + W * kLsChan, (double)(lh * hw * ga[u]));
+            if (bot && rig) atomicAdd(p00 + (W + 1) * kLsChan, (double)(lh * lw * ga[u]));
+        }
+    }
+    __syncthreads();
+
+    // every pixel of the slice, once: 16 B per lane group
+    float *dst = grad_value + ((int64_t)(b * g.S + g.start[li]) * g.M + m) * g.D + ch;
+    if (has_ch)
+        for (int px = grp; px < npx; px += kGroups) dst[(int64_t)px * g.M * g.D] = (float)win[px * kLsChan + j];
+}
+
+}  // namespace msda

@@ -52,7 +52,8 @@ constexpr int kScatterBatch = 2;                      // queries per group whose
 struct TiledGeom {
     int N, S, M, Lq, L, P;
     int GY, GX;            // region grid over the normalised image plane
-    int margin;            // window margin, in pixels of the sampled level
+    int margin;            // window margin, in pixels of the sampled level (base value)
+    int margin_l[kTL];     // per level, after growing into unused LDS
     int H[kTL], W[kTL], start[kTL];
     int phase[kTL];        // levels are processed in phases; the windows of one phase share the LDS
     int nphases;
@@ -122,6 +123,7 @@ struct TiledOptions {
     int bwd_halves = 0;  // backward location/attention gradients: 0 = 32 channels at once (faster as measured), 1 = two 16-channel passes
     int persist = 512;   // 0 = one workgroup per work item; n > 0 = at most n workgroups (n/2 for the 1024-thread kernels)
                          // walking the items (2 x 256 CUs by default: no per-item launch ramp)
+    int grow = 1;    // 1 = windows grow into the LDS their phase leaves unused (per-level margins)
     int accum = 2;   // grad_value: 0 = f64 LDS atomic window, 1 = integer block-floating-point window, 2 = sorted reduction
     int dbg = 0;
     unsigned long long *stamps = nullptr;
@@ -169,6 +171,16 @@ inline TiledPlan plan_tiled(int N, int S, int M, int D, int L, int Lq, int P, co
         Wmax = g.W[l] > Wmax ? g.W[l] : Wmax;
     }
     int cap_px = budget_bytes / px_bytes;
+    // largest window of level l over all regions, for a given margin
+    auto worst_window = [&g](int l, int mg) {
+        int worst = 0;
+        for (int gy = 0; gy < g.GY; ++gy)
+            for (int gx = 0; gx < g.GX; ++gx) {
+                const LevelRect r = level_rect(g.H[l], g.W[l], gy, gx, g.GY, g.GX, mg);
+                worst = r.nwr * r.nwc > worst ? r.nwr * r.nwc : worst;
+            }
+        return worst;
+    };
     // region grid: ~region_px pixels of the finest level per side; refine until queries and windows fit
     for (int rp = region_px; rp >= 4; rp -= 2) {
         g.GY = (Hmax + rp - 1) / rp;
@@ -181,11 +193,10 @@ inline TiledPlan plan_tiled(int N, int S, int M, int D, int L, int Lq, int P, co
                 for (int l = 0; l < L; ++l) {
                     const LevelRect r = level_rect(g.H[l], g.W[l], gy, gx, g.GY, g.GX, margin);
                     nq += r.qnr * r.qnc;
-                    const int w = r.nwr * r.nwc;
-                    max_win[l] = w > max_win[l] ? w : max_win[l];
                 }
                 max_q = nq > max_q ? nq : max_q;
             }
+        for (int l = 0; l < L; ++l) max_win[l] = worst_window(l, margin);
         cap_px = (budget_bytes - max_q * per_query_bytes) / px_bytes;   // LDS also holds per-query data in some kernels
         bool fits = max_q <= kMaxRegionQueries && cap_px > 0;
         for (int l = 0; l < L; ++l) fits = fits && max_win[l] <= cap_px;
@@ -200,7 +211,34 @@ inline TiledPlan plan_tiled(int N, int S, int M, int D, int L, int Lq, int P, co
         }
         for (int l = L; l < kTL; ++l) { g.phase[l] = -1; g.H[l] = g.W[l] = 1; g.start[l] = 0; }
         g.nphases = ph + 1;
+        // per-level margins.  With `grow` the LDS a phase leaves unused widens the windows of its levels, coarsest
+        // first (a pixel of margin is cheapest there and the queries of a coarse level sit closest to their region's
+        // edge), until the window is the whole map: fewer points on the general path when the offsets reach far.
+        int mg[kTL];
+        for (int l = 0; l < kTL; ++l) mg[l] = margin;
+        if (tiled_options().grow) {
+            for (int p = 0; p <= ph; ++p) {
+                int used_p = 0;
+                for (int l = 0; l < L; ++l) used_p += g.phase[l] == p ? max_win[l] : 0;
+                bool grew = true;
+                while (grew) {
+                    grew = false;
+                    for (int l = L - 1; l >= 0; --l) {
+                        if (g.phase[l] != p || mg[l] >= 64) continue;
+                        const int w = worst_window(l, mg[l] + 1);
+                        if (w == max_win[l] || used_p - max_win[l] + w > cap_px) continue;   // whole map / no room
+                        used_p += w - max_win[l];
+                        max_win[l] = w;
+                        ++mg[l];
+                        grew = true;
+                    }
+                }
+                max_phase_px = used_p > max_phase_px ? used_p : max_phase_px;
+            }
+        }
+        for (int l = 0; l < kTL; ++l) g.margin_l[l] = mg[l];
         for (int l = 0; l < kTL; ++l) {
+            const int margin = mg[l];
             for (int gy = 0; gy <= g.GY; ++gy) {
                 const LevelRect r = level_rect(g.H[l], g.W[l], gy < g.GY ? gy : g.GY - 1, 0, g.GY, g.GX, margin);
                 g.rq0[l][gy] = (short)(gy < g.GY ? r.qr0 : r.qr0 + r.qnr);
@@ -1359,7 +1397,7 @@ inline TiledPlan plan_bwd_gather(int N, int S, int M, int D, int L, int Lq, int 
             for (int gy = 0; gy < pl.g.GY; ++gy)
                 for (int gx = 0; gx < pl.g.GX; ++gx)
                     for (int l = 0; l < L; ++l) {
-                        const LevelRect r = level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin);
+                        const LevelRect r = level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin_l[l]);
                         max_px = r.nwr * r.nwc > max_px ? r.nwr * r.nwc : max_px;
                     }
             for (int l = 0; l < L; ++l) pl.g.phase[l] = l;
@@ -1385,7 +1423,7 @@ inline TiledPlan plan_scatter_bfp(int N, int S, int M, int D, int L, int Lq, int
         for (int gy = 0; gy < pl.g.GY; ++gy)
             for (int gx = 0; gx < pl.g.GX; ++gx)
                 for (int l = 0; l < L; ++l) {
-                    const LevelRect r = level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin);
+                    const LevelRect r = level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin_l[l]);
                     max_px = r.nwr * r.nwc > max_px ? r.nwr * r.nwc : max_px;
                 }
         for (int l = 0; l < L; ++l) pl.g.phase[l] = l;
@@ -1406,7 +1444,7 @@ inline TiledPlan plan_scatter_sorted(int N, int S, int M, int D, int L, int Lq, 
         for (int gy = 0; gy < pl.g.GY; ++gy)
             for (int gx = 0; gx < pl.g.GX; ++gx)
                 for (int l = 0; l < L; ++l) {
-                    const LevelRect r = level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin);
+                    const LevelRect r = level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin_l[l]);
                     max_px = r.nwr * r.nwc > max_px ? r.nwr * r.nwc : max_px;
                 }
         if (max_px > kSortMaxPx) { pl.ok = false; return pl; }

@@ -274,6 +274,7 @@ def test_full_size_properties(which):
     {"bwd_gather_halves": 1},                # backward gather on channel halves
     {"tile_region": 12, "tile_margin": 3},   # small windows: many samples take the general (global) path
     {"tile_margin": 0},
+    {"tile_grow": 0},                        # every level exactly tile_margin (default: windows grow into spare LDS)
 ])
 @pytest.mark.parametrize("which", ["E", "Em"])
 def test_window_kernel_options_do_not_change_results(which, opts):
@@ -361,3 +362,34 @@ def test_locality_monitor_picks_kernels_by_data(loc_mode, expect):
     _lib.set_option("locality_monitor", 0)
     assert _variants_of(fwd) == [2] and _variants_of(bwd) == [2]
     _lib.set_option("locality_monitor", 1)
+
+
+@pytest.mark.parametrize("loc_mode", ["init", "uniform"])
+@pytest.mark.parametrize("dims", [
+    dict(call="Dd"),                                                              # BASELINE decoder call, full size
+    dict(N=1, M=3, D=30, P=3, shapes=[(40, 50), (7, 9), (1, 1), (20, 20)], Lq=700),   # D not a multiple of the slice
+    dict(N=2, M=2, D=64, P=4, shapes=[(3, 2), (64, 64)], Lq=300),                 # only the first level qualifies
+])
+def test_levelsum_backward_matches_oracle_and_atomics(dims, loc_mode):
+    """Direct backward with whole small levels summed in LDS (msda_levelsum.h, default) against the oracle and against
+    the all-atomics form (bwd_levelsum=0)."""
+    if "call" in dims:
+        call = W.call_Dd(2)
+    else:
+        S = sum(h * w for h, w in dims["shapes"])
+        call = W.Call("ls", dims["N"], dims["M"], dims["D"], dims["P"], dims["shapes"], dims["Lq"], False)
+        assert call.S == S
+    t = W.make_inputs(call, loc_mode, seed=5)
+    z = {k: v.numpy() for k, v in t.items()}
+    ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
+    tf, tg = tols(np.float32)
+    res = {}
+    try:
+        for on in (1, 0):
+            _lib.set_option("bwd_levelsum", on)
+            _, gv, gl, ga = run_gpu(z, 1)
+            assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg
+            res[on] = gv
+    finally:
+        _lib.set_option("bwd_levelsum", 1)
+    assert torch.allclose(res[0], res[1], rtol=1e-3, atol=1e-3 * float(np.abs(ogv).max()))
