@@ -38,10 +38,20 @@ constexpr int kFwdLdsBudget = 75 * 1024;   // + header < 80 KiB: two workgroups 
 // Backward location / attention gradients need all 32 channels of a sample at once: 8 lanes per query, 1024 threads,
 // one workgroup per CU (two 16-channel passes with a read-modify-write of the per-point results measured slower).
 constexpr int kBwdGC = 32;
+constexpr int kBwdCPL = 8;            // backward gather: channels per lane (4 lanes per query)
 constexpr int kBwdLdsBudget = 152 * 1024;   // region 20 fits its finest-level window in one phase
 // ... alternatively on channel halves like the forward (two workgroups per CU, the first half's per-point results kept
 // in registers): needs one level per work item and P <= 4 (tile option "bwd_gather_halves")   // three phases = three independent workgroups per region (measured faster than two)
-constexpr int kGatherQPG = 4;        // queries per lane group (128 groups -> <= 512 queries per region)
+// Lane layout of the gather kernels: GC channels per workgroup pass, CPL channels per lane (4 or 8), so GL = GC/CPL lanes
+// per query; QPG queries per lane group so that one pass over k covers the largest region (kMaxRegionQueries).
+template <int GC, int CPL>
+struct GatherCfg {
+    static constexpr int GL = GC / CPL;
+    static constexpr int NV = CPL / 4;                       // float4 vectors per lane
+    static constexpr int kThreads = GC == 16 ? 512 : 1024;
+    static constexpr int kGroups = kThreads / GL;            // queries in flight per pass over k
+    static constexpr int QPG = 512 / kGroups;                // = kMaxRegionQueries / kGroups
+};
 // Scatter kernel (backward grad_value): 16 channels x f64 = 128 B per window pixel, one workgroup per CU.
 constexpr int kTiledThreads = 1024;
 constexpr int kSD = 16;              // channels per scatter workgroup (two workgroups per region: channel halves)
@@ -378,40 +388,44 @@ __device__ __forceinline__ float quad_sum(float v)
     return v;
 }
 
-// The four corner rows of an IN-WINDOW sampling point for this lane's 4 channels: straight-line LDS reads.
-template <int GC>
-__device__ __forceinline__ void lds_corners(const float *win, int nwc, int j, int mode, float4 &v1, float4 &v2, float4 &v3,
-                                            float4 &v4)
+// The four corner rows of an IN-WINDOW sampling point for this lane's 4*NV channels: straight-line LDS reads.
+template <int GC, int NV>
+__device__ __forceinline__ void lds_corners(const float *win, int nwc, int j, int mode, float4 (&v)[4][NV])
 {
-    const float *p = win + mode + 4 * j;
-    v1 = *reinterpret_cast<const float4 *>(p);
-    v2 = *reinterpret_cast<const float4 *>(p + GC);
-    v3 = *reinterpret_cast<const float4 *>(p + nwc * GC);
-    v4 = *reinterpret_cast<const float4 *>(p + nwc * GC + GC);
+    const float *p = win + mode + 4 * NV * j;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        v[0][n] = *reinterpret_cast<const float4 *>(p + 4 * n);
+        v[1][n] = *reinterpret_cast<const float4 *>(p + GC + 4 * n);
+        v[2][n] = *reinterpret_cast<const float4 *>(p + nwc * GC + 4 * n);
+        v[3][n] = *reinterpret_cast<const float4 *>(p + nwc * GC + GC + 4 * n);
+    }
 }
 
-// Sum over the GC/4 lanes of a query: the quad, plus the neighbouring quad (row_half_mirror) when a query spans 8 lanes.
-template <int GC>
+// Sum over the GL lanes of a query: the quad, plus the neighbouring quad (row_half_mirror) when a query spans 8 lanes.
+template <int GL>
 __device__ __forceinline__ float query_sum(float v)
 {
     v = quad_sum(v);
-    if (GC == 32) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+    if (GL == 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
     return v;
 }
 
 // General point (a corner outside the window): corners from global memory, zero outside the map.
-// `chan` = first channel of this lane inside the head (channel half * 16 + 4 * lane).
+// `chan` = first channel of this lane inside the head.
+template <int NV>
 __device__ __forceinline__ void global_corners(const float *__restrict__ value, const LevelCtx &lc, int row_elems, int chan,
-                                               float x, float y, float4 &v1, float4 &v2, float4 &v3, float4 &v4)
+                                               float x, float y, float4 (&v)[4][NV])
 {
     int o[4];
     float lh2, lw2;
     resolve_point<float>(x, y, lc.H, lc.W, lc.base_row, row_elems, o, lh2, lw2);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    v1 = o[0] >= 0 ? *reinterpret_cast<const float4 *>(value + o[0] + chan) : z;
-    v2 = o[1] >= 0 ? *reinterpret_cast<const float4 *>(value + o[1] + chan) : z;
-    v3 = o[2] >= 0 ? *reinterpret_cast<const float4 *>(value + o[2] + chan) : z;
-    v4 = o[3] >= 0 ? *reinterpret_cast<const float4 *>(value + o[3] + chan) : z;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int n = 0; n < NV; ++n)
+            v[c][n] = o[c] >= 0 ? *reinterpret_cast<const float4 *>(value + o[c] + chan + 4 * n) : z;
 }
 
 __device__ __forceinline__ void fwd_accumulate(float w1, float w2, float w3, float w4, const float4 &v1, const float4 &v2,
@@ -426,18 +440,22 @@ __device__ __forceinline__ void fwd_accumulate(float w1, float w2, float w3, flo
 //   grad_attn = w1*D1 + w2*D2 + w3*D3 + w4*D4,  d/dlw = hh*(D2-D1) + lh*(D4-D3),  d/dlh = hw*(D3-D1) + lw*(D4-D2)
 // so a lane only forms the four dots over its 4 channels (8 packed FMAs); the dots are summed over the query's lanes and
 // combined with the bilinear coefficients afterwards.
-__device__ __forceinline__ void corner_dots(const float4 &gq, const float4 &v1, const float4 &v2, const float4 &v3,
-                                            const float4 &v4, float &d1, float &d2, float &d3, float &d4)
+template <int NV>
+__device__ __forceinline__ void corner_dots(const float4 (&gq)[NV], const float4 (&v)[4][NV], float &d1, float &d2, float &d3,
+                                            float &d4)
 {
-    const v2f gl = {gq.x, gq.y}, gh = {gq.z, gq.w};
-    const v2f t1 = gl * (v2f){v1.x, v1.y} + gh * (v2f){v1.z, v1.w};
-    const v2f t2 = gl * (v2f){v2.x, v2.y} + gh * (v2f){v2.z, v2.w};
-    const v2f t3 = gl * (v2f){v3.x, v3.y} + gh * (v2f){v3.z, v3.w};
-    const v2f t4 = gl * (v2f){v4.x, v4.y} + gh * (v2f){v4.z, v4.w};
-    d1 = t1.x + t1.y;
-    d2 = t2.x + t2.y;
-    d3 = t3.x + t3.y;
-    d4 = t4.x + t4.y;
+    v2f t[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        t[c] = (v2f){gq[0].x, gq[0].y} * (v2f){v[c][0].x, v[c][0].y} + (v2f){gq[0].z, gq[0].w} * (v2f){v[c][0].z, v[c][0].w};
+#pragma unroll
+        for (int n = 1; n < NV; ++n)
+            t[c] += (v2f){gq[n].x, gq[n].y} * (v2f){v[c][n].x, v[c][n].y} + (v2f){gq[n].z, gq[n].w} * (v2f){v[c][n].z, v[c][n].w};
+    }
+    d1 = t[0].x + t[0].y;
+    d2 = t[1].x + t[1].y;
+    d3 = t[2].x + t[2].y;
+    d4 = t[3].x + t[3].y;
 }
 
 __device__ __forceinline__ void combine_dots(float lh, float lw, float d1, float d2, float d3, float d4, float &s_a,
@@ -452,18 +470,20 @@ __device__ __forceinline__ void combine_dots(float lh, float lw, float d1, float
 // This lane's sampling point (lane i of the quad holds point i of the level's first four) for each of the quad's
 // queries.  Loaded one level AHEAD of its use, so the global-memory latency hides behind the window fill / the
 // previous level's gather.
+template <int QPG>
 struct LevelOps {
-    float2 xy[kGatherQPG];
-    float a[kGatherQPG];
+    float2 xy[QPG];
+    float a[QPG];
 };
 
+template <int QPG>
 __device__ __forceinline__ void load_level_ops(const float *__restrict__ loc, const float *__restrict__ aw,
-                                               const unsigned (&item)[kGatherQPG], unsigned LP, unsigned lvl_pt0, int P,
-                                               int j, LevelOps &o)
+                                               const unsigned (&item)[QPG], unsigned LP, unsigned lvl_pt0, int P, int j,
+                                               LevelOps<QPG> &o)
 {
     const unsigned mp = lvl_pt0 + ((j & 3) < P ? (j & 3) : 0);
 #pragma unroll
-    for (int k = 0; k < kGatherQPG; ++k) {   // queries without a slot read a valid address and are masked later
+    for (int k = 0; k < QPG; ++k) {   // queries without a slot read a valid address and are masked later
         o.xy[k] = *reinterpret_cast<const float2 *>(loc + 2u * (item[k] * LP + mp));
         o.a[k] = aw[item[k] * LP + mp];
     }
@@ -492,15 +512,17 @@ __device__ __forceinline__ void store_point_grads(float *__restrict__ grad_loc, 
 // afterwards in ONE run-time loop per query (not unrolled), with shuffles instead of DPP.
 // MODE (backward): 0 = all 32 channels in one pass: store the per-point results; 1 = first channel half: keep them in
 // `part` (lane i of the quad keeps point i); 2 = second channel half: add `part` and store.
-template <bool BWD, bool P4, int MODE, int GC>
-__device__ __forceinline__ void gather_level(const float *__restrict__ value, const float *__restrict__ loc,
-                                             const float *__restrict__ aw, const float *win, const LevelCtx &lc,
-                                             int row_elems, int P_, int j, int chan, const unsigned (&pt0)[kGatherQPG],
-                                             const bool (&live)[kGatherQPG], const LevelOps &pre,
-                                             v2f (&acc_lo)[kGatherQPG], v2f (&acc_hi)[kGatherQPG],
-                                             const float4 (&gq)[kGatherQPG], float (&part)[kGatherQPG][3],
-                                             float *__restrict__ grad_loc, float *__restrict__ grad_aw, unsigned &n_general)
+template <bool BWD, bool P4, int MODE, int GC, int CPL>
+__device__ __forceinline__ void gather_level(
+    const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ aw, const float *win,
+    const LevelCtx &lc, int row_elems, int P_, int j, int chan, const unsigned (&pt0)[GatherCfg<GC, CPL>::QPG],
+    const bool (&live)[GatherCfg<GC, CPL>::QPG], const LevelOps<GatherCfg<GC, CPL>::QPG> &pre,
+    v2f (&acc_lo)[GatherCfg<GC, CPL>::QPG], v2f (&acc_hi)[GatherCfg<GC, CPL>::QPG],
+    const float4 (&gq)[GatherCfg<GC, CPL>::QPG][GatherCfg<GC, CPL>::NV], float (&part)[GatherCfg<GC, CPL>::QPG][3],
+    float *__restrict__ grad_loc, float *__restrict__ grad_aw, unsigned &n_general)
 {
+    constexpr int kGatherQPG = GatherCfg<GC, CPL>::QPG, NV = GatherCfg<GC, CPL>::NV, GL = GatherCfg<GC, CPL>::GL;
+    static_assert(BWD || NV == 1, "the forward keeps its accumulators for four channels per lane");
     const int P = P4 ? 4 : P_;
     for (int pc = 0; pc < P; pc += 4) {
         const int myp = pc + (j & 3);
@@ -540,22 +562,22 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
         any_slow |= m_ == -2;                                                                                          \
         if (!BWD) {                                                                                                    \
             if (m_ >= 0) {                                                                                             \
-                float4 v1, v2, v3, v4;                                                                                 \
-                lds_corners<GC>(win, lc.nwc, j, m_, v1, v2, v3, v4);                                                       \
-                fwd_accumulate(quad_bcast_f<I>(w1), quad_bcast_f<I>(w2), quad_bcast_f<I>(w3), quad_bcast_f<I>(w4), v1, \
-                               v2, v3, v4, acc_lo[k], acc_hi[k]);                                                      \
+                float4 v[4][NV];                                                                                       \
+                lds_corners<GC, NV>(win, lc.nwc, j, m_, v);                                                            \
+                fwd_accumulate(quad_bcast_f<I>(w1), quad_bcast_f<I>(w2), quad_bcast_f<I>(w3), quad_bcast_f<I>(w4),     \
+                               v[0][0], v[1][0], v[2][0], v[3][0], acc_lo[k], acc_hi[k]);                              \
             }                                                                                                          \
         } else {                                                                                                       \
             float d1 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f, s_a, s_w, s_h;                                               \
             if (m_ >= 0) {                                                                                             \
-                float4 v1, v2, v3, v4;                                                                                 \
-                lds_corners<GC>(win, lc.nwc, j, m_, v1, v2, v3, v4);                                                   \
-                corner_dots(gq[k], v1, v2, v3, v4, d1, d2, d3, d4);                                                    \
+                float4 v[4][NV];                                                                                       \
+                lds_corners<GC, NV>(win, lc.nwc, j, m_, v);                                                            \
+                corner_dots<NV>(gq[k], v, d1, d2, d3, d4);                                                             \
             }                                                                                                          \
-            d1 = query_sum<GC>(d1);                                                                                    \
-            d2 = query_sum<GC>(d2);                                                                                    \
-            d3 = query_sum<GC>(d3);                                                                                    \
-            d4 = query_sum<GC>(d4);                                                                                    \
+            d1 = query_sum<GL>(d1);                                                                                    \
+            d2 = query_sum<GL>(d2);                                                                                    \
+            d3 = query_sum<GL>(d3);                                                                                    \
+            d4 = query_sum<GL>(d4);                                                                                    \
             combine_dots(quad_bcast_f<I>(lh), quad_bcast_f<I>(lw), d1, d2, d3, d4, s_a, s_w, s_h);                     \
             /* lane I of the quad keeps point I (dropped / general points: zeros here, general ones redone below); */  \
             /* the four points are stored together after the loop: one 16-B and one 32-B segment per query */          \
@@ -593,19 +615,19 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
                     const float lh_ = __shfl(lh, lane0 + i, kWave), lw_ = __shfl(lw, lane0 + i, kWave);
                     const float a_ = __shfl(a, lane0 + i, kWave);
                     if (m_ != -2) continue;   // uniform over the quad
-                    float4 v1, v2, v3, v4;
-                    global_corners(value, lc, row_elems, chan, x_, y_, v1, v2, v3, v4);
+                    float4 v[4][NV];
+                    global_corners<NV>(value, lc, row_elems, chan, x_, y_, v);
                     if (!BWD) {
                         const float hh_ = 1.f - lh_, hw_ = 1.f - lw_;
-                        fwd_accumulate(hh_ * hw_ * a_, hh_ * lw_ * a_, lh_ * hw_ * a_, lh_ * lw_ * a_, v1, v2, v3, v4,
-                                       acc_lo[k], acc_hi[k]);
+                        fwd_accumulate(hh_ * hw_ * a_, hh_ * lw_ * a_, lh_ * hw_ * a_, lh_ * lw_ * a_, v[0][0], v[1][0],
+                                       v[2][0], v[3][0], acc_lo[k], acc_hi[k]);
                     } else {
                         float d1, d2, d3, d4, s_a, s_w, s_h;
-                        corner_dots(gq[k], v1, v2, v3, v4, d1, d2, d3, d4);
-                        d1 = query_sum<GC>(d1);
-                        d2 = query_sum<GC>(d2);
-                        d3 = query_sum<GC>(d3);
-                        d4 = query_sum<GC>(d4);
+                        corner_dots<NV>(gq[k], v, d1, d2, d3, d4);
+                        d1 = query_sum<GL>(d1);
+                        d2 = query_sum<GL>(d2);
+                        d3 = query_sum<GL>(d3);
+                        d4 = query_sum<GL>(d4);
                         combine_dots(lh_, lw_, d1, d2, d3, d4, s_a, s_w, s_h);
                         // the fast pass gave this point zeros: add ours on top (first half: in `part`, else in memory)
                         if (j == i) {
@@ -628,7 +650,7 @@ __device__ __forceinline__ void gather_level(const float *__restrict__ value, co
 // Forward (BWD = false): workgroup = (image, head, region, channel half); accumulates over the LDS phases in registers.
 // Backward (BWD = true): workgroup = (image, head, region, LDS phase); runs the two channel halves one after the other
 // (the per-point gradients are sums over all 32 channels).
-template <bool BWD, bool P4, int GC>
+template <bool BWD, bool P4, int GC, int CPL>
 __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled_gather_kernel(
     const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ aw,
     const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
@@ -640,9 +662,13 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
 
     // the sub-workgroups of a region are the fastest-varying part of the XCD-local index: they run back to back on one
     // XCD and share loc / attn / grad_out (and the value windows) in its L2
-    constexpr int GL = GC / 4;                              // lanes per query
-    constexpr int kThreads = GC == 16 ? 512 : 1024;
-    constexpr int kGroups = kThreads / GL;                   // 128 queries in flight per pass over k
+    using Cfg = GatherCfg<GC, CPL>;
+    constexpr int GL = Cfg::GL;                              // lanes per query
+    constexpr int NV = Cfg::NV;
+    constexpr int kThreads = Cfg::kThreads;
+    constexpr int kGroups = Cfg::kGroups;                    // queries in flight per pass over k
+    constexpr int kGatherQPG = Cfg::QPG;
+    constexpr int FL = GC / 4, kFillGroups = kThreads / FL;  // window fill: 16 B per lane, FL lanes per pixel
     constexpr int kHalves = kTD / GC;                        // channel passes per region
     const int nsub = BWD ? g.nphases : kHalves;
     // Persistent form: the grid may be smaller than the number of work items; a workgroup then walks the items
@@ -661,6 +687,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
 
     const int tid = threadIdx.x;
     const int j = tid & (GL - 1), grp = tid / GL;
+    const int fj = tid & (FL - 1), fgrp = tid / FL;
     const int row_elems = g.M * kTD;
     const int LP = g.L * g.P;
 
@@ -684,31 +711,33 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
     const int half_begin = BWD ? 0 : sub, half_end = BWD ? kHalves : sub + 1;
     int st = 2;
     for (int half = half_begin; half < half_end; ++half) {
-        const int chan = half * GC + 4 * j;   // this lane's first channel inside the head
-        float4 gq[kGatherQPG];                 // backward: grad_out of the quad's queries, this lane's 4 channels
+        const int chan = half * GC + CPL * j;   // this lane's first channel inside the head
+        float4 gq[kGatherQPG][NV];               // backward: grad_out of the group's queries, this lane's channels
 #pragma unroll
         for (int k = 0; k < kGatherQPG; ++k)
-            gq[k] = BWD ? *reinterpret_cast<const float4 *>(grad_out + item[k] * (unsigned)kTD + chan)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < NV; ++n)
+                gq[k][n] = BWD ? *reinterpret_cast<const float4 *>(grad_out + item[k] * (unsigned)kTD + chan + 4 * n)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int ph = ph_begin; ph < ph_end; ++ph) {
             // levels of this phase are consecutive: [lb, le)
             int lb = g.L, le = 0;
             for (int l = 0; l < g.L; ++l)
                 if (uni(hdr->phase[l]) == ph) { lb = l < lb ? l : lb; le = l + 1; }
-            LevelOps nxt;
+            LevelOps<kGatherQPG> nxt;
             load_level_ops(loc, aw, item, (unsigned)LP, (unsigned)(lb * g.P), g.P, j, nxt);   // in flight during the fill
             // ---- stage this phase's windows: 64-B pixel half-rows, 16 B per lane -------------------------------------
             for (int l = lb; l < le; ++l) {
                 const int wr0 = uni(hdr->r[l].wr0), wc0 = uni(hdr->r[l].wc0), nwc = uni(hdr->r[l].nwc);
                 const int npx = uni(hdr->r[l].nwr) * nwc, Wl = uni(hdr->W[l]), Hl = uni(hdr->H[l]);
-                const float *src = value + ((int64_t)(b * g.S + uni(hdr->start[l])) * g.M + m) * kTD + chan;
-                float *dst = win + (int64_t)uni(hdr->lds_px[l]) * GC + 4 * j;
+                const float *src = value + ((int64_t)(b * g.S + uni(hdr->start[l])) * g.M + m) * kTD + half * GC + 4 * fj;
+                float *dst = win + (int64_t)uni(hdr->lds_px[l]) * GC + 4 * fj;
                 // eight independent loads in flight per lane before the first LDS store
-                for (int px0 = grp; px0 < npx; px0 += 8 * kGroups) {
+                for (int px0 = fgrp; px0 < npx; px0 += 8 * kFillGroups) {
                     float4 v[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int px = min(px0 + u * kGroups, npx - 1);   // clamped; stored only if in range
+                        const int px = min(px0 + u * kFillGroups, npx - 1);   // clamped; stored only if in range
                         const int rr = px / nwc, cc = px - rr * nwc;
                         const int row = wr0 + rr, col = wc0 + cc;
                         const bool in_map = row >= 0 && row < Hl && col >= 0 && col < Wl;   // else: the zero apron
@@ -718,7 +747,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int px = px0 + u * kGroups;
+                        const int px = px0 + u * kFillGroups;
                         if (px < npx) *reinterpret_cast<float4 *>(dst + px * GC) = v[u];
                     }
                 }
@@ -728,7 +757,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
 
             // ---- gather -------------------------------------------------------------------------------------
             for (int l = lb; l < le; ++l) {
-                const LevelOps cur = nxt;
+                const LevelOps<kGatherQPG> cur = nxt;
                 if (l + 1 < le) load_level_ops(loc, aw, item, (unsigned)LP, (unsigned)((l + 1) * g.P), g.P, j, nxt);
                 LevelCtx lc;
                 lc.H = uni(hdr->H[l]);
@@ -743,13 +772,13 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
 #pragma unroll
                 for (int k = 0; k < kGatherQPG; ++k) pt0[k] = item[k] * (unsigned)LP + (unsigned)(l * g.P);
                 if (!BWD || kHalves == 1)
-                    gather_level<BWD, P4, 0, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
+                    gather_level<BWD, P4, 0, GC, CPL>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
                                                  acc_hi, gq, part, grad_loc, grad_aw, n_general);
                 else if (half == 0)
-                    gather_level<BWD, P4, 1, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
+                    gather_level<BWD, P4, 1, GC, CPL>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
                                                  acc_hi, gq, part, grad_loc, grad_aw, n_general);
                 else
-                    gather_level<BWD, P4, 2, GC>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
+                    gather_level<BWD, P4, 2, GC, CPL>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
                                                  acc_hi, gq, part, grad_loc, grad_aw, n_general);
             }
             __syncthreads();   // the next fill overwrites the windows
@@ -1522,7 +1551,7 @@ inline hipError_t launch_fwd_tiled<float>(const float *value, const int64_t *, c
     TiledPlan pl = plan_gather(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
     if (!pl.ok) return hipErrorInvalidValue;
     if (general_points) pl.g.stats = general_points;   // locality monitor (msda_api.hip); else the diagnostic override
-    auto kern = P == 4 ? &tiled_gather_kernel<false, true, kFwdGC> : &tiled_gather_kernel<false, false, kFwdGC>;
+    auto kern = P == 4 ? &tiled_gather_kernel<false, true, kFwdGC, 4> : &tiled_gather_kernel<false, false, kFwdGC, 4>;
     hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pl.lds_bytes);
     if (e != hipSuccess) return e;
     const int grid = persistent_grid(pl.grid * (kTD / kFwdGC), tiled_options().persist, kTD / kFwdGC);
@@ -1548,8 +1577,8 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
     if (!pg.ok || !ps.ok) return hipErrorInvalidValue;
     const size_t lds_scatter = ps.lds_bytes;
     const bool halves = pg.max_px == kFwdGC;
-    auto kern = halves ? (P == 4 ? &tiled_gather_kernel<true, true, kFwdGC> : &tiled_gather_kernel<true, false, kFwdGC>)
-                       : (P == 4 ? &tiled_gather_kernel<true, true, kBwdGC> : &tiled_gather_kernel<true, false, kBwdGC>);
+    auto kern = halves ? (P == 4 ? &tiled_gather_kernel<true, true, kFwdGC, 4> : &tiled_gather_kernel<true, false, kFwdGC, 4>)
+                       : (P == 4 ? &tiled_gather_kernel<true, true, kBwdGC, kBwdCPL> : &tiled_gather_kernel<true, false, kBwdGC, kBwdCPL>);
     hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pg.lds_bytes);
     if (e == hipSuccess) e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_kernel), lds_scatter);
     if (e != hipSuccess) return e;
