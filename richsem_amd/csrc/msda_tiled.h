@@ -1207,20 +1207,24 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_bfp_kernel(
 constexpr int kSortMaxPx = 1280;            // largest single-level window (pixels) the kernel takes
 constexpr int kSortMaxPts = kMaxRegionQueries * 4;
 
-struct alignas(4) SortRec {
-    int q;        // index of the query inside the region (row of gcache)
-    float w[4];   // bilinear weight x attention weight of the four corners
+struct alignas(8) SortRec {
+    int q;     // index of the query inside the region (row of gcache)
+    float w;   // bilinear weight x attention weight of the corner that is this pixel
 };
 
 struct SortLds {   // after the TileHeader
     float gcache[kMaxRegionQueries * kTD];
     int offs[kSortMaxPx + 4];               // histogram, then exclusive prefix (offs[npx] = total)
-    SortRec sorted[kSortMaxPts];
-    int genlist[kSortMaxPts];
+    SortRec sorted[4 * kSortMaxPts];        // one entry per (point, corner), grouped by destination pixel
+    unsigned short genlist[kSortMaxPts];    // points with a corner outside the window (index of the point in the region)
+    float stage[16][8 * kTD];               // step E: per wave, the 8 pixel rows it hands to the row atomics
+    int stage_row[16][8];                   //         and their element offsets in grad_value (-1 = not a map pixel)
     int wave_tot[16];
     int ngen;
     int pad[3];
 };
+static_assert(sizeof(TileHeader) + sizeof(SortLds) <= 160 * 1024, "sorted scatter: LDS budget");
+static_assert(kSortMaxPts <= 65536, "genlist holds 16-bit point indices");
 
 __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_sorted_kernel(
     const float *__restrict__ loc, const float *__restrict__ aw, const float *__restrict__ grad_out,
@@ -1259,14 +1263,14 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_sorted_kernel(
         if (tid == 0) S->ngen = 0;
         __syncthreads();
 
-        // ---- B: resolve; rank inside the bucket of the (h_low, w_low) pixel --------------------------------------------
-        int r_pix[2], r_rank[2];
-        SortRec r_rec[2];
+        // ---- B: resolve; every corner of an in-window point takes a rank in the list of its destination pixel ------------
+        int r_pix[2];
+        int r_rank[2][4];
+        float r_w[2][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int idx = tid + u * kTiledThreads;
             r_pix[u] = -1;
-            r_rank[u] = 0;
             if (idx < nq * g.P) {
                 const int qi = idx / g.P, pp = idx - qi * g.P;
                 const unsigned item = (unsigned)((b * g.Lq + hdr->qid[qi]) * g.M + m);
@@ -1280,14 +1284,19 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_sorted_kernel(
                     const int rr = (int)hf - wr0, cc = (int)wf - wc0;
                     if (rr >= 0 && rr + 1 < nwr && cc >= 0 && cc + 1 < nwc) {   // all four corners in the window (apron incl.)
                         r_pix[u] = rr * nwc + cc;
-                        r_rec[u].q = qi;
-                        r_rec[u].w[0] = hh * hw * a;
-                        r_rec[u].w[1] = hh * lw * a;
-                        r_rec[u].w[2] = lh * hw * a;
-                        r_rec[u].w[3] = lh * lw * a;
-                        r_rank[u] = atomicAdd(&S->offs[r_pix[u]], 1);
+                        r_w[u][0] = hh * hw * a;
+                        r_w[u][1] = hh * lw * a;
+                        r_w[u][2] = lh * hw * a;
+                        r_w[u][3] = lh * lw * a;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            // corners on the apron (outside the map) are dropped here: their pixels are never flushed
+                            const int row = (int)hf + (k >> 1), col = (int)wf + (k & 1);
+                            const bool in_map = row >= 0 && row < H && col >= 0 && col < W;
+                            r_rank[u][k] = in_map ? atomicAdd(&S->offs[r_pix[u] + (k >> 1) * nwc + (k & 1)], 1) : -1;
+                        }
                     } else {
-                        S->genlist[atomicAdd(&S->ngen, 1)] = idx;
+                        S->genlist[atomicAdd(&S->ngen, 1)] = (unsigned short)idx;
                     }
                 }
             }
@@ -1318,7 +1327,13 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_sorted_kernel(
         // ---- D: records to their sorted slots -----------------------------------------------------------------------------------
 #pragma unroll
         for (int u = 0; u < 2; ++u)
-            if (r_pix[u] >= 0) S->sorted[S->offs[r_pix[u]] + r_rank[u]] = r_rec[u];
+            if (r_pix[u] >= 0) {
+                const int qi = (tid + u * kTiledThreads) / g.P;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (r_rank[u][k] >= 0)
+                        S->sorted[S->offs[r_pix[u] + (k >> 1) * nwc + (k & 1)] + r_rank[u][k]] = SortRec{qi, r_w[u][k]};
+            }
         __syncthreads();
         stamp<1>(g, 3);
 
@@ -1332,53 +1347,45 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_sorted_kernel(
                 const bool valid = px < npx && row >= 0 && row < H && col >= 0 && col < W;
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (valid) {
+                    const int e1 = S->offs[px + 1];
+                    int e = S->offs[px];
+                    // several entries in flight: the entry -> gcache row dependency is the latency chain of this loop
+                    for (; e + 3 < e1; e += 4) {
+                        SortRec r[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int rk = rr - (k >> 1), ck = cc - (k & 1);   // (h_low, w_low) of points whose corner k is this pixel
-                        if (rk < 0 || ck < 0) continue;
-                        const int bin = rk * nwc + ck;
-                        const int e1 = S->offs[bin + 1];
-                        int e = S->offs[bin];
-                        // several records in flight: the record -> gcache row dependency is the latency chain of this loop
-                        for (; e + 3 < e1; e += 4) {
-                            float w[4];
-                            int q[4];
+                        for (int u = 0; u < 4; ++u) r[u] = S->sorted[e + u];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                w[u] = S->sorted[e + u].w[k];
-                                q[u] = S->sorted[e + u].q;
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const float4 gv = *reinterpret_cast<const float4 *>(S->gcache + q[u] * kTD + 4 * j8);
-                                acc.x += w[u] * gv.x;
-                                acc.y += w[u] * gv.y;
-                                acc.z += w[u] * gv.z;
-                                acc.w += w[u] * gv.w;
-                            }
-                        }
-                        for (; e < e1; ++e) {
-                            const float w = S->sorted[e].w[k];
-                            const float4 gv = *reinterpret_cast<const float4 *>(S->gcache + S->sorted[e].q * kTD + 4 * j8);
-                            acc.x += w * gv.x;
-                            acc.y += w * gv.y;
-                            acc.z += w * gv.z;
-                            acc.w += w * gv.w;
+                        for (int u = 0; u < 4; ++u) {
+                            const float4 gv = *reinterpret_cast<const float4 *>(S->gcache + r[u].q * kTD + 4 * j8);
+                            acc.x += r[u].w * gv.x;
+                            acc.y += r[u].w * gv.y;
+                            acc.z += r[u].w * gv.z;
+                            acc.w += r[u].w * gv.w;
                         }
                     }
+                    for (; e < e1; ++e) {
+                        const SortRec r = S->sorted[e];
+                        const float4 gv = *reinterpret_cast<const float4 *>(S->gcache + r.q * kTD + 4 * j8);
+                        acc.x += r.w * gv.x;
+                        acc.y += r.w * gv.y;
+                        acc.z += r.w * gv.z;
+                        acc.w += r.w * gv.w;
+                    }
                 }
-                const int rowoff = valid ? base_row + (row * W + col) * row_elems : -1;
-                // transpose: in round r the lower / upper half-wave adds the row of pixel slot 2r / 2r+1, one channel per lane
+                // hand-over through LDS: the lane group writes its pixel's 32 channels, then the wave re-reads one channel per
+                // lane so that each global atomic instruction adds two whole 128-B rows (same-wave LDS traffic is in order;
+                // the barriers only stop compiler motion)
+                *reinterpret_cast<float4 *>(S->stage[wave] + (lane >> 3) * kTD + 4 * j8) = acc;
+                if (j8 == 0) S->stage_row[wave][lane >> 3] = valid ? base_row + (row * W + col) * row_elems : -1;
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int src = ((2 * r + (lane >> 5)) << 3) + ((lane & 31) >> 2);
-                    const float vx = __shfl(acc.x, src, kWave), vy = __shfl(acc.y, src, kWave);
-                    const float vz = __shfl(acc.z, src, kWave), vw = __shfl(acc.w, src, kWave);
-                    const int ro = __shfl(rowoff, src, kWave);
-                    const int comp = lane & 3;
-                    const float v = comp == 0 ? vx : (comp == 1 ? vy : (comp == 2 ? vz : vw));
+                for (int r = 0; r < 4; ++r) {   // lower / upper half-wave: pixel slot 2r / 2r + 1
+                    const int slot = 2 * r + (lane >> 5);
+                    const float v = S->stage[wave][slot * kTD + (lane & 31)];
+                    const int ro = S->stage_row[wave][slot];
                     if (ro >= 0 && v != 0.f) atomicAdd(grad_value + ro + (lane & 31), v);
                 }
+                __builtin_amdgcn_wave_barrier();
             }
         }
         stamp<1>(g, 4);
