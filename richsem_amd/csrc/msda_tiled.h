@@ -1191,19 +1191,23 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_bfp_kernel(
 }
 
 // ---- backward: grad_value by sorted (segmented) reduction -- no floating-point LDS atomics ---------------------------------------
-// Work item = (image, head, region, LEVEL), all 32 channels.  Instead of adding every corner of every sampling point into an
-// LDS window with a float atomic (the f64 kernel above is bound by the ds_add_f64 issue rate), the points are BUCKETED by the
-// window pixel of their (h_low, w_low) corner with integer LDS atomics -- one lane per point, not per channel -- and every
-// output pixel then sums, in registers, the records of the (up to) four buckets whose points touch it:
-//   A  grad_out rows of the region's queries -> LDS (gcache); histogram cleared
-//   B  one thread per (query, point): resolve; in-window points take a rank in their bucket (ds_add_rtn_u32);
-//      points with a corner outside the window go to a side list
-//   C  exclusive scan of the histogram -> bucket offsets;  D  records written to their sorted slots
-//   E  8 lanes x 4 channels per output pixel: acc += w_k * gcache[q] over the records of buckets p, p-1, p-nwc, p-nwc-1
-//      (corner k = 0..3), then the wave transposes to one channel per lane and adds whole 128-B rows to grad_value
+// Work item = (image, head, region), all 32 channels, its levels one after the other.  Instead of adding every corner of every
+// sampling point into an LDS window with a float atomic (the f64 kernel above is bound by the ds_add_f64 issue rate), every
+// (point, corner) pair becomes an 8-byte ENTRY {query, weight} that is sorted -- with integer LDS atomics, one lane per point,
+// not per channel -- into the list of its destination pixel, and every output pixel then sums its list in registers:
+//   header + A  once per region: geometry, query list, grad_out rows of the region's queries -> LDS (gcache)
+//   per level (the next level's sampling locations / attention weights are fetched during the current level's E):
+//   B  one thread per (query, point): resolve; each in-map corner of an in-window point takes a rank in its pixel's list
+//      (ds_add_rtn_u32); points with a corner outside the window go to a side list
+//   C  exclusive scan of the per-pixel counts -> list offsets;  D  entries written to their sorted slots
+//   E  8 lanes x 4 channels per output pixel: acc += w * gcache[q] over the pixel's list, four entries in flight; the wave
+//      then hands its 8 pixel rows over through LDS, re-reads them one channel per lane and adds whole 128-B rows to
+//      grad_value (two rows per global atomic instruction)
 //   F  side list: 32 lanes per point, row atomics straight to global memory (as the direct kernel)
-// Sums are fp32 like the reference's; their order inside a bucket follows the atomic ranks (run-to-run variation at the
+// Sums are fp32 like the reference's; their order inside a list follows the atomic ranks (run-to-run variation at the
 // rounding level, as with the reference's float atomics).
+// What the step costs was measured per stage and per level (tools/stage_stamps.py): E is bound by instruction issue and LDS
+// traffic per list entry, which is why the entries are per pixel (one 8-B read, no corner / bucket arithmetic in the loop).
 constexpr int kSortMaxPx = 1280;            // largest single-level window (pixels) the kernel takes
 constexpr int kSortMaxPts = kMaxRegionQueries * 4;
 
@@ -1237,30 +1241,58 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_sorted_kernel(
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int row_elems = g.M * kTD;
     const int LP = g.L * g.P;
-    const int nsub = g.L;   // one level per work item
-    const int n_items = kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.GY * g.GX * nsub;
+    // work item = (image, head, region); its levels go through the tables one after the other, so the header and the
+    // grad_out rows are set up once per region and the next level's operands are fetched while the current level is reduced
+    const int n_items = kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.GY * g.GX;
     for (int vb = blockIdx.x; vb < n_items; vb += gridDim.x) {   // persistent form, see tiled_gather_kernel
-        int pair, rs;
-        if (!decode_block(vb, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) continue;
-        const int region = rs / nsub, lv = rs - region * nsub;
+        int pair, region;
+        if (!decode_block(vb, g.N * g.M, g.GY * g.GX, pair, region)) continue;
         const int b = pair / g.M, m = pair - b * g.M;
         const int gy = region / g.GX, gx = region - gy * g.GX;
         stamp<1>(g, 0);
         const int nq = build_header(hdr, g, gy, gx);
         stamp<1>(g, 1);
-        const int H = uni(hdr->H[lv]), W = uni(hdr->W[lv]), nwc = uni(hdr->r[lv].nwc), nwr = uni(hdr->r[lv].nwr);
-        const int wr0 = uni(hdr->r[lv].wr0), wc0 = uni(hdr->r[lv].wc0);
-        const int npx = nwr * nwc;
-        const int base_row = (b * g.S + uni(hdr->start[lv])) * row_elems + m * kTD;
-
-        // ---- A: grad_out rows -> LDS; clear the histogram -------------------------------------------------------------
+        // this thread's (up to) two sampling points per level: (query, point) = idx / P, idx % P
+        unsigned pt_base[2];
+        bool pt_live[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * kTiledThreads;
+            pt_live[u] = idx < nq * g.P;
+            const int qi = pt_live[u] ? idx / g.P : 0, pp = pt_live[u] ? idx - qi * g.P : 0;
+            pt_base[u] = (unsigned)((b * g.Lq + hdr->qid[qi]) * g.M + m) * (unsigned)LP + (unsigned)pp;
+        }
+        float2 nxt_xy[2];
+        float nxt_a[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {   // level 0
+            nxt_xy[u] = *reinterpret_cast<const float2 *>(loc + 2u * pt_base[u]);
+            nxt_a[u] = aw[pt_base[u]];
+        }
+        // ---- A: grad_out rows -> LDS ------------------------------------------------------------------------------
         for (int i = tid >> 3; i < nq; i += kTiledThreads / 8) {
             const unsigned item = (unsigned)((b * g.Lq + hdr->qid[i]) * g.M + m);
             *reinterpret_cast<float4 *>(S->gcache + i * kTD + 4 * (tid & 7)) =
                 *reinterpret_cast<const float4 *>(grad_out + item * (unsigned)kTD + 4u * (tid & 7));
         }
-        for (int i = tid; i <= npx; i += kTiledThreads) S->offs[i] = 0;
+        for (int lv = 0; lv < g.L; ++lv) {
+        const int H = uni(hdr->H[lv]), W = uni(hdr->W[lv]), nwc = uni(hdr->r[lv].nwc), nwr = uni(hdr->r[lv].nwr);
+        const int wr0 = uni(hdr->r[lv].wr0), wc0 = uni(hdr->r[lv].wc0);
+        const int npx = nwr * nwc;
+        const int base_row = (b * g.S + uni(hdr->start[lv])) * row_elems + m * kTD;
+        for (int i = tid; i <= npx; i += kTiledThreads) S->offs[i] = 0;   // clear the histogram
         if (tid == 0) S->ngen = 0;
+        float2 cur_xy[2];
+        float cur_a[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            cur_xy[u] = nxt_xy[u];
+            cur_a[u] = nxt_a[u];
+            if (lv + 1 < g.L) {   // in flight until the next level's step B
+                nxt_xy[u] = *reinterpret_cast<const float2 *>(loc + 2u * (pt_base[u] + (unsigned)((lv + 1) * g.P)));
+                nxt_a[u] = aw[pt_base[u] + (unsigned)((lv + 1) * g.P)];
+            }
+        }
         __syncthreads();
 
         // ---- B: resolve; every corner of an in-window point takes a rank in the list of its destination pixel ------------
@@ -1271,12 +1303,9 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_sorted_kernel(
         for (int u = 0; u < 2; ++u) {
             const int idx = tid + u * kTiledThreads;
             r_pix[u] = -1;
-            if (idx < nq * g.P) {
-                const int qi = idx / g.P, pp = idx - qi * g.P;
-                const unsigned item = (unsigned)((b * g.Lq + hdr->qid[qi]) * g.M + m);
-                const unsigned pt = item * (unsigned)LP + (unsigned)(lv * g.P + pp);
-                const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
-                const float a = aw[pt];
+            if (pt_live[u]) {
+                const float2 xy = cur_xy[u];
+                const float a = cur_a[u];
                 const float h_im = xy.y * (float)H - 0.5f, w_im = xy.x * (float)W - 0.5f;
                 if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
                     const float hf = floorf(h_im), wf = floorf(w_im);
@@ -1413,7 +1442,8 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_sorted_kernel(
             }
         }
         stamp<1>(g, 5);
-        __syncthreads();   // the next item rebuilds the header and the LDS tables
+        __syncthreads();   // the next level clears the tables; the next item rebuilds the header
+        }
     }
 }
 
@@ -1532,6 +1562,11 @@ inline bool tiled_bwd_applicable<float>(int N, int S, int M, int D, int L, int L
 inline int persistent_grid(int total, int cap, int nsub)
 {
     if (cap <= 0 || total <= cap) return total;
+    if (nsub == 1) {   // equal items: the smallest grid that needs no more rounds than `cap` workgroups would
+        const int rounds = (total + cap - 1) / cap;
+        const int need = (total + rounds - 1) / rounds;
+        return (need + kXcds - 1) / kXcds * kXcds;
+    }
     auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
     int g8 = cap / kXcds;
     while (g8 > 1 && gcd(g8, nsub) != 1) --g8;
@@ -1595,7 +1630,7 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
     if (tiled_options().accum == 2 && pso.ok) {
         e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_sorted_kernel), pso.lds_bytes);
         if (e != hipSuccess) return e;
-        const int sgrid = persistent_grid(pso.grid * pso.g.nphases, tiled_options().persist / 2, pso.g.nphases);
+        const int sgrid = persistent_grid(pso.grid, tiled_options().persist / 2, 1);
         hipLaunchKernelGGL(tiled_scatter_sorted_kernel, dim3(sgrid), dim3(kTiledThreads), pso.lds_bytes, stream, loc, aw,
                            grad_out, grad_value, pso.g);
     } else if (tiled_options().accum == 1 && pb.ok) {
