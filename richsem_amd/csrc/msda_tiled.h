@@ -669,6 +669,9 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
     constexpr int kGroups = Cfg::kGroups;                    // queries in flight per pass over k
     constexpr int kGatherQPG = Cfg::QPG;
     constexpr int FL = GC / 4, kFillGroups = kThreads / FL;  // window fill: 16 B per lane, FL lanes per pixel
+    // loads in flight per lane and batch.  A/B-timed on MI355X (tools/ab_probe.sh): 3..5 are equal, 8 costs ~4 us per
+    // call and 10 (the whole finest-level window in one batch) ~8 us -- deeper batches only queue up behind the L2
+    constexpr int kFillBatch = 4;
     constexpr int kHalves = kTD / GC;                        // channel passes per region
     const int nsub = BWD ? g.nphases : kHalves;
     // Persistent form: the grid may be smaller than the number of work items; a workgroup then walks the items
@@ -732,11 +735,11 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                 const int npx = uni(hdr->r[l].nwr) * nwc, Wl = uni(hdr->W[l]), Hl = uni(hdr->H[l]);
                 const float *src = value + ((int64_t)(b * g.S + uni(hdr->start[l])) * g.M + m) * kTD + half * GC + 4 * fj;
                 float *dst = win + (int64_t)uni(hdr->lds_px[l]) * GC + 4 * fj;
-                // eight independent loads in flight per lane before the first LDS store
-                for (int px0 = fgrp; px0 < npx; px0 += 8 * kFillGroups) {
-                    float4 v[8];
+                // kFillBatch independent loads in flight per lane before the first LDS store
+                for (int px0 = fgrp; px0 < npx; px0 += kFillBatch * kFillGroups) {
+                    float4 v[kFillBatch];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < kFillBatch; ++u) {
                         const int px = min(px0 + u * kFillGroups, npx - 1);   // clamped; stored only if in range
                         const int rr = px / nwc, cc = px - rr * nwc;
                         const int row = wr0 + rr, col = wc0 + cc;
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                         v[u] = in_map ? t : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < kFillBatch; ++u) {
                         const int px = px0 + u * kFillGroups;
                         if (px < npx) *reinterpret_cast<float4 *>(dst + px * GC) = v[u];
                     }
