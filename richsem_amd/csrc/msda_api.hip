@@ -307,6 +307,20 @@ hipError_t launch_levelsum<float>(const Problem &pb, const float *loc, const flo
     return hipGetLastError();
 }
 
+// the levels launch_levelsum would take for this problem (host-only)
+template <typename T>
+unsigned levelsum_levels(const Problem &)
+{
+    return 0;
+}
+template <>
+unsigned levelsum_levels<float>(const Problem &pb)
+{
+    msda::LevelSumGeom lg;
+    size_t lds = 0;
+    return msda::plan_levelsum(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(), pb.lsi.data(), lg, lds);
+}
+
 int direct_grid(const msda::DirectGeom &g)
 {
     const int pairs = g.N * g.M;
@@ -382,8 +396,8 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         return fail(MSDA_ERR_MISALIGNED, "misaligned pointer (sampling_loc / grad_sampling_loc need 2*sizeof(T))");
 
     // grad_value is accumulated into (the reference gets it from at::zeros_like, ms_deform_attn_cuda.cu:121)
-    hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(T) * (size_t)N * S * M * D, stream);
-    if (e != hipSuccess) return hip_fail(e, "zero-fill of grad_value");
+    hipError_t e = hipSuccess;
+    auto zero_grad_value = [&]() { return hipMemsetAsync(grad_value, 0, sizeof(T) * (size_t)N * S * M * D, stream); };
 
     int variant = g_bwd_variant.load();
     if (variant != 1 && msda::tiled_bwd_applicable<T>(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(),
@@ -391,6 +405,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         if (variant == 0)   // automatic: the forward calls of this problem measured how local its sampling points are
             variant = monitor_choose_bwd(monitor_for_current_device(), problem_key(N, S, M, L, P, pb.shapes.data()));
         if (variant == 2) {
+            if ((e = zero_grad_value()) != hipSuccess) return hip_fail(e, "zero-fill of grad_value");
             {
                 ProfileScope prof(1, 2, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
                 e = msda::launch_bwd_tiled<T>(value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw, pb.N,
@@ -402,18 +417,25 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         }
     }
 
+    // Levels summed in LDS by their own kernel (msda_levelsum.h) are taken away from the atomics below; when that is ALL
+    // levels (decoder-shaped calls) grad_value is written, not accumulated: no zero-fill, no atomics.
+    unsigned ls_levels = 0;
+    const unsigned all_levels = L >= 32 ? ~0u : (1u << L) - 1;
+    if (g_levelsum.load()) ls_levels = levelsum_levels<T>(pb);
+    if (ls_levels != all_levels && (e = zero_grad_value()) != hipSuccess) return hip_fail(e, "zero-fill of grad_value");
     // Float atomics run at full rate only as >= 128-B row segments (one dword per lane): with 32 or more
     // channels put ONE channel on a lane, so that a wave-instruction adds two whole 128-B rows.
     int C = pick_channels_per_lane<T>(D, {value, grad_out});
     if (g_bwd_cpl.load() > 0) C = g_bwd_cpl.load() <= C ? g_bwd_cpl.load() : C;
-    else if (D * (int)sizeof(T) >= 128) C = 1;
+    else if (D * (int)sizeof(T) >= 128 && ls_levels != all_levels) C = 1;
     msda::DirectGeom g = direct_geom(pb, C);
     const size_t lds = msda::direct_lds_bytes<T>(g);
     if (lds > 64 * 1024) return fail(MSDA_ERR_BAD_DIMS, "too many levels (L=%d) for the level table in LDS", L);
     const dim3 grid(direct_grid(g)), block(msda::kDirectThreads);
     ProfileScope prof(1, 1, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
-    // small levels that receive many points per pixel: summed whole in LDS, taken away from the atomics below
-    if (g_levelsum.load()) {
+    if (ls_levels) {
+        // (forking this kernel onto a second stream beside the direct kernel was tried: the cross-stream fork / join costs
+        // more than the overlap gains on a 90 us call -- 113 vs 96 us)
         e = launch_levelsum<T>(pb, loc, aw, grad_out, grad_value, stream, g.gv_skip);
         if (e != hipSuccess) return hip_fail(e, "launch of the level-sum backward kernel");
     }

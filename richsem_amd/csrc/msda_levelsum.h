@@ -16,41 +16,61 @@ namespace msda {
 
 constexpr int kLsChan = 4;          // channels per slice = lanes per sampling point
 constexpr int kLsThreads = 1024;
-constexpr int kLsMaxLevels = 8;     // levels one launch can take
+constexpr int kLsMaxLevels = 16;    // (level, row band) entries one launch can take
 constexpr int kLsUnroll = 4;        // points in flight per lane group
 constexpr int kLsLdsBudget = 150 * 1024;
 
 struct LevelSumGeom {
     int N, S, M, D, L, Lq, P;
-    int nlev, nslices;
-    int lev[kLsMaxLevels], H[kLsMaxLevels], W[kLsMaxLevels], start[kLsMaxLevels];
+    int nlev, nslices;   // entries, channel slices
+    // entry = a band of rows [r0, r0 + nr) of level lev (the whole level when it fits LDS)
+    int lev[kLsMaxLevels], H[kLsMaxLevels], W[kLsMaxLevels], start[kLsMaxLevels], r0[kLsMaxLevels], nr[kLsMaxLevels];
 };
 
 // Which levels of a call this kernel should take (bit l of the result), and the launch geometry for them.
-// A level qualifies when its slice window fits LDS and it receives at least two sampling points per pixel (otherwise
-// there is nothing to merge); the per-workgroup walk over Lq*P points is bounded so that one launch stays short.
+// First choice: ALL levels -- a level too large for LDS is cut into row bands, each band one window -- because the direct
+// backward kernel then issues no global atomic at all, needs no zero-fill and can keep 4 channels per lane.  That is
+// taken when the call is small enough for every workgroup to walk all Lq*P points of its level (decoder-shaped calls).
+// Otherwise: only the levels that fit LDS whole and receive at least two sampling points per pixel (there is something
+// to merge); the rest stays with the direct kernel's row atomics.
 inline unsigned plan_levelsum(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes,
                               const int64_t *lsi, LevelSumGeom &g, size_t &lds_bytes)
 {
-    g = LevelSumGeom{};
     lds_bytes = 0;
-    if (L > 32 || D > 128 || (int64_t)Lq * P > 65536) return 0;
-    g.N = N; g.S = S; g.M = M; g.D = D; g.L = L; g.Lq = Lq; g.P = P;
-    g.nslices = (D + kLsChan - 1) / kLsChan;
-    unsigned mask = 0;
-    for (int l = 0; l < L && g.nlev < kLsMaxLevels; ++l) {
-        const int64_t px = shapes[2 * l] * shapes[2 * l + 1];
-        const size_t bytes = (size_t)px * kLsChan * sizeof(double);
-        if (bytes > (size_t)kLsLdsBudget || (int64_t)Lq * P < 2 * px) continue;
-        g.lev[g.nlev] = l;
-        g.H[g.nlev] = (int)shapes[2 * l];
-        g.W[g.nlev] = (int)shapes[2 * l + 1];
-        g.start[g.nlev] = (int)lsi[l];
-        ++g.nlev;
-        mask |= 1u << l;
-        lds_bytes = bytes > lds_bytes ? bytes : lds_bytes;
+    if (L > 32 || D > 128 || (int64_t)Lq * P > 65536) { g = LevelSumGeom{}; return 0; }
+    const size_t px_bytes = (size_t)kLsChan * sizeof(double);
+    for (int all = 1; all >= 0; --all) {
+        g = LevelSumGeom{};
+        g.N = N; g.S = S; g.M = M; g.D = D; g.L = L; g.Lq = Lq; g.P = P;
+        g.nslices = (D + kLsChan - 1) / kLsChan;
+        lds_bytes = 0;
+        unsigned mask = 0;
+        bool ok = true;
+        for (int l = 0; l < L && ok; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+            const int64_t px = (int64_t)H * W;
+            const bool whole = px * px_bytes <= (size_t)kLsLdsBudget;
+            if (!all && (!whole || (int64_t)Lq * P < 2 * px)) continue;
+            const int rows_max = (int)(kLsLdsBudget / (px_bytes * W));   // rows of this level one window holds
+            if (rows_max < 1) { ok = false; break; }
+            const int bands = whole ? 1 : (H + rows_max - 1) / rows_max;
+            const int rows = (H + bands - 1) / bands;
+            if (bands > 8 || g.nlev + bands > kLsMaxLevels) { ok = false; break; }
+            for (int r0 = 0; r0 < H; r0 += rows) {
+                const int e = g.nlev++;
+                g.lev[e] = l; g.H[e] = H; g.W[e] = W; g.start[e] = (int)lsi[l];
+                g.r0[e] = r0;
+                g.nr[e] = H - r0 < rows ? H - r0 : rows;
+                const size_t bytes = (size_t)g.nr[e] * W * px_bytes;
+                lds_bytes = bytes > lds_bytes ? bytes : lds_bytes;
+            }
+            mask |= 1u << l;
+        }
+        if (all && (!ok || mask != (L >= 32 ? ~0u : (1u << L) - 1))) continue;   // fall back to the dense-levels rule
+        return mask;
     }
-    return mask;
+    g = LevelSumGeom{};
+    return 0;
 }
 
 inline int levelsum_grid(const LevelSumGeom &g)
@@ -71,8 +91,8 @@ __global__ __launch_bounds__(kLsThreads) void bwd_levelsum_kernel(const float *_
     // the slices of one level are neighbours in the XCD-local order: they read the same loc / attn lines
     const int li = t / g.nslices, slice = t - li * g.nslices;
     const int b = pair / g.M, m = pair - b * g.M;
-    const int l = g.lev[li], H = g.H[li], W = g.W[li];
-    const int npx = H * W;
+    const int l = g.lev[li], H = g.H[li], W = g.W[li], r0 = g.r0[li], nr = g.nr[li];
+    const int npx = nr * W;   // the window: rows [r0, r0 + nr) of the level
     const int tid = threadIdx.x;
     const int j = tid & (kLsChan - 1), grp = tid / kLsChan;
     constexpr int kGroups = kLsThreads / kLsChan;
@@ -108,8 +128,10 @@ __global__ __launch_bounds__(kLsThreads) void bwd_levelsum_kernel(const float *_
             const float hf = floorf(h_im), wf = floorf(w_im);
             const int h_low = (int)hf, w_low = (int)wf;
             const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-            const bool top = h_low >= 0, bot = h_low + 1 <= H - 1, lef = w_low >= 0, rig = w_low + 1 <= W - 1;
-            double *p00 = win + (h_low * W + w_low) * kLsChan + j;
+            // a corner counts if it is inside the map AND inside this workgroup's row band
+            const bool top = h_low >= r0 && h_low < r0 + nr, bot = h_low + 1 >= r0 && h_low + 1 < r0 + nr;
+            const bool lef = w_low >= 0, rig = w_low + 1 <= W - 1;
+            double *p00 = win + ((h_low - r0) * W + w_low) * kLsChan + j;
             if (top && lef) atomicAdd(p00, (double)(hh * hw * ga[u]));
             if (top && rig) atomicAdd(p00 + kLsChan, (double)(hh * lw * ga[u]));
             if (bot && lef) atomicAdd(p00 + W * kLsChan, (double)(lh * hw * ga[u]));
@@ -119,7 +141,7 @@ __global__ __launch_bounds__(kLsThreads) void bwd_levelsum_kernel(const float *_
     __syncthreads();
 
     // every pixel of the slice, once: 16 B per lane group
-    float *dst = grad_value + ((int64_t)(b * g.S + g.start[li]) * g.M + m) * g.D + ch;
+    float *dst = grad_value + ((int64_t)(b * g.S + g.start[li] + r0 * W) * g.M + m) * g.D + ch;
     if (has_ch)
         for (int px = grp; px < npx; px += kGroups) dst[(int64_t)px * g.M * g.D] = (float)win[px * kLsChan + j];
 }
