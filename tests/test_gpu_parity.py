@@ -368,7 +368,10 @@ def test_locality_monitor_picks_kernels_by_data(loc_mode, expect):
 @pytest.mark.parametrize("dims", [
     dict(call="Dd"),                                                              # BASELINE decoder call, full size
     dict(N=1, M=3, D=30, P=3, shapes=[(40, 50), (7, 9), (1, 1), (20, 20)], Lq=700),   # D not a multiple of the slice
-    dict(N=2, M=2, D=64, P=4, shapes=[(3, 2), (64, 64)], Lq=300),                 # only the first level qualifies
+    dict(N=2, M=2, D=64, P=4, shapes=[(3, 2), (64, 64)], Lq=300),                 # 16 channel slices
+    dict(N=1, M=2, D=30, P=2, shapes=[(91, 70), (5, 5)], Lq=500),                 # level 0 in two uneven row bands
+    dict(N=1, M=1, D=32, P=4, shapes=[(300, 300), (9, 9)], Lq=64),                # level 0 too large even in 8 bands:
+                                                                                  # only level 1 handed over, rest atomics
 ])
 def test_levelsum_backward_matches_oracle_and_atomics(dims, loc_mode):
     """Direct backward with whole small levels summed in LDS (msda_levelsum.h, default) against the oracle and against
