@@ -137,13 +137,14 @@ int monitor_choose_fwd(Monitor *mo, uint64_t key, hipStream_t stream, unsigned *
 {
     *probe = nullptr;
     if (!mo || !g_monitor_on.load()) return 2;
-    mo->mu.lock();
-    monitor_poll(*mo);
-    MonitorEntry &en = mo->table[key];
-    const unsigned call = en.calls++;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cap);
-    bool want = !mo->pending && cap == hipStreamCaptureStatusNone && call >= en.next_probe;
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    mo->mu.lock();
+    if (!capturing) monitor_poll(*mo);   // (querying an event is not allowed while a capture is under way)
+    MonitorEntry &en = mo->table[key];
+    const unsigned call = en.calls++;
+    bool want = !mo->pending && !capturing && call >= en.next_probe;
     if (want && !mo->dev) {   // first probe on this device
         if (hipMalloc(reinterpret_cast<void **>(&mo->dev), sizeof(unsigned)) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void **>(&mo->host), sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
@@ -176,11 +177,13 @@ void monitor_finish_probe(Monitor *mo, double points, hipStream_t stream, bool l
     mo->mu.unlock();
 }
 
-int monitor_choose_bwd(Monitor *mo, uint64_t key)
+int monitor_choose_bwd(Monitor *mo, uint64_t key, hipStream_t stream)
 {
     if (!mo || !g_monitor_on.load()) return 2;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
     std::lock_guard<std::mutex> lock(mo->mu);
-    monitor_poll(*mo);
+    if (cap == hipStreamCaptureStatusNone) monitor_poll(*mo);
     const auto it = mo->table.find(key);
     return it != mo->table.end() && it->second.known && it->second.share > kBwdShareMax ? 1 : 2;
 }
@@ -299,8 +302,7 @@ hipError_t launch_levelsum<float>(const Problem &pb, const float *loc, const flo
     size_t lds = 0;
     taken = msda::plan_levelsum(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(), pb.lsi.data(), lg, lds);
     if (!taken) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda::bwd_levelsum_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = msda::set_lds_limit(reinterpret_cast<const void *>(&msda::bwd_levelsum_kernel), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(msda::bwd_levelsum_kernel, dim3(msda::levelsum_grid(lg)), dim3(msda::kLsThreads), lds, stream, loc,
                        aw, grad_out, grad_value, lg);
@@ -403,7 +405,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
     if (variant != 1 && msda::tiled_bwd_applicable<T>(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(),
                                                      pb.lsi.data(), value, grad_out, grad_value)) {
         if (variant == 0)   // automatic: the forward calls of this problem measured how local its sampling points are
-            variant = monitor_choose_bwd(monitor_for_current_device(), problem_key(N, S, M, L, P, pb.shapes.data()));
+            variant = monitor_choose_bwd(monitor_for_current_device(), problem_key(N, S, M, L, P, pb.shapes.data()), stream);
         if (variant == 2) {
             if ((e = zero_grad_value()) != hipSuccess) return hip_fail(e, "zero-fill of grad_value");
             {

@@ -22,6 +22,10 @@
 // Semantics: identical to msda_direct.h (spec: reference ms_deform_im2col_cuda.cuh:33-159, 237-403).
 #pragma once
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "msda_common.h"
 
 namespace msda {
@@ -1576,9 +1580,20 @@ inline int persistent_grid(int total, int cap, int nsub)
     return g8 * kXcds;
 }
 
+// Raise a kernel's dynamic-LDS limit.  Done once per (device, kernel, size class): repeating the runtime call on every
+// launch costs time and is not something to issue while the caller captures its stream into a graph.
 inline hipError_t set_lds_limit(const void *fn, size_t bytes)
 {
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> granted;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = granted[std::make_pair(dev, fn)];
+    if (have >= bytes) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
 }
 
 template <typename T>

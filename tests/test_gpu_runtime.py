@@ -1,0 +1,76 @@
+"""GPU (-m gpu): runtime behaviour of the library around the kernels -- stream capture into a graph, concurrent callers on
+their own streams.  (The reference op launches on the current stream without synchronising and keeps no state,
+SURVEY.md section 8b; this library keeps a little -- the locality monitor, LDS-limit bookkeeping -- and must stay usable
+the same way.)"""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from richsem_amd import _lib, workload as W
+from richsem_amd import MultiScaleDeformableAttention as MSDA
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(t):
+    out = MSDA.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], 64)
+    grads = MSDA.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64)
+    return out, grads
+
+
+def _close(a, b, tol):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30)) < tol
+
+
+@pytest.mark.parametrize("which", ["E", "Dd"])   # window kernels + locality monitor / level-sum kernel + direct kernels
+def test_calls_can_be_captured_into_a_graph(which):
+    call = W.shrunk({"E": W.call_E, "Dd": W.call_Dd}[which](2), 2)
+    t = W.make_inputs(call, "init", seed=3, device="cuda")
+    ref_out, ref_g = _run(t)            # also warms up: host mirrors cached, LDS limits granted, first monitor probes
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            _run(t)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out, grads = _run(t)
+    out.zero_()
+    for x in grads:
+        x.fill_(float("nan"))
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_out)
+    assert _close(grads[0], ref_g[0], 2e-4)
+    assert _close(grads[1], ref_g[1], 2e-4) and _close(grads[2], ref_g[2], 2e-4)
+
+
+def test_concurrent_callers_on_their_own_streams():
+    call = W.shrunk(W.call_E(2), 2)
+    t = W.make_inputs(call, "init", seed=4, device="cuda")
+    ref_out, ref_g = _run(t)
+    torch.cuda.synchronize()
+    results, errors = [], []
+
+    def worker():
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(40):
+                    out, grads = _run(t)
+                st.synchronize()
+            results.append((torch.equal(out, ref_out), _close(grads[0], ref_g[0], 2e-4), _close(grads[1], ref_g[1], 2e-4)))
+        except Exception as e:   # noqa: BLE001 -- reported below, a thread must not swallow it
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker) for _ in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert results == [(True, True, True)] * 3
