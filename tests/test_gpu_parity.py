@@ -396,3 +396,47 @@ def test_levelsum_backward_matches_oracle_and_atomics(dims, loc_mode):
     finally:
         _lib.set_option("bwd_levelsum", 1)
     assert torch.allclose(res[0], res[1], rtol=1e-3, atol=1e-3 * float(np.abs(ogv).max()))
+
+
+def _random_problem(rng):
+    """A random small problem: any L / P / D / M, maps down to 1 x 1, encoder-shaped (Lq == S) half of the time, sampling
+    locations partly outside [0, 1] (dropped points, border corners)."""
+    L = int(rng.integers(1, 6))
+    P = int(rng.integers(1, 9)) if L * 8 <= 32 else int(rng.integers(1, 5))
+    shapes = [(int(rng.integers(1, 41)), int(rng.integers(1, 41))) for _ in range(L)]
+    S = sum(h * w for h, w in shapes)
+    N, M = int(rng.integers(1, 4)), int(rng.choice([1, 2, 3, 8]))
+    D = int(rng.choice([8, 16, 32, 32, 32, 48, 64]))
+    enc = bool(rng.integers(0, 2))
+    Lq = S if enc else int(rng.integers(1, 400))
+    g = torch.Generator().manual_seed(int(rng.integers(0, 2**31)))
+    value = torch.randn(N, S, M, D, generator=g)
+    aw = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P).contiguous()
+    grad_out = torch.randn(N, Lq, M * D, generator=g)
+    mode = int(rng.integers(0, 3))
+    if mode == 0:
+        loc = torch.rand(N, Lq, M, L, P, 2, generator=g)
+    elif mode == 1:
+        loc = torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.4 - 0.2
+    else:   # clustered around per-query centres, a few pixels wide: the pattern the window kernels are built for
+        ctr = torch.rand(N, Lq, 1, 1, 1, 2, generator=g)
+        loc = ctr + 0.08 * torch.randn(N, Lq, M, L, P, 2, generator=g)
+    call = W.Call("rnd", N, M, D, P, shapes, Lq, enc)
+    sh, lsi = W.level_tensors(call)
+    return dict(value=value, shapes=sh, lsi=lsi, loc=loc.contiguous(), aw=aw, grad_out=grad_out)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_problems_against_oracle(seed):
+    """Seeded random shapes through the automatic kernel choice (window, direct, level-sum, locality monitor in whatever
+    state earlier tests left it) against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    t = _random_problem(rng)
+    z = {k: v.numpy() for k, v in t.items()}
+    oo = O.forward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"])
+    ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
+    tf, tg = tols(np.float32)
+    for variant in (0, 2):
+        out, gv, gl, ga = run_gpu(z, variant)
+        assert rel_err(out, oo) < tf, (variant, z["value"].shape, z["loc"].shape)
+        assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg, (variant, z["value"].shape)
