@@ -202,7 +202,7 @@ def main():
             avg = sum(ms) / len(ms)
             scatter = {0: "tiled_scatter_kernel", 1: "tiled_scatter_bfp_kernel", 2: "tiled_scatter_sorted_kernel"}[
                 _lib.get_option("tile_accum")]
-            hip = {("fwd", 1): "fwd_direct_kernel", ("bwd", 1): "bwd_direct_kernel", ("fwd", 2): "tiled_gather_kernel<false>",
+            hip = {("fwd", 1): "fwd_direct_kernel", ("bwd", 1): "bwd_levelsum_kernel + bwd_direct_kernel", ("fwd", 2): "tiled_gather_kernel<false>",
                    ("bwd", 2): scatter + " + tiled_gather_kernel<true>"}[(kind, variant)]
             kernels.append({"kernel": f"msda_{kind}_{'direct' if variant == 1 else 'tiled'}[{call.name}]", "hip_kernels": hip,
                             "launches": len(ms), "avg_us": round(avg * 1e3, 2), "total_ms": round(sum(ms), 3),
