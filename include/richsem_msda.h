@@ -113,6 +113,13 @@ int msda_get_option(const char *key, int *value);
 int msda_tiled_plan(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
                     const int64_t *level_start_host, int info[8]);
 
+/* Host-only: what the level-sum backward kernel (fp32 direct backward, option "bwd_levelsum") would take for a problem.
+ * info[0] = bit mask of the levels handed over (0 = none; all L bits = no global atomics and no zero-fill at all);
+ * info[1] = (level, row band) windows; info[2] = 4-channel slices; info[3] = LDS bytes per workgroup;
+ * info[4] = workgroups; info[5] = most rows in one window; info[6..7] = 0. */
+int msda_levelsum_plan(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
+                       const int64_t *level_start_host, int info[8]);
+
 /* Diagnostic: when `device_buffer` is non-NULL the LDS-window kernels write shader-clock stamps into it, 16 x 8 bytes
  * per workgroup (buffer >= workgroups x 128 bytes), one per kernel stage; NULL (default) switches it off. */
 int msda_debug_stamps(void *device_buffer);

@@ -21,7 +21,7 @@ ABI_VERSION = 1
 # every symbol include/richsem_msda.h declares
 SYMBOLS = [
     "msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option",
-    "msda_profile_enable", "msda_profile_collect", "msda_tiled_plan", "msda_debug_stamps", "msda_debug_stats",
+    "msda_profile_enable", "msda_profile_collect", "msda_tiled_plan", "msda_levelsum_plan", "msda_debug_stamps", "msda_debug_stats",
     "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64",
 ]
 
@@ -58,6 +58,8 @@ def load():
     L.msda_get_option.restype = ci
     L.msda_tiled_plan.argtypes = [ci] * 7 + [vp, vp, ctypes.POINTER(ci)]
     L.msda_tiled_plan.restype = ci
+    L.msda_levelsum_plan.argtypes = [ci] * 7 + [vp, vp, ctypes.POINTER(ci)]
+    L.msda_levelsum_plan.restype = ci
     L.msda_debug_stamps.argtypes = [vp]
     L.msda_debug_stamps.restype = ci
     L.msda_debug_stats.argtypes = [vp]
@@ -116,6 +118,17 @@ def profile_collect(max_records=65536):
         out.append(dict(kind="bwd" if r.kind else "fwd", variant=r.variant, dtype_bytes=r.dtype_bytes, N=r.N, S=r.S,
                         M=r.M, D=r.D, L=r.L, Lq=r.Lq, P=r.P, kernel_ms=float(r.kernel_ms)))
     return out
+
+
+def levelsum_plan(N, S, M, D, L, Lq, P, shapes, lsi):
+    """What the level-sum backward kernel would take for a problem (host-only)."""
+    import numpy as np
+    sh = np.ascontiguousarray(shapes, dtype=np.int64)
+    ls = np.ascontiguousarray(lsi, dtype=np.int64)
+    info = (ctypes.c_int * 8)()
+    check(load().msda_levelsum_plan(N, S, M, D, L, Lq, P, sh.ctypes.data, ls.ctypes.data, info))
+    keys = ("levels_mask", "windows", "slices", "lds_bytes", "grid", "max_rows")
+    return dict(zip(keys, [int(v) for v in info]))
 
 
 def tiled_plan(N, S, M, D, L, Lq, P, shapes, lsi):

@@ -530,6 +530,26 @@ int msda_tiled_plan(int N, int S, int M, int D, int L, int Lq, int P, const int6
     return MSDA_OK;
 }
 
+int msda_levelsum_plan(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
+                       const int64_t *level_start_host, int *info)
+{
+    if (!shapes_host || !level_start_host || !info) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    if (L < 1 || L > 64) return fail(MSDA_ERR_BAD_DIMS, "bad L=%d", L);
+    msda::LevelSumGeom lg;
+    size_t lds = 0;
+    const unsigned mask = msda::plan_levelsum(N, S, M, D, L, Lq, P, shapes_host, level_start_host, lg, lds);
+    info[0] = (int)mask;
+    info[1] = lg.nlev;
+    info[2] = lg.nslices;
+    info[3] = (int)lds;
+    info[4] = mask ? msda::levelsum_grid(lg) : 0;
+    int rows = 0;
+    for (int e = 0; e < lg.nlev; ++e) rows = lg.nr[e] > rows ? lg.nr[e] : rows;
+    info[5] = rows;
+    info[6] = info[7] = 0;
+    return MSDA_OK;
+}
+
 int msda_debug_stats(void *device_counter)
 {
     msda::tiled_options().stats = static_cast<unsigned *>(device_counter);

@@ -128,3 +128,32 @@ def test_region_partition_covers_every_query_once():
                 lo, hi = region_first(H, g, G), region_first(H, g + 1, G)
                 assert [r for r in range(H) if owner[r] == g] == list(range(lo, hi))
             assert region_first(H, 0, G) == 0 and region_first(H, G, G) == H
+
+
+def test_levelsum_plan_hands_over_all_levels_of_decoder_calls():
+    """Host-only plan of the level-sum backward kernel (msda_levelsum_plan): decoder-shaped calls hand over every level
+    (the finest one in row bands), encoder-sized calls none, and a level too large for eight bands stays with the
+    direct kernel's atomics while the small ones are still taken."""
+    from richsem_amd import _lib
+
+    def plan(call):
+        sh, lsi = W.level_tensors(call)
+        return _lib.levelsum_plan(call.N, call.S, call.M, call.D, call.L, call.Lq, call.P, sh.tolist(), lsi.tolist())
+
+    Dd = W.call_Dd(2)
+    p = plan(Dd)
+    assert p["levels_mask"] == 0b1111
+    assert p["windows"] == 4 + 1 + 1 + 1            # 100 x 168 in four bands of 25 rows; the other levels whole
+    assert p["max_rows"] == 50                       # the 50 x 84 level, whole
+    assert p["slices"] == 8 and p["grid"] == 16 * 7 * 8
+    assert p["lds_bytes"] <= 150 * 1024 and p["lds_bytes"] == 25 * 168 * 4 * 8
+
+    assert plan(W.call_E(2))["levels_mask"] == 0     # Lq * P too large for every workgroup to walk all points
+
+    big = W.Call("big", 1, 1, 32, 4, [(300, 300), (9, 9)], 64, False)
+    p = plan(big)
+    assert p["levels_mask"] == 0b10 and p["windows"] == 1   # 9 x 9 receives 256 points (>= 2 per pixel); 300 x 300 does not fit
+
+    odd = W.Call("odd", 1, 2, 30, 2, [(91, 70), (5, 5)], 500, False)
+    p = plan(odd)
+    assert p["levels_mask"] == 0b11 and p["windows"] == 3 and p["max_rows"] == 46 and p["slices"] == 8
