@@ -94,7 +94,7 @@ const char *msda_last_error(void);
  *   "tile_grow"       1 (default) = a window grows into the LDS its phase leaves unused, coarsest level first (per-level
  *                     margins >= tile_margin); 0 = every level uses exactly tile_margin
  *   "bwd_levelsum"    1 (default) = direct backward, fp32: grad_value of whole levels (or row bands of a level) is summed
- *                     in an f64 LDS window by its own kernel and written once.  Calls with Lq*P <= 65536 (decoder-shaped)
+ *                     in an f64 LDS window by its own kernel and written once.  Calls with Lq*P <= 2^20 whose levels fit 16 windows
  *                     hand over ALL levels: no global atomics, no zero-fill, sums exact to fp32 rounding whatever the order.  Otherwise only
  *                     levels that fit LDS whole and receive >= 2 sampling points per pixel.  0 = off (row atomics only)
  *   "tile_accum"      grad_value of the window path: 2 = sorted (segmented) reduction, fp32 sums (default);

@@ -132,7 +132,7 @@ def test_region_partition_covers_every_query_once():
 
 def test_levelsum_plan_hands_over_all_levels_of_decoder_calls():
     """Host-only plan of the level-sum backward kernel (msda_levelsum_plan): decoder-shaped calls hand over every level
-    (the finest one in row bands), encoder-sized calls none, and a level too large for eight bands stays with the
+    (the finest one in row bands), encoder-sized calls too, and a level too large for eight bands stays with the
     direct kernel's atomics while the small ones are still taken."""
     from richsem_amd import _lib
 
@@ -148,7 +148,10 @@ def test_levelsum_plan_hands_over_all_levels_of_decoder_calls():
     assert p["slices"] == 8 and p["grid"] == 16 * 7 * 8
     assert p["lds_bytes"] <= 150 * 1024 and p["lds_bytes"] == 25 * 168 * 4 * 8
 
-    assert plan(W.call_E(2))["levels_mask"] == 0     # Lq * P too large for every workgroup to walk all points
+    p = plan(W.call_E(2))                            # the direct backward of an encoder-sized call (scattered data)
+    assert p["levels_mask"] == 0b1111 and p["windows"] == 7
+    huge = W.Call("huge", 1, 1, 32, 4, [(20, 20)], 300000, False)
+    assert plan(huge)["levels_mask"] == 0            # Lq * P beyond what one workgroup should walk: row atomics
 
     big = W.Call("big", 1, 1, 32, 4, [(300, 300), (9, 9)], 64, False)
     p = plan(big)
