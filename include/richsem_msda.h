@@ -85,7 +85,7 @@ const char *msda_last_error(void);
  *   "locality_monitor"  1 (default) = in auto mode the window forward kernel counts, on the first 8 calls of a problem
  *                     shape and on every 64th after, the points that miss their window; the count comes back by an
  *                     asynchronous copy and is read on a later call (no call waits, nothing is probed during graph
- *                     capture).  Share > 2 % -> direct forward, share > 25 % -> direct backward (crossovers measured on
+ *                     capture).  Share > 2 % -> direct forward, share > 23 % -> direct backward (crossovers measured on
  *                     MI355X).  0 = auto always takes the window kernels when they apply.  Setting it forgets what was
  *                     learnt.  "locality_share_ppm" (get only): last measured share in parts per million, -1 = none.
  *   "bwd_direct_cpl"  channels per lane of the direct backward kernel (0 = auto, 1, 2, 4)

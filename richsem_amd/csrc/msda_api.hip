@@ -79,7 +79,7 @@ struct ProfileScope {
 // forward kernel count its general points now and then (one atomic per wave), brings the count back with an
 // asynchronous copy + event on the caller's stream, and reads it on a LATER call once the event has completed -- no
 // call ever waits.  Nothing is probed while the stream is being captured into a graph.
-constexpr float kFwdShareMax = 0.02f, kBwdShareMax = 0.25f;
+constexpr float kFwdShareMax = 0.02f, kBwdShareMax = 0.23f;
 constexpr unsigned kProbeWarmCalls = 8, kProbeEvery = 64;
 constexpr int kMaxDevices = 64;
 std::atomic<int> g_monitor_on{1};
