@@ -608,44 +608,58 @@ __device__ __forceinline__ void gather_level(
                 }
             }
             if (any_slow) {   // uniform over the quad; rare
-                const int lane0 = (threadIdx.x & (kWave - 1)) & ~3;
-                // which of the four point slots has a general point anywhere in the wave: the others are skipped
-                // without their shuffles (wave-uniform test)
+                // A wave steps through this body whenever ONE of its lanes holds a general point, so the body is kept short:
+                // the owner lane resolves its point once, the quad receives corner offsets and coefficients by DPP
+                // (compile-time slots, no cross-lane LDS traffic), and a slot that has no general point anywhere in the wave
+                // is skipped by a wave-uniform test.
                 const unsigned long long slow_lanes = __ballot(mode == -2);
-                for (int i = 0; i < 4; ++i) {
-                    if (!(slow_lanes & (0x1111111111111111ull << i))) continue;
-                    const int m_ = __shfl(mode, lane0 + i, kWave);
-                    const float x_ = __shfl(xy.x, lane0 + i, kWave), y_ = __shfl(xy.y, lane0 + i, kWave);
-                    const float lh_ = __shfl(lh, lane0 + i, kWave), lw_ = __shfl(lw, lane0 + i, kWave);
-                    const float a_ = __shfl(a, lane0 + i, kWave);
-                    if (m_ != -2) continue;   // uniform over the quad
-                    float4 v[4][NV];
-                    global_corners<NV>(value, lc, row_elems, chan, x_, y_, v);
-                    if (!BWD) {
-                        const float hh_ = 1.f - lh_, hw_ = 1.f - lw_;
-                        fwd_accumulate(hh_ * hw_ * a_, hh_ * lw_ * a_, lh_ * hw_ * a_, lh_ * lw_ * a_, v[0][0], v[1][0],
-                                       v[2][0], v[3][0], acc_lo[k], acc_hi[k]);
-                    } else {
-                        float d1, d2, d3, d4, s_a, s_w, s_h;
-                        corner_dots<NV>(gq[k], v, d1, d2, d3, d4);
-                        d1 = query_sum<GL>(d1);
-                        d2 = query_sum<GL>(d2);
-                        d3 = query_sum<GL>(d3);
-                        d4 = query_sum<GL>(d4);
-                        combine_dots(lh_, lw_, d1, d2, d3, d4, s_a, s_w, s_h);
-                        // the fast pass gave this point zeros: add ours on top (first half: in `part`, else in memory)
-                        if (j == i) {
-                            const float gx_ = (float)lc.W * s_w * a_, gy_ = (float)lc.H * s_h * a_;
-                            if (MODE == 1) {
-                                part[k][0] += s_a;
-                                part[k][1] += gx_;
-                                part[k][2] += gy_;
-                            } else {
-                                store_point_grads<true>(grad_loc, grad_aw, pt0[k] + pc + i, s_a, gx_, gy_);
-                            }
-                        }
-                    }
+                int o[4] = {-1, -1, -1, -1};
+                if (mode == -2) {
+                    float t0, t1;
+                    resolve_point<float>(xy.x, xy.y, lc.H, lc.W, lc.base_row, row_elems, o, t0, t1);
                 }
+#define MSDA_SLOW(I)                                                                                                  \
+    if ((slow_lanes & (0x1111111111111111ull << I)) && quad_bcast_i<I>(mode) == -2) {                                  \
+        const int o0 = quad_bcast_i<I>(o[0]), o1 = quad_bcast_i<I>(o[1]), o2 = quad_bcast_i<I>(o[2]),                  \
+                  o3 = quad_bcast_i<I>(o[3]);                                                                          \
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
+        float4 v[4][NV];                                                                                               \
+        _Pragma("unroll") for (int n = 0; n < NV; ++n)                                                                 \
+        {                                                                                                              \
+            v[0][n] = o0 >= 0 ? *reinterpret_cast<const float4 *>(value + o0 + chan + 4 * n) : z;                      \
+            v[1][n] = o1 >= 0 ? *reinterpret_cast<const float4 *>(value + o1 + chan + 4 * n) : z;                      \
+            v[2][n] = o2 >= 0 ? *reinterpret_cast<const float4 *>(value + o2 + chan + 4 * n) : z;                      \
+            v[3][n] = o3 >= 0 ? *reinterpret_cast<const float4 *>(value + o3 + chan + 4 * n) : z;                      \
+        }                                                                                                              \
+        if (!BWD) {                                                                                                    \
+            fwd_accumulate(quad_bcast_f<I>(w1), quad_bcast_f<I>(w2), quad_bcast_f<I>(w3), quad_bcast_f<I>(w4), v[0][0], \
+                           v[1][0], v[2][0], v[3][0], acc_lo[k], acc_hi[k]);                                           \
+        } else {                                                                                                       \
+            float d1, d2, d3, d4, s_a, s_w, s_h;                                                                       \
+            corner_dots<NV>(gq[k], v, d1, d2, d3, d4);                                                                 \
+            d1 = query_sum<GL>(d1);                                                                                    \
+            d2 = query_sum<GL>(d2);                                                                                    \
+            d3 = query_sum<GL>(d3);                                                                                    \
+            d4 = query_sum<GL>(d4);                                                                                    \
+            combine_dots(quad_bcast_f<I>(lh), quad_bcast_f<I>(lw), d1, d2, d3, d4, s_a, s_w, s_h);                     \
+            /* the fast pass gave this point zeros: add ours on top (first half: in `part`, else in memory) */         \
+            if (j == I) {                                                                                              \
+                const float gx_ = (float)lc.W * s_w * a, gy_ = (float)lc.H * s_h * a;                                  \
+                if (MODE == 1) {                                                                                       \
+                    part[k][0] += s_a;                                                                                 \
+                    part[k][1] += gx_;                                                                                 \
+                    part[k][2] += gy_;                                                                                 \
+                } else {                                                                                               \
+                    store_point_grads<true>(grad_loc, grad_aw, pt0[k] + pc + I, s_a, gx_, gy_);                        \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+                MSDA_SLOW(0)
+                MSDA_SLOW(1)
+                MSDA_SLOW(2)
+                MSDA_SLOW(3)
+#undef MSDA_SLOW
             }
         }
     }
