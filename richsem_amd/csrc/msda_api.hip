@@ -371,11 +371,17 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
     if (lds > 64 * 1024) return fail(MSDA_ERR_BAD_DIMS, "too many levels (L=%d) for the level table in LDS", L);
     const dim3 grid(direct_grid(g)), block(msda::kDirectThreads);
     ProfileScope prof(0, 1, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
+    // large calls: more waves per SIMD, shallower per-wave pipeline (see fwd_direct_kernel)
+    const bool many = (int64_t)N * Lq * M >= 65536;
+#define MSDA_LAUNCH_FWD(CC)                                                                                              \
+    if (many) hipLaunchKernelGGL((msda::fwd_direct_kernel<T, CC, 8>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g); \
+    else hipLaunchKernelGGL((msda::fwd_direct_kernel<T, CC, 4>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g)
     switch (C) {
-        case 4: hipLaunchKernelGGL((msda::fwd_direct_kernel<T, (sizeof(T) == 4 ? 4 : 2)>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g); break;
-        case 2: hipLaunchKernelGGL((msda::fwd_direct_kernel<T, 2>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g); break;
-        default: hipLaunchKernelGGL((msda::fwd_direct_kernel<T, 1>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g); break;
+        case 4: MSDA_LAUNCH_FWD((sizeof(T) == 4 ? 4 : 2)); break;
+        case 2: MSDA_LAUNCH_FWD(2); break;
+        default: MSDA_LAUNCH_FWD(1); break;
     }
+#undef MSDA_LAUNCH_FWD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch of the direct forward kernel");
     return MSDA_OK;
