@@ -105,39 +105,40 @@ __global__ __launch_bounds__(kLsThreads) void bwd_levelsum_kernel(const float *_
     __syncthreads();
 
     const int LP = g.L * g.P;
-    const int npts = g.Lq * g.P;   // sampling points of this (image, head, level)
-    for (int i0 = grp; i0 < npts; i0 += kGroups * kLsUnroll) {
-        float x[kLsUnroll], y[kLsUnroll], ga[kLsUnroll];
+    // query-major walk: a lane group takes a query and its P points of this level (kLsUnroll at a time, all loads first) -- no
+    // index divisions in the loop, grad_out read once per query
+    for (int q = grp; q < g.Lq; q += kGroups) {
+        const unsigned item = (unsigned)((b * g.Lq + q) * g.M + m);
+        const unsigned pt0 = item * (unsigned)LP + (unsigned)(l * g.P);
+        const float go = has_ch ? grad_out[item * (unsigned)g.D + ch] : 0.f;
+        for (int p0 = 0; p0 < g.P; p0 += kLsUnroll) {
+            float x[kLsUnroll], y[kLsUnroll], ga[kLsUnroll];
 #pragma unroll
-        for (int u = 0; u < kLsUnroll; ++u) {   // all loads of the batch are issued before the first use
-            const int i = i0 + u * kGroups;
-            const bool live = i < npts;
-            const int q = live ? i / g.P : 0, p = live ? i - q * g.P : 0;
-            const unsigned item = (unsigned)((b * g.Lq + q) * g.M + m);
-            const unsigned pt = item * (unsigned)LP + (unsigned)(l * g.P + p);
-            const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
-            const float a = aw[pt];
-            const float go = has_ch ? grad_out[item * (unsigned)g.D + ch] : 0.f;
-            x[u] = xy.x;
-            y[u] = xy.y;
-            ga[u] = live ? go * a : 0.f;          // top_grad * attn_weight (ms_deform_im2col_cuda.cuh:117)
-            if (!live) x[u] = -4.f;               // dropped by the range test below
-        }
+            for (int u = 0; u < kLsUnroll; ++u) {
+                const bool live = p0 + u < g.P;
+                const unsigned pt = pt0 + (unsigned)(live ? p0 + u : 0);
+                const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
+                const float a = aw[pt];
+                x[u] = live ? xy.x : -4.f;            // (-4: dropped by the range test below)
+                y[u] = xy.y;
+                ga[u] = go * a;                       // top_grad * attn_weight (ms_deform_im2col_cuda.cuh:117)
+            }
 #pragma unroll
-        for (int u = 0; u < kLsUnroll; ++u) {
-            const float h_im = y[u] * (float)H - 0.5f, w_im = x[u] * (float)W - 0.5f;
-            if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) continue;
-            const float hf = floorf(h_im), wf = floorf(w_im);
-            const int h_low = (int)hf, w_low = (int)wf;
-            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-            // a corner counts if it is inside the map AND inside this workgroup's row band
-            const bool top = h_low >= r0 && h_low < r0 + nr, bot = h_low + 1 >= r0 && h_low + 1 < r0 + nr;
-            const bool lef = w_low >= 0, rig = w_low + 1 <= W - 1;
-            double *p00 = win + ((h_low - r0) * W + w_low) * kLsChan + j;
-            if (top && lef) atomicAdd(p00, (double)(hh * hw * ga[u]));
-            if (top && rig) atomicAdd(p00 + kLsChan, (double)(hh * lw * ga[u]));
-            if (bot && lef) atomicAdd(p00 + W * kLsChan, (double)(lh * hw * ga[u]));
-            if (bot && rig) atomicAdd(p00 + (W + 1) * kLsChan, (double)(lh * lw * ga[u]));
+            for (int u = 0; u < kLsUnroll; ++u) {
+                const float h_im = y[u] * (float)H - 0.5f, w_im = x[u] * (float)W - 0.5f;
+                if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) continue;
+                const float hf = floorf(h_im), wf = floorf(w_im);
+                const int h_low = (int)hf, w_low = (int)wf;
+                const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+                // a corner counts if it is inside the map AND inside this workgroup's row band
+                const bool top = h_low >= r0 && h_low < r0 + nr, bot = h_low + 1 >= r0 && h_low + 1 < r0 + nr;
+                const bool lef = w_low >= 0, rig = w_low + 1 <= W - 1;
+                double *p00 = win + ((h_low - r0) * W + w_low) * kLsChan + j;
+                if (top && lef) atomicAdd(p00, (double)(hh * hw * ga[u]));
+                if (top && rig) atomicAdd(p00 + kLsChan, (double)(hh * lw * ga[u]));
+                if (bot && lef) atomicAdd(p00 + W * kLsChan, (double)(lh * hw * ga[u]));
+                if (bot && rig) atomicAdd(p00 + (W + 1) * kLsChan, (double)(lh * lw * ga[u]));
+            }
         }
     }
     __syncthreads();
