@@ -302,10 +302,11 @@ hipError_t launch_levelsum<float>(const Problem &pb, const float *loc, const flo
     size_t lds = 0;
     taken = msda::plan_levelsum(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(), pb.lsi.data(), lg, lds);
     if (!taken) return hipSuccess;
-    hipError_t e = msda::set_lds_limit(reinterpret_cast<const void *>(&msda::bwd_levelsum_kernel), lds);
+    auto kern = pb.P == 4 ? &msda::bwd_levelsum_kernel<true> : &msda::bwd_levelsum_kernel<false>;
+    hipError_t e = msda::set_lds_limit(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(msda::bwd_levelsum_kernel, dim3(msda::levelsum_grid(lg)), dim3(msda::kLsThreads), lds, stream, loc,
-                       aw, grad_out, grad_value, lg);
+    hipLaunchKernelGGL(kern, dim3(msda::levelsum_grid(lg)), dim3(msda::kLsThreads), lds, stream, loc, aw, grad_out, grad_value,
+                       lg);
     return hipGetLastError();
 }
 

@@ -80,6 +80,7 @@ inline int levelsum_grid(const LevelSumGeom &g)
     return kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.nlev * g.nslices;
 }
 
+template <bool P4>   // P4: exactly four points per level (RichSem) -- their locations / weights are loaded as whole vectors
 __global__ __launch_bounds__(kLsThreads) void bwd_levelsum_kernel(const float *__restrict__ loc,
                                                                   const float *__restrict__ aw,
                                                                   const float *__restrict__ grad_out,
@@ -111,17 +112,27 @@ __global__ __launch_bounds__(kLsThreads) void bwd_levelsum_kernel(const float *_
         const unsigned item = (unsigned)((b * g.Lq + q) * g.M + m);
         const unsigned pt0 = item * (unsigned)LP + (unsigned)(l * g.P);
         const float go = has_ch ? grad_out[item * (unsigned)g.D + ch] : 0.f;
-        for (int p0 = 0; p0 < g.P; p0 += kLsUnroll) {
+        for (int p0 = 0; p0 < (P4 ? 4 : g.P); p0 += kLsUnroll) {
             float x[kLsUnroll], y[kLsUnroll], ga[kLsUnroll];
+            if (P4) {   // 32 B of locations + 16 B of weights, aligned (pt0 is a multiple of 4)
+                static_assert(kLsUnroll == 4, "P4 path loads four points at once");
+                const float4 xy01 = *reinterpret_cast<const float4 *>(loc + 2u * pt0);
+                const float4 xy23 = *reinterpret_cast<const float4 *>(loc + 2u * pt0 + 4);
+                const float4 a4 = *reinterpret_cast<const float4 *>(aw + pt0);
+                x[0] = xy01.x; y[0] = xy01.y; x[1] = xy01.z; y[1] = xy01.w;
+                x[2] = xy23.x; y[2] = xy23.y; x[3] = xy23.z; y[3] = xy23.w;
+                ga[0] = go * a4.x; ga[1] = go * a4.y; ga[2] = go * a4.z; ga[3] = go * a4.w;
+            } else {
 #pragma unroll
-            for (int u = 0; u < kLsUnroll; ++u) {
-                const bool live = p0 + u < g.P;
-                const unsigned pt = pt0 + (unsigned)(live ? p0 + u : 0);
-                const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
-                const float a = aw[pt];
-                x[u] = live ? xy.x : -4.f;            // (-4: dropped by the range test below)
-                y[u] = xy.y;
-                ga[u] = go * a;                       // top_grad * attn_weight (ms_deform_im2col_cuda.cuh:117)
+                for (int u = 0; u < kLsUnroll; ++u) {
+                    const bool live = p0 + u < g.P;
+                    const unsigned pt = pt0 + (unsigned)(live ? p0 + u : 0);
+                    const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
+                    const float a = aw[pt];
+                    x[u] = live ? xy.x : -4.f;            // (-4: dropped by the range test below)
+                    y[u] = xy.y;
+                    ga[u] = go * a;                       // top_grad * attn_weight (ms_deform_im2col_cuda.cuh:117)
+                }
             }
 #pragma unroll
             for (int u = 0; u < kLsUnroll; ++u) {
@@ -130,14 +141,19 @@ __global__ __launch_bounds__(kLsThreads) void bwd_levelsum_kernel(const float *_
                 const float hf = floorf(h_im), wf = floorf(w_im);
                 const int h_low = (int)hf, w_low = (int)wf;
                 const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-                // a corner counts if it is inside the map AND inside this workgroup's row band
+                // a corner counts if it is inside the map AND inside this workgroup's row band.  One branch for "not in this
+                // band at all"; after it every corner is added unconditionally -- a corner that does not count adds 0.0 to a
+                // clamped (valid) address, which costs less than four more branches
                 const bool top = h_low >= r0 && h_low < r0 + nr, bot = h_low + 1 >= r0 && h_low + 1 < r0 + nr;
+                if (!(top || bot)) continue;
                 const bool lef = w_low >= 0, rig = w_low + 1 <= W - 1;
-                double *p00 = win + ((h_low - r0) * W + w_low) * kLsChan + j;
-                if (top && lef) atomicAdd(p00, (double)(hh * hw * ga[u]));
-                if (top && rig) atomicAdd(p00 + kLsChan, (double)(hh * lw * ga[u]));
-                if (bot && lef) atomicAdd(p00 + W * kLsChan, (double)(lh * hw * ga[u]));
-                if (bot && rig) atomicAdd(p00 + (W + 1) * kLsChan, (double)(lh * lw * ga[u]));
+                const int rt = (top ? h_low : h_low + 1) - r0, rb = (bot ? h_low + 1 : h_low) - r0;
+                const int cl = lef ? w_low : w_low + 1, cr = rig ? w_low + 1 : w_low;
+                double *pt_ = win + (rt * W) * kLsChan + j, *pb_ = win + (rb * W) * kLsChan + j;
+                atomicAdd(pt_ + cl * kLsChan, (double)(top && lef ? hh * hw * ga[u] : 0.f));
+                atomicAdd(pt_ + cr * kLsChan, (double)(top && rig ? hh * lw * ga[u] : 0.f));
+                atomicAdd(pb_ + cl * kLsChan, (double)(bot && lef ? lh * hw * ga[u] : 0.f));
+                atomicAdd(pb_ + cr * kLsChan, (double)(bot && rig ? lh * lw * ga[u] : 0.f));
             }
         }
     }
