@@ -23,11 +23,29 @@ def build(force=False):
     return _SO
 
 
-def lib():
+def build_native():
+    """bench.py's cpu_baseline leg only: rebuild the oracle ON THIS BOX with -march=native (the committed recipe's
+    portable -mavx2 build travels with the snapshot; the host CPU of the GPU box differs from the build container's)
+    and switch to it.  Returns False -- and keeps the portable build -- when there is no compiler here."""
+    global _lib
+    src = os.path.join(_HERE, "msda_oracle.c")
+    so = os.path.join(_HERE, "libmsda_oracle_native.so")
+    try:
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fPIC", "-fopenmp", "-std=c11",
+                               "-shared", "-o", so, src, "-lm"], stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        return False
+    _lib = None
+    lib(so)
+    return True
+
+
+def lib(path=None):
     global _lib
     if _lib is None:
-        build()
-        L = ctypes.CDLL(_SO)
+        if path is None:
+            build()
+        L = ctypes.CDLL(path or _SO)
         vp, ip = ctypes.c_void_p, ctypes.c_int
         for sfx in ("f32", "f64"):
             f = getattr(L, "msda_oracle_forward_" + sfx)

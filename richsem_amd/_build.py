@@ -12,7 +12,11 @@ CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "librichsem_msda.so")
 SOURCES = ["msda_api.hip"]
-HEADERS = ["msda_common.h", "msda_direct.h", "msda_tiled.h", os.path.join("..", "..", "include", "richsem_msda.h")]
+def _headers():
+    """every header the library is built from: csrc/*.h and include/*.h (globbed, so a new kernel header can never be
+    forgotten by the staleness check)"""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(_PKG, "..", "include", "*.h")))
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 
@@ -27,7 +31,7 @@ def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, f) for f in SOURCES] + _headers() + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

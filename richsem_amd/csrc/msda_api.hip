@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -16,6 +17,7 @@
 #include "../../include/richsem_msda.h"
 #include "msda_direct.h"
 #include "msda_levelsum.h"
+#include "msda_psb.h"
 #include "msda_tiled.h"
 
 namespace {
@@ -63,6 +65,15 @@ struct ProfileScope {
         slot = &g_prof_slots[g_prof_used++];
         slot->rec = msda_profile_record{kind, variant, dtype_bytes, N, S, M, D, L, Lq, P, 0.f};
         (void)hipEventRecord(slot->start, stream);
+    }
+    // the call turned out not to run this variant: give the slot back (only the newest slot can be returned)
+    void cancel()
+    {
+        if (!slot) return;
+        std::lock_guard<std::mutex> lock(g_prof_mutex);
+        if (g_prof_used > 0 && slot == &g_prof_slots[g_prof_used - 1]) --g_prof_used;
+        else slot->rec.variant = -1;
+        slot = nullptr;
     }
     ~ProfileScope()
     {
@@ -302,7 +313,10 @@ hipError_t launch_levelsum<float>(const Problem &pb, const float *loc, const flo
     size_t lds = 0;
     taken = msda::plan_levelsum(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(), pb.lsi.data(), lg, lds);
     if (!taken) return hipSuccess;
-    auto kern = pb.P == 4 ? &msda::bwd_levelsum_kernel<true> : &msda::bwd_levelsum_kernel<false>;
+    // the P4 form loads a level's four locations / weights as 16-B vectors: only for 16-B aligned tensors (the ABI asks
+    // for element alignment only)
+    const bool vec = pb.P == 4 && is_aligned(loc, 16) && is_aligned(aw, 16);
+    auto kern = vec ? &msda::bwd_levelsum_kernel<true> : &msda::bwd_levelsum_kernel<false>;
     hipError_t e = msda::set_lds_limit(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(msda::levelsum_grid(lg)), dim3(msda::kLsThreads), lds, stream, loc, aw, grad_out, grad_value,
@@ -328,6 +342,105 @@ int direct_grid(const msda::DirectGeom &g)
 {
     const int pairs = g.N * g.M;
     return msda::kXcds * ((pairs + msda::kXcds - 1) / msda::kXcds) * g.ntiles;
+}
+
+// ---- pixel-stationary backward (msda_psb.h): workspace and launch ------------------------------------------------------
+// The kernel needs a few words of device memory (work-queue heads, far-point counter) and a list for the far points.
+// Kept per (device, stream): calls on one stream are ordered, so they can share it; calls on different streams cannot.
+struct PsbWorkspace {
+    unsigned *ctr = nullptr, *far = nullptr;
+    size_t far_cap = 0;
+};
+std::mutex g_psb_mu;
+std::map<std::pair<int, hipStream_t>, PsbWorkspace> g_psb_ws;
+int g_cu_count[kMaxDevices] = {0};
+
+bool psb_workspace(hipStream_t stream, size_t far_cap, PsbWorkspace &out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_psb_mu);
+    PsbWorkspace &ws = g_psb_ws[std::make_pair(dev, stream)];
+    if (!ws.ctr || ws.far_cap < far_cap) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &cap);
+        if (cap != hipStreamCaptureStatusNone) return false;   // no allocation while the stream is being captured
+        if (!ws.ctr && hipMalloc(reinterpret_cast<void **>(&ws.ctr), 64) != hipSuccess) { (void)hipGetLastError(); ws.ctr = nullptr; return false; }
+        if (ws.far_cap < far_cap || !ws.far) {
+            if (ws.far) (void)hipFree(ws.far);   // (waits for the work that may still use it)
+            ws.far = nullptr;
+            ws.far_cap = 0;
+            const size_t want = far_cap < 16 ? 16 : far_cap;
+            if (hipMalloc(reinterpret_cast<void **>(&ws.far), want * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            ws.far_cap = want;
+        }
+    }
+    out = ws;
+    return true;
+}
+
+int cu_count()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    if (!g_cu_count[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_cu_count[dev] = n;
+    }
+    return g_cu_count[dev];
+}
+
+// total chunk-phases per (image, head) a plan costs: what decides whether walking every query for every tile is affordable
+int64_t psb_cost(const msda::PsbPlan &pl, const Problem &pb)
+{
+    int64_t phases = 0;
+    for (int l = 0; l < pb.L; ++l) {
+        const msda::PsbLevel &v = pl.g.lv[l];
+        if (pl.g.encoder && v.mg >= 0) { phases += (int64_t)v.nty * v.ntx * 4; continue; }   // ~3-4 chunks per tile by geometry
+        phases += (int64_t)v.nty * v.ntx * ((pb.Lq + msda::kPsbQC - 1) / msda::kPsbQC);
+    }
+    return phases;
+}
+
+// returns hipErrorNotSupported when the plan does not apply or no workspace can be had right now
+hipError_t launch_bwd_psb(const Problem &pb, const float *value, const float *loc, const float *aw, const float *grad_out,
+                          float *grad_value, float *grad_loc, float *grad_aw, hipStream_t stream, bool forced)
+{
+    msda::PsbPlan pl = msda::plan_psb(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(), pb.lsi.data());
+    if (!pl.ok) return hipErrorNotSupported;
+    if (!forced && psb_cost(pl, pb) > 1200) return hipErrorNotSupported;
+    if ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_value)) & 15)
+        return hipErrorNotSupported;
+    if (reinterpret_cast<uintptr_t>(grad_loc) & 7) return hipErrorNotSupported;
+    PsbWorkspace ws;
+    if (!psb_workspace(stream, pl.far_cap, ws)) return hipErrorNotSupported;
+    pl.g.ctr = ws.ctr;
+    pl.g.far_list = ws.far;
+    pl.g.stamps = msda::tiled_options().stamps;
+    auto kern = pb.P == 4 ? &msda::psb_kernel<true> : &msda::psb_kernel<false>;
+    hipError_t e = msda::set_lds_limit(reinterpret_cast<const void *>(kern), sizeof(msda::PsbLds));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(msda::psb_prep_kernel, dim3(128), dim3(256), 0, stream, grad_value, pl.g);
+    const int grid = (cu_count() / msda::kXcds) * msda::kXcds;
+    hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 8), dim3(msda::kPsbThreads), sizeof(msda::PsbLds), stream, value, loc, aw,
+                       grad_out, grad_value, grad_loc, grad_aw, pl.g);
+    if (pl.far_cap)
+        hipLaunchKernelGGL(msda::psb_far_kernel, dim3(512), dim3(256), 0, stream, value, loc, aw, grad_out, grad_value,
+                           grad_loc, grad_aw, pl.g);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t try_bwd_psb(const Problem &, const T *, const T *, const T *, const T *, T *, T *, T *, hipStream_t, bool)
+{
+    return hipErrorNotSupported;
+}
+template <>
+hipError_t try_bwd_psb<float>(const Problem &pb, const float *value, const float *loc, const float *aw, const float *grad_out,
+                              float *grad_value, float *grad_loc, float *grad_aw, hipStream_t stream, bool forced)
+{
+    return launch_bwd_psb(pb, value, loc, aw, grad_out, grad_value, grad_loc, grad_aw, stream, forced);
 }
 
 template <typename T>
@@ -409,6 +522,22 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
     auto zero_grad_value = [&]() { return hipMemsetAsync(grad_value, 0, sizeof(T) * (size_t)N * S * M * D, stream); };
 
     int variant = g_bwd_variant.load();
+    // pixel-stationary backward: encoder-shaped calls while the sampling points are local enough (locality monitor),
+    // other calls when walking every query for every tile is cheap (decoder-shaped)
+    if (variant == 0 || variant == 3) {
+        bool want = true;
+        if (variant == 0 && Lq == S)
+            want = monitor_choose_bwd(monitor_for_current_device(), problem_key(N, S, M, L, P, pb.shapes.data()), stream) == 2;
+        if (want) {
+            ProfileScope prof(1, 3, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
+            e = try_bwd_psb<T>(pb, value, loc, aw, grad_out, grad_value, grad_loc, grad_aw, stream, variant == 3);
+            if (e == hipSuccess) return MSDA_OK;
+            prof.cancel();
+            if (e != hipErrorNotSupported) return hip_fail(e, "launch of the pixel-stationary backward kernels");
+            e = hipSuccess;
+        }
+    }
+    if (variant == 3) variant = 0;
     if (variant != 1 && msda::tiled_bwd_applicable<T>(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(),
                                                      pb.lsi.data(), value, grad_out, grad_value)) {
         if (variant == 0)   // automatic: the forward calls of this problem measured how local its sampling points are
@@ -430,7 +559,13 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
     // levels (decoder-shaped calls) grad_value is written, not accumulated: no zero-fill, no atomics.
     unsigned ls_levels = 0;
     const unsigned all_levels = L >= 32 ? ~0u : (1u << L) - 1;
-    if (g_levelsum.load()) ls_levels = levelsum_levels<T>(pb);
+    // (its plain per-level stores need the levels to tile [0, S) without overlap; check_problem only bounds them)
+    bool levels_tile = true;
+    for (int64_t l = 0, pre = 0; l < L; ++l) {
+        levels_tile = levels_tile && pb.lsi[l] == pre;
+        pre += pb.shapes[2 * l] * pb.shapes[2 * l + 1];
+    }
+    if (g_levelsum.load() && levels_tile) ls_levels = levelsum_levels<T>(pb);
     if (ls_levels != all_levels && (e = zero_grad_value()) != hipSuccess) return hip_fail(e, "zero-fill of grad_value");
     // Float atomics run at full rate only as >= 128-B row segments (one dword per lane): with 32 or more
     // channels put ONE channel on a lane, so that a wave-instruction adds two whole 128-B rows.
@@ -469,7 +604,11 @@ const char *msda_last_error(void) { return g_err; }
 int msda_set_option(const char *key, int value)
 {
     if (key && !strcmp(key, "fwd_variant") && value >= 0 && value <= 2) { g_fwd_variant = value; return MSDA_OK; }
-    if (key && !strcmp(key, "bwd_variant") && value >= 0 && value <= 2) { g_bwd_variant = value; return MSDA_OK; }
+    if (key && !strcmp(key, "bwd_variant") && value >= 0 && value <= 3) { g_bwd_variant = value; return MSDA_OK; }
+    if (key && !strcmp(key, "psb_margin") && value >= 0 && value <= 64) { msda::psb_options().margin = value; return MSDA_OK; }
+    if (key && !strcmp(key, "psb_tile") && value >= 4 && value <= 23) { msda::psb_options().tile = value; return MSDA_OK; }
+    if (key && !strcmp(key, "psb_max_chunks") && value >= 1 && value <= 4096) { msda::psb_options().max_chunks = value; return MSDA_OK; }
+    if (key && !strcmp(key, "psb_coarse_px") && value >= 0 && value <= 1000000) { msda::psb_options().coarse_px = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_direct_cpl") && (value == 0 || value == 1 || value == 2 || value == 4)) { g_bwd_cpl = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_region") && value >= 4 && value <= 64) { msda::tiled_options().region_px = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_margin") && value >= 0 && value <= 32) { msda::tiled_options().margin = value; return MSDA_OK; }
@@ -497,6 +636,10 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "fwd_variant")) { *value = g_fwd_variant; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_variant")) { *value = g_bwd_variant; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_direct_cpl")) { *value = g_bwd_cpl; return MSDA_OK; }
+    if (key && !strcmp(key, "psb_margin")) { *value = msda::psb_options().margin; return MSDA_OK; }
+    if (key && !strcmp(key, "psb_tile")) { *value = msda::psb_options().tile; return MSDA_OK; }
+    if (key && !strcmp(key, "psb_max_chunks")) { *value = msda::psb_options().max_chunks; return MSDA_OK; }
+    if (key && !strcmp(key, "psb_coarse_px")) { *value = msda::psb_options().coarse_px; return MSDA_OK; }
     if (key && !strcmp(key, "tile_region")) { *value = msda::tiled_options().region_px; return MSDA_OK; }
     if (key && !strcmp(key, "tile_margin")) { *value = msda::tiled_options().margin; return MSDA_OK; }
     if (key && !strcmp(key, "tile_accum")) { *value = msda::tiled_options().accum; return MSDA_OK; }

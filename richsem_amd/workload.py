@@ -104,6 +104,8 @@ def make_inputs(call, loc_mode="init", seed=0, dtype=torch.float32, device="cpu"
       "uniform" U[0,1)^2 as in ops/test.py:34 -- worst-case locality
     Generated on the CPU generator (reproducible everywhere), then moved to `device`.
     Returns dict(value, shapes, lsi, loc, aw, grad_out)."""
+    if loc_mode == "sigma4":   # the init pattern with 4 px of jitter (bench's middle distribution)
+        loc_mode, jitter_px = "init", 4.0
     g = torch.Generator().manual_seed(seed)
     N, M, D, L, P, S, Lq = call.N, call.M, call.D, call.L, call.P, call.S, call.Lq
     value = torch.randn(N, S, M, D, generator=g, dtype=dtype)
@@ -131,6 +133,37 @@ def make_inputs(call, loc_mode="init", seed=0, dtype=torch.float32, device="cpu"
     return {k: v.to(device) for k, v in t.items()}
 
 
-# one training step of the hot path: (call, repetitions)
+def make_loc(call, loc_mode, seed=0, dtype=torch.float32, device="cpu"):
+    """Only the sampling locations of make_inputs, drawn from their own generator, in one of the bench's three
+    distributions: "init" (1 px jitter), "sigma4" (the init pattern + N(0, 4 px): 5-6 % of the points leave a
+    6-px window margin -- offsets of a trained network are not 1 px) and "uniform"."""
+    mode, jitter = {"init": ("init", 1.0), "sigma4": ("init", 4.0), "uniform": ("uniform", 0.0)}[loc_mode]
+    g = torch.Generator().manual_seed(977 + seed)
+    N, M, L, P, Lq = call.N, call.M, call.L, call.P, call.Lq
+    if mode == "uniform":
+        return torch.rand(N, Lq, M, L, P, 2, generator=g, dtype=dtype).to(device)
+    if call.encoder:
+        ref = encoder_reference_points(call, dtype)[None].expand(N, Lq, 2)
+    else:
+        ref = torch.rand(N, Lq, 2, generator=g, dtype=dtype) * 0.8 + 0.1
+    th = torch.arange(M, dtype=dtype) * (2.0 * math.pi / M)
+    d = torch.stack([th.cos(), th.sin()], -1)
+    d = d / d.abs().max(-1, keepdim=True)[0]
+    k = torch.arange(1, P + 1, dtype=dtype)
+    off = (d[:, None, None, :] * k[None, None, :, None]).expand(M, L, P, 2)
+    off = off[None, None] + jitter * torch.randn(N, Lq, M, L, P, 2, generator=g, dtype=dtype)
+    wh = torch.tensor([[w, h] for h, w in call.shapes], dtype=dtype)
+    return (ref[:, :, None, None, None, :] + off / wh[None, None, None, :, None, :]).contiguous().to(device)
+
+
+LOC_MODES = ("init", "sigma4", "uniform")
+
+# one training step of the hot path: (call, repetitions) -- 6 encoder layers + 6 decoder layers, each with its OWN
+# tensors (deformable_transformer.py:870, :1017: every layer projects its own value and predicts its own offsets)
 def training_step_calls(N=2):
     return [(call_E(N), 6), (call_Dd(N), 6)]
+
+# trainable parameters whose gradients DDP all-reduces per step (SURVEY.md section 2.2: R50 C3-C5 23.3 M, input_proj
+# 5.6 M, 6 encoder layers 7.7 M, 6 decoder layers 9.3 M, heads / embeddings 1.7 M; reference main.py:204-206)
+GRAD_ALLREDUCE_ELEMS = 47_600_000
+DDP_BUCKET_BYTES = 25 * 1024 * 1024   # torch DDP's default bucket_cap_mb

@@ -80,3 +80,67 @@ def test_shard_batch_partitions_images():
     assert seen == list(range(8))
     with pytest.raises(ValueError):
         bench.shard_batch(t, 0, 3)
+
+
+def _allreduce_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    n = 1000
+    flat = torch.full((n,), float(rank + 1))
+    buckets = bench.grad_buckets(n, 4 * 128)            # 128-element buckets
+    fire = bench.bucket_schedule(len(buckets), 12)
+    works, nb = [], 0
+    for k in range(1, 13):                               # the 12 backward calls of a step
+        while nb < len(buckets) and fire[nb] <= k:
+            s, e = buckets[nb]
+            works.append(dist.all_reduce(flat[s:e], async_op=True))
+            nb += 1
+    assert nb == len(buckets)
+    for w in works:
+        w.wait()
+    assert torch.equal(flat, torch.full((n,), float(sum(range(1, world + 1)))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_bucketed_gradient_allreduce():
+    """bench.py --gpus N issues the reference's DDP gradient all-reduce bucket by bucket between the backward calls
+    (reference main.py:204-206); here the same schedule over gloo, world size 2."""
+    mp.spawn(_allreduce_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_bucket_plan_covers_the_gradient_once():
+    sys.path.insert(0, ROOT)
+    import bench
+    from richsem_amd import workload as W
+    b = bench.grad_buckets(W.GRAD_ALLREDUCE_ELEMS, W.DDP_BUCKET_BYTES)
+    assert b[0][0] == 0 and b[-1][1] == W.GRAD_ALLREDUCE_ELEMS and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    assert len(b) == 8 and 4 * (b[0][1] - b[0][0]) == 25 * 1024 * 1024
+    sched = bench.bucket_schedule(len(b), 12)
+    assert sched == sorted(sched) and sched[-1] == 12 and sched[0] >= 1
+
+
+def test_self_launch_builds_a_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts its ranks itself (as children, before any GPU call)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        class R:
+            returncode = 0
+        return R()
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

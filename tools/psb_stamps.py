@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Tuning aid: per-stage shader-clock shares of the pixel-stationary backward kernel (msda_debug_stamps)."""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from richsem_amd import _lib, workload as W   # noqa: E402
+from richsem_amd import MultiScaleDeformableAttention as MSDA   # noqa: E402
+
+NAMES = ["item header + value rows", "grad_out loads + clear + decode next", "resolve + ranks + gcache write", "scan",
+         "placement", "reduce (partial sums)", "corner dots", "combine", "fold + flush", "queue tail"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--call", default="E")
+    ap.add_argument("--loc", default="init")
+    ap.add_argument("--opt", action="append", default=[])
+    args = ap.parse_args()
+    lib = _lib.load()
+    _lib.set_option("locality_monitor", 0)
+    _lib.set_option("bwd_variant", 3)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
+    call = {"E": W.call_E, "Dd": W.call_Dd, "Em": W.call_Em}[args.call](2)
+    t = W.make_inputs(call, "init", seed=0, device="cuda")
+    loc = W.make_loc(call, args.loc, seed=0, device="cuda")
+    run = lambda: MSDA.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], loc, t["aw"], t["grad_out"], 64)
+    for _ in range(3):
+        run()
+    buf = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
+    lib.msda_debug_stamps(ctypes.c_void_p(buf.data_ptr()))
+    run()
+    torch.cuda.synchronize()
+    lib.msda_debug_stamps(None)
+    s = buf.view(-1, 16)[:256].cpu().double()
+    tot = s[:, :10].sum(1)
+    print(f"{args.call} loc-{args.loc}: per workgroup {tot.mean():.0f} cycles (min {tot.min():.0f}, max {tot.max():.0f})")
+    for i, n in enumerate(NAMES):
+        print(f"  {n:34s} {s[:, i].mean():10.0f} cycles  {100 * s[:, i].mean() / tot.mean():5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
