@@ -70,6 +70,7 @@ def parse_args(argv=None):
     ap.add_argument("--images-per-gpu", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-collective", action="store_true", help="N > 1: leave the gradient all-reduce out")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the extra bf16 pass")
     ap.add_argument("--fwd-variant", type=int, default=0)
     ap.add_argument("--bwd-variant", type=int, default=0)
     return ap.parse_args(argv)
@@ -168,13 +169,41 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_share():
+    """CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota when there is one (a
+    GPU box hands each job a share of its host cores; more OpenMP threads than that only fight each other)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(calls, n_images):
     """Oracle timed on the host: forward+backward of each distinct call (loc-init, layer 0), min of 5 runs at all
     cores and min of 2 at one thread, scaled by the call's repetitions per step."""
     from oracle import msda_oracle as O
     from richsem_amd import workload as W
     native = O.build_native()   # -march=native build made on THIS box (falls back to the portable -mavx2 one)
-    cores = min(len(os.sched_getaffinity(0)), O.max_threads())
+    cores = min(cpu_share(), O.max_threads())
+    # the fastest thread count for this box among a few candidates (one quick E forward+backward each)
+    probe = W.make_inputs(calls[0][0], "init", seed=0)
+    pz = {k: v.numpy() for k, v in probe.items()}
+    best_t, best_dt = cores, float("inf")
+    for cand in sorted({cores, min(cores, 64), min(cores, 32), min(cores, 16)}):
+        O.set_threads(cand)
+        dts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            O.forward(pz["value"], pz["shapes"], pz["lsi"], pz["loc"], pz["aw"])
+            O.backward(pz["value"], pz["shapes"], pz["lsi"], pz["loc"], pz["aw"], pz["grad_out"])
+            dts.append(time.perf_counter() - t0)
+        if min(dts) < best_dt:
+            best_t, best_dt = cand, min(dts)
+    cores = best_t
     out = {}
     parts = []
     for label, threads, reps_timed in (("all", cores, 5), ("one", 1, 2)):
@@ -256,12 +285,13 @@ def main(argv=None):
         buckets = grad_buckets(W.GRAD_ALLREDUCE_ELEMS, W.DDP_BUCKET_BYTES)
         fire_after = bucket_schedule(len(buckets), len(layers))
 
-    def step(mode, with_collective):
+    def step(mode, with_collective, bf16=False):
+        vk, gk = ("value_bf16", "grad_out_bf16") if bf16 else ("value", "grad_out")
         for c, t, locs in layers:
-            MSDA.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], locs[mode], t["aw"], 64)
+            MSDA.ms_deform_attn_forward(t[vk], t["shapes"], t["lsi"], locs[mode], t["aw"], 64)
         nb = 0
         for k, (c, t, locs) in enumerate(reversed(layers), 1):
-            MSDA.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], locs[mode], t["aw"], t["grad_out"], 64)
+            MSDA.ms_deform_attn_backward(t[vk], t["shapes"], t["lsi"], locs[mode], t["aw"], t[gk], 64)
             while with_collective and nb < len(buckets) and fire_after[nb] <= k:
                 s, e = buckets[nb]
                 works.append(dist.all_reduce(flat_grads[s:e], async_op=True))   # RCCL, its own stream: overlaps
@@ -275,17 +305,17 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(mode, with_collective, profile):
+    def timed(mode, with_collective, profile, bf16=False):
         _lib.set_option("locality_monitor", _lib.get_option("locality_monitor"))   # forget the previous distribution
         for _ in range(max(args.warmup, 3)):   # (the locality monitor settles within the first two steps)
-            step(mode, with_collective)
+            step(mode, with_collective, bf16)
         fence()
         if profile:
             _lib.profile_enable(calls_per_step * args.steps)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step(mode, with_collective)
+            step(mode, with_collective, bf16)
         fence()
         elapsed = time.perf_counter() - t0
         records = []
@@ -301,6 +331,11 @@ def main(argv=None):
         if collective:
             res["elapsed_nc"], _ = timed(mode, False, False)
         results[mode] = res
+    if not args.no_bf16:   # the same step with bf16 value / out / grad tensors (library entry points msda_*_bf16), headline distribution
+        for c, t, locs in layers:
+            t["value_bf16"], t["grad_out_bf16"] = t["value"].to(torch.bfloat16), t["grad_out"].to(torch.bfloat16)
+        elapsed, records = timed(modes[0], collective, True, bf16=True)
+        results["bf16"] = {"elapsed": elapsed, "records": records}
 
     if rank == 0:
         n_total = total_images(n_img, world)
@@ -313,7 +348,8 @@ def main(argv=None):
             kernels = []
             for (kind, Lq, variant), ms in sorted(by.items()):
                 call = next(c for c, _ in calls if c.Lq == Lq)
-                nbytes = call.bytes_bwd() if kind == "bwd" else call.bytes_fwd()
+                e_v = 2 if mode == "bf16" else 4   # bytes per value / out / grad element
+                nbytes = call.bytes_bwd(e_v) if kind == "bwd" else call.bytes_fwd(e_v)
                 avg = sum(ms) / len(ms)
                 kernels.append({"kernel": f"msda_{kind}_{VARIANT_NAMES.get(variant, variant)}[{call.name}]",
                                 "hip_kernels": HIP_KERNELS.get((kind, variant), "?"), "launches": len(ms),
@@ -352,6 +388,11 @@ def main(argv=None):
         for m in modes[1:]:
             line["value_" + m] = summ[m]["value"]
         line["distributions"] = {m: {k: v for k, v in summ[m].items() if k != "kernels" or m != modes[0]} for m in modes}
+        if "bf16" in results:
+            b = summarise("bf16")
+            line["bf16"] = {"dtype": "bf16 value/out/grad, f32 locations/weights and accumulation", "loc": modes[0],
+                            "value": b["value"], "ms_per_step": b["ms_per_step"], "roofline": b["roofline"],
+                            "kernels": b["kernels"]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(calls, n_img)
         else:

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RICHSEM_MSDA_ABI_VERSION 1
+#define RICHSEM_MSDA_ABI_VERSION 2
 
 /* Return codes: 0 = success; negative = argument error detected on the host (nothing was
  * launched); positive = hipError_t reported by the runtime. */
@@ -174,6 +174,29 @@ int msda_backward_f64(const double *value, const int64_t *spatial_shapes, const 
                       double *grad_value, double *grad_sampling_loc, double *grad_attn_weight,
                       const int64_t *shapes_host, const int64_t *level_start_host,
                       msda_stream_t stream);
+
+/* ---- bf16 storage, fp32 compute (new capability: the reference dispatches float / double only,
+ * src/cuda/ms_deform_attn_cuda.cu:64,134) -------------------------------------------------------
+ * value, out, grad_out, grad_value are bfloat16 (raw 16-bit words, same layouts as above);
+ * sampling_loc, attn_weight and their gradients stay float32.  Every sum is formed in fp32 (or in
+ * f64 LDS windows) and rounded to bf16 ONCE: grad_value is never accumulated in bf16.  Where the
+ * kernels accumulate grad_value with atomics, they do so in an fp32 scratch buffer owned by the
+ * library (one per device and stream, allocated on first use -- not while the stream is being
+ * captured -- and reused); decoder-shaped calls need no scratch.
+ * value / out / grad_out / grad_value must be 8-byte aligned for the fast paths (2 bytes minimum). */
+int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                      const float *sampling_loc, const float *attn_weight,
+                      int N, int S, int M, int D, int L, int Lq, int P, int im2col_step,
+                      uint16_t *out,
+                      const int64_t *shapes_host, const int64_t *level_start_host,
+                      msda_stream_t stream);
+
+int msda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                       const float *sampling_loc, const float *attn_weight, const uint16_t *grad_out,
+                       int N, int S, int M, int D, int L, int Lq, int P, int im2col_step,
+                       uint16_t *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
+                       const int64_t *shapes_host, const int64_t *level_start_host,
+                       msda_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,10 @@ from . import _lib
 
 __all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward"]
 
-_SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+# float32 / float64 as the reference (AT_DISPATCH_FLOATING_TYPES, ms_deform_attn_cuda.cu:64,134); bfloat16 is new here:
+# value / out / grad_output / grad_value in bf16, sampling locations and attention weights (and their gradients) in
+# float32, every accumulation in fp32 (include/richsem_msda.h, msda_*_bf16).
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}
 
 # Host mirrors of (spatial_shapes, level_start_index).  The launch geometry needs the level sizes on
 # the host; reading them back costs a stream synchronisation, so it is done once per tensor OBJECT
@@ -62,13 +65,16 @@ def _check_inputs(named, fn):
             raise RuntimeError(f"{name} must be a CUDA tensor")
         if t.device != value.device:
             raise RuntimeError(f"{name} must be on the same device as value")
-    if value.dtype not in _SUFFIX:   # AT_DISPATCH_FLOATING_TYPES: float and double only (ms_deform_attn_cuda.cu:64,134)
-        aten = {torch.float16: "Half", torch.bfloat16: "BFloat16", torch.int64: "Long", torch.int32: "Int"}
+    if value.dtype not in _SUFFIX:   # the reference: float and double only (ms_deform_attn_cuda.cu:64,134); here also bfloat16
+        aten = {torch.float16: "Half", torch.int64: "Long", torch.int32: "Int"}
         raise RuntimeError(f'"{fn}" not implemented for \'{aten.get(value.dtype, str(value.dtype))}\'')
     for name, t in named:
         if name in ("spatial_shapes", "level_start_index"):
             if t.dtype != torch.int64:
                 raise RuntimeError(f"{name} must be an int64 tensor")
+        elif value.dtype == torch.bfloat16 and name in ("sampling_loc", "attn_weight"):
+            if t.dtype not in (torch.float32, torch.bfloat16):   # bf16 ones are widened (positions need fp32)
+                raise RuntimeError(f"{name} must be float32 (or bfloat16) when value is bfloat16, got {t.dtype}")
         elif t.dtype != value.dtype:
             raise RuntimeError(f"{name} must have the dtype of value ({value.dtype}), got {t.dtype}")
 
@@ -95,6 +101,8 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
     lib = _lib.load()
     sh, ls = _host_mirror(spatial_shapes, level_start_index)
+    if value.dtype == torch.bfloat16:
+        sampling_loc, attn_weight = sampling_loc.float(), attn_weight.float()   # no-ops for float32 inputs
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
@@ -116,6 +124,9 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         raise RuntimeError(f"grad_output has {grad_output.numel()} elements, expected {N * Lq * M * D}")
     lib = _lib.load()
     sh, ls = _host_mirror(spatial_shapes, level_start_index)
+    loc_dtype, aw_dtype = sampling_loc.dtype, attn_weight.dtype
+    if value.dtype == torch.bfloat16:
+        sampling_loc, attn_weight = sampling_loc.float(), attn_weight.float()
     grad_value = torch.empty_like(value)            # zero-filled by the library, on the same stream
     grad_loc = torch.empty_like(sampling_loc)       # written exactly once per element by the kernel
     grad_aw = torch.empty_like(attn_weight)
@@ -126,4 +137,4 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
             attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L, Lq, P, int(im2col_step),
             grad_value.data_ptr(), grad_loc.data_ptr(), grad_aw.data_ptr(), sh.ctypes.data, ls.ctypes.data, stream)
     _lib.check(rc)
-    return [grad_value, grad_loc, grad_aw]
+    return [grad_value, grad_loc.to(loc_dtype), grad_aw.to(aw_dtype)]

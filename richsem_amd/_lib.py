@@ -16,13 +16,14 @@ ERR_NAMES = {
     -4: "MSDA_ERR_TOO_LARGE", -5: "MSDA_ERR_MISALIGNED", -6: "MSDA_ERR_NO_DEVICE", -7: "MSDA_ERR_BAD_OPTION",
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/richsem_msda.h declares
 SYMBOLS = [
     "msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option",
     "msda_profile_enable", "msda_profile_collect", "msda_tiled_plan", "msda_levelsum_plan", "msda_debug_stamps", "msda_debug_stats",
     "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64",
+    "msda_forward_bf16", "msda_backward_bf16",
 ]
 
 
@@ -68,7 +69,7 @@ def load():
     L.msda_profile_enable.restype = ci
     L.msda_profile_collect.argtypes = [ctypes.POINTER(ProfileRecord), ci, ctypes.POINTER(ci)]
     L.msda_profile_collect.restype = ci
-    for sfx in ("f32", "f64"):
+    for sfx in ("f32", "f64", "bf16"):
         f = getattr(L, "msda_forward_" + sfx)
         f.argtypes = [vp] * 5 + [ci] * 8 + [vp, vp, vp, vp]
         f.restype = ci

@@ -350,6 +350,8 @@ int direct_grid(const msda::DirectGeom &g)
 struct PsbWorkspace {
     unsigned *ctr = nullptr, *far = nullptr;
     size_t far_cap = 0;
+    float *gv32 = nullptr;   // bf16 backward: fp32 accumulation buffer for grad_value (rounded to bf16 once)
+    size_t gv32_cap = 0;
 };
 std::mutex g_psb_mu;
 std::map<std::pair<int, hipStream_t>, PsbWorkspace> g_psb_ws;
@@ -522,20 +524,15 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
     auto zero_grad_value = [&]() { return hipMemsetAsync(grad_value, 0, sizeof(T) * (size_t)N * S * M * D, stream); };
 
     int variant = g_bwd_variant.load();
-    // pixel-stationary backward: encoder-shaped calls while the sampling points are local enough (locality monitor),
-    // other calls when walking every query for every tile is cheap (decoder-shaped)
-    if (variant == 0 || variant == 3) {
-        bool want = true;
-        if (variant == 0 && Lq == S)
-            want = monitor_choose_bwd(monitor_for_current_device(), problem_key(N, S, M, L, P, pb.shapes.data()), stream) == 2;
-        if (want) {
-            ProfileScope prof(1, 3, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
-            e = try_bwd_psb<T>(pb, value, loc, aw, grad_out, grad_value, grad_loc, grad_aw, stream, variant == 3);
-            if (e == hipSuccess) return MSDA_OK;
-            prof.cancel();
-            if (e != hipErrorNotSupported) return hip_fail(e, "launch of the pixel-stationary backward kernels");
-            e = hipSuccess;
-        }
+    // pixel-stationary backward (msda_psb.h): opt-in (bwd_variant = 3).  Measured on MI355X it does not beat the window kernels
+    // (call E: 505 vs 382 us; call Dd: 126 vs 85 us), so the automatic choice never takes it.
+    if (variant == 3) {
+        ProfileScope prof(1, 3, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
+        e = try_bwd_psb<T>(pb, value, loc, aw, grad_out, grad_value, grad_loc, grad_aw, stream, true);
+        if (e == hipSuccess) return MSDA_OK;
+        prof.cancel();
+        if (e != hipErrorNotSupported) return hip_fail(e, "launch of the pixel-stationary backward kernels");
+        e = hipSuccess;
     }
     if (variant == 3) variant = 0;
     if (variant != 1 && msda::tiled_bwd_applicable<T>(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(),
@@ -590,6 +587,196 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
     }
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch of the direct backward kernel");
+    return MSDA_OK;
+}
+
+// ---- bf16 storage (value / out / grad_out / grad_value), fp32 compute ----------------------------------------------------------
+// New capability: the reference dispatches float / double only (ms_deform_attn_cuda.cu:64,134).  Sampling locations,
+// attention weights and their gradients stay fp32; every sum is formed in fp32 (or f64 LDS windows) and rounded to bf16 once.
+bool bf16_scratch(hipStream_t stream, size_t n_floats, float **out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_psb_mu);
+    PsbWorkspace &ws = g_psb_ws[std::make_pair(dev, stream)];
+    if (ws.gv32_cap < n_floats) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &cap);
+        if (cap != hipStreamCaptureStatusNone) return false;
+        if (ws.gv32) (void)hipFree(ws.gv32);
+        ws.gv32 = nullptr;
+        ws.gv32_cap = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&ws.gv32), n_floats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
+        ws.gv32_cap = n_floats;
+    }
+    *out = ws.gv32;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void round_to_bf16_kernel(const float *__restrict__ src, msda::bf16_t *__restrict__ dst, size_t n4)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        msda::st4(dst + 4 * i, *reinterpret_cast<const float4 *>(src + 4 * i));
+}
+
+int pick_channels_bf16(int D, std::initializer_list<const void *> ptrs)
+{
+    int c = 4;
+    for (; c > 1; c >>= 1) {
+        bool ok = D % c == 0;
+        for (const void *p : ptrs) ok = ok && is_aligned(p, 2 * (size_t)c);
+        if (ok) break;
+    }
+    return c;
+}
+
+int forward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *aw,
+                      int N, int S, int M, int D, int L, int Lq, int P, int im2col_step, msda::bf16_t *out,
+                      const int64_t *shapes_host, const int64_t *lsi_host, msda_stream_t stream_)
+{
+    g_err[0] = 0;
+    if (!value || !shapes || !lsi || !loc || !aw || !out) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Problem pb{N, S, M, D, L, Lq, P, {}, {}};
+    if (int rc = check_problem(pb, shapes, lsi, shapes_host, lsi_host, im2col_step, stream)) return rc;
+    if (!is_aligned(value, 2) || !is_aligned(out, 2) || !is_aligned(aw, 4) || !is_aligned(loc, 8) || !is_aligned(shapes, 8) ||
+        !is_aligned(lsi, 8))
+        return fail(MSDA_ERR_MISALIGNED, "misaligned pointer (sampling_loc needs 8 bytes)");
+
+    int variant = g_fwd_variant.load();
+    if (variant != 1 && is_aligned(value, 8) && is_aligned(out, 8) &&
+        msda::plan_gather(N, S, M, D, L, Lq, P, pb.shapes.data(), pb.lsi.data()).ok) {
+        unsigned *probe = nullptr;
+        Monitor *mo = nullptr;
+        if (variant == 0) {
+            mo = monitor_for_current_device();
+            variant = monitor_choose_fwd(mo, problem_key(N, S, M, L, P, pb.shapes.data()), stream, &probe);
+        }
+        if (variant == 2) {
+            hipError_t e;
+            {
+                ProfileScope prof(0, 2, 2, N, S, M, D, L, Lq, P, stream);
+                e = msda::launch_fwd_tiled_tv<msda::bf16_t>(value, loc, aw, out, N, S, M, D, L, Lq, P, pb.shapes.data(),
+                                                           pb.lsi.data(), probe, stream);
+            }
+            if (probe) monitor_finish_probe(mo, 2.0 * N * Lq * M * L * P, stream, e == hipSuccess);
+            if (e != hipSuccess) return hip_fail(e, "launch of the tiled forward kernel (bf16)");
+            return MSDA_OK;
+        }
+    }
+    const int C = pick_channels_bf16(D, {value, out});
+    const msda::DirectGeom g = direct_geom(pb, C);
+    const size_t lds = msda::direct_lds_bytes<float>(g);
+    if (lds > 64 * 1024) return fail(MSDA_ERR_BAD_DIMS, "too many levels (L=%d) for the level table in LDS", L);
+    const dim3 grid(direct_grid(g)), block(msda::kDirectThreads);
+    ProfileScope prof(0, 1, 2, N, S, M, D, L, Lq, P, stream);
+    const bool many = (int64_t)N * Lq * M >= 65536;
+#define MSDA_LAUNCH_FWD(CC)                                                                                                          \
+    if (many) hipLaunchKernelGGL((msda::fwd_direct_kernel<float, CC, 8, msda::bf16_t>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g); \
+    else hipLaunchKernelGGL((msda::fwd_direct_kernel<float, CC, 4, msda::bf16_t>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g)
+    switch (C) {
+        case 4: MSDA_LAUNCH_FWD(4); break;
+        case 2: MSDA_LAUNCH_FWD(2); break;
+        default: MSDA_LAUNCH_FWD(1); break;
+    }
+#undef MSDA_LAUNCH_FWD
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch of the direct forward kernel (bf16)");
+    return MSDA_OK;
+}
+
+int backward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *aw,
+                       const msda::bf16_t *grad_out, int N, int S, int M, int D, int L, int Lq, int P, int im2col_step,
+                       msda::bf16_t *grad_value, float *grad_loc, float *grad_aw, const int64_t *shapes_host,
+                       const int64_t *lsi_host, msda_stream_t stream_)
+{
+    g_err[0] = 0;
+    if (!value || !shapes || !lsi || !loc || !aw || !grad_out || !grad_value || !grad_loc || !grad_aw)
+        return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Problem pb{N, S, M, D, L, Lq, P, {}, {}};
+    if (int rc = check_problem(pb, shapes, lsi, shapes_host, lsi_host, im2col_step, stream)) return rc;
+    if (!is_aligned(value, 2) || !is_aligned(grad_out, 2) || !is_aligned(grad_value, 2) || !is_aligned(aw, 4) ||
+        !is_aligned(grad_aw, 4) || !is_aligned(loc, 8) || !is_aligned(grad_loc, 8) || !is_aligned(shapes, 8) || !is_aligned(lsi, 8))
+        return fail(MSDA_ERR_MISALIGNED, "misaligned pointer (sampling_loc / grad_sampling_loc need 8 bytes)");
+    const size_t n_value = (size_t)N * S * M * D;
+    hipError_t e = hipSuccess;
+    auto finish_from_scratch = [&](float *gv32) {   // one rounding of the fp32 sums
+        if (n_value % 4 == 0 && is_aligned(grad_value, 8)) {
+            hipLaunchKernelGGL(round_to_bf16_kernel, dim3(2048), dim3(256), 0, stream, gv32, grad_value, n_value / 4);
+            return hipGetLastError();
+        }
+        return hipErrorNotSupported;
+    };
+
+    int variant = g_bwd_variant.load();
+    if (variant != 1 && variant != 3 && is_aligned(value, 8) && is_aligned(grad_out, 8) && is_aligned(grad_value, 8)) {
+        if (variant == 0)
+            variant = monitor_choose_bwd(monitor_for_current_device(), problem_key(N, S, M, L, P, pb.shapes.data()), stream);
+        float *gv32 = nullptr;
+        if (variant == 2 && msda::plan_bwd_gather(N, S, M, D, L, Lq, P, pb.shapes.data(), pb.lsi.data()).ok &&
+            msda::plan_scatter_sorted(N, S, M, D, L, Lq, P, pb.shapes.data(), pb.lsi.data()).ok && bf16_scratch(stream, n_value, &gv32)) {
+            if ((e = hipMemsetAsync(gv32, 0, sizeof(float) * n_value, stream)) != hipSuccess) return hip_fail(e, "zero-fill of the fp32 scratch");
+            {
+                ProfileScope prof(1, 2, 2, N, S, M, D, L, Lq, P, stream);
+                e = msda::launch_bwd_tiled_tv<msda::bf16_t>(value, loc, aw, grad_out, gv32, grad_loc, grad_aw, N, S, M, D, L, Lq, P,
+                                                           pb.shapes.data(), pb.lsi.data(), stream);
+                if (e == hipSuccess) e = finish_from_scratch(gv32);
+            }
+            if (e == hipSuccess) return MSDA_OK;
+            if (e != hipErrorNotSupported) return hip_fail(e, "launch of the tiled backward kernels (bf16)");
+        }
+    }
+
+    // direct path.  All levels summed in f64 LDS windows (msda_levelsum.h) when the plan allows: no atomics, no scratch,
+    // the window is rounded to bf16 at its one store.  Otherwise every corner goes to an fp32 scratch buffer with row atomics.
+    bool levels_tile = true;
+    for (int64_t l = 0, pre = 0; l < L; ++l) {
+        levels_tile = levels_tile && pb.lsi[l] == pre;
+        pre += pb.shapes[2 * l] * pb.shapes[2 * l + 1];
+    }
+    const unsigned all_levels = L >= 32 ? ~0u : (1u << L) - 1;
+    msda::LevelSumGeom lg;
+    size_t ls_lds = 0;
+    unsigned ls_levels = 0;
+    if (g_levelsum.load() && levels_tile)
+        ls_levels = msda::plan_levelsum(N, S, M, D, L, Lq, P, pb.shapes.data(), pb.lsi.data(), lg, ls_lds);
+    const bool by_levelsum = ls_levels == all_levels;
+    float *gv32 = nullptr;
+    if (!by_levelsum) {
+        if (!bf16_scratch(stream, n_value, &gv32))
+            return fail(MSDA_ERR_BAD_DIMS, "bf16 backward of this shape needs an fp32 scratch buffer, which cannot be allocated "
+                                           "while the stream is being captured: run the call once outside the capture");
+        if ((e = hipMemsetAsync(gv32, 0, sizeof(float) * n_value, stream)) != hipSuccess) return hip_fail(e, "zero-fill of the fp32 scratch");
+    }
+    int C = pick_channels_bf16(D, {value, grad_out});
+    if (!by_levelsum && D * 4 >= 128) C = 1;   // row atomics: one channel per lane (see backward_impl)
+    msda::DirectGeom g = direct_geom(pb, C);
+    const size_t lds = msda::direct_lds_bytes<float>(g);
+    if (lds > 64 * 1024) return fail(MSDA_ERR_BAD_DIMS, "too many levels (L=%d) for the level table in LDS", L);
+    const dim3 grid(direct_grid(g)), block(msda::kDirectThreads);
+    ProfileScope prof(1, 1, 2, N, S, M, D, L, Lq, P, stream);
+    if (by_levelsum) {
+        const bool vec = P == 4 && is_aligned(loc, 16) && is_aligned(aw, 16);
+        auto kern = vec ? &msda::bwd_levelsum_kernel<true, msda::bf16_t> : &msda::bwd_levelsum_kernel<false, msda::bf16_t>;
+        if ((e = msda::set_lds_limit(reinterpret_cast<const void *>(kern), ls_lds)) != hipSuccess) return hip_fail(e, "LDS limit");
+        hipLaunchKernelGGL(kern, dim3(msda::levelsum_grid(lg)), dim3(msda::kLsThreads), ls_lds, stream, loc, aw, grad_out, grad_value, lg);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "launch of the level-sum backward kernel (bf16)");
+        g.gv_skip = all_levels;
+    }
+    switch (C) {
+        case 4: hipLaunchKernelGGL((msda::bwd_direct_kernel<float, 4, msda::bf16_t>), grid, block, lds, stream, value, shapes, lsi, loc, aw, grad_out, gv32, grad_loc, grad_aw, g); break;
+        case 2: hipLaunchKernelGGL((msda::bwd_direct_kernel<float, 2, msda::bf16_t>), grid, block, lds, stream, value, shapes, lsi, loc, aw, grad_out, gv32, grad_loc, grad_aw, g); break;
+        default: hipLaunchKernelGGL((msda::bwd_direct_kernel<float, 1, msda::bf16_t>), grid, block, lds, stream, value, shapes, lsi, loc, aw, grad_out, gv32, grad_loc, grad_aw, g); break;
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "launch of the direct backward kernel (bf16)");
+    if (!by_levelsum) {
+        e = finish_from_scratch(gv32);
+        if (e == hipErrorNotSupported) {   // odd sizes: element-wise tail-safe path
+            return fail(MSDA_ERR_MISALIGNED, "bf16 grad_value needs 8-byte alignment and a multiple of 4 elements");
+        }
+        if (e != hipSuccess) return hip_fail(e, "rounding grad_value to bf16");
+    }
     return MSDA_OK;
 }
 
@@ -788,6 +975,28 @@ int msda_backward_f64(const double *value, const int64_t *spatial_shapes, const 
     return backward_impl<double>(value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_out, N, S, M, D, L,
                                  Lq, P, im2col_step, grad_value, grad_sampling_loc, grad_attn_weight, shapes_host,
                                  level_start_host, stream);
+}
+
+int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                      const float *sampling_loc, const float *attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
+                      int im2col_step, uint16_t *out, const int64_t *shapes_host, const int64_t *level_start_host,
+                      msda_stream_t stream)
+{
+    return forward_bf16_impl(reinterpret_cast<const msda::bf16_t *>(value), spatial_shapes, level_start, sampling_loc,
+                             attn_weight, N, S, M, D, L, Lq, P, im2col_step, reinterpret_cast<msda::bf16_t *>(out), shapes_host,
+                             level_start_host, stream);
+}
+
+int msda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                       const float *sampling_loc, const float *attn_weight, const uint16_t *grad_out, int N, int S, int M,
+                       int D, int L, int Lq, int P, int im2col_step, uint16_t *grad_value, float *grad_sampling_loc,
+                       float *grad_attn_weight, const int64_t *shapes_host, const int64_t *level_start_host,
+                       msda_stream_t stream)
+{
+    return backward_bf16_impl(reinterpret_cast<const msda::bf16_t *>(value), spatial_shapes, level_start, sampling_loc,
+                              attn_weight, reinterpret_cast<const msda::bf16_t *>(grad_out), N, S, M, D, L, Lq, P, im2col_step,
+                              reinterpret_cast<msda::bf16_t *>(grad_value), grad_sampling_loc, grad_attn_weight, shapes_host,
+                              level_start_host, stream);
 }
 
 }  // extern "C"

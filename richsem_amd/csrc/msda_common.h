@@ -9,6 +9,7 @@
 //                       (reference ms_deform_im2col_cuda.cuh:33-84)
 #pragma once
 
+#include <hip/hip_bf16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -23,6 +24,38 @@ template <typename T, int C>
 struct alignas(sizeof(T) * C) Pack {
     T v[C];
 };
+
+// Storage type of value / out / grad_out / grad_value: the compute type itself (float, double), or bfloat16 with fp32
+// compute (msda_*_bf16 entry points: the reference has no half path, ms_deform_attn_cuda.cu:64,134 -- new capability).
+// Sampling locations, attention weights, their gradients and every accumulation stay in the compute type.
+using bf16_t = __hip_bfloat16;
+
+template <typename T, typename TV>
+__device__ __forceinline__ T to_compute(TV x) { return (T)x; }
+template <>
+__device__ __forceinline__ float to_compute<float, bf16_t>(bf16_t x) { return __bfloat162float(x); }
+
+template <typename TV, typename T>
+__device__ __forceinline__ TV to_storage(T x) { return (TV)x; }
+template <>
+__device__ __forceinline__ bf16_t to_storage<bf16_t, float>(float x) { return __float2bfloat16(x); }   // round to nearest even
+
+// four consecutive channels as fp32, from either storage type (16-B or 8-B aligned address)
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t *p)
+{
+    const uint2 u = *reinterpret_cast<const uint2 *>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float *p, const float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t *p, const float4 v)
+{
+    bf16_t r[4] = {__float2bfloat16(v.x), __float2bfloat16(v.y), __float2bfloat16(v.z), __float2bfloat16(v.w)};
+    *reinterpret_cast<uint2 *>(p) = *reinterpret_cast<const uint2 *>(r);
+}
+__device__ __forceinline__ float ld1(const float *p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t *p) { return __bfloat162float(*p); }
 
 // One sampling point of one (image, query, head), resolved once and shared through LDS by the
 // lanes that hold that query's channels: element offsets of the four corners into `value`

@@ -60,10 +60,11 @@ __device__ __forceinline__ void load_levels(LevelGeom *lv, const int64_t *shapes
 // OCC = waves per SIMD the register budget is cut for.  Measured on MI355X: the kernel waits on its gathers 78 % of the time
 // (PMC), so for large calls twice the waves with half the loads in flight each win (call E: 190 -> 157 us at OCC 8), while a
 // small call (decoder: 1092 queries) is faster with the deeper per-wave pipeline of OCC 4 (19.5 vs 23 us).
-template <typename T, int C, int OCC>
+// TV = storage type of value / out (T itself, or bf16_t with T = float)
+template <typename T, int C, int OCC, typename TV = T>
 __global__ __launch_bounds__(kDirectThreads, OCC) void fwd_direct_kernel(
-    const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
-    const T *__restrict__ loc, const T *__restrict__ aw, T *__restrict__ out, const DirectGeom g)
+    const TV *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
+    const T *__restrict__ loc, const T *__restrict__ aw, TV *__restrict__ out, const DirectGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LevelGeom *lv = reinterpret_cast<LevelGeom *>(smem);
@@ -124,7 +125,9 @@ __global__ __launch_bounds__(kDirectThreads, OCC) void fwd_direct_kernel(
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             if (r.o[k] >= 0) {
-                                v[k] = *reinterpret_cast<const Pack<T, C> *>(value + r.o[k] + c0);
+                                const Pack<TV, C> raw = *reinterpret_cast<const Pack<TV, C> *>(value + r.o[k] + c0);
+#pragma unroll
+                                for (int c = 0; c < C; ++c) v[k].v[c] = to_compute<T, TV>(raw.v[c]);
                             } else {
 #pragma unroll
                                 for (int c = 0; c < C; ++c) v[k].v[c] = (T)0;
@@ -138,19 +141,21 @@ __global__ __launch_bounds__(kDirectThreads, OCC) void fwd_direct_kernel(
                 __builtin_amdgcn_wave_barrier();
             }
             if (has_c) {
-                Pack<T, C> o;
+                Pack<TV, C> o;
 #pragma unroll
-                for (int c = 0; c < C; ++c) o.v[c] = acc[c];
-                *reinterpret_cast<Pack<T, C> *>(out + (int64_t)item * g.D + c0) = o;
+                for (int c = 0; c < C; ++c) o.v[c] = to_storage<TV, T>(acc[c]);
+                *reinterpret_cast<Pack<TV, C> *>(out + (int64_t)item * g.D + c0) = o;
             }
         }
     }
 }
 
-template <typename T, int C>
+// TV = storage type of value / grad_out.  grad_value is accumulated with atomics in the compute type T (in bf16 mode it
+// is an fp32 scratch buffer that is rounded to bf16 once, afterwards -- or nothing at all when gv_skip covers every level).
+template <typename T, int C, typename TV = T>
 __global__ __launch_bounds__(kDirectThreads) void bwd_direct_kernel(
-    const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
-    const T *__restrict__ loc, const T *__restrict__ aw, const T *__restrict__ grad_out,
+    const TV *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
+    const T *__restrict__ loc, const T *__restrict__ aw, const TV *__restrict__ grad_out,
     T *__restrict__ grad_value, T *__restrict__ grad_loc, T *__restrict__ grad_aw, const DirectGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -179,7 +184,11 @@ __global__ __launch_bounds__(kDirectThreads) void bwd_direct_kernel(
         Pack<T, C> g0;
 #pragma unroll
         for (int c = 0; c < C; ++c) g0.v[c] = (T)0;
-        if (live && j * C < g.D) g0 = *reinterpret_cast<const Pack<T, C> *>(grad_out + (int64_t)item * g.D + j * C);
+        if (live && j * C < g.D) {
+            const Pack<TV, C> raw = *reinterpret_cast<const Pack<TV, C> *>(grad_out + (int64_t)item * g.D + j * C);
+#pragma unroll
+            for (int c = 0; c < C; ++c) g0.v[c] = to_compute<T, TV>(raw.v[c]);
+        }
 
         for (int p0 = 0; p0 < LP; p0 += g.pbatch) {
             const int np = min(g.pbatch, LP - p0);
@@ -208,12 +217,18 @@ __global__ __launch_bounds__(kDirectThreads) void bwd_direct_kernel(
                     const int c0 = (ch * g.G + j) * C;
                     if (!(live && c0 < g.D)) continue;
                     Pack<T, C> tg = g0;
-                    if (ch > 0) tg = *reinterpret_cast<const Pack<T, C> *>(grad_out + (int64_t)item * g.D + c0);
+                    if (ch > 0) {
+                        const Pack<TV, C> raw = *reinterpret_cast<const Pack<TV, C> *>(grad_out + (int64_t)item * g.D + c0);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) tg.v[c] = to_compute<T, TV>(raw.v[c]);
+                    }
                     Pack<T, C> v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         if (r.o[k] >= 0) {
-                            v[k] = *reinterpret_cast<const Pack<T, C> *>(value + r.o[k] + c0);
+                            const Pack<TV, C> raw = *reinterpret_cast<const Pack<TV, C> *>(value + r.o[k] + c0);
+#pragma unroll
+                            for (int c = 0; c < C; ++c) v[k].v[c] = to_compute<T, TV>(raw.v[c]);
                         } else {
 #pragma unroll
                             for (int c = 0; c < C; ++c) v[k].v[c] = (T)0;

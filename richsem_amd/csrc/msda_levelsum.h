@@ -80,11 +80,13 @@ inline int levelsum_grid(const LevelSumGeom &g)
     return kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.nlev * g.nslices;
 }
 
-template <bool P4>   // P4: exactly four points per level (RichSem) -- their locations / weights are loaded as whole vectors
+// P4: exactly four points per level (RichSem) -- their locations / weights are loaded as whole vectors.
+// TV: storage type of grad_out / grad_value (float, or bf16_t: the f64 window is rounded to bf16 once, at the store).
+template <bool P4, typename TV = float>
 __global__ __launch_bounds__(kLsThreads) void bwd_levelsum_kernel(const float *__restrict__ loc,
                                                                   const float *__restrict__ aw,
-                                                                  const float *__restrict__ grad_out,
-                                                                  float *__restrict__ grad_value, const LevelSumGeom g)
+                                                                  const TV *__restrict__ grad_out,
+                                                                  TV *__restrict__ grad_value, const LevelSumGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *win = reinterpret_cast<double *>(smem);
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(kLsThreads) void bwd_levelsum_kernel(const float *_
     for (int q = grp; q < g.Lq; q += kGroups) {
         const unsigned item = (unsigned)((b * g.Lq + q) * g.M + m);
         const unsigned pt0 = item * (unsigned)LP + (unsigned)(l * g.P);
-        const float go = has_ch ? grad_out[item * (unsigned)g.D + ch] : 0.f;
+        const float go = has_ch ? ld1(grad_out + item * (unsigned)g.D + ch) : 0.f;
         for (int p0 = 0; p0 < (P4 ? 4 : g.P); p0 += kLsUnroll) {
             float x[kLsUnroll], y[kLsUnroll], ga[kLsUnroll];
             if (P4) {   // 32 B of locations + 16 B of weights, aligned (pt0 is a multiple of 4)
@@ -160,9 +162,9 @@ __global__ __launch_bounds__(kLsThreads) void bwd_levelsum_kernel(const float *_
     __syncthreads();
 
     // every pixel of the slice, once: 16 B per lane group
-    float *dst = grad_value + ((int64_t)(b * g.S + g.start[li] + r0 * W) * g.M + m) * g.D + ch;
+    TV *dst = grad_value + ((int64_t)(b * g.S + g.start[li] + r0 * W) * g.M + m) * g.D + ch;
     if (has_ch)
-        for (int px = grp; px < npx; px += kGroups) dst[(int64_t)px * g.M * g.D] = (float)win[px * kLsChan + j];
+        for (int px = grp; px < npx; px += kGroups) dst[(int64_t)px * g.M * g.D] = to_storage<TV, float>((float)win[px * kLsChan + j]);
 }
 
 }  // namespace msda

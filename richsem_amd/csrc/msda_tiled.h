@@ -516,9 +516,9 @@ __device__ __forceinline__ void store_point_grads(float *__restrict__ grad_loc, 
 // afterwards in ONE run-time loop per query (not unrolled), with shuffles instead of DPP.
 // MODE (backward): 0 = all 32 channels in one pass: store the per-point results; 1 = first channel half: keep them in
 // `part` (lane i of the quad keeps point i); 2 = second channel half: add `part` and store.
-template <bool BWD, bool P4, int MODE, int GC, int CPL>
+template <bool BWD, bool P4, int MODE, int GC, int CPL, typename TV>
 __device__ __forceinline__ void gather_level(
-    const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ aw, const float *win,
+    const TV *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ aw, const float *win,
     const LevelCtx &lc, int row_elems, int P_, int j, int chan, const unsigned (&pt0)[GatherCfg<GC, CPL>::QPG],
     const bool (&live)[GatherCfg<GC, CPL>::QPG], const LevelOps<GatherCfg<GC, CPL>::QPG> &pre,
     v2f (&acc_lo)[GatherCfg<GC, CPL>::QPG], v2f (&acc_hi)[GatherCfg<GC, CPL>::QPG],
@@ -626,10 +626,10 @@ __device__ __forceinline__ void gather_level(
         float4 v[4][NV];                                                                                               \
         _Pragma("unroll") for (int n = 0; n < NV; ++n)                                                                 \
         {                                                                                                              \
-            v[0][n] = o0 >= 0 ? *reinterpret_cast<const float4 *>(value + o0 + chan + 4 * n) : z;                      \
-            v[1][n] = o1 >= 0 ? *reinterpret_cast<const float4 *>(value + o1 + chan + 4 * n) : z;                      \
-            v[2][n] = o2 >= 0 ? *reinterpret_cast<const float4 *>(value + o2 + chan + 4 * n) : z;                      \
-            v[3][n] = o3 >= 0 ? *reinterpret_cast<const float4 *>(value + o3 + chan + 4 * n) : z;                      \
+            v[0][n] = o0 >= 0 ? ld4(value + o0 + chan + 4 * n) : z;                                                    \
+            v[1][n] = o1 >= 0 ? ld4(value + o1 + chan + 4 * n) : z;                                                    \
+            v[2][n] = o2 >= 0 ? ld4(value + o2 + chan + 4 * n) : z;                                                    \
+            v[3][n] = o3 >= 0 ? ld4(value + o3 + chan + 4 * n) : z;                                                    \
         }                                                                                                              \
         if (!BWD) {                                                                                                    \
             fwd_accumulate(quad_bcast_f<I>(w1), quad_bcast_f<I>(w2), quad_bcast_f<I>(w3), quad_bcast_f<I>(w4), v[0][0], \
@@ -668,10 +668,12 @@ __device__ __forceinline__ void gather_level(
 // Forward (BWD = false): workgroup = (image, head, region, channel half); accumulates over the LDS phases in registers.
 // Backward (BWD = true): workgroup = (image, head, region, LDS phase); runs the two channel halves one after the other
 // (the per-point gradients are sums over all 32 channels).
-template <bool BWD, bool P4, int GC, int CPL>
+// TV = storage type of value / grad_out / out (float, or bf16_t: converted at the loads / the store; the LDS windows and
+// all arithmetic are fp32 either way)
+template <bool BWD, bool P4, int GC, int CPL, typename TV = float>
 __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled_gather_kernel(
-    const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ aw,
-    const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
+    const TV *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ aw,
+    const TV *__restrict__ grad_out, TV *__restrict__ out, float *__restrict__ grad_loc,
     float *__restrict__ grad_aw, const TiledGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -738,8 +740,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
         for (int k = 0; k < kGatherQPG; ++k)
 #pragma unroll
             for (int n = 0; n < NV; ++n)
-                gq[k][n] = BWD ? *reinterpret_cast<const float4 *>(grad_out + item[k] * (unsigned)kTD + chan + 4 * n)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                gq[k][n] = BWD ? ld4(grad_out + item[k] * (unsigned)kTD + chan + 4 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int ph = ph_begin; ph < ph_end; ++ph) {
             // levels of this phase are consecutive: [lb, le)
             int lb = g.L, le = 0;
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
             for (int l = lb; l < le; ++l) {
                 const int wr0 = uni(hdr->r[l].wr0), wc0 = uni(hdr->r[l].wc0), nwc = uni(hdr->r[l].nwc);
                 const int npx = uni(hdr->r[l].nwr) * nwc, Wl = uni(hdr->W[l]), Hl = uni(hdr->H[l]);
-                const float *src = value + ((int64_t)(b * g.S + uni(hdr->start[l])) * g.M + m) * kTD + half * GC + 4 * fj;
+                const TV *src = value + ((int64_t)(b * g.S + uni(hdr->start[l])) * g.M + m) * kTD + half * GC + 4 * fj;
                 float *dst = win + (int64_t)uni(hdr->lds_px[l]) * GC + 4 * fj;
                 // kFillBatch independent loads in flight per lane before the first LDS store
                 for (int px0 = fgrp; px0 < npx; px0 += kFillBatch * kFillGroups) {
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                         const int row = wr0 + rr, col = wc0 + cc;
                         const bool in_map = row >= 0 && row < Hl && col >= 0 && col < Wl;   // else: the zero apron
                         const int rowc = min(max(row, 0), Hl - 1), colc = min(max(col, 0), Wl - 1);
-                        const float4 t = *reinterpret_cast<const float4 *>(src + (int64_t)(rowc * Wl + colc) * row_elems);
+                        const float4 t = ld4(src + (int64_t)(rowc * Wl + colc) * row_elems);
                         v[u] = in_map ? t : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
 #pragma unroll
@@ -793,13 +794,13 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
 #pragma unroll
                 for (int k = 0; k < kGatherQPG; ++k) pt0[k] = item[k] * (unsigned)LP + (unsigned)(l * g.P);
                 if (!BWD || kHalves == 1)
-                    gather_level<BWD, P4, 0, GC, CPL>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
+                    gather_level<BWD, P4, 0, GC, CPL, TV>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
                                                  acc_hi, gq, part, grad_loc, grad_aw, n_general);
                 else if (half == 0)
-                    gather_level<BWD, P4, 1, GC, CPL>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
+                    gather_level<BWD, P4, 1, GC, CPL, TV>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
                                                  acc_hi, gq, part, grad_loc, grad_aw, n_general);
                 else
-                    gather_level<BWD, P4, 2, GC, CPL>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
+                    gather_level<BWD, P4, 2, GC, CPL, TV>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
                                                  acc_hi, gq, part, grad_loc, grad_aw, n_general);
             }
             __syncthreads();   // the next fill overwrites the windows
@@ -812,8 +813,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
 #pragma unroll
         for (int k = 0; k < kGatherQPG; ++k)
             if (live[k])
-                *reinterpret_cast<float4 *>(out + item[k] * (unsigned)kTD + chan) =
-                    make_float4(acc_lo[k].x, acc_lo[k].y, acc_hi[k].x, acc_hi[k].y);
+                st4(out + item[k] * (unsigned)kTD + chan, make_float4(acc_lo[k].x, acc_lo[k].y, acc_hi[k].x, acc_hi[k].y));
     }
     __syncthreads();   // the next item rebuilds the header
     }
@@ -1251,8 +1251,10 @@ struct SortLds {   // after the TileHeader
 static_assert(sizeof(TileHeader) + sizeof(SortLds) <= 160 * 1024, "sorted scatter: LDS budget");
 static_assert(kSortMaxPts <= 65536, "genlist holds 16-bit point indices");
 
+// TV = storage type of grad_out.  grad_value is always accumulated in fp32 (bf16 mode: an fp32 scratch buffer, rounded once).
+template <typename TV = float>
 __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_sorted_kernel(
-    const float *__restrict__ loc, const float *__restrict__ aw, const float *__restrict__ grad_out,
+    const float *__restrict__ loc, const float *__restrict__ aw, const TV *__restrict__ grad_out,
     float *__restrict__ grad_value, const TiledGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1293,8 +1295,7 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_sorted_kernel(
         // ---- A: grad_out rows -> LDS ------------------------------------------------------------------------------
         for (int i = tid >> 3; i < nq; i += kTiledThreads / 8) {
             const unsigned item = (unsigned)((b * g.Lq + hdr->qid[i]) * g.M + m);
-            *reinterpret_cast<float4 *>(S->gcache + i * kTD + 4 * (tid & 7)) =
-                *reinterpret_cast<const float4 *>(grad_out + item * (unsigned)kTD + 4u * (tid & 7));
+            *reinterpret_cast<float4 *>(S->gcache + i * kTD + 4 * (tid & 7)) = ld4(grad_out + item * (unsigned)kTD + 4u * (tid & 7));
         }
         for (int lv = 0; lv < g.L; ++lv) {
         const int H = uni(hdr->H[lv]), W = uni(hdr->W[lv]), nwc = uni(hdr->r[lv].nwc), nwr = uni(hdr->r[lv].nwr);
@@ -1610,6 +1611,24 @@ inline hipError_t set_lds_limit(const void *fn, size_t bytes)
     return e;
 }
 
+// TV = float or bf16_t (storage of value / out / grad_out); loc / attn and their gradients are fp32
+template <typename TV>
+inline hipError_t launch_fwd_tiled_tv(const TV *value, const float *loc, const float *aw, TV *out, int N, int S, int M, int D,
+                                      int L, int Lq, int P, const int64_t *shapes_h, const int64_t *lsi_h,
+                                      unsigned *general_points, hipStream_t stream)
+{
+    TiledPlan pl = plan_gather(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
+    if (!pl.ok) return hipErrorInvalidValue;
+    if (general_points) pl.g.stats = general_points;   // locality monitor (msda_api.hip); else the diagnostic override
+    auto kern = P == 4 ? &tiled_gather_kernel<false, true, kFwdGC, 4, TV> : &tiled_gather_kernel<false, false, kFwdGC, 4, TV>;
+    hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pl.lds_bytes);
+    if (e != hipSuccess) return e;
+    const int grid = persistent_grid(pl.grid * (kTD / kFwdGC), tiled_options().persist, kTD / kFwdGC);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdGC == 16 ? 512 : 1024), pl.lds_bytes, stream, value, loc, aw,
+                       (const TV *)nullptr, out, (float *)nullptr, (float *)nullptr, pl.g);
+    return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_fwd_tiled(const T *, const int64_t *, const int64_t *, const T *, const T *, T *, int, int, int, int,
                             int, int, int, const int64_t *, const int64_t *, unsigned *, hipStream_t)
@@ -1622,15 +1641,35 @@ inline hipError_t launch_fwd_tiled<float>(const float *value, const int64_t *, c
                                           const int64_t *shapes_h, const int64_t *lsi_h, unsigned *general_points,
                                           hipStream_t stream)
 {
-    TiledPlan pl = plan_gather(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
-    if (!pl.ok) return hipErrorInvalidValue;
-    if (general_points) pl.g.stats = general_points;   // locality monitor (msda_api.hip); else the diagnostic override
-    auto kern = P == 4 ? &tiled_gather_kernel<false, true, kFwdGC, 4> : &tiled_gather_kernel<false, false, kFwdGC, 4>;
-    hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pl.lds_bytes);
+    return launch_fwd_tiled_tv<float>(value, loc, aw, out, N, S, M, D, L, Lq, P, shapes_h, lsi_h, general_points, stream);
+}
+
+// grad_value_f32: where grad_value is accumulated (pre-zeroed by the caller): the output itself for fp32, an fp32 scratch
+// buffer for bf16 storage.  The f64-window and integer-window scatter variants exist for fp32 storage only.
+template <typename TV>
+inline hipError_t launch_bwd_tiled_tv(const TV *value, const float *loc, const float *aw, const TV *grad_out,
+                                      float *grad_value_f32, float *grad_loc, float *grad_aw, int N, int S, int M, int D,
+                                      int L, int Lq, int P, const int64_t *shapes_h, const int64_t *lsi_h, hipStream_t stream);
+
+template <>
+inline hipError_t launch_bwd_tiled_tv<bf16_t>(const bf16_t *value, const float *loc, const float *aw, const bf16_t *grad_out,
+                                              float *grad_value_f32, float *grad_loc, float *grad_aw, int N, int S, int M,
+                                              int D, int L, int Lq, int P, const int64_t *shapes_h, const int64_t *lsi_h,
+                                              hipStream_t stream)
+{
+    const TiledPlan pg = plan_bwd_gather(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
+    const TiledPlan pso = plan_scatter_sorted(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
+    if (!pg.ok || !pso.ok || pg.max_px == kFwdGC) return hipErrorNotSupported;
+    auto kern = P == 4 ? &tiled_gather_kernel<true, true, kBwdGC, kBwdCPL, bf16_t> : &tiled_gather_kernel<true, false, kBwdGC, kBwdCPL, bf16_t>;
+    hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pg.lds_bytes);
+    if (e == hipSuccess) e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_sorted_kernel<bf16_t>), pso.lds_bytes);
     if (e != hipSuccess) return e;
-    const int grid = persistent_grid(pl.grid * (kTD / kFwdGC), tiled_options().persist, kTD / kFwdGC);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdGC == 16 ? 512 : 1024), pl.lds_bytes, stream, value, loc, aw,
-                       (const float *)nullptr, out, (float *)nullptr, (float *)nullptr, pl.g);
+    const int sgrid = persistent_grid(pso.grid, tiled_options().persist / 2, 1);
+    hipLaunchKernelGGL(tiled_scatter_sorted_kernel<bf16_t>, dim3(sgrid), dim3(kTiledThreads), pso.lds_bytes, stream, loc, aw,
+                       grad_out, grad_value_f32, pso.g);
+    const int ggrid = persistent_grid(pg.grid * pg.g.nphases, tiled_options().persist / 2, pg.g.nphases);
+    hipLaunchKernelGGL(kern, dim3(ggrid), dim3(1024), pg.lds_bytes, stream, value, loc, aw, grad_out, (bf16_t *)nullptr,
+                       grad_loc, grad_aw, pg.g);
     return hipGetLastError();
 }
 
@@ -1660,10 +1699,10 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
     const TiledPlan pb = plan_scatter_bfp(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
     const TiledPlan pso = plan_scatter_sorted(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
     if (tiled_options().accum == 2 && pso.ok) {
-        e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_sorted_kernel), pso.lds_bytes);
+        e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_sorted_kernel<float>), pso.lds_bytes);
         if (e != hipSuccess) return e;
         const int sgrid = persistent_grid(pso.grid, tiled_options().persist / 2, 1);
-        hipLaunchKernelGGL(tiled_scatter_sorted_kernel, dim3(sgrid), dim3(kTiledThreads), pso.lds_bytes, stream, loc, aw,
+        hipLaunchKernelGGL(tiled_scatter_sorted_kernel<float>, dim3(sgrid), dim3(kTiledThreads), pso.lds_bytes, stream, loc, aw,
                            grad_out, grad_value, pso.g);
     } else if (tiled_options().accum == 1 && pb.ok) {
         auto skern = P == 4 ? &tiled_scatter_bfp_kernel<true> : &tiled_scatter_bfp_kernel<false>;
