@@ -18,6 +18,7 @@
 #include "msda_direct.h"
 #include "msda_levelsum.h"
 #include "msda_psb.h"
+#include "msda_rps.h"
 #include "msda_tiled.h"
 
 namespace {
@@ -352,6 +353,10 @@ struct PsbWorkspace {
     size_t far_cap = 0;
     float *gv32 = nullptr;   // bf16 backward: fp32 accumulation buffer for grad_value (rounded to bf16 once)
     size_t gv32_cap = 0;
+    unsigned *rps_bins = nullptr;            // routed backward: queue heads (16) + bin_count + bin_start (+1) + bin_fill
+    size_t rps_bins_cap = 0;
+    unsigned long long *rps_entries = nullptr;   // [cap] entry codes, then [cap] float4 parameters
+    size_t rps_entries_cap = 0;
 };
 std::mutex g_psb_mu;
 std::map<std::pair<int, hipStream_t>, PsbWorkspace> g_psb_ws;
@@ -431,6 +436,85 @@ hipError_t launch_bwd_psb(const Problem &pb, const float *value, const float *lo
         hipLaunchKernelGGL(msda::psb_far_kernel, dim3(512), dim3(256), 0, stream, value, loc, aw, grad_out, grad_value,
                            grad_loc, grad_aw, pl.g);
     return hipGetLastError();
+}
+
+// ---- routed pixel-stationary backward (msda_rps.h) ---------------------------------------------------------------------------
+bool rps_workspace(hipStream_t stream, size_t n_bins, size_t n_entries, PsbWorkspace &out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_psb_mu);
+    PsbWorkspace &ws = g_psb_ws[std::make_pair(dev, stream)];
+    const size_t want_bins = 32 + (2 * msda::kRpsPad + 1) * n_bins + 8;
+    if (ws.rps_bins_cap < want_bins || ws.rps_entries_cap < n_entries) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &cap);
+        if (cap != hipStreamCaptureStatusNone) return false;   // no allocation while the stream is being captured
+        if (ws.rps_bins_cap < want_bins) {
+            if (ws.rps_bins) (void)hipFree(ws.rps_bins);
+            ws.rps_bins = nullptr;
+            ws.rps_bins_cap = 0;
+            if (hipMalloc(reinterpret_cast<void **>(&ws.rps_bins), want_bins * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            ws.rps_bins_cap = want_bins;
+        }
+        if (ws.rps_entries_cap < n_entries) {
+            if (ws.rps_entries) (void)hipFree(ws.rps_entries);
+            ws.rps_entries = nullptr;
+            ws.rps_entries_cap = 0;
+            if (hipMalloc(reinterpret_cast<void **>(&ws.rps_entries), n_entries * (sizeof(unsigned long long) + sizeof(float4))) != hipSuccess) { (void)hipGetLastError(); return false; }
+            ws.rps_entries_cap = n_entries;
+        }
+    }
+    out = ws;
+    return true;
+}
+
+// returns hipErrorNotSupported when the plan does not apply or no workspace can be had right now
+hipError_t launch_bwd_rps(const Problem &pb, const float *value, const float *loc, const float *aw, const float *grad_out,
+                          float *grad_value, float *grad_loc, float *grad_aw, hipStream_t stream)
+{
+    msda::RpsPlan pl = msda::plan_rps(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(), pb.lsi.data());
+    if (!pl.ok) return hipErrorNotSupported;
+    if ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_value)) & 15)
+        return hipErrorNotSupported;
+    if ((reinterpret_cast<uintptr_t>(grad_loc) | reinterpret_cast<uintptr_t>(loc)) & 7) return hipErrorNotSupported;
+    PsbWorkspace ws;
+    if (!rps_workspace(stream, (size_t)pl.g.nbins, pl.max_entries, ws)) return hipErrorNotSupported;
+    pl.g.ctr = ws.rps_bins;
+    pl.g.bin_count = ws.rps_bins + 32;   // (line-aligned)
+    pl.g.bin_fill = pl.g.bin_count + (size_t)pl.g.nbins * msda::kRpsPad;
+    pl.g.bin_start = pl.g.bin_fill + (size_t)pl.g.nbins * msda::kRpsPad;
+    pl.g.entries = ws.rps_entries;
+    pl.g.params = reinterpret_cast<float4 *>(ws.rps_entries + ws.rps_entries_cap);
+    pl.g.stamps = msda::tiled_options().stamps;
+    pl.g.dbg = msda::tiled_options().dbg;
+    auto kern = pb.P == 4 ? &msda::rps_tile_kernel<true> : &msda::rps_tile_kernel<false>;
+    hipError_t e = msda::set_lds_limit(reinterpret_cast<const void *>(kern), sizeof(msda::RpsLds));
+    if (e != hipSuccess) return e;
+    // route passes: one wave per 16 queries of an (image, head); 4 waves per block
+    const int qpw = pb.P <= 4 ? 16 : (pb.P <= 8 ? 8 : (pb.P <= 16 ? 4 : (pb.P <= 32 ? 2 : 1)));
+    const int64_t r_units = (int64_t)pb.N * pb.M * ((pb.Lq + qpw - 1) / qpw);
+    const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>((r_units + 3) / 4, 8 * (int64_t)cu_count()));
+    hipLaunchKernelGGL(msda::rps_prep_kernel, dim3(128), dim3(256), 0, stream, grad_value, pl.g);
+    hipLaunchKernelGGL(msda::rps_route_kernel<true>, dim3(rgrid), dim3(256), 0, stream, loc, aw, grad_loc, grad_aw, pl.g);
+    hipLaunchKernelGGL(msda::rps_scan_kernel, dim3(1), dim3(1024), 0, stream, pl.g);
+    hipLaunchKernelGGL(msda::rps_route_kernel<false>, dim3(rgrid), dim3(256), 0, stream, loc, aw, grad_loc, grad_aw, pl.g);
+    const int grid = (cu_count() / msda::kXcds) * msda::kXcds;
+    hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 8), dim3(msda::kRpsThreads), sizeof(msda::RpsLds), stream, value, grad_out,
+                       grad_value, grad_loc, grad_aw, pl.g);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t try_bwd_rps(const Problem &, const T *, const T *, const T *, const T *, T *, T *, T *, hipStream_t)
+{
+    return hipErrorNotSupported;
+}
+template <>
+hipError_t try_bwd_rps<float>(const Problem &pb, const float *value, const float *loc, const float *aw, const float *grad_out,
+                              float *grad_value, float *grad_loc, float *grad_aw, hipStream_t stream)
+{
+    return launch_bwd_rps(pb, value, loc, aw, grad_out, grad_value, grad_loc, grad_aw, stream);
 }
 
 template <typename T>
@@ -534,7 +618,15 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         if (e != hipErrorNotSupported) return hip_fail(e, "launch of the pixel-stationary backward kernels");
         e = hipSuccess;
     }
-    if (variant == 3) variant = 0;
+    if (variant == 4) {   // routed pixel-stationary backward (msda_rps.h)
+        ProfileScope prof(1, 4, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
+        e = try_bwd_rps<T>(pb, value, loc, aw, grad_out, grad_value, grad_loc, grad_aw, stream);
+        if (e == hipSuccess) return MSDA_OK;
+        prof.cancel();
+        if (e != hipErrorNotSupported) return hip_fail(e, "launch of the routed backward kernels");
+        e = hipSuccess;
+    }
+    if (variant == 3 || variant == 4) variant = 0;
     if (variant != 1 && msda::tiled_bwd_applicable<T>(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(),
                                                      pb.lsi.data(), value, grad_out, grad_value)) {
         if (variant == 0)   // automatic: the forward calls of this problem measured how local its sampling points are
@@ -613,10 +705,14 @@ bool bf16_scratch(hipStream_t stream, size_t n_floats, float **out)
     return true;
 }
 
-__global__ __launch_bounds__(256) void round_to_bf16_kernel(const float *__restrict__ src, msda::bf16_t *__restrict__ dst, size_t n4)
+// n4 vectors of four elements (dst 8-byte aligned), then the n - 4*n4 elements of the tail one by one
+__global__ __launch_bounds__(256) void round_to_bf16_kernel(const float *__restrict__ src, msda::bf16_t *__restrict__ dst, size_t n4,
+                                                             size_t n)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
         msda::st4(dst + 4 * i, *reinterpret_cast<const float4 *>(src + 4 * i));
+    for (size_t i = 4 * n4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = msda::to_storage<msda::bf16_t, float>(src[i]);
 }
 
 int pick_channels_bf16(int D, std::initializer_list<const void *> ptrs)
@@ -702,11 +798,9 @@ int backward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const i
     const size_t n_value = (size_t)N * S * M * D;
     hipError_t e = hipSuccess;
     auto finish_from_scratch = [&](float *gv32) {   // one rounding of the fp32 sums
-        if (n_value % 4 == 0 && is_aligned(grad_value, 8)) {
-            hipLaunchKernelGGL(round_to_bf16_kernel, dim3(2048), dim3(256), 0, stream, gv32, grad_value, n_value / 4);
-            return hipGetLastError();
-        }
-        return hipErrorNotSupported;
+        const size_t n4 = is_aligned(grad_value, 8) ? n_value / 4 : 0;
+        hipLaunchKernelGGL(round_to_bf16_kernel, dim3(2048), dim3(256), 0, stream, gv32, grad_value, n4, n_value);
+        return hipGetLastError();
     };
 
     int variant = g_bwd_variant.load();
@@ -772,9 +866,6 @@ int backward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const i
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "launch of the direct backward kernel (bf16)");
     if (!by_levelsum) {
         e = finish_from_scratch(gv32);
-        if (e == hipErrorNotSupported) {   // odd sizes: element-wise tail-safe path
-            return fail(MSDA_ERR_MISALIGNED, "bf16 grad_value needs 8-byte alignment and a multiple of 4 elements");
-        }
         if (e != hipSuccess) return hip_fail(e, "rounding grad_value to bf16");
     }
     return MSDA_OK;
@@ -791,7 +882,9 @@ const char *msda_last_error(void) { return g_err; }
 int msda_set_option(const char *key, int value)
 {
     if (key && !strcmp(key, "fwd_variant") && value >= 0 && value <= 2) { g_fwd_variant = value; return MSDA_OK; }
-    if (key && !strcmp(key, "bwd_variant") && value >= 0 && value <= 3) { g_bwd_variant = value; return MSDA_OK; }
+    if (key && !strcmp(key, "bwd_variant") && value >= 0 && value <= 4) { g_bwd_variant = value; return MSDA_OK; }
+    if (key && !strcmp(key, "rps_tile") && value >= 4 && value <= 20) { msda::rps_options().tile = value; return MSDA_OK; }
+    if (key && !strcmp(key, "rps_max_chunks") && value >= 1 && value <= 4096) { msda::rps_options().max_chunks = value; return MSDA_OK; }
     if (key && !strcmp(key, "psb_margin") && value >= 0 && value <= 64) { msda::psb_options().margin = value; return MSDA_OK; }
     if (key && !strcmp(key, "psb_tile") && value >= 4 && value <= 23) { msda::psb_options().tile = value; return MSDA_OK; }
     if (key && !strcmp(key, "psb_max_chunks") && value >= 1 && value <= 4096) { msda::psb_options().max_chunks = value; return MSDA_OK; }
@@ -823,6 +916,8 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "fwd_variant")) { *value = g_fwd_variant; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_variant")) { *value = g_bwd_variant; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_direct_cpl")) { *value = g_bwd_cpl; return MSDA_OK; }
+    if (key && !strcmp(key, "rps_tile")) { *value = msda::rps_options().tile; return MSDA_OK; }
+    if (key && !strcmp(key, "rps_max_chunks")) { *value = msda::rps_options().max_chunks; return MSDA_OK; }
     if (key && !strcmp(key, "psb_margin")) { *value = msda::psb_options().margin; return MSDA_OK; }
     if (key && !strcmp(key, "psb_tile")) { *value = msda::psb_options().tile; return MSDA_OK; }
     if (key && !strcmp(key, "psb_max_chunks")) { *value = msda::psb_options().max_chunks; return MSDA_OK; }

@@ -1,0 +1,744 @@
+// msda_rps.h -- "routed pixel-stationary" MSDeformAttn backward for gfx950 (fp32 compute, D = 32, L <= 4).
+//
+// The reference's backward (ms_deform_im2col_cuda.cuh:87-159, 301-403) is query-stationary: every bilinear corner of every
+// sampling point is ADDED to grad_value with a global float atomic -- 2.9 GB of atomics per encoder call, ~2.3 ms at the
+// chip's atomic rate.  Here the OUTPUT owns the work: grad_value is cut into tiles of <= 18x19 pixels per (image, head,
+// level), and a tile's workgroup pulls in exactly the sampling points that land on it.
+//
+//   route   (rps_route_kernel, two passes: count, then place at exact offsets)  one lane per sampling point: where does
+//           its corner (h_low, w_low) fall?  The point is appended -- 8 bytes: point index, position in the tile -- to the
+//           bin of that tile, and to the bin of the tile below / right of it when its lower / right corners cross the
+//           tile's edge.  Bins are exact (count -> scan -> place): no capacity guess, no overflow path.
+//   reduce  (rps_tile_kernel)  a workgroup takes a tile: its value rows (+ a one-pixel apron) go to LDS; the bin is
+//           walked in chunks of 2048 points: one lane per point re-derives the bilinear fractions, the points are
+//           sorted by the pixel under their corner (integer LDS atomics: count, scan, place), and eight lanes x four
+//           channels walk each pixel's list:  four partial sums (one per corner) += w * grad_out[q]  and the four
+//           "corner dots" <grad_out[q], value[corner]> that grad_sampling_loc / grad_attn_weight are linear in.
+//           The partial sums stay in registers for the whole tile and are folded (pixel = BR + BL' + TR' + TL') once.
+//
+// grad_value is written with plain stores, once per pixel -- no float atomics, no zero-fill, fp32 sums as in the
+// reference -- and value is read once.  Nothing depends on WHERE the points fall: uniform-random locations cost the same
+// as local ones, so there is no margin, no "far" path and no locality monitor on this side.
+// Coarse levels whose tile is the whole map split their bin into slabs over several workgroups; those add their rows to
+// the (pre-zeroed) level with 128-B row atomics -- a few MB per call.
+#pragma once
+
+#include <algorithm>
+#include <atomic>
+#include <vector>
+
+#include "msda_common.h"
+
+namespace msda {
+
+constexpr int kRpsThreads = 1024;
+constexpr int kRpsMaxPx = kRpsThreads / 4;      // tile + one row / column: one quad (4 lanes x 8 channels) per base pixel
+constexpr int kRpsChunk = 2 * kRpsThreads;      // sampling points per chunk
+constexpr int kRpsMaxL = 4;
+constexpr int kRpsMaxUnits = 448;
+constexpr int kRpsD = 32;
+constexpr int kRpsPad = 32;                     // atomically updated counters sit on lines of their own
+
+struct RpsLevel {
+    int H, W, start;
+    int TH, TW, nty, ntx;   // tile grid: tile (ty, tx) = rows [ty*TH, min(H, ty*TH + TH)) x cols [tx*TW, ...)
+    int bin0;               // first bin of this level inside a pair's bins; bin = bin0 + (ty*ntx + tx)*nslab + slab
+    int nslab;              // bins ("slabs") per tile: the points of a dense tile are dealt over several bins by query block,
+                            // each reduced by its own workgroup (and no single bin counter is hammered by every wave)
+    int atomic;             // 1: nslab > 1 -> rows are added to pre-zeroed grad_value with atomics
+    float inv_TH, inv_TW;   // tile of pixel row r: (int)((r + 0.5f) * inv_TH) -- exact for r < 2^15 (no integer division per point)
+};
+
+struct RpsGeom {
+    int N, S, M, Lq, L, P;
+    int nunits, ppx;        // work table; pairs per XCD queue = ceil(N*M / 8)
+    int bins_per_pair, nbins;
+    RpsLevel lv[kRpsMaxL];
+    unsigned units[kRpsMaxUnits];   // level | ty << 2 | tx << 8 | slab << 14 | nslab << 22, heaviest first
+    unsigned *ctr;          // workspace: [0..7] per-XCD queue heads
+    unsigned *bin_count;    // [nbins * kRpsPad]  points per bin (count pass); one counter per 128-B line
+    unsigned *bin_start;    // [nbins + 1]        exclusive prefix
+    unsigned *bin_fill;     // [nbins * kRpsPad]  place-pass cursors
+    unsigned long long *entries;    // point index | base-grid index << 32 | corners inside the map << 56 | owner << 63
+    float4 *params;                 // per entry: bilinear fractions (lh, lw), attention weight -- written by the route pass so
+                                    // that the tile kernel streams them instead of gathering 8 + 4 bytes per point
+    unsigned long long *stamps;     // diagnostic runs only (msda_debug_stamps)
+    int dbg;                        // diagnostic ablations (wrong results): 1 = no grad_out loads, 2 = no corner dots
+};
+
+struct alignas(16) RpsEnt {   // one sampling point in the list of its base pixel; overwritten by its four corner dots
+    int item;                 // (b*Lq + q)*M + m: row of grad_out
+    float lh, lw, a;          // bilinear fractions, attention weight
+};
+
+struct RpsLds {
+    int item_slot[2];                   // work-queue draws (current / next), double-buffered
+    int wave_tot[16];
+    int pad[2];
+    unsigned long long stamp_last, stamp_acc[14];
+    int offs[kRpsMaxPx + 4];            // histogram, then exclusive prefix
+    int len_hist[64];                   // lists per length class (single-chunk tiles hand their lists out sorted by length)
+    unsigned short order[kRpsMaxPx];    // quad -> base pixel whose list it walks
+    RpsEnt ent[kRpsChunk];              // sorted points of the chunk; plane of the final fold
+    float vtile[kRpsMaxPx * kRpsD];     // value rows of the tile + apron; plane of the final fold
+    float stage2[kRpsMaxPx * kRpsD], stage3[kRpsMaxPx * kRpsD];   // two more planes of the final fold
+};
+static_assert(sizeof(RpsLds) <= 160 * 1024, "rps: LDS budget");
+
+__device__ __forceinline__ float rps_group8_sum(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    return v;
+}
+
+__device__ __forceinline__ int rps_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+#define RPS_STAMP(i)                                                                   \
+    if (g.stamps && threadIdx.x == 0) {                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                  \
+        S->stamp_acc[i] += now_ - S->stamp_last;                                       \
+        S->stamp_last = now_;                                                          \
+    }
+
+// The one place where a sampling position is turned into pixel coordinates: route and reduce must agree bit for bit.
+struct RpsPos {
+    float h_im, w_im;
+    int h_low, w_low;
+    bool valid;
+};
+__device__ __forceinline__ RpsPos rps_position(float x, float y, int H, int W)
+{
+    RpsPos p;
+    p.h_im = y * (float)H - 0.5f;
+    p.w_im = x * (float)W - 0.5f;
+    p.valid = p.h_im > -1.f && p.w_im > -1.f && p.h_im < (float)H && p.w_im < (float)W;
+    p.h_low = (int)floorf(p.h_im);
+    p.w_low = (int)floorf(p.w_im);
+    return p;
+}
+
+// Zero the work-queue heads, the bin counters / cursors and the grad_value ranges of the levels flushed with atomics.
+__global__ __launch_bounds__(256) void rps_prep_kernel(float *__restrict__ grad_value, const RpsGeom g)
+{
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    if (gtid < 16) g.ctr[gtid] = 0u;
+    for (int i = gtid; i < g.nbins; i += gsz) { g.bin_count[i * kRpsPad] = 0u; g.bin_fill[i * kRpsPad] = 0u; }
+    const int row4 = g.M * kRpsD / 4;   // float4 per pixel
+    for (int l = 0; l < g.L; ++l) {
+        if (!g.lv[l].atomic) continue;
+        const int n4 = g.lv[l].H * g.lv[l].W * row4;
+        for (int b = 0; b < g.N; ++b) {
+            float4 *dst = reinterpret_cast<float4 *>(grad_value) + (size_t)(b * g.S + g.lv[l].start) * row4;
+            for (int i = gtid; i < n4; i += gsz) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+// Route pass.  COUNT = true: bin_count[bin] += points; dropped samples get their (zero) gradients here.
+// COUNT = false: the same points are written to entries[bin_start[bin] + cursor++].
+// A wave takes 16 consecutive queries of one (image, head): lane = (query, point), levels one after the other -- so all 64
+// lanes of an instruction go to the bins of ONE (image, head, level), typically one or two tiles: lanes that share a bin
+// are matched with ballots and one atomic per (wave, bin) is issued; the returning atomics of a level are all in flight
+// before the first result is used.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void rps_route_kernel(const float *__restrict__ loc, const float *__restrict__ aw,
+                                                        float *__restrict__ grad_loc, float *__restrict__ grad_aw, const RpsGeom g)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int P = g.P, LP = g.L * g.P;
+    const int qpw = P <= 4 ? 16 : (P <= 8 ? 8 : (P <= 16 ? 4 : (P <= 32 ? 2 : 1)));   // queries per wave: qpw * P <= 64 lanes
+    const int ql = lane / P, pp = lane - ql * P;
+    const int qblocks = (g.Lq + qpw - 1) / qpw;
+    const int pairs = g.N * g.M;
+    const int n_units = pairs * qblocks;
+    const int wave_id = (blockIdx.x * blockDim.x + threadIdx.x) / kWave, n_waves = gridDim.x * blockDim.x / kWave;
+    for (int unit = wave_id; unit < n_units; unit += n_waves) {   // wave-uniform
+        const int pair = unit % pairs, qb = unit / pairs;          // neighbouring waves: different pairs (different bins)
+        const unsigned rep_seed = (unsigned)qb;
+        const int b = pair / g.M, m = pair - b * g.M;
+        const int q = qb * qpw + ql;
+        const bool live = ql < qpw && pp < P && q < g.Lq;
+        const unsigned pt0 = (unsigned)(((b * g.Lq + (live ? q : 0)) * g.M + m) * LP + pp);
+        // all levels' locations first: one round trip to memory per unit, not one per level
+        float2 xy[kRpsMaxL];
+        float at[kRpsMaxL];
+#pragma unroll
+        for (int l = 0; l < kRpsMaxL; ++l) {
+            xy[l] = live && l < g.L ? *reinterpret_cast<const float2 *>(loc + 2u * (pt0 + (unsigned)(l * P))) : make_float2(-4.f, -4.f);
+            at[l] = !COUNT && live && l < g.L ? aw[pt0 + (unsigned)(l * P)] : 0.f;
+        }
+        // the owner-tile entry of every level is matched first and its (returning) atomic is left in flight; the rare
+        // entries of neighbouring tiles are handled on the spot
+        int bin0[kRpsMaxL], rank0[kRpsMaxL], leader0[kRpsMaxL];
+        unsigned code0[kRpsMaxL], cur0[kRpsMaxL];
+        float2 frac0[kRpsMaxL];
+#pragma unroll
+        for (int l = 0; l < kRpsMaxL; ++l) {
+            bin0[l] = -1;
+            rank0[l] = 0;
+            leader0[l] = lane;
+            code0[l] = cur0[l] = 0;
+            frac0[l] = make_float2(0.f, 0.f);
+            if (l >= g.L) continue;   // uniform
+            const unsigned pt = pt0 + (unsigned)(l * P);
+            int bin[4] = {-1, -1, -1, -1};
+            unsigned code[4] = {0, 0, 0, 0};
+            float2 frac = make_float2(0.f, 0.f);
+            if (live) {
+                const RpsLevel &v = g.lv[l];
+                const RpsPos p = rps_position(xy[l].x, xy[l].y, v.H, v.W);
+                frac = make_float2(p.h_im - (float)p.h_low, p.w_im - (float)p.w_low);
+                if (!p.valid) {
+                    if (COUNT) {   // dropped sample: zero gradients (reference ms_deform_im2col_cuda.cuh:285-291 skips it)
+                        grad_aw[pt] = 0.f;
+                        *reinterpret_cast<float2 *>(grad_loc + 2u * pt) = make_float2(0.f, 0.f);
+                    }
+                } else {
+                    const int br = max(p.h_low, 0), bc = max(p.w_low, 0);
+                    const int ty = (int)(((float)br + 0.5f) * v.inv_TH), tx = (int)(((float)bc + 0.5f) * v.inv_TW);
+                    const int R0 = ty * v.TH, C0 = tx * v.TW;
+                    const int R1 = min(v.H, R0 + v.TH), C1 = min(v.W, C0 + v.TW);
+                    const int gr = p.h_low - R0 + 1, gc = p.w_low - C0 + 1;   // base-grid position in the owner tile
+                    const int ns = v.nslab;
+                    bin[0] = pair * g.bins_per_pair + v.bin0 + (ty * v.ntx + tx) * ns + (int)rps_uni((int)(rep_seed % (unsigned)ns));
+                    const unsigned inmap = (p.h_low >= 0 && p.w_low >= 0 ? 1u : 0u) | (p.h_low >= 0 && p.w_low + 1 < v.W ? 2u : 0u) |
+                                           (p.h_low + 1 < v.H && p.w_low >= 0 ? 4u : 0u) | (p.h_low + 1 < v.H && p.w_low + 1 < v.W ? 8u : 0u);
+                    // owner: this tile also forms the point's gradients (it needs to know which corners lie inside the map)
+                    code[0] = (unsigned)(gr * (C1 - C0 + 1) + gc) | inmap << 24 | 0x80000000u;
+                    // lower / right corners beyond the tile's edge belong to the next tile: there the point sits in row / column 0
+                    const bool down = p.h_low == R1 - 1 && R1 < v.H, right = p.w_low == C1 - 1 && C1 < v.W;
+                    if (down) {
+                        bin[1] = bin[0] + v.ntx * ns;
+                        code[1] = (unsigned)gc;   // row 0 of a tile with the same columns
+                    }
+                    if (right) {
+                        const int gw2 = min(v.W, C1 + v.TW) - C1 + 1;
+                        bin[2] = bin[0] + ns;
+                        code[2] = (unsigned)(gr * gw2);
+                    }
+                    if (down && right) {
+                        bin[3] = bin[0] + (v.ntx + 1) * ns;
+                        code[3] = 0u;
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                // match lanes by bin: leader lane, rank among the lanes of the same bin, size of the group
+                int leader = lane, rank = 0, n_mine = 0;
+                unsigned long long todo = __ballot(bin[t] >= 0);
+                if (t > 0 && !todo) continue;   // (uniform) no lane feeds this neighbour tile: the usual case
+                while (todo) {
+                    const int ld = __ffsll((long long)todo) - 1;
+                    const int lb = __shfl(bin[t], ld, kWave);
+                    const unsigned long long match = __ballot(bin[t] == lb);
+                    if (bin[t] == lb) {
+                        leader = ld;
+                        rank = __popcll(match & ((1ull << lane) - 1ull));
+                        n_mine = __popcll(match);
+                    }
+                    todo &= ~match;
+                }
+                const bool lead = bin[t] >= 0 && leader == lane;   // one atomic per (wave, bin)
+                if (COUNT) {
+                    if (lead) atomicAdd(g.bin_count + bin[t] * kRpsPad, (unsigned)n_mine);
+                } else if (t == 0) {
+                    if (lead) cur0[l] = atomicAdd(g.bin_fill + bin[t] * kRpsPad, (unsigned)n_mine);   // left in flight
+                    bin0[l] = bin[t];
+                    code0[l] = code[t];
+                    rank0[l] = rank;
+                    leader0[l] = leader;
+                    frac0[l] = frac;
+                } else {
+                    unsigned cur = 0;
+                    if (lead) cur = atomicAdd(g.bin_fill + bin[t] * kRpsPad, (unsigned)n_mine);
+                    cur = (unsigned)__shfl((int)cur, leader, kWave);
+                    if (bin[t] >= 0) {
+                        const unsigned slot = g.bin_start[bin[t]] + cur + (unsigned)rank;
+                        g.entries[slot] = (unsigned long long)pt | ((unsigned long long)code[t] << 32);
+                        g.params[slot] = make_float4(frac.x, frac.y, at[l], 0.f);
+                    }
+                }
+            }
+        }
+        if (!COUNT) {
+#pragma unroll
+            for (int l = 0; l < kRpsMaxL; ++l) {
+                const unsigned c = (unsigned)__shfl((int)cur0[l], leader0[l], kWave);
+                if (bin0[l] >= 0) {
+                    const unsigned slot = g.bin_start[bin0[l]] + c + (unsigned)rank0[l];
+                    g.entries[slot] = (unsigned long long)(pt0 + (unsigned)(l * P)) | ((unsigned long long)code0[l] << 32);
+                    g.params[slot] = make_float4(frac0[l].x, frac0[l].y, at[l], 0.f);
+                }
+            }
+        }
+    }
+}
+
+// Exclusive prefix of the bin counts (one workgroup; a few thousand bins).
+__global__ __launch_bounds__(1024) void rps_scan_kernel(const RpsGeom g)
+{
+    __shared__ unsigned part[1024];
+    const int tid = threadIdx.x;
+    const int per = (g.nbins + 1023) / 1024;
+    const int i0 = tid * per, i1 = min(g.nbins, i0 + per);
+    unsigned s = 0;
+    for (int i = i0; i < i1; ++i) s += g.bin_count[i * kRpsPad];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned t = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    unsigned run = part[tid] - s;
+    for (int i = i0; i < i1; ++i) {
+        g.bin_start[i] = run;
+        run += g.bin_count[i * kRpsPad];
+    }
+    if (tid == 1023) g.bin_start[g.nbins] = part[1023];
+}
+
+typedef float rps_v2f __attribute__((ext_vector_type(2)));
+
+// Lane j of a quad ends up with the quad's sum of d[j] (j = 0..3): two exchange steps in which every lane keeps the half
+// of the values it is responsible for and hands the other half to its partner (9 instructions instead of 4 x 2 + selects).
+__device__ __forceinline__ float rps_quad_transpose_sum(float d0, float d1, float d2, float d3, int j4)
+{
+    const bool b0 = j4 & 1, b1 = j4 & 2;
+    const float keep_a = b0 ? d1 : d0, keep_b = b0 ? d3 : d2, send_a = b0 ? d0 : d1, send_b = b0 ? d2 : d3;
+    const float ra = keep_a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send_a), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+    const float rb = keep_b + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send_b), 0xB1, 0xF, 0xF, true));
+    const float keep = b1 ? rb : ra, send = b1 ? ra : rb;
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xF, 0xF, true));                  // lane ^ 2
+}
+
+// Work decomposition: a QUAD (4 lanes x 8 channels) walks the list of one base pixel of the tile: four partial sums
+// (32 registers per lane) and -- while the list is walked -- the value rows of the pixel's four corners.  Packed fp32
+// arithmetic (v_pk_fma_f32) throughout: the kernel is bound by vector instruction issue (measured: VALU busy ~60 %,
+// one quad-cycle per instruction), so every FMA carries two channels and the per-point overhead (weights, the dot
+// reduction, the entry read) is shared by 8 channels per lane instead of 4.
+// Lists of one wave are walked in lockstep, so a tile whose bin fits ONE chunk (the fine levels) hands its lists out
+// sorted by length -- the 16 lists of a wave are then equally long -- and a tile with several chunks (coarse levels, long
+// lists) keeps list p on quad p and its partial sums in registers across the chunks.
+// The next work item is drawn from the queue, and the first chunk of its bin fetched, while the current one is reduced.
+template <bool P4>
+__global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
+    const float *__restrict__ value, const float *__restrict__ grad_out, float *__restrict__ grad_value,
+    float *__restrict__ grad_loc, float *__restrict__ grad_aw, const RpsGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    RpsLds *S = reinterpret_cast<RpsLds *>(smem);
+
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int j4 = tid & 3, quad = tid >> 2;
+    const int P = P4 ? 4 : g.P;
+    const int LP = g.L * P;
+    const int row_elems = g.M * kRpsD;
+    const int pairs = g.N * g.M;
+    const int xq = blockIdx.x & (kXcds - 1);   // blocks equal mod 8 share an XCD (observed; speed only)
+    const int n_items = g.nunits * g.ppx;
+    const int imask = (g.dbg & 1) ? 1023 : -1;   // diagnostic: every grad_out row from a 128 KB (cache-resident) range
+    if (g.stamps && tid == 0) {
+        for (int i = 0; i < 14; ++i) S->stamp_acc[i] = 0;
+        S->stamp_last = __builtin_amdgcn_s_memtime();
+    }
+    // bin of a work item: first entry and number of entries (0 for ids past the table or pairs past the batch)
+    auto bin_range = [&](int id, unsigned &first, int &n) {
+        first = 0;
+        n = 0;
+        if (id < n_items) {
+            const unsigned unit = g.units[id / g.ppx];
+            const int pair = xq + kXcds * (id % g.ppx);
+            if (pair < pairs) {
+                const int l = unit & 3, ty = (unit >> 2) & 63, tx = (unit >> 8) & 63, slab = (unit >> 14) & 255, nslab = (unit >> 22) & 255;
+                const int bin = pair * g.bins_per_pair + g.lv[l].bin0 + (ty * g.lv[l].ntx + tx) * nslab + slab;
+                first = g.bin_start[bin];
+                n = (int)(g.bin_start[bin + 1] - first);
+            }
+        }
+    };
+    unsigned long long n_code[2];
+    float4 n_par[2];
+    auto fetch_codes = [&](unsigned first, int n, int ch) {   // both streams are contiguous: 8 + 16 bytes per point
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = ch * kRpsChunk + u * kRpsThreads + tid;
+            const bool ok = k < n;
+            n_code[u] = ok ? g.entries[first + (unsigned)k] : ~0ull;
+            n_par[u] = ok ? g.params[first + (unsigned)k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    if (tid == 0) S->item_slot[0] = (int)atomicAdd(g.ctr + xq, 1u);
+    __syncthreads();
+    int item_id = rps_uni(S->item_slot[0]);
+    unsigned e_first;
+    int n_ent;
+    bin_range(item_id, e_first, n_ent);
+    fetch_codes(e_first, n_ent, 0);
+    int par = 0;
+
+    while (item_id < n_items) {
+        if (tid == 0) S->item_slot[par ^ 1] = (int)atomicAdd(g.ctr + xq, 1u);   // read after the next barrier
+        const unsigned unit = g.units[item_id / g.ppx];
+        const int pair = min(xq + kXcds * (item_id % g.ppx), pairs - 1);
+        // (diagnostic: dbg bits 4..6 = 1 + level -> only that level's units do any work)
+        const bool live_item = xq + kXcds * (item_id % g.ppx) < pairs && (((g.dbg >> 4) & 7) == 0 || ((g.dbg >> 4) & 7) == (int)(unit & 3) + 1);
+        const int l = unit & 3, ty = (unit >> 2) & 63, tx = (unit >> 8) & 63;
+        const int b = pair / g.M, m = pair - b * g.M;
+        const int H = g.lv[l].H, W = g.lv[l].W;
+        const int R0 = ty * g.lv[l].TH, R1 = min(H, R0 + g.lv[l].TH), C0 = tx * g.lv[l].TW, C1 = min(W, C0 + g.lv[l].TW);
+        // Two grids of the same shape (th+1) x gw:
+        //   base grid   (gr, gc) <-> sampling points whose corner (h_low, w_low) is pixel (R0-1+gr, C0-1+gc): one list each
+        //   pixel grid  (vr, vc) <-> pixel (R0+vr, C0+vc): the tile plus one apron row / column (value rows for the dots)
+        // so the four corners of base p are the pixels p-gw-1, p-gw, p-1, p of the pixel grid.
+        const int gw = C1 - C0 + 1;
+        const int npx = live_item ? (R1 - R0 + 1) * gw : 0;
+        const int n_chunks = live_item ? (n_ent + kRpsChunk - 1) / kRpsChunk : 0;
+        const bool sort_lists = n_chunks == 1 && !(g.dbg & 4);
+        // this quad's pixel in the pixel grid
+        const bool has_px = quad < npx;
+        const int gr = quad / gw, gc = quad - gr * gw;
+        const int prow = R0 + gr, pcol = C0 + gc;
+        const int64_t px_off = ((int64_t)(b * g.S + g.lv[l].start + prow * W + pcol) * g.M + m) * kRpsD + 8 * j4;
+
+        // ---- the tile's value rows (+ apron, zeros beyond the map) -> LDS: 32 B per lane -----------------------------------
+        {
+            float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+            if (has_px && prow < H && pcol < W && n_chunks > 0) {
+                t0 = *reinterpret_cast<const float4 *>(value + px_off);
+                t1 = *reinterpret_cast<const float4 *>(value + px_off + 4);
+            }
+            if (has_px) {
+                *reinterpret_cast<float4 *>(S->vtile + quad * kRpsD + 8 * j4) = t0;
+                *reinterpret_cast<float4 *>(S->vtile + quad * kRpsD + 8 * j4 + 4) = t1;
+            }
+            if (tid < kRpsMaxPx) S->order[tid] = (unsigned short)tid;
+        }
+        // ---- four partial sums of one base pixel (one per corner), 8 channels per lane ---------------------------------------
+        rps_v2f acc[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[k][c] = (rps_v2f){0.f, 0.f};
+        __syncthreads();
+        const int next_id = rps_uni(S->item_slot[par ^ 1]);
+        unsigned next_first;
+        int next_n;
+        bin_range(next_id, next_first, next_n);
+        int my_p = quad;   // the base pixel whose list this quad walks
+        RPS_STAMP(0)
+
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            // ---- (1) this lane's two points of the chunk ---------------------------------------------------------------------
+            for (int i = tid; i <= npx; i += kRpsThreads) S->offs[i] = 0;
+            if (tid < 64) S->len_hist[tid] = 0;
+            int p_pt[2], pbase[2], pos[2];
+            float p_lh[2], p_lw[2], p_a[2];
+            unsigned p_own[2];    // bit 4: this tile forms the point's gradients; bits 0..3: corners inside the map
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                p_pt[u] = -1;
+                pbase[u] = 0;
+                pos[u] = -1;
+                p_lh[u] = n_par[u].x;
+                p_lw[u] = n_par[u].y;
+                p_a[u] = n_par[u].z;
+                p_own[u] = 0;
+                if (n_code[u] != ~0ull) {
+                    p_pt[u] = (int)(unsigned)n_code[u];
+                    pbase[u] = (int)((n_code[u] >> 32) & 0xFFFFFFu);
+                    p_own[u] = ((unsigned)(n_code[u] >> 63) << 4) | ((unsigned)(n_code[u] >> 56) & 15u);
+                }
+            }
+            // in flight until the next chunk -- or the next work item -- starts
+            if (ch + 1 < n_chunks) fetch_codes(e_first, n_ent, ch + 1);
+            else fetch_codes(next_first, next_n, 0);
+            __syncthreads();
+            RPS_STAMP(1)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (p_pt[u] >= 0) pos[u] = atomicAdd(&S->offs[pbase[u]], 1);
+            __syncthreads();
+            RPS_STAMP(2)
+
+            // ---- (2) exclusive scan of the per-list counts (<= 256: one per thread of the first 4 waves) --------------------------
+            int my_len = 0, my_rank = 0;
+            {
+                int c = 0, incl = 0;
+                if (tid < kRpsMaxPx) {
+                    c = tid < npx ? S->offs[tid] : 0;
+                    incl = c;
+#pragma unroll
+                    for (int d = 1; d < kWave; d <<= 1) {
+                        const int t = __shfl_up(incl, d, kWave);
+                        if (lane >= d) incl += t;
+                    }
+                    if (lane == kWave - 1) S->wave_tot[wave] = incl;
+                    // lists sorted by length, longest first (counting sort, 64 length classes)
+                    my_len = 63 - min(c, 63);
+                    if (sort_lists && tid < npx) my_rank = atomicAdd(&S->len_hist[my_len], 1);
+                }
+                __syncthreads();
+                if (tid < kRpsMaxPx) {
+                    int base = 0;
+#pragma unroll
+                    for (int w = 0; w < kRpsMaxPx / kWave; ++w) base += w < wave ? S->wave_tot[w] : 0;
+                    const int excl = base + incl - c;
+                    if (tid <= npx) S->offs[tid] = excl;      // tid == npx: the total (c = 0 there)
+                    if (tid == kRpsMaxPx - 1 && npx == kRpsMaxPx) S->offs[npx] = base + incl;
+                    if (sort_lists) {   // every wave scans the 64 classes itself: no barrier for it
+                        const int h = S->len_hist[lane];
+                        int hs = h;
+#pragma unroll
+                        for (int d = 1; d < kWave; d <<= 1) {
+                            const int t = __shfl_up(hs, d, kWave);
+                            if (lane >= d) hs += t;
+                        }
+                        const int start = __shfl(hs - h, my_len, kWave);
+                        if (tid < npx) S->order[start + my_rank] = (unsigned short)tid;
+                    }
+                }
+            }
+            __syncthreads();
+            RPS_STAMP(3)
+
+            // ---- (3) entries to their sorted slots ----------------------------------------------------------------------------
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (pos[u] >= 0) {
+                    pos[u] += S->offs[pbase[u]];
+                    S->ent[pos[u]] = RpsEnt{(int)((unsigned)p_pt[u] / (unsigned)LP), p_lh[u], p_lw[u], p_a[u]};
+                }
+            __syncthreads();
+            RPS_STAMP(4)
+
+            // ---- (4) every quad walks a list: four partial sums and four corner dots per point; grad_out rows straight from
+            //      global memory, two points in flight per quad -------------------------------------------------------------------
+            if (has_px) {
+                my_p = S->order[quad];
+                int e = S->offs[my_p];
+                const int e1 = S->offs[my_p + 1];
+                if (e < e1) {
+                    // value rows of the four corner pixels (clamped into the grid: a corner above / left of row / column 0 of
+                    // the grid lies outside the map or belongs to a point this tile does not form gradients for)
+                    const int lr = my_p / gw, lc = my_p - lr * gw;
+                    const int r0 = max(lr - 1, 0) * gw, c0 = max(lc - 1, 0);
+                    rps_v2f v[4][4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int vp = (k < 2 ? r0 : lr * gw) + ((k & 1) ? lc : c0);
+                        const float4 a0 = *reinterpret_cast<const float4 *>(S->vtile + vp * kRpsD + 8 * j4);
+                        const float4 a1 = *reinterpret_cast<const float4 *>(S->vtile + vp * kRpsD + 8 * j4 + 4);
+                        v[k][0] = (rps_v2f){a0.x, a0.y}; v[k][1] = (rps_v2f){a0.z, a0.w};
+                        v[k][2] = (rps_v2f){a1.x, a1.y}; v[k][3] = (rps_v2f){a1.z, a1.w};
+                    }
+#define RPS_POINT(EN, GA, GB, E)                                                                                                 \
+    {                                                                                                                            \
+        const float hh = 1.f - EN.lh, hw = 1.f - EN.lw, ha = hh * EN.a, la = EN.lh * EN.a;                                       \
+        const float w[4] = {ha * hw, ha * EN.lw, la * hw, la * EN.lw};                                                           \
+        const rps_v2f gq[4] = {(rps_v2f){GA.x, GA.y}, (rps_v2f){GA.z, GA.w}, (rps_v2f){GB.x, GB.y}, (rps_v2f){GB.z, GB.w}};       \
+        float d[4];                                                                                                              \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                            \
+        {                                                                                                                        \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) acc[k][c] += w[k] * gq[c];                                             \
+            rps_v2f t = gq[0] * v[k][0];                                                                                         \
+            t += gq[1] * v[k][1];                                                                                                \
+            t += gq[2] * v[k][2];                                                                                                \
+            t += gq[3] * v[k][3];                                                                                                \
+            d[k] = t.x + t.y;                                                                                                    \
+        }                                                                                                                        \
+        /* lane k of the quad writes dot k over the entry (all four lanes have read it) */                                       \
+        reinterpret_cast<float *>(S->ent + (E))[j4] = rps_quad_transpose_sum(d[0], d[1], d[2], d[3], j4);                        \
+    }
+                    for (; e + 1 < e1; e += 2) {
+                        const RpsEnt en0 = S->ent[e], en1 = S->ent[e + 1];
+                        const float *q0 = grad_out + (int64_t)(en0.item & imask) * kRpsD + 8 * j4;
+                        const float *q1 = grad_out + (int64_t)(en1.item & imask) * kRpsD + 8 * j4;
+                        const float4 g0a = *reinterpret_cast<const float4 *>(q0), g0b = *reinterpret_cast<const float4 *>(q0 + 4);
+                        const float4 g1a = *reinterpret_cast<const float4 *>(q1), g1b = *reinterpret_cast<const float4 *>(q1 + 4);
+                        RPS_POINT(en0, g0a, g0b, e)
+                        RPS_POINT(en1, g1a, g1b, e + 1)
+                    }
+                    if (e < e1) {
+                        const RpsEnt en0 = S->ent[e];
+                        const float *q0 = grad_out + (int64_t)(en0.item & imask) * kRpsD + 8 * j4;
+                        const float4 g0a = *reinterpret_cast<const float4 *>(q0), g0b = *reinterpret_cast<const float4 *>(q0 + 4);
+                        RPS_POINT(en0, g0a, g0b, e)
+                    }
+#undef RPS_POINT
+                }
+            }
+            __syncthreads();
+            RPS_STAMP(5)
+
+            // ---- (5) the lane that placed a point combines its corner dots into the two gradients -------------------------------------
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (p_pt[u] >= 0 && (p_own[u] & 16u)) {
+                    float4 d = *reinterpret_cast<const float4 *>(S->ent + pos[u]);
+                    if (!(p_own[u] & 1u)) d.x = 0.f;
+                    if (!(p_own[u] & 2u)) d.y = 0.f;
+                    if (!(p_own[u] & 4u)) d.z = 0.f;
+                    if (!(p_own[u] & 8u)) d.w = 0.f;
+                    const float lh = p_lh[u], lw = p_lw[u], hh = 1.f - lh, hw = 1.f - lw, a = p_a[u];
+                    const float s_a = hh * hw * d.x + hh * lw * d.y + lh * hw * d.z + lh * lw * d.w;
+                    const float s_w = hh * (d.y - d.x) + lh * (d.w - d.z);
+                    const float s_h = hw * (d.z - d.x) + lw * (d.w - d.y);
+                    grad_aw[p_pt[u]] = s_a;
+                    *reinterpret_cast<float2 *>(grad_loc + 2u * (unsigned)p_pt[u]) = make_float2((float)W * s_w * a, (float)H * s_h * a);
+                }
+            // (the next chunk clears the histogram now -- its last reader was the list walk -- and rewrites the entries only
+            // after three more barriers)
+            RPS_STAMP(6)
+        }
+        if (n_chunks == 0) fetch_codes(next_first, next_n, 0);
+
+        // ---- fold the partial sums: pixel x of the pixel grid = BR[x] + BL[x+1] + TR[x+gw] + TL[x+gw+1] of the base grid.  The
+        //      four partial sums of list my_p go to four LDS planes (the value rows and the entries are no longer needed) ------------
+        __syncthreads();
+        {
+            float *plane[4] = {S->stage2, reinterpret_cast<float *>(S->ent), S->stage3, S->vtile};   // TL, TR, BL, BR
+            if (has_px) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    *reinterpret_cast<float4 *>(plane[k] + my_p * kRpsD + 8 * j4) = make_float4(acc[k][0].x, acc[k][0].y, acc[k][1].x, acc[k][1].y);
+                    *reinterpret_cast<float4 *>(plane[k] + my_p * kRpsD + 8 * j4 + 4) = make_float4(acc[k][2].x, acc[k][2].y, acc[k][3].x, acc[k][3].y);
+                }
+            }
+            __syncthreads();
+            float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
+            if (has_px) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // BR: same index; BL: x + 1; TR: x + gw; TL: x + gw + 1 -- where those base pixels exist
+                    const int src = quad + (k == 2 || k == 0 ? 1 : 0) + (k < 2 ? gw : 0);
+                    const bool ok = ((k == 1 || k == 3) || gc + 1 < gw) && (k >= 2 || gr + 1 <= R1 - R0);
+                    if (ok) {
+                        const float4 t0 = *reinterpret_cast<const float4 *>(plane[k] + src * kRpsD + 8 * j4);
+                        const float4 t1 = *reinterpret_cast<const float4 *>(plane[k] + src * kRpsD + 8 * j4 + 4);
+                        o0.x += t0.x; o0.y += t0.y; o0.z += t0.z; o0.w += t0.w;
+                        o1.x += t1.x; o1.y += t1.y; o1.z += t1.z; o1.w += t1.w;
+                    }
+                }
+            }
+            // ---- flush the tile: one 128-B row per pixel ------------------------------------------------------------------------
+            const bool in_tile = has_px && prow < R1 && pcol < C1;
+            if (!g.lv[l].atomic) {
+                if (in_tile) {
+                    *reinterpret_cast<float4 *>(grad_value + px_off) = o0;
+                    *reinterpret_cast<float4 *>(grad_value + px_off + 4) = o1;
+                }
+            } else if (n_chunks > 0) {
+                // several workgroups share the tile: hand the rows over through LDS and add them one channel per lane, so that
+                // a wave instruction adds two whole 128-B rows (32-B atomic segments run ~4x slower)
+                __syncthreads();
+                float *stage = S->vtile;
+                if (has_px) {
+                    *reinterpret_cast<float4 *>(stage + quad * kRpsD + 8 * j4) = o0;
+                    *reinterpret_cast<float4 *>(stage + quad * kRpsD + 8 * j4 + 4) = o1;
+                }
+                __syncthreads();
+                const int c32 = tid & 31;
+                const int64_t tile_base = ((int64_t)(b * g.S + g.lv[l].start) * g.M + m) * kRpsD + c32;
+                for (int p = tid >> 5; p < npx; p += kRpsThreads / 32) {
+                    const int pr = p / gw, row = R0 + pr, col = C0 + (p - pr * gw);
+                    const float x = stage[p * kRpsD + c32];
+                    if (row < R1 && col < C1 && x != 0.f) atomicAdd(grad_value + tile_base + (int64_t)(row * W + col) * row_elems, x);
+                }
+            }
+        }
+        __syncthreads();
+        RPS_STAMP(7)
+        item_id = next_id;
+        e_first = next_first;
+        n_ent = next_n;
+        par ^= 1;
+    }
+    if (g.stamps && tid == 0) {
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();
+        S->stamp_acc[8] += now_ - S->stamp_last;   // waiting at the empty queue
+        for (int i = 0; i < 14; ++i) g.stamps[(size_t)blockIdx.x * 16 + i] = S->stamp_acc[i];
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------
+struct RpsOptions {
+    std::atomic<int> tile{16};         // largest tile side + 1 (tile + one row / column <= 256 pixels)
+    std::atomic<int> max_chunks{6};    // expected chunks of one workgroup before a tile is split into slabs
+};
+inline RpsOptions &rps_options()
+{
+    static RpsOptions o;
+    return o;
+}
+
+struct RpsPlan {
+    bool ok = false;
+    RpsGeom g{};
+    size_t max_entries = 0;   // capacity the entry list needs (every point can sit in up to four bins)
+};
+
+inline RpsPlan plan_rps(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
+{
+    RpsPlan pl;
+    if (D != kRpsD || L < 1 || L > kRpsMaxL || P < 1 || P > 64) return pl;
+    int64_t pre = 0;
+    bool tiles_s = true;
+    for (int l = 0; l < L; ++l) {
+        tiles_s = tiles_s && lsi[l] == pre;
+        pre += shapes[2 * l] * shapes[2 * l + 1];
+        if (shapes[2 * l] >= 32768 || shapes[2 * l + 1] >= 32768) return pl;
+    }
+    if (!tiles_s || pre != S) return pl;   // tiles must not overlap in grad_value
+    const int64_t n_pts = (int64_t)N * Lq * M * L * P;
+    if (n_pts >= ((int64_t)1 << 31)) return pl;
+    RpsGeom &g = pl.g;
+    g.N = N; g.S = S; g.M = M; g.Lq = Lq; g.L = L; g.P = P;
+    g.ppx = (N * M + kXcds - 1) / kXcds;
+    const int tmax = std::max(1, rps_options().tile.load() - 1), max_chunks = std::max(1, rps_options().max_chunks.load());
+    struct U { unsigned code; int64_t cost; };
+    std::vector<U> units;
+    int bins = 0;
+    for (int l = 0; l < L; ++l) {
+        RpsLevel &v = g.lv[l];
+        v.H = (int)shapes[2 * l]; v.W = (int)shapes[2 * l + 1]; v.start = (int)lsi[l];
+        for (int t = tmax; t >= 1; --t) {   // balanced tiles of at most t x t pixels whose grid (+1 row / column) fits the lane groups
+            v.nty = (v.H + t - 1) / t; v.ntx = (v.W + t - 1) / t;
+            v.TH = (v.H + v.nty - 1) / v.nty; v.TW = (v.W + v.ntx - 1) / v.ntx;
+            v.nty = (v.H + v.TH - 1) / v.TH; v.ntx = (v.W + v.TW - 1) / v.TW;
+            if ((v.TH + 1) * (v.TW + 1) <= kRpsMaxPx) break;
+        }
+        if ((v.TH + 1) * (v.TW + 1) > kRpsMaxPx || v.nty > 64 || v.ntx > 64) return pl;
+        // slabs per tile, from the points a tile receives if they spread evenly over the level (they need not: a slab just
+        // takes what lands in its bin)
+        const double per_px = (double)Lq * P / ((double)v.H * v.W);
+        const int nchunks = (int)(per_px * v.TH * v.TW * 1.2 / kRpsChunk) + 1;
+        v.nslab = std::min(255, std::max(1, (nchunks + max_chunks - 1) / max_chunks));
+        v.atomic = v.nslab > 1 ? 1 : 0;
+        v.inv_TH = 1.0f / (float)v.TH;
+        v.inv_TW = 1.0f / (float)v.TW;
+        v.bin0 = bins;
+        bins += v.nty * v.ntx * v.nslab;
+        for (int ty = 0; ty < v.nty; ++ty)
+            for (int tx = 0; tx < v.ntx; ++tx)
+                for (int sl = 0; sl < v.nslab; ++sl)
+                    units.push_back(U{(unsigned)l | (unsigned)ty << 2 | (unsigned)tx << 8 | (unsigned)sl << 14 | (unsigned)v.nslab << 22,
+                                      (int64_t)(nchunks + v.nslab - 1) / v.nslab * 16 + 8});
+    }
+    if (units.size() > (size_t)kRpsMaxUnits) return pl;
+    std::stable_sort(units.begin(), units.end(), [](const U &a, const U &b) { return a.cost > b.cost; });
+    g.nunits = (int)units.size();
+    for (int i = 0; i < g.nunits; ++i) g.units[i] = units[i].code;
+    g.bins_per_pair = bins;
+    g.nbins = bins * N * M;
+    pl.max_entries = (size_t)n_pts * 4;
+    pl.ok = true;
+    return pl;
+}
+
+}  // namespace msda

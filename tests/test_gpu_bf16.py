@@ -105,6 +105,7 @@ def test_bf16_shrunk_baseline_calls(which, loc_mode, variant):
     dict(N=1, M=2, D=30, P=3, shapes=[(9, 7), (3, 2)], Lq=40),        # two channels per lane
     dict(N=2, M=3, D=7, P=2, shapes=[(5, 5)], Lq=9),                  # one channel per lane, odd value count: scratch + rounding
     dict(N=1, M=1, D=64, P=4, shapes=[(300, 300), (9, 9)], Lq=64),    # level too large for the LDS windows: fp32 scratch
+    dict(N=1, M=1, D=3, P=2, shapes=[(301, 301)], Lq=50),             # scratch, value count not a multiple of 4
 ])
 def test_bf16_odd_shapes(dims):
     call = W.Call("o", dims["N"], dims["M"], dims["D"], dims["P"], dims["shapes"], dims["Lq"], False)

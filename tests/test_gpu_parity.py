@@ -24,7 +24,9 @@ pytestmark = pytest.mark.gpu
 
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
                if not os.path.basename(p).startswith("module_"))
-VARIANTS = [1, 2, 3]   # 1 = direct kernels, 2 = LDS-window kernels, 3 = pixel-stationary backward (where applicable; else direct)
+# 1 = direct kernels, 2 = LDS-window kernels, 3 = pixel-stationary backward (candidates by geometry), 4 = routed
+# pixel-stationary backward -- each where applicable, else the direct kernels
+VARIANTS = [1, 2, 3, 4]
 
 
 def dev(a):
@@ -264,7 +266,7 @@ def test_full_size_properties(which):
         _lib.set_option("bwd_variant", variant)
         res[variant] = (f(t["value"]),) + tuple(MSDA.ms_deform_attn_backward(
             t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64))
-    for other in (2, 3):
+    for other in (2, 3, 4):
         for a, b in zip(res[1], res[other]):
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-3)
 
@@ -437,7 +439,7 @@ def test_random_problems_against_oracle(seed):
     oo = O.forward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"])
     ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
     tf, tg = tols(np.float32)
-    for variant in (0, 2, 3):
+    for variant in (0, 2, 3, 4):
         out, gv, gl, ga = run_gpu(z, variant)
         assert rel_err(out, oo) < tf, (variant, z["value"].shape, z["loc"].shape)
         assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg, (variant, z["value"].shape)
@@ -504,6 +506,69 @@ def test_pixel_stationary_backward_overwrites_poisoned_outputs():
         N, S, M, D, L, Lq, P = call.N, call.S, call.M, call.D, call.L, call.Lq, call.P
         sh, ls = t["shapes"].cpu().numpy(), t["lsi"].cpu().numpy()
         _lib.set_option("bwd_variant", 3)
+        outs = []
+        for poison in (float("nan"), 321.0):
+            gv = torch.full_like(t["value"], poison)
+            gl = torch.full_like(t["loc"], poison)
+            ga = torch.full_like(t["aw"], poison)
+            _lib.check(lib.msda_backward_f32(t["value"].data_ptr(), t["shapes"].data_ptr(), t["lsi"].data_ptr(),
+                                             t["loc"].data_ptr(), t["aw"].data_ptr(), t["grad_out"].data_ptr(), N, S, M,
+                                             D, L, Lq, P, 64, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(),
+                                             sh.ctypes.data, ls.ctypes.data, torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            outs.append((gv, gl, ga))
+        for a, b in zip(*outs):
+            assert torch.isfinite(a).all()
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
+# ---- routed pixel-stationary backward (msda_rps.h) ------------------------------------------------------------------------
+@pytest.mark.parametrize("opts", [
+    {},                                              # defaults
+    {"rps_tile": 5},                                 # 4 x 4 tiles: nearly every point also feeds a neighbouring tile
+    {"rps_tile": 9, "rps_max_chunks": 1},            # every dense tile split into slabs: atomic flush of pre-zeroed levels
+    {"rps_max_chunks": 1000},                        # no slabs at all: plain stores everywhere
+])
+@pytest.mark.parametrize("which,scale", [("E", 4), ("Em", 4), ("E", 2), ("Dd", 1)])
+def test_routed_backward_options(which, scale, opts):
+    """Tile size and slab split decide who computes what, never the result -- for local, spread and uniform locations."""
+    base = {"E": W.call_E, "Dd": W.call_Dd, "Em": W.call_Em}[which](2)
+    call = W.shrunk(base, scale) if scale > 1 else base
+    defaults = {k: _lib.get_option(k) for k in opts}
+    try:
+        for k, v in opts.items():
+            _lib.set_option(k, v)
+        for loc_mode in ("init", "sigma4", "uniform"):
+            t = W.make_inputs(call, loc_mode, seed=41)
+            t["loc"][0, :7] = t["loc"][0, :7] * 3.0 - 1.0     # some dropped samples and border corners
+            z = {k: v.numpy() for k, v in t.items()}
+            _lib.set_option("bwd_variant", 4)
+            v, sh, ls, loc, aw, go = (dev(z[k]) for k in ("value", "shapes", "lsi", "loc", "aw", "grad_out"))
+            res = {}
+
+            def bwd():
+                res["g"] = MSDA.ms_deform_attn_backward(v, sh, ls, loc, aw, go, 64)
+            ran = _profiled_variants(bwd)
+            if not ("rps_tile" in opts and (which == "Dd" or scale < 4)):   # (large maps in tiny tiles exceed the work table: falls back)
+                assert ran == [("bwd", 4)], "the routed kernels must be the ones that ran"
+            gv, gl, ga = res["g"]
+            ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
+            tf, tg = tols(np.float32)
+            assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg, (loc_mode, opts)
+    finally:
+        for k, v in defaults.items():
+            _lib.set_option(k, v)
+
+
+def test_routed_backward_overwrites_poisoned_outputs():
+    """No zero-fill is needed: every element of the three gradients is written (C ABI, poisoned caller buffers)."""
+    lib = _lib.load()
+    for call in (W.shrunk(W.call_E(2), 4), W.call_Dd(2)):
+        t = {k: v.cuda() for k, v in W.make_inputs(call, "sigma4", seed=9).items()}
+        t["loc"][0, :5] += 3.0                                  # dropped samples: their zero gradients must be written too
+        N, S, M, D, L, Lq, P = call.N, call.S, call.M, call.D, call.L, call.Lq, call.P
+        sh, ls = t["shapes"].cpu().numpy(), t["lsi"].cpu().numpy()
+        _lib.set_option("bwd_variant", 4)
         outs = []
         for poison in (float("nan"), 321.0):
             gv = torch.full_like(t["value"], poison)

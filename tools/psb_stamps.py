@@ -21,10 +21,15 @@ def main():
     ap.add_argument("--call", default="E")
     ap.add_argument("--loc", default="init")
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--variant", type=int, default=4)
     args = ap.parse_args()
     lib = _lib.load()
     _lib.set_option("locality_monitor", 0)
-    _lib.set_option("bwd_variant", 3)
+    _lib.set_option("bwd_variant", args.variant)
+    global NAMES
+    if args.variant == 4:
+        NAMES = ["item header + value rows", "entries + locations", "ranks", "scan", "placement", "reduce + dots", "combine",
+                 "fold + flush", "queue tail", "-"]
     for kv in args.opt:
         k, v = kv.split("=")
         _lib.set_option(k, int(v))

@@ -61,11 +61,11 @@ def main():
             for fv in [int(x) for x in args.fwd.split(",") if x]:
                 _lib.set_option("fwd_variant", fv)
                 us = time_fn(lambda: run("fwd"), args.reps)
-                print(f"{cname:3s} {mode:8s} fwd variant {fv}: {us:8.1f} us  ({call.bytes_fwd() / us / 1e6 / 8000:.3f} of 8 TB/s)", flush=True)
+                print(f"{cname:3s} {mode:8s} fwd variant {fv}: {us:8.1f} us  ({call.bytes_fwd() / (us * 1e-6) / 8e12:.3f} of 8 TB/s)", flush=True)
             for bv in [int(x) for x in args.bwd.split(",") if x]:
                 _lib.set_option("bwd_variant", bv)
                 us = time_fn(lambda: run("bwd"), args.reps)
-                print(f"{cname:3s} {mode:8s} bwd variant {bv}: {us:8.1f} us  ({call.bytes_bwd() / us / 1e6 / 8000:.3f} of 8 TB/s)", flush=True)
+                print(f"{cname:3s} {mode:8s} bwd variant {bv}: {us:8.1f} us  ({call.bytes_bwd() / (us * 1e-6) / 8e12:.3f} of 8 TB/s)", flush=True)
 
 
 if __name__ == "__main__":
