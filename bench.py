@@ -56,8 +56,9 @@ HIP_KERNELS = {
     ("fwd", 2): "tiled_gather_kernel<false",
     ("bwd", 2): "tiled_scatter_sorted_kernel + tiled_gather_kernel<true",
     ("bwd", 3): "psb_kernel + psb_far_kernel",
+    ("bwd", 4): "rps_route_kernel<true> + rps_route_kernel<false> + rps_tile_kernel",
 }
-VARIANT_NAMES = {1: "direct", 2: "tiled", 3: "psb"}
+VARIANT_NAMES = {1: "direct", 2: "tiled", 3: "psb", 4: "routed"}
 
 
 def parse_args(argv=None):

@@ -92,6 +92,9 @@ struct ProfileScope {
 // asynchronous copy + event on the caller's stream, and reads it on a LATER call once the event has completed -- no
 // call ever waits.  Nothing is probed while the stream is being captured into a graph.
 constexpr float kFwdShareMax = 0.02f, kBwdShareMax = 0.23f;
+// Backward: above this share of window misses the routed kernels (msda_rps.h), whose cost does not depend on where the points
+// fall, beat the window kernels (MI355X, call E: window 383 / 497 / 2190 us at sigma 1 px / 4 px / uniform, routed 431 / 450 / 702)
+constexpr float kBwdRoutedShare = 0.03f;
 constexpr unsigned kProbeWarmCalls = 8, kProbeEvery = 64;
 constexpr int kMaxDevices = 64;
 std::atomic<int> g_monitor_on{1};
@@ -113,14 +116,20 @@ struct Monitor {
 };
 Monitor g_monitors[kMaxDevices];
 
-uint64_t problem_key(const int N, const int S, const int M, const int L, const int P, const int64_t *shapes)
+// What a verdict is keyed by: the problem's shape AND the sampling_loc buffer.  How far the offsets reach is a property of a
+// LAYER's weights; the layers of a network call with the same shapes but each with its own sampling_loc tensor, which a
+// steady-state training step finds at the same address every time (caching allocator) -- and the backward call of a layer
+// is handed the very tensor its forward call saw.  A pointer never seen before simply starts a new entry.
+uint64_t problem_key(const int N, const int S, const int M, const int L, const int P, const int64_t *shapes, const void *loc = nullptr)
 {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
     mix(N); mix(S); mix(M); mix(L); mix(P);
     for (int l = 0; l < 2 * L; ++l) mix((uint64_t)shapes[l]);
+    mix((uint64_t)reinterpret_cast<uintptr_t>(loc));
     return h;
 }
+constexpr size_t kMonitorMaxEntries = 512;   // (sampling_loc addresses that keep changing: forget and start over)
 
 // under mo.mu: fold a finished probe into its entry
 void monitor_poll(Monitor &mo)
@@ -154,6 +163,7 @@ int monitor_choose_fwd(Monitor *mo, uint64_t key, hipStream_t stream, unsigned *
     const bool capturing = cap != hipStreamCaptureStatusNone;
     mo->mu.lock();
     if (!capturing) monitor_poll(*mo);   // (querying an event is not allowed while a capture is under way)
+    if (mo->table.size() > kMonitorMaxEntries) mo->table.clear();
     MonitorEntry &en = mo->table[key];
     const unsigned call = en.calls++;
     bool want = !mo->pending && !capturing && call >= en.next_probe;
@@ -189,6 +199,7 @@ void monitor_finish_probe(Monitor *mo, double points, hipStream_t stream, bool l
     mo->mu.unlock();
 }
 
+// 2 = window kernels, 4 = routed kernels (when the caller can take them, else it falls back by itself), 1 = direct
 int monitor_choose_bwd(Monitor *mo, uint64_t key, hipStream_t stream)
 {
     if (!mo || !g_monitor_on.load()) return 2;
@@ -197,7 +208,8 @@ int monitor_choose_bwd(Monitor *mo, uint64_t key, hipStream_t stream)
     std::lock_guard<std::mutex> lock(mo->mu);
     if (cap == hipStreamCaptureStatusNone) monitor_poll(*mo);
     const auto it = mo->table.find(key);
-    return it != mo->table.end() && it->second.known && it->second.share > kBwdShareMax ? 1 : 2;
+    if (it == mo->table.end() || !it->second.known) return 2;
+    return it->second.share > kBwdRoutedShare ? 4 : 2;
 }
 
 struct Problem {
@@ -499,7 +511,7 @@ hipError_t launch_bwd_rps(const Problem &pb, const float *value, const float *lo
     hipLaunchKernelGGL(msda::rps_route_kernel<true>, dim3(rgrid), dim3(256), 0, stream, loc, aw, grad_loc, grad_aw, pl.g);
     hipLaunchKernelGGL(msda::rps_scan_kernel, dim3(1), dim3(1024), 0, stream, pl.g);
     hipLaunchKernelGGL(msda::rps_route_kernel<false>, dim3(rgrid), dim3(256), 0, stream, loc, aw, grad_loc, grad_aw, pl.g);
-    const int grid = (cu_count() / msda::kXcds) * msda::kXcds;
+    const int grid = (cu_count() / msda::kXcds) * msda::kXcds * (1024 / msda::kRpsThreads);   // persistent: two 512-thread workgroups per CU
     hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 8), dim3(msda::kRpsThreads), sizeof(msda::RpsLds), stream, value, grad_out,
                        grad_value, grad_loc, grad_aw, pl.g);
     return hipGetLastError();
@@ -550,7 +562,7 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
         Monitor *mo = nullptr;
         if (variant == 0) {   // automatic: follow the locality monitor
             mo = monitor_for_current_device();
-            variant = monitor_choose_fwd(mo, problem_key(N, S, M, L, P, pb.shapes.data()), stream, &probe);
+            variant = monitor_choose_fwd(mo, problem_key(N, S, M, L, P, pb.shapes.data(), loc), stream, &probe);
         }
         if (variant == 2) {
             hipError_t e;
@@ -627,10 +639,23 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         e = hipSuccess;
     }
     if (variant == 3 || variant == 4) variant = 0;
+    if (variant == 0 && Lq == S) {   // automatic, encoder-shaped: window kernels while the points are local, routed kernels otherwise
+        const int pick = monitor_choose_bwd(monitor_for_current_device(), problem_key(N, S, M, L, P, pb.shapes.data(), loc), stream);
+        if (pick == 4) {
+            ProfileScope prof(1, 4, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
+            e = try_bwd_rps<T>(pb, value, loc, aw, grad_out, grad_value, grad_loc, grad_aw, stream);
+            if (e == hipSuccess) return MSDA_OK;
+            prof.cancel();
+            if (e != hipErrorNotSupported) return hip_fail(e, "launch of the routed backward kernels");
+            e = hipSuccess;
+            variant = 1;   // not applicable here: the direct kernels take spread points better than the windows do
+        } else {
+            variant = 2;
+        }
+    }
     if (variant != 1 && msda::tiled_bwd_applicable<T>(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(),
                                                      pb.lsi.data(), value, grad_out, grad_value)) {
-        if (variant == 0)   // automatic: the forward calls of this problem measured how local its sampling points are
-            variant = monitor_choose_bwd(monitor_for_current_device(), problem_key(N, S, M, L, P, pb.shapes.data()), stream);
+        if (variant == 0) variant = 2;   // (automatic choice for encoder-shaped calls was made above)
         if (variant == 2) {
             if ((e = zero_grad_value()) != hipSuccess) return hip_fail(e, "zero-fill of grad_value");
             {
@@ -746,7 +771,7 @@ int forward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const in
         Monitor *mo = nullptr;
         if (variant == 0) {
             mo = monitor_for_current_device();
-            variant = monitor_choose_fwd(mo, problem_key(N, S, M, L, P, pb.shapes.data()), stream, &probe);
+            variant = monitor_choose_fwd(mo, problem_key(N, S, M, L, P, pb.shapes.data(), loc), stream, &probe);
         }
         if (variant == 2) {
             hipError_t e;
@@ -805,8 +830,10 @@ int backward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const i
 
     int variant = g_bwd_variant.load();
     if (variant != 1 && variant != 3 && is_aligned(value, 8) && is_aligned(grad_out, 8) && is_aligned(grad_value, 8)) {
-        if (variant == 0)
-            variant = monitor_choose_bwd(monitor_for_current_device(), problem_key(N, S, M, L, P, pb.shapes.data()), stream);
+        if (variant == 0) {   // (no routed kernels for bf16 storage yet: spread points go to the direct path)
+            variant = monitor_choose_bwd(monitor_for_current_device(), problem_key(N, S, M, L, P, pb.shapes.data(), loc), stream);
+            if (variant == 4) variant = 1;
+        }
         float *gv32 = nullptr;
         if (variant == 2 && msda::plan_bwd_gather(N, S, M, D, L, Lq, P, pb.shapes.data(), pb.lsi.data()).ok &&
             msda::plan_scatter_sorted(N, S, M, D, L, Lq, P, pb.shapes.data(), pb.lsi.data()).ok && bf16_scratch(stream, n_value, &gv32)) {
@@ -883,7 +910,7 @@ int msda_set_option(const char *key, int value)
 {
     if (key && !strcmp(key, "fwd_variant") && value >= 0 && value <= 2) { g_fwd_variant = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_variant") && value >= 0 && value <= 4) { g_bwd_variant = value; return MSDA_OK; }
-    if (key && !strcmp(key, "rps_tile") && value >= 4 && value <= 20) { msda::rps_options().tile = value; return MSDA_OK; }
+    if (key && !strcmp(key, "rps_tile") && value >= 4 && value <= 16) { msda::rps_options().tile = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_max_chunks") && value >= 1 && value <= 4096) { msda::rps_options().max_chunks = value; return MSDA_OK; }
     if (key && !strcmp(key, "psb_margin") && value >= 0 && value <= 64) { msda::psb_options().margin = value; return MSDA_OK; }
     if (key && !strcmp(key, "psb_tile") && value >= 4 && value <= 23) { msda::psb_options().tile = value; return MSDA_OK; }
@@ -903,6 +930,7 @@ int msda_set_option(const char *key, int value)
         for (Monitor &mo : g_monitors) {   // switching it (either way) forgets what was learnt
             std::lock_guard<std::mutex> lock(mo.mu);
             mo.table.clear();
+            mo.pending = false;   // (a probe still in flight belongs to what is being forgotten)
         }
         g_last_share_ppm = -1;
         return MSDA_OK;

@@ -31,7 +31,7 @@
 
 namespace msda {
 
-constexpr int kRpsThreads = 1024;
+constexpr int kRpsThreads = 1024;              // (two 512-thread workgroups per CU with 128-pixel tiles measured slower: 479 vs 420 us)
 constexpr int kRpsMaxPx = kRpsThreads / 4;      // tile + one row / column: one quad (4 lanes x 8 channels) per base pixel
 constexpr int kRpsChunk = 2 * kRpsThreads;      // sampling points per chunk
 constexpr int kRpsMaxL = 4;
@@ -63,7 +63,7 @@ struct RpsGeom {
     float4 *params;                 // per entry: bilinear fractions (lh, lw), attention weight -- written by the route pass so
                                     // that the tile kernel streams them instead of gathering 8 + 4 bytes per point
     unsigned long long *stamps;     // diagnostic runs only (msda_debug_stamps)
-    int dbg;                        // diagnostic ablations (wrong results): 1 = no grad_out loads, 2 = no corner dots
+    int dbg;                        // diagnostic: bits 4..6 = 1 + level -> only that level's tiles do any work (wrong results)
 };
 
 struct alignas(16) RpsEnt {   // one sampling point in the list of its base pixel; overwritten by its four corner dots
@@ -77,8 +77,6 @@ struct RpsLds {
     int pad[2];
     unsigned long long stamp_last, stamp_acc[14];
     int offs[kRpsMaxPx + 4];            // histogram, then exclusive prefix
-    int len_hist[64];                   // lists per length class (single-chunk tiles hand their lists out sorted by length)
-    unsigned short order[kRpsMaxPx];    // quad -> base pixel whose list it walks
     RpsEnt ent[kRpsChunk];              // sorted points of the chunk; plane of the final fold
     float vtile[kRpsMaxPx * kRpsD];     // value rows of the tile + apron; plane of the final fold
     float stage2[kRpsMaxPx * kRpsD], stage3[kRpsMaxPx * kRpsD];   // two more planes of the final fold
@@ -321,12 +319,10 @@ __device__ __forceinline__ float rps_quad_transpose_sum(float d0, float d1, floa
 // arithmetic (v_pk_fma_f32) throughout: the kernel is bound by vector instruction issue (measured: VALU busy ~60 %,
 // one quad-cycle per instruction), so every FMA carries two channels and the per-point overhead (weights, the dot
 // reduction, the entry read) is shared by 8 channels per lane instead of 4.
-// Lists of one wave are walked in lockstep, so a tile whose bin fits ONE chunk (the fine levels) hands its lists out
-// sorted by length -- the 16 lists of a wave are then equally long -- and a tile with several chunks (coarse levels, long
-// lists) keeps list p on quad p and its partial sums in registers across the chunks.
+// List p stays on quad p, whose partial sums live in registers across the chunks of a tile.
 // The next work item is drawn from the queue, and the first chunk of its bin fetched, while the current one is reduced.
 template <bool P4>
-__global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
+__global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
     const float *__restrict__ value, const float *__restrict__ grad_out, float *__restrict__ grad_value,
     float *__restrict__ grad_loc, float *__restrict__ grad_aw, const RpsGeom g)
 {
@@ -335,13 +331,15 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
 
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int j4 = tid & 3, quad = tid >> 2;
+    // this lane's 8 channels: [c_lo, c_lo + 4) and [c_hi, c_hi + 4) -- so that each of a lane's two 16-B accesses to a 128-B
+    // row forms, with the other three lanes of its quad, 64 contiguous bytes
+    const int c_lo = 4 * j4, c_hi = 16 + 4 * j4;
     const int P = P4 ? 4 : g.P;
     const int LP = g.L * P;
     const int row_elems = g.M * kRpsD;
     const int pairs = g.N * g.M;
     const int xq = blockIdx.x & (kXcds - 1);   // blocks equal mod 8 share an XCD (observed; speed only)
     const int n_items = g.nunits * g.ppx;
-    const int imask = (g.dbg & 1) ? 1023 : -1;   // diagnostic: every grad_out row from a 128 KB (cache-resident) range
     if (g.stamps && tid == 0) {
         for (int i = 0; i < 14; ++i) S->stamp_acc[i] = 0;
         S->stamp_last = __builtin_amdgcn_s_memtime();
@@ -399,25 +397,23 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
         const int gw = C1 - C0 + 1;
         const int npx = live_item ? (R1 - R0 + 1) * gw : 0;
         const int n_chunks = live_item ? (n_ent + kRpsChunk - 1) / kRpsChunk : 0;
-        const bool sort_lists = n_chunks == 1 && !(g.dbg & 4);
         // this quad's pixel in the pixel grid
         const bool has_px = quad < npx;
         const int gr = quad / gw, gc = quad - gr * gw;
         const int prow = R0 + gr, pcol = C0 + gc;
-        const int64_t px_off = ((int64_t)(b * g.S + g.lv[l].start + prow * W + pcol) * g.M + m) * kRpsD + 8 * j4;
+        const int64_t px_off = ((int64_t)(b * g.S + g.lv[l].start + prow * W + pcol) * g.M + m) * kRpsD;   // (+ c_lo / c_hi)
 
         // ---- the tile's value rows (+ apron, zeros beyond the map) -> LDS: 32 B per lane -----------------------------------
         {
             float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
             if (has_px && prow < H && pcol < W && n_chunks > 0) {
-                t0 = *reinterpret_cast<const float4 *>(value + px_off);
-                t1 = *reinterpret_cast<const float4 *>(value + px_off + 4);
+                t0 = *reinterpret_cast<const float4 *>(value + px_off + c_lo);
+                t1 = *reinterpret_cast<const float4 *>(value + px_off + c_hi);
             }
             if (has_px) {
-                *reinterpret_cast<float4 *>(S->vtile + quad * kRpsD + 8 * j4) = t0;
-                *reinterpret_cast<float4 *>(S->vtile + quad * kRpsD + 8 * j4 + 4) = t1;
+                *reinterpret_cast<float4 *>(S->vtile + quad * kRpsD + c_lo) = t0;
+                *reinterpret_cast<float4 *>(S->vtile + quad * kRpsD + c_hi) = t1;
             }
-            if (tid < kRpsMaxPx) S->order[tid] = (unsigned short)tid;
         }
         // ---- four partial sums of one base pixel (one per corner), 8 channels per lane ---------------------------------------
         rps_v2f acc[4][4];
@@ -426,17 +422,16 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[k][c] = (rps_v2f){0.f, 0.f};
         __syncthreads();
-        const int next_id = rps_uni(S->item_slot[par ^ 1]);
-        unsigned next_first;
-        int next_n;
-        bin_range(next_id, next_first, next_n);
-        int my_p = quad;   // the base pixel whose list this quad walks
+        // the next work item: its queue draw (issued above) is read behind a later barrier, so that nobody waits for it
+        int next_id = n_items;
+        unsigned next_first = 0;
+        int next_n = 0;
+        const int my_p = quad;   // the base pixel whose list this quad walks
         RPS_STAMP(0)
 
         for (int ch = 0; ch < n_chunks; ++ch) {
             // ---- (1) this lane's two points of the chunk ---------------------------------------------------------------------
             for (int i = tid; i <= npx; i += kRpsThreads) S->offs[i] = 0;
-            if (tid < 64) S->len_hist[tid] = 0;
             int p_pt[2], pbase[2], pos[2];
             float p_lh[2], p_lw[2], p_a[2];
             unsigned p_own[2];    // bit 4: this tile forms the point's gradients; bits 0..3: corners inside the map
@@ -455,11 +450,15 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
                     p_own[u] = ((unsigned)(n_code[u] >> 63) << 4) | ((unsigned)(n_code[u] >> 56) & 15u);
                 }
             }
-            // in flight until the next chunk -- or the next work item -- starts
+            // the next chunk -- or, behind the barrier, the first chunk of the next work item -- is in flight from here on
             if (ch + 1 < n_chunks) fetch_codes(e_first, n_ent, ch + 1);
-            else fetch_codes(next_first, next_n, 0);
             __syncthreads();
             RPS_STAMP(1)
+            if (ch == 0) {
+                next_id = rps_uni(S->item_slot[par ^ 1]);
+                bin_range(next_id, next_first, next_n);
+            }
+            if (ch + 1 == n_chunks) fetch_codes(next_first, next_n, 0);
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if (p_pt[u] >= 0) pos[u] = atomicAdd(&S->offs[pbase[u]], 1);
@@ -467,7 +466,6 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
             RPS_STAMP(2)
 
             // ---- (2) exclusive scan of the per-list counts (<= 256: one per thread of the first 4 waves) --------------------------
-            int my_len = 0, my_rank = 0;
             {
                 int c = 0, incl = 0;
                 if (tid < kRpsMaxPx) {
@@ -479,9 +477,6 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
                         if (lane >= d) incl += t;
                     }
                     if (lane == kWave - 1) S->wave_tot[wave] = incl;
-                    // lists sorted by length, longest first (counting sort, 64 length classes)
-                    my_len = 63 - min(c, 63);
-                    if (sort_lists && tid < npx) my_rank = atomicAdd(&S->len_hist[my_len], 1);
                 }
                 __syncthreads();
                 if (tid < kRpsMaxPx) {
@@ -491,17 +486,6 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
                     const int excl = base + incl - c;
                     if (tid <= npx) S->offs[tid] = excl;      // tid == npx: the total (c = 0 there)
                     if (tid == kRpsMaxPx - 1 && npx == kRpsMaxPx) S->offs[npx] = base + incl;
-                    if (sort_lists) {   // every wave scans the 64 classes itself: no barrier for it
-                        const int h = S->len_hist[lane];
-                        int hs = h;
-#pragma unroll
-                        for (int d = 1; d < kWave; d <<= 1) {
-                            const int t = __shfl_up(hs, d, kWave);
-                            if (lane >= d) hs += t;
-                        }
-                        const int start = __shfl(hs - h, my_len, kWave);
-                        if (tid < npx) S->order[start + my_rank] = (unsigned short)tid;
-                    }
                 }
             }
             __syncthreads();
@@ -520,7 +504,6 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
             // ---- (4) every quad walks a list: four partial sums and four corner dots per point; grad_out rows straight from
             //      global memory, two points in flight per quad -------------------------------------------------------------------
             if (has_px) {
-                my_p = S->order[quad];
                 int e = S->offs[my_p];
                 const int e1 = S->offs[my_p + 1];
                 if (e < e1) {
@@ -532,8 +515,8 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int vp = (k < 2 ? r0 : lr * gw) + ((k & 1) ? lc : c0);
-                        const float4 a0 = *reinterpret_cast<const float4 *>(S->vtile + vp * kRpsD + 8 * j4);
-                        const float4 a1 = *reinterpret_cast<const float4 *>(S->vtile + vp * kRpsD + 8 * j4 + 4);
+                        const float4 a0 = *reinterpret_cast<const float4 *>(S->vtile + vp * kRpsD + c_lo);
+                        const float4 a1 = *reinterpret_cast<const float4 *>(S->vtile + vp * kRpsD + c_hi);
                         v[k][0] = (rps_v2f){a0.x, a0.y}; v[k][1] = (rps_v2f){a0.z, a0.w};
                         v[k][2] = (rps_v2f){a1.x, a1.y}; v[k][3] = (rps_v2f){a1.z, a1.w};
                     }
@@ -557,17 +540,17 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
     }
                     for (; e + 1 < e1; e += 2) {
                         const RpsEnt en0 = S->ent[e], en1 = S->ent[e + 1];
-                        const float *q0 = grad_out + (int64_t)(en0.item & imask) * kRpsD + 8 * j4;
-                        const float *q1 = grad_out + (int64_t)(en1.item & imask) * kRpsD + 8 * j4;
-                        const float4 g0a = *reinterpret_cast<const float4 *>(q0), g0b = *reinterpret_cast<const float4 *>(q0 + 4);
-                        const float4 g1a = *reinterpret_cast<const float4 *>(q1), g1b = *reinterpret_cast<const float4 *>(q1 + 4);
+                        const float *q0 = grad_out + (int64_t)en0.item * kRpsD;
+                        const float *q1 = grad_out + (int64_t)en1.item * kRpsD;
+                        const float4 g0a = *reinterpret_cast<const float4 *>(q0 + c_lo), g0b = *reinterpret_cast<const float4 *>(q0 + c_hi);
+                        const float4 g1a = *reinterpret_cast<const float4 *>(q1 + c_lo), g1b = *reinterpret_cast<const float4 *>(q1 + c_hi);
                         RPS_POINT(en0, g0a, g0b, e)
                         RPS_POINT(en1, g1a, g1b, e + 1)
                     }
                     if (e < e1) {
                         const RpsEnt en0 = S->ent[e];
-                        const float *q0 = grad_out + (int64_t)(en0.item & imask) * kRpsD + 8 * j4;
-                        const float4 g0a = *reinterpret_cast<const float4 *>(q0), g0b = *reinterpret_cast<const float4 *>(q0 + 4);
+                        const float *q0 = grad_out + (int64_t)en0.item * kRpsD;
+                        const float4 g0a = *reinterpret_cast<const float4 *>(q0 + c_lo), g0b = *reinterpret_cast<const float4 *>(q0 + c_hi);
                         RPS_POINT(en0, g0a, g0b, e)
                     }
 #undef RPS_POINT
@@ -596,8 +579,6 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
             // after three more barriers)
             RPS_STAMP(6)
         }
-        if (n_chunks == 0) fetch_codes(next_first, next_n, 0);
-
         // ---- fold the partial sums: pixel x of the pixel grid = BR[x] + BL[x+1] + TR[x+gw] + TL[x+gw+1] of the base grid.  The
         //      four partial sums of list my_p go to four LDS planes (the value rows and the entries are no longer needed) ------------
         __syncthreads();
@@ -606,11 +587,16 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
             if (has_px) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    *reinterpret_cast<float4 *>(plane[k] + my_p * kRpsD + 8 * j4) = make_float4(acc[k][0].x, acc[k][0].y, acc[k][1].x, acc[k][1].y);
-                    *reinterpret_cast<float4 *>(plane[k] + my_p * kRpsD + 8 * j4 + 4) = make_float4(acc[k][2].x, acc[k][2].y, acc[k][3].x, acc[k][3].y);
+                    *reinterpret_cast<float4 *>(plane[k] + my_p * kRpsD + c_lo) = make_float4(acc[k][0].x, acc[k][0].y, acc[k][1].x, acc[k][1].y);
+                    *reinterpret_cast<float4 *>(plane[k] + my_p * kRpsD + c_hi) = make_float4(acc[k][2].x, acc[k][2].y, acc[k][3].x, acc[k][3].y);
                 }
             }
             __syncthreads();
+            if (n_chunks == 0) {   // (an empty bin: nothing was fetched ahead)
+                next_id = rps_uni(S->item_slot[par ^ 1]);
+                bin_range(next_id, next_first, next_n);
+                fetch_codes(next_first, next_n, 0);
+            }
             float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
             if (has_px) {
 #pragma unroll
@@ -619,8 +605,8 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
                     const int src = quad + (k == 2 || k == 0 ? 1 : 0) + (k < 2 ? gw : 0);
                     const bool ok = ((k == 1 || k == 3) || gc + 1 < gw) && (k >= 2 || gr + 1 <= R1 - R0);
                     if (ok) {
-                        const float4 t0 = *reinterpret_cast<const float4 *>(plane[k] + src * kRpsD + 8 * j4);
-                        const float4 t1 = *reinterpret_cast<const float4 *>(plane[k] + src * kRpsD + 8 * j4 + 4);
+                        const float4 t0 = *reinterpret_cast<const float4 *>(plane[k] + src * kRpsD + c_lo);
+                        const float4 t1 = *reinterpret_cast<const float4 *>(plane[k] + src * kRpsD + c_hi);
                         o0.x += t0.x; o0.y += t0.y; o0.z += t0.z; o0.w += t0.w;
                         o1.x += t1.x; o1.y += t1.y; o1.z += t1.z; o1.w += t1.w;
                     }
@@ -630,8 +616,8 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
             const bool in_tile = has_px && prow < R1 && pcol < C1;
             if (!g.lv[l].atomic) {
                 if (in_tile) {
-                    *reinterpret_cast<float4 *>(grad_value + px_off) = o0;
-                    *reinterpret_cast<float4 *>(grad_value + px_off + 4) = o1;
+                    *reinterpret_cast<float4 *>(grad_value + px_off + c_lo) = o0;
+                    *reinterpret_cast<float4 *>(grad_value + px_off + c_hi) = o1;
                 }
             } else if (n_chunks > 0) {
                 // several workgroups share the tile: hand the rows over through LDS and add them one channel per lane, so that
@@ -639,8 +625,8 @@ __global__ __launch_bounds__(kRpsThreads) void rps_tile_kernel(
                 __syncthreads();
                 float *stage = S->vtile;
                 if (has_px) {
-                    *reinterpret_cast<float4 *>(stage + quad * kRpsD + 8 * j4) = o0;
-                    *reinterpret_cast<float4 *>(stage + quad * kRpsD + 8 * j4 + 4) = o1;
+                    *reinterpret_cast<float4 *>(stage + quad * kRpsD + c_lo) = o0;
+                    *reinterpret_cast<float4 *>(stage + quad * kRpsD + c_hi) = o1;
                 }
                 __syncthreads();
                 const int c32 = tid & 31;

@@ -333,10 +333,11 @@ def _variants_of(fn, n=1):
     return [r["variant"] for r in recs]
 
 
-@pytest.mark.parametrize("loc_mode,expect", [("init", 2), ("uniform", 1)])
-def test_locality_monitor_picks_kernels_by_data(loc_mode, expect):
-    """Auto mode: the window kernels stay on a local sampling pattern and give way to the direct kernels on a
-    scattered one (after the first probe has come back); results match the oracle either way."""
+@pytest.mark.parametrize("loc_mode,expect,expect_bwd", [("init", 2, 2), ("uniform", 1, 4)])
+def test_locality_monitor_picks_kernels_by_data(loc_mode, expect, expect_bwd):
+    """Auto mode: the window kernels stay on a local sampling pattern; on a scattered one the forward gives way to the
+    direct kernel and the backward to the routed kernels (after the first probe has come back); results match the oracle
+    either way."""
     call = W.shrunk(W.call_E(2), 2)
     z = W.make_inputs(call, loc_mode, seed=11)
     t = {k: v.cuda() for k, v in z.items()}
@@ -354,7 +355,7 @@ def test_locality_monitor_picks_kernels_by_data(loc_mode, expect):
         fwd()
         torch.cuda.synchronize()
     assert _variants_of(fwd) == [expect]
-    assert _variants_of(bwd) == [expect]
+    assert _variants_of(bwd) == [expect_bwd]
     gv, gl, ga = bwd()
     zn = {k: v.numpy() for k, v in z.items()}
     oo = O.forward(zn["value"], zn["shapes"], zn["lsi"], zn["loc"], zn["aw"])
