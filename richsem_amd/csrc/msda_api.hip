@@ -86,16 +86,18 @@ struct ProfileScope {
 // ---- locality monitor -----------------------------------------------------------------------------------
 // The LDS-window kernels win only while most sampling points fall into the window of their query's region; the share
 // that does not ("general share") is a property of the DATA (how far the network's offsets reach).  Measured on MI355X
-// (tools/locality_sweep.sh, call E): the window forward beats the direct forward up to a general share of ~2.5 %, the
-// window backward beats the direct backward up to ~25 %.  In automatic mode the library therefore lets the window
+// (tools/locality_sweep2.sh, call E; profiles/r02_locality.md): the window forward -- which finishes the points that miss
+// their window per point, after the item -- beats the direct forward up to a share of ~8 % (sigma ~4.5 px); the window backward
+// beats the routed backward up to ~3.5 % (sigma ~3.5 px), and the routed backward, whose cost does not depend on the
+// distribution, beats the direct backward everywhere.  In automatic mode the library therefore lets the window
 // forward kernel count its general points now and then (one atomic per wave), brings the count back with an
 // asynchronous copy + event on the caller's stream, and reads it on a LATER call once the event has completed -- no
 // call ever waits.  Nothing is probed while the stream is being captured into a graph.
-constexpr float kFwdShareMax = 0.02f, kBwdShareMax = 0.23f;
+constexpr float kFwdShareMax = 0.08f, kBwdShareMax = 0.23f;
 // Backward: above this share of window misses the routed kernels (msda_rps.h), whose cost does not depend on where the points
 // fall, beat the window kernels (MI355X, call E: window 383 / 497 / 2190 us at sigma 1 px / 4 px / uniform, routed 431 / 450 / 702)
-constexpr float kBwdRoutedShare = 0.03f;
-constexpr unsigned kProbeWarmCalls = 8, kProbeEvery = 64;
+constexpr float kBwdRoutedShare = 0.035f;
+constexpr unsigned kProbeWarmCalls = 2, kProbeEvery = 64;   // per (shape, sampling_loc buffer)
 constexpr int kMaxDevices = 64;
 std::atomic<int> g_monitor_on{1};
 std::atomic<int> g_last_share_ppm{-1};
@@ -105,13 +107,18 @@ struct MonitorEntry {
     float share = 0.f;
     bool known = false;
 };
-struct Monitor {
-    std::mutex mu;
-    unsigned *dev = nullptr, *host = nullptr;   // one counter on the device, its pinned host copy
+constexpr int kProbeSlots = 8;   // probes in flight at once (the layers of a step call back to back)
+struct ProbeSlot {
     hipEvent_t done = nullptr;
     bool pending = false;
-    uint64_t pending_key = 0;
-    double pending_points = 0;
+    uint64_t key = 0;
+    double points = 0;
+};
+struct Monitor {
+    std::mutex mu;
+    unsigned *dev = nullptr, *host = nullptr;   // kProbeSlots counters on the device, their pinned host copies
+    ProbeSlot slot[kProbeSlots];
+    int held = -1;                               // slot of the probe being launched (between choose_fwd and finish_probe)
     std::unordered_map<uint64_t, MonitorEntry> table;
 };
 Monitor g_monitors[kMaxDevices];
@@ -131,17 +138,20 @@ uint64_t problem_key(const int N, const int S, const int M, const int L, const i
 }
 constexpr size_t kMonitorMaxEntries = 512;   // (sampling_loc addresses that keep changing: forget and start over)
 
-// under mo.mu: fold a finished probe into its entry
+// under mo.mu: fold the finished probes into their entries
 void monitor_poll(Monitor &mo)
 {
-    if (!mo.pending || hipEventQuery(mo.done) != hipSuccess) return;
-    mo.pending = false;
-    MonitorEntry &en = mo.table[mo.pending_key];
-    const float s = (float)((double)*mo.host / mo.pending_points);
-    // the first probes see different layers of the network: keep their worst; later ones track slowly
-    en.share = !en.known ? s : (en.probes <= kProbeWarmCalls ? (s > en.share ? s : en.share) : 0.5f * (en.share + s));
-    en.known = true;
-    g_last_share_ppm = (int)(s * 1e6f);
+    for (int i = 0; i < kProbeSlots; ++i) {
+        ProbeSlot &ps = mo.slot[i];
+        if (!ps.pending || hipEventQuery(ps.done) != hipSuccess) continue;
+        ps.pending = false;
+        MonitorEntry &en = mo.table[ps.key];
+        const float s = (float)((double)mo.host[i] / ps.points);
+        // the warm-up probes of a key keep their worst; later ones track slowly
+        en.share = !en.known ? s : (en.probes <= kProbeWarmCalls ? (s > en.share ? s : en.share) : 0.5f * (en.share + s));
+        en.known = true;
+        g_last_share_ppm = (int)(s * 1e6f);
+    }
 }
 
 Monitor *monitor_for_current_device()
@@ -166,22 +176,30 @@ int monitor_choose_fwd(Monitor *mo, uint64_t key, hipStream_t stream, unsigned *
     if (mo->table.size() > kMonitorMaxEntries) mo->table.clear();
     MonitorEntry &en = mo->table[key];
     const unsigned call = en.calls++;
-    bool want = !mo->pending && !capturing && call >= en.next_probe;
+    int free_slot = -1;
+    bool mine_in_flight = false;
+    for (int i = 0; i < kProbeSlots; ++i) {
+        if (!mo->slot[i].pending && free_slot < 0) free_slot = i;
+        mine_in_flight = mine_in_flight || (mo->slot[i].pending && mo->slot[i].key == key);
+    }
+    bool want = free_slot >= 0 && !mine_in_flight && !capturing && call >= en.next_probe;
     if (want && !mo->dev) {   // first probe on this device
-        if (hipMalloc(reinterpret_cast<void **>(&mo->dev), sizeof(unsigned)) != hipSuccess ||
-            hipHostMalloc(reinterpret_cast<void **>(&mo->host), sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&mo->done, hipEventDisableTiming) != hipSuccess) {
+        bool ok = hipMalloc(reinterpret_cast<void **>(&mo->dev), kProbeSlots * sizeof(unsigned)) == hipSuccess &&
+                  hipHostMalloc(reinterpret_cast<void **>(&mo->host), kProbeSlots * sizeof(unsigned), hipHostMallocDefault) == hipSuccess;
+        for (int i = 0; ok && i < kProbeSlots; ++i) ok = hipEventCreateWithFlags(&mo->slot[i].done, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
             (void)hipGetLastError();
             mo->dev = nullptr;
             want = false;
         }
     }
-    if (want && hipMemsetAsync(mo->dev, 0, sizeof(unsigned), stream) != hipSuccess) want = false;
+    if (want && hipMemsetAsync(mo->dev + free_slot, 0, sizeof(unsigned), stream) != hipSuccess) want = false;
     if (want) {
-        *probe = mo->dev;
+        *probe = mo->dev + free_slot;
         en.next_probe = call + (en.probes < kProbeWarmCalls ? 1 : kProbeEvery);
         ++en.probes;
-        mo->pending_key = key;
+        mo->slot[free_slot].key = key;
+        mo->held = free_slot;
         return 2;   // a probe IS a window-kernel call; the lock stays held
     }
     const int variant = en.known && en.share > kFwdShareMax ? 1 : 2;
@@ -191,10 +209,13 @@ int monitor_choose_fwd(Monitor *mo, uint64_t key, hipStream_t stream, unsigned *
 
 void monitor_finish_probe(Monitor *mo, double points, hipStream_t stream, bool launched)
 {
-    if (launched && hipMemcpyAsync(mo->host, mo->dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream) == hipSuccess &&
-        hipEventRecord(mo->done, stream) == hipSuccess) {
-        mo->pending = true;
-        mo->pending_points = points;
+    const int i = mo->held;
+    mo->held = -1;
+    if (i >= 0 && launched &&
+        hipMemcpyAsync(mo->host + i, mo->dev + i, sizeof(unsigned), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+        hipEventRecord(mo->slot[i].done, stream) == hipSuccess) {
+        mo->slot[i].pending = true;
+        mo->slot[i].points = points;
     }
     mo->mu.unlock();
 }
@@ -208,7 +229,8 @@ int monitor_choose_bwd(Monitor *mo, uint64_t key, hipStream_t stream)
     std::lock_guard<std::mutex> lock(mo->mu);
     if (cap == hipStreamCaptureStatusNone) monitor_poll(*mo);
     const auto it = mo->table.find(key);
-    if (it == mo->table.end() || !it->second.known) return 2;
+    // no verdict yet (the first step of a layer): the routed kernels, which cost the same wherever the points fall
+    if (it == mo->table.end() || !it->second.known) return 4;
     return it->second.share > kBwdRoutedShare ? 4 : 2;
 }
 
@@ -930,7 +952,7 @@ int msda_set_option(const char *key, int value)
         for (Monitor &mo : g_monitors) {   // switching it (either way) forgets what was learnt
             std::lock_guard<std::mutex> lock(mo.mu);
             mo.table.clear();
-            mo.pending = false;   // (a probe still in flight belongs to what is being forgotten)
+            for (ProbeSlot &ps : mo.slot) ps.pending = false;   // (probes still in flight belong to what is being forgotten)
         }
         g_last_share_ppm = -1;
         return MSDA_OK;

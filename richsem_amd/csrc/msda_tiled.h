@@ -343,6 +343,7 @@ __device__ __forceinline__ int build_header(TileHeader *h, const TiledGeom &g, i
             h->lds_px[i] = ldspx[i];
         }
         h->qpre[kTL] = qpre[kTL];
+        h->pad[0] = 0;   // forward: number of queries with points that missed their window (tiled_gather_kernel)
     }
     const int nq = qpre[kTL];
     for (int i = threadIdx.x; i < nq; i += blockDim.x) {   // level-major, row-major inside the level
@@ -523,8 +524,10 @@ __device__ __forceinline__ void gather_level(
     const bool (&live)[GatherCfg<GC, CPL>::QPG], const LevelOps<GatherCfg<GC, CPL>::QPG> &pre,
     v2f (&acc_lo)[GatherCfg<GC, CPL>::QPG], v2f (&acc_hi)[GatherCfg<GC, CPL>::QPG],
     const float4 (&gq)[GatherCfg<GC, CPL>::QPG][GatherCfg<GC, CPL>::NV], float (&part)[GatherCfg<GC, CPL>::QPG][3],
-    float *__restrict__ grad_loc, float *__restrict__ grad_aw, unsigned &n_general)
+    float *__restrict__ grad_loc, float *__restrict__ grad_aw, unsigned &n_general, const int lvl,
+    unsigned (&miss)[GatherCfg<GC, CPL>::QPG])
 {
+    constexpr bool defer = !BWD && P4 && GatherCfg<GC, CPL>::GL == 4;
     constexpr int kGatherQPG = GatherCfg<GC, CPL>::QPG, NV = GatherCfg<GC, CPL>::NV, GL = GatherCfg<GC, CPL>::GL;
     static_assert(BWD || NV == 1, "the forward keeps its accumulators for four channels per lane");
     const int P = P4 ? 4 : P_;
@@ -555,6 +558,10 @@ __device__ __forceinline__ void gather_level(
                 mode = inside ? lc.lds_base + (rr * lc.nwc + cc) * GC : -2;
             }
             n_general += (mode == -2 && j < 4) ? 1u : 0u;   // locality monitor (lanes 0..3 of a query hold its four points)
+            // forward: a point that missed its window is only NOTED here (bit = level*4 + point, kept by the lane that resolved
+            // it) and done after the item by whole lane groups (see tiled_gather_kernel) -- its cost is then per point, not
+            // per wave iteration
+            if (defer && mode == -2) miss[k] |= 1u << (lvl * 4 + (j & 3));
             const float hh = 1.f - lh, hw = 1.f - lw;
             // forward broadcasts finished weights; backward needs lh, lw and the attention weight separately
             const float w1 = hh * hw * a, w2 = hh * lw * a, w3 = lh * hw * a, w4 = lh * lw * a;
@@ -607,7 +614,7 @@ __device__ __forceinline__ void gather_level(
                                              ps_x + (MODE == 2 ? part[k][1] : 0.f), ps_y + (MODE == 2 ? part[k][2] : 0.f));
                 }
             }
-            if (any_slow) {   // uniform over the quad; rare
+            if (!defer && any_slow) {   // uniform over the quad; rare
                 // A wave steps through this body whenever ONE of its lanes holds a general point, so the body is kept short:
                 // the owner lane resolves its point once, the quad receives corner offsets and coefficients by DPP
                 // (compile-time slots, no cross-lane LDS traffic), and a slot that has no general point anywhere in the wave
@@ -728,8 +735,13 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
     // backward on channel halves keeps the first half's per-point results here; it then needs one level per work item and
     // at most four points per level (host-enforced)
     float part[kGatherQPG][3];
+    unsigned miss[kGatherQPG];   // forward: bit (level*4 + point) = that point of query k missed its window (this lane's point only)
 #pragma unroll
-    for (int k = 0; k < kGatherQPG; ++k) part[k][0] = part[k][1] = part[k][2] = 0.f;
+    for (int k = 0; k < kGatherQPG; ++k) {
+        part[k][0] = part[k][1] = part[k][2] = 0.f;
+        miss[k] = 0u;
+    }
+    constexpr bool defer = !BWD && P4 && GL == 4;   // (compile-time: the in-loop general path is not even compiled into this kernel)
     const int ph_begin = BWD ? sub : 0, ph_end = BWD ? ph_begin + 1 : g.nphases;
     const int half_begin = BWD ? 0 : sub, half_end = BWD ? kHalves : sub + 1;
     int st = 2;
@@ -795,19 +807,81 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                 for (int k = 0; k < kGatherQPG; ++k) pt0[k] = item[k] * (unsigned)LP + (unsigned)(l * g.P);
                 if (!BWD || kHalves == 1)
                     gather_level<BWD, P4, 0, GC, CPL, TV>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw, n_general);
+                                                 acc_hi, gq, part, grad_loc, grad_aw, n_general, l, miss);
                 else if (half == 0)
                     gather_level<BWD, P4, 1, GC, CPL, TV>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw, n_general);
+                                                 acc_hi, gq, part, grad_loc, grad_aw, n_general, l, miss);
                 else
                     gather_level<BWD, P4, 2, GC, CPL, TV>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw, n_general);
+                                                 acc_hi, gq, part, grad_loc, grad_aw, n_general, l, miss);
             }
-            __syncthreads();   // the next fill overwrites the windows
+            // the next fill overwrites the windows (forward, last phase: the barrier below, which also tells whether any point
+            // of the workgroup missed its window, takes this one's place)
+            if (BWD || !defer || ph + 1 < ph_end || half + 1 < half_end) __syncthreads();
             stamp<2>(g, st++);
         }
     }
 
+    if (!BWD && defer) {
+        // ---- points that missed their window: collected per query, then done by 4-lane groups (4 channels per lane of this
+        //      channel half) straight from global memory -- every lane works on a missed point, nobody idles beside one.  The
+        //      partial rows come back through LDS (the windows are free now) and the owners add them before they store. -------
+        int *fx_list = reinterpret_cast<int *>(win);          // [kMaxRegionQueries][2]: (query slot, mask of missed points)
+        float *fx_patch = win + 2 * kMaxRegionQueries;        // [kMaxRegionQueries][GC]
+        unsigned any_miss = 0u;
+#pragma unroll
+        for (int k = 0; k < kGatherQPG; ++k) any_miss |= live[k] ? miss[k] : 0u;
+        if (__syncthreads_or((int)any_miss)) {   // (uniform over the workgroup; the windows are free behind this barrier)
+            int my_row[kGatherQPG];
+#pragma unroll
+            for (int k = 0; k < kGatherQPG; ++k) {
+                unsigned mk = miss[k];
+                mk |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mk, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                mk |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mk, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+                int r = -1;
+                if (live[k] && mk && j == 0) {
+                    r = atomicAdd(&hdr->pad[0], 1);
+                    fx_list[2 * r] = grp + k * kGroups;
+                    fx_list[2 * r + 1] = (int)mk;
+                }
+                my_row[k] = quad_bcast_i<0>(r);
+            }
+            __syncthreads();
+            const int n_fix = uni(hdr->pad[0]);
+            const int chan = sub * GC + 4 * j;
+            for (int e = grp; e < n_fix; e += kGroups) {
+                const int slot = fx_list[2 * e];
+                unsigned mk = (unsigned)fx_list[2 * e + 1];
+                const unsigned itm = (unsigned)((b * g.Lq + hdr->qid[slot]) * g.M + m);
+                v2f lo = (v2f){0.f, 0.f}, hi = (v2f){0.f, 0.f};
+                while (mk) {
+                    const int bit = __ffs((int)mk) - 1;
+                    mk &= mk - 1u;
+                    const int lv = bit >> 2, pp = bit & 3;
+                    const unsigned pt = itm * (unsigned)LP + (unsigned)(lv * g.P + pp);
+                    const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
+                    const float a = aw[pt];
+                    int o[4];
+                    float lh, lw;
+                    resolve_point<float>(xy.x, xy.y, hdr->H[lv], hdr->W[lv], (b * g.S + hdr->start[lv]) * row_elems + m * kTD, row_elems, o, lh, lw);
+                    const float hh = 1.f - lh, hw = 1.f - lw;
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 v1 = o[0] >= 0 ? ld4(value + o[0] + chan) : z, v2 = o[1] >= 0 ? ld4(value + o[1] + chan) : z;
+                    const float4 v3 = o[2] >= 0 ? ld4(value + o[2] + chan) : z, v4 = o[3] >= 0 ? ld4(value + o[3] + chan) : z;
+                    fwd_accumulate(hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a, v1, v2, v3, v4, lo, hi);
+                }
+                *reinterpret_cast<float4 *>(fx_patch + e * GC + 4 * j) = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kGatherQPG; ++k)
+                if (my_row[k] >= 0) {
+                    const float4 t = *reinterpret_cast<const float4 *>(fx_patch + my_row[k] * GC + 4 * j);
+                    acc_lo[k] += (v2f){t.x, t.y};
+                    acc_hi[k] += (v2f){t.z, t.w};
+                }
+        }
+    }
     if (!BWD) {
         const int chan = sub * GC + 4 * j;
 #pragma unroll
@@ -1472,8 +1546,12 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_scatter_sorted_kernel(
 // ---- host entry points ----------------------------------------------------------------------------------------------
 inline TiledPlan plan_gather(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
 {
-    return plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin, kFwdLdsBudget,
-                      kFwdGC * (int)sizeof(float));
+    TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin, kFwdLdsBudget,
+                              kFwdGC * (int)sizeof(float));
+    // the forward's fix-up of window misses reuses the window memory: a list of queries and one partial row per query
+    const size_t fix = sizeof(TileHeader) + 2 * sizeof(int) * kMaxRegionQueries + (size_t)pl.max_q * kFwdGC * sizeof(float);
+    if (pl.ok && pl.lds_bytes < fix) pl.lds_bytes = fix;
+    return pl;
 }
 inline TiledPlan plan_bwd_gather(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
 {

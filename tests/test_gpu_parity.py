@@ -350,7 +350,7 @@ def test_locality_monitor_picks_kernels_by_data(loc_mode, expect, expect_bwd):
     torch.cuda.synchronize()
     out = fwd()                               # folds the finished probe in, then chooses
     share = _lib.get_option("locality_share_ppm") * 1e-6
-    assert (share < 0.02) == (expect == 2), share
+    assert (share < 0.08) == (expect == 2), share
     for _ in range(10):                       # past the warm-up probes
         fwd()
         torch.cuda.synchronize()
