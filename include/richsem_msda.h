@@ -198,6 +198,43 @@ int msda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes, con
                        const int64_t *shapes_host, const int64_t *level_start_host,
                        msda_stream_t stream);
 
+/* ---- module-level element-wise work ------------------------------------------------
+ * What reference models/richsem/ops/modules/ms_deform_attn.py:94-109 does with half a dozen PyTorch ops per call --
+ * masked_fill of value, softmax over the L*P logits of a (query, head), offsets / normaliser (+ reference points) --
+ * and what autograd replays backwards, as one kernel each way plus an in-place row mask.
+ *
+ *   offsets    raw output of the sampling_offsets projection: row (n, q) at offsets + (n*Lq + q)*off_stride, M*L*P*2 values
+ *   logits     raw output of the attention_weights projection: row (n, q) at logits + (n*Lq + q)*log_stride, M*L*P values
+ *              (strides in ELEMENTS: both may point into the output of ONE 256 -> 384 projection, stride 384)
+ *   ref        reference points (N, Lq, L, ref_dim), ref_dim = 2 (x, y) or 4 (x, y, w, h), contiguous
+ *   shapes_host  HOST copy of spatial_shapes (L, 2) int64 -- the offset normaliser (W_l, H_l) of ref_dim = 2
+ *   loc, aw    outputs, contiguous: sampling_loc (N, Lq, M, L, P, 2), attn_weight (N, Lq, M, L, P) -- the operator's inputs
+ * msda_prep_backward: grad_loc / grad_aw as returned by msda_backward_*, aw as produced by msda_prep_forward; writes
+ *   grad_offsets / grad_logits (with their own row strides: they may be the two parts of ONE gradient tensor) and, when
+ *   grad_ref is non-NULL, grad_reference_points (N, Lq, L, ref_dim); `offsets` is only read for ref_dim = 4 with grad_ref.
+ * msda_mask_rows: x (rows, row_elems), zeroes IN PLACE every row whose mask byte is non-zero (value rows of padded
+ *   pixels forward, grad_value rows backward).  Only masked rows cost memory traffic.
+ * L <= 16, L*P <= 64.  float32 and float64 (the module's golden vectors are float64). */
+int msda_prep_forward_f32(const float *offsets, int64_t off_stride, const float *logits, int64_t log_stride,
+                          const float *ref, int ref_dim, const int64_t *shapes_host,
+                          int N, int Lq, int M, int L, int P, float *loc, float *aw, msda_stream_t stream);
+int msda_prep_forward_f64(const double *offsets, int64_t off_stride, const double *logits, int64_t log_stride,
+                          const double *ref, int ref_dim, const int64_t *shapes_host,
+                          int N, int Lq, int M, int L, int P, double *loc, double *aw, msda_stream_t stream);
+int msda_prep_backward_f32(const float *grad_loc, const float *grad_aw, const float *aw,
+                           const float *offsets, int64_t off_stride, const float *ref, int ref_dim,
+                           const int64_t *shapes_host, int N, int Lq, int M, int L, int P,
+                           float *grad_offsets, int64_t goff_stride, float *grad_logits, int64_t glog_stride,
+                           float *grad_ref, msda_stream_t stream);
+int msda_prep_backward_f64(const double *grad_loc, const double *grad_aw, const double *aw,
+                           const double *offsets, int64_t off_stride, const double *ref, int ref_dim,
+                           const int64_t *shapes_host, int N, int Lq, int M, int L, int P,
+                           double *grad_offsets, int64_t goff_stride, double *grad_logits, int64_t glog_stride,
+                           double *grad_ref, msda_stream_t stream);
+int msda_mask_rows_f32(float *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);
+int msda_mask_rows_f64(double *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);
+int msda_mask_rows_bf16(uint16_t *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,8 @@ SYMBOLS = [
     "msda_profile_enable", "msda_profile_collect", "msda_tiled_plan", "msda_levelsum_plan", "msda_debug_stamps", "msda_debug_stats",
     "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64",
     "msda_forward_bf16", "msda_backward_bf16",
+    "msda_prep_forward_f32", "msda_prep_forward_f64", "msda_prep_backward_f32", "msda_prep_backward_f64",
+    "msda_mask_rows_f32", "msda_mask_rows_f64", "msda_mask_rows_bf16",
 ]
 
 
@@ -76,6 +78,18 @@ def load():
         g = getattr(L, "msda_backward_" + sfx)
         g.argtypes = [vp] * 6 + [ci] * 8 + [vp, vp, vp, vp, vp, vp]
         g.restype = ci
+    i64 = ctypes.c_int64
+    for sfx in ("f32", "f64"):
+        f = getattr(L, "msda_prep_forward_" + sfx)
+        f.argtypes = [vp, i64, vp, i64, vp, ci, vp] + [ci] * 5 + [vp, vp, vp]
+        f.restype = ci
+        g = getattr(L, "msda_prep_backward_" + sfx)
+        g.argtypes = [vp, vp, vp, vp, i64, vp, ci, vp] + [ci] * 5 + [vp, i64, vp, i64, vp, vp]
+        g.restype = ci
+    for sfx in ("f32", "f64", "bf16"):
+        f = getattr(L, "msda_mask_rows_" + sfx)
+        f.argtypes = [vp, vp, i64, ci, vp]
+        f.restype = ci
     if L.msda_abi_version() != ABI_VERSION:
         raise ImportError(f"{path}: ABI version {L.msda_abi_version()} != expected {ABI_VERSION}; rebuild")
     _lib = L

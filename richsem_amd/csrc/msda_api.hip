@@ -17,6 +17,7 @@
 #include "../../include/richsem_msda.h"
 #include "msda_direct.h"
 #include "msda_levelsum.h"
+#include "msda_prep.h"
 #include "msda_psb.h"
 #include "msda_rps.h"
 #include "msda_tiled.h"
@@ -920,6 +921,82 @@ int backward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const i
     return MSDA_OK;
 }
 
+// ---- module-level element-wise kernels (msda_prep.h) -----------------------------------------------------------------------------
+int prep_geom(msda::PrepGeom &g, int N, int Lq, int M, int L, int P, int ref_dim, const int64_t *shapes_host)
+{
+    if (N <= 0 || Lq <= 0 || M <= 0 || L <= 0 || P <= 0) return fail(MSDA_ERR_BAD_DIMS, "non-positive dimension");
+    if (L > msda::kPrepMaxL || L * P > 64) return fail(MSDA_ERR_BAD_DIMS, "L (%d) > %d or L*P (%d) > 64", L, msda::kPrepMaxL, L * P);
+    if (ref_dim != 2 && ref_dim != 4) return fail(MSDA_ERR_BAD_DIMS, "Last dim of reference_points must be 2 or 4, but get %d instead.", ref_dim);
+    if (!shapes_host) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    g = msda::PrepGeom{};
+    g.N = N; g.Lq = Lq; g.M = M; g.L = L; g.P = P; g.ref_dim = ref_dim;
+    int G = 1;
+    while (G < L * P) G <<= 1;
+    g.G = G;
+    for (int l = 0; l < L; ++l) {
+        g.H[l] = (float)shapes_host[2 * l];
+        g.W[l] = (float)shapes_host[2 * l + 1];
+    }
+    return MSDA_OK;
+}
+
+template <typename T>
+int prep_forward_impl(const T *offsets, int64_t off_stride, const T *logits, int64_t log_stride, const T *ref, int ref_dim,
+                      const int64_t *shapes_host, int N, int Lq, int M, int L, int P, T *loc, T *aw, msda_stream_t stream_)
+{
+    g_err[0] = 0;
+    if (!offsets || !logits || !ref || !loc || !aw) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    msda::PrepGeom g;
+    if (int rc = prep_geom(g, N, Lq, M, L, P, ref_dim, shapes_host)) return rc;
+    if (off_stride < (int64_t)M * L * P * 2 || log_stride < (int64_t)M * L * P)
+        return fail(MSDA_ERR_BAD_DIMS, "row stride smaller than a row (offsets %lld, logits %lld)", (long long)off_stride, (long long)log_stride);
+    g.off_stride = off_stride;
+    g.log_stride = log_stride;
+    const int64_t items = (int64_t)N * Lq * M, per_block = 256 / g.G;
+    const int grid = (int)std::min<int64_t>((items + per_block - 1) / per_block, 8192);
+    hipLaunchKernelGGL(msda::prep_forward_kernel<T>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_), offsets, logits, ref, loc, aw, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch of the location / softmax kernel");
+    return MSDA_OK;
+}
+
+template <typename T>
+int prep_backward_impl(const T *grad_loc, const T *grad_aw, const T *aw, const T *offsets, int64_t off_stride, const T *ref,
+                       int ref_dim, const int64_t *shapes_host, int N, int Lq, int M, int L, int P, T *grad_offsets,
+                       int64_t goff_stride, T *grad_logits, int64_t glog_stride, T *grad_ref, msda_stream_t stream_)
+{
+    g_err[0] = 0;
+    if (!grad_loc || !grad_aw || !aw || !ref || !grad_offsets || !grad_logits || (ref_dim == 4 && grad_ref && !offsets))
+        return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    msda::PrepGeom g;
+    if (int rc = prep_geom(g, N, Lq, M, L, P, ref_dim, shapes_host)) return rc;
+    if (goff_stride < (int64_t)M * L * P * 2 || glog_stride < (int64_t)M * L * P)
+        return fail(MSDA_ERR_BAD_DIMS, "row stride smaller than a row");
+    g.off_stride = off_stride;
+    g.goff_stride = goff_stride;
+    g.glog_stride = glog_stride;
+    const int64_t items = (int64_t)N * Lq, per_block = 256 / g.G;
+    const int grid = (int)std::min<int64_t>((items + per_block - 1) / per_block, 8192);
+    hipLaunchKernelGGL(msda::prep_backward_kernel<T>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_), grad_loc, grad_aw,
+                       aw, offsets, ref, grad_offsets, grad_logits, grad_ref, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch of the location / softmax backward kernel");
+    return MSDA_OK;
+}
+
+template <typename T>
+int mask_rows_impl(T *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream_)
+{
+    g_err[0] = 0;
+    if (!x || !mask) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    if (rows <= 0 || row_elems <= 0) return fail(MSDA_ERR_BAD_DIMS, "non-positive dimension");
+    const int grid = (int)std::min<int64_t>((rows + 255) / 256, 4096);
+    hipLaunchKernelGGL(msda::mask_rows_kernel<T>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_), x, mask, (long long)rows, row_elems);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch of the padding-mask kernel");
+    return MSDA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1142,6 +1219,38 @@ int msda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes, con
                               attn_weight, reinterpret_cast<const msda::bf16_t *>(grad_out), N, S, M, D, L, Lq, P, im2col_step,
                               reinterpret_cast<msda::bf16_t *>(grad_value), grad_sampling_loc, grad_attn_weight, shapes_host,
                               level_start_host, stream);
+}
+
+#define MSDA_PREP_EXPORTS(SFX, T)                                                                                                  \
+    int msda_prep_forward_##SFX(const T *offsets, int64_t off_stride, const T *logits, int64_t log_stride, const T *ref, int ref_dim, \
+                                const int64_t *shapes_host, int N, int Lq, int M, int L, int P, T *loc, T *aw, msda_stream_t stream)  \
+    {                                                                                                                             \
+        return prep_forward_impl<T>(offsets, off_stride, logits, log_stride, ref, ref_dim, shapes_host, N, Lq, M, L, P, loc, aw,    \
+                                    stream);                                                                                      \
+    }                                                                                                                             \
+    int msda_prep_backward_##SFX(const T *grad_loc, const T *grad_aw, const T *aw, const T *offsets, int64_t off_stride,           \
+                                 const T *ref, int ref_dim, const int64_t *shapes_host, int N, int Lq, int M, int L, int P,         \
+                                 T *grad_offsets, int64_t goff_stride, T *grad_logits, int64_t glog_stride, T *grad_ref,            \
+                                 msda_stream_t stream)                                                                            \
+    {                                                                                                                             \
+        return prep_backward_impl<T>(grad_loc, grad_aw, aw, offsets, off_stride, ref, ref_dim, shapes_host, N, Lq, M, L, P,         \
+                                     grad_offsets, goff_stride, grad_logits, glog_stride, grad_ref, stream);                       \
+    }
+MSDA_PREP_EXPORTS(f32, float)
+MSDA_PREP_EXPORTS(f64, double)
+#undef MSDA_PREP_EXPORTS
+
+int msda_mask_rows_f32(float *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream)
+{
+    return mask_rows_impl<float>(x, mask, rows, row_elems, stream);
+}
+int msda_mask_rows_f64(double *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream)
+{
+    return mask_rows_impl<double>(x, mask, rows, row_elems, stream);
+}
+int msda_mask_rows_bf16(uint16_t *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream)
+{
+    return mask_rows_impl<uint16_t>(x, mask, rows, row_elems, stream);
 }
 
 }  // extern "C"

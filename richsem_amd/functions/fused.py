@@ -1,0 +1,104 @@
+"""Fused module path: what the reference module does with half a dozen PyTorch ops around the
+operator (reference models/richsem/ops/modules/ms_deform_attn.py:94-109) as ONE kernel each way, plus an in-place padding
+mask -- kernels in richsem_amd/csrc/msda_prep.h, C ABI ``msda_prep_forward_* / msda_prep_backward_* / msda_mask_rows_*``.
+
+``MSDeformAttnFusedFunction.apply(value, spatial_shapes, level_start_index, qproj, reference_points, n_heads, n_levels,
+n_points, im2col_step)`` takes the RAW output of the offset and attention-weight projections -- one tensor
+(N, Lq, M*L*P*2 + M*L*P), i.e. one 256 -> 384 GEMM for RichSem -- and returns the operator's output; its backward returns the
+gradient of that one tensor (one GEMM backward), of value and of the reference points.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import MultiScaleDeformableAttention as MSDA
+from .. import _lib
+
+_SFX = {torch.float32: "f32", torch.float64: "f64"}
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class MaskRows(Function):
+    """value.masked_fill(mask[..., None], 0) IN PLACE: only the rows of padded pixels are touched (reference :95-96)."""
+
+    @staticmethod
+    def forward(ctx, value, mask):
+        assert value.is_contiguous() and mask.dtype == torch.bool
+        mask = mask.contiguous()
+        sfx = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}[value.dtype]
+        rows = mask.numel()
+        with torch.cuda.device(value.device):
+            _lib.check(getattr(_lib.load(), "msda_mask_rows_" + sfx)(
+                value.data_ptr(), mask.view(torch.uint8).data_ptr(), rows, value.numel() // rows, _stream(value)))
+        ctx.mark_dirty(value)
+        ctx.save_for_backward(mask)
+        return value
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        (mask,) = ctx.saved_tensors
+        grad = grad.contiguous().clone()
+        sfx = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}[grad.dtype]
+        rows = mask.numel()
+        with torch.cuda.device(grad.device):
+            _lib.check(getattr(_lib.load(), "msda_mask_rows_" + sfx)(
+                grad.data_ptr(), mask.view(torch.uint8).data_ptr(), rows, grad.numel() // rows, _stream(grad)))
+        return grad, None
+
+
+class MSDeformAttnFusedFunction(Function):
+    @staticmethod
+    def forward(ctx, value, spatial_shapes, level_start_index, qproj, reference_points, n_heads, n_levels, n_points,
+                im2col_step):
+        if not value.is_cuda:
+            raise RuntimeError("Not implemented on the CPU")
+        if qproj.dtype not in _SFX or reference_points.dtype != qproj.dtype:
+            raise RuntimeError(f"fused MSDeformAttn path: float32 / float64 projections, got {qproj.dtype}")
+        N, Lq = qproj.shape[0], qproj.shape[1]
+        M, L, P = n_heads, n_levels, n_points
+        n_off, n_log = M * L * P * 2, M * L * P
+        if qproj.shape[-1] != n_off + n_log or not qproj.is_contiguous():
+            raise RuntimeError("qproj must be a contiguous (N, Lq, M*L*P*3) tensor: offsets, then attention logits")
+        ref = reference_points.contiguous()
+        if ref.shape[:3] != (N, Lq, L) or ref.shape[-1] not in (2, 4):
+            raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {ref.shape[-1]} instead.")
+        sh, _ = MSDA._host_mirror(spatial_shapes, level_start_index)
+        lib = _lib.load()
+        loc = torch.empty((N, Lq, M, L, P, 2), dtype=qproj.dtype, device=qproj.device)
+        aw = torch.empty((N, Lq, M, L, P), dtype=qproj.dtype, device=qproj.device)
+        stride, esz = qproj.shape[-1], qproj.element_size()
+        with torch.cuda.device(qproj.device):
+            _lib.check(getattr(lib, "msda_prep_forward_" + _SFX[qproj.dtype])(
+                qproj.data_ptr(), stride, qproj.data_ptr() + n_off * esz, stride, ref.data_ptr(), ref.shape[-1],
+                sh.ctypes.data, N, Lq, M, L, P, loc.data_ptr(), aw.data_ptr(), _stream(qproj)))
+        out = MSDA.ms_deform_attn_forward(value, spatial_shapes, level_start_index, loc, aw, im2col_step)
+        ctx.save_for_backward(value, spatial_shapes, level_start_index, loc, aw, ref, qproj)
+        ctx.dims = (M, L, P, im2col_step)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, spatial_shapes, level_start_index, loc, aw, ref, qproj = ctx.saved_tensors
+        M, L, P, step = ctx.dims
+        grad_value, grad_loc, grad_aw = MSDA.ms_deform_attn_backward(
+            value, spatial_shapes, level_start_index, loc, aw, grad_output.contiguous(), step)
+        N, Lq = qproj.shape[0], qproj.shape[1]
+        n_off = M * L * P * 2
+        sh, _ = MSDA._host_mirror(spatial_shapes, level_start_index)
+        grad_qproj = torch.empty_like(qproj)
+        grad_ref = torch.empty_like(ref) if ctx.needs_input_grad[4] else None
+        stride, esz = qproj.shape[-1], qproj.element_size()
+        with torch.cuda.device(qproj.device):
+            _lib.check(getattr(_lib.load(), "msda_prep_backward_" + _SFX[qproj.dtype])(
+                grad_loc.data_ptr(), grad_aw.data_ptr(), aw.data_ptr(), qproj.data_ptr(), stride, ref.data_ptr(),
+                ref.shape[-1], sh.ctypes.data, N, Lq, M, L, P, grad_qproj.data_ptr(), stride,
+                grad_qproj.data_ptr() + n_off * esz, stride,
+                ctypes.c_void_p(grad_ref.data_ptr()) if grad_ref is not None else None, _stream(qproj)))
+        return grad_value, None, None, grad_qproj, grad_ref, None, None, None, None

@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions import MSDeformAttnFunction
+from ..functions import MaskRows, MSDeformAttnFunction, MSDeformAttnFusedFunction
 
 
 def _is_power_of_2(n):
@@ -37,6 +37,9 @@ class MSDeformAttn(nn.Module):
                           "fastest gfx950 kernels; other sizes run on the generic kernels.")
         self.im2col_step = 64
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        # True (default): one GEMM for offsets + attention logits, softmax / location arithmetic / padding mask in the library's
+        # own kernels (functions/fused.py).  False: the reference's op-by-op sequence.  Same parameters, same results.
+        self.fused = True
 
         self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
         self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
@@ -70,6 +73,22 @@ class MSDeformAttn(nn.Module):
         S = input_flatten.shape[1]
         H, L, P = self.n_heads, self.n_levels, self.n_points
         assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == S
+
+        if self.fused and query.is_cuda and query.dtype in (torch.float32, torch.float64) and L * P <= 64 and L <= 16:
+            if reference_points.shape[-1] not in (2, 4):
+                raise ValueError(
+                    f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
+            value = self.value_proj(input_flatten)
+            if input_padding_mask is not None:
+                value = MaskRows.apply(value, input_padding_mask)
+            # offsets and attention logits from ONE projection (the two weight matrices stacked: 256 -> 384 for RichSem)
+            weight = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
+            bias = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
+            qproj = F.linear(query, weight, bias)
+            out = MSDeformAttnFusedFunction.apply(value.view(N, S, H, self.d_model // H), input_spatial_shapes,
+                                                  input_level_start_index, qproj, reference_points.to(qproj.dtype), H, L, P,
+                                                  self.im2col_step)
+            return self.output_proj(out)
 
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:

@@ -19,8 +19,9 @@ def rel(a, b):
     return float(np.abs(a.detach().cpu().numpy() - b).max() / (np.abs(b).max() + 1e-300))
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("case", ["module_encoder_ref2d", "module_decoder_ref4d"])
-def test_module_matches_reference_module(case):
+def test_module_matches_reference_module(case, fused):
     z = np.load(os.path.join(GOLDEN, case + ".npz"))
     params = {k[len("param."):]: z[k] for k in z.files if k.startswith("param.") and not k.endswith(".grad")}
     C = params["value_proj.weight"].shape[0]
@@ -29,6 +30,7 @@ def test_module_matches_reference_module(case):
     mod = MSDeformAttn(C, L, heads, 4).double()
     mod.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})      # same state-dict keys as the reference
     mod = mod.cuda()
+    mod.fused = fused   # one GEMM + the library's softmax / location / mask kernels, or the reference's op-by-op sequence
     query = torch.from_numpy(z["query"]).cuda().requires_grad_(True)
     src = torch.from_numpy(z["src"]).cuda().requires_grad_(True)
     out = mod(query, torch.from_numpy(z["reference_points"]).cuda(), src, torch.from_numpy(z["shapes"]).cuda(),
@@ -54,3 +56,66 @@ def test_module_float32_tiled_path_close_to_float64():
     assert rel(out, z["out"]) < 1e-4
     out.backward(f("grad_out").float())
     assert rel(query.grad, z["grad_query"]) < 1e-4 and rel(src.grad, z["grad_src"]) < 1e-4
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+@pytest.mark.parametrize("dims", [dict(C=32, L=4, H=4, P=4), dict(C=24, L=3, H=2, P=3), dict(C=16, L=1, H=1, P=5)])
+def test_fused_path_equals_op_by_op_path(dims, ref_dim):
+    """Fused module path (one projection GEMM, softmax + location arithmetic + padding mask in msda_prep.h kernels) against
+    the reference's op-by-op sequence run through PyTorch autograd: output, input gradients, every parameter gradient and
+    the reference-point gradient -- fp64, power-of-two and odd L*P, 2-d and 4-d reference points."""
+    torch.manual_seed(1)
+    C, L, H, P = dims["C"], dims["L"], dims["H"], dims["P"]
+    shapes = torch.as_tensor([(9, 7), (5, 4), (3, 2), (2, 2)][:L], dtype=torch.long, device="cuda")
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S, N, Lq = int(shapes.prod(1).sum()), 2, 37
+    a = MSDeformAttn(C, L, H, P).double().cuda()
+    with torch.no_grad():
+        a.sampling_offsets.weight.normal_(0, 0.05)
+        a.attention_weights.weight.normal_(0, 0.3)
+        a.attention_weights.bias.normal_(0, 0.3)
+    b_ = MSDeformAttn(C, L, H, P).double().cuda()
+    b_.load_state_dict(a.state_dict())
+    a.fused, b_.fused = True, False
+    query = torch.randn(N, Lq, C, dtype=torch.float64, device="cuda")
+    src = torch.randn(N, S, C, dtype=torch.float64, device="cuda")
+    ref = torch.rand(N, Lq, L, ref_dim, dtype=torch.float64, device="cuda") * 0.8 + 0.1
+    mask = torch.rand(N, S, device="cuda") < 0.1
+    gout = torch.randn(N, Lq, C, dtype=torch.float64, device="cuda")
+    res = []
+    for mod in (a, b_):
+        q, s_, r = query.clone().requires_grad_(True), src.clone().requires_grad_(True), ref.clone().requires_grad_(True)
+        out = mod(q, r, s_, shapes, lsi, mask)
+        out.backward(gout)
+        res.append([out.detach(), q.grad, s_.grad, r.grad] + [p.grad for p in mod.parameters()])
+    for x, y in zip(*res):
+        scale = float(y.abs().max()) + 1e-30
+        assert float((x - y).abs().max()) / scale < 1e-9
+
+
+def test_fused_path_float32_full_size_encoder_call():
+    """fp32, BASELINE's encoder call through the fused module path against the op-by-op path (window kernels either way)."""
+    torch.manual_seed(0)
+    from richsem_amd import workload as W
+    call = W.call_E(1)
+    shapes, lsi = W.level_tensors(call, "cuda")
+    a = MSDeformAttn(256, 4, 8, 4).cuda()
+    with torch.no_grad():
+        a.sampling_offsets.weight.normal_(0, 0.01)
+        a.attention_weights.weight.normal_(0, 0.1)
+    b_ = MSDeformAttn(256, 4, 8, 4).cuda()
+    b_.load_state_dict(a.state_dict())
+    a.fused, b_.fused = True, False
+    query = torch.randn(1, call.Lq, 256, device="cuda")
+    src = torch.randn(1, call.S, 256, device="cuda")
+    ref = W.encoder_reference_points(call).cuda()[None, :, None, :].expand(1, call.Lq, 4, 2).contiguous()
+    mask = torch.zeros(1, call.S, dtype=torch.bool, device="cuda")
+    mask[:, ::173] = True
+    outs = []
+    for mod in (a, b_):
+        q = query.clone().requires_grad_(True)
+        out = mod(q, ref, src, shapes, lsi, mask)
+        out.square().mean().backward()
+        outs.append((out.detach(), q.grad, mod.sampling_offsets.weight.grad, mod.attention_weights.bias.grad))
+    for x, y in zip(*outs):
+        assert float((x - y).abs().max()) <= 2e-4 * float(y.abs().max()) + 1e-7
