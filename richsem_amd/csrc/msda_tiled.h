@@ -22,6 +22,7 @@
 // Semantics: identical to msda_direct.h (spec: reference ms_deform_im2col_cuda.cuh:33-159, 237-403).
 #pragma once
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -131,17 +132,18 @@ struct TileHeader {
 };
 static_assert(sizeof(TileHeader) % 16 == 0, "windows must stay 16-byte aligned behind the header");
 
+// Set by msda_set_option (any thread), read by every launch (any thread): plain atomics, like the other options.
 struct TiledOptions {
-    int region_px = 20;   // finest-level pixels per region side (swept on MI355X: 20 beats 16 by ~15 %; larger does not fit LDS)
-    int margin = 6;
-    int bwd_halves = 0;  // backward location/attention gradients: 0 = 32 channels at once (faster as measured), 1 = two 16-channel passes
-    int persist = 512;   // 0 = one workgroup per work item; n > 0 = at most n workgroups (n/2 for the 1024-thread kernels)
-                         // walking the items (2 x 256 CUs by default: no per-item launch ramp)
-    int grow = 1;    // 1 = windows grow into the LDS their phase leaves unused (per-level margins)
-    int accum = 2;   // grad_value: 0 = f64 LDS atomic window, 1 = integer block-floating-point window, 2 = sorted reduction
-    int dbg = 0;
-    unsigned long long *stamps = nullptr;
-    unsigned *stats = nullptr;   // diagnostic override of the locality counter (msda_debug_stats)
+    std::atomic<int> region_px{20};   // finest-level pixels per region side (swept on MI355X: 20 beats 16 by ~15 %; larger does not fit LDS)
+    std::atomic<int> margin{6};
+    std::atomic<int> bwd_halves{0};   // backward location/attention gradients: 0 = 32 channels at once (faster as measured), 1 = two 16-channel passes
+    std::atomic<int> persist{512};    // 0 = one workgroup per work item; n > 0 = at most n workgroups (n/2 for the 1024-thread kernels)
+                                      // walking the items (2 x 256 CUs by default: no per-item launch ramp)
+    std::atomic<int> grow{1};         // 1 = windows grow into the LDS their phase leaves unused (per-level margins)
+    std::atomic<int> accum{2};        // grad_value: 0 = f64 LDS atomic window, 1 = integer block-floating-point window, 2 = sorted reduction
+    std::atomic<int> dbg{0};
+    std::atomic<unsigned long long *> stamps{nullptr};
+    std::atomic<unsigned *> stats{nullptr};   // diagnostic override of the locality counter (msda_debug_stats)
 };
 inline TiledOptions &tiled_options()
 {
@@ -1798,7 +1800,7 @@ inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, c
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // grad_sampling_loc, grad_attn_weight: gather from LDS windows of value
-    const int ggrid = persistent_grid(pg.grid * pg.g.nphases, halves ? tiled_options().persist : tiled_options().persist / 2,
+    const int ggrid = persistent_grid(pg.grid * pg.g.nphases, halves ? tiled_options().persist.load() : tiled_options().persist.load() / 2,
                                       pg.g.nphases);
     hipLaunchKernelGGL(kern, dim3(ggrid), dim3(halves ? 512 : 1024), pg.lds_bytes, stream, value, loc, aw, grad_out,
                        (float *)nullptr, grad_loc, grad_aw, pg.g);

@@ -231,12 +231,13 @@ def test_autograd_function_gradcheck_like_reference():
     assert torch.autograd.gradcheck(MSDeformAttnFunction.apply, (value, shapes, lsi, loc, aw, 2))
 
 
-@pytest.mark.parametrize("which", ["E", "Dd"])
-def test_full_size_properties(which):
-    """BASELINE.json's full sizes, checked through properties that need no oracle run:
-    linearity in value, the adjoint identity <out(v), g> = <v, grad_value(g)>, constant-field reproduction,
-    and agreement of the two kernel variants."""
-    call = {"E": W.call_E, "Dd": W.call_Dd}[which](2)
+@pytest.mark.parametrize("which,n_images", [("E", 2), ("Dd", 2), ("Em", 2), ("E", 1), ("Dd", 1)])
+def test_full_size_properties(which, n_images):
+    """BASELINE.json's full sizes -- configs[1..3] (E, Dd, and the 1280x1280 mosaic step Em, S = 34000) at N = 2 and the
+    bs = 1 per GPU shape of configs[4] (N = 1: 8 (image, head) pairs = exactly one round of XCDs) -- checked through
+    properties that need no oracle run: linearity in value, the adjoint identity <out(v), g> = <v, grad_value(g)>,
+    constant-field reproduction, and agreement of all kernel variants."""
+    call = {"E": W.call_E, "Dd": W.call_Dd, "Em": W.call_Em}[which](n_images)
     t = {k: v.cuda() for k, v in W.make_inputs(call, "init", seed=0).items()}
     f = lambda v: MSDA.ms_deform_attn_forward(v, t["shapes"], t["lsi"], t["loc"], t["aw"], 64)
     out = f(t["value"])
