@@ -352,6 +352,7 @@ hipError_t launch_levelsum<float>(const Problem &pb, const float *loc, const flo
     // the P4 form loads a level's four locations / weights as 16-B vectors: only for 16-B aligned tensors (the ABI asks
     // for element alignment only)
     const bool vec = pb.P == 4 && is_aligned(loc, 16) && is_aligned(aw, 16);
+    lg.dbg = msda::tiled_options().dbg & 7;
     auto kern = vec ? &msda::bwd_levelsum_kernel<true> : &msda::bwd_levelsum_kernel<false>;
     hipError_t e = msda::set_lds_limit(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
@@ -1023,6 +1024,7 @@ int msda_set_option(const char *key, int value)
     if (key && !strcmp(key, "tile_persist") && value >= 0 && value <= 65536) { msda::tiled_options().persist = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_gather_halves") && (value == 0 || value == 1)) { msda::tiled_options().bwd_halves = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_levelsum") && (value == 0 || value == 1)) { g_levelsum = value; return MSDA_OK; }
+    if (key && !strcmp(key, "levelsum_lds_kb") && value >= 8 && value <= 150) { msda::levelsum_lds_kb() = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_grow") && (value == 0 || value == 1)) { msda::tiled_options().grow = value; return MSDA_OK; }
     if (key && !strcmp(key, "locality_monitor") && (value == 0 || value == 1)) {
         g_monitor_on = value;
@@ -1055,6 +1057,7 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "tile_persist")) { *value = msda::tiled_options().persist; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_gather_halves")) { *value = msda::tiled_options().bwd_halves; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_levelsum")) { *value = g_levelsum; return MSDA_OK; }
+    if (key && !strcmp(key, "levelsum_lds_kb")) { *value = msda::levelsum_lds_kb(); return MSDA_OK; }
     if (key && !strcmp(key, "tile_grow")) { *value = msda::tiled_options().grow; return MSDA_OK; }
     if (key && !strcmp(key, "locality_monitor")) { *value = g_monitor_on; return MSDA_OK; }
     if (key && !strcmp(key, "locality_share_ppm")) { *value = g_last_share_ppm; return MSDA_OK; }   // read-only

@@ -10,19 +10,27 @@
 // Semantics: reference ms_deform_im2col_cuda.cuh:87-159 (the grad_value part), products formed in fp32 as there.
 #pragma once
 
+#include <atomic>
+
 #include "msda_common.h"
 
 namespace msda {
 
 constexpr int kLsChan = 4;          // channels per slice = lanes per sampling point
 constexpr int kLsThreads = 1024;
-constexpr int kLsMaxLevels = 16;    // (level, row band) entries one launch can take
+constexpr int kLsMaxLevels = 32;    // (level, row band) entries one launch can take
 constexpr int kLsUnroll = 4;        // points in flight per lane group
 constexpr int kLsLdsBudget = 150 * 1024;
+inline std::atomic<int> &levelsum_lds_kb()   // window size: 150 KB = one workgroup per CU, 75 KB = two
+{
+    static std::atomic<int> kb{150};
+    return kb;
+}
 
 struct LevelSumGeom {
     int N, S, M, D, L, Lq, P;
     int nlev, nslices;   // entries, channel slices
+    int dbg;             // diagnostic (wrong results): 1 skip the walk, 2 skip the flush, 4 skip zeroing
     // entry = a band of rows [r0, r0 + nr) of level lev (the whole level when it fits LDS)
     int lev[kLsMaxLevels], H[kLsMaxLevels], W[kLsMaxLevels], start[kLsMaxLevels], r0[kLsMaxLevels], nr[kLsMaxLevels];
 };
@@ -41,6 +49,7 @@ inline unsigned plan_levelsum(int N, int S, int M, int D, int L, int Lq, int P, 
     lds_bytes = 0;
     if (L > 32 || D > 128 || (int64_t)Lq * P > 1048576) { g = LevelSumGeom{}; return 0; }
     const size_t px_bytes = (size_t)kLsChan * sizeof(double);
+    const size_t budget = std::min<size_t>(kLsLdsBudget, (size_t)std::max(8, levelsum_lds_kb().load()) * 1024);
     for (int all = 1; all >= 0; --all) {
         g = LevelSumGeom{};
         g.N = N; g.S = S; g.M = M; g.D = D; g.L = L; g.Lq = Lq; g.P = P;
@@ -51,13 +60,13 @@ inline unsigned plan_levelsum(int N, int S, int M, int D, int L, int Lq, int P, 
         for (int l = 0; l < L && ok; ++l) {
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
             const int64_t px = (int64_t)H * W;
-            const bool whole = px * px_bytes <= (size_t)kLsLdsBudget;
+            const bool whole = px * px_bytes <= budget;
             if (!all && (!whole || (int64_t)Lq * P < 2 * px)) continue;
-            const int rows_max = (int)(kLsLdsBudget / (px_bytes * W));   // rows of this level one window holds
+            const int rows_max = (int)(budget / (px_bytes * W));   // rows of this level one window holds
             if (rows_max < 1) { ok = false; break; }
             const int bands = whole ? 1 : (H + rows_max - 1) / rows_max;
             const int rows = (H + bands - 1) / bands;
-            if (bands > 8 || g.nlev + bands > kLsMaxLevels) { ok = false; break; }
+            if (bands > 16 || g.nlev + bands > kLsMaxLevels) { ok = false; break; }
             for (int r0 = 0; r0 < H; r0 += rows) {
                 const int e = g.nlev++;
                 g.lev[e] = l; g.H[e] = H; g.W[e] = W; g.start[e] = (int)lsi[l];
@@ -104,27 +113,56 @@ __global__ __launch_bounds__(kLsThreads) void bwd_levelsum_kernel(const float *_
     const int ch = slice * kLsChan + j;
     const bool has_ch = ch < g.D;
 
-    for (int e = tid; e < npx * kLsChan; e += kLsThreads) win[e] = 0.0;
+    if (!(g.dbg & 4)) for (int e = tid; e < npx * kLsChan; e += kLsThreads) win[e] = 0.0;
     __syncthreads();
 
     const int LP = g.L * g.P;
     // query-major walk: a lane group takes a query and its P points of this level (kLsUnroll at a time, all loads first) -- no
     // index divisions in the loop, grad_out read once per query
-    for (int q = grp; q < g.Lq; q += kGroups) {
+    for (int q = grp; q < ((g.dbg & 1) ? 0 : g.Lq); q += kGroups) {
         const unsigned item = (unsigned)((b * g.Lq + q) * g.M + m);
         const unsigned pt0 = item * (unsigned)LP + (unsigned)(l * g.P);
         const float go = has_ch ? ld1(grad_out + item * (unsigned)g.D + ch) : 0.f;
-        for (int p0 = 0; p0 < (P4 ? 4 : g.P); p0 += kLsUnroll) {
+        if (P4) {
+            // Lane j of the group resolves point j ONCE and the group shares it by quad broadcasts (DPP); each lane then adds
+            // its own channel of the four corners -- the four lanes of a group still hit four consecutive doubles.
+            static_assert(kLsChan == 4, "one quad per query");
+            const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * (pt0 + (unsigned)j));
+            const float a = aw[pt0 + (unsigned)j];
+            const float h_im = xy.y * (float)H - 0.5f, w_im = xy.x * (float)W - 0.5f;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)hf, w_low = (int)wf;
+            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+            const bool top = h_low >= r0 && h_low < r0 + nr, bot = h_low + 1 >= r0 && h_low + 1 < r0 + nr;
+            const bool alive = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W && (top || bot);
+            const bool lef = w_low >= 0, rig = w_low + 1 <= W - 1;
+            const int rt = (top ? h_low : h_low + 1) - r0, rb = (bot ? h_low + 1 : h_low) - r0;
+            const int cl = lef ? w_low : w_low + 1, cr = rig ? w_low + 1 : w_low;
+            // element offsets of the four corners (clamped to valid addresses) and their weights (0 for a corner that does not count)
+            const int my_o[4] = {(rt * W + cl) * kLsChan, (rt * W + cr) * kLsChan, (rb * W + cl) * kLsChan, (rb * W + cr) * kLsChan};
+            const float my_w[4] = {top && lef ? hh * hw : 0.f, top && rig ? hh * lw : 0.f, bot && lef ? lh * hw : 0.f, bot && rig ? lh * lw : 0.f};
+#define LS_BCAST_I(V, K) __builtin_amdgcn_update_dpp(0, (V), (K) * 0x55, 0xF, 0xF, true)
+#define LS_BCAST_F(V, K) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(V), (K) * 0x55, 0xF, 0xF, true))
+#define LS_POINT(K)                                                                                     \
+    if (LS_BCAST_I((int)alive, K)) {                                                                    \
+        const float ga_ = go * LS_BCAST_F(a, K); /* top_grad * attn_weight (ms_deform_im2col_cuda.cuh:117) */ \
+        atomicAdd(win + LS_BCAST_I(my_o[0], K) + j, (double)(LS_BCAST_F(my_w[0], K) * ga_));            \
+        atomicAdd(win + LS_BCAST_I(my_o[1], K) + j, (double)(LS_BCAST_F(my_w[1], K) * ga_));            \
+        atomicAdd(win + LS_BCAST_I(my_o[2], K) + j, (double)(LS_BCAST_F(my_w[2], K) * ga_));            \
+        atomicAdd(win + LS_BCAST_I(my_o[3], K) + j, (double)(LS_BCAST_F(my_w[3], K) * ga_));            \
+    }
+            LS_POINT(0)
+            LS_POINT(1)
+            LS_POINT(2)
+            LS_POINT(3)
+#undef LS_POINT
+#undef LS_BCAST_I
+#undef LS_BCAST_F
+            continue;
+        }
+        for (int p0 = 0; p0 < g.P; p0 += kLsUnroll) {
             float x[kLsUnroll], y[kLsUnroll], ga[kLsUnroll];
-            if (P4) {   // 32 B of locations + 16 B of weights, aligned (pt0 is a multiple of 4)
-                static_assert(kLsUnroll == 4, "P4 path loads four points at once");
-                const float4 xy01 = *reinterpret_cast<const float4 *>(loc + 2u * pt0);
-                const float4 xy23 = *reinterpret_cast<const float4 *>(loc + 2u * pt0 + 4);
-                const float4 a4 = *reinterpret_cast<const float4 *>(aw + pt0);
-                x[0] = xy01.x; y[0] = xy01.y; x[1] = xy01.z; y[1] = xy01.w;
-                x[2] = xy23.x; y[2] = xy23.y; x[3] = xy23.z; y[3] = xy23.w;
-                ga[0] = go * a4.x; ga[1] = go * a4.y; ga[2] = go * a4.z; ga[3] = go * a4.w;
-            } else {
+            {
 #pragma unroll
                 for (int u = 0; u < kLsUnroll; ++u) {
                     const bool live = p0 + u < g.P;
@@ -163,7 +201,7 @@ __global__ __launch_bounds__(kLsThreads) void bwd_levelsum_kernel(const float *_
 
     // every pixel of the slice, once: 16 B per lane group
     TV *dst = grad_value + ((int64_t)(b * g.S + g.start[li] + r0 * W) * g.M + m) * g.D + ch;
-    if (has_ch)
+    if (has_ch && !(g.dbg & 2))
         for (int px = grp; px < npx; px += kGroups) dst[(int64_t)px * g.M * g.D] = to_storage<TV, float>((float)win[px * kLsChan + j]);
 }
 

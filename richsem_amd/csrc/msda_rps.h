@@ -538,21 +538,30 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         /* lane k of the quad writes dot k over the entry (all four lanes have read it) */                                       \
         reinterpret_cast<float *>(S->ent + (E))[j4] = rps_quad_transpose_sum(d[0], d[1], d[2], d[3], j4);                        \
     }
+                    // software pipeline: while point e is reduced, the grad_out row of point e + 1 is in flight and the entry of
+                    // point e + 2 is being read (the chain entry -> row address -> row is what a list walk waits for)
+#define RPS_ROW(EN, GA, GB)                                                                                                      \
+    {                                                                                                                            \
+        const float *q_ = grad_out + (int64_t)EN.item * kRpsD;                                                                   \
+        GA = *reinterpret_cast<const float4 *>(q_ + c_lo);                                                                       \
+        GB = *reinterpret_cast<const float4 *>(q_ + c_hi);                                                                       \
+    }
+                    const int e_last = e1 - 1;
+                    RpsEnt enA = S->ent[e], enB = S->ent[min(e + 1, e_last)];
+                    float4 gAa, gAb, gBa, gBb;
+                    RPS_ROW(enA, gAa, gAb)
                     for (; e + 1 < e1; e += 2) {
-                        const RpsEnt en0 = S->ent[e], en1 = S->ent[e + 1];
-                        const float *q0 = grad_out + (int64_t)en0.item * kRpsD;
-                        const float *q1 = grad_out + (int64_t)en1.item * kRpsD;
-                        const float4 g0a = *reinterpret_cast<const float4 *>(q0 + c_lo), g0b = *reinterpret_cast<const float4 *>(q0 + c_hi);
-                        const float4 g1a = *reinterpret_cast<const float4 *>(q1 + c_lo), g1b = *reinterpret_cast<const float4 *>(q1 + c_hi);
-                        RPS_POINT(en0, g0a, g0b, e)
-                        RPS_POINT(en1, g1a, g1b, e + 1)
+                        RPS_ROW(enB, gBa, gBb)
+                        const RpsEnt enA2 = S->ent[min(e + 2, e_last)];
+                        RPS_POINT(enA, gAa, gAb, e)
+                        RPS_ROW(enA2, gAa, gAb)
+                        const RpsEnt enB2 = S->ent[min(e + 3, e_last)];
+                        RPS_POINT(enB, gBa, gBb, e + 1)
+                        enA = enA2;
+                        enB = enB2;
                     }
-                    if (e < e1) {
-                        const RpsEnt en0 = S->ent[e];
-                        const float *q0 = grad_out + (int64_t)en0.item * kRpsD;
-                        const float4 g0a = *reinterpret_cast<const float4 *>(q0 + c_lo), g0b = *reinterpret_cast<const float4 *>(q0 + c_hi);
-                        RPS_POINT(en0, g0a, g0b, e)
-                    }
+                    if (e < e1) RPS_POINT(enA, gAa, gAb, e)
+#undef RPS_ROW
 #undef RPS_POINT
                 }
             }
