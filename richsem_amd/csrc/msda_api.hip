@@ -389,10 +389,12 @@ struct PsbWorkspace {
     size_t far_cap = 0;
     float *gv32 = nullptr;   // bf16 backward: fp32 accumulation buffer for grad_value (rounded to bf16 once)
     size_t gv32_cap = 0;
-    unsigned *rps_bins = nullptr;            // routed backward: queue heads (16) + bin_count + bin_start (+1) + bin_fill
-    size_t rps_bins_cap = 0;
-    unsigned long long *rps_entries = nullptr;   // [cap] entry codes, then [cap] float4 parameters
+    unsigned *rps_bins = nullptr;            // routed backward: queue heads (32 words), bin_count, bin_fill, bin_start (+1) -- laid
+    size_t rps_bins_cap = 0;                 // out by the CAPACITY in bins, so that bin_count stays where it is (and zero)
+    size_t rps_bins_n = 0;                   // capacity in bins
+    msda::RpsRec *rps_entries = nullptr;     // [cap] routed records
     size_t rps_entries_cap = 0;
+    bool rps_dirty = false;                  // a failed launch may have left the bin counters non-zero
 };
 std::mutex g_psb_mu;
 std::map<std::pair<int, hipStream_t>, PsbWorkspace> g_psb_ws;
@@ -475,34 +477,51 @@ hipError_t launch_bwd_psb(const Problem &pb, const float *value, const float *lo
 }
 
 // ---- routed pixel-stationary backward (msda_rps.h) ---------------------------------------------------------------------------
+// The bin counters are zero between calls (the scan kernel re-zeroes them after reading them), so that no call has to clear
+// them first: they are cleared when allocated and after a launch error.
 bool rps_workspace(hipStream_t stream, size_t n_bins, size_t n_entries, PsbWorkspace &out)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     std::lock_guard<std::mutex> lock(g_psb_mu);
     PsbWorkspace &ws = g_psb_ws[std::make_pair(dev, stream)];
-    const size_t want_bins = 32 + (2 * msda::kRpsPad + 1) * n_bins + 8;
-    if (ws.rps_bins_cap < want_bins || ws.rps_entries_cap < n_entries) {
+    if (ws.rps_bins_n < n_bins || ws.rps_entries_cap < n_entries || ws.rps_dirty) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(stream, &cap);
         if (cap != hipStreamCaptureStatusNone) return false;   // no allocation while the stream is being captured
-        if (ws.rps_bins_cap < want_bins) {
+        if (ws.rps_bins_n < n_bins) {
+            const size_t cap_n = n_bins + n_bins / 2 + 64;
+            const size_t want_bins = 32 + (2 * msda::kRpsPad + 1) * cap_n + 8;
             if (ws.rps_bins) (void)hipFree(ws.rps_bins);
             ws.rps_bins = nullptr;
-            ws.rps_bins_cap = 0;
+            ws.rps_bins_cap = ws.rps_bins_n = 0;
             if (hipMalloc(reinterpret_cast<void **>(&ws.rps_bins), want_bins * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
             ws.rps_bins_cap = want_bins;
+            ws.rps_bins_n = cap_n;
+            ws.rps_dirty = true;
+        }
+        if (ws.rps_dirty) {
+            if (hipMemsetAsync(ws.rps_bins, 0, ws.rps_bins_cap * sizeof(unsigned), stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+            ws.rps_dirty = false;
         }
         if (ws.rps_entries_cap < n_entries) {
             if (ws.rps_entries) (void)hipFree(ws.rps_entries);
             ws.rps_entries = nullptr;
             ws.rps_entries_cap = 0;
-            if (hipMalloc(reinterpret_cast<void **>(&ws.rps_entries), n_entries * (sizeof(unsigned long long) + sizeof(float4))) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (hipMalloc(reinterpret_cast<void **>(&ws.rps_entries), n_entries * sizeof(msda::RpsRec)) != hipSuccess) { (void)hipGetLastError(); return false; }
             ws.rps_entries_cap = n_entries;
         }
     }
     out = ws;
     return true;
+}
+
+void rps_mark_dirty(hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_psb_mu);
+    g_psb_ws[std::make_pair(dev, stream)].rps_dirty = true;
 }
 
 // returns hipErrorNotSupported when the plan does not apply or no workspace can be had right now
@@ -518,27 +537,30 @@ hipError_t launch_bwd_rps(const Problem &pb, const float *value, const float *lo
     if (!rps_workspace(stream, (size_t)pl.g.nbins, pl.max_entries, ws)) return hipErrorNotSupported;
     pl.g.ctr = ws.rps_bins;
     pl.g.bin_count = ws.rps_bins + 32;   // (line-aligned)
-    pl.g.bin_fill = pl.g.bin_count + (size_t)pl.g.nbins * msda::kRpsPad;
-    pl.g.bin_start = pl.g.bin_fill + (size_t)pl.g.nbins * msda::kRpsPad;
+    pl.g.bin_fill = pl.g.bin_count + ws.rps_bins_n * msda::kRpsPad;
+    pl.g.bin_start = pl.g.bin_fill + ws.rps_bins_n * msda::kRpsPad;
     pl.g.entries = ws.rps_entries;
-    pl.g.params = reinterpret_cast<float4 *>(ws.rps_entries + ws.rps_entries_cap);
     pl.g.stamps = msda::tiled_options().stamps;
     pl.g.dbg = msda::tiled_options().dbg;
     auto kern = pb.P == 4 ? &msda::rps_tile_kernel<true> : &msda::rps_tile_kernel<false>;
     hipError_t e = msda::set_lds_limit(reinterpret_cast<const void *>(kern), sizeof(msda::RpsLds));
     if (e != hipSuccess) return e;
-    // route passes: one wave per 16 queries of an (image, head); 4 waves per block
+    // route passes: a workgroup (8 waves) per block of queries of an (image, head)
     const int qpw = pb.P <= 4 ? 16 : (pb.P <= 8 ? 8 : (pb.P <= 16 ? 4 : (pb.P <= 32 ? 2 : 1)));
-    const int64_t r_units = (int64_t)pb.N * pb.M * ((pb.Lq + qpw - 1) / qpw);
-    const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>((r_units + 3) / 4, 8 * (int64_t)cu_count()));
-    hipLaunchKernelGGL(msda::rps_prep_kernel, dim3(128), dim3(256), 0, stream, grad_value, pl.g);
-    hipLaunchKernelGGL(msda::rps_route_kernel<true>, dim3(rgrid), dim3(256), 0, stream, loc, aw, grad_loc, grad_aw, pl.g);
+    const int qpb = qpw * (msda::kRpsRouteThreads / msda::kWave);
+    const int64_t r_items = (int64_t)pb.N * pb.M * ((pb.Lq + qpb - 1) / qpb);
+    const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(r_items, 4 * (int64_t)cu_count()));
+    hipLaunchKernelGGL(msda::rps_route_kernel<true>, dim3(rgrid), dim3(msda::kRpsRouteThreads), 0, stream, loc, aw, grad_value, grad_loc,
+                       grad_aw, pl.g);
     hipLaunchKernelGGL(msda::rps_scan_kernel, dim3(1), dim3(1024), 0, stream, pl.g);
-    hipLaunchKernelGGL(msda::rps_route_kernel<false>, dim3(rgrid), dim3(256), 0, stream, loc, aw, grad_loc, grad_aw, pl.g);
-    const int grid = (cu_count() / msda::kXcds) * msda::kXcds * (1024 / msda::kRpsThreads);   // persistent: two 512-thread workgroups per CU
+    hipLaunchKernelGGL(msda::rps_route_kernel<false>, dim3(rgrid), dim3(msda::kRpsRouteThreads), 0, stream, loc, aw, grad_value, grad_loc,
+                       grad_aw, pl.g);
+    const int grid = (cu_count() / msda::kXcds) * msda::kXcds * (1024 / msda::kRpsThreads);   // persistent: one workgroup per CU
     hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 8), dim3(msda::kRpsThreads), sizeof(msda::RpsLds), stream, value, grad_out,
                        grad_value, grad_loc, grad_aw, pl.g);
-    return hipGetLastError();
+    e = hipGetLastError();
+    if (e != hipSuccess) rps_mark_dirty(stream);
+    return e;
 }
 
 template <typename T>

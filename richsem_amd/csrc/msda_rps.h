@@ -38,6 +38,7 @@ constexpr int kRpsMaxL = 4;
 constexpr int kRpsMaxUnits = 448;
 constexpr int kRpsD = 32;
 constexpr int kRpsPad = 32;                     // atomically updated counters sit on lines of their own
+constexpr int kRpsQpBits = 19;                  // entry code: query * P + point below this bit (plan: Lq * P < 2^19)
 
 struct RpsLevel {
     int H, W, start;
@@ -49,19 +50,25 @@ struct RpsLevel {
     float inv_TH, inv_TW;   // tile of pixel row r: (int)((r + 0.5f) * inv_TH) -- exact for r < 2^15 (no integer division per point)
 };
 
+// Routed sampling point, as the route pass writes it and the tile kernel streams it.
+//   code = (query * P + point)  |  base-grid index in the tile << 19  |  corners inside the map << 27  |  owner << 31
+// (owner: this tile also forms the point's gradients).  The bin fixes (image, head, level).
+struct alignas(16) RpsRec {
+    unsigned code;
+    float lh, lw, a;   // bilinear fractions, attention weight
+};
+
 struct RpsGeom {
     int N, S, M, Lq, L, P;
     int nunits, ppx;        // work table; pairs per XCD queue = ceil(N*M / 8)
     int bins_per_pair, nbins;
     RpsLevel lv[kRpsMaxL];
     unsigned units[kRpsMaxUnits];   // level | ty << 2 | tx << 8 | slab << 14 | nslab << 22, heaviest first
-    unsigned *ctr;          // workspace: [0..7] per-XCD queue heads
-    unsigned *bin_count;    // [nbins * kRpsPad]  points per bin (count pass); one counter per 128-B line
+    unsigned *ctr;          // workspace: [0..7] per-XCD queue heads (reset by the count pass)
+    unsigned *bin_count;    // [nbins * kRpsPad]  points per bin (count pass); one counter per 128-B line; zero between calls
     unsigned *bin_start;    // [nbins + 1]        exclusive prefix
     unsigned *bin_fill;     // [nbins * kRpsPad]  place-pass cursors
-    unsigned long long *entries;    // point index | base-grid index << 32 | corners inside the map << 56 | owner << 63
-    float4 *params;                 // per entry: bilinear fractions (lh, lw), attention weight -- written by the route pass so
-                                    // that the tile kernel streams them instead of gathering 8 + 4 bytes per point
+    struct RpsRec *entries;         // one 16-byte record per (point, bin it was routed to)
     unsigned long long *stamps;     // diagnostic runs only (msda_debug_stamps)
     int dbg;                        // diagnostic: bits 4..6 = 1 + level -> only that level's tiles do any work (wrong results)
 };
@@ -77,9 +84,10 @@ struct RpsLds {
     int pad[2];
     unsigned long long stamp_last, stamp_acc[14];
     int offs[kRpsMaxPx + 4];            // histogram, then exclusive prefix
-    RpsEnt ent[kRpsChunk];              // sorted points of the chunk; plane of the final fold
+    RpsEnt ent[kRpsChunk];              // sorted points of the chunk, then their corner dots; plane of the final fold
+    RpsRec meta[kRpsChunk];             // the routed records in the same order (for the gradient combine); plane of the final fold
     float vtile[kRpsMaxPx * kRpsD];     // value rows of the tile + apron; plane of the final fold
-    float stage2[kRpsMaxPx * kRpsD], stage3[kRpsMaxPx * kRpsD];   // two more planes of the final fold
+    float stage2[kRpsMaxPx * kRpsD];    // fourth plane of the final fold
 };
 static_assert(sizeof(RpsLds) <= 160 * 1024, "rps: LDS budget");
 
@@ -117,49 +125,100 @@ __device__ __forceinline__ RpsPos rps_position(float x, float y, int H, int W)
     return p;
 }
 
-// Zero the work-queue heads, the bin counters / cursors and the grad_value ranges of the levels flushed with atomics.
-__global__ __launch_bounds__(256) void rps_prep_kernel(float *__restrict__ grad_value, const RpsGeom g)
+// One sampling point at one level: the bins (pair-local ids) it is appended to and its position inside each tile.
+struct RpsTarget {
+    int bin[4];           // [0] owner tile, [1] tile below, [2] tile to the right, [3] below-right; -1 = none
+    unsigned pbase[4];    // base-grid index inside that tile
+    unsigned inmap;       // corners inside the map (owner entry): bit 0 TL, 1 TR, 2 BL, 3 BR
+    float lh, lw;
+    bool valid;           // false: the reference drops the sample (ms_deform_im2col_cuda.cuh:285-291)
+};
+__device__ __forceinline__ RpsTarget rps_targets(float x, float y, const RpsLevel &v, int slab)
 {
-    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
-    if (gtid < 16) g.ctr[gtid] = 0u;
-    for (int i = gtid; i < g.nbins; i += gsz) { g.bin_count[i * kRpsPad] = 0u; g.bin_fill[i * kRpsPad] = 0u; }
-    const int row4 = g.M * kRpsD / 4;   // float4 per pixel
-    for (int l = 0; l < g.L; ++l) {
-        if (!g.lv[l].atomic) continue;
-        const int n4 = g.lv[l].H * g.lv[l].W * row4;
-        for (int b = 0; b < g.N; ++b) {
-            float4 *dst = reinterpret_cast<float4 *>(grad_value) + (size_t)(b * g.S + g.lv[l].start) * row4;
-            for (int i = gtid; i < n4; i += gsz) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    RpsTarget t;
+    t.bin[0] = t.bin[1] = t.bin[2] = t.bin[3] = -1;
+    t.pbase[0] = t.pbase[1] = t.pbase[2] = t.pbase[3] = 0u;
+    t.inmap = 0u;
+    const RpsPos p = rps_position(x, y, v.H, v.W);
+    t.valid = p.valid;
+    t.lh = p.h_im - (float)p.h_low;
+    t.lw = p.w_im - (float)p.w_low;
+    if (p.valid) {
+        const int br = max(p.h_low, 0), bc = max(p.w_low, 0);
+        const int ty = (int)(((float)br + 0.5f) * v.inv_TH), tx = (int)(((float)bc + 0.5f) * v.inv_TW);
+        const int R0 = ty * v.TH, C0 = tx * v.TW;
+        const int R1 = min(v.H, R0 + v.TH), C1 = min(v.W, C0 + v.TW);
+        const int gr = p.h_low - R0 + 1, gc = p.w_low - C0 + 1;   // base-grid position in the owner tile
+        const int ns = v.nslab;
+        t.bin[0] = v.bin0 + (ty * v.ntx + tx) * ns + slab;
+        t.inmap = (p.h_low >= 0 && p.w_low >= 0 ? 1u : 0u) | (p.h_low >= 0 && p.w_low + 1 < v.W ? 2u : 0u) |
+                  (p.h_low + 1 < v.H && p.w_low >= 0 ? 4u : 0u) | (p.h_low + 1 < v.H && p.w_low + 1 < v.W ? 8u : 0u);
+        t.pbase[0] = (unsigned)(gr * (C1 - C0 + 1) + gc);
+        // lower / right corners beyond the tile's edge belong to the next tile: there the point sits in row / column 0
+        const bool down = p.h_low == R1 - 1 && R1 < v.H, right = p.w_low == C1 - 1 && C1 < v.W;
+        if (down) {
+            t.bin[1] = t.bin[0] + v.ntx * ns;
+            t.pbase[1] = (unsigned)gc;   // row 0 of a tile with the same columns
         }
+        if (right) {
+            const int gw2 = min(v.W, C1 + v.TW) - C1 + 1;
+            t.bin[2] = t.bin[0] + ns;
+            t.pbase[2] = (unsigned)(gr * gw2);
+        }
+        if (down && right) t.bin[3] = t.bin[0] + (v.ntx + 1) * ns;
     }
+    return t;
 }
 
-// Route pass.  COUNT = true: bin_count[bin] += points; dropped samples get their (zero) gradients here.
-// COUNT = false: the same points are written to entries[bin_start[bin] + cursor++].
-// A wave takes 16 consecutive queries of one (image, head): lane = (query, point), levels one after the other -- so all 64
-// lanes of an instruction go to the bins of ONE (image, head, level), typically one or two tiles: lanes that share a bin
-// are matched with ballots and one atomic per (wave, bin) is issued; the returning atomics of a level are all in flight
-// before the first result is used.
+// Route pass.  A workgroup takes a block of consecutive queries of one (image, head); lane = (query, point), levels one
+// after the other.  The workgroup first sorts out its own points in LDS -- a histogram over the pair's bins; the value an
+// LDS atomic returns is the point's rank among the workgroup's points of that bin -- and then talks to global memory once
+// per (workgroup, bin):
+//   COUNT = true   bin_count[bin] += the workgroup's count; dropped samples get their (zero) gradients here; the levels
+//                  flushed with atomics later are zeroed in grad_value; the tile kernel's queue heads are reset.
+//   COUNT = false  one returning atomic per (workgroup, bin) reserves a run in the bin; every lane then writes its 16-byte
+//                  entries -- position code, bilinear fractions, attention weight -- at run start + rank.
+// Lanes of a wave usually share the owner bin (neighbouring queries, neighbouring points): they are matched with one
+// ballot and served by a single LDS atomic; the others take one each.
+constexpr int kRpsRouteThreads = 512;
+
 template <bool COUNT>
-__global__ __launch_bounds__(256) void rps_route_kernel(const float *__restrict__ loc, const float *__restrict__ aw,
-                                                        float *__restrict__ grad_loc, float *__restrict__ grad_aw, const RpsGeom g)
+__global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float *__restrict__ loc, const float *__restrict__ aw,
+                                                                     float *__restrict__ grad_value, float *__restrict__ grad_loc,
+                                                                     float *__restrict__ grad_aw, const RpsGeom g)
 {
-    const int lane = threadIdx.x & (kWave - 1);
+    __shared__ unsigned hist[kRpsMaxUnits], base[kRpsMaxUnits];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int B = g.bins_per_pair;
+    if (COUNT) {
+        const int gtid = blockIdx.x * blockDim.x + tid, gsz = gridDim.x * blockDim.x;
+        if (gtid < 16) g.ctr[gtid] = 0u;
+        const int row4 = g.M * kRpsD / 4;   // float4 per pixel
+        for (int l = 0; l < g.L; ++l) {
+            if (!g.lv[l].atomic) continue;
+            const int n4 = g.lv[l].H * g.lv[l].W * row4;
+            for (int b = 0; b < g.N; ++b) {
+                float4 *dst = reinterpret_cast<float4 *>(grad_value) + (size_t)(b * g.S + g.lv[l].start) * row4;
+                for (int i = gtid; i < n4; i += gsz) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
     const int P = g.P, LP = g.L * g.P;
     const int qpw = P <= 4 ? 16 : (P <= 8 ? 8 : (P <= 16 ? 4 : (P <= 32 ? 2 : 1)));   // queries per wave: qpw * P <= 64 lanes
     const int ql = lane / P, pp = lane - ql * P;
-    const int qblocks = (g.Lq + qpw - 1) / qpw;
+    const int qpb = qpw * (kRpsRouteThreads / kWave);   // queries per workgroup item
+    const int qblocks = (g.Lq + qpb - 1) / qpb;
     const int pairs = g.N * g.M;
-    const int n_units = pairs * qblocks;
-    const int wave_id = (blockIdx.x * blockDim.x + threadIdx.x) / kWave, n_waves = gridDim.x * blockDim.x / kWave;
-    for (int unit = wave_id; unit < n_units; unit += n_waves) {   // wave-uniform
-        const int pair = unit % pairs, qb = unit / pairs;          // neighbouring waves: different pairs (different bins)
-        const unsigned rep_seed = (unsigned)qb;
+    const int n_items = pairs * qblocks;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {   // (uniform)
+        const int pair = item % pairs, qb = item / pairs;               // neighbouring workgroups: different pairs (different bins)
         const int b = pair / g.M, m = pair - b * g.M;
-        const int q = qb * qpw + ql;
+        for (int i = tid; i < B; i += kRpsRouteThreads) hist[i] = 0u;
+        const int q = qb * qpb + wave * qpw + ql;
         const bool live = ql < qpw && pp < P && q < g.Lq;
         const unsigned pt0 = (unsigned)(((b * g.Lq + (live ? q : 0)) * g.M + m) * LP + pp);
-        // all levels' locations first: one round trip to memory per unit, not one per level
+        // all levels' locations first: one round trip to memory per item, not one per level
         float2 xy[kRpsMaxL];
         float at[kRpsMaxL];
 #pragma unroll
@@ -167,115 +226,97 @@ __global__ __launch_bounds__(256) void rps_route_kernel(const float *__restrict_
             xy[l] = live && l < g.L ? *reinterpret_cast<const float2 *>(loc + 2u * (pt0 + (unsigned)(l * P))) : make_float2(-4.f, -4.f);
             at[l] = !COUNT && live && l < g.L ? aw[pt0 + (unsigned)(l * P)] : 0.f;
         }
-        // the owner-tile entry of every level is matched first and its (returning) atomic is left in flight; the rare
-        // entries of neighbouring tiles are handled on the spot
-        int bin0[kRpsMaxL], rank0[kRpsMaxL], leader0[kRpsMaxL];
-        unsigned code0[kRpsMaxL], cur0[kRpsMaxL];
-        float2 frac0[kRpsMaxL];
+        __syncthreads();
+        // ---- A: ranks inside the workgroup ---------------------------------------------------------------------------------------
+        unsigned word[kRpsMaxL][4];   // bin | rank << 9 | pbase << 23; ~0u = no entry
+        unsigned own_rank[kRpsMaxL], inmap[kRpsMaxL];
+        int lead[kRpsMaxL];           // (uniform) lane whose LDS atomic served the matched lanes; -1 = none
+        bool matched[kRpsMaxL];
+        float lh[kRpsMaxL], lw[kRpsMaxL];
 #pragma unroll
         for (int l = 0; l < kRpsMaxL; ++l) {
-            bin0[l] = -1;
-            rank0[l] = 0;
-            leader0[l] = lane;
-            code0[l] = cur0[l] = 0;
-            frac0[l] = make_float2(0.f, 0.f);
-            if (l >= g.L) continue;   // uniform
-            const unsigned pt = pt0 + (unsigned)(l * P);
-            int bin[4] = {-1, -1, -1, -1};
-            unsigned code[4] = {0, 0, 0, 0};
-            float2 frac = make_float2(0.f, 0.f);
-            if (live) {
-                const RpsLevel &v = g.lv[l];
-                const RpsPos p = rps_position(xy[l].x, xy[l].y, v.H, v.W);
-                frac = make_float2(p.h_im - (float)p.h_low, p.w_im - (float)p.w_low);
-                if (!p.valid) {
-                    if (COUNT) {   // dropped sample: zero gradients (reference ms_deform_im2col_cuda.cuh:285-291 skips it)
-                        grad_aw[pt] = 0.f;
-                        *reinterpret_cast<float2 *>(grad_loc + 2u * pt) = make_float2(0.f, 0.f);
-                    }
-                } else {
-                    const int br = max(p.h_low, 0), bc = max(p.w_low, 0);
-                    const int ty = (int)(((float)br + 0.5f) * v.inv_TH), tx = (int)(((float)bc + 0.5f) * v.inv_TW);
-                    const int R0 = ty * v.TH, C0 = tx * v.TW;
-                    const int R1 = min(v.H, R0 + v.TH), C1 = min(v.W, C0 + v.TW);
-                    const int gr = p.h_low - R0 + 1, gc = p.w_low - C0 + 1;   // base-grid position in the owner tile
-                    const int ns = v.nslab;
-                    bin[0] = pair * g.bins_per_pair + v.bin0 + (ty * v.ntx + tx) * ns + (int)rps_uni((int)(rep_seed % (unsigned)ns));
-                    const unsigned inmap = (p.h_low >= 0 && p.w_low >= 0 ? 1u : 0u) | (p.h_low >= 0 && p.w_low + 1 < v.W ? 2u : 0u) |
-                                           (p.h_low + 1 < v.H && p.w_low >= 0 ? 4u : 0u) | (p.h_low + 1 < v.H && p.w_low + 1 < v.W ? 8u : 0u);
-                    // owner: this tile also forms the point's gradients (it needs to know which corners lie inside the map)
-                    code[0] = (unsigned)(gr * (C1 - C0 + 1) + gc) | inmap << 24 | 0x80000000u;
-                    // lower / right corners beyond the tile's edge belong to the next tile: there the point sits in row / column 0
-                    const bool down = p.h_low == R1 - 1 && R1 < v.H, right = p.w_low == C1 - 1 && C1 < v.W;
-                    if (down) {
-                        bin[1] = bin[0] + v.ntx * ns;
-                        code[1] = (unsigned)gc;   // row 0 of a tile with the same columns
-                    }
-                    if (right) {
-                        const int gw2 = min(v.W, C1 + v.TW) - C1 + 1;
-                        bin[2] = bin[0] + ns;
-                        code[2] = (unsigned)(gr * gw2);
-                    }
-                    if (down && right) {
-                        bin[3] = bin[0] + (v.ntx + 1) * ns;
-                        code[3] = 0u;
-                    }
-                }
+            word[l][0] = word[l][1] = word[l][2] = word[l][3] = ~0u;
+            own_rank[l] = 0u;
+            inmap[l] = 0u;
+            lead[l] = -1;
+            matched[l] = false;
+            lh[l] = lw[l] = 0.f;
+            if (l >= g.L) continue;   // (uniform)
+            const RpsLevel &v = g.lv[l];
+            RpsTarget t;
+            t.bin[0] = t.bin[1] = t.bin[2] = t.bin[3] = -1;
+            t.valid = true;
+            if (live) t = rps_targets(xy[l].x, xy[l].y, v, rps_uni(qb % v.nslab));
+            if (COUNT && live && !t.valid) {   // dropped sample: zero gradients
+                const unsigned pt = pt0 + (unsigned)(l * P);
+                grad_aw[pt] = 0.f;
+                *reinterpret_cast<float2 *>(grad_loc + 2u * pt) = make_float2(0.f, 0.f);
+            }
+            lh[l] = t.lh;
+            lw[l] = t.lw;
+            inmap[l] = t.inmap;
+            const int ob = t.bin[0];
+            const unsigned long long vote = __ballot(ob >= 0);
+            if (vote) {   // (uniform)
+                const int ld = __ffsll((long long)vote) - 1;
+                const int lb = __shfl(ob, ld, kWave);
+                const unsigned long long match = __ballot(ob == lb);
+                lead[l] = ld;
+                matched[l] = ob == lb;
+                if (lane == ld) own_rank[l] = atomicAdd(&hist[lb], (unsigned)__popcll(match));
+                else if (ob >= 0 && ob != lb) own_rank[l] = atomicAdd(&hist[ob], 1u);
+                else own_rank[l] = (unsigned)__popcll(match & lt_mask);   // + the leader's result, below
+                if (ob >= 0) word[l][0] = (unsigned)ob | t.pbase[0] << 23;
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                // match lanes by bin: leader lane, rank among the lanes of the same bin, size of the group
-                int leader = lane, rank = 0, n_mine = 0;
-                unsigned long long todo = __ballot(bin[t] >= 0);
-                if (t > 0 && !todo) continue;   // (uniform) no lane feeds this neighbour tile: the usual case
-                while (todo) {
-                    const int ld = __ffsll((long long)todo) - 1;
-                    const int lb = __shfl(bin[t], ld, kWave);
-                    const unsigned long long match = __ballot(bin[t] == lb);
-                    if (bin[t] == lb) {
-                        leader = ld;
-                        rank = __popcll(match & ((1ull << lane) - 1ull));
-                        n_mine = __popcll(match);
-                    }
-                    todo &= ~match;
+            for (int k = 1; k < 4; ++k)
+                if (t.bin[k] >= 0) {   // the few points on a tile's last row / column
+                    const unsigned r = atomicAdd(&hist[t.bin[k]], 1u);
+                    word[l][k] = (unsigned)t.bin[k] | r << 9 | t.pbase[k] << 23;
                 }
-                const bool lead = bin[t] >= 0 && leader == lane;   // one atomic per (wave, bin)
-                if (COUNT) {
-                    if (lead) atomicAdd(g.bin_count + bin[t] * kRpsPad, (unsigned)n_mine);
-                } else if (t == 0) {
-                    if (lead) cur0[l] = atomicAdd(g.bin_fill + bin[t] * kRpsPad, (unsigned)n_mine);   // left in flight
-                    bin0[l] = bin[t];
-                    code0[l] = code[t];
-                    rank0[l] = rank;
-                    leader0[l] = leader;
-                    frac0[l] = frac;
-                } else {
-                    unsigned cur = 0;
-                    if (lead) cur = atomicAdd(g.bin_fill + bin[t] * kRpsPad, (unsigned)n_mine);
-                    cur = (unsigned)__shfl((int)cur, leader, kWave);
-                    if (bin[t] >= 0) {
-                        const unsigned slot = g.bin_start[bin[t]] + cur + (unsigned)rank;
-                        g.entries[slot] = (unsigned long long)pt | ((unsigned long long)code[t] << 32);
-                        g.params[slot] = make_float4(frac.x, frac.y, at[l], 0.f);
-                    }
-                }
+        }
+        __syncthreads();
+        // ---- B: one global atomic per (workgroup, bin) ---------------------------------------------------------------------------
+        for (int i = tid; i < B; i += kRpsRouteThreads) {
+            const unsigned c = hist[i];
+            if (c) {
+                const size_t gb = (size_t)pair * B + i;
+                if (COUNT) atomicAdd(g.bin_count + gb * kRpsPad, c);
+                else base[i] = g.bin_start[gb] + atomicAdd(g.bin_fill + gb * kRpsPad, c);
             }
         }
         if (!COUNT) {
+            // ---- C: entries to their slots --------------------------------------------------------------------------------------
 #pragma unroll
             for (int l = 0; l < kRpsMaxL; ++l) {
-                const unsigned c = (unsigned)__shfl((int)cur0[l], leader0[l], kWave);
-                if (bin0[l] >= 0) {
-                    const unsigned slot = g.bin_start[bin0[l]] + c + (unsigned)rank0[l];
-                    g.entries[slot] = (unsigned long long)(pt0 + (unsigned)(l * P)) | ((unsigned long long)code0[l] << 32);
-                    g.params[slot] = make_float4(frac0[l].x, frac0[l].y, at[l], 0.f);
+                if (l >= g.L) continue;
+                unsigned r = own_rank[l];
+                if (lead[l] >= 0) {
+                    const unsigned rl = (unsigned)__shfl((int)r, lead[l], kWave);
+                    if (matched[l] && lane != lead[l]) r += rl;
                 }
+                if (word[l][0] != ~0u) word[l][0] |= r << 9;
             }
+            __syncthreads();
+            const unsigned qp = (unsigned)((live ? q : 0) * P + pp);
+#pragma unroll
+            for (int l = 0; l < kRpsMaxL; ++l)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned w = word[l][k];
+                    if (w != ~0u) {
+                        const unsigned slot = base[w & 511u] + ((w >> 9) & 16383u);
+                        const unsigned code = qp | (w >> 23) << kRpsQpBits | (k == 0 ? inmap[l] << 27 | 0x80000000u : 0u);
+                        g.entries[slot] = RpsRec{code, lh[l], lw[l], at[l]};
+                    }
+                }
         }
+        __syncthreads();   // hist / base are reused by the next item
     }
 }
 
-// Exclusive prefix of the bin counts (one workgroup; a few thousand bins).
+// Exclusive prefix of the bin counts (one workgroup; a few thousand bins).  Leaves the counters zeroed for the next call
+// and the place-pass cursors zeroed for this one.
 __global__ __launch_bounds__(1024) void rps_scan_kernel(const RpsGeom g)
 {
     __shared__ unsigned part[1024];
@@ -283,7 +324,7 @@ __global__ __launch_bounds__(1024) void rps_scan_kernel(const RpsGeom g)
     const int per = (g.nbins + 1023) / 1024;
     const int i0 = tid * per, i1 = min(g.nbins, i0 + per);
     unsigned s = 0;
-    for (int i = i0; i < i1; ++i) s += g.bin_count[i * kRpsPad];
+    for (int i = i0; i < i1; ++i) s += g.bin_count[(size_t)i * kRpsPad];
     part[tid] = s;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
@@ -295,7 +336,9 @@ __global__ __launch_bounds__(1024) void rps_scan_kernel(const RpsGeom g)
     unsigned run = part[tid] - s;
     for (int i = i0; i < i1; ++i) {
         g.bin_start[i] = run;
-        run += g.bin_count[i * kRpsPad];
+        run += g.bin_count[(size_t)i * kRpsPad];
+        g.bin_count[(size_t)i * kRpsPad] = 0u;
+        g.bin_fill[(size_t)i * kRpsPad] = 0u;
     }
     if (tid == 1023) g.bin_start[g.nbins] = part[1023];
 }
@@ -320,7 +363,10 @@ __device__ __forceinline__ float rps_quad_transpose_sum(float d0, float d1, floa
 // one quad-cycle per instruction), so every FMA carries two channels and the per-point overhead (weights, the dot
 // reduction, the entry read) is shared by 8 channels per lane instead of 4.
 // List p stays on quad p, whose partial sums live in registers across the chunks of a tile.
-// The next work item is drawn from the queue, and the first chunk of its bin fetched, while the current one is reduced.
+// Everything a work item needs from memory is requested while the previous one is still being reduced: the queue is drawn
+// two items ahead (the draw of item k+2 is issued at the start of item k and first looked at one item later), the bin
+// bounds of the next item are read at the start of the current one, its first chunk of records during the last list walk
+// and its value rows during the fold.
 template <bool P4>
 __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
     const float *__restrict__ value, const float *__restrict__ grad_out, float *__restrict__ grad_value,
@@ -344,7 +390,46 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         for (int i = 0; i < 14; ++i) S->stamp_acc[i] = 0;
         S->stamp_last = __builtin_amdgcn_s_memtime();
     }
-    // bin of a work item: first entry and number of entries (0 for ids past the table or pairs past the batch)
+    // a work item: tile, pair, and this quad's pixel of the pixel grid
+    struct Item {
+        bool live;
+        int l, b, m, H, W, R0, R1, C0, C1, gw, npx;
+        bool has_px;
+        int gr, gc, prow, pcol;
+        int64_t px_off;
+    };
+    auto item_geom = [&](int id) {
+        Item it;
+        const unsigned unit = g.units[min(id, n_items - 1) / g.ppx];
+        const int pr = xq + kXcds * (min(id, n_items - 1) % g.ppx);
+        const int pair = min(pr, pairs - 1);
+        // (diagnostic: dbg bits 4..6 = 1 + level -> only that level's units do any work)
+        it.live = id < n_items && pr < pairs && (((g.dbg >> 4) & 7) == 0 || ((g.dbg >> 4) & 7) == (int)(unit & 3) + 1);
+        it.l = unit & 3;
+        const int ty = (unit >> 2) & 63, tx = (unit >> 8) & 63;
+        it.b = pair / g.M;
+        it.m = pair - it.b * g.M;
+        it.H = g.lv[it.l].H;
+        it.W = g.lv[it.l].W;
+        it.R0 = ty * g.lv[it.l].TH;
+        it.R1 = min(it.H, it.R0 + g.lv[it.l].TH);
+        it.C0 = tx * g.lv[it.l].TW;
+        it.C1 = min(it.W, it.C0 + g.lv[it.l].TW);
+        // Two grids of the same shape (th+1) x gw:
+        //   base grid   (gr, gc) <-> sampling points whose corner (h_low, w_low) is pixel (R0-1+gr, C0-1+gc): one list each
+        //   pixel grid  (vr, vc) <-> pixel (R0+vr, C0+vc): the tile plus one apron row / column (value rows for the dots)
+        // so the four corners of base p are the pixels p-gw-1, p-gw, p-1, p of the pixel grid.
+        it.gw = it.C1 - it.C0 + 1;
+        it.npx = it.live ? (it.R1 - it.R0 + 1) * it.gw : 0;
+        it.has_px = quad < it.npx;
+        it.gr = quad / it.gw;
+        it.gc = quad - it.gr * it.gw;
+        it.prow = it.R0 + it.gr;
+        it.pcol = it.C0 + it.gc;
+        it.px_off = ((int64_t)(it.b * g.S + g.lv[it.l].start + it.prow * it.W + it.pcol) * g.M + it.m) * kRpsD;   // (+ c_lo / c_hi)
+        return it;
+    };
+    // bin of a work item: first record and number of records (0 for ids past the table or pairs past the batch)
     auto bin_range = [&](int id, unsigned &first, int &n) {
         first = 0;
         n = 0;
@@ -359,61 +444,55 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
             }
         }
     };
-    unsigned long long n_code[2];
-    float4 n_par[2];
-    auto fetch_codes = [&](unsigned first, int n, int ch) {   // both streams are contiguous: 8 + 16 bytes per point
+    RpsRec n_rec[2];   // this lane's two records of the chunk in flight
+    auto fetch_recs = [&](unsigned first, int n, int ch) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int k = ch * kRpsChunk + u * kRpsThreads + tid;
-            const bool ok = k < n;
-            n_code[u] = ok ? g.entries[first + (unsigned)k] : ~0ull;
-            n_par[u] = ok ? g.params[first + (unsigned)k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            n_rec[u] = k < n ? g.entries[first + (unsigned)k] : RpsRec{~0u, 0.f, 0.f, 0.f};
+        }
+    };
+    // value rows of a work item's pixel grid (zeros beyond the map): 32 B per lane
+    float4 nv0, nv1;
+    auto fetch_rows = [&](const Item &it, bool any) {
+        nv0 = nv1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (any && it.has_px && it.prow < it.H && it.pcol < it.W) {
+            nv0 = *reinterpret_cast<const float4 *>(value + it.px_off + c_lo);
+            nv1 = *reinterpret_cast<const float4 *>(value + it.px_off + c_hi);
         }
     };
 
-    if (tid == 0) S->item_slot[0] = (int)atomicAdd(g.ctr + xq, 1u);
+    unsigned draw = 0;   // (thread 0) the queue draw in flight
+    if (tid == 0) {
+        S->item_slot[0] = (int)atomicAdd(g.ctr + xq, 1u);
+        draw = atomicAdd(g.ctr + xq, 1u);
+    }
     __syncthreads();
     int item_id = rps_uni(S->item_slot[0]);
     unsigned e_first;
     int n_ent;
     bin_range(item_id, e_first, n_ent);
-    fetch_codes(e_first, n_ent, 0);
+    fetch_recs(e_first, n_ent, 0);
+    Item it = item_geom(item_id);
+    fetch_rows(it, n_ent > 0);
     int par = 0;
 
     while (item_id < n_items) {
-        if (tid == 0) S->item_slot[par ^ 1] = (int)atomicAdd(g.ctr + xq, 1u);   // read after the next barrier
-        const unsigned unit = g.units[item_id / g.ppx];
-        const int pair = min(xq + kXcds * (item_id % g.ppx), pairs - 1);
-        // (diagnostic: dbg bits 4..6 = 1 + level -> only that level's units do any work)
-        const bool live_item = xq + kXcds * (item_id % g.ppx) < pairs && (((g.dbg >> 4) & 7) == 0 || ((g.dbg >> 4) & 7) == (int)(unit & 3) + 1);
-        const int l = unit & 3, ty = (unit >> 2) & 63, tx = (unit >> 8) & 63;
-        const int b = pair / g.M, m = pair - b * g.M;
-        const int H = g.lv[l].H, W = g.lv[l].W;
-        const int R0 = ty * g.lv[l].TH, R1 = min(H, R0 + g.lv[l].TH), C0 = tx * g.lv[l].TW, C1 = min(W, C0 + g.lv[l].TW);
-        // Two grids of the same shape (th+1) x gw:
-        //   base grid   (gr, gc) <-> sampling points whose corner (h_low, w_low) is pixel (R0-1+gr, C0-1+gc): one list each
-        //   pixel grid  (vr, vc) <-> pixel (R0+vr, C0+vc): the tile plus one apron row / column (value rows for the dots)
-        // so the four corners of base p are the pixels p-gw-1, p-gw, p-1, p of the pixel grid.
-        const int gw = C1 - C0 + 1;
-        const int npx = live_item ? (R1 - R0 + 1) * gw : 0;
-        const int n_chunks = live_item ? (n_ent + kRpsChunk - 1) / kRpsChunk : 0;
-        // this quad's pixel in the pixel grid
-        const bool has_px = quad < npx;
-        const int gr = quad / gw, gc = quad - gr * gw;
-        const int prow = R0 + gr, pcol = C0 + gc;
-        const int64_t px_off = ((int64_t)(b * g.S + g.lv[l].start + prow * W + pcol) * g.M + m) * kRpsD;   // (+ c_lo / c_hi)
-
-        // ---- the tile's value rows (+ apron, zeros beyond the map) -> LDS: 32 B per lane -----------------------------------
-        {
-            float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
-            if (has_px && prow < H && pcol < W && n_chunks > 0) {
-                t0 = *reinterpret_cast<const float4 *>(value + px_off + c_lo);
-                t1 = *reinterpret_cast<const float4 *>(value + px_off + c_hi);
-            }
-            if (has_px) {
-                *reinterpret_cast<float4 *>(S->vtile + quad * kRpsD + c_lo) = t0;
-                *reinterpret_cast<float4 *>(S->vtile + quad * kRpsD + c_hi) = t1;
-            }
+        if (tid == 0) {
+            S->item_slot[par ^ 1] = (int)draw;   // issued one item ago
+            draw = atomicAdd(g.ctr + xq, 1u);
+        }
+        const int l = it.l, b = it.b, m = it.m, H = it.H, W = it.W, R0 = it.R0, R1 = it.R1, C0 = it.C0, C1 = it.C1, gw = it.gw;
+        const int npx = it.npx;
+        const int n_chunks = it.live ? (n_ent + kRpsChunk - 1) / kRpsChunk : 0;
+        const bool has_px = it.has_px;
+        const int gr = it.gr, gc = it.gc, prow = it.prow, pcol = it.pcol;
+        const int64_t px_off = it.px_off;
+        const int bq0 = b * g.Lq;
+        // ---- the tile's value rows (+ apron), fetched during the previous item's fold -> LDS --------------------------------------
+        if (has_px) {
+            *reinterpret_cast<float4 *>(S->vtile + quad * kRpsD + c_lo) = nv0;
+            *reinterpret_cast<float4 *>(S->vtile + quad * kRpsD + c_hi) = nv1;
         }
         // ---- four partial sums of one base pixel (one per corner), 8 channels per lane ---------------------------------------
         rps_v2f acc[4][4];
@@ -422,46 +501,28 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[k][c] = (rps_v2f){0.f, 0.f};
         __syncthreads();
-        // the next work item: its queue draw (issued above) is read behind a later barrier, so that nobody waits for it
-        int next_id = n_items;
-        unsigned next_first = 0;
-        int next_n = 0;
+        const int next_id = rps_uni(S->item_slot[par ^ 1]);
+        unsigned next_first;
+        int next_n;
+        bin_range(next_id, next_first, next_n);   // (first looked at during the last list walk)
         const int my_p = quad;   // the base pixel whose list this quad walks
         RPS_STAMP(0)
 
         for (int ch = 0; ch < n_chunks; ++ch) {
-            // ---- (1) this lane's two points of the chunk ---------------------------------------------------------------------
+            const int n_here = min(kRpsChunk, n_ent - ch * kRpsChunk);
+            // ---- (1) this lane's two points of the chunk: rank in the list of their base pixel -----------------------------------
             for (int i = tid; i <= npx; i += kRpsThreads) S->offs[i] = 0;
-            int p_pt[2], pbase[2], pos[2];
-            float p_lh[2], p_lw[2], p_a[2];
-            unsigned p_own[2];    // bit 4: this tile forms the point's gradients; bits 0..3: corners inside the map
+            int pbase[2], pos[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                p_pt[u] = -1;
-                pbase[u] = 0;
+                pbase[u] = (int)((n_rec[u].code >> kRpsQpBits) & 0xFFu);
                 pos[u] = -1;
-                p_lh[u] = n_par[u].x;
-                p_lw[u] = n_par[u].y;
-                p_a[u] = n_par[u].z;
-                p_own[u] = 0;
-                if (n_code[u] != ~0ull) {
-                    p_pt[u] = (int)(unsigned)n_code[u];
-                    pbase[u] = (int)((n_code[u] >> 32) & 0xFFFFFFu);
-                    p_own[u] = ((unsigned)(n_code[u] >> 63) << 4) | ((unsigned)(n_code[u] >> 56) & 15u);
-                }
             }
-            // the next chunk -- or, behind the barrier, the first chunk of the next work item -- is in flight from here on
-            if (ch + 1 < n_chunks) fetch_codes(e_first, n_ent, ch + 1);
             __syncthreads();
             RPS_STAMP(1)
-            if (ch == 0) {
-                next_id = rps_uni(S->item_slot[par ^ 1]);
-                bin_range(next_id, next_first, next_n);
-            }
-            if (ch + 1 == n_chunks) fetch_codes(next_first, next_n, 0);
 #pragma unroll
             for (int u = 0; u < 2; ++u)
-                if (p_pt[u] >= 0) pos[u] = atomicAdd(&S->offs[pbase[u]], 1);
+                if (n_rec[u].code != ~0u) pos[u] = atomicAdd(&S->offs[pbase[u]], 1);
             __syncthreads();
             RPS_STAMP(2)
 
@@ -491,18 +552,23 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
             __syncthreads();
             RPS_STAMP(3)
 
-            // ---- (3) entries to their sorted slots ----------------------------------------------------------------------------
+            // ---- (3) records to their sorted slots; the next chunk -- or the first chunk of the next work item -- is requested ----
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if (pos[u] >= 0) {
-                    pos[u] += S->offs[pbase[u]];
-                    S->ent[pos[u]] = RpsEnt{(int)((unsigned)p_pt[u] / (unsigned)LP), p_lh[u], p_lw[u], p_a[u]};
+                    const int e = pos[u] + S->offs[pbase[u]];
+                    const unsigned qp = n_rec[u].code & ((1u << kRpsQpBits) - 1u);
+                    const int q = P4 ? (int)(qp >> 2) : (int)(qp / (unsigned)P);
+                    S->ent[e] = RpsEnt{(bq0 + q) * g.M + m, n_rec[u].lh, n_rec[u].lw, n_rec[u].a};
+                    S->meta[e] = n_rec[u];
                 }
+            if (ch + 1 < n_chunks) fetch_recs(e_first, n_ent, ch + 1);
+            else fetch_recs(next_first, next_n, 0);
             __syncthreads();
             RPS_STAMP(4)
 
             // ---- (4) every quad walks a list: four partial sums and four corner dots per point; grad_out rows straight from
-            //      global memory, two points in flight per quad -------------------------------------------------------------------
+            //      global memory, software-pipelined ---------------------------------------------------------------------------------
             if (has_px) {
                 int e = S->offs[my_p];
                 const int e1 = S->offs[my_p + 1];
@@ -568,31 +634,42 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
             __syncthreads();
             RPS_STAMP(5)
 
-            // ---- (5) the lane that placed a point combines its corner dots into the two gradients -------------------------------------
+            // ---- (5) gradients of the points this tile owns: one lane per record, in list order -------------------------------------
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (p_pt[u] >= 0 && (p_own[u] & 16u)) {
-                    float4 d = *reinterpret_cast<const float4 *>(S->ent + pos[u]);
-                    if (!(p_own[u] & 1u)) d.x = 0.f;
-                    if (!(p_own[u] & 2u)) d.y = 0.f;
-                    if (!(p_own[u] & 4u)) d.z = 0.f;
-                    if (!(p_own[u] & 8u)) d.w = 0.f;
-                    const float lh = p_lh[u], lw = p_lw[u], hh = 1.f - lh, hw = 1.f - lw, a = p_a[u];
-                    const float s_a = hh * hw * d.x + hh * lw * d.y + lh * hw * d.z + lh * lw * d.w;
-                    const float s_w = hh * (d.y - d.x) + lh * (d.w - d.z);
-                    const float s_h = hw * (d.z - d.x) + lw * (d.w - d.y);
-                    grad_aw[p_pt[u]] = s_a;
-                    *reinterpret_cast<float2 *>(grad_loc + 2u * (unsigned)p_pt[u]) = make_float2((float)W * s_w * a, (float)H * s_h * a);
+            for (int u = 0; u < 2; ++u) {
+                const int e = u * kRpsThreads + tid;
+                if (e < n_here) {
+                    const RpsRec r = S->meta[e];
+                    if (r.code >> 31) {
+                        float4 d = *reinterpret_cast<const float4 *>(S->ent + e);
+                        const unsigned in = r.code >> 27;
+                        if (!(in & 1u)) d.x = 0.f;
+                        if (!(in & 2u)) d.y = 0.f;
+                        if (!(in & 4u)) d.z = 0.f;
+                        if (!(in & 8u)) d.w = 0.f;
+                        const float lh = r.lh, lw = r.lw, hh = 1.f - lh, hw = 1.f - lw;
+                        const float s_a = hh * hw * d.x + hh * lw * d.y + lh * hw * d.z + lh * lw * d.w;
+                        const float s_w = hh * (d.y - d.x) + lh * (d.w - d.z);
+                        const float s_h = hw * (d.z - d.x) + lw * (d.w - d.y);
+                        const unsigned qp = r.code & ((1u << kRpsQpBits) - 1u);
+                        const unsigned q = P4 ? qp >> 2 : qp / (unsigned)P, pp = qp - q * (unsigned)P;
+                        const unsigned pt = (unsigned)((bq0 + (int)q) * g.M + m) * (unsigned)LP + (unsigned)(l * P) + pp;
+                        grad_aw[pt] = s_a;
+                        *reinterpret_cast<float2 *>(grad_loc + 2u * pt) = make_float2((float)W * s_w * r.a, (float)H * s_h * r.a);
+                    }
                 }
+            }
             // (the next chunk clears the histogram now -- its last reader was the list walk -- and rewrites the entries only
             // after three more barriers)
             RPS_STAMP(6)
         }
+        if (n_chunks == 0) fetch_recs(next_first, next_n, 0);   // (an empty bin: nothing was fetched ahead)
         // ---- fold the partial sums: pixel x of the pixel grid = BR[x] + BL[x+1] + TR[x+gw] + TL[x+gw+1] of the base grid.  The
         //      four partial sums of list my_p go to four LDS planes (the value rows and the entries are no longer needed) ------------
         __syncthreads();
+        const Item nit = item_geom(next_id);
         {
-            float *plane[4] = {S->stage2, reinterpret_cast<float *>(S->ent), S->stage3, S->vtile};   // TL, TR, BL, BR
+            float *plane[4] = {S->stage2, reinterpret_cast<float *>(S->ent), reinterpret_cast<float *>(S->meta), S->vtile};   // TL, TR, BL, BR
             if (has_px) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -600,12 +677,8 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
                     *reinterpret_cast<float4 *>(plane[k] + my_p * kRpsD + c_hi) = make_float4(acc[k][2].x, acc[k][2].y, acc[k][3].x, acc[k][3].y);
                 }
             }
+            fetch_rows(nit, next_n > 0);   // the next item's value rows travel while this one is folded and flushed
             __syncthreads();
-            if (n_chunks == 0) {   // (an empty bin: nothing was fetched ahead)
-                next_id = rps_uni(S->item_slot[par ^ 1]);
-                bin_range(next_id, next_first, next_n);
-                fetch_codes(next_first, next_n, 0);
-            }
             float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
             if (has_px) {
 #pragma unroll
@@ -652,6 +725,7 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         item_id = next_id;
         e_first = next_first;
         n_ent = next_n;
+        it = nit;
         par ^= 1;
     }
     if (g.stamps && tid == 0) {
@@ -691,7 +765,7 @@ inline RpsPlan plan_rps(int N, int S, int M, int D, int L, int Lq, int P, const 
     }
     if (!tiles_s || pre != S) return pl;   // tiles must not overlap in grad_value
     const int64_t n_pts = (int64_t)N * Lq * M * L * P;
-    if (n_pts >= ((int64_t)1 << 31)) return pl;
+    if (n_pts >= ((int64_t)1 << 31) || (int64_t)Lq * P >= ((int64_t)1 << kRpsQpBits)) return pl;
     RpsGeom &g = pl.g;
     g.N = N; g.S = S; g.M = M; g.Lq = Lq; g.L = L; g.P = P;
     g.ppx = (N * M + kXcds - 1) / kXcds;
