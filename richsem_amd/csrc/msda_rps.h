@@ -74,8 +74,11 @@ struct RpsGeom {
 };
 
 struct alignas(16) RpsEnt {   // one sampling point in the list of its base pixel; overwritten by its four corner dots
-    int item;                 // (b*Lq + q)*M + m: row of grad_out
     float lh, lw, a;          // bilinear fractions, attention weight
+    int item;                 // (b*Lq + q)*M + m: row of grad_out -- read ahead of the rest (it is all a row request needs)
+};
+struct RpsCoef {
+    float lh, lw, a;
 };
 
 struct RpsLds {
@@ -86,8 +89,9 @@ struct RpsLds {
     int offs[kRpsMaxPx + 4];            // histogram, then exclusive prefix
     RpsEnt ent[kRpsChunk];              // sorted points of the chunk, then their corner dots; plane of the final fold
     RpsRec meta[kRpsChunk];             // the routed records in the same order (for the gradient combine); plane of the final fold
-    float vtile[kRpsMaxPx * kRpsD];     // value rows of the tile + apron; plane of the final fold
-    float stage2[kRpsMaxPx * kRpsD];    // fourth plane of the final fold
+    // value rows of the tile + apron, double-buffered: the rows of the NEXT work item are fetched while the last chunk's
+    // gradients are written.  The current buffer is the third plane of the final fold.
+    float vtile[2][kRpsMaxPx * kRpsD];
 };
 static_assert(sizeof(RpsLds) <= 160 * 1024, "rps: LDS budget");
 
@@ -365,8 +369,11 @@ __device__ __forceinline__ float rps_quad_transpose_sum(float d0, float d1, floa
 // List p stays on quad p, whose partial sums live in registers across the chunks of a tile.
 // Everything a work item needs from memory is requested while the previous one is still being reduced: the queue is drawn
 // two items ahead (the draw of item k+2 is issued at the start of item k and first looked at one item later), the bin
-// bounds of the next item are read at the start of the current one, its first chunk of records during the last list walk
-// and its value rows during the fold.
+// bounds of the next item are requested at the start of the current one, its first chunk of records and its value rows
+// (into the second value buffer) while the last chunk's gradients are written.
+// Registers are the scarce resource (128 at 1024 threads, ~110 of them in the list walk): work-item geometry is kept
+// uniform (SGPRs), per-lane positions are recomputed where needed, prefetches are unconditional loads from clamped addresses
+// (a conditional load ends in a register copy right behind it -- and with it a wait for the data).
 template <bool P4>
 __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
     const float *__restrict__ value, const float *__restrict__ grad_out, float *__restrict__ grad_value,
@@ -390,17 +397,14 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         for (int i = 0; i < 14; ++i) S->stamp_acc[i] = 0;
         S->stamp_last = __builtin_amdgcn_s_memtime();
     }
-    // a work item: tile, pair, and this quad's pixel of the pixel grid
+    // a work item (uniform): tile and pair
     struct Item {
         bool live;
         int l, b, m, H, W, R0, R1, C0, C1, gw, npx;
-        bool has_px;
-        int gr, gc, prow, pcol;
-        int64_t px_off;
     };
     auto item_geom = [&](int id) {
         Item it;
-        const unsigned unit = g.units[min(id, n_items - 1) / g.ppx];
+        const unsigned unit = (unsigned)rps_uni((int)g.units[min(id, n_items - 1) / g.ppx]);
         const int pr = xq + kXcds * (min(id, n_items - 1) % g.ppx);
         const int pair = min(pr, pairs - 1);
         // (diagnostic: dbg bits 4..6 = 1 + level -> only that level's units do any work)
@@ -421,12 +425,6 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         // so the four corners of base p are the pixels p-gw-1, p-gw, p-1, p of the pixel grid.
         it.gw = it.C1 - it.C0 + 1;
         it.npx = it.live ? (it.R1 - it.R0 + 1) * it.gw : 0;
-        it.has_px = quad < it.npx;
-        it.gr = quad / it.gw;
-        it.gc = quad - it.gr * it.gw;
-        it.prow = it.R0 + it.gr;
-        it.pcol = it.C0 + it.gc;
-        it.px_off = ((int64_t)(it.b * g.S + g.lv[it.l].start + it.prow * it.W + it.pcol) * g.M + it.m) * kRpsD;   // (+ c_lo / c_hi)
         return it;
     };
     // bin of a work item: first record and number of records (0 for ids past the table or pairs past the batch)
@@ -434,32 +432,37 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         first = 0;
         n = 0;
         if (id < n_items) {
-            const unsigned unit = g.units[id / g.ppx];
+            const unsigned unit = (unsigned)rps_uni((int)g.units[id / g.ppx]);
             const int pair = xq + kXcds * (id % g.ppx);
             if (pair < pairs) {
                 const int l = unit & 3, ty = (unit >> 2) & 63, tx = (unit >> 8) & 63, slab = (unit >> 14) & 255, nslab = (unit >> 22) & 255;
                 const int bin = pair * g.bins_per_pair + g.lv[l].bin0 + (ty * g.lv[l].ntx + tx) * nslab + slab;
-                first = g.bin_start[bin];
-                n = (int)(g.bin_start[bin + 1] - first);
+                first = (unsigned)rps_uni((int)g.bin_start[bin]);
+                n = rps_uni((int)g.bin_start[bin + 1]) - (int)first;
             }
         }
     };
-    RpsRec n_rec[2];   // this lane's two records of the chunk in flight
+    RpsRec n_rec[2];   // this lane's two records of the chunk in flight (lanes past the end of the bin: a copy of its last record)
     auto fetch_recs = [&](unsigned first, int n, int ch) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int k = ch * kRpsChunk + u * kRpsThreads + tid;
-            n_rec[u] = k < n ? g.entries[first + (unsigned)k] : RpsRec{~0u, 0.f, 0.f, 0.f};
+            n_rec[u] = g.entries[n > 0 ? first + (unsigned)min(k, n - 1) : 0u];
         }
     };
-    // value rows of a work item's pixel grid (zeros beyond the map): 32 B per lane
+    // value rows of a work item's pixel grid: 32 B per lane.  Quads without a pixel, and pixels beyond the map, fetch a clamped
+    // (valid) row: nothing reads the former, and corners outside the map are masked where the gradients are formed.
     float4 nv0, nv1;
-    auto fetch_rows = [&](const Item &it, bool any) {
-        nv0 = nv1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (any && it.has_px && it.prow < it.H && it.pcol < it.W) {
-            nv0 = *reinterpret_cast<const float4 *>(value + it.px_off + c_lo);
-            nv1 = *reinterpret_cast<const float4 *>(value + it.px_off + c_hi);
-        }
+    auto fetch_rows = [&](const Item &it) {
+        const int gr_ = min(quad / it.gw, it.R1 - it.R0), gc_ = quad % it.gw;
+        const int prow_ = min(it.R0 + gr_, it.H - 1), pcol_ = min(it.C0 + gc_, it.W - 1);
+        const float *src = value + ((int64_t)(it.b * g.S + g.lv[it.l].start + prow_ * it.W + pcol_) * g.M + it.m) * kRpsD;
+        nv0 = *reinterpret_cast<const float4 *>(src + c_lo);
+        nv1 = *reinterpret_cast<const float4 *>(src + c_hi);
+    };
+    auto store_rows = [&](int buf) {
+        *reinterpret_cast<float4 *>(S->vtile[buf] + quad * kRpsD + c_lo) = nv0;
+        *reinterpret_cast<float4 *>(S->vtile[buf] + quad * kRpsD + c_hi) = nv1;
     };
 
     unsigned draw = 0;   // (thread 0) the queue draw in flight
@@ -474,7 +477,8 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
     bin_range(item_id, e_first, n_ent);
     fetch_recs(e_first, n_ent, 0);
     Item it = item_geom(item_id);
-    fetch_rows(it, n_ent > 0);
+    fetch_rows(it);
+    store_rows(0);
     int par = 0;
 
     while (item_id < n_items) {
@@ -485,15 +489,9 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         const int l = it.l, b = it.b, m = it.m, H = it.H, W = it.W, R0 = it.R0, R1 = it.R1, C0 = it.C0, C1 = it.C1, gw = it.gw;
         const int npx = it.npx;
         const int n_chunks = it.live ? (n_ent + kRpsChunk - 1) / kRpsChunk : 0;
-        const bool has_px = it.has_px;
-        const int gr = it.gr, gc = it.gc, prow = it.prow, pcol = it.pcol;
-        const int64_t px_off = it.px_off;
+        const bool has_px = quad < npx;
         const int bq0 = b * g.Lq;
-        // ---- the tile's value rows (+ apron), fetched during the previous item's fold -> LDS --------------------------------------
-        if (has_px) {
-            *reinterpret_cast<float4 *>(S->vtile + quad * kRpsD + c_lo) = nv0;
-            *reinterpret_cast<float4 *>(S->vtile + quad * kRpsD + c_hi) = nv1;
-        }
+        float *vt = S->vtile[par];
         // ---- four partial sums of one base pixel (one per corner), 8 channels per lane ---------------------------------------
         rps_v2f acc[4][4];
 #pragma unroll
@@ -504,7 +502,8 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         const int next_id = rps_uni(S->item_slot[par ^ 1]);
         unsigned next_first;
         int next_n;
-        bin_range(next_id, next_first, next_n);   // (first looked at during the last list walk)
+        bin_range(next_id, next_first, next_n);
+        const Item nit = item_geom(next_id);
         const int my_p = quad;   // the base pixel whose list this quad walks
         RPS_STAMP(0)
 
@@ -514,15 +513,14 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
             for (int i = tid; i <= npx; i += kRpsThreads) S->offs[i] = 0;
             int pbase[2], pos[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                pbase[u] = (int)((n_rec[u].code >> kRpsQpBits) & 0xFFu);
-                pos[u] = -1;
-            }
+            for (int u = 0; u < 2; ++u) pos[u] = -1;
             __syncthreads();
             RPS_STAMP(1)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (n_rec[u].code != ~0u) pos[u] = atomicAdd(&S->offs[pbase[u]], 1);
+            for (int u = 0; u < 2; ++u) {
+                pbase[u] = (int)((n_rec[u].code >> kRpsQpBits) & 0xFFu);
+                if (u * kRpsThreads + tid < n_here) pos[u] = atomicAdd(&S->offs[pbase[u]], 1);
+            }
             __syncthreads();
             RPS_STAMP(2)
 
@@ -552,18 +550,16 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
             __syncthreads();
             RPS_STAMP(3)
 
-            // ---- (3) records to their sorted slots; the next chunk -- or the first chunk of the next work item -- is requested ----
+            // ---- (3) records to their sorted slots ------------------------------------------------------------------------------------
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if (pos[u] >= 0) {
                     const int e = pos[u] + S->offs[pbase[u]];
                     const unsigned qp = n_rec[u].code & ((1u << kRpsQpBits) - 1u);
                     const int q = P4 ? (int)(qp >> 2) : (int)(qp / (unsigned)P);
-                    S->ent[e] = RpsEnt{(bq0 + q) * g.M + m, n_rec[u].lh, n_rec[u].lw, n_rec[u].a};
+                    S->ent[e] = RpsEnt{n_rec[u].lh, n_rec[u].lw, n_rec[u].a, (bq0 + q) * g.M + m};
                     S->meta[e] = n_rec[u];
                 }
-            if (ch + 1 < n_chunks) fetch_recs(e_first, n_ent, ch + 1);
-            else fetch_recs(next_first, next_n, 0);
             __syncthreads();
             RPS_STAMP(4)
 
@@ -581,8 +577,8 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int vp = (k < 2 ? r0 : lr * gw) + ((k & 1) ? lc : c0);
-                        const float4 a0 = *reinterpret_cast<const float4 *>(S->vtile + vp * kRpsD + c_lo);
-                        const float4 a1 = *reinterpret_cast<const float4 *>(S->vtile + vp * kRpsD + c_hi);
+                        const float4 a0 = *reinterpret_cast<const float4 *>(vt + vp * kRpsD + c_lo);
+                        const float4 a1 = *reinterpret_cast<const float4 *>(vt + vp * kRpsD + c_hi);
                         v[k][0] = (rps_v2f){a0.x, a0.y}; v[k][1] = (rps_v2f){a0.z, a0.w};
                         v[k][2] = (rps_v2f){a1.x, a1.y}; v[k][3] = (rps_v2f){a1.z, a1.w};
                     }
@@ -604,35 +600,53 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         /* lane k of the quad writes dot k over the entry (all four lanes have read it) */                                       \
         reinterpret_cast<float *>(S->ent + (E))[j4] = rps_quad_transpose_sum(d[0], d[1], d[2], d[3], j4);                        \
     }
-                    // software pipeline: while point e is reduced, the grad_out row of point e + 1 is in flight and the entry of
-                    // point e + 2 is being read (the chain entry -> row address -> row is what a list walk waits for)
-#define RPS_ROW(EN, GA, GB)                                                                                                      \
+                    // software pipeline: while point e is reduced, the grad_out row of point e + 1 is in flight and the row index
+                    // of point e + 2 is being read (the chain entry -> row address -> row is what a list walk waits for).  Only the
+                    // row index is read ahead; fractions and weight are read when the point is reduced (registers).
+#define RPS_ROW(ITEM, GA, GB)                                                                                                    \
     {                                                                                                                            \
-        const float *q_ = grad_out + (int64_t)EN.item * kRpsD;                                                                   \
+        const float *q_ = grad_out + (int64_t)(ITEM) * kRpsD;                                                                    \
         GA = *reinterpret_cast<const float4 *>(q_ + c_lo);                                                                       \
         GB = *reinterpret_cast<const float4 *>(q_ + c_hi);                                                                       \
     }
+#define RPS_COEF(E) (*reinterpret_cast<const RpsCoef *>(S->ent + (E)))
                     const int e_last = e1 - 1;
-                    RpsEnt enA = S->ent[e], enB = S->ent[min(e + 1, e_last)];
+                    int itA = S->ent[e].item, itB = S->ent[min(e + 1, e_last)].item;
                     float4 gAa, gAb, gBa, gBb;
-                    RPS_ROW(enA, gAa, gAb)
+                    RPS_ROW(itA, gAa, gAb)
                     for (; e + 1 < e1; e += 2) {
-                        RPS_ROW(enB, gBa, gBb)
-                        const RpsEnt enA2 = S->ent[min(e + 2, e_last)];
-                        RPS_POINT(enA, gAa, gAb, e)
-                        RPS_ROW(enA2, gAa, gAb)
-                        const RpsEnt enB2 = S->ent[min(e + 3, e_last)];
-                        RPS_POINT(enB, gBa, gBb, e + 1)
-                        enA = enA2;
-                        enB = enB2;
+                        RPS_ROW(itB, gBa, gBb)
+                        itA = S->ent[min(e + 2, e_last)].item;
+                        {
+                            const RpsCoef en = RPS_COEF(e);
+                            RPS_POINT(en, gAa, gAb, e)
+                        }
+                        RPS_ROW(itA, gAa, gAb)
+                        itB = S->ent[min(e + 3, e_last)].item;
+                        {
+                            const RpsCoef en = RPS_COEF(e + 1);
+                            RPS_POINT(en, gBa, gBb, e + 1)
+                        }
                     }
-                    if (e < e1) RPS_POINT(enA, gAa, gAb, e)
+                    if (e < e1) {
+                        const RpsCoef en = RPS_COEF(e);
+                        RPS_POINT(en, gAa, gAb, e)
+                    }
+#undef RPS_COEF
 #undef RPS_ROW
 #undef RPS_POINT
                 }
             }
             __syncthreads();
             RPS_STAMP(5)
+            // the next chunk -- or the first chunk of the next work item -- travels while the gradients are written (requested
+            // only now: held across the list walk, the eight registers would spill)
+            const bool last_chunk = ch + 1 == n_chunks;
+            if (!last_chunk) fetch_recs(e_first, n_ent, ch + 1);
+            else {
+                fetch_recs(next_first, next_n, 0);
+                fetch_rows(nit);   // ... and so do the next item's value rows (their buffer was last read in the previous fold)
+            }
 
             // ---- (5) gradients of the points this tile owns: one lane per record, in list order -------------------------------------
 #pragma unroll
@@ -659,33 +673,40 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
                     }
                 }
             }
+            if (last_chunk) store_rows(par ^ 1);
             // (the next chunk clears the histogram now -- its last reader was the list walk -- and rewrites the entries only
             // after three more barriers)
             RPS_STAMP(6)
         }
-        if (n_chunks == 0) fetch_recs(next_first, next_n, 0);   // (an empty bin: nothing was fetched ahead)
-        // ---- fold the partial sums: pixel x of the pixel grid = BR[x] + BL[x+1] + TR[x+gw] + TL[x+gw+1] of the base grid.  The
-        //      four partial sums of list my_p go to four LDS planes (the value rows and the entries are no longer needed) ------------
+        if (n_chunks == 0) {   // (an empty bin: nothing was fetched ahead)
+            fetch_recs(next_first, next_n, 0);
+            fetch_rows(nit);
+            store_rows(par ^ 1);
+        }
+        // ---- fold the partial sums: pixel x of the pixel grid = BR[x] + BL[x+1] + TR[x+gw] + TL[x+gw+1] of the base grid.  BR[x]
+        //      is this quad's own; the other three go through three LDS planes (entries, records and value rows are done with) ----
         __syncthreads();
-        const Item nit = item_geom(next_id);
         {
-            float *plane[4] = {S->stage2, reinterpret_cast<float *>(S->ent), reinterpret_cast<float *>(S->meta), S->vtile};   // TL, TR, BL, BR
+            float *plane[3] = {reinterpret_cast<float *>(S->ent), reinterpret_cast<float *>(S->meta), vt};   // TL, TR, BL
             if (has_px) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < 3; ++k) {
                     *reinterpret_cast<float4 *>(plane[k] + my_p * kRpsD + c_lo) = make_float4(acc[k][0].x, acc[k][0].y, acc[k][1].x, acc[k][1].y);
                     *reinterpret_cast<float4 *>(plane[k] + my_p * kRpsD + c_hi) = make_float4(acc[k][2].x, acc[k][2].y, acc[k][3].x, acc[k][3].y);
                 }
             }
-            fetch_rows(nit, next_n > 0);   // the next item's value rows travel while this one is folded and flushed
             __syncthreads();
-            float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
+            float4 o0 = make_float4(acc[3][0].x, acc[3][0].y, acc[3][1].x, acc[3][1].y);
+            float4 o1 = make_float4(acc[3][2].x, acc[3][2].y, acc[3][3].x, acc[3][3].y);
+            const int gr = quad / gw, gc = quad - gr * gw;
+            const int prow = R0 + gr, pcol = C0 + gc;
+            const int64_t px_off = ((int64_t)(b * g.S + g.lv[l].start + prow * W + pcol) * g.M + m) * kRpsD;   // (+ c_lo / c_hi)
             if (has_px) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    // BR: same index; BL: x + 1; TR: x + gw; TL: x + gw + 1 -- where those base pixels exist
+                for (int k = 0; k < 3; ++k) {
+                    // BL: x + 1; TR: x + gw; TL: x + gw + 1 -- where those base pixels exist
                     const int src = quad + (k == 2 || k == 0 ? 1 : 0) + (k < 2 ? gw : 0);
-                    const bool ok = ((k == 1 || k == 3) || gc + 1 < gw) && (k >= 2 || gr + 1 <= R1 - R0);
+                    const bool ok = (k == 1 || gc + 1 < gw) && (k == 2 || gr + 1 <= R1 - R0);
                     if (ok) {
                         const float4 t0 = *reinterpret_cast<const float4 *>(plane[k] + src * kRpsD + c_lo);
                         const float4 t1 = *reinterpret_cast<const float4 *>(plane[k] + src * kRpsD + c_hi);
@@ -705,7 +726,7 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
                 // several workgroups share the tile: hand the rows over through LDS and add them one channel per lane, so that
                 // a wave instruction adds two whole 128-B rows (32-B atomic segments run ~4x slower)
                 __syncthreads();
-                float *stage = S->vtile;
+                float *stage = reinterpret_cast<float *>(S->ent);
                 if (has_px) {
                     *reinterpret_cast<float4 *>(stage + quad * kRpsD + c_lo) = o0;
                     *reinterpret_cast<float4 *>(stage + quad * kRpsD + c_hi) = o1;
