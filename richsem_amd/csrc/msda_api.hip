@@ -549,7 +549,7 @@ hipError_t launch_bwd_rps(const Problem &pb, const float *value, const float *lo
     const int qpw = pb.P <= 4 ? 16 : (pb.P <= 8 ? 8 : (pb.P <= 16 ? 4 : (pb.P <= 32 ? 2 : 1)));
     const int qpb = qpw * (msda::kRpsRouteThreads / msda::kWave);
     const int64_t r_items = (int64_t)pb.N * pb.M * ((pb.Lq + qpb - 1) / qpb);
-    const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(r_items, 4 * (int64_t)cu_count()));
+    const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(r_items, (int64_t)msda::rps_options().route_wgs.load() * cu_count()));
     hipLaunchKernelGGL(msda::rps_route_kernel<true>, dim3(rgrid), dim3(msda::kRpsRouteThreads), 0, stream, loc, aw, grad_value, grad_loc,
                        grad_aw, pl.g);
     hipLaunchKernelGGL(msda::rps_scan_kernel, dim3(1), dim3(1024), 0, stream, pl.g);
@@ -1034,6 +1034,7 @@ int msda_set_option(const char *key, int value)
     if (key && !strcmp(key, "bwd_variant") && value >= 0 && value <= 4) { g_bwd_variant = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_tile") && value >= 4 && value <= 16) { msda::rps_options().tile = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_max_chunks") && value >= 1 && value <= 4096) { msda::rps_options().max_chunks = value; return MSDA_OK; }
+    if (key && !strcmp(key, "rps_route_wgs") && value >= 1 && value <= 64) { msda::rps_options().route_wgs = value; return MSDA_OK; }
     if (key && !strcmp(key, "psb_margin") && value >= 0 && value <= 64) { msda::psb_options().margin = value; return MSDA_OK; }
     if (key && !strcmp(key, "psb_tile") && value >= 4 && value <= 23) { msda::psb_options().tile = value; return MSDA_OK; }
     if (key && !strcmp(key, "psb_max_chunks") && value >= 1 && value <= 4096) { msda::psb_options().max_chunks = value; return MSDA_OK; }
@@ -1069,6 +1070,7 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "bwd_direct_cpl")) { *value = g_bwd_cpl; return MSDA_OK; }
     if (key && !strcmp(key, "rps_tile")) { *value = msda::rps_options().tile; return MSDA_OK; }
     if (key && !strcmp(key, "rps_max_chunks")) { *value = msda::rps_options().max_chunks; return MSDA_OK; }
+    if (key && !strcmp(key, "rps_route_wgs")) { *value = msda::rps_options().route_wgs; return MSDA_OK; }
     if (key && !strcmp(key, "psb_margin")) { *value = msda::psb_options().margin; return MSDA_OK; }
     if (key && !strcmp(key, "psb_tile")) { *value = msda::psb_options().tile; return MSDA_OK; }
     if (key && !strcmp(key, "psb_max_chunks")) { *value = msda::psb_options().max_chunks; return MSDA_OK; }

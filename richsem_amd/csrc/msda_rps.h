@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         float at[kRpsMaxL];
 #pragma unroll
         for (int l = 0; l < kRpsMaxL; ++l) {
-            xy[l] = live && l < g.L ? *reinterpret_cast<const float2 *>(loc + 2u * (pt0 + (unsigned)(l * P))) : make_float2(-4.f, -4.f);
+            xy[l] = live && l < g.L && !(g.dbg & 4) ? *reinterpret_cast<const float2 *>(loc + 2u * (pt0 + (unsigned)(l * P))) : make_float2((g.dbg & 4) ? 0.001f * (float)(q & 511) : -4.f, (g.dbg & 4) ? 0.3f : -4.f);
             at[l] = !COUNT && live && l < g.L ? aw[pt0 + (unsigned)(l * P)] : 0.f;
         }
         __syncthreads();
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
             inmap[l] = t.inmap;
             const int ob = t.bin[0];
             const unsigned long long vote = __ballot(ob >= 0);
-            if (vote) {   // (uniform)
+            if (vote && !(g.dbg & 2)) {   // (uniform)
                 const int ld = __ffsll((long long)vote) - 1;
                 const int lb = __shfl(ob, ld, kWave);
                 const unsigned long long match = __ballot(ob == lb);
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
             const unsigned c = hist[i];
             if (c) {
                 const size_t gb = (size_t)pair * B + i;
-                if (COUNT) atomicAdd(g.bin_count + gb * kRpsPad, c);
+                if (COUNT) { if (!(g.dbg & 1)) atomicAdd(g.bin_count + gb * kRpsPad, c); }
                 else base[i] = g.bin_start[gb] + atomicAdd(g.bin_fill + gb * kRpsPad, c);
             }
         }
@@ -323,28 +323,38 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
 // and the place-pass cursors zeroed for this one.
 __global__ __launch_bounds__(1024) void rps_scan_kernel(const RpsGeom g)
 {
-    __shared__ unsigned part[1024];
-    const int tid = threadIdx.x;
+    __shared__ unsigned wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int per = (g.nbins + 1023) / 1024;
     const int i0 = tid * per, i1 = min(g.nbins, i0 + per);
+    constexpr int kKeep = 4;   // counts kept in registers (all of them for the usual few thousand bins)
+    unsigned keep[kKeep];
     unsigned s = 0;
-    for (int i = i0; i < i1; ++i) s += g.bin_count[(size_t)i * kRpsPad];
-    part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const unsigned t = tid >= d ? part[tid - d] : 0u;
-        __syncthreads();
-        part[tid] += t;
-        __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kKeep; ++k) {
+        keep[k] = i0 + k < i1 ? g.bin_count[(size_t)(i0 + k) * kRpsPad] : 0u;
+        s += keep[k];
     }
-    unsigned run = part[tid] - s;
+    for (int i = i0 + kKeep; i < i1; ++i) s += g.bin_count[(size_t)i * kRpsPad];
+    unsigned incl = s;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const unsigned t = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += t;
+    }
+    if (lane == kWave - 1) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned run = incl - s;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) run += w < wave ? wave_tot[w] : 0u;
+    if (tid == 1023) g.bin_start[g.nbins] = run + s;
     for (int i = i0; i < i1; ++i) {
+        const unsigned c = i - i0 < kKeep ? keep[min(i - i0, kKeep - 1)] : g.bin_count[(size_t)i * kRpsPad];
         g.bin_start[i] = run;
-        run += g.bin_count[(size_t)i * kRpsPad];
+        run += c;
         g.bin_count[(size_t)i * kRpsPad] = 0u;
         g.bin_fill[(size_t)i * kRpsPad] = 0u;
     }
-    if (tid == 1023) g.bin_start[g.nbins] = part[1023];
 }
 
 typedef float rps_v2f __attribute__((ext_vector_type(2)));
@@ -368,8 +378,7 @@ __device__ __forceinline__ float rps_quad_transpose_sum(float d0, float d1, floa
 // reduction, the entry read) is shared by 8 channels per lane instead of 4.
 // List p stays on quad p, whose partial sums live in registers across the chunks of a tile.
 // Everything a work item needs from memory is requested while the previous one is still being reduced: the queue is drawn
-// two items ahead (the draw of item k+2 is issued at the start of item k and first looked at one item later), the bin
-// bounds of the next item are requested at the start of the current one, its first chunk of records and its value rows
+// two items ahead, the bin bounds of the next item are requested at the start of the current one, its first chunk of records and its value rows
 // (into the second value buffer) while the last chunk's gradients are written.
 // Registers are the scarce resource (128 at 1024 threads, ~110 of them in the list walk): work-item geometry is kept
 // uniform (SGPRs), per-lane positions are recomputed where needed, prefetches are unconditional loads from clamped addresses
@@ -432,18 +441,20 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         first = 0;
         n = 0;
         if (id < n_items) {
-            const unsigned unit = (unsigned)rps_uni((int)g.units[id / g.ppx]);
+            const unsigned unit = g.units[id / g.ppx];
             const int pair = xq + kXcds * (id % g.ppx);
             if (pair < pairs) {
                 const int l = unit & 3, ty = (unit >> 2) & 63, tx = (unit >> 8) & 63, slab = (unit >> 14) & 255, nslab = (unit >> 22) & 255;
                 const int bin = pair * g.bins_per_pair + g.lv[l].bin0 + (ty * g.lv[l].ntx + tx) * nslab + slab;
-                first = (unsigned)rps_uni((int)g.bin_start[bin]);
-                n = rps_uni((int)g.bin_start[bin + 1]) - (int)first;
+                first = g.bin_start[bin];
+                n = (int)(g.bin_start[bin + 1] - first);
             }
         }
     };
     RpsRec n_rec[2];   // this lane's two records of the chunk in flight (lanes past the end of the bin: a copy of its last record)
-    auto fetch_recs = [&](unsigned first, int n, int ch) {
+    auto fetch_recs = [&](unsigned first_, int n_, int ch) {
+        const unsigned first = (unsigned)rps_uni((int)first_);
+        const int n = rps_uni(n_);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int k = ch * kRpsChunk + u * kRpsThreads + tid;
@@ -475,6 +486,8 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
     unsigned e_first;
     int n_ent;
     bin_range(item_id, e_first, n_ent);
+    e_first = (unsigned)rps_uni((int)e_first);
+    n_ent = rps_uni(n_ent);
     fetch_recs(e_first, n_ent, 0);
     Item it = item_geom(item_id);
     fetch_rows(it);
@@ -502,7 +515,7 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         const int next_id = rps_uni(S->item_slot[par ^ 1]);
         unsigned next_first;
         int next_n;
-        bin_range(next_id, next_first, next_n);
+        bin_range(next_id, next_first, next_n);   // (made uniform where first used: that waits for the two loads)
         const Item nit = item_geom(next_id);
         const int my_p = quad;   // the base pixel whose list this quad walks
         RPS_STAMP(0)
@@ -744,8 +757,8 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         __syncthreads();
         RPS_STAMP(7)
         item_id = next_id;
-        e_first = next_first;
-        n_ent = next_n;
+        e_first = (unsigned)rps_uni((int)next_first);
+        n_ent = rps_uni(next_n);
         it = nit;
         par ^= 1;
     }
@@ -760,6 +773,7 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
 struct RpsOptions {
     std::atomic<int> tile{16};         // largest tile side + 1 (tile + one row / column <= 256 pixels)
     std::atomic<int> max_chunks{6};    // expected chunks of one workgroup before a tile is split into slabs
+    std::atomic<int> route_wgs{4};     // route passes: workgroups per CU (persistent over the query blocks)
 };
 inline RpsOptions &rps_options()
 {
