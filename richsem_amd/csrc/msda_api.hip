@@ -89,15 +89,16 @@ struct ProfileScope {
 // that does not ("general share") is a property of the DATA (how far the network's offsets reach).  Measured on MI355X
 // (tools/locality_sweep2.sh, call E; profiles/r02_locality.md): the window forward -- which finishes the points that miss
 // their window per point, after the item -- beats the direct forward up to a share of ~8 % (sigma ~4.5 px); the window backward
-// beats the routed backward up to ~3.5 % (sigma ~3.5 px), and the routed backward, whose cost does not depend on the
-// distribution, beats the direct backward everywhere.  In automatic mode the library therefore lets the window
+// beats the routed backward only up to ~1 % (sigma ~2 px: 376 us both; at 1 px 372 vs 374), and the routed backward, whose cost
+// does not depend on the distribution, beats the direct backward everywhere.  In automatic mode the library therefore lets the window
 // forward kernel count its general points now and then (one atomic per wave), brings the count back with an
 // asynchronous copy + event on the caller's stream, and reads it on a LATER call once the event has completed -- no
 // call ever waits.  Nothing is probed while the stream is being captured into a graph.
 constexpr float kFwdShareMax = 0.08f, kBwdShareMax = 0.23f;
 // Backward: above this share of window misses the routed kernels (msda_rps.h), whose cost does not depend on where the points
-// fall, beat the window kernels (MI355X, call E: window 383 / 497 / 2190 us at sigma 1 px / 4 px / uniform, routed 431 / 450 / 702)
-constexpr float kBwdRoutedShare = 0.035f;
+// fall, beat the window kernels (MI355X, call E: window 372 / 405 / 485 / 2190 us at sigma 1 / 3 / 4 px / uniform, routed 374 /
+// 375 / 375 / 447)
+constexpr float kBwdRoutedShare = 0.01f;
 constexpr unsigned kProbeWarmCalls = 2, kProbeEvery = 64;   // per (shape, sampling_loc buffer)
 constexpr int kMaxDevices = 64;
 std::atomic<int> g_monitor_on{1};
