@@ -98,7 +98,7 @@ constexpr float kFwdShareMax = 0.08f, kBwdShareMax = 0.23f;
 // Backward: above this share of window misses the routed kernels (msda_rps.h), whose cost does not depend on where the points
 // fall, beat the window kernels (MI355X, call E: window 372 / 405 / 485 / 2190 us at sigma 1 / 3 / 4 px / uniform, routed 374 /
 // 375 / 375 / 447)
-constexpr float kBwdRoutedShare = 0.01f;
+constexpr float kBwdRoutedShare = 0.015f;
 constexpr unsigned kProbeWarmCalls = 2, kProbeEvery = 64;   // per (shape, sampling_loc buffer)
 constexpr int kMaxDevices = 64;
 std::atomic<int> g_monitor_on{1};
@@ -633,7 +633,7 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
     // large calls: more waves per SIMD, shallower per-wave pipeline (see fwd_direct_kernel)
     const bool many = (int64_t)N * Lq * M >= 65536;
 #define MSDA_LAUNCH_FWD(CC)                                                                                              \
-    if (many) hipLaunchKernelGGL((msda::fwd_direct_kernel<T, CC, 8>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g); \
+    if (many) hipLaunchKernelGGL((msda::fwd_direct_kernel<T, CC, 6>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g); \
     else hipLaunchKernelGGL((msda::fwd_direct_kernel<T, CC, 4>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g)
     switch (C) {
         case 4: MSDA_LAUNCH_FWD((sizeof(T) == 4 ? 4 : 2)); break;
@@ -840,7 +840,7 @@ int forward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const in
     ProfileScope prof(0, 1, 2, N, S, M, D, L, Lq, P, stream);
     const bool many = (int64_t)N * Lq * M >= 65536;
 #define MSDA_LAUNCH_FWD(CC)                                                                                                          \
-    if (many) hipLaunchKernelGGL((msda::fwd_direct_kernel<float, CC, 8, msda::bf16_t>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g); \
+    if (many) hipLaunchKernelGGL((msda::fwd_direct_kernel<float, CC, 6, msda::bf16_t>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g); \
     else hipLaunchKernelGGL((msda::fwd_direct_kernel<float, CC, 4, msda::bf16_t>), grid, block, lds, stream, value, shapes, lsi, loc, aw, out, g)
     switch (C) {
         case 4: MSDA_LAUNCH_FWD(4); break;

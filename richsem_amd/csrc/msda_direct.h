@@ -58,9 +58,9 @@ __device__ __forceinline__ void load_levels(LevelGeom *lv, const int64_t *shapes
 }
 
 // OCC = waves per SIMD the register budget is cut for.  Measured on MI355X: the kernel waits on its gathers 78 % of the time
-// (PMC), so for large calls twice the waves with half the loads in flight each win (call E: 190 -> 157 us at OCC 8), while a
-// small call (decoder: 1092 queries) is faster with the deeper per-wave pipeline of OCC 4 (19.5 vs 23 us).
-// TV = storage type of value / out (T itself, or bf16_t with T = float)
+// (PMC), so for large calls more waves with half the loads in flight each win (call E: 190 -> 157 us), while a small call
+// (decoder: 1092 queries) is faster with the deeper per-wave pipeline of OCC 4 (19.5 vs 23 us).  Large calls use OCC 6:
+// at 8 the 64-register budget spills (28 B per lane, 64 MB of scratch writes per E call) and runs 2.5 % slower.
 template <typename T, int C, int OCC, typename TV = T>
 __global__ __launch_bounds__(kDirectThreads, OCC) void fwd_direct_kernel(
     const TV *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kDirectThreads, OCC) void fwd_direct_kernel(
                 __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is in order; stop compiler motion
                 // (2) gather: every lane walks the item's points, C channels each
                 if (has_c) {
-#pragma unroll(OCC >= 8 ? 2 : 4)
+#pragma unroll(OCC >= 6 ? 2 : 4)
                     for (int pt = 0; pt < np; ++pt) {
                         const PointRec<T> r = my[pt];
                         Pack<T, C> v[4];
