@@ -79,15 +79,27 @@ const char *msda_last_error(void);
 
 /* Tuning / test hooks.  Keys:
  *   "fwd_variant"     0 = auto, 1 = direct gather kernel, 2 = LDS-window kernel (when applicable)
- *   "bwd_variant"     0 = auto, 1 = global-atomic kernel, 2 = LDS-accumulation kernels (when applicable)
- *                     auto = window kernels for encoder-shaped fp32 calls while the locality monitor (below) finds the
- *                     sampling points local enough, the direct kernels otherwise
- *   "locality_monitor"  1 (default) = in auto mode the window forward kernel counts, on the first 8 calls of a problem
- *                     shape and on every 64th after, the points that miss their window; the count comes back by an
- *                     asynchronous copy and is read on a later call (no call waits, nothing is probed during graph
- *                     capture).  Share > 2 % -> direct forward, share > 23 % -> direct backward (crossovers measured on
- *                     MI355X).  0 = auto always takes the window kernels when they apply.  Setting it forgets what was
- *                     learnt.  "locality_share_ppm" (get only): last measured share in parts per million, -1 = none.
+ *   "bwd_variant"     0 = auto, 1 = direct kernel (level-sum windows / row atomics), 2 = LDS-window kernels, 3 = pixel-
+ *                     stationary kernel with candidate queries by geometry (opt-in only: slower), 4 = routed pixel-
+ *                     stationary kernels (sampling points routed to output tiles in two exact passes; cost independent of
+ *                     where the points fall).  2-4 apply to fp32, D = 32, L <= 4 (2 also needs Lq == S); otherwise the
+ *                     call falls back to 1.
+ *                     auto = for encoder-shaped fp32 calls the locality monitor (below) decides: window kernels while the
+ *                     sampling points are local, direct forward / routed backward otherwise; other calls: direct kernels
+ *   "locality_monitor"  1 (default) = in auto mode the window forward kernel counts the points that miss their window on the
+ *                     first 2 calls of a (problem shape, sampling_loc buffer) and on every 64th after; the count comes back
+ *                     by an asynchronous copy and is read on a later call (no call waits, nothing is probed during graph
+ *                     capture, up to 8 probes in flight).  Until a share is known: direct forward, routed backward.
+ *                     Share > 8 % -> direct forward, share > 1.5 % -> routed backward (crossovers measured on MI355X,
+ *                     profiles/r02_locality.md).  0 = auto always takes the window kernels when they apply.  Setting it
+ *                     forgets what was learnt.  "locality_share_ppm" (get only): last measured share in parts per
+ *                     million, -1 = none.
+ *   "rps_tile"        routed backward: largest tile side + 1 (4..16, default 16: tile + one row / column <= 256 pixels)
+ *   "rps_max_chunks"  routed backward: chunks of 2048 points one workgroup takes before a tile's points are dealt over
+ *                     several workgroups (default 12)
+ *   "rps_route_wgs"   routed backward: workgroups per CU of the route passes (default 4)
+ *   "psb_margin", "psb_tile", "psb_max_chunks", "psb_coarse_px"   geometry of bwd_variant 3
+ *   "levelsum_lds_kb" level-sum window size in KB (8..150, default 150 = one workgroup per CU)
  *   "bwd_direct_cpl"  channels per lane of the direct backward kernel (0 = auto, 1, 2, 4)
  *   "tile_region"     side of an LDS-window region, in pixels of the finest level (default 20)
  *   "tile_margin"     window margin around a region, in pixels of the sampled level (default 6)

@@ -772,7 +772,7 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 struct RpsOptions {
     std::atomic<int> tile{16};         // largest tile side + 1 (tile + one row / column <= 256 pixels)
-    std::atomic<int> max_chunks{6};    // expected chunks of one workgroup before a tile is split into slabs
+    std::atomic<int> max_chunks{12};   // expected chunks of one workgroup before a tile is split into slabs (MI355X, call E: 6 -> 12 = 463 -> 447 us on uniform locations, equal at the init pattern)
     std::atomic<int> route_wgs{4};     // route passes: workgroups per CU (persistent over the query blocks)
 };
 inline RpsOptions &rps_options()
