@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RICHSEM_MSDA_ABI_VERSION 2
+#define RICHSEM_MSDA_ABI_VERSION 3
 
 /* Return codes: 0 = success; negative = argument error detected on the host (nothing was
  * launched); positive = hipError_t reported by the runtime. */
@@ -246,6 +246,22 @@ int msda_prep_backward_f64(const double *grad_loc, const double *grad_aw, const 
 int msda_mask_rows_f32(float *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);
 int msda_mask_rows_f64(double *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);
 int msda_mask_rows_bf16(uint16_t *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);
+
+/* ---- feed-forward block of the transformer layers on the matrix cores ----------
+ *     out = LayerNorm(x + W2 . relu(W1 . x + b1) + b2)
+ * reference: models/richsem/deformable_transformer.py:862-866 (encoder forward_ffn), :940-944 (decoder forward_ffn), with
+ * activation = relu and the dropouts inactive (p = 0.0 in the shipped configs, or eval mode).  bf16 storage, fp32
+ * accumulation; the hidden activation is rounded to bf16 once (as a bf16 nn.Linear would), everything after the second
+ * product (bias, residual, LayerNorm) is fp32 and rounded once at the store.  New capability: the reference runs fp32.
+ *   x, out       (tokens, d_model) bf16, row-major;  d_model must be 256
+ *   w1           (d_ffn, d_model) bf16 = linear1.weight;  b1 (d_ffn) f32 = linear1.bias;  d_ffn % 32 == 0, <= 4096
+ *   w2_packed    linear2.weight (d_model, d_ffn) bf16 after msda_ffn_pack_w2_bf16 (a fixed permutation of the hidden
+ *                columns inside every group of 16: repack whenever the weight changes);  b2 (d_model) f32
+ *   ln_weight, ln_bias (d_model) f32, eps as nn.LayerNorm.  All pointers 16-byte aligned. */
+int msda_ffn_pack_w2_bf16(const uint16_t *w2, int d_model, int d_ffn, uint16_t *w2_packed, msda_stream_t stream);
+int msda_ffn_forward_bf16(const uint16_t *x, const uint16_t *w1, const float *b1, const uint16_t *w2_packed, const float *b2,
+                          const float *ln_weight, const float *ln_bias, float eps, int tokens, int d_model, int d_ffn,
+                          uint16_t *out, msda_stream_t stream);
 
 #ifdef __cplusplus
 }

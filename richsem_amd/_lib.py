@@ -16,7 +16,7 @@ ERR_NAMES = {
     -4: "MSDA_ERR_TOO_LARGE", -5: "MSDA_ERR_MISALIGNED", -6: "MSDA_ERR_NO_DEVICE", -7: "MSDA_ERR_BAD_OPTION",
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/richsem_msda.h declares
 SYMBOLS = [
@@ -26,6 +26,7 @@ SYMBOLS = [
     "msda_forward_bf16", "msda_backward_bf16",
     "msda_prep_forward_f32", "msda_prep_forward_f64", "msda_prep_backward_f32", "msda_prep_backward_f64",
     "msda_mask_rows_f32", "msda_mask_rows_f64", "msda_mask_rows_bf16",
+    "msda_ffn_pack_w2_bf16", "msda_ffn_forward_bf16",
 ]
 
 
@@ -71,6 +72,10 @@ def load():
     L.msda_profile_enable.restype = ci
     L.msda_profile_collect.argtypes = [ctypes.POINTER(ProfileRecord), ci, ctypes.POINTER(ci)]
     L.msda_profile_collect.restype = ci
+    L.msda_ffn_pack_w2_bf16.argtypes = [vp, ci, ci, vp, vp]
+    L.msda_ffn_pack_w2_bf16.restype = ci
+    L.msda_ffn_forward_bf16.argtypes = [vp] * 7 + [ctypes.c_float, ci, ci, ci, vp, vp]
+    L.msda_ffn_forward_bf16.restype = ci
     for sfx in ("f32", "f64", "bf16"):
         f = getattr(L, "msda_forward_" + sfx)
         f.argtypes = [vp] * 5 + [ci] * 8 + [vp, vp, vp, vp]

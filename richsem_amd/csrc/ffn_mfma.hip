@@ -1,0 +1,256 @@
+// ffn_mfma.hip -- the transformer layers' feed-forward block as ONE gfx950 MFMA kernel (bf16 storage, fp32 accumulation):
+//
+//     out = LayerNorm(x + W2 . relu(W1 . x + b1) + b2)            reference: models/richsem/deformable_transformer.py:862-866
+//                                                                  (encoder forward_ffn) and :940-944 (decoder forward_ffn)
+//
+// RichSem: d_model = 256, d_ffn = 2048; the encoder calls it on N*S = 44646 tokens per layer: 93.6 GFLOP, the largest dense
+// contraction of the transformer.  The hidden activation (44646 x 2048: 183 MB in bf16) never
+// leaves the chip.
+//
+// Everything is computed TRANSPOSED, so that tokens sit on the lanes and channels in the registers:
+//     H^T   (hidden x tokens) = W1 (hidden x 256)  . x^T        A operand = nn.Linear's own row-major weight, B = x rows
+//     out^T (256 x tokens)   += W2 (256 x hidden)  . relu(H^T)   A operand = nn.Linear's own weight again
+// A 32x32 accumulator tile of mfma_f32_32x32x16_bf16 has its column (token) on the lane and its rows (hidden) in the 16
+// registers, and the second product sums over exactly those rows -- so relu(H^T), converted to bf16, IS the B operand of
+// the second product: no LDS round trip, no lane movement (guide: "an accumulator tile as the next MFMA's operand").  The k
+// order inside such an operand is permuted (element j of lane half h is row 16s + 8(j>>2) + 4h + (j&3)), so W2 is repacked
+// once (msda_ffn_pack_w2_bf16: the two middle groups of four of every 16 hidden columns change places) and then read with
+// plain 16-byte fragments.  The LayerNorm runs over registers: a lane holds 128 of its token's 256 channels, lane ^ 32 the rest.
+//
+// Work decomposition: a wave owns 64 tokens (two MFMA column tiles: every weight fragment it reads feeds two MFMAs), a
+// workgroup is two waves, two workgroups share a CU (one wave per SIMD, up to 512 registers each: 256 accumulators for out^T,
+// 128 for the wave's x fragments, 32 for the hidden tile).  The weights stream through LDS in tiles of 32 hidden units
+// (16 KB of W1 + 16 KB of W2), double-buffered, by LDS DMA (global_load_lds_dwordx4: no registers) straight into
+// FRAGMENT ORDER -- fragment f is 1 KB, lane l's 16 bytes at l*16 -- so every operand read is a conflict-free ds_read_b128.
+// LDS traffic: 32 KB per wave and tile against 64 MFMAs of 32 cycles: half of the LDS rate with four waves per CU.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "../../include/richsem_msda.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kD = 256;            // d_model (fixed: 8 output row tiles, 16 k-steps)
+constexpr int kTokWave = 64;       // tokens per wave
+constexpr int kWaves = 2;
+constexpr int kTokWg = kTokWave * kWaves;
+constexpr int kHT = 32;            // hidden units per weight tile
+constexpr int kFragShorts = 512;   // one MFMA operand fragment: 64 lanes x 8 bf16
+constexpr int kTileFrags = 32;     // 16 of W1 (k-steps over d_model) + 16 of W2 (8 row tiles x 2 k-steps)
+constexpr int kMaxFfn = 4096;
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+{
+    const __hip_bfloat162 p = __float22bfloat162_rn(make_float2(a, b));
+    return *reinterpret_cast<const unsigned *>(&p);
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+// W2 (256 x F, row-major) -> the k order the accumulator-as-operand idiom needs: inside every 16 hidden columns the groups of
+// four are stored in the order 0, 2, 1, 3.
+__global__ void pack_w2_kernel(const uint16_t *__restrict__ w2, uint16_t *__restrict__ w2p, long long n)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)((i >> 2) & 3);
+        const int sg = g == 1 ? 2 : (g == 2 ? 1 : g);
+        w2p[i] = w2[(i & ~15ll) + sg * 4 + (i & 3)];
+    }
+}
+
+__global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w1, const float *__restrict__ b1,
+                    const uint16_t *__restrict__ w2p, const float *__restrict__ b2, const float *__restrict__ gamma,
+                    const float *__restrict__ beta, float eps, int T, int F, uint16_t *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    short *wbuf = reinterpret_cast<short *>(smem);                                  // [2][kTileFrags * kFragShorts]
+    float *lb1 = reinterpret_cast<float *>(smem + 2 * kTileFrags * kFragShorts * 2);   // [F]
+    float *lb2 = lb1 + F, *lgam = lb2 + kD, *lbet = lgam + kD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tok0 = blockIdx.x * kTokWg + wave * kTokWave;
+    const int nt = F / kHT;
+
+    // biases and LayerNorm parameters -> LDS (ordinary loads: all of them retire before the first LDS DMA is issued)
+    for (int i = tid; i < F; i += kWaves * 64) lb1[i] = b1[i];
+    for (int i = tid; i < kD; i += kWaves * 64) { lb2[i] = b2[i]; lgam[i] = gamma[i]; lbet[i] = beta[i]; }
+
+    // this wave's x fragments (B operand of the first product): lane (r, h) holds x[token r][16 s + 8 h + 0..7]
+    bf16x8 xf[2][16];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int tok = min(tok0 + 32 * ct + r, T - 1);
+        const uint16_t *row = x + (size_t)tok * kD + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) xf[ct][s] = *reinterpret_cast<const bf16x8 *>(row + 16 * s);
+    }
+
+    f32x16 acc[2][8];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ct][t][i] = 0.f;
+
+    // weight tile `ht` -> LDS buffer, in fragment order; each wave brings half of the 32 fragments
+    auto stage = [&](int ht, int buf) {
+        short *dst = wbuf + buf * (kTileFrags * kFragShorts);
+#pragma unroll
+        for (int i = 0; i < kTileFrags / kWaves; ++i) {
+            const int f = wave * (kTileFrags / kWaves) + i;   // (uniform)
+            const uint16_t *src;
+            if (f < 16) src = w1 + (size_t)(ht * kHT + r) * kD + 16 * f + 8 * h;                                   // k-step f of W1
+            else src = w2p + (size_t)(32 * ((f - 16) >> 1) + r) * F + ht * kHT + 16 * ((f - 16) & 1) + 8 * h;       // (row tile, k-step) of W2
+            __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void *>(
+                                                      reinterpret_cast<uintptr_t>(dst + f * kFragShorts)), 16, 0, 0);
+        }
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the ordinary loads above have retired
+    stage(0, 0);
+
+    for (int ht = 0; ht < nt; ++ht) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of tile ht has landed
+        __syncthreads();                      // ... and everybody's; everybody is done with the other buffer
+        if (ht + 1 < nt) stage(ht + 1, (ht + 1) & 1);
+        const short *wt = wbuf + (ht & 1) * (kTileFrags * kFragShorts) + lane * 8;
+
+        // ---- H^T tile = W1 tile . x^T + b1 ------------------------------------------------------------------------------
+        f32x16 hacc[2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {   // rows 8 g + 4 h + 0..3 of the tile live in registers 4 g .. 4 g + 3
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(lb1 + ht * kHT + 8 * g + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hacc[0][4 * g + i] = hacc[1][4 * g + i] = bb[i];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wt + s * kFragShorts);
+            hacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[0][s], hacc[0], 0, 0, 0);
+            hacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[1][s], hacc[1], 0, 0, 0);
+        }
+        // ---- relu, to bf16: registers 8 s .. 8 s + 7 are the B fragment of k-step s ------------------------------------------
+        bf16x8 hb[2][2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                unsigned u[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    u[p] = pack_bf16(fmaxf(hacc[ct][8 * s + 2 * p], 0.f), fmaxf(hacc[ct][8 * s + 2 * p + 1], 0.f));
+                hb[ct][s] = *reinterpret_cast<const bf16x8 *>(u);
+            }
+        // ---- out^T += W2 tile . relu(H^T) ----------------------------------------------------------------------------------
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wt + (16 + 2 * t + s) * kFragShorts);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[0][s], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[1][s], acc[1][t], 0, 0, 0);
+            }
+    }
+
+    // ---- epilogue: + b2 + x, LayerNorm over the 256 channels of a token (128 in this lane, 128 in lane ^ 32), bf16 store -----------
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int tok = tok0 + 32 * ct + r;
+        const bool live = tok < T;
+        const uint16_t *xrow = x + (size_t)min(tok, T - 1) * kD;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = 32 * t + 8 * g + 4 * h;   // channels c .. c + 3 <-> registers 4 g .. 4 g + 3 of tile t
+                const uint2 xr = *reinterpret_cast<const uint2 *>(xrow + c);
+                const f32x4 bb = *reinterpret_cast<const f32x4 *>(lb2 + c);
+                const float xv[4] = {bf16_lo(xr.x), bf16_hi(xr.x), bf16_lo(xr.y), bf16_hi(xr.y)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[ct][t][4 * g + i] += bb[i] + xv[i];
+                    sum += acc[ct][t][4 * g + i];
+                }
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.f / kD);
+        float var = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float d = acc[ct][t][i] - mean;
+                var += d * d;
+            }
+        var += __shfl_xor(var, 32, 64);
+        const float rstd = rsqrtf(var * (1.f / kD) + eps);
+        if (live) {
+            uint16_t *orow = out + (size_t)tok * kD;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = 32 * t + 8 * g + 4 * h;
+                    const f32x4 ga = *reinterpret_cast<const f32x4 *>(lgam + c), be = *reinterpret_cast<const f32x4 *>(lbet + c);
+                    float y[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] = (acc[ct][t][4 * g + i] - mean) * rstd * ga[i] + be[i];
+                    uint2 o;
+                    o.x = pack_bf16(y[0], y[1]);
+                    o.y = pack_bf16(y[2], y[3]);
+                    *reinterpret_cast<uint2 *>(orow + c) = o;
+                }
+        }
+    }
+}
+
+size_t ffn_lds_bytes(int F) { return (size_t)2 * kTileFrags * kFragShorts * 2 + (size_t)(F + 3 * kD) * 4; }
+
+}  // namespace
+
+extern "C" {
+
+int msda_ffn_pack_w2_bf16(const uint16_t *w2, int d_model, int d_ffn, uint16_t *w2_packed, msda_stream_t stream)
+{
+    if (!w2 || !w2_packed) return MSDA_ERR_NULL_POINTER;
+    if (d_model != kD || d_ffn < kHT || d_ffn % kHT != 0 || d_ffn > kMaxFfn) return MSDA_ERR_BAD_DIMS;
+    const long long n = (long long)d_model * d_ffn;
+    hipLaunchKernelGGL(pack_w2_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), w2, w2_packed, n);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
+
+int msda_ffn_forward_bf16(const uint16_t *x, const uint16_t *w1, const float *b1, const uint16_t *w2_packed, const float *b2,
+                          const float *ln_weight, const float *ln_bias, float eps, int tokens, int d_model, int d_ffn,
+                          uint16_t *out, msda_stream_t stream)
+{
+    if (!x || !w1 || !b1 || !w2_packed || !b2 || !ln_weight || !ln_bias || !out) return MSDA_ERR_NULL_POINTER;
+    if (d_model != kD || d_ffn < kHT || d_ffn % kHT != 0 || d_ffn > kMaxFfn || tokens < 0) return MSDA_ERR_BAD_DIMS;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2_packed) |
+         reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(b2) |
+         reinterpret_cast<uintptr_t>(ln_weight) | reinterpret_cast<uintptr_t>(ln_bias)) & 15)
+        return MSDA_ERR_MISALIGNED;
+    if (tokens == 0) return MSDA_OK;
+    const size_t lds = ffn_lds_bytes(d_ffn);
+    static bool raised = false;   // (per process; the limit is a property of the function)
+    if (!raised) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return (int)e;
+        raised = true;
+    }
+    const int grid = (tokens + kTokWg - 1) / kTokWg;
+    hipLaunchKernelGGL(ffn_fwd_kernel, dim3(grid), dim3(kWaves * 64), lds, static_cast<hipStream_t>(stream), x, w1, b1, w2_packed, b2,
+                       ln_weight, ln_bias, eps, tokens, d_ffn, out);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
+
+}  // extern "C"
