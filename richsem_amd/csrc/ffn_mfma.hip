@@ -18,11 +18,15 @@
 // plain 16-byte fragments.  The LayerNorm runs over registers: a lane holds 128 of its token's 256 channels, lane ^ 32 the rest.
 //
 // Work decomposition: a wave owns 64 tokens (two MFMA column tiles: every weight fragment it reads feeds two MFMAs), a
-// workgroup is two waves, two workgroups share a CU (one wave per SIMD, up to 512 registers each: 256 accumulators for out^T,
-// 128 for the wave's x fragments, 32 for the hidden tile).  The weights stream through LDS in tiles of 32 hidden units
-// (16 KB of W1 + 16 KB of W2), double-buffered, by LDS DMA (global_load_lds_dwordx4: no registers) straight into
+// workgroup is four waves -- one per SIMD, up to 512 registers each: 256 accumulators for out^T, 128 for the wave's x
+// fragments, 32 for the hidden tile -- and has its CU to itself.  The weights stream through LDS in tiles of 32 hidden
+// units (16 KB of W1 + 16 KB of W2), a ring of three, by LDS DMA (global_load_lds_dwordx4: no registers) straight into
 // FRAGMENT ORDER -- fragment f is 1 KB, lane l's 16 bytes at l*16 -- so every operand read is a conflict-free ds_read_b128.
-// LDS traffic: 32 KB per wave and tile against 64 MFMAs of 32 cycles: half of the LDS rate with four waves per CU.
+// LDS traffic: 32 KB per wave and tile against 64 MFMAs of 32 cycles: half of the LDS rate.
+// The pipeline is hand-scheduled where hipcc would drain it: tiles are requested TWO ahead and waited for with a partial
+// vmcnt before a bare s_barrier (a __syncthreads, or any LDS read the compiler can see, waits for every LDS DMA in flight),
+// and the operand reads are inline ds_read_b128 a group ahead of the MFMAs that use them, released by partial lgkmcnt waits
+// (a wave has its SIMD to itself, so nothing else hides the LDS latency).
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
@@ -37,7 +41,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kD = 256;            // d_model (fixed: 8 output row tiles, 16 k-steps)
 constexpr int kTokWave = 64;       // tokens per wave
-constexpr int kWaves = 2;
+constexpr int kWaves = 4;
+constexpr int kRing = 3;           // weight tiles in LDS
 constexpr int kTokWg = kTokWave * kWaves;
 constexpr int kHT = 32;            // hidden units per weight tile
 constexpr int kFragShorts = 512;   // one MFMA operand fragment: 64 lanes x 8 bf16
@@ -63,14 +68,21 @@ __global__ void pack_w2_kernel(const uint16_t *__restrict__ w2, uint16_t *__rest
     }
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// one operand fragment from LDS, not visible to the compiler's wait-count bookkeeping (see the header)
+#define FFN_READ(dst, addr, byte_off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(byte_off))
+// "at most n LDS reads still in flight": everything older has arrived.  The operands tie the fragments to the wait.
+#define FFN_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n))
+
 __global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w1, const float *__restrict__ b1,
                     const uint16_t *__restrict__ w2p, const float *__restrict__ b2, const float *__restrict__ gamma,
                     const float *__restrict__ beta, float eps, int T, int F, uint16_t *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    short *wbuf = reinterpret_cast<short *>(smem);                                  // [2][kTileFrags * kFragShorts]
-    float *lb1 = reinterpret_cast<float *>(smem + 2 * kTileFrags * kFragShorts * 2);   // [F]
+    short *wbuf = reinterpret_cast<short *>(smem);                                          // [kRing][kTileFrags * kFragShorts]
+    float *lb1 = reinterpret_cast<float *>(smem + kRing * kTileFrags * kFragShorts * 2);    // [F]
     float *lb2 = lb1 + F, *lgam = lb2 + kD, *lbet = lgam + kD;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -100,27 +112,39 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[ct][t][i] = 0.f;
 
-    // weight tile `ht` -> LDS buffer, in fragment order; each wave brings half of the 32 fragments
-    auto stage = [&](int ht, int buf) {
-        short *dst = wbuf + buf * (kTileFrags * kFragShorts);
+    // Weight tile `ht` -> ring slot, in fragment order.  Wave w brings k-steps 4 w .. 4 w + 3 of the W1 tile (fragments 4 w + i)
+    // and row tiles 2 w, 2 w + 1 of the W2 tile (fragments 16 + 2 (2 w + t) + s): 8 DMAs of 1 KB per wave and tile.
+    const uint16_t *p1 = w1 + (size_t)r * kD + 8 * h + 64 * wave;
+    const uint16_t *p2 = w2p + (size_t)(64 * wave + r) * F + 8 * h;
+    auto stage = [&](int ht, int slot) {
+        short *dst = wbuf + slot * (kTileFrags * kFragShorts);
+        const uint16_t *s1 = p1 + (size_t)ht * (kHT * kD), *s2 = p2 + ht * kHT;
 #pragma unroll
-        for (int i = 0; i < kTileFrags / kWaves; ++i) {
-            const int f = wave * (kTileFrags / kWaves) + i;   // (uniform)
-            const uint16_t *src;
-            if (f < 16) src = w1 + (size_t)(ht * kHT + r) * kD + 16 * f + 8 * h;                                   // k-step f of W1
-            else src = w2p + (size_t)(32 * ((f - 16) >> 1) + r) * F + ht * kHT + 16 * ((f - 16) & 1) + 8 * h;       // (row tile, k-step) of W2
-            __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void *>(
-                                                      reinterpret_cast<uintptr_t>(dst + f * kFragShorts)), 16, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(s1 + 16 * i, reinterpret_cast<__attribute__((address_space(3))) void *>(
+                                                              reinterpret_cast<uintptr_t>(dst + (4 * wave + i) * kFragShorts)), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(s2 + (size_t)(i >> 1) * 32 * F + 16 * (i & 1),
+                                             reinterpret_cast<__attribute__((address_space(3))) void *>(
+                                                 reinterpret_cast<uintptr_t>(dst + (16 + 4 * wave + i) * kFragShorts)), 16, 0, 0);
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the ordinary loads above have retired
+    __syncthreads();                      // (parameters in LDS)
     stage(0, 0);
+    if (nt > 1) stage(1, 1);
 
+    int slot = 0;
     for (int ht = 0; ht < nt; ++ht) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of tile ht has landed
-        __syncthreads();                      // ... and everybody's; everybody is done with the other buffer
-        if (ht + 1 < nt) stage(ht + 1, (ht + 1) & 1);
-        const short *wt = wbuf + (ht & 1) * (kTileFrags * kFragShorts) + lane * 8;
+        // tile ht has landed: at most the 8 DMAs of tile ht + 1 may still be in flight
+        if (ht + 1 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // ... everybody's share of it; and everybody is done with tile ht - 1, whose slot is refilled now
+        if (ht + 2 < nt) stage(ht + 2, slot == 0 ? 2 : slot - 1);
+        const unsigned wt = (unsigned)(uintptr_t)(wbuf + slot * (kTileFrags * kFragShorts)) + lane * 16;   // LDS byte address of this lane's piece of fragment 0
+
+        u32x4 fa[4], fb[4];   // two groups of four fragments: one being used, one arriving
+        FFN_READ(fa[0], wt, 0 * 1024); FFN_READ(fa[1], wt, 1 * 1024); FFN_READ(fa[2], wt, 2 * 1024); FFN_READ(fa[3], wt, 3 * 1024);
 
         // ---- H^T tile = W1 tile . x^T + b1 ------------------------------------------------------------------------------
         f32x16 hacc[2];
@@ -130,33 +154,59 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
 #pragma unroll
             for (int i = 0; i < 4; ++i) hacc[0][4 * g + i] = hacc[1][4 * g + i] = bb[i];
         }
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wt + s * kFragShorts);
-            hacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[0][s], hacc[0], 0, 0, 0);
-            hacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[1][s], hacc[1], 0, 0, 0);
-        }
+#define FFN_G1(FR, S0)                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                            \
+    {                                                                                                                        \
+        const bf16x8 a = __builtin_bit_cast(bf16x8, FR[i]);                                                                  \
+        hacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[0][(S0) + i], hacc[0], 0, 0, 0);                             \
+        hacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[1][(S0) + i], hacc[1], 0, 0, 0);                             \
+    }
+        FFN_READ(fb[0], wt, 4 * 1024); FFN_READ(fb[1], wt, 5 * 1024); FFN_READ(fb[2], wt, 6 * 1024); FFN_READ(fb[3], wt, 7 * 1024);
+        FFN_WAIT4(4, fa[0], fa[1], fa[2], fa[3]);
+        FFN_G1(fa, 0)
+        FFN_READ(fa[0], wt, 8 * 1024); FFN_READ(fa[1], wt, 9 * 1024); FFN_READ(fa[2], wt, 10 * 1024); FFN_READ(fa[3], wt, 11 * 1024);
+        FFN_WAIT4(4, fb[0], fb[1], fb[2], fb[3]);
+        FFN_G1(fb, 4)
+        FFN_READ(fb[0], wt, 12 * 1024); FFN_READ(fb[1], wt, 13 * 1024); FFN_READ(fb[2], wt, 14 * 1024); FFN_READ(fb[3], wt, 15 * 1024);
+        FFN_WAIT4(4, fa[0], fa[1], fa[2], fa[3]);
+        FFN_G1(fa, 8)
+        FFN_READ(fa[0], wt, 16 * 1024); FFN_READ(fa[1], wt, 17 * 1024); FFN_READ(fa[2], wt, 18 * 1024); FFN_READ(fa[3], wt, 19 * 1024);
+        FFN_WAIT4(4, fb[0], fb[1], fb[2], fb[3]);
+        FFN_G1(fb, 12)
+#undef FFN_G1
         // ---- relu, to bf16: registers 8 s .. 8 s + 7 are the B fragment of k-step s ------------------------------------------
         bf16x8 hb[2][2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                unsigned u[4];
+                u32x4 u;
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
                     u[p] = pack_bf16(fmaxf(hacc[ct][8 * s + 2 * p], 0.f), fmaxf(hacc[ct][8 * s + 2 * p + 1], 0.f));
-                hb[ct][s] = *reinterpret_cast<const bf16x8 *>(u);
+                hb[ct][s] = __builtin_bit_cast(bf16x8, u);
             }
-        // ---- out^T += W2 tile . relu(H^T) ----------------------------------------------------------------------------------
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wt + (16 + 2 * t + s) * kFragShorts);
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[0][s], acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[1][s], acc[1][t], 0, 0, 0);
-            }
+        // ---- out^T += W2 tile . relu(H^T): fragment 16 + 2 t + s = (row tile t, k-step s); a group of four = row tiles T0, T0 + 1 ----
+#define FFN_G2(FR, T0)                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                            \
+    {                                                                                                                        \
+        const bf16x8 a = __builtin_bit_cast(bf16x8, FR[i]);                                                                  \
+        acc[0][(T0) + (i >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[0][i & 1], acc[0][(T0) + (i >> 1)], 0, 0, 0); \
+        acc[1][(T0) + (i >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[1][i & 1], acc[1][(T0) + (i >> 1)], 0, 0, 0); \
+    }
+        FFN_READ(fb[0], wt, 20 * 1024); FFN_READ(fb[1], wt, 21 * 1024); FFN_READ(fb[2], wt, 22 * 1024); FFN_READ(fb[3], wt, 23 * 1024);
+        FFN_WAIT4(4, fa[0], fa[1], fa[2], fa[3]);
+        FFN_G2(fa, 0)
+        FFN_READ(fa[0], wt, 24 * 1024); FFN_READ(fa[1], wt, 25 * 1024); FFN_READ(fa[2], wt, 26 * 1024); FFN_READ(fa[3], wt, 27 * 1024);
+        FFN_WAIT4(4, fb[0], fb[1], fb[2], fb[3]);
+        FFN_G2(fb, 2)
+        FFN_READ(fb[0], wt, 28 * 1024); FFN_READ(fb[1], wt, 29 * 1024); FFN_READ(fb[2], wt, 30 * 1024); FFN_READ(fb[3], wt, 31 * 1024);
+        FFN_WAIT4(4, fa[0], fa[1], fa[2], fa[3]);
+        FFN_G2(fa, 4)
+        FFN_WAIT4(0, fb[0], fb[1], fb[2], fb[3]);
+        FFN_G2(fb, 6)
+#undef FFN_G2
+        slot = slot == kRing - 1 ? 0 : slot + 1;
     }
 
     // ---- epilogue: + b2 + x, LayerNorm over the 256 channels of a token (128 in this lane, 128 in lane ^ 32), bf16 store -----------
@@ -212,7 +262,7 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
     }
 }
 
-size_t ffn_lds_bytes(int F) { return (size_t)2 * kTileFrags * kFragShorts * 2 + (size_t)(F + 3 * kD) * 4; }
+size_t ffn_lds_bytes(int F) { return (size_t)kRing * kTileFrags * kFragShorts * 2 + (size_t)(F + 3 * kD) * 4; }
 
 }  // namespace
 
@@ -242,7 +292,7 @@ int msda_ffn_forward_bf16(const uint16_t *x, const uint16_t *w1, const float *b1
     const size_t lds = ffn_lds_bytes(d_ffn);
     static bool raised = false;   // (per process; the limit is a property of the function)
     if (!raised) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         raised = true;
     }
