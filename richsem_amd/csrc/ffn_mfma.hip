@@ -25,7 +25,7 @@
 // LDS traffic: 32 KB per wave and tile against 64 MFMAs of 32 cycles: half of the LDS rate.
 // The pipeline is hand-scheduled where hipcc would drain it: tiles are requested TWO ahead and waited for with a partial
 // vmcnt before a bare s_barrier (a __syncthreads, or any LDS read the compiler can see, waits for every LDS DMA in flight),
-// and the operand reads are inline ds_read_b128 a group ahead of the MFMAs that use them, released by partial lgkmcnt waits
+// and the operand reads are inline ds_read_b128 seven fragments ahead of the MFMAs that use them, released by partial lgkmcnt waits
 // (a wave has its SIMD to itself, so nothing else hides the LDS latency).
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
@@ -72,8 +72,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // one operand fragment from LDS, not visible to the compiler's wait-count bookkeeping (see the header)
 #define FFN_READ(dst, addr, byte_off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(byte_off))
-// "at most n LDS reads still in flight": everything older has arrived.  The operands tie the fragments to the wait.
-#define FFN_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n))
+// "at most n LDS reads still in flight": everything older has arrived.  The operand ties the fragment to the wait.
+#define FFN_WAIT(n, a) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(n))
 
 __global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w1, const float *__restrict__ b1,
@@ -143,8 +143,11 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
         if (ht + 2 < nt) stage(ht + 2, slot == 0 ? 2 : slot - 1);
         const unsigned wt = (unsigned)(uintptr_t)(wbuf + slot * (kTileFrags * kFragShorts)) + lane * 16;   // LDS byte address of this lane's piece of fragment 0
 
-        u32x4 fa[4], fb[4];   // two groups of four fragments: one being used, one arriving
-        FFN_READ(fa[0], wt, 0 * 1024); FFN_READ(fa[1], wt, 1 * 1024); FFN_READ(fa[2], wt, 2 * 1024); FFN_READ(fa[3], wt, 3 * 1024);
+        // The operand stream of a tile: a ring of eight fragment registers; fragment p lives in fr[p & 7], is waited for with
+        // "at most 7 newer reads in flight", feeds two MFMAs and is at once replaced by the read of fragment p + 8.
+        u32x4 fr[8];
+        FFN_READ(fr[0], wt, 0 * 1024); FFN_READ(fr[1], wt, 1 * 1024); FFN_READ(fr[2], wt, 2 * 1024); FFN_READ(fr[3], wt, 3 * 1024);
+        FFN_READ(fr[4], wt, 4 * 1024); FFN_READ(fr[5], wt, 5 * 1024); FFN_READ(fr[6], wt, 6 * 1024); FFN_READ(fr[7], wt, 7 * 1024);
 
         // ---- H^T tile = W1 tile . x^T + b1 ------------------------------------------------------------------------------
         f32x16 hacc[2];
@@ -154,28 +157,37 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
 #pragma unroll
             for (int i = 0; i < 4; ++i) hacc[0][4 * g + i] = hacc[1][4 * g + i] = bb[i];
         }
-#define FFN_G1(FR, S0)                                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                            \
-    {                                                                                                                        \
-        const bf16x8 a = __builtin_bit_cast(bf16x8, FR[i]);                                                                  \
-        hacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[0][(S0) + i], hacc[0], 0, 0, 0);                             \
-        hacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[1][(S0) + i], hacc[1], 0, 0, 0);                             \
-    }
-        FFN_READ(fb[0], wt, 4 * 1024); FFN_READ(fb[1], wt, 5 * 1024); FFN_READ(fb[2], wt, 6 * 1024); FFN_READ(fb[3], wt, 7 * 1024);
-        FFN_WAIT4(4, fa[0], fa[1], fa[2], fa[3]);
-        FFN_G1(fa, 0)
-        FFN_READ(fa[0], wt, 8 * 1024); FFN_READ(fa[1], wt, 9 * 1024); FFN_READ(fa[2], wt, 10 * 1024); FFN_READ(fa[3], wt, 11 * 1024);
-        FFN_WAIT4(4, fb[0], fb[1], fb[2], fb[3]);
-        FFN_G1(fb, 4)
-        FFN_READ(fb[0], wt, 12 * 1024); FFN_READ(fb[1], wt, 13 * 1024); FFN_READ(fb[2], wt, 14 * 1024); FFN_READ(fb[3], wt, 15 * 1024);
-        FFN_WAIT4(4, fa[0], fa[1], fa[2], fa[3]);
-        FFN_G1(fa, 8)
-        FFN_READ(fa[0], wt, 16 * 1024); FFN_READ(fa[1], wt, 17 * 1024); FFN_READ(fa[2], wt, 18 * 1024); FFN_READ(fa[3], wt, 19 * 1024);
-        FFN_WAIT4(4, fb[0], fb[1], fb[2], fb[3]);
-        FFN_G1(fb, 12)
-#undef FFN_G1
-        // ---- relu, to bf16: registers 8 s .. 8 s + 7 are the B fragment of k-step s ------------------------------------------
         bf16x8 hb[2][2];
+#define FFN_USE1(P)                                                                                                          \
+    {                                                                                                                        \
+        const bf16x8 a_ = __builtin_bit_cast(bf16x8, fr[(P) & 7]);                                                           \
+        hacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, xf[0][P], hacc[0], 0, 0, 0);                                   \
+        hacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, xf[1][P], hacc[1], 0, 0, 0);                                   \
+    }
+#define FFN_USE2(P)                                                                                                          \
+    {                                                                                                                        \
+        const bf16x8 a_ = __builtin_bit_cast(bf16x8, fr[(P) & 7]);                                                           \
+        constexpr int t_ = ((P) - 16) >> 1, s_ = ((P) - 16) & 1;                                                             \
+        acc[0][t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, hb[0][s_], acc[0][t_], 0, 0, 0);                            \
+        acc[1][t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, hb[1][s_], acc[1][t_], 0, 0, 0);                            \
+    }
+        FFN_WAIT(7, fr[0]); FFN_USE1(0) FFN_READ(fr[0], wt, 8 * 1024);
+        FFN_WAIT(7, fr[1]); FFN_USE1(1) FFN_READ(fr[1], wt, 9 * 1024);
+        FFN_WAIT(7, fr[2]); FFN_USE1(2) FFN_READ(fr[2], wt, 10 * 1024);
+        FFN_WAIT(7, fr[3]); FFN_USE1(3) FFN_READ(fr[3], wt, 11 * 1024);
+        FFN_WAIT(7, fr[4]); FFN_USE1(4) FFN_READ(fr[4], wt, 12 * 1024);
+        FFN_WAIT(7, fr[5]); FFN_USE1(5) FFN_READ(fr[5], wt, 13 * 1024);
+        FFN_WAIT(7, fr[6]); FFN_USE1(6) FFN_READ(fr[6], wt, 14 * 1024);
+        FFN_WAIT(7, fr[7]); FFN_USE1(7) FFN_READ(fr[7], wt, 15 * 1024);
+        FFN_WAIT(7, fr[0]); FFN_USE1(8) FFN_READ(fr[0], wt, 16 * 1024);
+        FFN_WAIT(7, fr[1]); FFN_USE1(9) FFN_READ(fr[1], wt, 17 * 1024);
+        FFN_WAIT(7, fr[2]); FFN_USE1(10) FFN_READ(fr[2], wt, 18 * 1024);
+        FFN_WAIT(7, fr[3]); FFN_USE1(11) FFN_READ(fr[3], wt, 19 * 1024);
+        FFN_WAIT(7, fr[4]); FFN_USE1(12) FFN_READ(fr[4], wt, 20 * 1024);
+        FFN_WAIT(7, fr[5]); FFN_USE1(13) FFN_READ(fr[5], wt, 21 * 1024);
+        FFN_WAIT(7, fr[6]); FFN_USE1(14) FFN_READ(fr[6], wt, 22 * 1024);
+        FFN_WAIT(7, fr[7]); FFN_USE1(15) FFN_READ(fr[7], wt, 23 * 1024);
+        // ---- relu, to bf16: registers 8 s .. 8 s + 7 are the B fragment of k-step s ------------------------------------------
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -186,26 +198,25 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
                     u[p] = pack_bf16(fmaxf(hacc[ct][8 * s + 2 * p], 0.f), fmaxf(hacc[ct][8 * s + 2 * p + 1], 0.f));
                 hb[ct][s] = __builtin_bit_cast(bf16x8, u);
             }
-        // ---- out^T += W2 tile . relu(H^T): fragment 16 + 2 t + s = (row tile t, k-step s); a group of four = row tiles T0, T0 + 1 ----
-#define FFN_G2(FR, T0)                                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                            \
-    {                                                                                                                        \
-        const bf16x8 a = __builtin_bit_cast(bf16x8, FR[i]);                                                                  \
-        acc[0][(T0) + (i >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[0][i & 1], acc[0][(T0) + (i >> 1)], 0, 0, 0); \
-        acc[1][(T0) + (i >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[1][i & 1], acc[1][(T0) + (i >> 1)], 0, 0, 0); \
-    }
-        FFN_READ(fb[0], wt, 20 * 1024); FFN_READ(fb[1], wt, 21 * 1024); FFN_READ(fb[2], wt, 22 * 1024); FFN_READ(fb[3], wt, 23 * 1024);
-        FFN_WAIT4(4, fa[0], fa[1], fa[2], fa[3]);
-        FFN_G2(fa, 0)
-        FFN_READ(fa[0], wt, 24 * 1024); FFN_READ(fa[1], wt, 25 * 1024); FFN_READ(fa[2], wt, 26 * 1024); FFN_READ(fa[3], wt, 27 * 1024);
-        FFN_WAIT4(4, fb[0], fb[1], fb[2], fb[3]);
-        FFN_G2(fb, 2)
-        FFN_READ(fb[0], wt, 28 * 1024); FFN_READ(fb[1], wt, 29 * 1024); FFN_READ(fb[2], wt, 30 * 1024); FFN_READ(fb[3], wt, 31 * 1024);
-        FFN_WAIT4(4, fa[0], fa[1], fa[2], fa[3]);
-        FFN_G2(fa, 4)
-        FFN_WAIT4(0, fb[0], fb[1], fb[2], fb[3]);
-        FFN_G2(fb, 6)
-#undef FFN_G2
+        // ---- out^T += W2 tile . relu(H^T): fragment 16 + 2 t + s = (row tile t, k-step s) ----------------------------------------
+        FFN_WAIT(7, fr[0]); FFN_USE2(16) FFN_READ(fr[0], wt, 24 * 1024);
+        FFN_WAIT(7, fr[1]); FFN_USE2(17) FFN_READ(fr[1], wt, 25 * 1024);
+        FFN_WAIT(7, fr[2]); FFN_USE2(18) FFN_READ(fr[2], wt, 26 * 1024);
+        FFN_WAIT(7, fr[3]); FFN_USE2(19) FFN_READ(fr[3], wt, 27 * 1024);
+        FFN_WAIT(7, fr[4]); FFN_USE2(20) FFN_READ(fr[4], wt, 28 * 1024);
+        FFN_WAIT(7, fr[5]); FFN_USE2(21) FFN_READ(fr[5], wt, 29 * 1024);
+        FFN_WAIT(7, fr[6]); FFN_USE2(22) FFN_READ(fr[6], wt, 30 * 1024);
+        FFN_WAIT(7, fr[7]); FFN_USE2(23) FFN_READ(fr[7], wt, 31 * 1024);
+        FFN_WAIT(7, fr[0]); FFN_USE2(24)
+        FFN_WAIT(6, fr[1]); FFN_USE2(25)
+        FFN_WAIT(5, fr[2]); FFN_USE2(26)
+        FFN_WAIT(4, fr[3]); FFN_USE2(27)
+        FFN_WAIT(3, fr[4]); FFN_USE2(28)
+        FFN_WAIT(2, fr[5]); FFN_USE2(29)
+        FFN_WAIT(1, fr[6]); FFN_USE2(30)
+        FFN_WAIT(0, fr[7]); FFN_USE2(31)
+#undef FFN_USE1
+#undef FFN_USE2
         slot = slot == kRing - 1 ? 0 : slot + 1;
     }
 

@@ -1,0 +1,107 @@
+"""GPU (-m gpu): the fused feed-forward kernel (reference forward_ffn,
+models/richsem/deformable_transformer.py:862-866) against its definition in PyTorch fp32 ops.
+
+A floating-point MFMA kernel, so the reference is a plain PyTorch fp32 computation of the same block on the same
+(bf16-representable) inputs.  Tolerance: the kernel keeps everything in fp32 except the hidden activation, which it rounds to
+bf16 once (like a bf16 nn.Linear) and the output (one rounding): |err| <= 2^-7 * max(1, |ref|) element-wise and 3e-3 on
+average for LayerNorm-scaled outputs -- a transposed / permuted operand anywhere gives errors of order 1.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from richsem_amd import _lib
+from richsem_amd.functions import FusedFFNFunction, ffn_forward_bf16, pack_w2_bf16
+from richsem_amd.modules.ffn import FFN
+
+pytestmark = pytest.mark.gpu
+D = 256
+
+
+def make(T, Fh, seed=0, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    x = (scale * r(T, D)).to(torch.bfloat16)
+    w1 = (r(Fh, D) * D ** -0.5).to(torch.bfloat16)
+    w2 = (r(D, Fh) * Fh ** -0.5).to(torch.bfloat16)
+    return x, w1, 0.1 * r(Fh), w2, 0.1 * r(D), 1 + 0.1 * r(D), 0.1 * r(D)
+
+
+def ref_fp32(x, w1, b1, w2, b2, gw, gb, eps=1e-5):
+    xf = x.float()
+    return F.layer_norm(xf + F.linear(torch.relu(F.linear(xf, w1.float(), b1)), w2.float(), b2), (D,), gw, gb, eps)
+
+
+@pytest.mark.parametrize("T,Fh", [(1, 32), (63, 32), (64, 64), (255, 96), (256, 2048), (257, 1024), (1100 * 2, 2048), (5000, 4096)])
+def test_forward_matches_fp32_definition(T, Fh):
+    x, w1, b1, w2, b2, gw, gb = make(T, Fh, seed=T + Fh)
+    out = ffn_forward_bf16(x, w1, b1, pack_w2_bf16(w2), b2, gw, gb)
+    ref = ref_fp32(x, w1, b1, w2, b2, gw, gb)
+    err = (out.float() - ref).abs()
+    assert torch.isfinite(out.float()).all()
+    assert float((err / ref.abs().clamp(min=1.0)).max()) < 2 ** -7, (T, Fh)
+    assert float(err.mean()) < 3e-3
+
+
+def test_rows_are_independent_and_tail_is_masked():
+    """A token's output depends on its own row only; rows past `tokens` are never written."""
+    x, w1, b1, w2, b2, gw, gb = make(300, 64, seed=5)
+    w2p = pack_w2_bf16(w2)
+    full = ffn_forward_bf16(x, w1, b1, w2p, b2, gw, gb)
+    part = ffn_forward_bf16(x[:129].contiguous(), w1, b1, w2p, b2, gw, gb)
+    assert torch.equal(full[:129], part)
+    lib = _lib.load()
+    out = torch.full((300, D), 7.0, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.msda_ffn_forward_bf16(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), gw.data_ptr(),
+                                         gb.data_ptr(), 1e-5, 129, D, 64, out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(out[:129], part) and bool((out[129:] == 7.0).all())
+
+
+def test_weight_packing_is_the_documented_permutation():
+    w2 = torch.arange(D * 64, device="cuda", dtype=torch.float32).remainder(251).to(torch.bfloat16).view(D, 64)
+    p = pack_w2_bf16(w2).view(D, 4, 4, 4)
+    src = w2.view(D, 4, 4, 4)
+    assert torch.equal(p[:, :, 0], src[:, :, 0]) and torch.equal(p[:, :, 1], src[:, :, 2])
+    assert torch.equal(p[:, :, 2], src[:, :, 1]) and torch.equal(p[:, :, 3], src[:, :, 3])
+
+
+def test_bad_arguments_are_rejected():
+    lib = _lib.load()
+    x, w1, b1, w2, b2, gw, gb = make(8, 32)
+    out = torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    args = lambda dm, df: (x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), gw.data_ptr(), gb.data_ptr(), 1e-5,
+                           8, dm, df, out.data_ptr(), s)
+    assert lib.msda_ffn_forward_bf16(*args(128, 32)) == -2      # d_model must be 256
+    assert lib.msda_ffn_forward_bf16(*args(256, 48)) == -2      # d_ffn % 32
+    assert lib.msda_ffn_forward_bf16(x.data_ptr(), None, b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                                     1e-5, 8, 256, 32, out.data_ptr(), s) == -1
+    with pytest.raises(RuntimeError):
+        ffn_forward_bf16(x.cpu(), w1.cpu(), b1.cpu(), w2.cpu(), b2.cpu(), gw.cpu(), gb.cpu())
+
+
+def test_function_gradients_match_fp32_autograd():
+    """FusedFFNFunction (fused forward, recomputing GEMM backward in bf16) against fp32 autograd of the op-by-op block."""
+    x, w1, b1, w2, b2, gw, gb = make(512, 256, seed=3)
+    leaves = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2, gw, gb)]
+    out = FusedFFNFunction.apply(*leaves, 1e-5)
+    go = torch.randn(512, D, device="cuda").to(torch.bfloat16)
+    out.backward(go)
+    refl = [t.float().clone().requires_grad_(True) for t in (x, w1, b1, w2, b2, gw, gb)]
+    ref_fp32(*refl).backward(go.float())
+    for a, b, name in zip(leaves, refl, ("x", "w1", "b1", "w2", "b2", "ln_w", "ln_b")):
+        err = (a.grad.float() - b.grad).abs()   # bf16 GEMMs + bf16 storage of the gradients of the bf16 leaves
+        assert float(err.max()) / (float(b.grad.abs().max()) + 1e-12) < 8e-2, name
+        assert float(err.mean()) / (float(b.grad.abs().mean()) + 1e-12) < 2e-2, name
+
+
+def test_module_fused_path_equals_op_by_op_path_within_bf16():
+    torch.manual_seed(0)
+    m = FFN(256, 2048, dropout=0.0).cuda()
+    src = torch.randn(2, 700, 256, device="cuda").to(torch.bfloat16)
+    fused = m(src)
+    m.fused = False
+    plain = m.to(torch.bfloat16)(src)
+    assert fused.shape == src.shape and fused.dtype == torch.bfloat16
+    assert float((fused.float() - plain.float()).abs().mean()) < 6e-3
