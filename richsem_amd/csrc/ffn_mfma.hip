@@ -10,23 +10,23 @@
 // Everything is computed TRANSPOSED, so that tokens sit on the lanes and channels in the registers:
 //     H^T   (hidden x tokens) = W1 (hidden x 256)  . x^T        A operand = nn.Linear's own row-major weight, B = x rows
 //     out^T (256 x tokens)   += W2 (256 x hidden)  . relu(H^T)   A operand = nn.Linear's own weight again
-// A 32x32 accumulator tile of mfma_f32_32x32x16_bf16 has its column (token) on the lane and its rows (hidden) in the 16
-// registers, and the second product sums over exactly those rows -- so relu(H^T), converted to bf16, IS the B operand of
-// the second product: no LDS round trip, no lane movement (guide: "an accumulator tile as the next MFMA's operand").  The k
-// order inside such an operand is permuted (element j of lane half h is row 16s + 8(j>>2) + 4h + (j&3)), so W2 is repacked
-// once (msda_ffn_pack_w2_bf16: the two middle groups of four of every 16 hidden columns change places) and then read with
-// plain 16-byte fragments.  The LayerNorm runs over registers: a lane holds 128 of its token's 256 channels, lane ^ 32 the rest.
+// with mfma_f32_16x16x32_bf16.  An accumulator tile has its column (token) on the lane (l & 15) and rows 4 (l >> 4) + reg in its
+// four registers, and the second product sums over exactly those rows -- so relu(H^T) of two stacked 16-row tiles, converted
+// to bf16, IS the B operand (k = 32) of the second product: no LDS round trip, no lane movement (guide: "an accumulator
+// tile as the next MFMA's operand").  The k order of such an operand is permuted -- lane group q holds hidden units 4 q .. 4 q + 3
+// and 16 + 4 q .. 16 + 4 q + 3 of the tile -- so W2 is repacked once (msda_ffn_pack_w2_bf16) and then read with plain 16-byte
+// fragments.  The LayerNorm runs over registers: a lane holds 64 of its token's 256 channels, lanes l ^ 16, l ^ 32, l ^ 48 the rest.
 //
-// Work decomposition: a wave owns 64 tokens (two MFMA column tiles: every weight fragment it reads feeds two MFMAs), a
-// workgroup is four waves -- one per SIMD, up to 512 registers each: 256 accumulators for out^T, 128 for the wave's x
-// fragments, 32 for the hidden tile -- and has its CU to itself.  The weights stream through LDS in tiles of 32 hidden
-// units (16 KB of W1 + 16 KB of W2), a ring of three, by LDS DMA (global_load_lds_dwordx4: no registers) straight into
-// FRAGMENT ORDER -- fragment f is 1 KB, lane l's 16 bytes at l*16 -- so every operand read is a conflict-free ds_read_b128.
-// LDS traffic: 32 KB per wave and tile against 64 MFMAs of 32 cycles: half of the LDS rate.
+// Work decomposition: a wave owns 48 tokens (three MFMA column tiles: every weight fragment it reads feeds three MFMAs;
+// 44646 tokens = 931 waves for the chip's 1024 SIMDs), a workgroup is four waves -- one per SIMD: 192 accumulators for out^T,
+// 96 registers for the wave's x fragments, 24 for the hidden tile -- and has its CU to itself.  The weights stream through
+// LDS in tiles of 32 hidden units (16 KB of W1 + 16 KB of W2), a ring of three, by LDS DMA (global_load_lds_dwordx4: no
+// registers) straight into FRAGMENT ORDER -- fragment f is 1 KB, lane l's 16 bytes at l*16 -- so every operand read is a
+// conflict-free ds_read_b128.
 // The pipeline is hand-scheduled where hipcc would drain it: tiles are requested TWO ahead and waited for with a partial
 // vmcnt before a bare s_barrier (a __syncthreads, or any LDS read the compiler can see, waits for every LDS DMA in flight),
-// and the operand reads are inline ds_read_b128 seven fragments ahead of the MFMAs that use them, released by partial lgkmcnt waits
-// (a wave has its SIMD to itself, so nothing else hides the LDS latency).
+// and the operand reads are inline ds_read_b128 seven fragments ahead of the MFMAs that use them, released by partial lgkmcnt
+// waits (a wave has its SIMD to itself, so nothing else hides the LDS latency).
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
@@ -40,7 +40,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kD = 256;            // d_model (fixed: 8 output row tiles, 16 k-steps)
-constexpr int kTokWave = 64;       // tokens per wave
+constexpr int kTokWave = 48;       // tokens per wave (three 16-token MFMA column tiles)
 constexpr int kWaves = 4;
 constexpr int kRing = 3;           // weight tiles in LDS
 constexpr int kTokWg = kTokWave * kWaves;
@@ -57,14 +57,14 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 
-// W2 (256 x F, row-major) -> the k order the accumulator-as-operand idiom needs: inside every 16 hidden columns the groups of
-// four are stored in the order 0, 2, 1, 3.
+// W2 (256 x F, row-major) -> the k order the accumulator-as-operand idiom needs: inside every 32 hidden columns, position
+// 8 q + j holds column 4 q + j (j < 4) or 16 + 4 q + (j - 4) (j >= 4).
 __global__ void pack_w2_kernel(const uint16_t *__restrict__ w2, uint16_t *__restrict__ w2p, long long n)
 {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int g = (int)((i >> 2) & 3);
-        const int sg = g == 1 ? 2 : (g == 2 ? 1 : g);
-        w2p[i] = w2[(i & ~15ll) + sg * 4 + (i & 3)];
+        const int p = (int)(i & 31), q = p >> 3, j = p & 7;
+        const int src = j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4);
+        w2p[i] = w2[(i & ~31ll) + src];
     }
 }
 
@@ -86,7 +86,7 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
     float *lb2 = lb1 + F, *lgam = lb2 + kD, *lbet = lgam + kD;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
+    const int c = lane & 15, q = lane >> 4;   // MFMA column (token) / lane group
     const int tok0 = blockIdx.x * kTokWg + wave * kTokWave;
     const int nt = F / kHT;
 
@@ -94,40 +94,41 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
     for (int i = tid; i < F; i += kWaves * 64) lb1[i] = b1[i];
     for (int i = tid; i < kD; i += kWaves * 64) { lb2[i] = b2[i]; lgam[i] = gamma[i]; lbet[i] = beta[i]; }
 
-    // this wave's x fragments (B operand of the first product): lane (r, h) holds x[token r][16 s + 8 h + 0..7]
-    bf16x8 xf[2][16];
+    // this wave's x fragments (B operand of the first product): lane (c, q) holds x[token c][32 s + 8 q + 0..7]
+    bf16x8 xf[3][8];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int tok = min(tok0 + 32 * ct + r, T - 1);
-        const uint16_t *row = x + (size_t)tok * kD + 8 * h;
+    for (int ct = 0; ct < 3; ++ct) {
+        const int tok = min(tok0 + 16 * ct + c, T - 1);
+        const uint16_t *row = x + (size_t)tok * kD + 8 * q;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) xf[ct][s] = *reinterpret_cast<const bf16x8 *>(row + 16 * s);
+        for (int s = 0; s < 8; ++s) xf[ct][s] = *reinterpret_cast<const bf16x8 *>(row + 32 * s);
     }
 
-    f32x16 acc[2][8];
+    f32x4 acc[3][16];   // out^T: [token tile][16-channel row tile]; lane (c, q) holds channels 16 t + 4 q + 0..3 of token c
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < 16; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[ct][t][i] = 0.f;
+            for (int i = 0; i < 4; ++i) acc[ct][t][i] = 0.f;
 
-    // Weight tile `ht` -> ring slot, in fragment order.  Wave w brings k-steps 4 w .. 4 w + 3 of the W1 tile (fragments 4 w + i)
-    // and row tiles 2 w, 2 w + 1 of the W2 tile (fragments 16 + 2 (2 w + t) + s): 8 DMAs of 1 KB per wave and tile.
-    const uint16_t *p1 = w1 + (size_t)r * kD + 8 * h + 64 * wave;
-    const uint16_t *p2 = w2p + (size_t)(64 * wave + r) * F + 8 * h;
+    // Weight tile `ht` -> ring slot, in fragment order (lane (r, q) of a fragment = row r, k = 8 q ..).  W1 fragment 2 s + rt =
+    // (k-step s, 16-row tile rt), W2 fragment 16 + t = 16-channel row tile t.  Wave w brings k-steps 2 w, 2 w + 1 of W1 and row
+    // tiles 4 w .. 4 w + 3 of W2: 8 DMAs of 1 KB per wave and tile.
+    const uint16_t *p1 = w1 + (size_t)c * kD + 8 * q + 64 * wave;
+    const uint16_t *p2 = w2p + (size_t)(64 * wave + c) * F + 8 * q;
     auto stage = [&](int ht, int slot) {
         short *dst = wbuf + slot * (kTileFrags * kFragShorts);
         const uint16_t *s1 = p1 + (size_t)ht * (kHT * kD), *s2 = p2 + ht * kHT;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds(s1 + 16 * i, reinterpret_cast<__attribute__((address_space(3))) void *>(
-                                                              reinterpret_cast<uintptr_t>(dst + (4 * wave + i) * kFragShorts)), 16, 0, 0);
+        for (int i = 0; i < 4; ++i)   // i = 2 (s - 2 w) + rt
+            __builtin_amdgcn_global_load_lds(s1 + (size_t)(i & 1) * 16 * kD + 32 * (i >> 1),
+                                             reinterpret_cast<__attribute__((address_space(3))) void *>(
+                                                 reinterpret_cast<uintptr_t>(dst + (4 * wave + i) * kFragShorts)), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds(s2 + (size_t)(i >> 1) * 32 * F + 16 * (i & 1),
-                                             reinterpret_cast<__attribute__((address_space(3))) void *>(
-                                                 reinterpret_cast<uintptr_t>(dst + (16 + 4 * wave + i) * kFragShorts)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(s2 + (size_t)i * 16 * F, reinterpret_cast<__attribute__((address_space(3))) void *>(
+                                                                          reinterpret_cast<uintptr_t>(dst + (16 + 4 * wave + i) * kFragShorts)), 16, 0, 0);
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the ordinary loads above have retired
     __syncthreads();                      // (parameters in LDS)
@@ -144,32 +145,34 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
         const unsigned wt = (unsigned)(uintptr_t)(wbuf + slot * (kTileFrags * kFragShorts)) + lane * 16;   // LDS byte address of this lane's piece of fragment 0
 
         // The operand stream of a tile: a ring of eight fragment registers; fragment p lives in fr[p & 7], is waited for with
-        // "at most 7 newer reads in flight", feeds two MFMAs and is at once replaced by the read of fragment p + 8.
+        // "at most 7 newer reads in flight", feeds three MFMAs and is at once replaced by the read of fragment p + 8.
         u32x4 fr[8];
         FFN_READ(fr[0], wt, 0 * 1024); FFN_READ(fr[1], wt, 1 * 1024); FFN_READ(fr[2], wt, 2 * 1024); FFN_READ(fr[3], wt, 3 * 1024);
         FFN_READ(fr[4], wt, 4 * 1024); FFN_READ(fr[5], wt, 5 * 1024); FFN_READ(fr[6], wt, 6 * 1024); FFN_READ(fr[7], wt, 7 * 1024);
 
-        // ---- H^T tile = W1 tile . x^T + b1 ------------------------------------------------------------------------------
-        f32x16 hacc[2];
+        // ---- H^T tile (two 16-row tiles) = W1 tile . x^T + b1 ---------------------------------------------------------------
+        f32x4 hacc[3][2];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {   // rows 8 g + 4 h + 0..3 of the tile live in registers 4 g .. 4 g + 3
-            const f32x4 bb = *reinterpret_cast<const f32x4 *>(lb1 + ht * kHT + 8 * g + 4 * h);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hacc[0][4 * g + i] = hacc[1][4 * g + i] = bb[i];
+        for (int rt = 0; rt < 2; ++rt) {   // rows 16 rt + 4 q + 0..3 of the tile
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(lb1 + ht * kHT + 16 * rt + 4 * q);
+            hacc[0][rt] = hacc[1][rt] = hacc[2][rt] = bb;
         }
-        bf16x8 hb[2][2];
+        bf16x8 hb[3];
 #define FFN_USE1(P)                                                                                                          \
     {                                                                                                                        \
         const bf16x8 a_ = __builtin_bit_cast(bf16x8, fr[(P) & 7]);                                                           \
-        hacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, xf[0][P], hacc[0], 0, 0, 0);                                   \
-        hacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, xf[1][P], hacc[1], 0, 0, 0);                                   \
+        constexpr int s_ = (P) >> 1, rt_ = (P) & 1;                                                                          \
+        hacc[0][rt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, xf[0][s_], hacc[0][rt_], 0, 0, 0);                        \
+        hacc[1][rt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, xf[1][s_], hacc[1][rt_], 0, 0, 0);                        \
+        hacc[2][rt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, xf[2][s_], hacc[2][rt_], 0, 0, 0);                        \
     }
 #define FFN_USE2(P)                                                                                                          \
     {                                                                                                                        \
         const bf16x8 a_ = __builtin_bit_cast(bf16x8, fr[(P) & 7]);                                                           \
-        constexpr int t_ = ((P) - 16) >> 1, s_ = ((P) - 16) & 1;                                                             \
-        acc[0][t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, hb[0][s_], acc[0][t_], 0, 0, 0);                            \
-        acc[1][t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, hb[1][s_], acc[1][t_], 0, 0, 0);                            \
+        constexpr int t_ = (P) - 16;                                                                                         \
+        acc[0][t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, hb[0], acc[0][t_], 0, 0, 0);                                \
+        acc[1][t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, hb[1], acc[1][t_], 0, 0, 0);                                \
+        acc[2][t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, hb[2], acc[2][t_], 0, 0, 0);                                \
     }
         FFN_WAIT(7, fr[0]); FFN_USE1(0) FFN_READ(fr[0], wt, 8 * 1024);
         FFN_WAIT(7, fr[1]); FFN_USE1(1) FFN_READ(fr[1], wt, 9 * 1024);
@@ -187,18 +190,17 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
         FFN_WAIT(7, fr[5]); FFN_USE1(13) FFN_READ(fr[5], wt, 21 * 1024);
         FFN_WAIT(7, fr[6]); FFN_USE1(14) FFN_READ(fr[6], wt, 22 * 1024);
         FFN_WAIT(7, fr[7]); FFN_USE1(15) FFN_READ(fr[7], wt, 23 * 1024);
-        // ---- relu, to bf16: registers 8 s .. 8 s + 7 are the B fragment of k-step s ------------------------------------------
+        // ---- relu, to bf16: elements 0..3 = rows 4 q + 0..3 of row tile 0, elements 4..7 = the same rows of row tile 1 ------------
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                u32x4 u;
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    u[p] = pack_bf16(fmaxf(hacc[ct][8 * s + 2 * p], 0.f), fmaxf(hacc[ct][8 * s + 2 * p + 1], 0.f));
-                hb[ct][s] = __builtin_bit_cast(bf16x8, u);
-            }
-        // ---- out^T += W2 tile . relu(H^T): fragment 16 + 2 t + s = (row tile t, k-step s) ----------------------------------------
+        for (int ct = 0; ct < 3; ++ct) {
+            u32x4 u;
+            u[0] = pack_bf16(fmaxf(hacc[ct][0][0], 0.f), fmaxf(hacc[ct][0][1], 0.f));
+            u[1] = pack_bf16(fmaxf(hacc[ct][0][2], 0.f), fmaxf(hacc[ct][0][3], 0.f));
+            u[2] = pack_bf16(fmaxf(hacc[ct][1][0], 0.f), fmaxf(hacc[ct][1][1], 0.f));
+            u[3] = pack_bf16(fmaxf(hacc[ct][1][2], 0.f), fmaxf(hacc[ct][1][3], 0.f));
+            hb[ct] = __builtin_bit_cast(bf16x8, u);
+        }
+        // ---- out^T += W2 tile . relu(H^T): fragment 16 + t = 16-channel row tile t ------------------------------------------------
         FFN_WAIT(7, fr[0]); FFN_USE2(16) FFN_READ(fr[0], wt, 24 * 1024);
         FFN_WAIT(7, fr[1]); FFN_USE2(17) FFN_READ(fr[1], wt, 25 * 1024);
         FFN_WAIT(7, fr[2]); FFN_USE2(18) FFN_READ(fr[2], wt, 26 * 1024);
@@ -220,55 +222,53 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
         slot = slot == kRing - 1 ? 0 : slot + 1;
     }
 
-    // ---- epilogue: + b2 + x, LayerNorm over the 256 channels of a token (128 in this lane, 128 in lane ^ 32), bf16 store -----------
+    // ---- epilogue: + b2 + x, LayerNorm over the 256 channels of a token (64 in this lane, the rest in lanes ^16, ^32, ^48), bf16 store ---
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int tok = tok0 + 32 * ct + r;
+    for (int ct = 0; ct < 3; ++ct) {
+        const int tok = tok0 + 16 * ct + c;
         const bool live = tok < T;
         const uint16_t *xrow = x + (size_t)min(tok, T - 1) * kD;
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < 16; ++t) {
+            const int ch = 16 * t + 4 * q;   // channels ch .. ch + 3 <-> the four registers of row tile t
+            const uint2 xr = *reinterpret_cast<const uint2 *>(xrow + ch);
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(lb2 + ch);
+            const float xv[4] = {bf16_lo(xr.x), bf16_hi(xr.x), bf16_lo(xr.y), bf16_hi(xr.y)};
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = 32 * t + 8 * g + 4 * h;   // channels c .. c + 3 <-> registers 4 g .. 4 g + 3 of tile t
-                const uint2 xr = *reinterpret_cast<const uint2 *>(xrow + c);
-                const f32x4 bb = *reinterpret_cast<const f32x4 *>(lb2 + c);
-                const float xv[4] = {bf16_lo(xr.x), bf16_hi(xr.x), bf16_lo(xr.y), bf16_hi(xr.y)};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc[ct][t][4 * g + i] += bb[i] + xv[i];
-                    sum += acc[ct][t][4 * g + i];
-                }
+            for (int i = 0; i < 4; ++i) {
+                acc[ct][t][i] += bb[i] + xv[i];
+                sum += acc[ct][t][i];
             }
+        }
+        sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float mean = sum * (1.f / kD);
         float var = 0.f;
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < 16; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 const float d = acc[ct][t][i] - mean;
                 var += d * d;
             }
+        var += __shfl_xor(var, 16, 64);
         var += __shfl_xor(var, 32, 64);
         const float rstd = rsqrtf(var * (1.f / kD) + eps);
         if (live) {
             uint16_t *orow = out + (size_t)tok * kD;
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
+            for (int t = 0; t < 16; ++t) {
+                const int ch = 16 * t + 4 * q;
+                const f32x4 ga = *reinterpret_cast<const f32x4 *>(lgam + ch), be = *reinterpret_cast<const f32x4 *>(lbet + ch);
+                float y[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = 32 * t + 8 * g + 4 * h;
-                    const f32x4 ga = *reinterpret_cast<const f32x4 *>(lgam + c), be = *reinterpret_cast<const f32x4 *>(lbet + c);
-                    float y[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] = (acc[ct][t][4 * g + i] - mean) * rstd * ga[i] + be[i];
-                    uint2 o;
-                    o.x = pack_bf16(y[0], y[1]);
-                    o.y = pack_bf16(y[2], y[3]);
-                    *reinterpret_cast<uint2 *>(orow + c) = o;
-                }
+                for (int i = 0; i < 4; ++i) y[i] = (acc[ct][t][i] - mean) * rstd * ga[i] + be[i];
+                uint2 o;
+                o.x = pack_bf16(y[0], y[1]);
+                o.y = pack_bf16(y[2], y[3]);
+                *reinterpret_cast<uint2 *>(orow + ch) = o;
+            }
         }
     }
 }

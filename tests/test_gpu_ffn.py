@@ -59,11 +59,12 @@ def test_rows_are_independent_and_tail_is_masked():
 
 
 def test_weight_packing_is_the_documented_permutation():
+    """inside every 32 hidden columns, position 8 q + j holds column 4 q + j (j < 4) or 16 + 4 q + (j - 4)"""
     w2 = torch.arange(D * 64, device="cuda", dtype=torch.float32).remainder(251).to(torch.bfloat16).view(D, 64)
-    p = pack_w2_bf16(w2).view(D, 4, 4, 4)
-    src = w2.view(D, 4, 4, 4)
-    assert torch.equal(p[:, :, 0], src[:, :, 0]) and torch.equal(p[:, :, 1], src[:, :, 2])
-    assert torch.equal(p[:, :, 2], src[:, :, 1]) and torch.equal(p[:, :, 3], src[:, :, 3])
+    perm = [4 * (p >> 3) + (p & 7) if (p & 7) < 4 else 16 + 4 * (p >> 3) + (p & 7) - 4 for p in range(32)]
+    assert sorted(perm) == list(range(32))
+    idx = torch.tensor([32 * g + perm[p] for g in range(2) for p in range(32)], device="cuda")
+    assert torch.equal(pack_w2_bf16(w2), w2[:, idx])
 
 
 def test_bad_arguments_are_rejected():
