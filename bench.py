@@ -72,6 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-collective", action="store_true", help="N > 1: leave the gradient all-reduce out")
     ap.add_argument("--no-bf16", action="store_true", help="skip the extra bf16 pass")
+    ap.add_argument("--no-ffn", action="store_true", help="skip the feed-forward (MFMA) row beside the path")
     ap.add_argument("--fwd-variant", type=int, default=0)
     ap.add_argument("--bwd-variant", type=int, default=0)
     return ap.parse_args(argv)
@@ -235,6 +236,48 @@ def cpu_baseline(calls, n_images):
 
 
 # ---- the measured loop -----------------------------------------------------------------------------------------------
+def ffn_row(n_img, dev):
+    """The first MFMA row beside the path (NOT part of the timed step or of `value`): the
+    encoder layer's feed-forward block on n_img x 22323 tokens as the library's one-kernel bf16 forward, timed with events on the
+    current stream, against the same block as PyTorch bf16 ops.  Roofline: dense bf16 MFMA peak of the guide (2.5 PFLOP/s)."""
+    import torch.nn.functional as F
+    from richsem_amd.functions import ffn_forward_bf16, pack_w2_bf16
+    T, D, Fh = n_img * W.call_E(n_img).S, 256, 2048
+    g = torch.Generator(device=dev).manual_seed(7)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    x, w1, w2 = r(T, D).to(torch.bfloat16), (r(Fh, D) * D ** -0.5).to(torch.bfloat16), (r(D, Fh) * Fh ** -0.5).to(torch.bfloat16)
+    b1, b2, gw, gb = 0.1 * r(Fh), 0.1 * r(D), 1 + 0.1 * r(D), 0.1 * r(D)
+    w2p = pack_w2_bf16(w2)
+
+    def fused():
+        return ffn_forward_bf16(x, w1, b1, w2p, b2, gw, gb)
+
+    def ops():
+        h = torch.relu(F.linear(x, w1, b1.to(torch.bfloat16)))
+        return F.layer_norm(x + F.linear(h, w2, b2.to(torch.bfloat16)), (D,), gw.to(torch.bfloat16), gb.to(torch.bfloat16))
+
+    def timeit(fn, reps=20):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e-3
+
+    flop = 4.0 * T * D * Fh
+    t_f, t_o = timeit(fused), timeit(ops)
+    return {"what": "encoder feed-forward block forward (256 -> 2048 -> 256, relu, residual, LayerNorm), bf16, one HIP kernel; "
+                    "outside the timed step", "hip_kernel": "ffn_fwd_kernel", "tokens": T, "flop": flop,
+            "avg_launch_us": round(t_f * 1e6, 1),
+            "roofline": {"bound": "mfma", "achieved": round(flop / t_f / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(flop / t_f / 1e12 / 2500.0, 4)},
+            "pytorch_bf16_ops_us": round(t_o * 1e6, 1)}
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -394,6 +437,8 @@ def main(argv=None):
             line["bf16"] = {"dtype": "bf16 value/out/grad, f32 locations/weights and accumulation", "loc": modes[0],
                             "value": b["value"], "ms_per_step": b["ms_per_step"], "roofline": b["roofline"],
                             "kernels": b["kernels"]}
+        if not args.no_ffn:
+            line["mfma_row"] = ffn_row(n_img, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(calls, n_img)
         else:

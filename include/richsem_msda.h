@@ -256,7 +256,7 @@ int msda_mask_rows_bf16(uint16_t *x, const uint8_t *mask, int64_t rows, int row_
  *   x, out       (tokens, d_model) bf16, row-major;  d_model must be 256
  *   w1           (d_ffn, d_model) bf16 = linear1.weight;  b1 (d_ffn) f32 = linear1.bias;  d_ffn % 32 == 0, <= 4096
  *   w2_packed    linear2.weight (d_model, d_ffn) bf16 after msda_ffn_pack_w2_bf16 (a fixed permutation of the hidden
- *                columns inside every group of 16: repack whenever the weight changes);  b2 (d_model) f32
+ *                columns inside every group of 32: repack whenever the weight changes);  b2 (d_model) f32
  *   ln_weight, ln_bias (d_model) f32, eps as nn.LayerNorm.  All pointers 16-byte aligned. */
 int msda_ffn_pack_w2_bf16(const uint16_t *w2, int d_model, int d_ffn, uint16_t *w2_packed, msda_stream_t stream);
 int msda_ffn_forward_bf16(const uint16_t *x, const uint16_t *w1, const float *b1, const uint16_t *w2_packed, const float *b2,
