@@ -240,7 +240,9 @@ def ffn_row(n_img, dev):
     """The first MFMA row beside the path (NOT part of the timed step or of `value`): the
     encoder layer's feed-forward block on n_img x 22323 tokens as the library's one-kernel bf16 forward, timed with events on the
     current stream, against the same block as PyTorch bf16 ops.  Roofline: dense bf16 MFMA peak of the guide (2.5 PFLOP/s)."""
+    import torch
     import torch.nn.functional as F
+    from richsem_amd import workload as W
     from richsem_amd.functions import ffn_forward_bf16, pack_w2_bf16
     T, D, Fh = n_img * W.call_E(n_img).S, 256, 2048
     g = torch.Generator(device=dev).manual_seed(7)
