@@ -31,7 +31,7 @@ def main(path):
     print("| kernel | VGPRs | AGPRs | SGPRs | scratch B/lane | LDS B (static) | occupancy (waves/SIMD) |")
     print("|---|---|---|---|---|---|---|")
     for r, n in zip(rows, names):
-        n = re.sub(r"^void ", "", n)
+        n = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "")
         n = re.sub(r"\(.*$", "", n).replace("msda::", "")
         print(f"| `{n[:110]}` | {r.get('VGPRs', '?')} | {r.get('AGPRs', '?')} | {r.get('SGPRs', '?')} | {r.get('ScratchSize [bytes/lane]', '?')} "
               f"| {r.get('LDS Size [bytes/block]', '?')} | {r.get('Occupancy [waves/SIMD]', '?')} |")
