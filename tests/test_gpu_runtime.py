@@ -74,3 +74,37 @@ def test_concurrent_callers_on_their_own_streams():
         th.join()
     assert not errors, errors
     assert results == [(True, True, True)] * 3
+
+
+def test_routed_backward_replays_from_a_graph():
+    """The routed backward keeps device state between calls (bin counters that its scan kernel leaves zeroed, a workspace per
+    stream): captured on a stream that has run it before, the graph must reproduce the eager result on every replay, also
+    with a call of another geometry in between."""
+    call = W.shrunk(W.call_E(2), 2)
+    t = W.make_inputs(call, "uniform", seed=11, device="cuda")
+    other = W.make_inputs(W.shrunk(W.call_E(2), 4), "sigma4", seed=12, device="cuda")
+    _lib.set_option("bwd_variant", 4)
+    try:
+        ref = MSDA.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):       # the workspace of this stream is allocated here, outside the capture
+            for _ in range(2):
+                MSDA.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            grads = MSDA.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64)
+        for rep in range(3):
+            for x in grads:
+                x.fill_(float("nan"))
+            graph.replay()
+            torch.cuda.synchronize()
+            for a, b in zip(grads, ref):
+                assert torch.isfinite(a).all() and _close(a, b, 2e-4), rep
+            with torch.cuda.stream(side):   # another geometry on the same stream between replays
+                MSDA.ms_deform_attn_backward(other["value"], other["shapes"], other["lsi"], other["loc"], other["aw"],
+                                             other["grad_out"], 64)
+            torch.cuda.synchronize()
+    finally:
+        _lib.set_option("bwd_variant", 0)
