@@ -525,14 +525,18 @@ void rps_mark_dirty(hipStream_t stream)
     g_psb_ws[std::make_pair(dev, stream)].rps_dirty = true;
 }
 
-// returns hipErrorNotSupported when the plan does not apply or no workspace can be had right now
-hipError_t launch_bwd_rps(const Problem &pb, const float *value, const float *loc, const float *aw, const float *grad_out,
-                          float *grad_value, float *grad_loc, float *grad_aw, hipStream_t stream)
+// returns hipErrorNotSupported when the plan does not apply or no workspace can be had right now.
+// TV = bf16_t: grad_acc is an fp32 image of grad_value for the levels accumulated with atomics (rounded at the end).
+template <typename TV>
+hipError_t launch_bwd_rps(const Problem &pb, const TV *value, const float *loc, const float *aw, const TV *grad_out,
+                          TV *grad_value, float *grad_acc, float *grad_loc, float *grad_aw, hipStream_t stream)
 {
     msda::RpsPlan pl = msda::plan_rps(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(), pb.lsi.data());
     if (!pl.ok) return hipErrorNotSupported;
-    if ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_value)) & 15)
+    constexpr uintptr_t row_align = sizeof(TV) * 4 - 1;   // 16 B (fp32) / 8 B (bf16) per lane access
+    if ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_value)) & row_align)
         return hipErrorNotSupported;
+    if (reinterpret_cast<uintptr_t>(grad_acc) & 15) return hipErrorNotSupported;
     if ((reinterpret_cast<uintptr_t>(grad_loc) | reinterpret_cast<uintptr_t>(loc)) & 7) return hipErrorNotSupported;
     PsbWorkspace ws;
     if (!rps_workspace(stream, (size_t)pl.g.nbins, pl.max_entries, ws)) return hipErrorNotSupported;
@@ -543,7 +547,7 @@ hipError_t launch_bwd_rps(const Problem &pb, const float *value, const float *lo
     pl.g.entries = ws.rps_entries;
     pl.g.stamps = msda::tiled_options().stamps;
     pl.g.dbg = msda::tiled_options().dbg;
-    auto kern = pb.P == 4 ? &msda::rps_tile_kernel<true> : &msda::rps_tile_kernel<false>;
+    auto kern = pb.P == 4 ? &msda::rps_tile_kernel<true, TV> : &msda::rps_tile_kernel<false, TV>;
     hipError_t e = msda::set_lds_limit(reinterpret_cast<const void *>(kern), sizeof(msda::RpsLds));
     if (e != hipSuccess) return e;
     // route passes: a workgroup (8 waves) per block of queries of an (image, head)
@@ -551,14 +555,19 @@ hipError_t launch_bwd_rps(const Problem &pb, const float *value, const float *lo
     const int qpb = qpw * (msda::kRpsRouteThreads / msda::kWave);
     const int64_t r_items = (int64_t)pb.N * pb.M * ((pb.Lq + qpb - 1) / qpb);
     const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(r_items, (int64_t)msda::rps_options().route_wgs.load() * cu_count()));
-    hipLaunchKernelGGL(msda::rps_route_kernel<true>, dim3(rgrid), dim3(msda::kRpsRouteThreads), 0, stream, loc, aw, grad_value, grad_loc,
+    hipLaunchKernelGGL(msda::rps_route_kernel<true>, dim3(rgrid), dim3(msda::kRpsRouteThreads), 0, stream, loc, aw, grad_acc, grad_loc,
                        grad_aw, pl.g);
     hipLaunchKernelGGL(msda::rps_scan_kernel, dim3(1), dim3(1024), 0, stream, pl.g);
-    hipLaunchKernelGGL(msda::rps_route_kernel<false>, dim3(rgrid), dim3(msda::kRpsRouteThreads), 0, stream, loc, aw, grad_value, grad_loc,
+    hipLaunchKernelGGL(msda::rps_route_kernel<false>, dim3(rgrid), dim3(msda::kRpsRouteThreads), 0, stream, loc, aw, grad_acc, grad_loc,
                        grad_aw, pl.g);
     const int grid = (cu_count() / msda::kXcds) * msda::kXcds * (1024 / msda::kRpsThreads);   // persistent: one workgroup per CU
     hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 8), dim3(msda::kRpsThreads), sizeof(msda::RpsLds), stream, value, grad_out,
-                       grad_value, grad_loc, grad_aw, pl.g);
+                       grad_value, grad_acc, grad_loc, grad_aw, pl.g);
+    if constexpr (!std::is_same<TV, float>::value) {
+        bool any_atomic = false;
+        for (int l = 0; l < pb.L; ++l) any_atomic = any_atomic || pl.g.lv[l].atomic;
+        if (any_atomic) hipLaunchKernelGGL(msda::rps_round_kernel, dim3(256), dim3(256), 0, stream, grad_acc, grad_value, pl.g);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) rps_mark_dirty(stream);
     return e;
@@ -573,7 +582,7 @@ template <>
 hipError_t try_bwd_rps<float>(const Problem &pb, const float *value, const float *loc, const float *aw, const float *grad_out,
                               float *grad_value, float *grad_loc, float *grad_aw, hipStream_t stream)
 {
-    return launch_bwd_rps(pb, value, loc, aw, grad_out, grad_value, grad_loc, grad_aw, stream);
+    return launch_bwd_rps<float>(pb, value, loc, aw, grad_out, grad_value, grad_value, grad_loc, grad_aw, stream);
 }
 
 template <typename T>
@@ -877,11 +886,23 @@ int backward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const i
 
     int variant = g_bwd_variant.load();
     if (variant != 1 && variant != 3 && is_aligned(value, 8) && is_aligned(grad_out, 8) && is_aligned(grad_value, 8)) {
-        if (variant == 0) {   // (no routed kernels for bf16 storage yet: spread points go to the direct path)
-            variant = monitor_choose_bwd(monitor_for_current_device(), problem_key(N, S, M, L, P, pb.shapes.data(), loc), stream);
-            if (variant == 4) variant = 1;
-        }
+        // automatic: for bf16 storage the routed kernels beat the window kernels at every spread of the sampling points (MI355X,
+        // call E: 369 / 359 / 396 us at the init pattern / sigma 4 px / uniform against 397 / 570 / 2170: the rows they
+        // request per point are half as wide), so encoder-shaped calls take them whatever the locality monitor says
+        if (variant == 0) variant = Lq == S ? 4 : 1;
         float *gv32 = nullptr;
+        if (variant == 4 && D == msda::kRpsD && bf16_scratch(stream, n_value, &gv32)) {
+            // routed kernels: plain bf16 stores for the levels a workgroup owns alone; the levels shared by several workgroups are
+            // accumulated in the fp32 scratch (zeroed by the count pass) and rounded once
+            {
+                ProfileScope prof(1, 4, 2, N, S, M, D, L, Lq, P, stream);
+                e = launch_bwd_rps<msda::bf16_t>(pb, value, loc, aw, grad_out, grad_value, gv32, grad_loc, grad_aw, stream);
+                if (e == hipErrorNotSupported) prof.cancel();
+            }
+            if (e == hipSuccess) return MSDA_OK;
+            if (e != hipErrorNotSupported) return hip_fail(e, "launch of the routed backward kernels (bf16)");
+        }
+        if (variant == 4) variant = 1;
         if (variant == 2 && msda::plan_bwd_gather(N, S, M, D, L, Lq, P, pb.shapes.data(), pb.lsi.data()).ok &&
             msda::plan_scatter_sorted(N, S, M, D, L, Lq, P, pb.shapes.data(), pb.lsi.data()).ok && bf16_scratch(stream, n_value, &gv32)) {
             if ((e = hipMemsetAsync(gv32, 0, sizeof(float) * n_value, stream)) != hipSuccess) return hip_fail(e, "zero-fill of the fp32 scratch");

@@ -371,6 +371,41 @@ __device__ __forceinline__ float rps_quad_transpose_sum(float d0, float d1, floa
     return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xF, 0xF, true));                  // lane ^ 2
 }
 
+// A lane's 8 channels of a grad_out row as they travel from memory: fp32 as two float4, bf16 as two packed 8-byte words that are
+// widened only where the point is reduced (half the registers in flight).
+template <typename TV>
+struct RpsRow;
+template <>
+struct RpsRow<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float *row, int c_lo, int c_hi)
+    {
+        a = *reinterpret_cast<const float4 *>(row + c_lo);
+        b = *reinterpret_cast<const float4 *>(row + c_hi);
+    }
+    __device__ __forceinline__ void unpack(rps_v2f (&gq)[4]) const
+    {
+        gq[0] = (rps_v2f){a.x, a.y}; gq[1] = (rps_v2f){a.z, a.w};
+        gq[2] = (rps_v2f){b.x, b.y}; gq[3] = (rps_v2f){b.z, b.w};
+    }
+};
+template <>
+struct RpsRow<bf16_t> {
+    uint2 a, b;
+    __device__ __forceinline__ void load(const bf16_t *row, int c_lo, int c_hi)
+    {
+        a = *reinterpret_cast<const uint2 *>(row + c_lo);
+        b = *reinterpret_cast<const uint2 *>(row + c_hi);
+    }
+    __device__ __forceinline__ void unpack(rps_v2f (&gq)[4]) const
+    {
+        gq[0] = (rps_v2f){__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xFFFF0000u)};
+        gq[1] = (rps_v2f){__uint_as_float(a.y << 16), __uint_as_float(a.y & 0xFFFF0000u)};
+        gq[2] = (rps_v2f){__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xFFFF0000u)};
+        gq[3] = (rps_v2f){__uint_as_float(b.y << 16), __uint_as_float(b.y & 0xFFFF0000u)};
+    }
+};
+
 // Work decomposition: a QUAD (4 lanes x 8 channels) walks the list of one base pixel of the tile: four partial sums
 // (32 registers per lane) and -- while the list is walked -- the value rows of the pixel's four corners.  Packed fp32
 // arithmetic (v_pk_fma_f32) throughout: the kernel is bound by vector instruction issue (measured: VALU busy ~60 %,
@@ -383,9 +418,12 @@ __device__ __forceinline__ float rps_quad_transpose_sum(float d0, float d1, floa
 // Registers are the scarce resource (128 at 1024 threads, ~110 of them in the list walk): work-item geometry is kept
 // uniform (SGPRs), per-lane positions are recomputed where needed, prefetches are unconditional loads from clamped addresses
 // (a conditional load ends in a register copy right behind it -- and with it a wait for the data).
-template <bool P4>
+// TV: storage type of value / grad_out / grad_value (float, or bf16_t with fp32 arithmetic).  grad_acc: where the levels whose
+// tiles are shared by several workgroups are accumulated with fp32 atomics -- grad_value itself for TV = float, an fp32 scratch
+// image of it for bf16 (rounded by rps_round_kernel afterwards).
+template <bool P4, typename TV = float>
 __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
-    const float *__restrict__ value, const float *__restrict__ grad_out, float *__restrict__ grad_value,
+    const TV *__restrict__ value, const TV *__restrict__ grad_out, TV *__restrict__ grad_value, float *__restrict__ grad_acc,
     float *__restrict__ grad_loc, float *__restrict__ grad_aw, const RpsGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -467,9 +505,9 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
     auto fetch_rows = [&](const Item &it) {
         const int gr_ = min(quad / it.gw, it.R1 - it.R0), gc_ = quad % it.gw;
         const int prow_ = min(it.R0 + gr_, it.H - 1), pcol_ = min(it.C0 + gc_, it.W - 1);
-        const float *src = value + ((int64_t)(it.b * g.S + g.lv[it.l].start + prow_ * it.W + pcol_) * g.M + it.m) * kRpsD;
-        nv0 = *reinterpret_cast<const float4 *>(src + c_lo);
-        nv1 = *reinterpret_cast<const float4 *>(src + c_hi);
+        const TV *src = value + ((int64_t)(it.b * g.S + g.lv[it.l].start + prow_ * it.W + pcol_) * g.M + it.m) * kRpsD;
+        nv0 = ld4(src + c_lo);
+        nv1 = ld4(src + c_hi);
     };
     auto store_rows = [&](int buf) {
         *reinterpret_cast<float4 *>(S->vtile[buf] + quad * kRpsD + c_lo) = nv0;
@@ -595,11 +633,12 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
                         v[k][0] = (rps_v2f){a0.x, a0.y}; v[k][1] = (rps_v2f){a0.z, a0.w};
                         v[k][2] = (rps_v2f){a1.x, a1.y}; v[k][3] = (rps_v2f){a1.z, a1.w};
                     }
-#define RPS_POINT(EN, GA, GB, E)                                                                                                 \
+#define RPS_POINT(EN, ROW, E)                                                                                                    \
     {                                                                                                                            \
         const float hh = 1.f - EN.lh, hw = 1.f - EN.lw, ha = hh * EN.a, la = EN.lh * EN.a;                                       \
         const float w[4] = {ha * hw, ha * EN.lw, la * hw, la * EN.lw};                                                           \
-        const rps_v2f gq[4] = {(rps_v2f){GA.x, GA.y}, (rps_v2f){GA.z, GA.w}, (rps_v2f){GB.x, GB.y}, (rps_v2f){GB.z, GB.w}};       \
+        rps_v2f gq[4];                                                                                                           \
+        ROW.unpack(gq);                                                                                                          \
         float d[4];                                                                                                              \
         _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                            \
         {                                                                                                                        \
@@ -616,34 +655,29 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
                     // software pipeline: while point e is reduced, the grad_out row of point e + 1 is in flight and the row index
                     // of point e + 2 is being read (the chain entry -> row address -> row is what a list walk waits for).  Only the
                     // row index is read ahead; fractions and weight are read when the point is reduced (registers).
-#define RPS_ROW(ITEM, GA, GB)                                                                                                    \
-    {                                                                                                                            \
-        const float *q_ = grad_out + (int64_t)(ITEM) * kRpsD;                                                                    \
-        GA = *reinterpret_cast<const float4 *>(q_ + c_lo);                                                                       \
-        GB = *reinterpret_cast<const float4 *>(q_ + c_hi);                                                                       \
-    }
+#define RPS_ROW(ITEM, ROW) ROW.load(grad_out + (int64_t)(ITEM) * kRpsD, c_lo, c_hi);
 #define RPS_COEF(E) (*reinterpret_cast<const RpsCoef *>(S->ent + (E)))
                     const int e_last = e1 - 1;
                     int itA = S->ent[e].item, itB = S->ent[min(e + 1, e_last)].item;
-                    float4 gAa, gAb, gBa, gBb;
-                    RPS_ROW(itA, gAa, gAb)
+                    RpsRow<TV> gA, gB;
+                    RPS_ROW(itA, gA)
                     for (; e + 1 < e1; e += 2) {
-                        RPS_ROW(itB, gBa, gBb)
+                        RPS_ROW(itB, gB)
                         itA = S->ent[min(e + 2, e_last)].item;
                         {
                             const RpsCoef en = RPS_COEF(e);
-                            RPS_POINT(en, gAa, gAb, e)
+                            RPS_POINT(en, gA, e)
                         }
-                        RPS_ROW(itA, gAa, gAb)
+                        RPS_ROW(itA, gA)
                         itB = S->ent[min(e + 3, e_last)].item;
                         {
                             const RpsCoef en = RPS_COEF(e + 1);
-                            RPS_POINT(en, gBa, gBb, e + 1)
+                            RPS_POINT(en, gB, e + 1)
                         }
                     }
                     if (e < e1) {
                         const RpsCoef en = RPS_COEF(e);
-                        RPS_POINT(en, gAa, gAb, e)
+                        RPS_POINT(en, gA, e)
                     }
 #undef RPS_COEF
 #undef RPS_ROW
@@ -732,8 +766,8 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
             const bool in_tile = has_px && prow < R1 && pcol < C1;
             if (!g.lv[l].atomic) {
                 if (in_tile) {
-                    *reinterpret_cast<float4 *>(grad_value + px_off + c_lo) = o0;
-                    *reinterpret_cast<float4 *>(grad_value + px_off + c_hi) = o1;
+                    st4(grad_value + px_off + c_lo, o0);
+                    st4(grad_value + px_off + c_hi, o1);
                 }
             } else if (n_chunks > 0) {
                 // several workgroups share the tile: hand the rows over through LDS and add them one channel per lane, so that
@@ -750,7 +784,7 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
                 for (int p = tid >> 5; p < npx; p += kRpsThreads / 32) {
                     const int pr = p / gw, row = R0 + pr, col = C0 + (p - pr * gw);
                     const float x = stage[p * kRpsD + c32];
-                    if (row < R1 && col < C1 && x != 0.f) atomicAdd(grad_value + tile_base + (int64_t)(row * W + col) * row_elems, x);
+                    if (row < R1 && col < C1 && x != 0.f) atomicAdd(grad_acc + tile_base + (int64_t)(row * W + col) * row_elems, x);
                 }
             }
         }
@@ -766,6 +800,21 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();
         S->stamp_acc[8] += now_ - S->stamp_last;   // waiting at the empty queue
         for (int i = 0; i < 14; ++i) g.stamps[(size_t)blockIdx.x * 16 + i] = S->stamp_acc[i];
+    }
+}
+
+// bf16 storage: the levels accumulated with atomics live in the fp32 image `acc`; round them into grad_value once.
+__global__ __launch_bounds__(256) void rps_round_kernel(const float *__restrict__ acc, bf16_t *__restrict__ grad_value, const RpsGeom g)
+{
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    const int row4 = g.M * kRpsD / 4;
+    for (int l = 0; l < g.L; ++l) {
+        if (!g.lv[l].atomic) continue;
+        const int n4 = g.lv[l].H * g.lv[l].W * row4;
+        for (int b = 0; b < g.N; ++b) {
+            const size_t base = (size_t)(b * g.S + g.lv[l].start) * row4 * 4;
+            for (int i = gtid; i < n4; i += gsz) st4(grad_value + base + 4 * (size_t)i, *reinterpret_cast<const float4 *>(acc + base + 4 * (size_t)i));
+        }
     }
 }
 

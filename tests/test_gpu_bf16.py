@@ -80,7 +80,7 @@ def check(got, want, loc64=None):
     assert rel_err(gl, ogl) < 2e-4
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 4])
 @pytest.mark.parametrize("case", ["pyramid_encoder_f32", "decoder_n2m8_f64", "ref_test_grad_D32", "ref_test_grad_D30",
                                   "border_bands_grad"])
 def test_bf16_golden_inputs(case, variant):
@@ -91,7 +91,7 @@ def test_bf16_golden_inputs(case, variant):
     check(got, want)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 4])   # direct, LDS-window, routed
 @pytest.mark.parametrize("loc_mode", ["init", "sigma4", "uniform"])
 @pytest.mark.parametrize("which", ["E", "Dd", "Em"])
 def test_bf16_shrunk_baseline_calls(which, loc_mode, variant):
