@@ -49,11 +49,14 @@ constexpr int kFragShorts = 512;   // one MFMA operand fragment: 64 lanes x 8 bf
 constexpr int kTileFrags = 32;     // 16 of W1 (k-steps over d_model) + 16 of W2 (8 row tiles x 2 k-steps)
 constexpr int kMaxFfn = 4096;
 
-__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)   // one v_cvt_pk_bf16_f32 (round to nearest even)
 {
-    const __hip_bfloat162 p = __float22bfloat162_rn(make_float2(a, b));
-    return *reinterpret_cast<const unsigned *>(&p);
+    const bf16x2_t p = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, p);
 }
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }   // one v_med3_f32
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 
@@ -117,18 +120,20 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
     // tiles 4 w .. 4 w + 3 of W2: 8 DMAs of 1 KB per wave and tile.
     const uint16_t *p1 = w1 + (size_t)c * kD + 8 * q + 64 * wave;
     const uint16_t *p2 = w2p + (size_t)(64 * wave + c) * F + 8 * q;
-    auto stage = [&](int ht, int slot) {
+    auto stage_piece = [&](int ht, int slot, int i) {   // piece i of 8 (i < 4: W1, else W2)
         short *dst = wbuf + slot * (kTileFrags * kFragShorts);
-        const uint16_t *s1 = p1 + (size_t)ht * (kHT * kD), *s2 = p2 + ht * kHT;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)   // i = 2 (s - 2 w) + rt
-            __builtin_amdgcn_global_load_lds(s1 + (size_t)(i & 1) * 16 * kD + 32 * (i >> 1),
+        if (i < 4)   // i = 2 (s - 2 w) + rt
+            __builtin_amdgcn_global_load_lds(p1 + (size_t)ht * (kHT * kD) + (size_t)(i & 1) * 16 * kD + 32 * (i >> 1),
                                              reinterpret_cast<__attribute__((address_space(3))) void *>(
                                                  reinterpret_cast<uintptr_t>(dst + (4 * wave + i) * kFragShorts)), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds(p2 + ht * kHT + (size_t)(i - 4) * 16 * F,
+                                             reinterpret_cast<__attribute__((address_space(3))) void *>(
+                                                 reinterpret_cast<uintptr_t>(dst + (16 + 4 * wave + (i - 4)) * kFragShorts)), 16, 0, 0);
+    };
+    auto stage = [&](int ht, int slot) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds(s2 + (size_t)i * 16 * F, reinterpret_cast<__attribute__((address_space(3))) void *>(
-                                                                          reinterpret_cast<uintptr_t>(dst + (16 + 4 * wave + i) * kFragShorts)), 16, 0, 0);
+        for (int i = 0; i < 8; ++i) stage_piece(ht, slot, i);
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the ordinary loads above have retired
     __syncthreads();                      // (parameters in LDS)
@@ -141,7 +146,11 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
         if (ht + 1 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // ... everybody's share of it; and everybody is done with tile ht - 1, whose slot is refilled now
-        if (ht + 2 < nt) stage(ht + 2, slot == 0 ? 2 : slot - 1);
+        // the 8 pieces of tile ht + 2 are requested one by one between the MFMA groups below (an LDS-DMA instruction costs its wave
+        // 60-185 cycles of issue depending on what surrounds it: guide, "LDS-DMA piece issue cost")
+        const bool refill = ht + 2 < nt;
+        const int rslot = slot == 0 ? 2 : slot - 1;
+#define FFN_STAGE(I) if (refill) stage_piece(ht + 2, rslot, I);
         const unsigned wt = (unsigned)(uintptr_t)(wbuf + slot * (kTileFrags * kFragShorts)) + lane * 16;   // LDS byte address of this lane's piece of fragment 0
 
         // The operand stream of a tile: a ring of eight fragment registers; fragment p lives in fr[p & 7], is waited for with
@@ -177,48 +186,57 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
         FFN_WAIT(7, fr[0]); FFN_USE1(0) FFN_READ(fr[0], wt, 8 * 1024);
         FFN_WAIT(7, fr[1]); FFN_USE1(1) FFN_READ(fr[1], wt, 9 * 1024);
         FFN_WAIT(7, fr[2]); FFN_USE1(2) FFN_READ(fr[2], wt, 10 * 1024);
+        FFN_STAGE(0)
         FFN_WAIT(7, fr[3]); FFN_USE1(3) FFN_READ(fr[3], wt, 11 * 1024);
         FFN_WAIT(7, fr[4]); FFN_USE1(4) FFN_READ(fr[4], wt, 12 * 1024);
         FFN_WAIT(7, fr[5]); FFN_USE1(5) FFN_READ(fr[5], wt, 13 * 1024);
         FFN_WAIT(7, fr[6]); FFN_USE1(6) FFN_READ(fr[6], wt, 14 * 1024);
+        FFN_STAGE(1)
         FFN_WAIT(7, fr[7]); FFN_USE1(7) FFN_READ(fr[7], wt, 15 * 1024);
         FFN_WAIT(7, fr[0]); FFN_USE1(8) FFN_READ(fr[0], wt, 16 * 1024);
         FFN_WAIT(7, fr[1]); FFN_USE1(9) FFN_READ(fr[1], wt, 17 * 1024);
         FFN_WAIT(7, fr[2]); FFN_USE1(10) FFN_READ(fr[2], wt, 18 * 1024);
+        FFN_STAGE(2)
         FFN_WAIT(7, fr[3]); FFN_USE1(11) FFN_READ(fr[3], wt, 19 * 1024);
         FFN_WAIT(7, fr[4]); FFN_USE1(12) FFN_READ(fr[4], wt, 20 * 1024);
         FFN_WAIT(7, fr[5]); FFN_USE1(13) FFN_READ(fr[5], wt, 21 * 1024);
         FFN_WAIT(7, fr[6]); FFN_USE1(14) FFN_READ(fr[6], wt, 22 * 1024);
+        FFN_STAGE(3)
         FFN_WAIT(7, fr[7]); FFN_USE1(15) FFN_READ(fr[7], wt, 23 * 1024);
         // ---- relu, to bf16: elements 0..3 = rows 4 q + 0..3 of row tile 0, elements 4..7 = the same rows of row tile 1 ------------
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) {
             u32x4 u;
-            u[0] = pack_bf16(fmaxf(hacc[ct][0][0], 0.f), fmaxf(hacc[ct][0][1], 0.f));
-            u[1] = pack_bf16(fmaxf(hacc[ct][0][2], 0.f), fmaxf(hacc[ct][0][3], 0.f));
-            u[2] = pack_bf16(fmaxf(hacc[ct][1][0], 0.f), fmaxf(hacc[ct][1][1], 0.f));
-            u[3] = pack_bf16(fmaxf(hacc[ct][1][2], 0.f), fmaxf(hacc[ct][1][3], 0.f));
+            u[0] = pack_bf16(relu1(hacc[ct][0][0]), relu1(hacc[ct][0][1]));
+            u[1] = pack_bf16(relu1(hacc[ct][0][2]), relu1(hacc[ct][0][3]));
+            u[2] = pack_bf16(relu1(hacc[ct][1][0]), relu1(hacc[ct][1][1]));
+            u[3] = pack_bf16(relu1(hacc[ct][1][2]), relu1(hacc[ct][1][3]));
             hb[ct] = __builtin_bit_cast(bf16x8, u);
         }
         // ---- out^T += W2 tile . relu(H^T): fragment 16 + t = 16-channel row tile t ------------------------------------------------
         FFN_WAIT(7, fr[0]); FFN_USE2(16) FFN_READ(fr[0], wt, 24 * 1024);
         FFN_WAIT(7, fr[1]); FFN_USE2(17) FFN_READ(fr[1], wt, 25 * 1024);
         FFN_WAIT(7, fr[2]); FFN_USE2(18) FFN_READ(fr[2], wt, 26 * 1024);
+        FFN_STAGE(4)
         FFN_WAIT(7, fr[3]); FFN_USE2(19) FFN_READ(fr[3], wt, 27 * 1024);
         FFN_WAIT(7, fr[4]); FFN_USE2(20) FFN_READ(fr[4], wt, 28 * 1024);
         FFN_WAIT(7, fr[5]); FFN_USE2(21) FFN_READ(fr[5], wt, 29 * 1024);
         FFN_WAIT(7, fr[6]); FFN_USE2(22) FFN_READ(fr[6], wt, 30 * 1024);
+        FFN_STAGE(5)
         FFN_WAIT(7, fr[7]); FFN_USE2(23) FFN_READ(fr[7], wt, 31 * 1024);
         FFN_WAIT(7, fr[0]); FFN_USE2(24)
         FFN_WAIT(6, fr[1]); FFN_USE2(25)
         FFN_WAIT(5, fr[2]); FFN_USE2(26)
+        FFN_STAGE(6)
         FFN_WAIT(4, fr[3]); FFN_USE2(27)
         FFN_WAIT(3, fr[4]); FFN_USE2(28)
         FFN_WAIT(2, fr[5]); FFN_USE2(29)
         FFN_WAIT(1, fr[6]); FFN_USE2(30)
+        FFN_STAGE(7)
         FFN_WAIT(0, fr[7]); FFN_USE2(31)
 #undef FFN_USE1
 #undef FFN_USE2
+#undef FFN_STAGE
         slot = slot == kRing - 1 ? 0 : slot + 1;
     }
 
