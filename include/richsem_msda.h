@@ -258,6 +258,9 @@ int msda_mask_rows_bf16(uint16_t *x, const uint8_t *mask, int64_t rows, int row_
  *   w2_packed    linear2.weight (d_model, d_ffn) bf16 after msda_ffn_pack_w2_bf16 (a fixed permutation of the hidden
  *                columns inside every group of 32: repack whenever the weight changes);  b2 (d_model) f32
  *   ln_weight, ln_bias (d_model) f32, eps as nn.LayerNorm.  All pointers 16-byte aligned. */
+/* Diagnostic: non-NULL = the kernel adds up the shader clocks wave 0 of every workgroup spends per loop stage (wait for the
+ * weight tile, barrier, first product, relu + conversion, second product) into 8 x 8 bytes per workgroup; NULL = off. */
+int msda_ffn_debug_stamps(void *device_buffer);
 int msda_ffn_pack_w2_bf16(const uint16_t *w2, int d_model, int d_ffn, uint16_t *w2_packed, msda_stream_t stream);
 int msda_ffn_forward_bf16(const uint16_t *x, const uint16_t *w1, const float *b1, const uint16_t *w2_packed, const float *b2,
                           const float *ln_weight, const float *ln_bias, float eps, int tokens, int d_model, int d_ffn,

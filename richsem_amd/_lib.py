@@ -26,7 +26,7 @@ SYMBOLS = [
     "msda_forward_bf16", "msda_backward_bf16",
     "msda_prep_forward_f32", "msda_prep_forward_f64", "msda_prep_backward_f32", "msda_prep_backward_f64",
     "msda_mask_rows_f32", "msda_mask_rows_f64", "msda_mask_rows_bf16",
-    "msda_ffn_pack_w2_bf16", "msda_ffn_forward_bf16",
+    "msda_ffn_pack_w2_bf16", "msda_ffn_forward_bf16", "msda_ffn_debug_stamps",
 ]
 
 
@@ -72,6 +72,8 @@ def load():
     L.msda_profile_enable.restype = ci
     L.msda_profile_collect.argtypes = [ctypes.POINTER(ProfileRecord), ci, ctypes.POINTER(ci)]
     L.msda_profile_collect.restype = ci
+    L.msda_ffn_debug_stamps.argtypes = [vp]
+    L.msda_ffn_debug_stamps.restype = ci
     L.msda_ffn_pack_w2_bf16.argtypes = [vp, ci, ci, vp, vp]
     L.msda_ffn_pack_w2_bf16.restype = ci
     L.msda_ffn_forward_bf16.argtypes = [vp] * 7 + [ctypes.c_float, ci, ci, ci, vp, vp]

@@ -81,7 +81,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w1, const float *__restrict__ b1,
                     const uint16_t *__restrict__ w2p, const float *__restrict__ b2, const float *__restrict__ gamma,
-                    const float *__restrict__ beta, float eps, int T, int F, uint16_t *__restrict__ out)
+                    const float *__restrict__ beta, float eps, int T, int F, uint16_t *__restrict__ out,
+                    unsigned long long *__restrict__ stamps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     short *wbuf = reinterpret_cast<short *>(smem);                                          // [kRing][kTileFrags * kFragShorts]
@@ -140,12 +141,23 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
     stage(0, 0);
     if (nt > 1) stage(1, 1);
 
+    // diagnostic (msda_ffn_debug_stamps): shader-clock totals of the loop's stages, wave 0 of every workgroup
+    unsigned long long t_last = 0, t_acc[6] = {0, 0, 0, 0, 0, 0};
+#define FFN_STAMP(i)                                               \
+    if (stamps) {                                                  \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        t_acc[i] += now_ - t_last;                                 \
+        t_last = now_;                                             \
+    }
+    if (stamps) t_last = __builtin_amdgcn_s_memtime();
     int slot = 0;
     for (int ht = 0; ht < nt; ++ht) {
         // tile ht has landed: at most the 8 DMAs of tile ht + 1 may still be in flight
         if (ht + 1 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FFN_STAMP(0)   // wait for the tile's DMAs
         __builtin_amdgcn_s_barrier();   // ... everybody's share of it; and everybody is done with tile ht - 1, whose slot is refilled now
+        FFN_STAMP(1)   // barrier
         // the 8 pieces of tile ht + 2 are requested one by one between the MFMA groups below (an LDS-DMA instruction costs its wave
         // 60-185 cycles of issue depending on what surrounds it: guide, "LDS-DMA piece issue cost")
         const bool refill = ht + 2 < nt;
@@ -156,24 +168,35 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
         // The operand stream of a tile: a ring of eight fragment registers; fragment p lives in fr[p & 7], is waited for with
         // "at most 7 newer reads in flight", feeds three MFMAs and is at once replaced by the read of fragment p + 8.
         u32x4 fr[8];
+        f32x4 bias[2];   // rows 16 rt + 4 q + 0..3 of the tile: read in the same stream, ahead of fragment 0 (whose wait covers them)
+        {
+            const unsigned ba = (unsigned)(uintptr_t)lb1 + (unsigned)(ht * kHT + 4 * q) * 4u;
+            FFN_READ(bias[0], ba, 0);
+            FFN_READ(bias[1], ba, 64);
+        }
         FFN_READ(fr[0], wt, 0 * 1024); FFN_READ(fr[1], wt, 1 * 1024); FFN_READ(fr[2], wt, 2 * 1024); FFN_READ(fr[3], wt, 3 * 1024);
         FFN_READ(fr[4], wt, 4 * 1024); FFN_READ(fr[5], wt, 5 * 1024); FFN_READ(fr[6], wt, 6 * 1024); FFN_READ(fr[7], wt, 7 * 1024);
 
         // ---- H^T tile (two 16-row tiles) = W1 tile . x^T + b1 ---------------------------------------------------------------
+        // The MFMAs of this product are inline: their accumulators must be VGPRs (relu and the conversion read them; hipcc
+        // would put them into AGPRs, on top of six out^T tiles that it then parks in VGPRs around every hidden tile: ~100 register
+        // moves per tile), and the first k-step takes the bias as its C operand instead of copying it into the accumulators.
         f32x4 hacc[3][2];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {   // rows 16 rt + 4 q + 0..3 of the tile
-            const f32x4 bb = *reinterpret_cast<const f32x4 *>(lb1 + ht * kHT + 16 * rt + 4 * q);
-            hacc[0][rt] = hacc[1][rt] = hacc[2][rt] = bb;
-        }
         bf16x8 hb[3];
+#define FFN_MFMA1(D, A, B, C) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=v"(D) : "v"(A), "v"(B), "v"(C))
+#define FFN_MFMA1_ACC(D, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(D) : "v"(A), "v"(B))
 #define FFN_USE1(P)                                                                                                          \
     {                                                                                                                        \
-        const bf16x8 a_ = __builtin_bit_cast(bf16x8, fr[(P) & 7]);                                                           \
         constexpr int s_ = (P) >> 1, rt_ = (P) & 1;                                                                          \
-        hacc[0][rt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, xf[0][s_], hacc[0][rt_], 0, 0, 0);                        \
-        hacc[1][rt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, xf[1][s_], hacc[1][rt_], 0, 0, 0);                        \
-        hacc[2][rt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, xf[2][s_], hacc[2][rt_], 0, 0, 0);                        \
+        if (s_ == 0) {                                                                                                       \
+            FFN_MFMA1(hacc[0][rt_], fr[(P) & 7], xf[0][s_], bias[rt_]);                                                      \
+            FFN_MFMA1(hacc[1][rt_], fr[(P) & 7], xf[1][s_], bias[rt_]);                                                      \
+            FFN_MFMA1(hacc[2][rt_], fr[(P) & 7], xf[2][s_], bias[rt_]);                                                      \
+        } else {                                                                                                             \
+            FFN_MFMA1_ACC(hacc[0][rt_], fr[(P) & 7], xf[0][s_]);                                                             \
+            FFN_MFMA1_ACC(hacc[1][rt_], fr[(P) & 7], xf[1][s_]);                                                             \
+            FFN_MFMA1_ACC(hacc[2][rt_], fr[(P) & 7], xf[2][s_]);                                                             \
+        }                                                                                                                    \
     }
 #define FFN_USE2(P)                                                                                                          \
     {                                                                                                                        \
@@ -183,7 +206,9 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
         acc[1][t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, hb[1], acc[1][t_], 0, 0, 0);                                \
         acc[2][t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, hb[2], acc[2][t_], 0, 0, 0);                                \
     }
-        FFN_WAIT(7, fr[0]); FFN_USE1(0) FFN_READ(fr[0], wt, 8 * 1024);
+        FFN_WAIT(7, fr[0]);
+        asm volatile("" : "+v"(bias[0]), "+v"(bias[1]));
+        FFN_USE1(0) FFN_READ(fr[0], wt, 8 * 1024);
         FFN_WAIT(7, fr[1]); FFN_USE1(1) FFN_READ(fr[1], wt, 9 * 1024);
         FFN_WAIT(7, fr[2]); FFN_USE1(2) FFN_READ(fr[2], wt, 10 * 1024);
         FFN_STAGE(0)
@@ -203,6 +228,10 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
         FFN_WAIT(7, fr[6]); FFN_USE1(14) FFN_READ(fr[6], wt, 22 * 1024);
         FFN_STAGE(3)
         FFN_WAIT(7, fr[7]); FFN_USE1(15) FFN_READ(fr[7], wt, 23 * 1024);
+        FFN_STAMP(2)   // first product
+        // (results of an inline MFMA: the compiler does not know to keep its distance -- a 4-pass MFMA's result may be read by a
+        // vector instruction 11 wait states later)
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(hacc[0][0]), "+v"(hacc[0][1]), "+v"(hacc[1][0]), "+v"(hacc[1][1]), "+v"(hacc[2][0]), "+v"(hacc[2][1]));
         // ---- relu, to bf16: elements 0..3 = rows 4 q + 0..3 of row tile 0, elements 4..7 = the same rows of row tile 1 ------------
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) {
@@ -213,6 +242,7 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
             u[3] = pack_bf16(relu1(hacc[ct][1][2]), relu1(hacc[ct][1][3]));
             hb[ct] = __builtin_bit_cast(bf16x8, u);
         }
+        FFN_STAMP(3)   // relu + conversion
         // ---- out^T += W2 tile . relu(H^T): fragment 16 + t = 16-channel row tile t ------------------------------------------------
         FFN_WAIT(7, fr[0]); FFN_USE2(16) FFN_READ(fr[0], wt, 24 * 1024);
         FFN_WAIT(7, fr[1]); FFN_USE2(17) FFN_READ(fr[1], wt, 25 * 1024);
@@ -237,8 +267,15 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
 #undef FFN_USE1
 #undef FFN_USE2
 #undef FFN_STAGE
+#undef FFN_MFMA1
+#undef FFN_MFMA1_ACC
+        FFN_STAMP(4)   // second product
         slot = slot == kRing - 1 ? 0 : slot + 1;
     }
+
+    if (stamps && lane == 0 && wave == 0)
+        for (int i = 0; i < 5; ++i) stamps[(size_t)blockIdx.x * 8 + i] = t_acc[i];
+#undef FFN_STAMP
 
     // ---- epilogue: + b2 + x, LayerNorm over the 256 channels of a token (64 in this lane, the rest in lanes ^16, ^32, ^48), bf16 store ---
 #pragma unroll
@@ -295,7 +332,17 @@ size_t ffn_lds_bytes(int F) { return (size_t)kRing * kTileFrags * kFragShorts * 
 
 }  // namespace
 
+unsigned long long *g_ffn_stamps = nullptr;
+
 extern "C" {
+
+/* Diagnostic: when `device_buffer` is non-NULL the feed-forward kernel adds up the shader clocks its wave 0 spends per loop stage
+ * (wait for the weight tile, barrier, first product, relu + conversion, second product) into 8 x 8 bytes per workgroup. */
+int msda_ffn_debug_stamps(void *device_buffer)
+{
+    g_ffn_stamps = static_cast<unsigned long long *>(device_buffer);
+    return MSDA_OK;
+}
 
 int msda_ffn_pack_w2_bf16(const uint16_t *w2, int d_model, int d_ffn, uint16_t *w2_packed, msda_stream_t stream)
 {
@@ -327,7 +374,7 @@ int msda_ffn_forward_bf16(const uint16_t *x, const uint16_t *w1, const float *b1
     }
     const int grid = (tokens + kTokWg - 1) / kTokWg;
     hipLaunchKernelGGL(ffn_fwd_kernel, dim3(grid), dim3(kWaves * 64), lds, static_cast<hipStream_t>(stream), x, w1, b1, w2_packed, b2,
-                       ln_weight, ln_bias, eps, tokens, d_ffn, out);
+                       ln_weight, ln_bias, eps, tokens, d_ffn, out, g_ffn_stamps);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
 }

@@ -58,6 +58,17 @@ def main():
     t_t = timeit(torch_bf16, args.reps)
     print(f"  fused kernel {t_f:8.1f} us  {flop / t_f / 1e6:7.1f} TFLOP/s  ({flop / t_f / 1e6 / 2500:.3f} of 2.5 PFLOP/s dense bf16)")
     print(f"  PyTorch bf16 {t_t:8.1f} us  {flop / t_t / 1e6:7.1f} TFLOP/s")
+    from richsem_amd import _lib
+    buf = torch.zeros(((T + 191) // 192) * 8, dtype=torch.int64, device=dev)
+    _lib.load().msda_ffn_debug_stamps(buf.data_ptr())
+    ffn_forward_bf16(x, w1, b1, w2p, b2, gw, gb)
+    torch.cuda.synchronize()
+    _lib.load().msda_ffn_debug_stamps(None)
+    st = buf.view(-1, 8).double().mean(0)
+    names = ["wait for the weight tile", "barrier", "first product (48 MFMAs per tile)", "relu + conversion", "second product (48 MFMAs per tile)"]
+    tot = float(st[:5].sum())
+    for n, v in zip(names, st[:5].tolist()):
+        print(f"    {n:36s} {v / (Fh // 32):8.0f} cycles per tile  {100 * v / tot:5.1f} %")
 
 
 if __name__ == "__main__":
