@@ -31,6 +31,8 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/richsem_msda.h"
 
 namespace {
@@ -366,11 +368,13 @@ int msda_ffn_forward_bf16(const uint16_t *x, const uint16_t *w1, const float *b1
         return MSDA_ERR_MISALIGNED;
     if (tokens == 0) return MSDA_OK;
     const size_t lds = ffn_lds_bytes(d_ffn);
-    static bool raised = false;   // (per process; the limit is a property of the function)
-    if (!raised) {
+    static std::atomic<bool> raised[64];   // per device: the dynamic-LDS limit is a property of (function, device)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MSDA_ERR_NO_DEVICE;
+    if (!raised[dev].load()) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        raised = true;
+        raised[dev] = true;
     }
     const int grid = (tokens + kTokWg - 1) / kTokWg;
     hipLaunchKernelGGL(ffn_fwd_kernel, dim3(grid), dim3(kWaves * 64), lds, static_cast<hipStream_t>(stream), x, w1, b1, w2_packed, b2,
