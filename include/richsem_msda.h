@@ -243,6 +243,16 @@ int msda_prep_backward_f64(const double *grad_loc, const double *grad_aw, const 
                            const int64_t *shapes_host, int N, int Lq, int M, int L, int P,
                            double *grad_offsets, int64_t goff_stride, double *grad_logits, int64_t glog_stride,
                            double *grad_ref, msda_stream_t stream);
+/* the same with a bfloat16 projection: offsets / logits (and their gradients) are raw 16-bit bf16 words -- the output of a bf16
+ * GEMM -- while locations, weights, reference points and their gradients are float32 and all arithmetic is fp32 */
+int msda_prep_forward_bf16(const uint16_t *offsets, int64_t off_stride, const uint16_t *logits, int64_t log_stride,
+                           const float *ref, int ref_dim, const int64_t *shapes_host, int N, int Lq, int M, int L, int P,
+                           float *loc, float *aw, msda_stream_t stream);
+int msda_prep_backward_bf16(const float *grad_loc, const float *grad_aw, const float *aw,
+                            const uint16_t *offsets, int64_t off_stride, const float *ref, int ref_dim,
+                            const int64_t *shapes_host, int N, int Lq, int M, int L, int P,
+                            uint16_t *grad_offsets, int64_t goff_stride, uint16_t *grad_logits, int64_t glog_stride,
+                            float *grad_ref, msda_stream_t stream);
 int msda_mask_rows_f32(float *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);
 int msda_mask_rows_f64(double *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);
 int msda_mask_rows_bf16(uint16_t *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);

@@ -25,6 +25,7 @@ SYMBOLS = [
     "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64",
     "msda_forward_bf16", "msda_backward_bf16",
     "msda_prep_forward_f32", "msda_prep_forward_f64", "msda_prep_backward_f32", "msda_prep_backward_f64",
+    "msda_prep_forward_bf16", "msda_prep_backward_bf16",
     "msda_mask_rows_f32", "msda_mask_rows_f64", "msda_mask_rows_bf16",
     "msda_ffn_pack_w2_bf16", "msda_ffn_forward_bf16", "msda_ffn_debug_stamps",
 ]
@@ -86,7 +87,7 @@ def load():
         g.argtypes = [vp] * 6 + [ci] * 8 + [vp, vp, vp, vp, vp, vp]
         g.restype = ci
     i64 = ctypes.c_int64
-    for sfx in ("f32", "f64"):
+    for sfx in ("f32", "f64", "bf16"):
         f = getattr(L, "msda_prep_forward_" + sfx)
         f.argtypes = [vp, i64, vp, i64, vp, ci, vp] + [ci] * 5 + [vp, vp, vp]
         f.restype = ci

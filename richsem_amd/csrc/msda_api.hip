@@ -985,8 +985,8 @@ int prep_geom(msda::PrepGeom &g, int N, int Lq, int M, int L, int P, int ref_dim
     return MSDA_OK;
 }
 
-template <typename T>
-int prep_forward_impl(const T *offsets, int64_t off_stride, const T *logits, int64_t log_stride, const T *ref, int ref_dim,
+template <typename T, typename TP = T>
+int prep_forward_impl(const TP *offsets, int64_t off_stride, const TP *logits, int64_t log_stride, const T *ref, int ref_dim,
                       const int64_t *shapes_host, int N, int Lq, int M, int L, int P, T *loc, T *aw, msda_stream_t stream_)
 {
     g_err[0] = 0;
@@ -999,16 +999,16 @@ int prep_forward_impl(const T *offsets, int64_t off_stride, const T *logits, int
     g.log_stride = log_stride;
     const int64_t items = (int64_t)N * Lq * M, per_block = 256 / g.G;
     const int grid = (int)std::min<int64_t>((items + per_block - 1) / per_block, 8192);
-    hipLaunchKernelGGL(msda::prep_forward_kernel<T>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_), offsets, logits, ref, loc, aw, g);
+    hipLaunchKernelGGL((msda::prep_forward_kernel<T, TP>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_), offsets, logits, ref, loc, aw, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch of the location / softmax kernel");
     return MSDA_OK;
 }
 
-template <typename T>
-int prep_backward_impl(const T *grad_loc, const T *grad_aw, const T *aw, const T *offsets, int64_t off_stride, const T *ref,
-                       int ref_dim, const int64_t *shapes_host, int N, int Lq, int M, int L, int P, T *grad_offsets,
-                       int64_t goff_stride, T *grad_logits, int64_t glog_stride, T *grad_ref, msda_stream_t stream_)
+template <typename T, typename TP = T>
+int prep_backward_impl(const T *grad_loc, const T *grad_aw, const T *aw, const TP *offsets, int64_t off_stride, const T *ref,
+                       int ref_dim, const int64_t *shapes_host, int N, int Lq, int M, int L, int P, TP *grad_offsets,
+                       int64_t goff_stride, TP *grad_logits, int64_t glog_stride, T *grad_ref, msda_stream_t stream_)
 {
     g_err[0] = 0;
     if (!grad_loc || !grad_aw || !aw || !ref || !grad_offsets || !grad_logits || (ref_dim == 4 && grad_ref && !offsets))
@@ -1022,7 +1022,7 @@ int prep_backward_impl(const T *grad_loc, const T *grad_aw, const T *aw, const T
     g.glog_stride = glog_stride;
     const int64_t items = (int64_t)N * Lq, per_block = 256 / g.G;
     const int grid = (int)std::min<int64_t>((items + per_block - 1) / per_block, 8192);
-    hipLaunchKernelGGL(msda::prep_backward_kernel<T>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_), grad_loc, grad_aw,
+    hipLaunchKernelGGL((msda::prep_backward_kernel<T, TP>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_), grad_loc, grad_aw,
                        aw, offsets, ref, grad_offsets, grad_logits, grad_ref, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch of the location / softmax backward kernel");
@@ -1288,6 +1288,24 @@ int msda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes, con
 MSDA_PREP_EXPORTS(f32, float)
 MSDA_PREP_EXPORTS(f64, double)
 #undef MSDA_PREP_EXPORTS
+
+int msda_prep_forward_bf16(const uint16_t *offsets, int64_t off_stride, const uint16_t *logits, int64_t log_stride, const float *ref,
+                           int ref_dim, const int64_t *shapes_host, int N, int Lq, int M, int L, int P, float *loc, float *aw,
+                           msda_stream_t stream)
+{
+    return prep_forward_impl<float, msda::bf16_t>(reinterpret_cast<const msda::bf16_t *>(offsets), off_stride,
+                                                  reinterpret_cast<const msda::bf16_t *>(logits), log_stride, ref, ref_dim, shapes_host, N,
+                                                  Lq, M, L, P, loc, aw, stream);
+}
+int msda_prep_backward_bf16(const float *grad_loc, const float *grad_aw, const float *aw, const uint16_t *offsets, int64_t off_stride,
+                            const float *ref, int ref_dim, const int64_t *shapes_host, int N, int Lq, int M, int L, int P,
+                            uint16_t *grad_offsets, int64_t goff_stride, uint16_t *grad_logits, int64_t glog_stride, float *grad_ref,
+                            msda_stream_t stream)
+{
+    return prep_backward_impl<float, msda::bf16_t>(grad_loc, grad_aw, aw, reinterpret_cast<const msda::bf16_t *>(offsets), off_stride, ref,
+                                                   ref_dim, shapes_host, N, Lq, M, L, P, reinterpret_cast<msda::bf16_t *>(grad_offsets),
+                                                   goff_stride, reinterpret_cast<msda::bf16_t *>(grad_logits), glog_stride, grad_ref, stream);
+}
 
 int msda_mask_rows_f32(float *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream)
 {

@@ -30,6 +30,15 @@ struct PrepGeom {
     float W[kPrepMaxL], H[kPrepMaxL];     // offset normaliser per level (2-d reference points)
 };
 
+// element load / store of the projection tensor in compute type T
+template <typename T, typename TP>
+__device__ __forceinline__ T prep_ld(const TP *p) { return (T)*p; }
+template <>
+__device__ __forceinline__ float prep_ld<float, bf16_t>(const bf16_t *p) { return __bfloat162float(*p); }
+template <typename TP, typename T>
+__device__ __forceinline__ void prep_st(TP *p, T v) { *p = (TP)v; }
+__device__ __forceinline__ void prep_st(bf16_t *p, float v) { *p = __float2bfloat16(v); }
+
 // width-G (power of two) butterfly reductions inside a wave
 template <typename T>
 __device__ __forceinline__ T group_max(T v, int G)
@@ -49,8 +58,10 @@ __device__ __forceinline__ T group_sum(T v, int G)
 
 // sampling_loc (N, Lq, M, L, P, 2) and attn_weight (N, Lq, M, L, P) from raw offsets, logits and reference points.
 // reference ms_deform_attn.py:100 (softmax), :102-109 (location arithmetic).
-template <typename T>
-__global__ __launch_bounds__(256) void prep_forward_kernel(const T *__restrict__ offsets, const T *__restrict__ logits,
+// TP: storage type of the raw projection (offsets, logits) and of its gradient: T, or bf16_t with T = float (a bf16 GEMM feeds
+// the kernel; locations, weights and reference points stay T).
+template <typename T, typename TP = T>
+__global__ __launch_bounds__(256) void prep_forward_kernel(const TP *__restrict__ offsets, const TP *__restrict__ logits,
                                                            const T *__restrict__ ref, T *__restrict__ loc, T *__restrict__ aw,
                                                            const PrepGeom g)
 {
@@ -66,10 +77,10 @@ __global__ __launch_bounds__(256) void prep_forward_kernel(const T *__restrict__
         T x = (T)-3.0e38;   // padding lanes: exp() = 0
         T ox = 0, oy = 0, rx = 0, ry = 0, rw = 0, rh = 0;
         if (live) {
-            x = logits[nq * g.log_stride + (long long)m * LP + lane_g];
-            const T *o = offsets + nq * g.off_stride + ((long long)m * LP + lane_g) * 2;
-            ox = o[0];
-            oy = o[1];
+            x = prep_ld<T>(logits + nq * g.log_stride + (long long)m * LP + lane_g);
+            const TP *o = offsets + nq * g.off_stride + ((long long)m * LP + lane_g) * 2;
+            ox = prep_ld<T>(o);
+            oy = prep_ld<T>(o + 1);
             const T *r = ref + (nq * g.L + l) * g.ref_dim;
             rx = r[0];
             ry = r[1];
@@ -97,11 +108,11 @@ __global__ __launch_bounds__(256) void prep_forward_kernel(const T *__restrict__
 
 // grad_offsets, grad_logits (+ grad_reference_points when grad_ref != nullptr) from grad_sampling_loc and grad_attn_weight.
 // A lane group takes one (image, query) and walks its M heads.
-template <typename T>
+template <typename T, typename TP = T>
 __global__ __launch_bounds__(256) void prep_backward_kernel(const T *__restrict__ grad_loc, const T *__restrict__ grad_aw,
-                                                            const T *__restrict__ aw, const T *__restrict__ offsets,
-                                                            const T *__restrict__ ref, T *__restrict__ grad_offsets,
-                                                            T *__restrict__ grad_logits, T *__restrict__ grad_ref, const PrepGeom g)
+                                                            const T *__restrict__ aw, const TP *__restrict__ offsets,
+                                                            const T *__restrict__ ref, TP *__restrict__ grad_offsets,
+                                                            TP *__restrict__ grad_logits, T *__restrict__ grad_ref, const PrepGeom g)
 {
     const int LP = g.L * g.P;
     const int lane_g = threadIdx.x & (g.G - 1);
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(256) void prep_backward_kernel(const T *__restrict_
             // softmax backward: dL/dlogit_p = a_p * (g_p - sum_j a_j g_j)
             const T dot = group_sum<T>(a * ga, g.G);
             if (live) {
-                grad_logits[nq * g.glog_stride + (long long)m * LP + lane_g] = a * (ga - dot);
+                prep_st(grad_logits + nq * g.glog_stride + (long long)m * LP + lane_g, a * (ga - dot));
                 T dox, doy;
                 if (g.ref_dim == 2) {
                     dox = gx / (T)g.W[l];
@@ -139,14 +150,14 @@ __global__ __launch_bounds__(256) void prep_backward_kernel(const T *__restrict_
                     dox = gx / (T)g.P * rw * (T)0.5;
                     doy = gy / (T)g.P * rh * (T)0.5;
                     if (grad_ref) {
-                        const T *o = offsets + nq * g.off_stride + ((long long)m * LP + lane_g) * 2;
-                        sw += gx * (o[0] / (T)g.P) * (T)0.5;
-                        sh += gy * (o[1] / (T)g.P) * (T)0.5;
+                        const TP *o = offsets + nq * g.off_stride + ((long long)m * LP + lane_g) * 2;
+                        sw += gx * (prep_ld<T>(o) / (T)g.P) * (T)0.5;
+                        sh += gy * (prep_ld<T>(o + 1) / (T)g.P) * (T)0.5;
                     }
                 }
-                T *d = grad_offsets + nq * g.goff_stride + ((long long)m * LP + lane_g) * 2;
-                d[0] = dox;
-                d[1] = doy;
+                TP *d = grad_offsets + nq * g.goff_stride + ((long long)m * LP + lane_g) * 2;
+                prep_st(d, dox);
+                prep_st(d + 1, doy);
                 sx += gx;
                 sy += gy;
             }

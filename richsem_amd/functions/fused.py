@@ -16,7 +16,7 @@ from torch.autograd.function import once_differentiable
 from .. import MultiScaleDeformableAttention as MSDA
 from .. import _lib
 
-_SFX = {torch.float32: "f32", torch.float64: "f64"}
+_SFX = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}
 
 
 def _stream(t):
@@ -58,8 +58,12 @@ class MSDeformAttnFusedFunction(Function):
                 im2col_step):
         if not value.is_cuda:
             raise RuntimeError("Not implemented on the CPU")
-        if qproj.dtype not in _SFX or reference_points.dtype != qproj.dtype:
-            raise RuntimeError(f"fused MSDeformAttn path: float32 / float64 projections, got {qproj.dtype}")
+        # bfloat16: value and the raw projection are bf16 (bf16 GEMMs around the operator); reference points, locations and
+        # attention weights are float32, arithmetic fp32 (msda_prep_*_bf16, msda_forward_bf16 / msda_backward_bf16)
+        work = torch.float32 if qproj.dtype == torch.bfloat16 else qproj.dtype
+        if qproj.dtype not in _SFX or reference_points.dtype != work:
+            raise RuntimeError(f"fused MSDeformAttn path: float32 / float64 / bfloat16 projections with reference points in "
+                               f"{work}, got {qproj.dtype} / {reference_points.dtype}")
         N, Lq = qproj.shape[0], qproj.shape[1]
         M, L, P = n_heads, n_levels, n_points
         n_off, n_log = M * L * P * 2, M * L * P
@@ -70,8 +74,8 @@ class MSDeformAttnFusedFunction(Function):
             raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {ref.shape[-1]} instead.")
         sh, _ = MSDA._host_mirror(spatial_shapes, level_start_index)
         lib = _lib.load()
-        loc = torch.empty((N, Lq, M, L, P, 2), dtype=qproj.dtype, device=qproj.device)
-        aw = torch.empty((N, Lq, M, L, P), dtype=qproj.dtype, device=qproj.device)
+        loc = torch.empty((N, Lq, M, L, P, 2), dtype=work, device=qproj.device)
+        aw = torch.empty((N, Lq, M, L, P), dtype=work, device=qproj.device)
         stride, esz = qproj.shape[-1], qproj.element_size()
         with torch.cuda.device(qproj.device):
             _lib.check(getattr(lib, "msda_prep_forward_" + _SFX[qproj.dtype])(

@@ -66,14 +66,9 @@ class DeformableTransformerEncoderLayer(nn.Module):
         return self.norm2(src + self.dropout3(src2))
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, key_padding_mask=None):
-        if src.dtype == torch.bfloat16:
-            # the operator's bf16 entry points take bf16 value / output with fp32 locations and weights: the attention module runs
-            # its projections in fp32 on the bf16 activations (new capability: the reference has no half path)
-            q = self.with_pos_embed(src, pos).float()
-            src2 = self.self_attn(q, reference_points.float(), src.float(), spatial_shapes, level_start_index, key_padding_mask)
-            src = self.norm1((src.float() + self.dropout1(src2))).to(torch.bfloat16)
-        else:
-            src2 = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes, level_start_index,
-                                  key_padding_mask)
-            src = self.norm1(src + self.dropout1(src2))
+        # (bfloat16 activations: the attention module runs its projections as bf16 GEMMs and the operator's bf16 entry points, with
+        # fp32 locations / weights -- new capability: the reference has no half path; the LayerNorms compute in fp32 internally)
+        src2 = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes, level_start_index, key_padding_mask)
+        src = F.layer_norm(src + self.dropout1(src2), (src.shape[-1],), self.norm1.weight.to(src.dtype), self.norm1.bias.to(src.dtype),
+                           self.norm1.eps)
         return self.forward_ffn(src)

@@ -74,21 +74,28 @@ class MSDeformAttn(nn.Module):
         H, L, P = self.n_heads, self.n_levels, self.n_points
         assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == S
 
-        if self.fused and query.is_cuda and query.dtype in (torch.float32, torch.float64) and L * P <= 64 and L <= 16:
+        if (self.fused and query.is_cuda and query.dtype in (torch.float32, torch.float64, torch.bfloat16) and L * P <= 64
+                and L <= 16):
             if reference_points.shape[-1] not in (2, 4):
                 raise ValueError(
                     f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
-            value = self.value_proj(input_flatten)
+            # bfloat16 activations (new capability: the reference has no half path): the four projections run as bf16 GEMMs on the
+            # module's (fp32) parameters cast per call, value / output travel as bf16 through the operator's bf16 entry points,
+            # locations and attention weights are formed and kept in fp32
+            dt = query.dtype
+            cast = (lambda p: p.to(dt)) if dt == torch.bfloat16 else (lambda p: p)
+            value = F.linear(input_flatten.to(dt), cast(self.value_proj.weight), cast(self.value_proj.bias))
             if input_padding_mask is not None:
                 value = MaskRows.apply(value, input_padding_mask)
             # offsets and attention logits from ONE projection (the two weight matrices stacked: 256 -> 384 for RichSem)
             weight = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
             bias = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
-            qproj = F.linear(query, weight, bias)
+            qproj = F.linear(query, cast(weight), cast(bias))
+            ref_dt = torch.float32 if dt == torch.bfloat16 else dt
             out = MSDeformAttnFusedFunction.apply(value.view(N, S, H, self.d_model // H), input_spatial_shapes,
-                                                  input_level_start_index, qproj, reference_points.to(qproj.dtype), H, L, P,
+                                                  input_level_start_index, qproj, reference_points.to(ref_dt), H, L, P,
                                                   self.im2col_step)
-            return self.output_proj(out)
+            return F.linear(out, cast(self.output_proj.weight), cast(self.output_proj.bias))
 
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:

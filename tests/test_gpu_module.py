@@ -187,3 +187,43 @@ def test_decoder_layer_fp64_equals_the_reference_sequence():
     want = F.layer_norm(t + F.linear(h, layer.linear2.weight, layer.linear2.bias), (256,), layer.norm3.weight, layer.norm3.bias)
     assert out.shape == (nq, bs, 256)
     assert rel(out, want.detach().cpu().numpy()) < 1e-12
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+def test_module_bf16_path_close_to_fp32(ref_dim):
+    """bf16 activations through the fused path (bf16 GEMMs, msda_prep_*_bf16, the operator's bf16 entry points) against the
+    same module in fp32: outputs and gradients agree at bf16 level."""
+    from richsem_amd import workload as W
+    torch.manual_seed(5)
+    call = W.shrunk(W.call_E(2) if ref_dim == 2 else W.call_Dd(2), 4)
+    shapes, lsi = W.level_tensors(call, "cuda")
+    C = 256
+    mod = MSDeformAttn(C, call.L, call.M, call.P).cuda()
+    with torch.no_grad():
+        mod.sampling_offsets.weight.normal_(0, 0.02)
+        mod.attention_weights.weight.normal_(0, 0.1)
+    query, src = torch.randn(call.N, call.Lq, C, device="cuda"), torch.randn(call.N, call.S, C, device="cuda")
+    if ref_dim == 2:
+        ref = torch.rand(call.N, call.Lq, call.L, 2, device="cuda") * 0.8 + 0.1
+    else:
+        ref = torch.cat([torch.rand(call.N, call.Lq, call.L, 2, device="cuda") * 0.6 + 0.2,
+                         torch.rand(call.N, call.Lq, call.L, 2, device="cuda") * 0.2 + 0.05], -1)
+    mask = torch.zeros(call.N, call.S, dtype=torch.bool, device="cuda")
+    mask[:, -7:] = True
+    grad = torch.randn(call.N, call.Lq, C, device="cuda")
+
+    def run(dt):
+        q, s = query.detach().clone().to(dt).requires_grad_(True), src.detach().clone().to(dt).requires_grad_(True)
+        r = ref.detach().clone().requires_grad_(True)
+        out = mod(q, r, s, shapes, lsi, mask)
+        out.backward(grad.to(dt))
+        g = {n: p.grad.clone() for n, p in mod.named_parameters()}
+        mod.zero_grad()
+        return out.float(), q.grad.float(), s.grad.float(), r.grad.float(), g
+
+    o32, q32, s32, r32, g32 = run(torch.float32)
+    o16, q16, s16, r16, g16 = run(torch.bfloat16)
+    close = lambda a, b, tol: float((a - b).abs().mean()) <= tol * (float(b.abs().mean()) + 1e-12)
+    assert close(o16, o32, 2e-2) and close(q16, q32, 5e-2) and close(s16, s32, 3e-2) and close(r16, r32, 8e-2)
+    for n in g32:
+        assert close(g16[n].float(), g32[n], 8e-2), n

@@ -27,12 +27,13 @@ def main():
         mask = torch.zeros(call.N, call.S, dtype=torch.bool, device="cuda")
         mask.view(-1)[::122] = True
         gout = torch.randn(call.N, call.Lq, 256, device="cuda")
-        for fused in (False, True):
+        for fused, dt in ((False, torch.float32), (True, torch.float32), (True, torch.bfloat16)):
             mod.fused = fused
+            q, s_, go = (query.detach().to(dt).requires_grad_(True), src.detach().to(dt).requires_grad_(True), gout.to(dt))
 
             def step():
-                out = mod(query, ref, src, shapes, lsi, mask)
-                out.backward(gout)
+                out = mod(q, ref, s_, shapes, lsi, mask)
+                out.backward(go)
             for _ in range(5):
                 step()
             torch.cuda.synchronize()
@@ -42,8 +43,8 @@ def main():
                 step()
             b.record()
             torch.cuda.synchronize()
-            print(f"{name}: module forward+backward, {'fused   ' if fused else 'op-by-op'}: {a.elapsed_time(b) / 20 * 1e3:8.1f} us", flush=True)
-
+            label = ("fused   " if fused else "op-by-op") + (" bf16" if dt == torch.bfloat16 else " fp32")
+            print(f"{name}: module forward+backward, {label}: {a.elapsed_time(b) / 20 * 1e3:8.1f} us", flush=True)
 
 if __name__ == "__main__":
     main()
