@@ -257,6 +257,17 @@ int msda_mask_rows_f32(float *x, const uint8_t *mask, int64_t rows, int row_elem
 int msda_mask_rows_f64(double *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);
 int msda_mask_rows_bf16(uint16_t *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);
 
+/* ---- integer part of the contrastive-denoising set-up (reference
+ * models/richsem/dn_components.py:42-71, 131-179): bit-exact int64 / bool results ---------------------------------
+ * msda_dn_indices_i64: cum = exclusive prefix of the per-image box counts (batch + 1 int64 on the device), total = cum[batch],
+ *   groups2 = 2 * dn_number.  Writes total * groups2 entries: known_bid[i] = image of box i % total,
+ *   map_known_indice[i] = index of that box inside its image + single_pad * (i / total).
+ * msda_dn_attn_mask_u8: (tgt_size x tgt_size) bytes, 1 = masked: columns < pad_size are hidden from rows >= pad_size, and
+ *   from rows of another denoising group (group = index / group_pad). */
+int msda_dn_indices_i64(const int64_t *cum, int batch, int64_t total, int groups2, int64_t single_pad, int64_t *known_bid,
+                        int64_t *map_known_indice, msda_stream_t stream);
+int msda_dn_attn_mask_u8(uint8_t *mask, int64_t tgt_size, int64_t pad_size, int64_t group_pad, msda_stream_t stream);
+
 /* ---- feed-forward block of the transformer layers on the matrix cores ----------
  *     out = LayerNorm(x + W2 . relu(W1 . x + b1) + b2)
  * reference: models/richsem/deformable_transformer.py:862-866 (encoder forward_ffn), :940-944 (decoder forward_ffn), with

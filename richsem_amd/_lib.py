@@ -27,6 +27,7 @@ SYMBOLS = [
     "msda_prep_forward_f32", "msda_prep_forward_f64", "msda_prep_backward_f32", "msda_prep_backward_f64",
     "msda_prep_forward_bf16", "msda_prep_backward_bf16",
     "msda_mask_rows_f32", "msda_mask_rows_f64", "msda_mask_rows_bf16",
+    "msda_dn_indices_i64", "msda_dn_attn_mask_u8",
     "msda_ffn_pack_w2_bf16", "msda_ffn_forward_bf16", "msda_ffn_debug_stamps",
 ]
 
@@ -73,6 +74,11 @@ def load():
     L.msda_profile_enable.restype = ci
     L.msda_profile_collect.argtypes = [ctypes.POINTER(ProfileRecord), ci, ctypes.POINTER(ci)]
     L.msda_profile_collect.restype = ci
+    i64 = ctypes.c_int64
+    L.msda_dn_indices_i64.argtypes = [vp, ci, i64, ci, i64, vp, vp, vp]
+    L.msda_dn_indices_i64.restype = ci
+    L.msda_dn_attn_mask_u8.argtypes = [vp, i64, i64, i64, vp]
+    L.msda_dn_attn_mask_u8.restype = ci
     L.msda_ffn_debug_stamps.argtypes = [vp]
     L.msda_ffn_debug_stamps.restype = ci
     L.msda_ffn_pack_w2_bf16.argtypes = [vp, ci, ci, vp, vp]

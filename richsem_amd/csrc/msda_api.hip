@@ -18,6 +18,7 @@
 #include "msda_direct.h"
 #include "msda_levelsum.h"
 #include "msda_prep.h"
+#include "msda_dn.h"
 #include "msda_psb.h"
 #include "msda_rps.h"
 #include "msda_tiled.h"
@@ -1305,6 +1306,37 @@ int msda_prep_backward_bf16(const float *grad_loc, const float *grad_aw, const f
     return prep_backward_impl<float, msda::bf16_t>(grad_loc, grad_aw, aw, reinterpret_cast<const msda::bf16_t *>(offsets), off_stride, ref,
                                                    ref_dim, shapes_host, N, Lq, M, L, P, reinterpret_cast<msda::bf16_t *>(grad_offsets),
                                                    goff_stride, reinterpret_cast<msda::bf16_t *>(grad_logits), glog_stride, grad_ref, stream);
+}
+
+int msda_dn_indices_i64(const int64_t *cum, int batch, int64_t total, int groups2, int64_t single_pad, int64_t *known_bid,
+                        int64_t *map_known_indice, msda_stream_t stream)
+{
+    g_err[0] = 0;
+    if (!cum || !known_bid || !map_known_indice) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    if (batch < 1 || total < 0 || groups2 < 0 || single_pad < 0) return fail(MSDA_ERR_BAD_DIMS, "bad denoising dimensions");
+    const int64_t n = total * groups2;
+    if (n == 0) return MSDA_OK;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(msda::dn_indices_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), cum, batch, total, n, single_pad,
+                       known_bid, map_known_indice);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch of the denoising index kernel");
+    return MSDA_OK;
+}
+
+int msda_dn_attn_mask_u8(uint8_t *mask, int64_t tgt_size, int64_t pad_size, int64_t group_pad, msda_stream_t stream)
+{
+    g_err[0] = 0;
+    if (!mask) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    if (tgt_size < 0 || pad_size < 0 || pad_size > tgt_size || group_pad < 0) return fail(MSDA_ERR_BAD_DIMS, "bad mask dimensions");
+    if (tgt_size == 0) return MSDA_OK;
+    const int64_t n = tgt_size * tgt_size;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(msda::dn_attn_mask_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), mask, tgt_size, pad_size,
+                       group_pad);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch of the denoising mask kernel");
+    return MSDA_OK;
 }
 
 int msda_mask_rows_f32(float *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream)

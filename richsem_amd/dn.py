@@ -1,0 +1,67 @@
+"""Host-side mirror of the integer part of the reference's ``prepare_for_cdn`` (models/richsem/dn_components.py:11-193): the
+denoising-group arithmetic on the host (plain Python ints, as the reference) and the index / mask tensors on the device
+(kernels richsem_amd/csrc/msda_dn.h, C ABI ``msda_dn_indices_i64`` / ``msda_dn_attn_mask_u8``).  SURVEY.md section 8 row a12:
+int64 / bool work, bit-exact.  The noisy labels / boxes and the embeddings around it stay with the caller (they are random
+floating-point work, not part of this row).
+"""
+import torch
+
+from . import _lib
+
+
+def dn_group_count(dn_number, known_num, add_gt=False):
+    """dn_components.py:27-41: denoising groups from the configured dn_number and the per-image ground-truth counts."""
+    dn_number = dn_number * 2
+    mx = int(max(known_num)) if len(known_num) else 0
+    if mx == 0:
+        dn_number = 1
+    elif dn_number >= 100:
+        dn_number = dn_number // (mx * 2)
+    elif dn_number < 1:
+        dn_number = 1
+    if dn_number == 0:
+        dn_number = 1
+    if add_gt:
+        dn_number += 1
+    return dn_number
+
+
+def prepare_dn_layout(known_num, dn_number, num_queries, use_cdn=True, add_gt=False, device="cuda"):
+    """known_num: ground-truth boxes per image; dn_number as configured (before the reference's scaling).  Returns a dict with
+    the reference's names: ``known_bid``, ``map_known_indice`` (int64), ``attn_mask`` (bool (tgt, tgt)), ``positive_idx`` /
+    ``negative_idx`` (int64), ``pad_size``, ``num_dn_group``, ``single_pad``, ``group_pad``."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("Not implemented on the CPU")
+    known_num = [int(k) for k in known_num]
+    batch = len(known_num)
+    groups = dn_group_count(dn_number, known_num, add_gt)
+    total = sum(known_num)
+    single_pad = int(max(known_num)) if batch else 0
+    pad_size = single_pad * 2 * groups
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    cum = torch.tensor([0] + list(torch.tensor(known_num, dtype=torch.int64).cumsum(0).tolist()) if batch else [0], dtype=torch.int64,
+                       device=dev)
+    n = total * 2 * groups
+    known_bid = torch.empty(n, dtype=torch.int64, device=dev)
+    map_known_indice = torch.empty(n, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        if batch and n:
+            _lib.check(lib.msda_dn_indices_i64(cum.data_ptr(), batch, total, 2 * groups, single_pad, known_bid.data_ptr(),
+                                               map_known_indice.data_ptr(), stream))
+        # dn_components.py:58-61: positive_idx = arange(total) + 2 * total * group, negative_idx = positive_idx + total
+        grp = torch.arange(groups, dtype=torch.int64, device=dev)[:, None]
+        positive_idx = (torch.arange(total, dtype=torch.int64, device=dev)[None, :] + grp * (total * 2)).flatten()
+        negative_idx = positive_idx + total
+        if use_cdn:
+            group_pad = single_pad * 2
+        else:   # dn_components.py:144-151: the negative halves are dropped
+            pad_size = pad_size // 2
+            group_pad = single_pad
+        tgt = pad_size + num_queries
+        mask = torch.empty((tgt, tgt), dtype=torch.uint8, device=dev)
+        _lib.check(lib.msda_dn_attn_mask_u8(mask.data_ptr(), tgt, pad_size, group_pad, stream))
+    return {"known_bid": known_bid, "map_known_indice": map_known_indice, "attn_mask": mask.view(torch.bool),
+            "positive_idx": positive_idx, "negative_idx": negative_idx, "pad_size": pad_size, "num_dn_group": groups,
+            "single_pad": single_pad, "group_pad": group_pad}

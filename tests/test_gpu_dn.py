@@ -1,0 +1,64 @@
+"""GPU (-m gpu): the integer part of the denoising set-up (reference dn_components.py:27-61,
+131-179) -- device tensors of richsem_amd/dn.py against the numpy restatement oracle/dn_oracle.py, BIT-EXACT (int64 / bool).
+(The oracle is a restatement of the source text only: parity unpinned, see its header.)"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dn_oracle
+from richsem_amd import _lib
+from richsem_amd.dn import dn_group_count, prepare_dn_layout
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ([12, 12], 100, 900, True),          # the bench's synthetic batch: 12 boxes per image
+    ([3, 0, 7, 1], 100, 900, True),      # ragged, an image without boxes
+    ([1], 100, 300, True),
+    ([5, 9], 100, 900, False),           # use_cdn = False: negative halves dropped
+    ([40, 13, 27], 100, 900, True),      # many boxes: few groups
+    ([2, 2], 3, 50, True),               # small dn_number (not rescaled)
+    ([60, 60], 100, 100, True),          # dn_number // (2 * max) == 0 -> 1 group
+    ([0, 0], 100, 10, True),             # no boxes at all: one (empty) group
+]
+
+
+@pytest.mark.parametrize("known_num,dn_number,num_queries,use_cdn", CASES)
+def test_layout_is_bit_exact(known_num, dn_number, num_queries, use_cdn):
+    want = dn_oracle.prepare_for_cdn_indices(known_num, dn_number, num_queries, use_cdn)
+    got = prepare_dn_layout(known_num, dn_number, num_queries, use_cdn)
+    for k in ("pad_size", "num_dn_group", "single_pad", "group_pad"):
+        assert got[k] == want[k], k
+    for k in ("known_bid", "map_known_indice", "positive_idx", "negative_idx"):
+        a = got[k].cpu().numpy()
+        assert a.dtype == np.int64 and a.shape == want[k].shape and np.array_equal(a, want[k]), k
+    m = got["attn_mask"]
+    assert m.dtype == torch.bool and np.array_equal(m.cpu().numpy(), want["attn_mask"])
+
+
+def test_add_gt_and_group_count_follow_the_reference_arithmetic():
+    for known, dn, add_gt in (([12, 12], 100, True), ([7], 100, False), ([0], 100, False), ([3], 0, False), ([200], 100, False)):
+        want = dn_oracle.prepare_for_cdn_indices(known, dn, 10, True, add_gt)["num_dn_group"]
+        assert dn_group_count(dn, known, add_gt) == want
+    got = prepare_dn_layout([4, 2], 100, 20, True, add_gt=True)
+    want = dn_oracle.prepare_for_cdn_indices([4, 2], 100, 20, True, add_gt=True)
+    assert np.array_equal(got["attn_mask"].cpu().numpy(), want["attn_mask"])
+    assert np.array_equal(got["map_known_indice"].cpu().numpy(), want["map_known_indice"])
+
+
+def test_scatter_through_the_indices_reproduces_the_padded_layout():
+    """dn_components.py:140-142: input_query[(known_bid, map_known_indice)] = values -- every (image, slot) pair is hit once"""
+    got = prepare_dn_layout([3, 5], 100, 30, True)
+    bid, slot = got["known_bid"], got["map_known_indice"]
+    pairs = torch.stack([bid, slot], 1)
+    assert pairs.unique(dim=0).shape[0] == pairs.shape[0]
+    assert int(slot.max()) < got["pad_size"] and int(bid.max()) == 1
+
+
+def test_bad_arguments():
+    lib = _lib.load()
+    m = torch.empty(16, dtype=torch.uint8, device="cuda")
+    assert lib.msda_dn_attn_mask_u8(m.data_ptr(), 4, 5, 1, None) == -2     # pad_size > tgt_size
+    assert lib.msda_dn_attn_mask_u8(None, 4, 2, 1, None) == -1
+    with pytest.raises(RuntimeError):
+        prepare_dn_layout([1], 100, 10, device="cpu")

@@ -160,3 +160,22 @@ def test_levelsum_plan_hands_over_all_levels_of_decoder_calls():
     odd = W.Call("odd", 1, 2, 30, 2, [(91, 70), (5, 5)], 500, False)
     p = plan(odd)
     assert p["levels_mask"] == 0b11 and p["windows"] == 3 and p["max_rows"] == 46 and p["slices"] == 8
+
+
+def test_dn_group_count_matches_the_restated_reference_arithmetic():
+    """richsem_amd/dn.py (host ints) against oracle/dn_oracle.py for the denoising-group arithmetic (dn_components.py:27-41),
+    and the oracle's mask against the properties the reference's comments state."""
+    from oracle import dn_oracle
+    from richsem_amd.dn import dn_group_count
+    for known in ([12, 12], [3, 0, 7], [0, 0], [1], [250, 3]):
+        for dn in (0, 1, 3, 99, 100, 101, 1000):
+            for add_gt in (False, True):
+                want = dn_oracle.prepare_for_cdn_indices(known, dn, 5, True, add_gt)["num_dn_group"]
+                assert dn_group_count(dn, known, add_gt) == want
+    o = dn_oracle.prepare_for_cdn_indices([3, 2], 100, 7, True)
+    m, pad, gp = o["attn_mask"], o["pad_size"], o["group_pad"]
+    assert m.shape == (pad + 7, pad + 7)
+    assert m[pad:, :pad].all() and not m[:, pad:].any()              # match queries cannot see the denoising part; everyone sees the matching part
+    for i in range(pad):
+        for j in range(pad):
+            assert m[i, j] == (i // gp != j // gp)                   # denoising groups cannot see each other
