@@ -268,6 +268,11 @@ int msda_dn_indices_i64(const int64_t *cum, int batch, int64_t total, int groups
                         int64_t *map_known_indice, msda_stream_t stream);
 int msda_dn_attn_mask_u8(uint8_t *mask, int64_t tgt_size, int64_t pad_size, int64_t group_pad, msda_stream_t stream);
 
+/* Top-k query selection (reference models/richsem/deformable_transformer.py:370-372: torch.topk(scores, k, dim=1)[1]): for every
+ * row of `scores` (rows x n, float32) the indices -- and, if `values` is non-NULL, the scores -- of its k largest elements in
+ * descending order; equal scores lowest index first.  n <= 36864, k <= 1024 (one workgroup holds a row in LDS). */
+int msda_topk_f32(const float *scores, int rows, int n, int k, int64_t *indices, float *values, msda_stream_t stream);
+
 /* ---- feed-forward block of the transformer layers on the matrix cores ----------
  *     out = LayerNorm(x + W2 . relu(W1 . x + b1) + b2)
  * reference: models/richsem/deformable_transformer.py:862-866 (encoder forward_ffn), :940-944 (decoder forward_ffn), with

@@ -19,6 +19,7 @@
 #include "msda_levelsum.h"
 #include "msda_prep.h"
 #include "msda_dn.h"
+#include "msda_topk.h"
 #include "msda_psb.h"
 #include "msda_rps.h"
 #include "msda_tiled.h"
@@ -1336,6 +1337,23 @@ int msda_dn_attn_mask_u8(uint8_t *mask, int64_t tgt_size, int64_t pad_size, int6
                        group_pad);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch of the denoising mask kernel");
+    return MSDA_OK;
+}
+
+int msda_topk_f32(const float *scores, int rows, int n, int k, int64_t *indices, float *values, msda_stream_t stream)
+{
+    g_err[0] = 0;
+    if (!scores || !indices) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    if (rows < 0 || n < 1 || k < 1 || k > n || k > msda::kTopkMaxK || n > msda::kTopkMaxN)
+        return fail(MSDA_ERR_BAD_DIMS, "top-k: 1 <= k <= min(n, %d), n <= %d (got n=%d, k=%d)", msda::kTopkMaxK, msda::kTopkMaxN, n, k);
+    if (rows == 0) return MSDA_OK;
+    const size_t lds = msda::topk_lds_bytes(n);
+    hipError_t e = msda::set_lds_limit(reinterpret_cast<const void *>(msda::topk_rows_kernel), lds);
+    if (e != hipSuccess) return hip_fail(e, "LDS limit of the top-k kernel");
+    hipLaunchKernelGGL(msda::topk_rows_kernel, dim3(rows), dim3(msda::kTopkThreads), lds, static_cast<hipStream_t>(stream), scores, n, k,
+                       indices, values);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch of the top-k kernel");
     return MSDA_OK;
 }
 

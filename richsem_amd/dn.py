@@ -65,3 +65,23 @@ def prepare_dn_layout(known_num, dn_number, num_queries, use_cdn=True, add_gt=Fa
     return {"known_bid": known_bid, "map_known_indice": map_known_indice, "attn_mask": mask.view(torch.bool),
             "positive_idx": positive_idx, "negative_idx": negative_idx, "pad_size": pad_size, "num_dn_group": groups,
             "single_pad": single_pad, "group_pad": group_pad}
+
+
+def topk_indices(scores, k, return_values=False):
+    """``torch.topk(scores, k, dim=1)[1]`` for a (rows, n) float32 tensor on the GPU (deformable_transformer.py:370-372: the 900
+    encoder proposals with the largest class score), one workgroup per row: indices in descending order of the score, equal scores
+    lowest index first.  Rows too long for the kernel (n > 36864) or k > 1024 go to ``torch.topk``."""
+    if not scores.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
+    assert scores.dim() == 2 and scores.dtype == torch.float32
+    rows, n = scores.shape
+    if n > 36864 or k > 1024:
+        v, i = torch.topk(scores, k, dim=1)
+        return (i, v) if return_values else i
+    s = scores.contiguous()
+    idx = torch.empty((rows, k), dtype=torch.int64, device=s.device)
+    val = torch.empty((rows, k), dtype=torch.float32, device=s.device) if return_values else None
+    with torch.cuda.device(s.device):
+        _lib.check(_lib.load().msda_topk_f32(s.data_ptr(), rows, n, k, idx.data_ptr(), val.data_ptr() if val is not None else None,
+                                             torch.cuda.current_stream(s.device).cuda_stream))
+    return (idx, val) if return_values else idx

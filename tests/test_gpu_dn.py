@@ -62,3 +62,44 @@ def test_bad_arguments():
     assert lib.msda_dn_attn_mask_u8(None, 4, 2, 1, None) == -1
     with pytest.raises(RuntimeError):
         prepare_dn_layout([1], 100, 10, device="cpu")
+
+
+# ---- top-k query selection (deformable_transformer.py:370-372) ---------------------------------------------------------------
+from richsem_amd.dn import topk_indices   # noqa: E402
+
+
+@pytest.mark.parametrize("rows,n,k", [(2, 22323, 900), (2, 34000, 900), (1, 1, 1), (3, 1000, 1000), (4, 5000, 1), (2, 36864, 1024),
+                                      (5, 777, 300)])
+def test_topk_equals_torch_topk_on_distinct_scores(rows, n, k):
+    g = torch.Generator(device="cuda").manual_seed(rows * 1000 + k)
+    # pairwise different scores per row (torch.topk leaves the order of equal scores open): a random permutation of a grid
+    scores = torch.stack([torch.randperm(n, device="cuda", generator=g).float() for _ in range(rows)]) * (8.0 / n) - 4.0
+    assert all(scores[r].unique().numel() == n for r in range(rows))
+    idx, val = topk_indices(scores, k, return_values=True)
+    tv, ti = torch.topk(scores, k, dim=1)
+    assert idx.dtype == torch.int64 and torch.equal(idx, ti) and torch.equal(val, tv)
+
+
+def test_topk_with_ties_infinities_and_negative_zero():
+    scores = torch.zeros(2, 3000, device="cuda")
+    scores[0, 100:160] = 5.0                      # 60 equal maxima, then zeros (+0.0 and -0.0 are different keys: -0.0 sorts below)
+    scores[0, 7] = float("inf")
+    scores[0, 9] = -float("inf")
+    scores[1] = torch.arange(3000, device="cuda").float().remainder(7)   # heavy ties
+    idx, val = topk_indices(scores, 64, return_values=True)
+    tv, _ = torch.topk(scores, 64, dim=1)
+    assert torch.equal(val, tv)                                           # same multiset of scores, descending
+    assert idx[0, 0] == 7 and torch.equal(idx[0, 1:61], torch.arange(100, 160, device="cuda"))
+    assert torch.equal(idx[0, 61:64], torch.tensor([0, 1, 2], device="cuda"))          # ties: lowest index first
+    exp = torch.cat([torch.arange(6, 3000, 7)[:64]]).cuda()
+    assert torch.equal(idx[1], exp[:64])
+    assert all(idx[r].unique().numel() == 64 for r in range(2))
+
+
+def test_topk_bad_arguments_and_fallback():
+    lib = _lib.load()
+    s = torch.zeros(1, 10, device="cuda")
+    i = torch.empty(1, 20, dtype=torch.int64, device="cuda")
+    assert lib.msda_topk_f32(s.data_ptr(), 1, 10, 11, i.data_ptr(), None, None) == -2
+    big = torch.randn(1, 40000, device="cuda")
+    assert torch.equal(topk_indices(big, 5), torch.topk(big, 5, dim=1)[1])          # too long for the kernel: torch.topk
