@@ -273,6 +273,17 @@ int msda_dn_attn_mask_u8(uint8_t *mask, int64_t tgt_size, int64_t pad_size, int6
  * descending order; equal scores lowest index first.  n <= 36864, k <= 1024 (one workgroup holds a row in LDS). */
 int msda_topk_f32(const float *scores, int rows, int n, int k, int64_t *indices, float *values, msda_stream_t stream);
 
+/* ROIAlign forward (reference models/richsem/richsem.py:750, :878:
+ * detectron2.layers.ROIAlign(output_size, spatial_scale, sampling_ratio = 0, aligned = True) on the frozen CLIP feature map).
+ * input (N, C, H, W) contiguous; rois (K, 5) = (batch index, x1, y1, x2, y2) in input pixels; output (K, C, pooled_h, pooled_w).
+ * detectron2's published algorithm (= torchvision.ops.roi_align); no gradient (the teacher is frozen). */
+int msda_roi_align_forward_f32(const float *input, const float *rois, int K, int N, int C, int H, int W, int pooled_h,
+                               int pooled_w, double spatial_scale, int sampling_ratio, int aligned, float *output,
+                               msda_stream_t stream);
+int msda_roi_align_forward_f64(const double *input, const double *rois, int K, int N, int C, int H, int W, int pooled_h,
+                               int pooled_w, double spatial_scale, int sampling_ratio, int aligned, double *output,
+                               msda_stream_t stream);
+
 /* ---- feed-forward block of the transformer layers on the matrix cores ----------
  *     out = LayerNorm(x + W2 . relu(W1 . x + b1) + b2)
  * reference: models/richsem/deformable_transformer.py:862-866 (encoder forward_ffn), :940-944 (decoder forward_ffn), with

@@ -27,7 +27,7 @@ SYMBOLS = [
     "msda_prep_forward_f32", "msda_prep_forward_f64", "msda_prep_backward_f32", "msda_prep_backward_f64",
     "msda_prep_forward_bf16", "msda_prep_backward_bf16",
     "msda_mask_rows_f32", "msda_mask_rows_f64", "msda_mask_rows_bf16",
-    "msda_dn_indices_i64", "msda_dn_attn_mask_u8", "msda_topk_f32",
+    "msda_dn_indices_i64", "msda_dn_attn_mask_u8", "msda_topk_f32", "msda_roi_align_forward_f32", "msda_roi_align_forward_f64",
     "msda_ffn_pack_w2_bf16", "msda_ffn_forward_bf16", "msda_ffn_debug_stamps",
 ]
 
@@ -81,6 +81,10 @@ def load():
     L.msda_dn_attn_mask_u8.restype = ci
     L.msda_topk_f32.argtypes = [vp, ci, ci, ci, vp, vp, vp]
     L.msda_topk_f32.restype = ci
+    for sfx in ("f32", "f64"):
+        f = getattr(L, "msda_roi_align_forward_" + sfx)
+        f.argtypes = [vp, vp] + [ci] * 7 + [ctypes.c_double, ci, ci, vp, vp]
+        f.restype = ci
     L.msda_ffn_debug_stamps.argtypes = [vp]
     L.msda_ffn_debug_stamps.restype = ci
     L.msda_ffn_pack_w2_bf16.argtypes = [vp, ci, ci, vp, vp]

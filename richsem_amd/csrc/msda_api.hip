@@ -20,6 +20,7 @@
 #include "msda_prep.h"
 #include "msda_dn.h"
 #include "msda_topk.h"
+#include "msda_roi.h"
 #include "msda_psb.h"
 #include "msda_rps.h"
 #include "msda_tiled.h"
@@ -987,6 +988,25 @@ int prep_geom(msda::PrepGeom &g, int N, int Lq, int M, int L, int P, int ref_dim
     return MSDA_OK;
 }
 
+template <typename T>
+int roi_align_impl(const T *input, const T *rois, int K, int N, int C, int H, int W, int PH, int PW, double spatial_scale,
+                   int sampling_ratio, int aligned, T *output, msda_stream_t stream)
+{
+    g_err[0] = 0;
+    if (!input || !rois || !output) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    if (K < 0 || N < 1 || C < 1 || H < 1 || W < 1 || PH < 1 || PW < 1 || sampling_ratio < 0 || !(spatial_scale > 0))
+        return fail(MSDA_ERR_BAD_DIMS, "bad ROIAlign dimensions");
+    const int64_t n_out = (int64_t)K * C * PH * PW;
+    if (n_out == 0) return MSDA_OK;
+    if ((int64_t)N * C * H * W >= ((int64_t)1 << 40)) return fail(MSDA_ERR_TOO_LARGE, "input too large");
+    const int grid = (int)std::min<int64_t>((n_out + 255) / 256, 65536);
+    hipLaunchKernelGGL(msda::roi_align_fwd_kernel<T>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), input, rois, n_out, N, C,
+                       H, W, PH, PW, (T)spatial_scale, sampling_ratio, aligned, output);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch of the ROIAlign kernel");
+    return MSDA_OK;
+}
+
 template <typename T, typename TP = T>
 int prep_forward_impl(const TP *offsets, int64_t off_stride, const TP *logits, int64_t log_stride, const T *ref, int ref_dim,
                       const int64_t *shapes_host, int N, int Lq, int M, int L, int P, T *loc, T *aw, msda_stream_t stream_)
@@ -1338,6 +1358,17 @@ int msda_dn_attn_mask_u8(uint8_t *mask, int64_t tgt_size, int64_t pad_size, int6
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch of the denoising mask kernel");
     return MSDA_OK;
+}
+
+int msda_roi_align_forward_f32(const float *input, const float *rois, int K, int N, int C, int H, int W, int pooled_h, int pooled_w,
+                               double spatial_scale, int sampling_ratio, int aligned, float *output, msda_stream_t stream)
+{
+    return roi_align_impl<float>(input, rois, K, N, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, output, stream);
+}
+int msda_roi_align_forward_f64(const double *input, const double *rois, int K, int N, int C, int H, int W, int pooled_h, int pooled_w,
+                               double spatial_scale, int sampling_ratio, int aligned, double *output, msda_stream_t stream)
+{
+    return roi_align_impl<double>(input, rois, K, N, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, output, stream);
 }
 
 int msda_topk_f32(const float *scores, int rows, int n, int k, int64_t *indices, float *values, msda_stream_t stream)
