@@ -884,6 +884,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                 }
         }
     }
+    stamp<2>(g, st++);
     if (!BWD) {
         const int chan = sub * GC + 4 * j;
 #pragma unroll
@@ -892,6 +893,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                 st4(out + item[k] * (unsigned)kTD + chan, make_float4(acc_lo[k].x, acc_lo[k].y, acc_hi[k].x, acc_hi[k].y));
     }
     __syncthreads();   // the next item rebuilds the header
+    stamp<2>(g, st++);
     }
     if (g.stats) {   // locality monitor: one atomic per wave (only when the host asked for the count)
         for (int o = kWave / 2; o > 0; o >>= 1) n_general += __shfl_xor(n_general, o, kWave);
