@@ -73,6 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-collective", action="store_true", help="N > 1: leave the gradient all-reduce out")
     ap.add_argument("--no-bf16", action="store_true", help="skip the extra bf16 pass")
     ap.add_argument("--no-ffn", action="store_true", help="skip the feed-forward (MFMA) row beside the path")
+    ap.add_argument("--no-graph", action="store_true", help="skip the graph-replay variant of the step")
     ap.add_argument("--fwd-variant", type=int, default=0)
     ap.add_argument("--bwd-variant", type=int, default=0)
     return ap.parse_args(argv)
@@ -370,6 +371,33 @@ def main(argv=None):
             _lib.profile_enable(0)
         return reduce_elapsed(elapsed, dist), records
 
+    def graph_replay(mode):
+        """The same step captured once into a HIP graph and replayed (what a caller that captures its training step gets: no
+        launch gaps between the ~40 kernels of a step).  Reported beside `value`, never as it; no collective inside.  The library
+        allocates nothing during capture, so the stream is warmed up first; None if capture is not possible here."""
+        try:
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step(mode, False)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                step(mode, False)
+            for _ in range(2):
+                graph.replay()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.steps):
+                graph.replay()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / args.steps
+        except Exception as e:   # noqa: BLE001 -- a diagnostic extra must never take the benchmark line down
+            print(f"[bench] graph replay skipped: {e}", file=sys.stderr)
+            return None
+
     results = {}
     for mode in modes:
         elapsed, records = timed(mode, collective, True)
@@ -377,6 +405,7 @@ def main(argv=None):
         if collective:
             res["elapsed_nc"], _ = timed(mode, False, False)
         results[mode] = res
+    graph_ms = graph_replay(modes[0]) if (world == 1 and not args.no_graph) else None
     if not args.no_bf16:   # the same step with bf16 value / out / grad tensors (library entry points msda_*_bf16), headline distribution
         for c, t, locs in layers:
             t["value_bf16"], t["grad_out_bf16"] = t["value"].to(torch.bfloat16), t["grad_out"].to(torch.bfloat16)
@@ -439,6 +468,9 @@ def main(argv=None):
             line["bf16"] = {"dtype": "bf16 value/out/grad, f32 locations/weights and accumulation", "loc": modes[0],
                             "value": b["value"], "ms_per_step": b["ms_per_step"], "roofline": b["roofline"],
                             "kernels": b["kernels"]}
+        if graph_ms is not None:
+            line["graph_replay"] = {"what": "the same step (no collective) captured into one HIP graph and replayed; not `value`",
+                                    "ms_per_step": round(graph_ms, 4), "img_per_s": round(n_total / (graph_ms * 1e-3), 3)}
         if not args.no_ffn:
             line["mfma_row"] = ffn_row(n_img, dev)
         if world == 1 and not args.no_cpu_baseline:
