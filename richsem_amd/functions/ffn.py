@@ -14,6 +14,12 @@ from torch.autograd.function import once_differentiable
 from .. import _lib
 
 
+# The one-kernel forward walks all d_ffn / 32 weight tiles in every workgroup of 192 tokens: below this many tokens too few
+# CUs are busy and the block as library GEMMs is faster (MI355X: 2200 tokens 97 vs 78 us, 8000 tokens 100 vs 78 us, 44646 tokens
+# 117 vs 290 us).  The modules fall back to the op-by-op sequence below it.
+FUSED_FFN_MIN_TOKENS = 16384
+
+
 def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 

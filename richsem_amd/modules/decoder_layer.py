@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions.ffn import FusedFFNFunction
+from ..functions.ffn import FUSED_FFN_MIN_TOKENS, FusedFFNFunction
 from .ms_deform_attn import MSDeformAttn
 
 
@@ -43,7 +43,8 @@ class DeformableTransformerDecoderLayer(nn.Module):
     def forward_ffn(self, tgt):
         drop = self.training and (self.dropout3.p > 0 or self.dropout4.p > 0)
         if (self.fused_ffn and tgt.is_cuda and tgt.dtype == torch.bfloat16 and self.activation == "relu" and not drop
-                and tgt.shape[-1] == 256 and self.linear1.out_features % 32 == 0 and self.linear1.out_features <= 4096):
+                and tgt.shape[-1] == 256 and self.linear1.out_features % 32 == 0 and self.linear1.out_features <= 4096
+                and tgt.numel() // tgt.shape[-1] >= FUSED_FFN_MIN_TOKENS):
             return FusedFFNFunction.apply(tgt, self.linear1.weight.to(torch.bfloat16), self.linear1.bias.float(),
                                           self.linear2.weight.to(torch.bfloat16), self.linear2.bias.float(),
                                           self.norm3.weight.float(), self.norm3.bias.float(), self.norm3.eps)

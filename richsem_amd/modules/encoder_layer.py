@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions.ffn import FusedFFNFunction
+from ..functions.ffn import FUSED_FFN_MIN_TOKENS, FusedFFNFunction
 from .ms_deform_attn import MSDeformAttn
 
 
@@ -54,7 +54,8 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def _ffn_fusable(self, src):
         drop = self.training and (self.dropout2.p > 0 or self.dropout3.p > 0)
         return (self.fused_ffn and src.is_cuda and src.dtype == torch.bfloat16 and self.activation == "relu" and not drop
-                and src.shape[-1] == 256 and self.linear1.out_features % 32 == 0 and self.linear1.out_features <= 4096)
+                and src.shape[-1] == 256 and self.linear1.out_features % 32 == 0 and self.linear1.out_features <= 4096
+                and src.numel() // src.shape[-1] >= FUSED_FFN_MIN_TOKENS)
 
     def forward_ffn(self, src):
         if self._ffn_fusable(src):

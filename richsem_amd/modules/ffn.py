@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions.ffn import FusedFFNFunction
+from ..functions.ffn import FUSED_FFN_MIN_TOKENS, FusedFFNFunction
 
 
 class FFN(nn.Module):
@@ -28,7 +28,8 @@ class FFN(nn.Module):
     def _can_fuse(self, src):
         drop = self.dropout_p > 0 and self.training
         return (self.fused and src.is_cuda and src.dtype == torch.bfloat16 and self.activation == "relu" and not drop
-                and src.shape[-1] == 256 and self.linear1.out_features % 32 == 0 and self.linear1.out_features <= 4096)
+                and src.shape[-1] == 256 and self.linear1.out_features % 32 == 0 and self.linear1.out_features <= 4096
+                and src.numel() // src.shape[-1] >= FUSED_FFN_MIN_TOKENS)
 
     def forward(self, src):
         if self._can_fuse(src):
