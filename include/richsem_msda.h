@@ -284,6 +284,22 @@ int msda_roi_align_forward_f64(const double *input, const double *rois, int K, i
                                int pooled_w, double spatial_scale, int sampling_ratio, int aligned, double *output,
                                msda_stream_t stream);
 
+/* ---- the Hungarian matcher's cost blocks (reference models/richsem/matcher.py:49-78 with
+ * util/box_ops.py:9-59) --------------------------------------------------------------------------------------------
+ *     C[b][q][t] = w_bbox * |box_q - box_t|_1 + w_class * (focal-style class cost at label_t) + w_giou * (-GIoU(box_q, box_t))
+ * for query q of image b against target t of THE SAME image only (the blocks the reference keeps, matcher.py:76-77), with the
+ * reference's arithmetic in the reference's order.  logits (B, Q, C); boxes (B, Q, 4) cxcywh; tgt_ids (n_targets) int64;
+ * tgt_boxes (n_targets, 4) cxcywh; tgt_offsets (B + 1) int64 ON THE DEVICE = exclusive prefix of the per-image target counts
+ * (tgt_offsets[B] == n_targets).  cost: Q * n_targets elements; image b's (Q x T_b) row-major block starts at element
+ * Q * tgt_offsets[b].  Several decoder outputs are matched by calling this once per output into consecutive slices of one buffer
+ * and copying that buffer to the host once.  A label outside [0, C) gives NaN in its column. */
+int msda_matcher_cost_f32(const float *logits, const float *boxes, const int64_t *tgt_ids, const float *tgt_boxes,
+                          const int64_t *tgt_offsets, int B, int Q, int C, int64_t n_targets, double w_class, double w_bbox,
+                          double w_giou, double alpha, float *cost, msda_stream_t stream);
+int msda_matcher_cost_f64(const double *logits, const double *boxes, const int64_t *tgt_ids, const double *tgt_boxes,
+                          const int64_t *tgt_offsets, int B, int Q, int C, int64_t n_targets, double w_class, double w_bbox,
+                          double w_giou, double alpha, double *cost, msda_stream_t stream);
+
 /* ---- feed-forward block of the transformer layers on the matrix cores ----------
  *     out = LayerNorm(x + W2 . relu(W1 . x + b1) + b2)
  * reference: models/richsem/deformable_transformer.py:862-866 (encoder forward_ffn), :940-944 (decoder forward_ffn), with

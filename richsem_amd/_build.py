@@ -11,13 +11,14 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "librichsem_msda.so")
-SOURCES = ["msda_api.hip", "ffn_mfma.hip"]
+SOURCES = ["msda_api.hip", "ffn_mfma.hip", "rows_api.hip"]
 def _headers():
     """every header the library is built from: csrc/*.h and include/*.h (globbed, so a new kernel header can never be
     forgotten by the staleness check)"""
     import glob
     return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(_PKG, "..", "include", "*.h")))
-HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function"]
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 
 
 def find_hipcc():
@@ -36,13 +37,30 @@ def is_stale():
 
 
 def build(force=False, verbose=False):
-    """Compile the library if it is missing or older than its sources.  Returns its path."""
+    """Compile the library if it is missing or older than its sources.  Returns its path.  Every translation unit is compiled
+    to an object of its own (in parallel; only the stale ones unless `force`), then linked."""
     if not force and not is_stale():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = find_hipcc()
+    newest_header = max(os.path.getmtime(h) for h in _headers() + [os.path.abspath(__file__)])
+
+    def compile_one(src):
+        path, obj = os.path.join(CSRC, src), os.path.join(OBJ_DIR, src + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), newest_header):
+            return obj
+        cmd = [hipcc] + HIPCC_FLAGS + ["-c", "-o", obj, path]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH + ".tmp"] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH

@@ -1,0 +1,178 @@
+"""Hungarian matching with the cost blocks formed on the GPU (criterion plumbing).
+
+Mirror of the reference's ``HungarianMatcher`` (models/richsem/matcher.py:8-78; same constructor, same ``forward(outputs,
+targets)`` result: a list over images of (query indices, target indices) as int64 tensors).  What changes is the plumbing the
+survey names: the reference forms the cost of every query against every target of the whole batch with a dozen element-wise
+kernels, keeps the diagonal blocks only, and brings each matrix to the host with a synchronising ``.cpu()`` -- seven times a step
+(richsem.py:1136, :1204, :1255).  Here one kernel (``msda_matcher_cost_*``, csrc/msda_matcher.h) writes the diagonal blocks only,
+and :func:`match_many` lays the blocks of ALL decoder outputs of a step into one buffer that reaches the host with ONE
+asynchronous copy and ONE event wait.  The assignment itself stays scipy's ``linear_sum_assignment`` on the host, as
+``north_star`` asks (criterion in host Python).
+
+:func:`global_num_boxes` / :class:`AsyncLossLog` remove the two remaining per-step device round trips of the criterion and the
+engine (richsem.py:1143-1147, engine.py:84-91): the box count is known on the host and reduced there, the reduced loss dictionary
+for the log is read one step late.
+"""
+import torch
+from scipy.optimize import linear_sum_assignment
+from torch import nn
+
+from . import _lib
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class CostPlan:
+    """Host-side bookkeeping of one batch of targets: per-image counts, their prefix on host and device, concatenated labels /
+    boxes (matcher.py:55-57)."""
+
+    def __init__(self, targets, device, dtype):
+        self.sizes = [int(v["boxes"].shape[0]) for v in targets]
+        self.offsets = [0]
+        for s in self.sizes:
+            self.offsets.append(self.offsets[-1] + s)
+        self.total = self.offsets[-1]
+        self.offsets_dev = torch.tensor(self.offsets, dtype=torch.int64).to(device, non_blocking=True)
+        if self.total:
+            self.tgt_ids = torch.cat([v["labels"] for v in targets]).to(device=device, dtype=torch.int64).contiguous()
+            self.tgt_boxes = torch.cat([v["boxes"] for v in targets]).to(device=device, dtype=dtype).contiguous()
+        else:
+            self.tgt_ids = torch.zeros(0, dtype=torch.int64, device=device)
+            self.tgt_boxes = torch.zeros(0, 4, dtype=dtype, device=device)
+
+
+def cost_blocks(pred_logits, pred_boxes, plan, cost_class, cost_bbox, cost_giou, focal_alpha, out=None):
+    """Diagonal cost blocks of one decoder output on the device: a flat tensor of nq * plan.total elements, image b's (nq x T_b)
+    block starting at nq * plan.offsets[b].  ``out``: slice of a larger buffer to write into."""
+    if not pred_logits.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
+    dt = pred_logits.dtype
+    if dt not in (torch.float32, torch.float64):
+        raise RuntimeError(f"matcher cost: float32 / float64 logits, got {dt}")
+    bs, nq, C = pred_logits.shape
+    assert pred_boxes.shape == (bs, nq, 4) and len(plan.sizes) == bs
+    logits, boxes = pred_logits.detach().contiguous(), pred_boxes.detach().to(dt).contiguous()
+    n = nq * plan.total
+    if out is None:
+        out = torch.empty(n, dtype=dt, device=logits.device)
+    assert out.numel() == n and out.dtype == dt and out.is_contiguous()
+    if n:
+        fn = getattr(_lib.load(), "msda_matcher_cost_" + ("f32" if dt == torch.float32 else "f64"))
+        with torch.cuda.device(logits.device):
+            _lib.check(fn(logits.data_ptr(), boxes.data_ptr(), plan.tgt_ids.data_ptr(), plan.tgt_boxes.data_ptr(),
+                          plan.offsets_dev.data_ptr(), bs, nq, C, plan.total, float(cost_class), float(cost_bbox), float(cost_giou),
+                          float(focal_alpha), out.data_ptr(), _stream(logits.device)))
+    return out
+
+
+def _assign(host, nq, plan):
+    res = []
+    for b, tb in enumerate(plan.sizes):
+        block = host[nq * plan.offsets[b]: nq * plan.offsets[b + 1]].view(nq, tb)
+        i, j = linear_sum_assignment(block.numpy())
+        res.append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
+    return res
+
+
+class HungarianMatcher(nn.Module):
+    """Same signature and result as the reference's class (matcher.py:8-78)."""
+
+    def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1, focal_alpha=0.25):
+        super().__init__()
+        self.cost_class, self.cost_bbox, self.cost_giou = cost_class, cost_bbox, cost_giou
+        assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
+        self.focal_alpha = focal_alpha
+        self._pinned = None
+
+    def _host_buffer(self, n, dtype):
+        if self._pinned is None or self._pinned.numel() < n or self._pinned.dtype != dtype:
+            self._pinned = torch.empty(max(n, 1), dtype=dtype, pin_memory=True)
+        return self._pinned[:n]
+
+    @torch.no_grad()
+    def match_many(self, outputs_list, targets):
+        """Match several decoder outputs (each a dict with "pred_logits" (bs, nq_o, C) and "pred_boxes" (bs, nq_o, 4)) against the
+        same targets: one cost kernel per output into one device buffer, one copy to the host, one wait.  Returns a list (per
+        output) of the reference's per-image index pairs."""
+        first = outputs_list[0]["pred_logits"]
+        plan = CostPlan(targets, first.device, first.dtype)
+        nqs = [o["pred_logits"].shape[1] for o in outputs_list]
+        total = sum(nq * plan.total for nq in nqs)
+        dev_buf = torch.empty(total, dtype=first.dtype, device=first.device)
+        at = 0
+        for o, nq in zip(outputs_list, nqs):
+            cost_blocks(o["pred_logits"], o["pred_boxes"], plan, self.cost_class, self.cost_bbox, self.cost_giou, self.focal_alpha,
+                        out=dev_buf[at: at + nq * plan.total])
+            at += nq * plan.total
+        host = self._host_buffer(total, first.dtype)
+        host.copy_(dev_buf, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(first.device))
+        done.synchronize()          # the one wait of the step's matching (the reference: one .cpu() per output)
+        res, at = [], 0
+        for nq in nqs:
+            res.append(_assign(host[at: at + nq * plan.total], nq, plan))
+            at += nq * plan.total
+        return res
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        return self.match_many([outputs], targets)[0]
+
+
+def global_num_boxes(indices, world_size=1, group=None):
+    """``num_boxes`` of the criterion (richsem.py:1143-1147: number of matched targets summed over the ranks, divided by the world
+    size, clamped to >= 1) without the device round trip: the count is a host integer already, so it is reduced as a host tensor
+    (a gloo group) -- or not at all on one rank -- instead of a CUDA tensor + ``.item()``."""
+    n = float(sum(len(t[1]) for t in indices))
+    if world_size > 1:
+        import torch.distributed as dist
+        t = torch.tensor([n], dtype=torch.float32)
+        dist.all_reduce(t, group=group)     # `group` must be a CPU (gloo) group: the tensor lives on the host
+        n = float(t.item())
+    return max(n / world_size, 1.0)
+
+
+class AsyncLossLog:
+    """The engine's logging reduction (engine.py:84-91 with util/misc.py:139-164) without its per-step ``.item()``: the loss
+    dictionary is stacked in sorted key order (as reduce_dict does), all-reduced asynchronously, copied to pinned memory, and
+    READ ONE STEP LATE -- ``push`` returns the previous step's reduced dictionary (None on the first call), ``flush`` the last."""
+
+    def __init__(self, world_size=1, group=None, average=True):
+        self.world_size, self.group, self.average = world_size, group, average
+        self._pending = None
+
+    def _finish(self):
+        if self._pending is None:
+            return None
+        names, host, event = self._pending
+        if event is not None:
+            event.synchronize()
+        self._pending = None
+        return {k: float(v) for k, v in zip(names, host.tolist())}
+
+    @torch.no_grad()
+    def push(self, loss_dict):
+        prev = self._finish()
+        names = sorted(loss_dict.keys())
+        values = torch.stack([loss_dict[k].detach().float().reshape(()) for k in names], dim=0)
+        if self.world_size > 1:
+            import torch.distributed as dist
+            # on RCCL the wait below is a stream dependency, not a host block; on a host (gloo) group it blocks, as it must
+            dist.all_reduce(values, group=self.group, async_op=True).wait()
+            if self.average:
+                values = values / self.world_size
+        if values.is_cuda:
+            host = torch.empty(values.shape, dtype=values.dtype, pin_memory=True)
+            host.copy_(values, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record(torch.cuda.current_stream(values.device))
+        else:
+            host, event = values, None
+        self._pending = (names, host, event)
+        return prev
+
+    def flush(self):
+        return self._finish()

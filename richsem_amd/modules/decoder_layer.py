@@ -35,6 +35,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.dropout4 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
         self.fused_ffn = True
+        self.fused_min_tokens = FUSED_FFN_MIN_TOKENS   # below it the op sequence is faster (functions/ffn.py)
 
     @staticmethod
     def with_pos_embed(tensor, pos):
@@ -44,7 +45,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         drop = self.training and (self.dropout3.p > 0 or self.dropout4.p > 0)
         if (self.fused_ffn and tgt.is_cuda and tgt.dtype == torch.bfloat16 and self.activation == "relu" and not drop
                 and tgt.shape[-1] == 256 and self.linear1.out_features % 32 == 0 and self.linear1.out_features <= 4096
-                and tgt.numel() // tgt.shape[-1] >= FUSED_FFN_MIN_TOKENS):
+                and tgt.numel() // tgt.shape[-1] >= self.fused_min_tokens):
             return FusedFFNFunction.apply(tgt, self.linear1.weight.to(torch.bfloat16), self.linear1.bias.float(),
                                           self.linear2.weight.to(torch.bfloat16), self.linear2.bias.float(),
                                           self.norm3.weight.float(), self.norm3.bias.float(), self.norm3.eps)

@@ -46,6 +46,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         self.dropout3 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
         self.fused_ffn = True
+        self.fused_min_tokens = FUSED_FFN_MIN_TOKENS   # below it the op sequence is faster (functions/ffn.py)
 
     @staticmethod
     def with_pos_embed(tensor, pos):
@@ -55,7 +56,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         drop = self.training and (self.dropout2.p > 0 or self.dropout3.p > 0)
         return (self.fused_ffn and src.is_cuda and src.dtype == torch.bfloat16 and self.activation == "relu" and not drop
                 and src.shape[-1] == 256 and self.linear1.out_features % 32 == 0 and self.linear1.out_features <= 4096
-                and src.numel() // src.shape[-1] >= FUSED_FFN_MIN_TOKENS)
+                and src.numel() // src.shape[-1] >= self.fused_min_tokens)
 
     def forward_ffn(self, src):
         if self._ffn_fusable(src):

@@ -24,12 +24,13 @@ class FFN(nn.Module):
         self.dropout_p = dropout
         self.activation = activation
         self.fused = True
+        self.fused_min_tokens = FUSED_FFN_MIN_TOKENS   # below it the op sequence is faster (functions/ffn.py)
 
     def _can_fuse(self, src):
         drop = self.dropout_p > 0 and self.training
         return (self.fused and src.is_cuda and src.dtype == torch.bfloat16 and self.activation == "relu" and not drop
                 and src.shape[-1] == 256 and self.linear1.out_features % 32 == 0 and self.linear1.out_features <= 4096
-                and src.numel() // src.shape[-1] >= FUSED_FFN_MIN_TOKENS)
+                and src.numel() // src.shape[-1] >= self.fused_min_tokens)
 
     def forward(self, src):
         if self._can_fuse(src):

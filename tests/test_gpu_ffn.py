@@ -101,6 +101,9 @@ def test_module_fused_path_equals_op_by_op_path_within_bf16():
     torch.manual_seed(0)
     m = FFN(256, 2048, dropout=0.0).cuda()
     src = torch.randn(2, 700, 256, device="cuda").to(torch.bfloat16)
+    assert not m._can_fuse(src)          # 1400 tokens: below the size from which the one-kernel block pays
+    m.fused_min_tokens = 0
+    assert m._can_fuse(src)
     fused = m(src)
     m.fused = False
     plain = m.to(torch.bfloat16)(src)
