@@ -284,6 +284,19 @@ int msda_roi_align_forward_f64(const double *input, const double *rois, int K, i
                                int pooled_w, double spatial_scale, int sampling_ratio, int aligned, double *output,
                                msda_stream_t stream);
 
+/* ---- attention core of CLIP's AttentionPool2d for its single query token (reference
+ * clip/model.py:58-91, called at models/richsem/richsem.py:753 on the ROIAlign output) -----------------------------------
+ * With one query per head the key / value projections move to the other side of the attention (csrc/msda_attnpool.h): the caller
+ * forms u[k, h, :] = head_dim^-1/2 * Wk_h^T q[k, h, :] with a library GEMM, this kernel computes per (ROI k, head h)
+ *     x_0 = mean_t feat[k, :, t] + pos[0],  x_{t+1} = feat[k, :, t] + pos[t + 1]          (tokens, never materialised)
+ *     a = softmax_t(u[k, h] . x_t),   z[k, h, :] = sum_t a_t x_t
+ * and the caller finishes with Wv_h z[k, h] + bv_h and the output projection.
+ * u, z (K, H, C); feat (K, C, T) as msda_roi_align_forward_* writes it; pos (T + 1, C); T <= 1024. */
+int msda_attnpool_core_f32(const float *u, const float *feat, const float *pos, int K, int H, int C, int T, float *z,
+                           msda_stream_t stream);
+int msda_attnpool_core_f64(const double *u, const double *feat, const double *pos, int K, int H, int C, int T, double *z,
+                           msda_stream_t stream);
+
 /* ---- the Hungarian matcher's cost blocks (reference models/richsem/matcher.py:49-78 with
  * util/box_ops.py:9-59) --------------------------------------------------------------------------------------------
  *     C[b][q][t] = w_bbox * |box_q - box_t|_1 + w_class * (focal-style class cost at label_t) + w_giou * (-GIoU(box_q, box_t))

@@ -29,7 +29,7 @@ SYMBOLS = [
     "msda_mask_rows_f32", "msda_mask_rows_f64", "msda_mask_rows_bf16",
     "msda_dn_indices_i64", "msda_dn_attn_mask_u8", "msda_topk_f32", "msda_roi_align_forward_f32", "msda_roi_align_forward_f64",
     "msda_ffn_pack_w2_bf16", "msda_ffn_forward_bf16", "msda_ffn_debug_stamps",
-    "msda_matcher_cost_f32", "msda_matcher_cost_f64",
+    "msda_matcher_cost_f32", "msda_matcher_cost_f64", "msda_attnpool_core_f32", "msda_attnpool_core_f64",
 ]
 
 
@@ -89,6 +89,10 @@ def load():
     for sfx in ("f32", "f64"):
         f = getattr(L, "msda_matcher_cost_" + sfx)
         f.argtypes = [vp] * 5 + [ci] * 3 + [i64] + [ctypes.c_double] * 4 + [vp, vp]
+        f.restype = ci
+    for sfx in ("f32", "f64"):
+        f = getattr(L, "msda_attnpool_core_" + sfx)
+        f.argtypes = [vp] * 3 + [ci] * 4 + [vp, vp]
         f.restype = ci
     L.msda_ffn_debug_stamps.argtypes = [vp]
     L.msda_ffn_debug_stamps.restype = ci

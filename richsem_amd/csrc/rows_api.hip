@@ -1,5 +1,5 @@
 // rows_api.hip -- C ABI of the rows around the operator that SURVEY.md section 8 marks "next" (declared in
-// include/richsem_msda.h): the matcher's cost blocks (section 8f rank 4).  A translation unit of its own so that the operator's
+// include/richsem_msda.h): the matcher's cost blocks (section 8f rank 4), the attention-pool core (rank 3).  A translation unit of its own so that the operator's
 // kernels (msda_api.hip) are not rebuilt with it.  Error reporting: return codes only (msda_last_error covers msda_api.hip's calls).
 #include <hip/hip_runtime.h>
 
@@ -7,6 +7,7 @@
 #include <cstdint>
 
 #include "../../include/richsem_msda.h"
+#include "msda_attnpool.h"
 #include "msda_matcher.h"
 
 namespace {
@@ -29,9 +30,34 @@ int matcher_cost_impl(const T *logits, const T *boxes, const int64_t *tgt_ids, c
     return e == hipSuccess ? MSDA_OK : (int)e;
 }
 
+template <typename T>
+int attnpool_core_impl(const T *u, const T *feat, const T *pos, int K, int H, int C, int Tn, T *z, msda_stream_t stream)
+{
+    if (!u || !feat || !pos || !z) return MSDA_ERR_NULL_POINTER;
+    if (K < 0 || H < 1 || C < 1 || Tn < 1 || Tn > msda::kAttnPoolMaxT) return MSDA_ERR_BAD_DIMS;
+    if (K == 0) return MSDA_OK;
+    if ((int64_t)K * H >= ((int64_t)1 << 31) || (int64_t)K * C * Tn >= ((int64_t)1 << 40)) return MSDA_ERR_TOO_LARGE;
+    const size_t lds = (size_t)(2 * (msda::kAttnPoolThreads / msda::kWave) + 1) * (Tn + 1) * sizeof(T);
+    hipLaunchKernelGGL(msda::attnpool_core_kernel<T>, dim3(K * H), dim3(msda::kAttnPoolThreads), lds, static_cast<hipStream_t>(stream), u,
+                       feat, pos, H, C, Tn, z);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
+
 }  // namespace
 
 extern "C" {
+
+int msda_attnpool_core_f32(const float *u, const float *feat, const float *pos, int K, int H, int C, int T, float *z,
+                           msda_stream_t stream)
+{
+    return attnpool_core_impl<float>(u, feat, pos, K, H, C, T, z, stream);
+}
+int msda_attnpool_core_f64(const double *u, const double *feat, const double *pos, int K, int H, int C, int T, double *z,
+                           msda_stream_t stream)
+{
+    return attnpool_core_impl<double>(u, feat, pos, K, H, C, T, z, stream);
+}
 
 int msda_matcher_cost_f32(const float *logits, const float *boxes, const int64_t *tgt_ids, const float *tgt_boxes,
                           const int64_t *tgt_offsets, int B, int Q, int C, int64_t n_targets, double w_class, double w_bbox,
