@@ -284,6 +284,20 @@ int msda_roi_align_forward_f64(const double *input, const double *rois, int K, i
                                int pooled_w, double spatial_scale, int sampling_ratio, int aligned, double *output,
                                msda_stream_t stream);
 
+/* ---- two-stage query selection: row maxima of the class logits without the logits (reference
+ * models/richsem/deformable_transformer.py:368-372 with the CLIP-text classifier models/richsem/richsem.py:176-184 in its shipped
+ * configuration: bias-free linear projection Wp (proj x 256), text embeddings t_c) ------------------------------------------------
+ *     score[token] = max_c  exp(logit_scale) * (Wp x / |Wp x|) . (t_c / |t_c|)  =  scale * max_c (G x)_c / sqrt(x . (A x))
+ * with G = T^ Wp (classes x 256) and A = Wp^T Wp (256 x 256), both formed by the caller in fp32 whenever the weights change
+ * (csrc/cls_mfma.hip).  msda_cls_pack lays [G; A] out in MFMA fragment order as bf16 hi + lo parts (msda_cls_packed_elems uint16
+ * elements); msda_cls_max_scores computes the scores of `tokens` rows of x (fp32, or bf16 when x_is_bf16) with bf16 MFMAs on the
+ * split operands: parts = 2 keeps the weights' lo part (fp32-level accuracy with fp32 x), parts = 1 is a plain bf16 product.
+ * d_model must be 256; classes <= 8192; x and packed 16-byte aligned.  Forward only (the selection carries no gradient). */
+int msda_cls_packed_elems(int classes, int64_t *elems);
+int msda_cls_pack(const float *G, int classes, const float *A, int d_model, uint16_t *packed, msda_stream_t stream);
+int msda_cls_max_scores(const void *x, int x_is_bf16, const uint16_t *packed, int tokens, int d_model, int classes, float scale,
+                        int parts, float *scores, msda_stream_t stream);
+
 /* ---- attention core of CLIP's AttentionPool2d for its single query token (reference
  * clip/model.py:58-91, called at models/richsem/richsem.py:753 on the ROIAlign output) -----------------------------------
  * With one query per head the key / value projections move to the other side of the attention (csrc/msda_attnpool.h): the caller

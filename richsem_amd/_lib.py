@@ -30,6 +30,7 @@ SYMBOLS = [
     "msda_dn_indices_i64", "msda_dn_attn_mask_u8", "msda_topk_f32", "msda_roi_align_forward_f32", "msda_roi_align_forward_f64",
     "msda_ffn_pack_w2_bf16", "msda_ffn_forward_bf16", "msda_ffn_debug_stamps",
     "msda_matcher_cost_f32", "msda_matcher_cost_f64", "msda_attnpool_core_f32", "msda_attnpool_core_f64",
+    "msda_cls_packed_elems", "msda_cls_pack", "msda_cls_max_scores",
 ]
 
 
@@ -94,6 +95,12 @@ def load():
         f = getattr(L, "msda_attnpool_core_" + sfx)
         f.argtypes = [vp] * 3 + [ci] * 4 + [vp, vp]
         f.restype = ci
+    L.msda_cls_packed_elems.argtypes = [ci, ctypes.POINTER(i64)]
+    L.msda_cls_packed_elems.restype = ci
+    L.msda_cls_pack.argtypes = [vp, ci, vp, ci, vp, vp]
+    L.msda_cls_pack.restype = ci
+    L.msda_cls_max_scores.argtypes = [vp, ci, vp, ci, ci, ci, ctypes.c_float, ci, vp, vp]
+    L.msda_cls_max_scores.restype = ci
     L.msda_ffn_debug_stamps.argtypes = [vp]
     L.msda_ffn_debug_stamps.restype = ci
     L.msda_ffn_pack_w2_bf16.argtypes = [vp, ci, ci, vp, vp]
