@@ -284,6 +284,23 @@ int msda_roi_align_forward_f64(const double *input, const double *rois, int K, i
                                int pooled_w, double spatial_scale, int sampling_ratio, int aligned, double *output,
                                msda_stream_t stream);
 
+/* ---- convolution forward on the matrix cores with the frozen-BatchNorm affine, residual add and ReLU in its epilogue (SURVEY.md
+ * section 8a rows a10 / a11; reference clip/model.py:10-56, :94-167 -- the frozen CLIP teacher called at models/richsem/richsem.py:628 --
+ * and models/richsem/backbone.py:20-56 around the ResNet-50 convolutions; csrc/conv_mfma.hip) -------------------------------------
+ *     out[n, ho, wo, co] = act( scale[co] * sum_{kh, kw, ci} x[n, ho s + kh - p, wo s + kw - p, ci] w[co, ci, kh, kw] + shift[co]
+ *                               (+ residual[n, ho, wo, co]) ),   act = relu or identity
+ * Activations NHWC bf16, fp32 accumulation, fp32 scale / shift (BatchNorm folded: scale = w rsqrt(var + eps), shift = b - mean scale;
+ * a plain bias is scale = 1, shift = bias).  C_in % 32 == 0 and C_out % 32 == 0; all pointers 16-byte aligned; residual may be NULL.
+ * msda_conv_pack_weight: weight (C_out, C_in, KH, KW) fp32 (torch layout) -> C_out C_in KH KW uint16 in MFMA fragment order (repack when
+ * the weight changes).  msda_conv_patches_bf16: explicit patches for inputs with few channels (the 3-channel stems): x (N, H, W, C) ->
+ * (N Ho Wo, Kpad), k = (kh KW + kw) C + ci, zero-padded to Kpad (a multiple of 32), to be followed by a 1 x 1 convolution.  Forward only. */
+int msda_conv_pack_weight(const float *weight, int Cout, int Cin, int KH, int KW, uint16_t *packed, msda_stream_t stream);
+int msda_conv_patches_bf16(const uint16_t *x, int N, int H, int W, int C, int KH, int KW, int stride, int pad, int Kpad,
+                           uint16_t *patches, msda_stream_t stream);
+int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, const float *scale, const float *shift,
+                           const uint16_t *residual, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
+                           uint16_t *out, msda_stream_t stream);
+
 /* ---- two-stage query selection: row maxima of the class logits without the logits (reference
  * models/richsem/deformable_transformer.py:368-372 with the CLIP-text classifier models/richsem/richsem.py:176-184 in its shipped
  * configuration: bias-free linear projection Wp (proj x 256), text embeddings t_c) ------------------------------------------------

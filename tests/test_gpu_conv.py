@@ -1,0 +1,73 @@
+"""GPU (-m gpu): the MFMA convolution (csrc/conv_mfma.hip) against its definition in PyTorch fp32
+ops on the same bf16-rounded operands (F.conv2d on the CPU; no reference fixture exists for a single convolution -- the network-level
+fixtures are in test_gpu_clip_resnet.py).  Tolerance: fp32 accumulation of exactly representable products, so the only differences
+are the summation order and the final rounding to bf16: 2^-8 relative per element."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # N, H, W, Cin, Cout, k, stride, pad
+    (2, 13, 17, 64, 64, 1, 1, 0),
+    (2, 13, 17, 64, 64, 3, 1, 1),
+    (1, 20, 31, 32, 32, 3, 1, 1),        # CLIP stem conv2 (two row tiles)
+    (1, 20, 31, 32, 64, 3, 1, 1),
+    (2, 9, 11, 128, 512, 1, 1, 0),       # two channel blocks of 256
+    (2, 15, 14, 256, 128, 3, 2, 1),      # torchvision-style strided 3 x 3
+    (1, 7, 9, 512, 256, 1, 2, 0),        # strided 1 x 1 (downsample)
+    (2, 21, 33, 3, 32, 3, 2, 1),         # 3-channel stem through patches
+    (1, 37, 41, 3, 64, 7, 2, 3),         # torchvision stem
+    (1, 8, 8, 16, 32, 3, 1, 1),          # C_in = 16 through patches
+    (3, 1, 1, 64, 96, 1, 1, 0),          # C_out = 96: three blocks of 32
+    (1, 50, 84, 1024, 256, 1, 1, 0),     # input_proj shape of C4 (richsem.py:295-303)
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+@pytest.mark.parametrize("epilogue", ["affine_relu", "residual_relu", "plain"])
+def test_conv_against_fp32_definition(case, epilogue):
+    from richsem_amd.conv import ConvAffine, to_nhwc_bf16
+    N, H, W, Cin, Cout, k, stride, pad = case
+    torch.manual_seed(hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, k, k) * (Cin * k * k) ** -0.5).to(torch.bfloat16).float()
+    scale = (1 + 0.3 * torch.randn(Cout)) if epilogue != "plain" else None
+    shift = torch.randn(Cout) if epilogue != "plain" else None
+    ref = F.conv2d(x.float(), w, stride=stride, padding=pad)
+    if scale is not None:
+        ref = ref * scale[None, :, None, None] + shift[None, :, None, None]
+    res = None
+    if epilogue == "residual_relu":
+        res = torch.randn_like(ref).to(torch.bfloat16)
+        ref = ref + res.float()
+    if epilogue != "plain":
+        ref = torch.relu(ref)
+    conv = ConvAffine(w.cuda(), None if scale is None else scale.cuda(), None if shift is None else shift.cuda(), stride, pad,
+                      relu=epilogue != "plain")
+    got = conv(to_nhwc_bf16(x.cuda()), None if res is None else to_nhwc_bf16(res.cuda()))
+    got = got.permute(0, 3, 1, 2).float().cpu()
+    assert got.shape == ref.shape
+    err = (got - ref).abs()
+    assert float((err / (ref.abs() + 1.0)).max()) < 2 ** -7, float((err / (ref.abs() + 1.0)).max())
+    assert float(err.mean()) < 4e-3 * float(ref.abs().mean() + 1e-3)
+    assert "librichsem_msda.so" in open("/proc/self/maps").read()
+
+
+def test_errors():
+    from richsem_amd.conv import ConvAffine
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        ConvAffine(torch.zeros(32, 32, 1, 1))
+    with pytest.raises(AssertionError):
+        ConvAffine(torch.zeros(24, 32, 1, 1, device="cuda"))
+    conv = ConvAffine(torch.zeros(32, 32, 1, 1, device="cuda"))
+    with pytest.raises(AssertionError):
+        conv(torch.zeros(1, 4, 4, 32, device="cuda"))            # fp32 input
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        conv(torch.zeros(1, 4, 4, 32, dtype=torch.bfloat16))
