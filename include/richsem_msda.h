@@ -290,13 +290,14 @@ int msda_roi_align_forward_f64(const double *input, const double *rois, int K, i
  *     out[n, ho, wo, co] = act( scale[co] * sum_{kh, kw, ci} x[n, ho s + kh - p, wo s + kw - p, ci] w[co, ci, kh, kw] + shift[co]
  *                               (+ residual[n, ho, wo, co]) ),   act = relu or identity
  * Activations NHWC bf16, fp32 accumulation, fp32 scale / shift (BatchNorm folded: scale = w rsqrt(var + eps), shift = b - mean scale;
- * a plain bias is scale = 1, shift = bias).  C_in % 32 == 0 and C_out % 32 == 0; all pointers 16-byte aligned; residual may be NULL.
- * msda_conv_pack_weight: weight (C_out, C_in, KH, KW) fp32 (torch layout) -> C_out C_in KH KW uint16 in MFMA fragment order (repack when
- * the weight changes).  msda_conv_patches_bf16: explicit patches for inputs with few channels (the 3-channel stems): x (N, H, W, C) ->
- * (N Ho Wo, Kpad), k = (kh KW + kw) C + ci, zero-padded to Kpad (a multiple of 32), to be followed by a 1 x 1 convolution.  Forward only. */
+ * a plain bias is scale = 1, shift = bias).  C_out % 16 == 0; C_in % 32 == 0, or any C_in with KH KW C_in <= 512 (the 3-channel stems:
+ * operand fragments gathered element by element); all pointers 16-byte aligned (x: 2-byte for few-channel inputs); residual may be NULL.
+ * msda_conv_pack_weight: weight (C_out, C_in, KH, KW) fp32 (torch layout) -> msda_conv_packed_elems uint16 in MFMA fragment order
+ * (repack when the weight changes).  msda_conv_set_tiling forces the per-wave tile (channel tiles in {1, 2, 4, 8, 16}, pixel tiles in
+ * {1, 2, 3}; 0 = chosen per call so that the grid fills the chip) -- results do not depend on it beyond summation order.  Forward only. */
+int msda_conv_set_tiling(int co_tiles, int pixel_tiles);
+int msda_conv_packed_elems(int Cout, int Cin, int KH, int KW, int64_t *elems);
 int msda_conv_pack_weight(const float *weight, int Cout, int Cin, int KH, int KW, uint16_t *packed, msda_stream_t stream);
-int msda_conv_patches_bf16(const uint16_t *x, int N, int H, int W, int C, int KH, int KW, int stride, int pad, int Kpad,
-                           uint16_t *patches, msda_stream_t stream);
 int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, const float *scale, const float *shift,
                            const uint16_t *residual, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
                            uint16_t *out, msda_stream_t stream);

@@ -31,7 +31,7 @@ SYMBOLS = [
     "msda_ffn_pack_w2_bf16", "msda_ffn_forward_bf16", "msda_ffn_debug_stamps",
     "msda_matcher_cost_f32", "msda_matcher_cost_f64", "msda_attnpool_core_f32", "msda_attnpool_core_f64",
     "msda_cls_packed_elems", "msda_cls_pack", "msda_cls_max_scores",
-    "msda_conv_pack_weight", "msda_conv_patches_bf16", "msda_conv_forward_bf16",
+    "msda_conv_set_tiling", "msda_conv_packed_elems", "msda_conv_pack_weight", "msda_conv_forward_bf16",
 ]
 
 
@@ -104,8 +104,10 @@ def load():
     L.msda_cls_max_scores.restype = ci
     L.msda_conv_pack_weight.argtypes = [vp, ci, ci, ci, ci, vp, vp]
     L.msda_conv_pack_weight.restype = ci
-    L.msda_conv_patches_bf16.argtypes = [vp] + [ci] * 9 + [vp, vp]
-    L.msda_conv_patches_bf16.restype = ci
+    L.msda_conv_set_tiling.argtypes = [ci, ci]
+    L.msda_conv_set_tiling.restype = ci
+    L.msda_conv_packed_elems.argtypes = [ci] * 4 + [ctypes.POINTER(i64)]
+    L.msda_conv_packed_elems.restype = ci
     L.msda_conv_forward_bf16.argtypes = [vp] * 5 + [ci] * 10 + [vp, vp]
     L.msda_conv_forward_bf16.restype = ci
     L.msda_ffn_debug_stamps.argtypes = [vp]

@@ -4,6 +4,8 @@ Activations are NHWC bfloat16 tensors of shape (N, H, W, C) (contiguous); a conv
 it in the backbones (frozen / eval-mode BatchNorm folded into scale and shift -- reference models/richsem/backbone.py:20-56,
 clip/model.py:16-27), an optional residual and an optional ReLU, all applied in the kernel's epilogue.  Forward only.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -29,30 +31,25 @@ def to_nchw(x_nhwc, dtype=torch.float32):
 
 class ConvAffine:
     """One convolution + affine (+ residual) (+ ReLU).  ``weight`` (C_out, C_in, KH, KW) as nn.Conv2d stores it; ``scale`` / ``shift``
-    (C_out) fp32 (``None``: identity / zero).  C_out must be a multiple of 32.  Inputs with C_in not a multiple of 32 (the 3-channel
-    stems, CLIP's 16-wide stem at small widths) go through explicit patches + a 1 x 1 product."""
+    (C_out) fp32 (``None``: identity / zero).  C_out must be a multiple of 16; C_in a multiple of 32, or KH KW C_in <= 512 (the
+    3-channel stems)."""
 
     def __init__(self, weight, scale=None, shift=None, stride=1, padding=0, relu=False):
         if not weight.is_cuda:
             raise RuntimeError("Not implemented on the CPU")
         w = weight.detach().float().contiguous()
         self.Cout, self.Cin, self.KH, self.KW = w.shape
-        assert self.Cout % 32 == 0, "C_out must be a multiple of 32"
+        assert self.Cout % 16 == 0, "C_out must be a multiple of 16"
         self.stride, self.pad, self.relu = int(stride), int(padding), bool(relu)
         dev = w.device
         self.scale = (torch.ones(self.Cout, device=dev) if scale is None else scale.detach().float().to(dev)).contiguous()
         self.shift = (torch.zeros(self.Cout, device=dev) if shift is None else shift.detach().float().to(dev)).contiguous()
-        self.patches = self.Cin % 32 != 0
-        if self.patches:      # k = (kh KW + kw) C_in + ci, padded to a multiple of 32: a 1 x 1 convolution over the patches
-            k = self.KH * self.KW * self.Cin
-            self.Kpad = (k + 31) // 32 * 32
-            w2 = torch.zeros(self.Cout, self.Kpad, device=dev)
-            w2[:, :k] = w.permute(0, 2, 3, 1).reshape(self.Cout, k)
-            w = w2.view(self.Cout, self.Kpad, 1, 1).contiguous()
-        self.packed = torch.empty(w.numel(), dtype=torch.int16, device=dev)
+        L = _lib.load()
+        n = ctypes.c_int64(0)
+        _lib.check(L.msda_conv_packed_elems(self.Cout, self.Cin, self.KH, self.KW, ctypes.byref(n)))
+        self.packed = torch.empty(n.value, dtype=torch.int16, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(_lib.load().msda_conv_pack_weight(w.data_ptr(), w.shape[0], w.shape[1], w.shape[2], w.shape[3],
-                                                         self.packed.data_ptr(), _stream(dev)))
+            _lib.check(L.msda_conv_pack_weight(w.data_ptr(), self.Cout, self.Cin, self.KH, self.KW, self.packed.data_ptr(), _stream(dev)))
 
     def out_hw(self, H, W):
         return (H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1
@@ -66,25 +63,21 @@ class ConvAffine:
         x = x.contiguous()
         N, H, W, _ = x.shape
         Ho, Wo = self.out_hw(H, W)
-        L = _lib.load()
         out = torch.empty((N, Ho, Wo, self.Cout), dtype=torch.bfloat16, device=x.device)
         if residual is not None:
             assert residual.shape == out.shape and residual.dtype == torch.bfloat16
             residual = residual.contiguous()
         with torch.cuda.device(x.device):
-            st = _stream(x.device)
-            if self.patches:
-                pt = torch.empty((N, Ho, Wo, self.Kpad), dtype=torch.bfloat16, device=x.device)
-                _lib.check(L.msda_conv_patches_bf16(x.data_ptr(), N, H, W, self.Cin, self.KH, self.KW, self.stride, self.pad, self.Kpad,
-                                                    pt.data_ptr(), st))
-                _lib.check(L.msda_conv_forward_bf16(pt.data_ptr(), self.packed.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
-                                                    residual.data_ptr() if residual is not None else None, N, Ho, Wo, self.Kpad,
-                                                    self.Cout, 1, 1, 1, 0, int(self.relu), out.data_ptr(), st))
-            else:
-                _lib.check(L.msda_conv_forward_bf16(x.data_ptr(), self.packed.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
-                                                    residual.data_ptr() if residual is not None else None, N, H, W, self.Cin, self.Cout,
-                                                    self.KH, self.KW, self.stride, self.pad, int(self.relu), out.data_ptr(), st))
+            _lib.check(_lib.load().msda_conv_forward_bf16(
+                x.data_ptr(), self.packed.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                residual.data_ptr() if residual is not None else None, N, H, W, self.Cin, self.Cout, self.KH, self.KW, self.stride,
+                self.pad, int(self.relu), out.data_ptr(), _stream(x.device)))
         return out
+
+
+def set_tiling(co_tiles=0, pixel_tiles=0):
+    """Tuning / tests: force the kernel's per-wave tile (0 = automatic)."""
+    _lib.check(_lib.load().msda_conv_set_tiling(int(co_tiles), int(pixel_tiles)))
 
 
 def avg_pool_nhwc(x, k):

@@ -12,16 +12,21 @@
 // fragment is one 16-byte load per lane, and the output tile's four consecutive channels per lane are one 8-byte store).
 // Everything is computed TRANSPOSED as in csrc/ffn_mfma.hip: out^T (C_out x pixels) = W (C_out x K) . im2col^T (K x pixels) with
 // mfma_f32_16x16x32_bf16: pixels on the lanes, output channels in the registers.
-//   * a wave owns 48 output pixels (three column tiles) x up to 256 output channels (CO_TILES row tiles: 192 accumulators);
-//   * the weights are packed once (msda_conv_pack_weight) into fragment order per (channel block, k-step, row tile) and stream through
+//   * a wave owns 16 PT output pixels (PT <= 3 column tiles) x 16 CO_TILES <= 256 output channels (192 accumulators at most); the host
+//     picks (CO_TILES, PT) per call so that the grid fills the chip (deep layers have few pixels: smaller tiles, more workgroups);
+//   * the weights are packed once (msda_conv_pack_weight) into fragment order per (k-step, row tile) and stream through
 //     LDS, double-buffered through registers, one barrier per k-step of 32; all four waves of a workgroup share them;
 //   * the im2col operand is never formed: lane (pixel c, group q) loads x[n, ho s + kh - p, wo s + kw - p, 32 cb + 8 q ..] one k-step
 //     ahead of its MFMAs (zero fragment outside the image).
-// C_in must be a multiple of 32 (the 3-channel stems go through msda_conv_patches_bf16 first: explicit patches of a few channels,
-// padded to 32, then a 1 x 1 convolution); C_out a multiple of 16 * CO_TILES with CO_TILES in {2, 4, 8, 16}.
+// C_in must be a multiple of 32, except for inputs of a few channels (the 3-channel stems): their operand fragments are gathered
+// element by element through a k -> (kh, kw, ci) table in LDS (k = (kh KW + kw) C_in + ci, padded to a multiple of 32; the weight is
+// packed in that order).  C_out must be a multiple of 16.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+
+#include <atomic>
+#include <initializer_list>
 
 #include "../../include/richsem_msda.h"
 
@@ -50,64 +55,61 @@ struct ConvGeom {
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
 };
 
-// weight (Cout, Cin, KH, KW) fp32, torch layout -> packed[co block][k-step][row tile][lane][8] bf16;
-// k-step s = (kh KW + kw) (Cin / 32) + cb; lane (r, q) = output channel 16 tile + r, input channel 32 cb + 8 q + 0..7
-__global__ void conv_pack_kernel(const float *__restrict__ w, uint16_t *__restrict__ packed, int Cout, int Cin, int KH, int KW, int co_tiles)
+// weight (Cout, Cin, KH, KW) fp32, torch layout -> packed[k-step][row tile][lane][8] bf16, K = KH KW Cin padded to Kpad (multiple of 32);
+// lane (r, q) = output channel 16 tile + r, k = 32 step + 8 q + 0..7.  small_c = 0: k = (kh KW + kw) Cin + ci with Cin % 32 == 0 (a k-step
+// is one tap and 32 channels); small_c = 1: the same flat order for any Cin, zero beyond KH KW Cin.
+__global__ void conv_pack_kernel(const float *__restrict__ w, uint16_t *__restrict__ packed, int Cout, int Cin, int KH, int KW, int Kpad)
 {
-    const int cpb = Cin / 32, S = KH * KW * cpb;
-    const long long n = (long long)Cout * Cin * KH * KW;
+    const int tiles = Cout / 16, K = KH * KW * Cin;
+    const long long n = (long long)Cout * Kpad;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        long long r = i >> 9;
-        const int tile = (int)(r % co_tiles);
-        r /= co_tiles;
-        const int s = (int)(r % S), blk = (int)(r / S);
-        const int co = (blk * co_tiles + tile) * 16 + (lane & 15);
-        const int tap = s / cpb, cb = s - tap * cpb;
-        const int ci = 32 * cb + 8 * (lane >> 4) + j, kh = tap / KW, kw = tap - kh * KW;
-        packed[i] = (uint16_t)(pack_bf16(w[(((long long)co * Cin + ci) * KH + kh) * KW + kw], 0.f) & 0xFFFFu);
-    }
-}
-
-// x (N, H, W, C) bf16 with small C -> patches (N Ho Wo, Kpad) bf16, k = (kh KW + kw) C + ci, zero beyond KH KW C
-__global__ void conv_patches_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ patches, int N, int H, int W, int C, int Ho,
-                                    int Wo, int KH, int KW, int stride, int pad, int Kpad)
-{
-    const long long n = (long long)N * Ho * Wo * Kpad;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % Kpad);
-        const long long p = i / Kpad;
-        uint16_t v = 0;
-        if (k < KH * KW * C) {
-            const int ci = k % C, tap = k / C, kh = tap / KW, kw = tap - kh * KW;
-            const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), b = (int)(p / ((long long)Wo * Ho));
-            const int hi = ho * stride + kh - pad, wi = wo * stride + kw - pad;
-            if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = x[(((long long)b * H + hi) * W + wi) * C + ci];
+        const long long r = i >> 9;
+        const int tile = (int)(r % tiles), s = (int)(r / tiles);
+        const int co = tile * 16 + (lane & 15), k = 32 * s + 8 * (lane >> 4) + j;
+        float v = 0.f;
+        if (k < K) {
+            const int ci = k % Cin, tap = k / Cin, kh = tap / KW, kw = tap - kh * KW;
+            v = w[(((long long)co * Cin + ci) * KH + kh) * KW + kw];
         }
-        patches[i] = v;
+        packed[i] = (uint16_t)(pack_bf16(v, 0.f) & 0xFFFFu);
     }
 }
 
-template <int CO_TILES>
-__global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+template <int CO_TILES, int PT, bool SMALLC>
+__global__ __launch_bounds__(kWaves * 64)
 void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wpk, const float *__restrict__ scale,
                      const float *__restrict__ shift, const uint16_t *__restrict__ residual, uint16_t *__restrict__ out, ConvGeom g,
                      int relu)
 {
     __shared__ __attribute__((aligned(16))) short wbuf[2][CO_TILES * kFragShorts];
+    __shared__ unsigned lut[SMALLC ? 512 : 1];     // k -> kh << 20 | kw << 12 | ci   (0xFFFFFFFF: padding)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
     const long long P = (long long)g.N * g.Ho * g.Wo;
-    const long long pix0 = (long long)blockIdx.x * kPixWg + wave * kPixWave;
-    const int cpb = g.Cin / 32, S = g.KH * g.KW * cpb;
+    const long long pix0 = (long long)blockIdx.x * (kWaves * 16 * PT) + wave * (16 * PT);
+    const int Ktot = g.KH * g.KW * g.Cin;
+    const int cpb = SMALLC ? 1 : g.Cin / 32, S = SMALLC ? (Ktot + 31) / 32 : g.KH * g.KW * cpb;
+    const int tiles_all = g.Cout / 16;
     const int co0 = blockIdx.y * (16 * CO_TILES);
 
-    // this lane's three output pixels: image base, top-left input coordinate of the receptive field
-    long long img[3];
-    int hi0[3], wi0[3];
+    if (SMALLC) {
+        for (int k = tid; k < 32 * S; k += kWaves * 64) {
+            unsigned v = 0xFFFFFFFFu;
+            if (k < Ktot) {
+                const int ci = k % g.Cin, tap = k / g.Cin, kh = tap / g.KW, kw = tap - kh * g.KW;
+                v = (unsigned)kh << 20 | (unsigned)kw << 12 | (unsigned)ci;
+            }
+            lut[k] = v;
+        }
+    }
+
+    // this lane's output pixels: image base, top-left input coordinate of the receptive field
+    long long img[PT];
+    int hi0[PT], wi0[PT];
 #pragma unroll
-    for (int t3 = 0; t3 < 3; ++t3) {
+    for (int t3 = 0; t3 < PT; ++t3) {
         long long p = pix0 + 16 * t3 + c;
         if (p > P - 1) p = P - 1;
         const int wo = (int)(p % g.Wo), ho = (int)((p / g.Wo) % g.Ho);
@@ -116,22 +118,23 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
         wi0[t3] = wo * g.stride - g.pad;
     }
 
-    f32x4 acc[3][CO_TILES];
+    f32x4 acc[PT][CO_TILES];
 #pragma unroll
-    for (int t3 = 0; t3 < 3; ++t3)
+    for (int t3 = 0; t3 < PT; ++t3)
 #pragma unroll
         for (int t = 0; t < CO_TILES; ++t) acc[t3][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // weights: tile of k-step s for this channel block -> registers -> LDS
+    // weights: this channel block's row tiles of k-step s -> registers -> LDS
     constexpr int kTileChunks = CO_TILES * kFragShorts * 2 / 16;                       // 16-byte chunks per tile
     constexpr int kChunks = (kTileChunks + kWaves * 64 - 1) / (kWaves * 64);
-    const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(wpk + (size_t)blockIdx.y * S * CO_TILES * kFragShorts);
+    const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(wpk + (size_t)blockIdx.y * CO_TILES * kFragShorts);
+    const size_t step_chunks = (size_t)tiles_all * kFragShorts * 2 / 16;
     u32x4 stage[kChunks];
     auto fetch = [&](int s) {
 #pragma unroll
         for (int i = 0; i < kChunks; ++i) {
             const int idx = tid + i * (kWaves * 64);
-            if (idx < kTileChunks) stage[i] = wsrc[(size_t)s * kTileChunks + idx];
+            if (idx < kTileChunks) stage[i] = wsrc[(size_t)s * step_chunks + idx];
         }
     };
     auto park = [&](int slot) {
@@ -142,20 +145,40 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
             if (idx < kTileChunks) dst[idx] = stage[i];
         }
     };
-    // im2col fragment of k-step (tap kh, kw; channel block cb) for the three pixels
+    // im2col fragment of a k-step for the lane's pixels: (tap kh, kw; channel block cb), or k-step cb through the table
     auto gather = [&](int kh, int kw, int cb, bf16x8 *b) {
+        if (SMALLC) {
+            unsigned e[8];
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) {
-            const int hi = hi0[t3] + kh, wi = wi0[t3] + kw;
-            const bool in = hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
-            const long long off = in ? ((img[t3] + (long long)hi * g.W + wi) * g.Cin + 32 * cb + 8 * q) : 0;
-            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + off);
-            b[t3] = in ? v : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < 8; ++j) e[j] = lut[32 * cb + 8 * q + j];
+#pragma unroll
+            for (int t3 = 0; t3 < PT; ++t3) {
+                unsigned short v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int hi = hi0[t3] + (int)(e[j] >> 20), wi = wi0[t3] + (int)((e[j] >> 12) & 255);
+                    const bool in = e[j] != 0xFFFFFFFFu && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+                    const long long off = in ? ((img[t3] + (long long)hi * g.W + wi) * g.Cin + (e[j] & 4095)) : 0;
+                    const unsigned short u = x[off];
+                    v[j] = in ? u : (unsigned short)0;
+                }
+                b[t3] = (bf16x8){(short)v[0], (short)v[1], (short)v[2], (short)v[3], (short)v[4], (short)v[5], (short)v[6], (short)v[7]};
+            }
+        } else {
+#pragma unroll
+            for (int t3 = 0; t3 < PT; ++t3) {
+                const int hi = hi0[t3] + kh, wi = wi0[t3] + kw;
+                const bool in = hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+                const long long off = in ? ((img[t3] + (long long)hi * g.W + wi) * g.Cin + 32 * cb + 8 * q) : 0;
+                const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + off);
+                b[t3] = in ? v : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
         }
     };
 
-    bf16x8 bcur[3], bnext[3];
+    bf16x8 bcur[PT], bnext[PT];
     int kh = 0, kw = 0, cb = 0;
+    if (SMALLC) __syncthreads();      // the table
     gather(0, 0, 0, bnext);
     fetch(0);
     park(0);
@@ -163,9 +186,9 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
 
     for (int s = 0; s < S; ++s) {
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) bcur[t3] = bnext[t3];
+        for (int t3 = 0; t3 < PT; ++t3) bcur[t3] = bnext[t3];
         if (s + 1 < S) {
-            if (++cb == cpb) {
+            if (++cb == cpb && !SMALLC) {
                 cb = 0;
                 if (++kw == g.KW) { kw = 0; ++kh; }
             }
@@ -177,7 +200,7 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
         for (int t = 0; t < CO_TILES; ++t) {
             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wt + t * kFragShorts + lane * 8);
 #pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) acc[t3][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[t3], acc[t3][t], 0, 0, 0);
+            for (int t3 = 0; t3 < PT; ++t3) acc[t3][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[t3], acc[t3][t], 0, 0, 0);
         }
         if (s + 1 < S) park((s + 1) & 1);
         __syncthreads();
@@ -185,7 +208,7 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
 
     // epilogue: lane (c, q) holds channels co0 + 16 t + 4 q + 0..3 of pixel c: affine, residual, relu, 8-byte store
 #pragma unroll
-    for (int t3 = 0; t3 < 3; ++t3) {
+    for (int t3 = 0; t3 < PT; ++t3) {
         const long long p = pix0 + 16 * t3 + c;
         if (p >= P) continue;
 #pragma unroll
@@ -207,52 +230,103 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
     }
 }
 
-template <int CO_TILES>
-int launch_conv(const uint16_t *x, const uint16_t *wpk, const float *scale, const float *shift, const uint16_t *residual, uint16_t *out,
-                const ConvGeom &g, int relu, hipStream_t stream)
+struct ConvArgs {
+    const uint16_t *x, *wpk;
+    const float *scale, *shift;
+    const uint16_t *residual;
+    uint16_t *out;
+    ConvGeom g;
+    int relu;
+    hipStream_t stream;
+};
+
+template <int CO_TILES, int PT, bool SMALLC>
+int launch_conv(const ConvArgs &a)
 {
-    const long long P = (long long)g.N * g.Ho * g.Wo;
-    const dim3 grid((unsigned)((P + kPixWg - 1) / kPixWg), (unsigned)(g.Cout / (16 * CO_TILES)));
-    hipLaunchKernelGGL(conv_fwd_kernel<CO_TILES>, grid, dim3(kWaves * 64), 0, stream, x, wpk, scale, shift, residual, out, g, relu);
+    const long long P = (long long)a.g.N * a.g.Ho * a.g.Wo;
+    const dim3 grid((unsigned)((P + kWaves * 16 * PT - 1) / (kWaves * 16 * PT)), (unsigned)(a.g.Cout / (16 * CO_TILES)));
+    hipLaunchKernelGGL((conv_fwd_kernel<CO_TILES, PT, SMALLC>), grid, dim3(kWaves * 64), 0, a.stream, a.x, a.wpk, a.scale, a.shift,
+                       a.residual, a.out, a.g, a.relu);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
 }
 
-int co_tiles_for(int Cout)
+template <int CO_TILES, bool SMALLC>
+int launch_pt(const ConvArgs &a, int pt)
 {
-    if (Cout % 256 == 0) return 16;
-    if (Cout % 128 == 0) return 8;
-    if (Cout % 64 == 0) return 4;
-    if (Cout % 32 == 0) return 2;
-    return 0;
+    switch (pt) {
+    case 3: return launch_conv<CO_TILES, 3, SMALLC>(a);
+    case 2: return launch_conv<CO_TILES, 2, SMALLC>(a);
+    default: return launch_conv<CO_TILES, 1, SMALLC>(a);
+    }
+}
+
+template <bool SMALLC>
+int launch_ct(const ConvArgs &a, int ct, int pt)
+{
+    switch (ct) {
+    case 16: return launch_pt<16, SMALLC>(a, pt);
+    case 8: return launch_pt<8, SMALLC>(a, pt);
+    case 4: return launch_pt<4, SMALLC>(a, pt);
+    case 2: return launch_pt<2, SMALLC>(a, pt);
+    default: return launch_pt<1, SMALLC>(a, pt);
+    }
+}
+
+std::atomic<int> g_force_ct{0}, g_force_pt{0};   // tuning: msda_conv_set_tiling
+
+// Tile choice: the largest (channel tiles x pixel tiles) per wave that still gives the chip about two workgroups per CU; when even the
+// smallest does not (deep layers on small inputs), the one with the most workgroups.
+void choose_tiling(long long P, int Cout, int &ct, int &pt)
+{
+    const int tiles = Cout / 16;
+    long long best_n = -1;
+    int best_ct = 1, best_pt = 1;
+    for (int c : {16, 8, 4, 2, 1}) {
+        if (tiles % c) continue;
+        for (int p : {3, 2, 1}) {
+            const long long n = ((P + 64 * p - 1) / (64 * p)) * (tiles / c);
+            if (n >= 512) { ct = c; pt = p; return; }
+            if (n > best_n) { best_n = n; best_ct = c; best_pt = p; }
+        }
+    }
+    ct = best_ct;
+    pt = best_pt;
 }
 
 }  // namespace
 
 extern "C" {
 
+/* Tuning / tests: force the tile shape (channel tiles per wave in {1, 2, 4, 8, 16}, pixel tiles per wave in {1, 2, 3}); 0 = automatic. */
+int msda_conv_set_tiling(int co_tiles, int pixel_tiles)
+{
+    if ((co_tiles != 0 && co_tiles != 1 && co_tiles != 2 && co_tiles != 4 && co_tiles != 8 && co_tiles != 16) || pixel_tiles < 0 ||
+        pixel_tiles > 3)
+        return MSDA_ERR_BAD_OPTION;
+    g_force_ct = co_tiles;
+    g_force_pt = pixel_tiles;
+    return MSDA_OK;
+}
+
+int msda_conv_packed_elems(int Cout, int Cin, int KH, int KW, int64_t *elems)
+{
+    if (!elems) return MSDA_ERR_NULL_POINTER;
+    if (Cout < 16 || Cout % 16 != 0 || Cin < 1 || KH < 1 || KW < 1 || KH > 16 || KW > 16) return MSDA_ERR_BAD_DIMS;
+    const int64_t K = (int64_t)KH * KW * Cin;
+    if (Cin % 32 != 0 && K > 512) return MSDA_ERR_BAD_DIMS;      // few-channel inputs only (table of 512 entries)
+    *elems = (int64_t)Cout * ((K + 31) / 32 * 32);
+    return MSDA_OK;
+}
+
 int msda_conv_pack_weight(const float *weight, int Cout, int Cin, int KH, int KW, uint16_t *packed, msda_stream_t stream)
 {
     if (!weight || !packed) return MSDA_ERR_NULL_POINTER;
-    const int ct = co_tiles_for(Cout);
-    if (Cout < 1 || Cin < 32 || Cin % 32 != 0 || KH < 1 || KW < 1 || KH > 16 || KW > 16 || ct == 0) return MSDA_ERR_BAD_DIMS;
-    hipLaunchKernelGGL(conv_pack_kernel, dim3(512), dim3(256), 0, static_cast<hipStream_t>(stream), weight, packed, Cout, Cin, KH, KW, ct);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? MSDA_OK : (int)e;
-}
-
-int msda_conv_patches_bf16(const uint16_t *x, int N, int H, int W, int C, int KH, int KW, int stride, int pad, int Kpad,
-                           uint16_t *patches, msda_stream_t stream)
-{
-    if (!x || !patches) return MSDA_ERR_NULL_POINTER;
-    if (N < 1 || H < 1 || W < 1 || C < 1 || KH < 1 || KW < 1 || stride < 1 || pad < 0 || Kpad < KH * KW * C || Kpad % 32 != 0)
-        return MSDA_ERR_BAD_DIMS;
-    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    if (Ho < 1 || Wo < 1) return MSDA_ERR_BAD_DIMS;
-    const long long n = (long long)N * Ho * Wo * Kpad;
-    const int grid = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
-    hipLaunchKernelGGL(conv_patches_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, patches, N, H, W, C, Ho, Wo, KH,
-                       KW, stride, pad, Kpad);
+    int64_t n = 0;
+    const int rc = msda_conv_packed_elems(Cout, Cin, KH, KW, &n);
+    if (rc != MSDA_OK) return rc;
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(512), dim3(256), 0, static_cast<hipStream_t>(stream), weight, packed, Cout, Cin, KH, KW,
+                       (int)(n / Cout));
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
 }
@@ -262,23 +336,25 @@ int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, con
                            uint16_t *out, msda_stream_t stream)
 {
     if (!x || !packed_weight || !scale || !shift || !out) return MSDA_ERR_NULL_POINTER;
-    const int ct = co_tiles_for(Cout);
-    if (N < 1 || H < 1 || W < 1 || Cin < 32 || Cin % 32 != 0 || ct == 0 || KH < 1 || KW < 1 || KH > 16 || KW > 16 || stride < 1 || pad < 0)
-        return MSDA_ERR_BAD_DIMS;
+    int64_t n = 0;
+    const int rc = msda_conv_packed_elems(Cout, Cin, KH, KW, &n);
+    if (rc != MSDA_OK) return rc;
+    if (N < 1 || H < 1 || W < 1 || stride < 1 || pad < 0) return MSDA_ERR_BAD_DIMS;
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     if (Ho < 1 || Wo < 1) return MSDA_ERR_BAD_DIMS;
     if ((long long)N * H * W * Cin >= (1ll << 40) || (long long)N * Ho * Wo * Cout >= (1ll << 40)) return MSDA_ERR_TOO_LARGE;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed_weight) | reinterpret_cast<uintptr_t>(scale) |
-         reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(residual)) & 15)
+    const bool small_c = Cin % 32 != 0;
+    if ((reinterpret_cast<uintptr_t>(packed_weight) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
+         reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(residual) | (small_c ? 0 : reinterpret_cast<uintptr_t>(x))) & 15)
         return MSDA_ERR_MISALIGNED;
-    const ConvGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad};
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    switch (ct) {
-    case 16: return launch_conv<16>(x, packed_weight, scale, shift, residual, out, g, relu, st);
-    case 8: return launch_conv<8>(x, packed_weight, scale, shift, residual, out, g, relu, st);
-    case 4: return launch_conv<4>(x, packed_weight, scale, shift, residual, out, g, relu, st);
-    default: return launch_conv<2>(x, packed_weight, scale, shift, residual, out, g, relu, st);
-    }
+    int ct, pt;
+    choose_tiling((long long)N * Ho * Wo, Cout, ct, pt);
+    const int fct = g_force_ct.load(), fpt = g_force_pt.load();
+    if (fct && (Cout / 16) % fct == 0) ct = fct;
+    if (fpt) pt = fpt;
+    const ConvArgs a{x, packed_weight, scale, shift, residual, out, ConvGeom{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad}, relu,
+                     static_cast<hipStream_t>(stream)};
+    return small_c ? launch_ct<true>(a, ct, pt) : launch_ct<false>(a, ct, pt);
 }
 
 }  // extern "C"

@@ -26,6 +26,7 @@ CASES = [  # N, H, W, Cin, Cout, k, stride, pad
     (1, 37, 41, 3, 64, 7, 2, 3),         # torchvision stem
     (1, 8, 8, 16, 32, 3, 1, 1),          # C_in = 16 through patches
     (3, 1, 1, 64, 96, 1, 1, 0),          # C_out = 96: three blocks of 32
+    (2, 5, 6, 32, 48, 3, 1, 1),          # C_out = 48: three blocks of 16
     (1, 50, 84, 1024, 256, 1, 1, 0),     # input_proj shape of C4 (richsem.py:295-303)
 ]
 
@@ -60,12 +61,30 @@ def test_conv_against_fp32_definition(case, epilogue):
     assert "librichsem_msda.so" in open("/proc/self/maps").read()
 
 
+@pytest.mark.parametrize("co_tiles,pixel_tiles", [(1, 1), (2, 3), (4, 2), (8, 1), (16, 3), (16, 1), (8, 2)])
+def test_every_tile_shape_gives_the_same_result(co_tiles, pixel_tiles):
+    from richsem_amd.conv import ConvAffine, set_tiling, to_nhwc_bf16
+    torch.manual_seed(5)
+    x = torch.randn(2, 64, 19, 23).to(torch.bfloat16)
+    w = (torch.randn(256, 64, 3, 3) * 576 ** -0.5).to(torch.bfloat16).float()
+    ref = torch.relu(F.conv2d(x.float(), w, stride=1, padding=1))
+    conv = ConvAffine(w.cuda(), None, None, 1, 1, relu=True)
+    try:
+        set_tiling(co_tiles, pixel_tiles)
+        got = conv(to_nhwc_bf16(x.cuda())).permute(0, 3, 1, 2).float().cpu()
+    finally:
+        set_tiling(0, 0)
+    assert float(((got - ref).abs() / (ref.abs() + 1.0)).max()) < 2 ** -7
+
+
 def test_errors():
     from richsem_amd.conv import ConvAffine
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         ConvAffine(torch.zeros(32, 32, 1, 1))
     with pytest.raises(AssertionError):
         ConvAffine(torch.zeros(24, 32, 1, 1, device="cuda"))
+    with pytest.raises(RuntimeError, match="BAD_DIMS"):
+        ConvAffine(torch.zeros(32, 40, 5, 5, device="cuda"))       # C_in neither a multiple of 32 nor a few-channel input
     conv = ConvAffine(torch.zeros(32, 32, 1, 1, device="cuda"))
     with pytest.raises(AssertionError):
         conv(torch.zeros(1, 4, 4, 32, device="cuda"))            # fp32 input

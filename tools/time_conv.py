@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Tuning aid: the MFMA convolution (csrc/conv_mfma.hip) at the convolution shapes of ResNet-50 / CLIP-RN50 on an 800 x 1344 batch of 2,
+against torch.nn.functional.conv2d (MIOpen) in bf16 channels-last with the affine + ReLU as separate ops.
+
+    python tools/time_conv.py [--reps 10]
+"""
+import argparse
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from richsem_amd.conv import ConvAffine   # noqa: E402
+
+SHAPES = [  # name, H, W, Cin, Cout, k, stride, pad   (N = 2; torchvision ResNet-50 v1.5 at 800 x 1344)
+    ("stem 7x7 s2", 800, 1344, 3, 64, 7, 2, 3),
+    ("l1 1x1 64-64", 200, 336, 64, 64, 1, 1, 0),
+    ("l1 3x3 64", 200, 336, 64, 64, 3, 1, 1),
+    ("l1 1x1 64-256", 200, 336, 64, 256, 1, 1, 0),
+    ("l1 1x1 256-64", 200, 336, 256, 64, 1, 1, 0),
+    ("l2 3x3 128", 100, 168, 128, 128, 3, 1, 1),
+    ("l2 1x1 128-512", 100, 168, 128, 512, 1, 1, 0),
+    ("l2 1x1 512-128", 100, 168, 512, 128, 1, 1, 0),
+    ("l3 3x3 256", 50, 84, 256, 256, 3, 1, 1),
+    ("l3 1x1 256-1024", 50, 84, 256, 1024, 1, 1, 0),
+    ("l3 1x1 1024-256", 50, 84, 1024, 256, 1, 1, 0),
+    ("l4 3x3 512", 25, 42, 512, 512, 3, 1, 1),
+    ("l4 1x1 512-2048", 25, 42, 512, 2048, 1, 1, 0),
+    ("l4 1x1 2048-512", 25, 42, 2048, 512, 1, 1, 0),
+    ("l3 3x3 s2 256", 100, 168, 256, 256, 3, 2, 1),
+]
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=10)
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    N = 2
+    print(f"{'shape':18s} {'GFLOP':>7s} {'mfma us':>8s} {'TFLOP/s':>8s} {'of peak':>8s} {'MIOpen bf16 us':>15s} {'(+bn+relu)':>11s}")
+    tot = [0.0, 0.0, 0.0, 0.0]
+    for name, H, W, Cin, Cout, k, stride, pad in SHAPES:
+        x = torch.randn(N, H, W, Cin, device="cuda").to(torch.bfloat16)
+        w = torch.randn(Cout, Cin, k, k, device="cuda") * (Cin * k * k) ** -0.5
+        scale, shift = 1 + 0.1 * torch.randn(Cout, device="cuda"), 0.1 * torch.randn(Cout, device="cuda")
+        conv = ConvAffine(w, scale, shift, stride, pad, relu=True)
+        Ho, Wo = conv.out_hw(H, W)
+        flop = 2.0 * N * Ho * Wo * Cout * Cin * k * k
+        t = timeit(lambda: conv(x), args.reps)
+        xc = x.permute(0, 3, 1, 2)     # NCHW view of channels-last memory
+        wc = w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        s16, b16 = scale.to(torch.bfloat16)[None, :, None, None], shift.to(torch.bfloat16)[None, :, None, None]
+        t_conv = timeit(lambda: F.conv2d(xc, wc, stride=stride, padding=pad), args.reps)
+        t_full = timeit(lambda: torch.relu(F.conv2d(xc, wc, stride=stride, padding=pad) * s16 + b16), args.reps)
+        print(f"{name:18s} {flop / 1e9:7.2f} {t:8.1f} {flop / t / 1e6:8.1f} {flop / t / 1e6 / 2500:8.3f} {t_conv:15.1f} {t_full:11.1f}")
+        tot[0] += flop; tot[1] += t; tot[2] += t_conv; tot[3] += t_full
+    print(f"{'sum':18s} {tot[0] / 1e9:7.2f} {tot[1]:8.1f} {tot[0] / tot[1] / 1e6:8.1f} {tot[0] / tot[1] / 1e6 / 2500:8.3f} {tot[2]:15.1f} {tot[3]:11.1f}")
+
+
+if __name__ == "__main__":
+    main()
