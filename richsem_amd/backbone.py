@@ -1,0 +1,105 @@
+"""The detector backbone's forward on the MFMA convolution kernel: ResNet-50 with FrozenBatchNorm2d
+(models/richsem/backbone.py:20-56, :123-158: torchvision's resnet50 with ``norm_layer = FrozenBatchNorm2d``, stages layer2..layer4
+returned for the 4-scale configuration) and the input projections models/richsem/richsem.py:295-310, :593-612 (1 x 1 convolution +
+GroupNorm(32) per stage, 3 x 3 stride-2 convolution + GroupNorm for the extra level).
+
+torchvision is a third-party dependency outside the reference tree (``torchvision>=0.6.0``, unpinned) and absent from the image; the
+architecture restated here is its published ResNet-50 v1.5 (stem 7 x 7 stride 2 + 3 x 3 stride-2 max pool; bottlenecks [3, 4, 6, 3] with
+the stride on the 3 x 3 convolution; projection shortcut = 1 x 1 stride-s convolution + norm), read from the parameter names of its
+``state_dict`` (conv1, bn1, layer{1..4}.{i}.conv{1,2,3} / bn{1,2,3} / downsample.{0,1}).  **Forward only**: the frozen affine, the ReLU
+and the residual add run in the convolution's epilogue, activations are NHWC bf16.  The backward of the trained stages (layer2-4) is
+not built; training them still needs a library convolution backward.
+"""
+import torch
+import torch.nn.functional as F
+
+from .conv import ConvAffine, fold_bn, to_nhwc_bf16
+
+
+def _conv_bn(sd, conv, bn, dev, stride=1, padding=0, relu=True):
+    scale, shift = fold_bn(sd[bn + ".weight"].to(dev), sd[bn + ".bias"].to(dev), sd[bn + ".running_mean"].to(dev),
+                           sd[bn + ".running_var"].to(dev), 1e-5)                     # backbone.py:51-55
+    return ConvAffine(sd[conv + ".weight"].to(dev), scale, shift, stride, padding, relu)
+
+
+class _Bottleneck:
+    def __init__(self, sd, p, stride, dev):
+        self.conv1 = _conv_bn(sd, p + "conv1", p + "bn1", dev)
+        self.conv2 = _conv_bn(sd, p + "conv2", p + "bn2", dev, stride=stride, padding=1)
+        self.conv3 = _conv_bn(sd, p + "conv3", p + "bn3", dev, relu=True)              # relu after the residual add: fused
+        self.down = _conv_bn(sd, p + "downsample.0", p + "downsample.1", dev, stride=stride, relu=False) \
+            if p + "downsample.0.weight" in sd else None
+
+    def __call__(self, x):
+        identity = x if self.down is None else self.down(x)
+        return self.conv3(self.conv2(self.conv1(x)), residual=identity)
+
+
+class ResNet50Frozen:
+    """``state_dict``: torchvision resnet's (any depth with bottleneck blocks).  ``__call__(images)`` returns the NHWC bf16 outputs of
+    the stages named in ``return_layers`` (default layer2, layer3, layer4 = backbone.py's return_interm_indices [1, 2, 3])."""
+
+    def __init__(self, state_dict, return_layers=(2, 3, 4), device="cuda"):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("Not implemented on the CPU")
+        sd = {k: v.detach() for k, v in state_dict.items()}
+        self.stem = _conv_bn(sd, "conv1", "bn1", dev, stride=2, padding=3)
+        self.layers = []
+        for li in range(1, 5):
+            blocks, b = [], 0
+            while f"layer{li}.{b}.conv1.weight" in sd:
+                blocks.append(_Bottleneck(sd, f"layer{li}.{b}.", 2 if (li > 1 and b == 0) else 1, dev))
+                b += 1
+            self.layers.append(blocks)
+        self.return_layers = tuple(return_layers)
+        self.num_channels = [sd[f"layer{li}.0.conv3.weight"].shape[0] for li in self.return_layers]
+
+    @torch.no_grad()
+    def __call__(self, images):
+        x = self.stem(to_nhwc_bf16(images))
+        x = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()     # PyTorch op on the channels-last view
+        outs = []
+        for li, blocks in enumerate(self.layers, start=1):
+            for blk in blocks:
+                x = blk(x)
+            if li in self.return_layers:
+                outs.append(x)
+        return outs
+
+
+class InputProj:
+    """richsem.py:295-310 / :593-612: ``input_proj[l]`` = Conv2d(C_l, 256, 1) + GroupNorm(32, 256) on stage l, and for every further
+    level Conv2d(., 256, 3, stride 2, padding 1) + GroupNorm on the last stage's map (then on the previous extra level).  Built from the
+    ``input_proj.*`` entries of the model's state_dict (``input_proj.{l}.0.weight / .bias`` convolution, ``.1.weight / .bias`` norm).
+    Returns per level the projected map as the (N, H_l W_l, 256) token matrix the encoder consumes, and its (H_l, W_l)."""
+
+    def __init__(self, state_dict, device="cuda", groups=32):
+        dev = torch.device(device)
+        sd = {k: v.detach().to(dev) for k, v in state_dict.items()}
+        self.convs, self.norms, self.groups = [], [], groups
+        l = 0
+        while f"{l}.0.weight" in sd:
+            w = sd[f"{l}.0.weight"]
+            k = w.shape[-1]
+            self.convs.append(ConvAffine(w, None, sd[f"{l}.0.bias"], stride=1 if k == 1 else 2, padding=0 if k == 1 else 1, relu=False))
+            self.norms.append((sd[f"{l}.1.weight"].float(), sd[f"{l}.1.bias"].float()))
+            l += 1
+
+    @torch.no_grad()
+    def __call__(self, features, out_dtype=torch.float32):
+        srcs, shapes = [], []
+        n_stage = len(features)
+        for l, conv in enumerate(self.convs):
+            if l < n_stage:
+                y = conv(features[l])
+            elif l == n_stage:
+                y = conv(features[-1])                                   # richsem.py:604
+            else:
+                y = conv(prev)                                           # :606 (the previous projected level, after its norm)
+            N, H, W, C = y.shape
+            g = F.group_norm(y.permute(0, 3, 1, 2).float(), self.groups, self.norms[l][0], self.norms[l][1], 1e-5)
+            prev = g.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+            srcs.append(g.permute(0, 2, 3, 1).reshape(N, H * W, C).to(out_dtype))
+            shapes.append((H, W))
+        return srcs, shapes
