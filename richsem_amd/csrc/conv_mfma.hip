@@ -39,8 +39,6 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kWaves = 4;
-constexpr int kPixWave = 48;
-constexpr int kPixWg = kPixWave * kWaves;
 constexpr int kFragShorts = 512;
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b)
@@ -55,18 +53,33 @@ struct ConvGeom {
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
 };
 
+// Operand orders that make the memory accesses wide (both are permutations INSIDE the product, fixed by C_in / C_out alone, applied
+// by msda_conv_pack_weight and undone nowhere):
+//   * output channels: inside every group of G = min(4, largest power of two dividing C_out / 16) row tiles, row 4 q + i of tile u is
+//     channel q (4 G) + 4 u + i of the group -- so lane group q of an accumulator holds 4 G CONSECUTIVE channels of its pixel across the
+//     group's tiles (32 bytes of bf16 for G = 4: the four lane groups of a pixel write one 128-byte line);
+//   * input channels, when C_in % 64 == 0: k-steps are taken in pairs over 64 channels, lane group q covering channels 16 q + 8 h + 0..7
+//     in step h of the pair -- so a lane loads 32 consecutive bytes per pair and the four lane groups of a pixel read a whole line.
+__host__ __device__ inline int conv_group(int Cout)
+{
+    const int tiles = Cout / 16;
+    return tiles % 4 == 0 ? 4 : (tiles % 2 == 0 ? 2 : 1);
+}
+
 // weight (Cout, Cin, KH, KW) fp32, torch layout -> packed[k-step][row tile][lane][8] bf16, K = KH KW Cin padded to Kpad (multiple of 32);
-// lane (r, q) = output channel 16 tile + r, k = 32 step + 8 q + 0..7.  small_c = 0: k = (kh KW + kw) Cin + ci with Cin % 32 == 0 (a k-step
-// is one tap and 32 channels); small_c = 1: the same flat order for any Cin, zero beyond KH KW Cin.
+// flat k = (kh KW + kw) Cin + ci, zero beyond KH KW Cin, with the two permutations above.
 __global__ void conv_pack_kernel(const float *__restrict__ w, uint16_t *__restrict__ packed, int Cout, int Cin, int KH, int KW, int Kpad)
 {
-    const int tiles = Cout / 16, K = KH * KW * Cin;
+    const int tiles = Cout / 16, K = KH * KW * Cin, G = conv_group(Cout);
+    const bool pairs = Cin % 64 == 0;
     const long long n = (long long)Cout * Kpad;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
         const long long r = i >> 9;
         const int tile = (int)(r % tiles), s = (int)(r / tiles);
-        const int co = tile * 16 + (lane & 15), k = 32 * s + 8 * (lane >> 4) + j;
+        const int row = lane & 15, q = lane >> 4;
+        const int co = (tile / G) * 16 * G + (row >> 2) * 4 * G + 4 * (tile % G) + (row & 3);
+        const int k = pairs ? 64 * (s >> 1) + 16 * q + 8 * (s & 1) + j : 32 * s + 8 * q + j;
         float v = 0.f;
         if (k < K) {
             const int ci = k % Cin, tap = k / Cin, kh = tap / KW, kw = tap - kh * KW;
@@ -76,13 +89,18 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, uint16_t *__restri
     }
 }
 
-template <int CO_TILES, int PT, bool SMALLC>
+// MODE 0: few-channel input (fragments gathered element by element through a table); 1: C_in % 32 == 0, one k-step per barrier;
+// 2: C_in % 64 == 0, two k-steps (one 32-byte load per lane and pixel) per barrier.
+template <int CO_TILES, int PT, int MODE>
 __global__ __launch_bounds__(kWaves * 64)
 void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wpk, const float *__restrict__ scale,
                      const float *__restrict__ shift, const uint16_t *__restrict__ residual, uint16_t *__restrict__ out, ConvGeom g,
                      int relu)
 {
-    __shared__ __attribute__((aligned(16))) short wbuf[2][CO_TILES * kFragShorts];
+    constexpr bool SMALLC = MODE == 0;
+    constexpr int KT = MODE == 2 ? 2 : 1;
+    constexpr int G = CO_TILES >= 4 ? 4 : CO_TILES;          // == conv_group(C_out): the host only launches matching shapes
+    __shared__ __attribute__((aligned(16))) short wbuf[2][KT * CO_TILES * kFragShorts];
     __shared__ unsigned lut[SMALLC ? 512 : 1];     // k -> kh << 20 | kw << 12 | ci   (0xFFFFFFFF: padding)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -90,7 +108,8 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
     const long long P = (long long)g.N * g.Ho * g.Wo;
     const long long pix0 = (long long)blockIdx.x * (kWaves * 16 * PT) + wave * (16 * PT);
     const int Ktot = g.KH * g.KW * g.Cin;
-    const int cpb = SMALLC ? 1 : g.Cin / 32, S = SMALLC ? (Ktot + 31) / 32 : g.KH * g.KW * cpb;
+    const int cpb = SMALLC ? 1 : g.Cin / (32 * KT);                                    // iterations per tap
+    const int S = SMALLC ? (Ktot + 31) / 32 : g.KH * g.KW * cpb;                      // iterations (KT k-steps each)
     const int tiles_all = g.Cout / 16;
     const int co0 = blockIdx.y * (16 * CO_TILES);
 
@@ -124,17 +143,18 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
 #pragma unroll
         for (int t = 0; t < CO_TILES; ++t) acc[t3][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // weights: this channel block's row tiles of k-step s -> registers -> LDS
-    constexpr int kTileChunks = CO_TILES * kFragShorts * 2 / 16;                       // 16-byte chunks per tile
+    // weights: this channel block's row tiles of the iteration's k-steps -> registers -> LDS
+    constexpr int kStepChunks = CO_TILES * kFragShorts * 2 / 16;                       // 16-byte chunks per k-step
+    constexpr int kTileChunks = KT * kStepChunks;
     constexpr int kChunks = (kTileChunks + kWaves * 64 - 1) / (kWaves * 64);
     const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(wpk + (size_t)blockIdx.y * CO_TILES * kFragShorts);
     const size_t step_chunks = (size_t)tiles_all * kFragShorts * 2 / 16;
     u32x4 stage[kChunks];
-    auto fetch = [&](int s) {
+    auto fetch = [&](int it) {
 #pragma unroll
         for (int i = 0; i < kChunks; ++i) {
             const int idx = tid + i * (kWaves * 64);
-            if (idx < kTileChunks) stage[i] = wsrc[(size_t)s * step_chunks + idx];
+            if (idx < kTileChunks) stage[i] = wsrc[(size_t)(KT * it + idx / kStepChunks) * step_chunks + idx % kStepChunks];
         }
     };
     auto park = [&](int slot) {
@@ -145,8 +165,8 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
             if (idx < kTileChunks) dst[idx] = stage[i];
         }
     };
-    // im2col fragment of a k-step for the lane's pixels: (tap kh, kw; channel block cb), or k-step cb through the table
-    auto gather = [&](int kh, int kw, int cb, bf16x8 *b) {
+    // im2col fragments of an iteration for the lane's pixels: (tap kh, kw; channel block cb), or k-step cb through the table
+    auto gather = [&](int kh, int kw, int cb, bf16x8 (*b)[PT]) {
         if (SMALLC) {
             unsigned e[8];
 #pragma unroll
@@ -162,21 +182,24 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
                     const unsigned short u = x[off];
                     v[j] = in ? u : (unsigned short)0;
                 }
-                b[t3] = (bf16x8){(short)v[0], (short)v[1], (short)v[2], (short)v[3], (short)v[4], (short)v[5], (short)v[6], (short)v[7]};
+                b[0][t3] = (bf16x8){(short)v[0], (short)v[1], (short)v[2], (short)v[3], (short)v[4], (short)v[5], (short)v[6], (short)v[7]};
             }
         } else {
 #pragma unroll
             for (int t3 = 0; t3 < PT; ++t3) {
                 const int hi = hi0[t3] + kh, wi = wi0[t3] + kw;
                 const bool in = hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
-                const long long off = in ? ((img[t3] + (long long)hi * g.W + wi) * g.Cin + 32 * cb + 8 * q) : 0;
-                const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + off);
-                b[t3] = in ? v : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                const long long off = in ? ((img[t3] + (long long)hi * g.W + wi) * g.Cin + 32 * KT * cb + 8 * KT * q) : 0;
+#pragma unroll
+                for (int h = 0; h < KT; ++h) {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + off + 8 * h);
+                    b[h][t3] = in ? v : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                }
             }
         }
     };
 
-    bf16x8 bcur[PT], bnext[PT];
+    bf16x8 bcur[KT][PT], bnext[KT][PT];
     int kh = 0, kw = 0, cb = 0;
     if (SMALLC) __syncthreads();      // the table
     gather(0, 0, 0, bnext);
@@ -186,7 +209,9 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
 
     for (int s = 0; s < S; ++s) {
 #pragma unroll
-        for (int t3 = 0; t3 < PT; ++t3) bcur[t3] = bnext[t3];
+        for (int h = 0; h < KT; ++h)
+#pragma unroll
+            for (int t3 = 0; t3 < PT; ++t3) bcur[h][t3] = bnext[h][t3];
         if (s + 1 < S) {
             if (++cb == cpb && !SMALLC) {
                 cb = 0;
@@ -197,35 +222,59 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
         }
         const short *wt = wbuf[s & 1];
 #pragma unroll
-        for (int t = 0; t < CO_TILES; ++t) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wt + t * kFragShorts + lane * 8);
+        for (int h = 0; h < KT; ++h)
 #pragma unroll
-            for (int t3 = 0; t3 < PT; ++t3) acc[t3][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[t3], acc[t3][t], 0, 0, 0);
-        }
+            for (int t = 0; t < CO_TILES; ++t) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wt + (h * CO_TILES + t) * kFragShorts + lane * 8);
+#pragma unroll
+                for (int t3 = 0; t3 < PT; ++t3) acc[t3][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[h][t3], acc[t3][t], 0, 0, 0);
+            }
         if (s + 1 < S) park((s + 1) & 1);
         __syncthreads();
     }
 
-    // epilogue: lane (c, q) holds channels co0 + 16 t + 4 q + 0..3 of pixel c: affine, residual, relu, 8-byte store
+    // epilogue: lane (c, q) holds, for every group of G tiles, the 4 G consecutive channels co0 + 16 G grp + 4 G q + (4 u + i) of pixel c
+    // (tile u of the group, register i): affine, residual, relu, one 8 G-byte store
 #pragma unroll
     for (int t3 = 0; t3 < PT; ++t3) {
         const long long p = pix0 + 16 * t3 + c;
         if (p >= P) continue;
 #pragma unroll
-        for (int t = 0; t < CO_TILES; ++t) {
-            const int co = co0 + 16 * t + 4 * q;
-            const float4 sc = *reinterpret_cast<const float4 *>(scale + co), sh = *reinterpret_cast<const float4 *>(shift + co);
-            float y0 = fmaf(acc[t3][t][0], sc.x, sh.x), y1 = fmaf(acc[t3][t][1], sc.y, sh.y);
-            float y2 = fmaf(acc[t3][t][2], sc.z, sh.z), y3 = fmaf(acc[t3][t][3], sc.w, sh.w);
-            if (residual) {
-                const uint2 r = *reinterpret_cast<const uint2 *>(residual + p * g.Cout + co);
-                y0 += bf16_lo(r.x); y1 += bf16_hi(r.x); y2 += bf16_lo(r.y); y3 += bf16_hi(r.y);
+        for (int grp = 0; grp < CO_TILES / G; ++grp) {
+            const int co = co0 + 16 * G * grp + 4 * G * q;
+            float y[4 * G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const float4 sc = *reinterpret_cast<const float4 *>(scale + co + 4 * u), sh = *reinterpret_cast<const float4 *>(shift + co + 4 * u);
+                y[4 * u + 0] = fmaf(acc[t3][grp * G + u][0], sc.x, sh.x);
+                y[4 * u + 1] = fmaf(acc[t3][grp * G + u][1], sc.y, sh.y);
+                y[4 * u + 2] = fmaf(acc[t3][grp * G + u][2], sc.z, sh.z);
+                y[4 * u + 3] = fmaf(acc[t3][grp * G + u][3], sc.w, sh.w);
             }
-            if (relu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
-            uint2 o;
-            o.x = pack_bf16(y0, y1);
-            o.y = pack_bf16(y2, y3);
-            *reinterpret_cast<uint2 *>(out + p * g.Cout + co) = o;
+            if (residual) {
+                const uint2 *rp = reinterpret_cast<const uint2 *>(residual + p * g.Cout + co);
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const uint2 r = rp[u];
+                    y[4 * u + 0] += bf16_lo(r.x); y[4 * u + 1] += bf16_hi(r.x); y[4 * u + 2] += bf16_lo(r.y); y[4 * u + 3] += bf16_hi(r.y);
+                }
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4 * G; ++e) y[e] = fmaxf(y[e], 0.f);
+            }
+            unsigned o[2 * G];
+#pragma unroll
+            for (int e = 0; e < 2 * G; ++e) o[e] = pack_bf16(y[2 * e], y[2 * e + 1]);
+            uint16_t *dst = out + p * g.Cout + co;
+            if (G == 4) {
+                reinterpret_cast<u32x4 *>(dst)[0] = (u32x4){o[0], o[1], o[2], o[3]};
+                reinterpret_cast<u32x4 *>(dst)[1] = (u32x4){o[4 % (2 * G)], o[5 % (2 * G)], o[6 % (2 * G)], o[7 % (2 * G)]};
+            } else if (G == 2) {
+                reinterpret_cast<u32x4 *>(dst)[0] = (u32x4){o[0], o[1], o[2 % (2 * G)], o[3 % (2 * G)]};
+            } else {
+                reinterpret_cast<uint2 *>(dst)[0] = make_uint2(o[0], o[1]);
+            }
         }
     }
 }
@@ -240,36 +289,36 @@ struct ConvArgs {
     hipStream_t stream;
 };
 
-template <int CO_TILES, int PT, bool SMALLC>
+template <int CO_TILES, int PT, int MODE>
 int launch_conv(const ConvArgs &a)
 {
     const long long P = (long long)a.g.N * a.g.Ho * a.g.Wo;
     const dim3 grid((unsigned)((P + kWaves * 16 * PT - 1) / (kWaves * 16 * PT)), (unsigned)(a.g.Cout / (16 * CO_TILES)));
-    hipLaunchKernelGGL((conv_fwd_kernel<CO_TILES, PT, SMALLC>), grid, dim3(kWaves * 64), 0, a.stream, a.x, a.wpk, a.scale, a.shift,
+    hipLaunchKernelGGL((conv_fwd_kernel<CO_TILES, PT, MODE>), grid, dim3(kWaves * 64), 0, a.stream, a.x, a.wpk, a.scale, a.shift,
                        a.residual, a.out, a.g, a.relu);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
 }
 
-template <int CO_TILES, bool SMALLC>
+template <int CO_TILES, int MODE>
 int launch_pt(const ConvArgs &a, int pt)
 {
     switch (pt) {
-    case 3: return launch_conv<CO_TILES, 3, SMALLC>(a);
-    case 2: return launch_conv<CO_TILES, 2, SMALLC>(a);
-    default: return launch_conv<CO_TILES, 1, SMALLC>(a);
+    case 3: return launch_conv<CO_TILES, 3, MODE>(a);
+    case 2: return launch_conv<CO_TILES, 2, MODE>(a);
+    default: return launch_conv<CO_TILES, 1, MODE>(a);
     }
 }
 
-template <bool SMALLC>
+template <int MODE>
 int launch_ct(const ConvArgs &a, int ct, int pt)
 {
     switch (ct) {
-    case 16: return launch_pt<16, SMALLC>(a, pt);
-    case 8: return launch_pt<8, SMALLC>(a, pt);
-    case 4: return launch_pt<4, SMALLC>(a, pt);
-    case 2: return launch_pt<2, SMALLC>(a, pt);
-    default: return launch_pt<1, SMALLC>(a, pt);
+    case 16: return launch_pt<16, MODE>(a, pt);
+    case 8: return launch_pt<8, MODE>(a, pt);
+    case 4: return launch_pt<4, MODE>(a, pt);
+    case 2: return launch_pt<2, MODE>(a, pt);
+    default: return launch_pt<1, MODE>(a, pt);
     }
 }
 
@@ -282,8 +331,9 @@ void choose_tiling(long long P, int Cout, int &ct, int &pt)
     const int tiles = Cout / 16;
     long long best_n = -1;
     int best_ct = 1, best_pt = 1;
+    const int G = conv_group(Cout);
     for (int c : {16, 8, 4, 2, 1}) {
-        if (tiles % c) continue;
+        if (tiles % c || c % G) continue;      // whole channel groups per wave (the epilogue's wide stores)
         for (int p : {3, 2, 1}) {
             const long long n = ((P + 64 * p - 1) / (64 * p)) * (tiles / c);
             if (n >= 512) { ct = c; pt = p; return; }
@@ -350,11 +400,12 @@ int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, con
     int ct, pt;
     choose_tiling((long long)N * Ho * Wo, Cout, ct, pt);
     const int fct = g_force_ct.load(), fpt = g_force_pt.load();
-    if (fct && (Cout / 16) % fct == 0) ct = fct;
+    if (fct && (Cout / 16) % fct == 0 && fct % conv_group(Cout) == 0) ct = fct;
     if (fpt) pt = fpt;
     const ConvArgs a{x, packed_weight, scale, shift, residual, out, ConvGeom{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad}, relu,
                      static_cast<hipStream_t>(stream)};
-    return small_c ? launch_ct<true>(a, ct, pt) : launch_ct<false>(a, ct, pt);
+    if (small_c) return launch_ct<0>(a, ct, pt);
+    return Cin % 64 == 0 ? launch_ct<2>(a, ct, pt) : launch_ct<1>(a, ct, pt);
 }
 
 }  // extern "C"

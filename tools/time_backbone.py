@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Whole-network timing: ResNet-50 (frozen BN) forward on the MFMA convolution kernel at the training shape (2 x 3 x 800 x 1344) against
+the same network as PyTorch ops (F.conv2d through MIOpen, channels-last bf16 and NCHW fp32 -- the reference's precision).
+
+    python tools/time_backbone.py [--reps 5]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from richsem_amd.backbone import ResNet50Frozen   # noqa: E402
+
+
+def state_dict(seed=0, width=64, layers=(3, 4, 6, 3)):
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = torch.from_numpy(rng.normal(0, (1.2 / (ci * k * k)) ** 0.5, (co, ci, k, k)).astype(np.float32))
+
+    def bn(name, c):
+        sd[name + ".weight"] = torch.from_numpy(rng.uniform(0.3, 0.9, c).astype(np.float32))
+        sd[name + ".bias"] = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32))
+        sd[name + ".running_mean"] = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32))
+        sd[name + ".running_var"] = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32))
+
+    conv("conv1", width, 3, 7); bn("bn1", width)
+    inplanes = width
+    for li, (n, planes) in enumerate(zip(layers, (width, width * 2, width * 4, width * 8)), start=1):
+        for b in range(n):
+            p = f"layer{li}.{b}."
+            conv(p + "conv1", planes, inplanes, 1); bn(p + "bn1", planes)
+            conv(p + "conv2", planes, planes, 3); bn(p + "bn2", planes)
+            conv(p + "conv3", planes * 4, planes, 1); bn(p + "bn3", planes * 4)
+            if b == 0:
+                conv(p + "downsample.0", planes * 4, inplanes, 1); bn(p + "downsample.1", planes * 4)
+            inplanes = planes * 4
+    return sd
+
+
+def torch_net(sd, dtype, channels_last):
+    """the same forward with library convolutions; frozen BN as scale / shift tensors (backbone.py:45-56)"""
+    dev = "cuda"
+    P = {}
+    for k, v in sd.items():
+        if k.endswith(".weight") and v.dim() == 4:
+            w = v.to(dev, dtype)
+            P[k] = w.contiguous(memory_format=torch.channels_last) if channels_last else w
+    for k in list(sd):
+        if k.endswith("running_var"):
+            p = k[: -len(".running_var")]
+            scale = sd[p + ".weight"] * (sd[p + ".running_var"] + 1e-5).rsqrt()
+            P[p + ".s"] = scale.to(dev, dtype).reshape(1, -1, 1, 1)
+            P[p + ".b"] = (sd[p + ".bias"] - sd[p + ".running_mean"] * scale).to(dev, dtype).reshape(1, -1, 1, 1)
+
+    def fbn(x, p):
+        return x * P[p + ".s"] + P[p + ".b"]
+
+    def fwd(x):
+        x = x.to(dtype)
+        if channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        x = torch.relu(fbn(F.conv2d(x, P["conv1.weight"], stride=2, padding=3), "bn1"))
+        x = F.max_pool2d(x, 3, 2, 1)
+        outs = []
+        for li in range(1, 5):
+            b = 0
+            while f"layer{li}.{b}.conv1.weight" in P:
+                p = f"layer{li}.{b}."
+                s = 2 if (li > 1 and b == 0) else 1
+                o = torch.relu(fbn(F.conv2d(x, P[p + "conv1.weight"]), p + "bn1"))
+                o = torch.relu(fbn(F.conv2d(o, P[p + "conv2.weight"], stride=s, padding=1), p + "bn2"))
+                o = fbn(F.conv2d(o, P[p + "conv3.weight"]), p + "bn3")
+                idt = fbn(F.conv2d(x, P[p + "downsample.0.weight"], stride=s), p + "downsample.1") if b == 0 else x
+                x = torch.relu(o + idt)
+                b += 1
+            if li > 1:
+                outs.append(x)
+        return outs
+    return fwd
+
+
+def timeit(fn, reps):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    sd = state_dict()
+    x = torch.randn(2, 3, 800, 1344, device="cuda")
+    net = ResNet50Frozen(sd)
+    ref32 = torch_net(sd, torch.float32, False)
+    ref16 = torch_net(sd, torch.bfloat16, True)
+    want = ref32(x)
+    got = net(x)
+    for g, w, n in zip(got, want, ("C3", "C4", "C5")):
+        e = (g.permute(0, 3, 1, 2).float() - w).abs()
+        print(f"{n}: {tuple(w.shape)}  max err {float(e.max()) / float(w.abs().max()):.3e}  mean err {float(e.mean()) / float(w.abs().max()):.3e} (of the map's max)")
+    e16 = [(a.float() - w).abs().mean().item() / w.abs().max().item() for a, w in zip(ref16(x), want)]
+    print("PyTorch bf16 channels-last against fp32: mean err", " ".join(f"{v:.3e}" for v in e16))
+    flop = 2 * 2 * 4.09e9 * (800 * 1344) / (224 * 224)      # torchvision's 4.09 GMAC at 224 x 224, scaled
+    t = timeit(lambda: net(x), args.reps)
+    t16 = timeit(lambda: ref16(x), args.reps)
+    t32 = timeit(lambda: ref32(x), args.reps)
+    print(f"ResNet-50 forward, 2 x 800 x 1344 (~{flop / 1e9:.0f} GFLOP): MFMA kernels {t:.2f} ms ({flop / t / 1e9:.0f} TFLOP/s, "
+          f"{flop / t / 1e9 / 2500:.3f} of the dense bf16 peak);  PyTorch bf16 channels-last {t16:.2f} ms;  PyTorch fp32 {t32:.2f} ms")
+
+
+if __name__ == "__main__":
+    main()
