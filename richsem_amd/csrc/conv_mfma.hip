@@ -13,7 +13,7 @@
 // Everything is computed TRANSPOSED as in csrc/ffn_mfma.hip: out^T (C_out x pixels) = W (C_out x K) . im2col^T (K x pixels) with
 // mfma_f32_16x16x32_bf16: pixels on the lanes, output channels in the registers.
 //   * a wave owns 16 PT output pixels (PT <= 3 column tiles) x 16 CO_TILES <= 256 output channels (192 accumulators at most); the host
-//     picks (CO_TILES, PT) per call so that the grid fills the chip (deep layers have few pixels: smaller tiles, more workgroups);
+//     picks (CO_TILES, PT) per call (choose_tiling: measured -- small tiles, i.e. more waves per SIMD, win almost everywhere);
 //   * the weights are packed once (msda_conv_pack_weight) into fragment order per (k-step, row tile) and stream through
 //     LDS, double-buffered through registers, one barrier per k-step of 32; all four waves of a workgroup share them;
 //   * the im2col operand is never formed: lane (pixel c, group q) loads x[n, ho s + kh - p, wo s + kw - p, 32 cb + 8 q ..] one k-step
@@ -324,24 +324,19 @@ int launch_ct(const ConvArgs &a, int ct, int pt)
 
 std::atomic<int> g_force_ct{0}, g_force_pt{0};   // tuning: msda_conv_set_tiling
 
-// Tile choice: the largest (channel tiles x pixel tiles) per wave that still gives the chip about two workgroups per CU; when even the
-// smallest does not (deep layers on small inputs), the one with the most workgroups.
-void choose_tiling(long long P, int Cout, int &ct, int &pt)
+// Tile choice (tools/time_conv.py --sweep on MI355X, ResNet-50 shapes at 2 x 800 x 1344): the kernel is bound by latency, not by operand
+// re-use -- small tiles (more waves per SIMD, more workgroups) win almost everywhere: 16 pixels per wave, 128 output channels per wave
+// while that still gives two workgroups per CU, else 64; only wide, shallow 3 x 3 layers (thousands of workgroups) take 48 pixels.
+void choose_tiling(long long P, int Cout, int K, int &ct, int &pt)
 {
-    const int tiles = Cout / 16;
-    long long best_n = -1;
-    int best_ct = 1, best_pt = 1;
-    const int G = conv_group(Cout);
-    for (int c : {16, 8, 4, 2, 1}) {
-        if (tiles % c || c % G) continue;      // whole channel groups per wave (the epilogue's wide stores)
-        for (int p : {3, 2, 1}) {
-            const long long n = ((P + 64 * p - 1) / (64 * p)) * (tiles / c);
-            if (n >= 512) { ct = c; pt = p; return; }
-            if (n > best_n) { best_n = n; best_ct = c; best_pt = p; }
-        }
+    const int tiles = Cout / 16, G = conv_group(Cout);
+    auto n_wg = [&](int c, int p) { return ((P + 64 * p - 1) / (64 * p)) * (tiles / c); };
+    if (G < 4) {
+        ct = G;
+    } else {
+        ct = (tiles % 8 == 0 && n_wg(8, 1) >= 512) ? 8 : 4;
     }
-    ct = best_ct;
-    pt = best_pt;
+    pt = (K >= 288 && n_wg(ct, 1) > 2048) ? 3 : 1;
 }
 
 }  // namespace
@@ -398,7 +393,7 @@ int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, con
          reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(residual) | (small_c ? 0 : reinterpret_cast<uintptr_t>(x))) & 15)
         return MSDA_ERR_MISALIGNED;
     int ct, pt;
-    choose_tiling((long long)N * Ho * Wo, Cout, ct, pt);
+    choose_tiling((long long)N * Ho * Wo, Cout, KH * KW * Cin, ct, pt);
     const int fct = g_force_ct.load(), fpt = g_force_pt.load();
     if (fct && (Cout / 16) % fct == 0 && fct % conv_group(Cout) == 0) ct = fct;
     if (fpt) pt = fpt;

@@ -46,10 +46,35 @@ def timeit(fn, reps):
     return a.elapsed_time(b) / reps * 1e3
 
 
+def sweep(args):
+    from richsem_amd.conv import set_tiling
+    torch.manual_seed(0)
+    N = 2
+    for name, H, W, Cin, Cout, k, stride, pad in SHAPES:
+        x = torch.randn(N, H, W, Cin, device="cuda").to(torch.bfloat16)
+        w = torch.randn(Cout, Cin, k, k, device="cuda") * (Cin * k * k) ** -0.5
+        conv = ConvAffine(w, None, None, stride, pad, relu=True)
+        set_tiling(0, 0)
+        auto = timeit(lambda: conv(x), args.reps)
+        res = []
+        for ct in (16, 8, 4, 2, 1):
+            if (Cout // 16) % ct or (ct < 4 and (Cout // 16) % 4 == 0):
+                continue
+            for pt in (3, 2, 1):
+                set_tiling(ct, pt)
+                res.append((timeit(lambda: conv(x), args.reps), ct, pt))
+        set_tiling(0, 0)
+        res.sort()
+        print(f"{name:18s} auto {auto:7.1f} us | " + "  ".join(f"({ct:2d},{pt}) {t:6.1f}" for t, ct, pt in res[:6]), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--sweep", action="store_true", help="time every tile shape per convolution (msda_conv_set_tiling)")
     args = ap.parse_args()
+    if args.sweep:
+        return sweep(args)
     torch.manual_seed(0)
     N = 2
     print(f"{'shape':18s} {'GFLOP':>7s} {'mfma us':>8s} {'TFLOP/s':>8s} {'of peak':>8s} {'MIOpen bf16 us':>15s} {'(+bn+relu)':>11s}")
