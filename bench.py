@@ -281,6 +281,106 @@ def ffn_row(n_img, dev):
             "pytorch_bf16_ops_us": round(t_o * 1e6, 1)}
 
 
+def _time_events(fn, reps):
+    import torch
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e-3
+
+
+def cls_row(n_img, dev):
+    """Two-stage selection score (second half; NOT part of `value`): row maxima of the class logits of
+    n_img x 22323 encoder tokens against 1204 text embeddings as ONE MFMA kernel on bf16 hi/lo split operands (fp32-level result), against
+    the reference's op sequence (project, normalise, text product, max) as PyTorch fp32 ops.  `flop` counts the MFMA work issued."""
+    import torch
+    from richsem_amd import workload as W
+    from richsem_amd.two_stage import ClassScorer
+    T, C, P = n_img * W.call_E(n_img).S, 1204, 1024
+    g = torch.Generator(device=dev).manual_seed(11)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    mem, wp, text, ls = r(T, 256), r(P, 256) * P ** -0.5, r(C, P), torch.tensor(2.659)
+    sc = ClassScorer(2).prepare(wp, text, ls)
+
+    def ops():
+        f = mem @ wp.t()
+        f = f / f.norm(dim=-1, keepdim=True)
+        tt = text / text.norm(dim=-1, keepdim=True)
+        return (ls.exp().to(dev) * (f @ tt.t())).max(-1)[0]
+
+    want = ops()
+    got = sc.max_logits(mem)
+    err = float((got - want).abs().max() / want.abs().max())
+    flop = 2.0 * T * 256 * (16 * ((C + 15) // 16) + 256) * 3
+    t_f, t_o = _time_events(lambda: sc.max_logits(mem), 20), _time_events(ops, 5)
+    return {"what": "two-stage query selection score: max over 1204 class logits per encoder token, projection + normalisation + text "
+                    "product collapsed onto the 256-wide memory, bf16 hi/lo split operands (three MFMAs per tile), one HIP kernel; "
+                    "outside the timed step", "hip_kernel": "cls_score_kernel<true, 2>", "tokens": T, "flop": flop,
+            "avg_launch_us": round(t_f * 1e6, 1), "max_rel_diff_vs_pytorch_fp32": err,
+            "roofline": {"bound": "mfma", "achieved": round(flop / t_f / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(flop / t_f / 1e12 / 2500.0, 4)},
+            "pytorch_fp32_ops_us": round(t_o * 1e6, 1)}
+
+
+def backbone_row(n_img, dev):
+    """ResNet-50 (frozen BatchNorm) forward at the training shape n_img x 3 x 800 x 1344 on the MFMA convolution kernel (SURVEY.md
+    section 8a row a10, forward; NOT part of `value`): 53 convolutions with affine / ReLU / residual in their epilogues, NHWC bf16,
+    against the same network as PyTorch convolutions (MIOpen) in channels-last bf16.  Synthetic weights."""
+    import torch
+    import torch.nn.functional as F
+    from richsem_amd import workload as W
+    from richsem_amd.backbone import ResNet50Frozen
+    from richsem_amd.conv import ConvAffine
+    sd = W.resnet50_state_dict()
+    net = ResNet50Frozen(sd, device=dev)
+    x = torch.randn(n_img, 3, 800, 1344, device=dev, generator=torch.Generator(device=dev).manual_seed(13))
+    ConvAffine.flop_counter = [0.0]
+    net(x)
+    flop = ConvAffine.flop_counter[0]
+    ConvAffine.flop_counter = None
+
+    P = {}
+    for k, v in sd.items():
+        if v.dim() == 4:
+            P[k] = v.to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    for k in sd:
+        if k.endswith("running_var"):
+            p = k[: -len(".running_var")]
+            scale = sd[p + ".weight"] * (sd[p + ".running_var"] + 1e-5).rsqrt()
+            P[p + ".s"] = scale.to(dev, torch.bfloat16).reshape(1, -1, 1, 1)
+            P[p + ".b"] = (sd[p + ".bias"] - sd[p + ".running_mean"] * scale).to(dev, torch.bfloat16).reshape(1, -1, 1, 1)
+
+    def ops():
+        y = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        y = torch.relu(F.conv2d(y, P["conv1.weight"], stride=2, padding=3) * P["bn1.s"] + P["bn1.b"])
+        y = F.max_pool2d(y, 3, 2, 1)
+        for li in range(1, 5):
+            b = 0
+            while f"layer{li}.{b}.conv1.weight" in P:
+                p, s = f"layer{li}.{b}.", 2 if (li > 1 and b == 0) else 1
+                o = torch.relu(F.conv2d(y, P[p + "conv1.weight"]) * P[p + "bn1.s"] + P[p + "bn1.b"])
+                o = torch.relu(F.conv2d(o, P[p + "conv2.weight"], stride=s, padding=1) * P[p + "bn2.s"] + P[p + "bn2.b"])
+                o = F.conv2d(o, P[p + "conv3.weight"]) * P[p + "bn3.s"] + P[p + "bn3.b"]
+                idt = (F.conv2d(y, P[p + "downsample.0.weight"], stride=s) * P[p + "downsample.1.s"] + P[p + "downsample.1.b"]) if b == 0 else y
+                y = torch.relu(o + idt)
+                b += 1
+        return y
+
+    t_f, t_o = _time_events(lambda: net(x), 5), _time_events(ops, 3)
+    return {"what": "ResNet-50 + FrozenBatchNorm2d forward (53 convolutions, affine / relu / residual in the epilogues), NHWC bf16, "
+                    "HIP implicit-GEMM kernel; outside the timed step; forward only", "hip_kernel": "conv_fwd_kernel<CO_TILES, PT, MODE>",
+            "input": [n_img, 3, 800, 1344], "flop": flop, "ms": round(t_f * 1e3, 3),
+            "roofline": {"bound": "mfma", "achieved": round(flop / t_f / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(flop / t_f / 1e12 / 2500.0, 4)},
+            "pytorch_bf16_channels_last_ms": round(t_o * 1e3, 3)}
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -473,6 +573,7 @@ def main(argv=None):
                                     "ms_per_step": round(graph_ms, 4), "img_per_s": round(n_total / (graph_ms * 1e-3), 3)}
         if not args.no_ffn:
             line["mfma_row"] = ffn_row(n_img, dev)
+            line["mfma_rows"] = {"two_stage_class_score": cls_row(n_img, dev), "resnet50_forward": backbone_row(n_img, dev)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(calls, n_img)
         else:

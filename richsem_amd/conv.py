@@ -34,6 +34,8 @@ class ConvAffine:
     (C_out) fp32 (``None``: identity / zero).  C_out must be a multiple of 16; C_in a multiple of 32, or KH KW C_in <= 512 (the
     3-channel stems)."""
 
+    flop_counter = None      # set to [0.0] to add up 2 * MACs of the calls that follow (bench.py's MFMA rows)
+
     def __init__(self, weight, scale=None, shift=None, stride=1, padding=0, relu=False):
         if not weight.is_cuda:
             raise RuntimeError("Not implemented on the CPU")
@@ -63,6 +65,8 @@ class ConvAffine:
         x = x.contiguous()
         N, H, W, _ = x.shape
         Ho, Wo = self.out_hw(H, W)
+        if ConvAffine.flop_counter is not None:
+            ConvAffine.flop_counter[0] += 2.0 * N * Ho * Wo * self.Cout * self.Cin * self.KH * self.KW
         out = torch.empty((N, Ho, Wo, self.Cout), dtype=torch.bfloat16, device=x.device)
         if residual is not None:
             assert residual.shape == out.shape and residual.dtype == torch.bfloat16

@@ -167,3 +167,39 @@ def training_step_calls(N=2):
 # 5.6 M, 6 encoder layers 7.7 M, 6 decoder layers 9.3 M, heads / embeddings 1.7 M; reference main.py:204-206)
 GRAD_ALLREDUCE_ELEMS = 47_600_000
 DDP_BUCKET_BYTES = 25 * 1024 * 1024   # torch DDP's default bucket_cap_mb
+
+
+def resnet50_state_dict(seed=0, width=64, layers=(3, 4, 6, 3)):
+    """Synthetic parameters with the names and shapes of torchvision's ResNet-50 ``state_dict`` (no checkpoint is available offline):
+    convolutions at He scale, frozen-BatchNorm statistics spread around (0, 1).  Used by bench.py's backbone row and tools/."""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = torch.from_numpy(rng.normal(0, (1.2 / (ci * k * k)) ** 0.5, (co, ci, k, k)).astype(np.float32))
+
+    def bn(name, c):
+        sd[name + ".weight"] = torch.from_numpy(rng.uniform(0.3, 0.9, c).astype(np.float32))
+        sd[name + ".bias"] = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32))
+        sd[name + ".running_mean"] = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32))
+        sd[name + ".running_var"] = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32))
+
+    conv("conv1", width, 3, 7)
+    bn("bn1", width)
+    inplanes = width
+    for li, (n, planes) in enumerate(zip(layers, (width, width * 2, width * 4, width * 8)), start=1):
+        for b in range(n):
+            p = f"layer{li}.{b}."
+            conv(p + "conv1", planes, inplanes, 1)
+            bn(p + "bn1", planes)
+            conv(p + "conv2", planes, planes, 3)
+            bn(p + "bn2", planes)
+            conv(p + "conv3", planes * 4, planes, 1)
+            bn(p + "bn3", planes * 4)
+            if b == 0:
+                conv(p + "downsample.0", planes * 4, inplanes, 1)
+                bn(p + "downsample.1", planes * 4)
+            inplanes = planes * 4
+    return sd

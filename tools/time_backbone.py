@@ -17,31 +17,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from richsem_amd.backbone import ResNet50Frozen   # noqa: E402
 
 
-def state_dict(seed=0, width=64, layers=(3, 4, 6, 3)):
-    rng = np.random.default_rng(seed)
-    sd = {}
-
-    def conv(name, co, ci, k):
-        sd[name + ".weight"] = torch.from_numpy(rng.normal(0, (1.2 / (ci * k * k)) ** 0.5, (co, ci, k, k)).astype(np.float32))
-
-    def bn(name, c):
-        sd[name + ".weight"] = torch.from_numpy(rng.uniform(0.3, 0.9, c).astype(np.float32))
-        sd[name + ".bias"] = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32))
-        sd[name + ".running_mean"] = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32))
-        sd[name + ".running_var"] = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32))
-
-    conv("conv1", width, 3, 7); bn("bn1", width)
-    inplanes = width
-    for li, (n, planes) in enumerate(zip(layers, (width, width * 2, width * 4, width * 8)), start=1):
-        for b in range(n):
-            p = f"layer{li}.{b}."
-            conv(p + "conv1", planes, inplanes, 1); bn(p + "bn1", planes)
-            conv(p + "conv2", planes, planes, 3); bn(p + "bn2", planes)
-            conv(p + "conv3", planes * 4, planes, 1); bn(p + "bn3", planes * 4)
-            if b == 0:
-                conv(p + "downsample.0", planes * 4, inplanes, 1); bn(p + "downsample.1", planes * 4)
-            inplanes = planes * 4
-    return sd
+from richsem_amd.workload import resnet50_state_dict as state_dict   # noqa: E402
 
 
 def torch_net(sd, dtype, channels_last):
@@ -115,7 +91,11 @@ def main():
         print(f"{n}: {tuple(w.shape)}  max err {float(e.max()) / float(w.abs().max()):.3e}  mean err {float(e.mean()) / float(w.abs().max()):.3e} (of the map's max)")
     e16 = [(a.float() - w).abs().mean().item() / w.abs().max().item() for a, w in zip(ref16(x), want)]
     print("PyTorch bf16 channels-last against fp32: mean err", " ".join(f"{v:.3e}" for v in e16))
-    flop = 2 * 2 * 4.09e9 * (800 * 1344) / (224 * 224)      # torchvision's 4.09 GMAC at 224 x 224, scaled
+    from richsem_amd.conv import ConvAffine
+    ConvAffine.flop_counter = [0.0]
+    net(x)
+    flop = ConvAffine.flop_counter[0]
+    ConvAffine.flop_counter = None
     t = timeit(lambda: net(x), args.reps)
     t16 = timeit(lambda: ref16(x), args.reps)
     t32 = timeit(lambda: ref32(x), args.reps)
