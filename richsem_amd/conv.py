@@ -90,3 +90,89 @@ def avg_pool_nhwc(x, k):
         return x
     y = torch.nn.functional.avg_pool2d(x.permute(0, 3, 1, 2), k)
     return y.permute(0, 2, 3, 1).contiguous()
+
+
+# ---- training: the same convolution with gradients ----------------------------------------------------------------------------------
+def _pack(w):
+    L = _lib.load()
+    Cout, Cin, KH, KW = w.shape
+    n = ctypes.c_int64(0)
+    _lib.check(L.msda_conv_packed_elems(Cout, Cin, KH, KW, ctypes.byref(n)))
+    packed = torch.empty(n.value, dtype=torch.int16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(L.msda_conv_pack_weight(w.data_ptr(), Cout, Cin, KH, KW, packed.data_ptr(), _stream(w.device)))
+    return packed
+
+
+class ConvAffineFunction(torch.autograd.Function):
+    """y = act(scale * conv(x, weight) + shift (+ residual)) on NHWC bf16 activations with gradients for x, weight and residual
+    (scale / shift are the frozen BatchNorm's: no gradient, backbone.py:20-56).  Forward: ``msda_conv_forward_bf16``.  Backward: the ReLU
+    mask is a PyTorch element-wise op; the input gradient is ``msda_conv_dgrad_bf16`` (the forward kernel on the zero-upsampled output
+    gradient with the flipped, transposed, scale-folded weight); the WEIGHT gradient is the library's (MIOpen through
+    ``aten::convolution_backward`` on channels-last views) -- this repository has no wgrad kernel yet."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, residual, stride, padding, relu):
+        assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
+        w = weight.detach().float().contiguous()
+        Cout, Cin, KH, KW = w.shape
+        x = x.contiguous()
+        N, H, W, _ = x.shape
+        Ho, Wo = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
+        out = torch.empty((N, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
+        res = residual.contiguous() if residual is not None else None
+        packed = _pack(w)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().msda_conv_forward_bf16(
+                x.data_ptr(), packed.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr() if res is not None else None,
+                N, H, W, Cin, Cout, KH, KW, stride, padding, int(relu), out.data_ptr(), _stream(x.device)))
+        ctx.save_for_backward(x, weight, scale, out if relu else None)
+        ctx.cfg = (stride, padding, relu, residual is not None)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, weight, scale, out = ctx.saved_tensors
+        stride, padding, relu, has_res = ctx.cfg
+        Cout, Cin, KH, KW = weight.shape
+        N, H, W, _ = x.shape
+        dz = dy.contiguous()
+        if relu:
+            dz = dz * (out > 0)                                    # gradient at the ReLU's input (= the residual's gradient)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if Cout % 32 or Cin % 16 or KH != KW:
+                raise RuntimeError("ConvAffineFunction: the input gradient needs C_out % 32 == 0, C_in % 16 == 0 and a square kernel")
+            w_t = (weight.detach().float() * scale.view(-1, 1, 1, 1)).flip(2, 3).permute(1, 0, 2, 3).contiguous()     # (Cin, Cout, KH, KW)
+            packed_t = _pack(w_t)
+            dx = torch.empty_like(x)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.load().msda_conv_dgrad_bf16(dz.data_ptr(), packed_t.data_ptr(), N, dz.shape[1], dz.shape[2], Cout, Cin, KH,
+                                                            KW, stride, padding, H, W, dx.data_ptr(), _stream(x.device)))
+        if ctx.needs_input_grad[1]:
+            g = (dz.float() * scale).to(torch.bfloat16).permute(0, 3, 1, 2)       # gradient at the convolution's output, NCHW view
+            _, dw, _ = torch.ops.aten.convolution_backward(g, x.permute(0, 3, 1, 2), weight.detach().to(torch.bfloat16), None,
+                                                           [stride, stride], [padding, padding], [1, 1], False, [0, 0], 1,
+                                                           [False, True, False])
+            dw = dw.to(weight.dtype)
+        return dx, dw, None, None, (dz if has_res else None), None, None, None
+
+
+class ConvBNAct(torch.nn.Module):
+    """nn.Conv2d(bias = False) + FrozenBatchNorm2d (+ residual) (+ ReLU) as one trainable module on NHWC bf16 activations: ``weight`` is
+    the fp32 parameter under the name nn.Conv2d gives it; the four FrozenBatchNorm2d tensors are buffers (backbone.py:28-33)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, relu=True):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        torch.nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        self.register_buffer("bn_weight", torch.ones(out_channels))
+        self.register_buffer("bn_bias", torch.zeros(out_channels))
+        self.register_buffer("running_mean", torch.zeros(out_channels))
+        self.register_buffer("running_var", torch.ones(out_channels))
+        self.stride, self.padding, self.relu = stride, padding, relu
+
+    def forward(self, x, residual=None):
+        scale, shift = fold_bn(self.bn_weight, self.bn_bias, self.running_mean, self.running_var, 1e-5)
+        return ConvAffineFunction.apply(x, self.weight, scale, shift, residual, self.stride, self.padding, self.relu)

@@ -51,6 +51,7 @@ __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u 
 
 struct ConvGeom {
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+    int up;   // > 1: the input is read as if zero-upsampled by `up` (transposed convolution = gradient w.r.t. the input of a strided one)
 };
 
 // Operand orders that make the memory accesses wide (both are permutations INSIDE the product, fixed by C_in / C_out alone, applied
@@ -187,8 +188,14 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
         } else {
 #pragma unroll
             for (int t3 = 0; t3 < PT; ++t3) {
-                const int hi = hi0[t3] + kh, wi = wi0[t3] + kw;
-                const bool in = hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+                int hi = hi0[t3] + kh, wi = wi0[t3] + kw;
+                bool in = hi >= 0 && wi >= 0;
+                if (g.up > 1) {      // virtual (zero-upsampled) coordinates: only multiples of `up` hold data
+                    in = in && hi % g.up == 0 && wi % g.up == 0;
+                    hi /= g.up;
+                    wi /= g.up;
+                }
+                in = in && hi < g.H && wi < g.W;
                 const long long off = in ? ((img[t3] + (long long)hi * g.W + wi) * g.Cin + 32 * KT * cb + 8 * KT * q) : 0;
 #pragma unroll
                 for (int h = 0; h < KT; ++h) {
@@ -245,7 +252,8 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
             float y[4 * G];
 #pragma unroll
             for (int u = 0; u < G; ++u) {
-                const float4 sc = *reinterpret_cast<const float4 *>(scale + co + 4 * u), sh = *reinterpret_cast<const float4 *>(shift + co + 4 * u);
+                const float4 sc = scale ? *reinterpret_cast<const float4 *>(scale + co + 4 * u) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float4 sh = shift ? *reinterpret_cast<const float4 *>(shift + co + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
                 y[4 * u + 0] = fmaf(acc[t3][grp * G + u][0], sc.x, sh.x);
                 y[4 * u + 1] = fmaf(acc[t3][grp * G + u][1], sc.y, sh.y);
                 y[4 * u + 2] = fmaf(acc[t3][grp * G + u][2], sc.z, sh.z);
@@ -397,10 +405,35 @@ int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, con
     const int fct = g_force_ct.load(), fpt = g_force_pt.load();
     if (fct && (Cout / 16) % fct == 0 && fct % conv_group(Cout) == 0) ct = fct;
     if (fpt) pt = fpt;
-    const ConvArgs a{x, packed_weight, scale, shift, residual, out, ConvGeom{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad}, relu,
+    const ConvArgs a{x, packed_weight, scale, shift, residual, out, ConvGeom{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, 1}, relu,
                      static_cast<hipStream_t>(stream)};
     if (small_c) return launch_ct<0>(a, ct, pt);
     return Cin % 64 == 0 ? launch_ct<2>(a, ct, pt) : launch_ct<1>(a, ct, pt);
+}
+
+/* Gradient of msda_conv_forward_bf16 w.r.t. its input, by the same kernel: a stride-1 convolution of the (zero-upsampled, for a
+ * strided forward) output gradient with the flipped, transposed weight.  dy (N, Ho, Wo, Cout) bf16; packed_weight_t =
+ * msda_conv_pack_weight of w_t[ci][co][kh][kw] = w[co][ci][KH-1-kh][KW-1-kw] (times the forward's scale[co] if the gradient is taken
+ * before the affine); dx (N, H, W, Cin) bf16, every element written.  Cout % 32 == 0 (it is the k dimension here), Cin % 16 == 0. */
+int msda_conv_dgrad_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW,
+                         int stride, int pad, int H, int W, uint16_t *dx, msda_stream_t stream)
+{
+    if (!dy || !packed_weight_t || !dx) return MSDA_ERR_NULL_POINTER;
+    if (N < 1 || Ho < 1 || Wo < 1 || H < 1 || W < 1 || Cout < 32 || Cout % 32 != 0 || Cin < 16 || Cin % 16 != 0 || KH < 1 || KW < 1 ||
+        KH > 16 || KW > 16 || stride < 1 || pad < 0 || pad > KH - 1 || pad > KW - 1)
+        return MSDA_ERR_BAD_DIMS;
+    if ((H + 2 * pad - KH) / stride + 1 != Ho || (W + 2 * pad - KW) / stride + 1 != Wo) return MSDA_ERR_BAD_DIMS;
+    if ((long long)N * H * W * Cin >= (1ll << 40) || (long long)N * Ho * Wo * Cout >= (1ll << 40)) return MSDA_ERR_TOO_LARGE;
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(packed_weight_t) | reinterpret_cast<uintptr_t>(dx)) & 15)
+        return MSDA_ERR_MISALIGNED;
+    // as a forward call: input dy with Cout channels, output dx with Cin channels and H x W pixels, padding KH - 1 - pad
+    // (KH == KW is not required: the column padding is KW - 1 - pad, see below), virtual input upsampled by `stride`
+    if (KH - 1 - pad != KW - 1 - pad) return MSDA_ERR_BAD_DIMS;      // one padding value in the kernel's geometry: square kernels
+    int ct, pt;
+    choose_tiling((long long)N * H * W, Cin, KH * KW * Cout, ct, pt);
+    const ConvArgs a{dy, packed_weight_t, nullptr, nullptr, nullptr, dx, ConvGeom{N, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, KH - 1 - pad, stride},
+                     0, static_cast<hipStream_t>(stream)};
+    return Cout % 64 == 0 ? launch_ct<2>(a, ct, pt) : launch_ct<1>(a, ct, pt);
 }
 
 }  // extern "C"

@@ -90,3 +90,51 @@ def test_errors():
         conv(torch.zeros(1, 4, 4, 32, device="cuda"))            # fp32 input
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         conv(torch.zeros(1, 4, 4, 32, dtype=torch.bfloat16))
+
+
+GRAD_CASES = [  # N, H, W, Cin, Cout, k, stride, pad
+    (2, 12, 14, 64, 64, 3, 1, 1),
+    (2, 12, 14, 64, 128, 1, 1, 0),
+    (1, 13, 15, 128, 64, 3, 2, 1),       # strided 3 x 3: the input gradient reads the zero-upsampled output gradient
+    (2, 9, 10, 256, 512, 1, 2, 0),       # strided 1 x 1 (projection shortcut)
+    (1, 8, 8, 32, 96, 3, 1, 1),          # C_in = 32 (one k-step per barrier), C_out = 96 (the input gradient's k: 3 x 32)
+]
+
+
+@pytest.mark.parametrize("case", GRAD_CASES, ids=[str(c) for c in GRAD_CASES])
+@pytest.mark.parametrize("with_residual", [False, True])
+def test_gradients_against_fp32_autograd(case, with_residual):
+    """ConvAffineFunction (forward + input gradient on the MFMA kernel, weight gradient by the library) against torch autograd through
+    the same block in fp32 on the same bf16-rounded operands.  Tolerance: bf16 rounding of dy, dz and of the results."""
+    from richsem_amd.conv import ConvAffineFunction, to_nhwc_bf16
+    N, H, W, Cin, Cout, k, stride, pad = case
+    torch.manual_seed(3 + hash(case) % 100)
+    x = torch.randn(N, Cin, H, W).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, k, k) * (Cin * k * k) ** -0.5).to(torch.bfloat16).float()
+    scale, shift = 1 + 0.3 * torch.randn(Cout), 0.5 * torch.randn(Cout)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(N, Cout, Ho, Wo).to(torch.bfloat16) if with_residual else None
+    dy = torch.randn(N, Cout, Ho, Wo).to(torch.bfloat16)
+    # reference: fp32 autograd
+    xr, wr = x.float().requires_grad_(True), w.clone().requires_grad_(True)
+    rr = res.float().requires_grad_(True) if with_residual else None
+    z = F.conv2d(xr, wr, stride=stride, padding=pad) * scale[None, :, None, None] + shift[None, :, None, None]
+    if with_residual:
+        z = z + rr
+    torch.relu(z).backward(dy.float())
+    # product
+    xg = to_nhwc_bf16(x.cuda()).requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    rg = to_nhwc_bf16(res.cuda()).requires_grad_(True) if with_residual else None
+    y = ConvAffineFunction.apply(xg, wg, scale.cuda(), shift.cuda(), rg, stride, pad, True)
+    y.backward(to_nhwc_bf16(dy.cuda()))
+
+    def close(got, want, name):
+        err = (got - want).abs()
+        s = float(want.abs().max())
+        assert float(err.max()) <= 2e-2 * s and float(err.mean()) <= 3e-3 * s, (name, float(err.max()) / s, float(err.mean()) / s)
+
+    close(xg.grad.permute(0, 3, 1, 2).float().cpu(), xr.grad, "dx")
+    close(wg.grad.cpu(), wr.grad, "dw")
+    if with_residual:
+        close(rg.grad.permute(0, 3, 1, 2).float().cpu(), rr.grad, "dres")
