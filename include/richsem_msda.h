@@ -306,9 +306,16 @@ int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, con
  * convolution of the output gradient -- read as if zero-upsampled by `stride` -- with the flipped, transposed weight.
  * dy (N, Ho, Wo, Cout) bf16 (already multiplied by the ReLU mask); packed_weight_t = msda_conv_pack_weight(w_t, Cin, Cout, KH, KW) with
  * w_t[ci][co][kh][kw] = scale[co] * w[co][ci][KH-1-kh][KW-1-kw]; dx (N, H, W, Cin) bf16, every element written.  Square kernels,
- * Cout % 32 == 0, Cin % 16 == 0, pad <= KH - 1.  (The weight gradient is not provided by this library.) */
+ * Cout % 32 == 0, Cin % 16 == 0, pad <= KH - 1. */
 int msda_conv_dgrad_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW,
                          int stride, int pad, int H, int W, uint16_t *dx, msda_stream_t stream);
+
+/* Gradient of msda_conv_forward_bf16 w.r.t. its weight (csrc/conv_wgrad.hip): dw[co][kh][kw][ci] = sum over output pixels of
+ * dz[n, ho, wo, co] * x[n, ho stride + kh - pad, wo stride + kw - pad, ci].  dz (N, Ho, Wo, Cout) bf16 = gradient at the CONVOLUTION's
+ * output (ReLU mask and affine scale already applied); x (N, H, W, Cin) bf16; dw (Cout, KH, KW, Cin) fp32, zeroed and filled here
+ * (split over pixel chunks, fp32 atomics: summation order varies at rounding level).  Cout % 128 == 0, Cin % 128 == 0. */
+int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                         int pad, float *dw, msda_stream_t stream);
 
 /* ---- two-stage query selection: row maxima of the class logits without the logits (reference
  * models/richsem/deformable_transformer.py:368-372 with the CLIP-text classifier models/richsem/richsem.py:176-184 in its shipped

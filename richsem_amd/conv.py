@@ -108,8 +108,11 @@ class ConvAffineFunction(torch.autograd.Function):
     """y = act(scale * conv(x, weight) + shift (+ residual)) on NHWC bf16 activations with gradients for x, weight and residual
     (scale / shift are the frozen BatchNorm's: no gradient, backbone.py:20-56).  Forward: ``msda_conv_forward_bf16``.  Backward: the ReLU
     mask is a PyTorch element-wise op; the input gradient is ``msda_conv_dgrad_bf16`` (the forward kernel on the zero-upsampled output
-    gradient with the flipped, transposed, scale-folded weight); the WEIGHT gradient is the library's (MIOpen through
-    ``aten::convolution_backward`` on channels-last views) -- this repository has no wgrad kernel yet."""
+    gradient with the flipped, transposed, scale-folded weight); the weight gradient is ``msda_conv_wgrad_bf16`` (csrc/conv_wgrad.hip:
+    pixel-contraction GEMM per tap with transposed LDS reads) when both channel counts are multiples of 128 -- every convolution of
+    ResNet-50's trained stages -- and MIOpen's (``aten::convolution_backward``) otherwise."""
+
+    library_wgrad = False      # tests / timing: True sends every weight gradient to MIOpen
 
     @staticmethod
     def forward(ctx, x, weight, scale, shift, residual, stride, padding, relu):
@@ -151,11 +154,18 @@ class ConvAffineFunction(torch.autograd.Function):
                 _lib.check(_lib.load().msda_conv_dgrad_bf16(dz.data_ptr(), packed_t.data_ptr(), N, dz.shape[1], dz.shape[2], Cout, Cin, KH,
                                                             KW, stride, padding, H, W, dx.data_ptr(), _stream(x.device)))
         if ctx.needs_input_grad[1]:
-            g = (dz.float() * scale).to(torch.bfloat16).permute(0, 3, 1, 2)       # gradient at the convolution's output, NCHW view
-            _, dw, _ = torch.ops.aten.convolution_backward(g, x.permute(0, 3, 1, 2), weight.detach().to(torch.bfloat16), None,
-                                                           [stride, stride], [padding, padding], [1, 1], False, [0, 0], 1,
-                                                           [False, True, False])
-            dw = dw.to(weight.dtype)
+            g = (dz.float() * scale).to(torch.bfloat16).contiguous()              # gradient at the convolution's output, NHWC
+            if Cout % 128 == 0 and Cin % 128 == 0 and not ConvAffineFunction.library_wgrad:
+                dw4 = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=x.device)
+                with torch.cuda.device(x.device):
+                    _lib.check(_lib.load().msda_conv_wgrad_bf16(g.data_ptr(), x.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, padding,
+                                                                dw4.data_ptr(), _stream(x.device)))
+                dw = dw4.permute(0, 3, 1, 2).to(weight.dtype)
+            else:       # channel counts the wgrad kernel does not take (ResNet-50's layer2-4 never get here): MIOpen
+                _, dw, _ = torch.ops.aten.convolution_backward(g.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2),
+                                                               weight.detach().to(torch.bfloat16), None, [stride, stride],
+                                                               [padding, padding], [1, 1], False, [0, 0], 1, [False, True, False])
+                dw = dw.to(weight.dtype)
         return dx, dw, None, None, (dz if has_res else None), None, None, None
 
 

@@ -1,0 +1,181 @@
+// conv_wgrad.hip -- gradient of the convolution w.r.t. its weight on the gfx950 matrix cores (the trained
+// backbone stages layer2-4, models/richsem/backbone.py:65-67).
+//
+//     dW[co][kh][kw][ci] = sum over output pixels p = (n, ho, wo) of  dz[p][co] * x[n, ho s + kh - pad, wo s + kw - pad][ci]
+//
+// (dz = gradient at the convolution's output, i.e. after the ReLU mask and the frozen affine's scale).  Per tap (kh, kw) that is a GEMM
+// dz^T (C_out x P) . x_shifted (P x C_in) whose contraction index is the PIXEL -- the strided dimension of both NHWC operands.  The
+// operands are therefore staged through LDS in their natural [pixel][channel] layout (coalesced 16-byte loads of whole pixel rows, any
+// stride / shift / padding handled at the load) and read back TRANSPOSED by gfx950's ds_read_b64_tr_b16 (tools/tr_probe.hip checks what
+// it delivers): a 16-lane group fetches 4 pixels x 16 channels and every lane receives its channel's 4 pixels, two such reads make
+// one mfma_f32_16x16x32_bf16 operand (A: row = output channel, B: column = input channel, k = 8 consecutive pixels per lane group).
+// The LDS image is the guide's swizzled 256-byte-row layout (16-byte chunk ch of row r at 256 r + 16 (ch ^ ((r & 3) << 2 | (r >> 2) & 3)))
+// so that neither the row-wise stores nor the transposed reads conflict.
+//   workgroup = (pixel chunk, tap, 128 output channels, 128 input channels), four waves of 64 x 64 (16 accumulator tiles each);
+//   64 pixels per stage (two k-steps), double-buffered through registers, one barrier per stage;
+//   split-K over pixel chunks; partial sums are added to the zeroed fp32 result with atomics (layout (C_out, KH, KW, C_in)).
+// bf16 operands, fp32 accumulation.  C_out % 128 == 0 and C_in % 128 == 0 (all convolutions of ResNet-50's layer2-4).
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "../../include/richsem_msda.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBM = 128, kBN = 128;     // output / input channels per workgroup
+constexpr int kStagePx = 64;            // pixels per stage (two k-steps of 32)
+constexpr int kThreads = 256;
+constexpr int kImageBytes = kStagePx * 256;   // one operand's stage: 64 rows of 128 bf16
+
+struct WgradGeom {
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+    long long P, chunk;     // output pixels; pixels per workgroup (multiple of kStagePx)
+};
+
+__device__ __forceinline__ int lds_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__restrict__ dz, const uint16_t *__restrict__ x,
+                                                              float *__restrict__ dw, WgradGeom g)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * kImageBytes];   // [buffer][A image | B image]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb_ci = g.Cin / kBN, nb_co = g.Cout / kBM;
+    int by = blockIdx.y;
+    const int cib = by % nb_ci;
+    by /= nb_ci;
+    const int cob = by % nb_co, tap = by / nb_co;
+    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+    const long long p0 = (long long)blockIdx.x * g.chunk;
+    const long long p1 = p0 + g.chunk < g.P ? p0 + g.chunk : g.P;
+    const int n_stage = (int)((p1 - p0 + kStagePx - 1) / kStagePx);
+
+    // staging: thread -> chunk column ch = tid % 16 of rows tid / 16 + 16 i (i < 4), for both operands
+    const int ch = tid & 15, row0 = tid >> 4;
+    u32x4 sa[4], sb[4];
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long p = p0 + (long long)s * kStagePx + row0 + 16 * i;
+            u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
+            if (p < p1) {
+                va = *reinterpret_cast<const u32x4 *>(dz + p * g.Cout + cob * kBM + ch * 8);
+                const int wo = (int)(p % g.Wo), ho = (int)((p / g.Wo) % g.Ho);
+                const long long n = p / ((long long)g.Wo * g.Ho);
+                const int hi = ho * g.stride + kh - g.pad, wi = wo * g.stride + kw - g.pad;
+                if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W)
+                    vb = *reinterpret_cast<const u32x4 *>(x + ((n * g.H + hi) * g.W + wi) * g.Cin + cib * kBN + ch * 8);
+            }
+            sa[i] = va;
+            sb[i] = vb;
+        }
+    };
+    auto park = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = lds_off(row0 + 16 * i, ch);
+            *reinterpret_cast<u32x4 *>(lds[slot] + off) = sa[i];
+            *reinterpret_cast<u32x4 *>(lds[slot] + kImageBytes + off) = sb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // transposed operand reads: lane = (group gI = lane / 16, i = lane % 16 = 4 q + p); the group's block = pixels 8 gI (+ 4) .. of the
+    // k-step, channels of the tile; this lane supplies row q, 16-byte chunk 2 tile + (p >> 1), half p & 1
+    const int gI = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int wm = wave & 1, wn = wave >> 1;
+    auto frag = [&](unsigned char *image, int ks, int tile) {
+        const int r = 32 * ks + 8 * gI + q;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4 *)(image + lds_off(r, 2 * tile + (pp >> 1)) + 8 * (pp & 1)));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4 *)(image + lds_off(r + 4, 2 * tile + (pp >> 1)) + 8 * (pp & 1)));
+        return (bf16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    };
+
+    if (n_stage > 0) {
+        fetch(0);
+        park(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < n_stage; ++s) {
+        if (s + 1 < n_stage) fetch(s + 1);
+        unsigned char *img_a = lds[s & 1], *img_b = lds[s & 1] + kImageBytes;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fa[t] = frag(img_a, ks, 4 * wm + t);
+                fb[t] = frag(img_b, ks, 4 * wn + t);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        if (s + 1 < n_stage) park((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // accumulator tile: lane (c = lane & 15, gI) holds rows (output channels) 4 gI + i, column (input channel) c
+    const int taps = g.KH * g.KW;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int ci = cib * kBN + 16 * (4 * wn + b) + li;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = cob * kBM + 16 * (4 * wm + a) + 4 * gI + i;
+                atomicAdd(dw + ((long long)co * taps + tap) * g.Cin + ci, acc[a][b][i]);
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                         int pad, float *dw, msda_stream_t stream)
+{
+    if (!dz || !x || !dw) return MSDA_ERR_NULL_POINTER;
+    if (N < 1 || H < 1 || W < 1 || Cin < kBN || Cin % kBN != 0 || Cout < kBM || Cout % kBM != 0 || KH < 1 || KW < 1 || KH > 16 || KW > 16 ||
+        stride < 1 || pad < 0)
+        return MSDA_ERR_BAD_DIMS;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    if (Ho < 1 || Wo < 1) return MSDA_ERR_BAD_DIMS;
+    if ((long long)N * H * W * Cin >= (1ll << 40) || (long long)N * Ho * Wo * Cout >= (1ll << 40)) return MSDA_ERR_TOO_LARGE;
+    if ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dw)) & 15) return MSDA_ERR_MISALIGNED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t bytes = (size_t)Cout * KH * KW * Cin * sizeof(float);
+    hipError_t e = hipMemsetAsync(dw, 0, bytes, st);
+    if (e != hipSuccess) return (int)e;
+    WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, (long long)N * Ho * Wo, 0};
+    // split the pixels so that the grid has about four workgroups per CU (but at least 256 pixels per workgroup: the atomics at its end)
+    const long long blocks_y = (long long)KH * KW * (Cout / kBM) * (Cin / kBN);
+    long long split = (1024 + blocks_y - 1) / blocks_y;
+    const long long max_split = (g.P + 255) / 256;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    g.chunk = ((g.P + split - 1) / split + kStagePx - 1) / kStagePx * kStagePx;
+    const long long gx = (g.P + g.chunk - 1) / g.chunk;
+    if (blocks_y > 65535 || gx > 0x7fffffffll) return MSDA_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)gx, (unsigned)blocks_y), dim3(kThreads), 0, st, dz, x, dw, g);
+    e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
+
+}  // extern "C"

@@ -98,6 +98,11 @@ GRAD_CASES = [  # N, H, W, Cin, Cout, k, stride, pad
     (1, 13, 15, 128, 64, 3, 2, 1),       # strided 3 x 3: the input gradient reads the zero-upsampled output gradient
     (2, 9, 10, 256, 512, 1, 2, 0),       # strided 1 x 1 (projection shortcut)
     (1, 8, 8, 32, 96, 3, 1, 1),          # C_in = 32 (one k-step per barrier), C_out = 96 (the input gradient's k: 3 x 32)
+    (2, 14, 19, 128, 128, 3, 1, 1),      # from here: channel counts the wgrad kernel takes (multiples of 128)
+    (2, 15, 17, 256, 128, 3, 2, 1),
+    (3, 7, 9, 128, 256, 1, 1, 0),
+    (1, 11, 13, 256, 512, 1, 2, 0),
+    (2, 30, 41, 128, 128, 3, 1, 1),      # 2460 pixels: several pixel chunks per tap (split-K atomics)
 ]
 
 
