@@ -103,3 +103,94 @@ class InputProj:
             srcs.append(g.permute(0, 2, 3, 1).reshape(N, H * W, C).to(out_dtype))
             shapes.append((H, W))
         return srcs, shapes
+
+
+# ---- trainable form (forward + backward on the library's kernels) -----------------------------------------------------------------
+from torch import nn                                         # noqa: E402
+
+from .conv import ConvAffineFunction                         # noqa: E402
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """Buffers of the reference's FrozenBatchNorm2d (models/richsem/backbone.py:20-44: weight, bias, running_mean, running_var; a
+    ``num_batches_tracked`` entry in a loaded state_dict is dropped as the reference does).  The affine itself runs in the preceding
+    convolution's epilogue; ``scale_shift`` is backbone.py:51-55."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        state_dict.pop(prefix + "num_batches_tracked", None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def scale_shift(self):
+        return fold_bn(self.weight, self.bias, self.running_mean, self.running_var, 1e-5)
+
+
+class _ConvWeight(nn.Module):
+    """the parameter of a bias-free nn.Conv2d under its own name (``<name>.weight``)"""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
+        self.stride, self.padding = stride, padding
+
+
+def _conv_bn_act(x, conv, bn, relu, residual=None):
+    scale, shift = bn.scale_shift()
+    return ConvAffineFunction.apply(x, conv.weight, scale, shift, residual, conv.stride, conv.padding, relu)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=False):
+        super().__init__()
+        self.conv1, self.bn1 = _ConvWeight(inplanes, planes, 1), FrozenBatchNorm2d(planes)
+        self.conv2, self.bn2 = _ConvWeight(planes, planes, 3, stride, 1), FrozenBatchNorm2d(planes)
+        self.conv3, self.bn3 = _ConvWeight(planes, planes * 4, 1), FrozenBatchNorm2d(planes * 4)
+        self.downsample = nn.Sequential(_ConvWeight(inplanes, planes * 4, 1, stride), FrozenBatchNorm2d(planes * 4)) if downsample else None
+
+    def forward(self, x):
+        identity = x if self.downsample is None else _conv_bn_act(x, self.downsample[0], self.downsample[1], False)
+        out = _conv_bn_act(x, self.conv1, self.bn1, True)
+        out = _conv_bn_act(out, self.conv2, self.bn2, True)
+        return _conv_bn_act(out, self.conv3, self.bn3, True, residual=identity)
+
+
+class ResNet50(nn.Module):
+    """Trainable ResNet-50 body with torchvision's module / parameter names (so ``load_state_dict`` takes its checkpoint and the
+    reference's ``'layer2' / 'layer3' / 'layer4' in name`` freezing rule applies, backbone.py:65-67), every convolution through
+    ConvAffineFunction: forward, input gradient and weight gradient on the library's MFMA kernels, NHWC bf16 activations, fp32 master
+    weights.  ``forward(images)`` returns the NHWC bf16 outputs of ``return_layers``."""
+
+    def __init__(self, layers=(3, 4, 6, 3), width=64, return_layers=(2, 3, 4), train_backbone=True):
+        super().__init__()
+        self.conv1, self.bn1 = _ConvWeight(3, width, 7, 2, 3), FrozenBatchNorm2d(width)
+        inplanes = width
+        for li, (n, planes) in enumerate(zip(layers, (width, width * 2, width * 4, width * 8)), start=1):
+            blocks = []
+            for b in range(n):
+                blocks.append(Bottleneck(inplanes, planes, 2 if (li > 1 and b == 0) else 1, downsample=b == 0))
+                inplanes = planes * 4
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        self.return_layers = tuple(return_layers)
+        self.num_channels = [width * 2 ** (li - 1) * 4 for li in self.return_layers]
+        for name, p in self.named_parameters():          # backbone.py:65-67
+            if not train_backbone or ("layer2" not in name and "layer3" not in name and "layer4" not in name):
+                p.requires_grad_(False)
+
+    def forward(self, images):
+        x = _conv_bn_act(to_nhwc_bf16(images), self.conv1, self.bn1, True)
+        x = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+        outs = []
+        for li in range(1, 5):
+            x = getattr(self, f"layer{li}")(x)
+            if li in self.return_layers:
+                outs.append(x)
+        return outs

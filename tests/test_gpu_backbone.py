@@ -84,3 +84,49 @@ def test_resnet50_stages_and_input_proj_against_oracle():
         assert s.shape == w.shape and s.dtype == torch.float32
         check(s.cpu(), w, 3e-2, 4e-3)
     assert "librichsem_msda.so" in open("/proc/self/maps").read()
+
+
+def test_trainable_resnet_names_forward_and_gradients():
+    """ResNet50 (nn.Module): torchvision's state_dict keys, the reference's freezing rule, forward equal to the inference form, and the
+    gradients of the trained stages against fp32 autograd through the oracle's op sequence (reduced depth / size)."""
+    from richsem_amd.backbone import ResNet50, ResNet50Frozen
+    layers = (1, 2, 1, 1)
+    sd = resnet_state_dict(layers=layers, seed=4)
+    net = ResNet50(layers=layers).cuda()
+    assert sorted(net.state_dict().keys()) == sorted(sd.keys())
+    net.load_state_dict(sd)
+    trainable = [n for n, p in net.named_parameters() if p.requires_grad]
+    assert trainable and all(n.startswith(("layer2", "layer3", "layer4")) for n in trainable)
+    assert all(not p.requires_grad for n, p in net.named_parameters() if n.startswith(("conv1", "layer1")))
+    x = torch.from_numpy(np.random.default_rng(6).normal(0, 1, (2, 3, 64, 96)).astype(np.float32))
+    outs = net(x.cuda())
+    frozen = ResNet50Frozen(sd)(x.cuda())
+    for a, b in zip(outs, frozen):
+        assert torch.equal(a, b)
+    # gradients: loss = sum_l <out_l, g_l>
+    gs = [torch.from_numpy(np.random.default_rng(7 + i).normal(0, 1, tuple(o.shape)).astype(np.float32)).to(torch.bfloat16) for i, o in enumerate(outs)]
+    sum((o.float() * g.cuda().float()).sum() for o, g in zip(outs, gs)).backward()
+    sdr = {k: v.clone().requires_grad_(k.startswith(("layer2", "layer3", "layer4")) and v.dim() == 4) for k, v in sd.items()}
+    with torch.enable_grad():
+        want = BO.resnet_stages.__wrapped__(x, sdr)
+        sum((w * g.float().permute(0, 3, 1, 2)).sum() for w, g in zip(want, gs)).backward()
+    # yardstick: the same op sequence as PyTorch bf16 ops on the GPU (its own rounding + ReLU-mask flips against the fp32 run)
+    sd16 = {k: v.cuda().to(torch.bfloat16).requires_grad_(k.startswith(("layer2", "layer3", "layer4")) and v.dim() == 4) for k, v in sd.items()}
+    with torch.enable_grad():
+        w16 = BO.resnet_stages.__wrapped__(x.cuda().to(torch.bfloat16), sd16)
+        sum((w.float() * g.cuda().float().permute(0, 3, 1, 2)).sum() for w, g in zip(w16, gs)).backward()
+    worst = 0.0
+    for n, p in net.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None
+            continue
+        ref = sdr[n].grad
+        s = float(ref.abs().max())
+        mine = float((p.grad.cpu() - ref).abs().mean()) / s
+        theirs = float((sd16[n].grad.float().cpu() - ref).abs().mean()) / s
+        cos = float((p.grad.cpu() * ref).sum() / (p.grad.cpu().norm() * ref.norm() + 1e-30))
+        worst = max(worst, mine)
+        # bf16 activations flip a few ReLU masks against the fp32 run (single elements move by several per cent of the maximum); the
+        # tensors as a whole must agree as well as PyTorch's own bf16 path does
+        assert mine <= 1.5 * theirs + 1e-3 and cos >= 0.99, (n, mine, theirs, cos)
+    print("worst mean weight-gradient error (of the tensor's maximum):", worst)
