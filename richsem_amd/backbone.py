@@ -128,7 +128,11 @@ class FrozenBatchNorm2d(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def scale_shift(self):
-        return fold_bn(self.weight, self.bias, self.running_mean, self.running_var, 1e-5)
+        ver = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version, self.weight.data_ptr())
+        if getattr(self, "_folded_ver", None) != ver:       # the buffers are frozen: folded once (and again after a load_state_dict)
+            self._folded = fold_bn(self.weight, self.bias, self.running_mean, self.running_var, 1e-5)
+            self._folded_ver = ver
+        return self._folded
 
 
 class _ConvWeight(nn.Module):

@@ -104,6 +104,27 @@ def _pack(w):
     return packed
 
 
+_pack_cache = {}      # (weight storage, transposed?) -> (weight version, scale version, packed): repacked when the optimizer has stepped
+
+
+def _packed_for(weight, scale, transposed):
+    """the packed forward weight, or the packed flipped / transposed / scale-folded weight of the input gradient, cached per parameter
+    and refreshed when the parameter (or the scale) has been modified in place"""
+    key = (weight.data_ptr(), transposed)
+    ver = (weight._version, scale._version if transposed else 0, tuple(weight.shape))
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    w = weight.detach().float()
+    if transposed:
+        w = (w * scale.view(-1, 1, 1, 1)).flip(2, 3).permute(1, 0, 2, 3)          # (Cin, Cout, KH, KW)
+    packed = _pack(w.contiguous())
+    if len(_pack_cache) > 4096:
+        _pack_cache.clear()
+    _pack_cache[key] = (ver, packed)
+    return packed
+
+
 class ConvAffineFunction(torch.autograd.Function):
     """y = act(scale * conv(x, weight) + shift (+ residual)) on NHWC bf16 activations with gradients for x, weight and residual
     (scale / shift are the frozen BatchNorm's: no gradient, backbone.py:20-56).  Forward: ``msda_conv_forward_bf16``.  Backward: the ReLU
@@ -117,14 +138,13 @@ class ConvAffineFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, scale, shift, residual, stride, padding, relu):
         assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
-        w = weight.detach().float().contiguous()
-        Cout, Cin, KH, KW = w.shape
+        Cout, Cin, KH, KW = weight.shape
         x = x.contiguous()
         N, H, W, _ = x.shape
         Ho, Wo = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
         out = torch.empty((N, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
         res = residual.contiguous() if residual is not None else None
-        packed = _pack(w)
+        packed = _packed_for(weight, scale, False)
         with torch.cuda.device(x.device):
             _lib.check(_lib.load().msda_conv_forward_bf16(
                 x.data_ptr(), packed.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr() if res is not None else None,
@@ -142,30 +162,29 @@ class ConvAffineFunction(torch.autograd.Function):
         N, H, W, _ = x.shape
         dz = dy.contiguous()
         if relu:
-            dz = dz * (out > 0)                                    # gradient at the ReLU's input (= the residual's gradient)
+            dz = torch.ops.aten.threshold_backward(dz, out, 0)     # gradient at the ReLU's input (= the residual's gradient)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if Cout % 32 or Cin % 16 or KH != KW:
                 raise RuntimeError("ConvAffineFunction: the input gradient needs C_out % 32 == 0, C_in % 16 == 0 and a square kernel")
-            w_t = (weight.detach().float() * scale.view(-1, 1, 1, 1)).flip(2, 3).permute(1, 0, 2, 3).contiguous()     # (Cin, Cout, KH, KW)
-            packed_t = _pack(w_t)
+            packed_t = _packed_for(weight, scale, True)
             dx = torch.empty_like(x)
             with torch.cuda.device(x.device):
                 _lib.check(_lib.load().msda_conv_dgrad_bf16(dz.data_ptr(), packed_t.data_ptr(), N, dz.shape[1], dz.shape[2], Cout, Cin, KH,
                                                             KW, stride, padding, H, W, dx.data_ptr(), _stream(x.device)))
         if ctx.needs_input_grad[1]:
-            g = (dz.float() * scale).to(torch.bfloat16).contiguous()              # gradient at the convolution's output, NHWC
+            # the weight gradient is taken with dz and scaled per output channel afterwards (the affine's scale commutes with the sum)
             if Cout % 128 == 0 and Cin % 128 == 0 and not ConvAffineFunction.library_wgrad:
                 dw4 = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=x.device)
                 with torch.cuda.device(x.device):
-                    _lib.check(_lib.load().msda_conv_wgrad_bf16(g.data_ptr(), x.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, padding,
+                    _lib.check(_lib.load().msda_conv_wgrad_bf16(dz.data_ptr(), x.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, padding,
                                                                 dw4.data_ptr(), _stream(x.device)))
-                dw = dw4.permute(0, 3, 1, 2).to(weight.dtype)
+                dw = (dw4 * scale.view(-1, 1, 1, 1)).permute(0, 3, 1, 2).to(weight.dtype)
             else:       # channel counts the wgrad kernel does not take (ResNet-50's layer2-4 never get here): MIOpen
-                _, dw, _ = torch.ops.aten.convolution_backward(g.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2),
+                _, dw, _ = torch.ops.aten.convolution_backward(dz.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2),
                                                                weight.detach().to(torch.bfloat16), None, [stride, stride],
                                                                [padding, padding], [1, 1], False, [0, 0], 1, [False, True, False])
-                dw = dw.to(weight.dtype)
+                dw = (dw.float() * scale.view(-1, 1, 1, 1)).to(weight.dtype)
         return dx, dw, None, None, (dz if has_res else None), None, None, None
 
 
