@@ -56,24 +56,42 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
     const long long p1 = p0 + g.chunk < g.P ? p0 + g.chunk : g.P;
     const int n_stage = (int)((p1 - p0 + kStagePx - 1) / kStagePx);
 
-    // staging: thread -> chunk column ch = tid % 16 of rows tid / 16 + 16 i (i < 4), for both operands
+    // staging: thread -> chunk column ch = tid % 16 of rows tid / 16 + 16 i (i < 4), for both operands.  The rows' pixels are decoded
+    // once (32-bit: the host checks P < 2^31) and advanced by a stage's 64 pixels from then on -- no division in the loop.
     const int ch = tid & 15, row0 = tid >> 4;
+    const int P1 = (int)p1;
+    int rp[4], rn[4], rho[4], rwo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rp[i] = (int)p0 + row0 + 16 * i;
+        const int pc = rp[i] < (int)g.P ? rp[i] : 0;
+        rwo[i] = pc % g.Wo;
+        rho[i] = (pc / g.Wo) % g.Ho;
+        rn[i] = pc / (g.Wo * g.Ho);
+    }
+    const uint16_t *dz_col = dz + cob * kBM + ch * 8, *x_col = x + cib * kBN + ch * 8;
     u32x4 sa[4], sb[4];
-    auto fetch = [&](int s) {
+    auto fetch = [&]() {      // the next stage's rows; advances the row coordinates
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long long p = p0 + (long long)s * kStagePx + row0 + 16 * i;
             u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
-            if (p < p1) {
-                va = *reinterpret_cast<const u32x4 *>(dz + p * g.Cout + cob * kBM + ch * 8);
-                const int wo = (int)(p % g.Wo), ho = (int)((p / g.Wo) % g.Ho);
-                const long long n = p / ((long long)g.Wo * g.Ho);
-                const int hi = ho * g.stride + kh - g.pad, wi = wo * g.stride + kw - g.pad;
+            if (rp[i] < P1) {
+                va = *reinterpret_cast<const u32x4 *>(dz_col + (size_t)rp[i] * g.Cout);
+                const int hi = rho[i] * g.stride + kh - g.pad, wi = rwo[i] * g.stride + kw - g.pad;
                 if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W)
-                    vb = *reinterpret_cast<const u32x4 *>(x + ((n * g.H + hi) * g.W + wi) * g.Cin + cib * kBN + ch * 8);
+                    vb = *reinterpret_cast<const u32x4 *>(x_col + ((size_t)(rn[i] * g.H + hi) * g.W + wi) * g.Cin);
             }
             sa[i] = va;
             sb[i] = vb;
+            rp[i] += kStagePx;
+            rwo[i] += kStagePx;
+            while (rwo[i] >= g.Wo) {
+                rwo[i] -= g.Wo;
+                if (++rho[i] == g.Ho) {
+                    rho[i] = 0;
+                    ++rn[i];
+                }
+            }
         }
     };
     auto park = [&](int slot) {
@@ -105,12 +123,12 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
     };
 
     if (n_stage > 0) {
-        fetch(0);
+        fetch();
         park(0);
     }
     __syncthreads();
     for (int s = 0; s < n_stage; ++s) {
-        if (s + 1 < n_stage) fetch(s + 1);
+        if (s + 1 < n_stage) fetch();
         unsigned char *img_a = lds[s & 1], *img_b = lds[s & 1] + kImageBytes;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -164,10 +182,12 @@ int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, in
     hipError_t e = hipMemsetAsync(dw, 0, bytes, st);
     if (e != hipSuccess) return (int)e;
     WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, (long long)N * Ho * Wo, 0};
-    // split the pixels so that the grid has about four workgroups per CU (but at least 256 pixels per workgroup: the atomics at its end)
+    if (g.P >= (1ll << 31) || (long long)N * H * W >= (1ll << 31)) return MSDA_ERR_TOO_LARGE;
+    // split the pixels so that the grid has about two workgroups per CU (but at least 1024 pixels per workgroup: every workgroup ends
+    // with 16384 atomics per wave-tile set, and a finer split only multiplies them)
     const long long blocks_y = (long long)KH * KW * (Cout / kBM) * (Cin / kBN);
-    long long split = (1024 + blocks_y - 1) / blocks_y;
-    const long long max_split = (g.P + 255) / 256;
+    long long split = (512 + blocks_y - 1) / blocks_y;
+    const long long max_split = (g.P + 1023) / 1024;
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
     g.chunk = ((g.P + split - 1) / split + kStagePx - 1) / kStagePx * kStagePx;
