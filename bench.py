@@ -373,9 +373,22 @@ def backbone_row(n_img, dev):
         return y
 
     t_f, t_o = _time_events(lambda: net(x), 5), _time_events(ops, 3)
-    return {"what": "ResNet-50 + FrozenBatchNorm2d forward (53 convolutions, affine / relu / residual in the epilogues), NHWC bf16, "
-                    "HIP implicit-GEMM kernel; outside the timed step; forward only", "hip_kernel": "conv_fwd_kernel<CO_TILES, PT, MODE>",
+    # training form: layer2-4 trained (backbone.py:65-67), forward + input gradients + weight gradients on the library's kernels
+    from richsem_amd.backbone import ResNet50
+    tnet = ResNet50().to(dev)
+    tnet.load_state_dict(sd)
+    gs = [torch.randn_like(o) for o in tnet(x)]
+
+    def train_step():
+        for p in tnet.parameters():
+            p.grad = None
+        torch.autograd.backward(tnet(x), gs)
+
+    t_t = _time_events(train_step, 3)
+    return {"what": "ResNet-50 + FrozenBatchNorm2d (53 convolutions, affine / relu / residual in the epilogues), NHWC bf16, HIP implicit-GEMM "
+                    "kernels; outside the timed step", "hip_kernel": "conv_fwd_kernel<CO_TILES, PT, MODE> (+ conv_wgrad_kernel in training)",
             "input": [n_img, 3, 800, 1344], "flop": flop, "ms": round(t_f * 1e3, 3),
+            "train_forward_backward_ms": round(t_t * 1e3, 3),
             "roofline": {"bound": "mfma", "achieved": round(flop / t_f / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(flop / t_f / 1e12 / 2500.0, 4)},
             "pytorch_bf16_channels_last_ms": round(t_o * 1e3, 3)}

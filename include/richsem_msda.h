@@ -294,7 +294,7 @@ int msda_roi_align_forward_f64(const double *input, const double *rois, int K, i
  * operand fragments gathered element by element); all pointers 16-byte aligned (x: 2-byte for few-channel inputs); residual may be NULL.
  * msda_conv_pack_weight: weight (C_out, C_in, KH, KW) fp32 (torch layout) -> msda_conv_packed_elems uint16 in MFMA fragment order
  * (repack when the weight changes).  msda_conv_set_tiling forces the per-wave tile (channel tiles in {1, 2, 4, 8, 16}, pixel tiles in
- * {1, 2, 3}; 0 = chosen per call so that the grid fills the chip) -- results do not depend on it beyond summation order.  Forward only. */
+ * {1, 2, 3}; 0 = chosen per call so that the grid fills the chip) -- results do not depend on it beyond summation order. */
 int msda_conv_set_tiling(int co_tiles, int pixel_tiles);
 int msda_conv_packed_elems(int Cout, int Cin, int KH, int KW, int64_t *elems);
 int msda_conv_pack_weight(const float *weight, int Cout, int Cin, int KH, int KW, uint16_t *packed, msda_stream_t stream);

@@ -6,9 +6,9 @@ GroupNorm(32) per stage, 3 x 3 stride-2 convolution + GroupNorm for the extra le
 torchvision is a third-party dependency outside the reference tree (``torchvision>=0.6.0``, unpinned) and absent from the image; the
 architecture restated here is its published ResNet-50 v1.5 (stem 7 x 7 stride 2 + 3 x 3 stride-2 max pool; bottlenecks [3, 4, 6, 3] with
 the stride on the 3 x 3 convolution; projection shortcut = 1 x 1 stride-s convolution + norm), read from the parameter names of its
-``state_dict`` (conv1, bn1, layer{1..4}.{i}.conv{1,2,3} / bn{1,2,3} / downsample.{0,1}).  **Forward only**: the frozen affine, the ReLU
-and the residual add run in the convolution's epilogue, activations are NHWC bf16.  The backward of the trained stages (layer2-4) is
-not built; training them still needs a library convolution backward.
+``state_dict`` (conv1, bn1, layer{1..4}.{i}.conv{1,2,3} / bn{1,2,3} / downsample.{0,1}).  The frozen affine, the ReLU and the residual
+add run in the convolution's epilogue, activations are NHWC bf16.  ``ResNet50Frozen`` is the inference form (weights packed once);
+``ResNet50`` below is the trainable ``nn.Module`` (forward, input gradient and weight gradient of layer2-4 on the library's kernels).
 """
 import torch
 import torch.nn.functional as F

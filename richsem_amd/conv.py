@@ -2,7 +2,8 @@
 
 Activations are NHWC bfloat16 tensors of shape (N, H, W, C) (contiguous); a convolution comes with the per-channel affine that follows
 it in the backbones (frozen / eval-mode BatchNorm folded into scale and shift -- reference models/richsem/backbone.py:20-56,
-clip/model.py:16-27), an optional residual and an optional ReLU, all applied in the kernel's epilogue.  Forward only.
+clip/model.py:16-27), an optional residual and an optional ReLU, all applied in the kernel's epilogue.  ``ConvAffine`` is the inference form;
+``ConvAffineFunction`` / ``ConvBNAct`` add the input and weight gradients.
 """
 import ctypes
 

@@ -129,6 +129,9 @@ def train(args):
         torch.autograd.backward(fwd_t(x), gs_t)
 
     t = timeit(step, args.reps)
+    if args.ours_only:
+        print(f"forward + backward {t:.2f} ms")
+        return
     ConvAffineFunction.library_wgrad = True
     t_lib = timeit(step, args.reps)
     ConvAffineFunction.library_wgrad = False
@@ -141,6 +144,7 @@ def train(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--ours-only", action="store_true", help="with --train: skip the PyTorch side (for rocprofv3 runs)")
     ap.add_argument("--train", action="store_true", help="forward + backward of the trained stages (layer2-4) instead of the forward")
     args = ap.parse_args()
     if args.train:
