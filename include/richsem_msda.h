@@ -312,10 +312,12 @@ int msda_conv_dgrad_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, in
 
 /* Gradient of msda_conv_forward_bf16 w.r.t. its weight (csrc/conv_wgrad.hip): dw[co][kh][kw][ci] = sum over output pixels of
  * dz[n, ho, wo, co] * x[n, ho stride + kh - pad, wo stride + kw - pad, ci].  dz (N, Ho, Wo, Cout) bf16 = gradient at the CONVOLUTION's
- * output (ReLU mask and affine scale already applied); x (N, H, W, Cin) bf16; dw (Cout, KH, KW, Cin) fp32, zeroed and filled here
- * (split over pixel chunks, fp32 atomics: summation order varies at rounding level).  Cout % 128 == 0, Cin % 128 == 0. */
+ * output (ReLU mask applied); x (N, H, W, Cin) bf16; dw (Cout, KH, KW, Cin) fp32, every element written.  The pixels are split into
+ * chunks where the (tap, channel block) grid alone cannot fill the chip; the chunks' partial sums go through `workspace`
+ * (msda_conv_wgrad_workspace_bytes; may be NULL when that is 0) and a second kernel.  Cout % 128 == 0, Cin % 128 == 0. */
+int msda_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t *bytes);
 int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                         int pad, float *dw, msda_stream_t stream);
+                         int pad, float *dw, void *workspace, msda_stream_t stream);
 
 /* ---- two-stage query selection: row maxima of the class logits without the logits (reference
  * models/richsem/deformable_transformer.py:368-372 with the CLIP-text classifier models/richsem/richsem.py:176-184 in its shipped

@@ -13,7 +13,9 @@
 // so that neither the row-wise stores nor the transposed reads conflict.
 //   workgroup = (pixel chunk, tap, 128 output channels, 128 input channels), four waves of 64 x 64 (16 accumulator tiles each);
 //   64 pixels per stage (two k-steps), double-buffered through registers, one barrier per stage;
-//   split-K over pixel chunks; partial sums are added to the zeroed fp32 result with atomics (layout (C_out, KH, KW, C_in)).
+//   split-K over pixel chunks only where the (tap, channel block) grid alone cannot fill the chip; the chunks' partial results go to a
+//   caller-provided workspace with plain stores and are summed by a second kernel (fp32 atomics into the result were tried first: the
+//   L2 atomic rate made them the whole run time -- 39 us of a 40 us launch for layer4's 3 x 3).  Result layout (C_out, KH, KW, C_in).
 // bf16 operands, fp32 accumulation.  C_out % 128 == 0 and C_in % 128 == 0 (all convolutions of ResNet-50's layer2-4).
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
@@ -70,6 +72,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
         rn[i] = pc / (g.Wo * g.Ho);
     }
     const uint16_t *dz_col = dz + cob * kBM + ch * 8, *x_col = x + cib * kBN + ch * 8;
+    // one stage ahead in one register set (a second set -- two stages in flight -- spills 195 registers at the 256-register budget of
+    // two workgroups per CU and doubles the run time; with 512 registers the kernel runs one wave per SIMD and gains nothing)
     u32x4 sa[4], sb[4];
     auto fetch = [&]() {      // the next stage's rows; advances the row coordinates
 #pragma unroll
@@ -122,14 +126,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
         return (bf16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     };
 
-    if (n_stage > 0) {
-        fetch();
-        park(0);
-    }
-    __syncthreads();
-    for (int s = 0; s < n_stage; ++s) {
-        if (s + 1 < n_stage) fetch();
-        unsigned char *img_a = lds[s & 1], *img_b = lds[s & 1] + kImageBytes;
+    auto products = [&](int buf) {
+        unsigned char *img_a = lds[buf], *img_b = lds[buf] + kImageBytes;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[4], fb[4];
@@ -143,12 +141,23 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
+    };
+    if (n_stage > 0) {
+        fetch();
+        park(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < n_stage; ++s) {
+        if (s + 1 < n_stage) fetch();
+        products(s & 1);
         if (s + 1 < n_stage) park((s + 1) & 1);
         __syncthreads();
     }
 
-    // accumulator tile: lane (c = lane & 15, gI) holds rows (output channels) 4 gI + i, column (input channel) c
+    // accumulator tile: lane (c = lane & 15, gI) holds rows (output channels) 4 gI + i, column (input channel) c; pixel chunk
+    // blockIdx.x writes its own slice of the output (the result itself when there is one chunk, else the workspace)
     const int taps = g.KH * g.KW;
+    float *out = dw + (size_t)blockIdx.x * g.Cout * taps * g.Cin;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -157,17 +166,59 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int co = cob * kBM + 16 * (4 * wm + a) + 4 * gI + i;
-                atomicAdd(dw + ((long long)co * taps + tap) * g.Cin + ci, acc[a][b][i]);
+                out[((long long)co * taps + tap) * g.Cin + ci] = acc[a][b][i];
             }
         }
+}
+
+// dw[i] = sum over the chunks' slices
+__global__ void conv_wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, long long n4, int split)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4 *>(ws)[i];
+        for (int s = 1; s < split; ++s) {
+            const float4 b = reinterpret_cast<const float4 *>(ws)[(long long)s * n4 + i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4 *>(dw)[i] = a;
+    }
+}
+
+// pixel chunks for a problem: 1 when the (tap, channel block) grid gives the chip a workgroup per CU by itself, else enough chunks
+// for about two per CU, of at least 512 pixels each
+void wgrad_split(const WgradGeom &g, long long &split, long long &chunk)
+{
+    const long long blocks_y = (long long)g.KH * g.KW * (g.Cout / kBM) * (g.Cin / kBN);
+    split = blocks_y >= 128 ? 1 : (512 + blocks_y - 1) / blocks_y;
+    const long long max_split = (g.P + 511) / 512;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    chunk = ((g.P + split - 1) / split + kStagePx - 1) / kStagePx * kStagePx;
+    split = (g.P + chunk - 1) / chunk;
 }
 
 }  // namespace
 
 extern "C" {
 
+/* bytes of workspace msda_conv_wgrad_bf16 needs for a problem (0: none) */
+int msda_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t *bytes)
+{
+    if (!bytes) return MSDA_ERR_NULL_POINTER;
+    if (N < 1 || H < 1 || W < 1 || Cin < kBN || Cin % kBN != 0 || Cout < kBM || Cout % kBM != 0 || KH < 1 || KW < 1 || KH > 16 || KW > 16 ||
+        stride < 1 || pad < 0)
+        return MSDA_ERR_BAD_DIMS;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    if (Ho < 1 || Wo < 1) return MSDA_ERR_BAD_DIMS;
+    WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, (long long)N * Ho * Wo, 0};
+    long long split, chunk;
+    wgrad_split(g, split, chunk);
+    *bytes = split > 1 ? (int64_t)split * Cout * KH * KW * Cin * (int64_t)sizeof(float) : 0;
+    return MSDA_OK;
+}
+
 int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                         int pad, float *dw, msda_stream_t stream)
+                         int pad, float *dw, void *workspace, msda_stream_t stream)
 {
     if (!dz || !x || !dw) return MSDA_ERR_NULL_POINTER;
     if (N < 1 || H < 1 || W < 1 || Cin < kBN || Cin % kBN != 0 || Cout < kBM || Cout % kBM != 0 || KH < 1 || KW < 1 || KH > 16 || KW > 16 ||
@@ -178,22 +229,23 @@ int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, in
     if ((long long)N * H * W * Cin >= (1ll << 40) || (long long)N * Ho * Wo * Cout >= (1ll << 40)) return MSDA_ERR_TOO_LARGE;
     if ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dw)) & 15) return MSDA_ERR_MISALIGNED;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t bytes = (size_t)Cout * KH * KW * Cin * sizeof(float);
-    hipError_t e = hipMemsetAsync(dw, 0, bytes, st);
-    if (e != hipSuccess) return (int)e;
     WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, (long long)N * Ho * Wo, 0};
     if (g.P >= (1ll << 31) || (long long)N * H * W >= (1ll << 31)) return MSDA_ERR_TOO_LARGE;
-    // split the pixels so that the grid has about two workgroups per CU (but at least 1024 pixels per workgroup: every workgroup ends
-    // with 16384 atomics per wave-tile set, and a finer split only multiplies them)
+    long long split;
+    wgrad_split(g, split, g.chunk);
     const long long blocks_y = (long long)KH * KW * (Cout / kBM) * (Cin / kBN);
-    long long split = (512 + blocks_y - 1) / blocks_y;
-    const long long max_split = (g.P + 1023) / 1024;
-    if (split > max_split) split = max_split;
-    if (split < 1) split = 1;
-    g.chunk = ((g.P + split - 1) / split + kStagePx - 1) / kStagePx * kStagePx;
-    const long long gx = (g.P + g.chunk - 1) / g.chunk;
-    if (blocks_y > 65535 || gx > 0x7fffffffll) return MSDA_ERR_TOO_LARGE;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)gx, (unsigned)blocks_y), dim3(kThreads), 0, st, dz, x, dw, g);
+    const long long n_dw = (long long)Cout * KH * KW * Cin;
+    if (split > 1 && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15))) return MSDA_ERR_NULL_POINTER;
+    if (blocks_y > 65535) return MSDA_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)split, (unsigned)blocks_y), dim3(kThreads), 0, st, dz, x,
+                       split > 1 ? static_cast<float *>(workspace) : dw, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (split > 1) {
+        const long long n4 = n_dw / 4;
+        const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, static_cast<const float *>(workspace), dw, n4, (int)split);
+    }
     e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
 }
