@@ -40,6 +40,15 @@ def pmc(d, sub, counter):
     return acc
 
 
+OURS = ("msda::", "(anonymous namespace)::", "tiled_", "rps_", "fwd_direct", "bwd_", "ffn_fwd", "cls_", "conv_fwd", "conv_wgrad", "conv_pack",
+        "prep_", "mask_rows", "topk_rows", "roi_align", "matcher_cost", "attnpool", "dn_")
+
+
+def ours(name):
+    """kernels of this library (the bench's comparison rows also launch PyTorch / MIOpen / hipBLASLt kernels: summarised as one line)"""
+    return any(t in name for t in OURS) and "at::native" not in name and "ck::" not in name
+
+
 def main():
     d, tag = sys.argv[1], sys.argv[2]
     out = [f"# rocprofv3 summary {tag}", ""]
@@ -50,11 +59,18 @@ def main():
         out += [f"(no bench line: {e})", ""]
     out += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline`", "",
             "| kernel | calls | avg µs | total ms | % |", "|---|---|---|---|---|"]
+    other_calls, other_ms, other_pct = 0, 0.0, 0.0
     for name, calls, avg, tot, pct in kernel_stats(d):
-        out.append(f"| `{name[:90]}` | {calls} | {avg:.1f} | {tot:.2f} | {pct:.1f} |")
+        if ours(name):
+            out.append(f"| `{name[:90]}` | {calls} | {avg:.1f} | {tot:.2f} | {pct:.1f} |")
+        else:
+            other_calls, other_ms, other_pct = other_calls + calls, other_ms + tot, other_pct + pct
+    out.append(f"| (PyTorch / MIOpen / hipBLASLt / RCCL / memset kernels of the comparison rows and the harness) | {other_calls} | | {other_ms:.2f} | {other_pct:.1f} |")
     out += ["", "### per (kernel, grid): E and Dd launches of the same kernel separated", "",
             "| kernel | grid (threads) | launches | avg µs |", "|---|---|---|---|"]
     for (name, grid), v in sorted(per_grid(d).items()):
+        if not ours(name):
+            continue
         out.append(f"| `{name[:70]}` | {'x'.join(g for g in grid if g)} | {len(v)} | {sum(v) / len(v):.1f} |")
     fetch, write = pmc(d, "pmc_fetch", "FETCH_SIZE"), pmc(d, "pmc_write", "WRITE_SIZE")
     out += ["", "## HBM traffic per launch (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes)", "",
@@ -63,12 +79,16 @@ def main():
             "16-B-per-lane stores and float atomics. Other access widths are uncalibrated, so treat the sum as an estimate.", "",
             "| kernel | grid | FETCH_SIZE KiB | WRITE_SIZE KiB | est. HBM MB = (2·fetch + write)·1024/1e6 |", "|---|---|---|---|---|"]
     for key in sorted(set(fetch) | set(write)):
+        if not ours(key[0]):
+            continue
         f = sum(fetch.get(key, [0])) / max(1, len(fetch.get(key, [0])))
         w = sum(write.get(key, [0])) / max(1, len(write.get(key, [0])))
         out.append(f"| `{key[0][:60]}` | {key[1]} | {f:.0f} | {w:.0f} | {(2 * f + w) * 1024 / 1e6:.1f} |")
     # machine-readable traffic table for bench.py's roofline.traffic (bytes per launch, corrected as above)
     traffic = {}
     for key in sorted(set(fetch) | set(write)):
+        if not ours(key[0]):
+            continue
         f = sum(fetch.get(key, [0])) / max(1, len(fetch.get(key, [0])))
         w = sum(write.get(key, [0])) / max(1, len(write.get(key, [0])))
         traffic[f"{key[0]}|{key[1]}"] = {"fetch_size_kib": f, "write_size_kib": w, "hbm_bytes_est": int((2 * f + w) * 1024)}
