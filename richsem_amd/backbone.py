@@ -108,7 +108,7 @@ class InputProj:
 # ---- trainable form (forward + backward on the library's kernels) -----------------------------------------------------------------
 from torch import nn                                         # noqa: E402
 
-from .conv import ConvAffineFunction                         # noqa: E402
+from .conv import ConvAffineFunction, PackCache              # noqa: E402
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -143,11 +143,12 @@ class _ConvWeight(nn.Module):
         self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
         self.stride, self.padding = stride, padding
+        self.pack_cache = PackCache()
 
 
 def _conv_bn_act(x, conv, bn, relu, residual=None):
     scale, shift = bn.scale_shift()
-    return ConvAffineFunction.apply(x, conv.weight, scale, shift, residual, conv.stride, conv.padding, relu)
+    return ConvAffineFunction.apply(x, conv.weight, scale, shift, residual, conv.stride, conv.padding, relu, conv.pack_cache)
 
 
 class Bottleneck(nn.Module):

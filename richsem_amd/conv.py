@@ -105,25 +105,34 @@ def _pack(w):
     return packed
 
 
-_pack_cache = {}      # (weight storage, transposed?) -> (weight version, scale version, packed): repacked when the optimizer has stepped
+class PackCache:
+    """Packed forms of ONE convolution weight, owned by the module that owns the parameter (no global table: a freed tensor's address
+    can come back with the same version counter): the forward weight and the flipped / transposed / scale-folded weight of the input
+    gradient, refreshed when the parameter (or the scale) has been modified in place -- i.e. after an optimizer step."""
+
+    def __init__(self):
+        self._slots = {}
+
+    def get(self, weight, scale, transposed):
+        ver = (weight.data_ptr(), weight._version, scale.data_ptr() if transposed else 0, scale._version if transposed else 0,
+               tuple(weight.shape))
+        hit = self._slots.get(transposed)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        packed = _pack_form(weight, scale, transposed)
+        self._slots[transposed] = (ver, packed)
+        return packed
 
 
-def _packed_for(weight, scale, transposed):
-    """the packed forward weight, or the packed flipped / transposed / scale-folded weight of the input gradient, cached per parameter
-    and refreshed when the parameter (or the scale) has been modified in place"""
-    key = (weight.data_ptr(), transposed)
-    ver = (weight._version, scale._version if transposed else 0, tuple(weight.shape))
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1]
+def _pack_form(weight, scale, transposed):
     w = weight.detach().float()
     if transposed:
         w = (w * scale.view(-1, 1, 1, 1)).flip(2, 3).permute(1, 0, 2, 3)          # (Cin, Cout, KH, KW)
-    packed = _pack(w.contiguous())
-    if len(_pack_cache) > 4096:
-        _pack_cache.clear()
-    _pack_cache[key] = (ver, packed)
-    return packed
+    return _pack(w.contiguous())
+
+
+def _packed_for(weight, scale, transposed, cache=None):
+    return cache.get(weight, scale, transposed) if cache is not None else _pack_form(weight, scale, transposed)
 
 
 class ConvAffineFunction(torch.autograd.Function):
@@ -137,7 +146,7 @@ class ConvAffineFunction(torch.autograd.Function):
     library_wgrad = False      # tests / timing: True sends every weight gradient to MIOpen
 
     @staticmethod
-    def forward(ctx, x, weight, scale, shift, residual, stride, padding, relu):
+    def forward(ctx, x, weight, scale, shift, residual, stride, padding, relu, cache=None):
         assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
         Cout, Cin, KH, KW = weight.shape
         x = x.contiguous()
@@ -145,20 +154,20 @@ class ConvAffineFunction(torch.autograd.Function):
         Ho, Wo = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
         out = torch.empty((N, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
         res = residual.contiguous() if residual is not None else None
-        packed = _packed_for(weight, scale, False)
+        packed = _packed_for(weight, scale, False, cache)
         with torch.cuda.device(x.device):
             _lib.check(_lib.load().msda_conv_forward_bf16(
                 x.data_ptr(), packed.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr() if res is not None else None,
                 N, H, W, Cin, Cout, KH, KW, stride, padding, int(relu), out.data_ptr(), _stream(x.device)))
         ctx.save_for_backward(x, weight, scale, out if relu else None)
-        ctx.cfg = (stride, padding, relu, residual is not None)
+        ctx.cfg = (stride, padding, relu, residual is not None, cache)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, weight, scale, out = ctx.saved_tensors
-        stride, padding, relu, has_res = ctx.cfg
+        stride, padding, relu, has_res, cache = ctx.cfg
         Cout, Cin, KH, KW = weight.shape
         N, H, W, _ = x.shape
         dz = dy.contiguous()
@@ -168,7 +177,7 @@ class ConvAffineFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if Cout % 32 or Cin % 16 or KH != KW:
                 raise RuntimeError("ConvAffineFunction: the input gradient needs C_out % 32 == 0, C_in % 16 == 0 and a square kernel")
-            packed_t = _packed_for(weight, scale, True)
+            packed_t = _packed_for(weight, scale, True, cache)
             dx = torch.empty_like(x)
             with torch.cuda.device(x.device):
                 _lib.check(_lib.load().msda_conv_dgrad_bf16(dz.data_ptr(), packed_t.data_ptr(), N, dz.shape[1], dz.shape[2], Cout, Cin, KH,
@@ -190,7 +199,7 @@ class ConvAffineFunction(torch.autograd.Function):
                                                                weight.detach().to(torch.bfloat16), None, [stride, stride],
                                                                [padding, padding], [1, 1], False, [0, 0], 1, [False, True, False])
                 dw = (dw.float() * scale.view(-1, 1, 1, 1)).to(weight.dtype)
-        return dx, dw, None, None, (dz if has_res else None), None, None, None
+        return dx, dw, None, None, (dz if has_res else None), None, None, None, None
 
 
 class ConvBNAct(torch.nn.Module):
@@ -206,7 +215,8 @@ class ConvBNAct(torch.nn.Module):
         self.register_buffer("running_mean", torch.zeros(out_channels))
         self.register_buffer("running_var", torch.ones(out_channels))
         self.stride, self.padding, self.relu = stride, padding, relu
+        self._pack_cache = PackCache()
 
     def forward(self, x, residual=None):
         scale, shift = fold_bn(self.bn_weight, self.bn_bias, self.running_mean, self.running_var, 1e-5)
-        return ConvAffineFunction.apply(x, self.weight, scale, shift, residual, self.stride, self.padding, self.relu)
+        return ConvAffineFunction.apply(x, self.weight, scale, shift, residual, self.stride, self.padding, self.relu, self._pack_cache)

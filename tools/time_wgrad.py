@@ -13,7 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from richsem_amd import _lib   # noqa: E402
-from richsem_amd.conv import _packed_for   # noqa: E402
+from richsem_amd.conv import _pack_form   # noqa: E402
 
 SHAPES = [  # name, H, W (input), Cin, Cout, k, stride, pad    (N = 2)
     ("l2 1x1 256-128", 200, 336, 256, 128, 1, 1, 0),
@@ -65,7 +65,7 @@ def main():
         nb = ctypes.c_int64(0)
         _lib.check(L.msda_conv_wgrad_workspace_bytes(N, H, W, Cin, Cout, k, k, stride, pad, ctypes.byref(nb)))
         ws = torch.empty(max(nb.value // 4, 4), device="cuda")
-        pk = _packed_for(w, scale, True)
+        pk = _pack_form(w, scale, True)
         dx = torch.empty_like(x)
 
         def wgrad():
