@@ -137,7 +137,7 @@ def _packed_for(weight, scale, transposed, cache=None):
 
 class ConvAffineFunction(torch.autograd.Function):
     """y = act(scale * conv(x, weight) + shift (+ residual)) on NHWC bf16 activations with gradients for x, weight and residual
-    (scale / shift are the frozen BatchNorm's: no gradient, backbone.py:20-56).  Forward: ``msda_conv_forward_bf16``.  Backward: the ReLU
+    (scale is the frozen BatchNorm's: no gradient, backbone.py:20-56; shift gets one when it is a trained bias).  Forward: ``msda_conv_forward_bf16``.  Backward: the ReLU
     mask is a PyTorch element-wise op; the input gradient is ``msda_conv_dgrad_bf16`` (the forward kernel on the zero-upsampled output
     gradient with the flipped, transposed, scale-folded weight); the weight gradient is ``msda_conv_wgrad_bf16`` (csrc/conv_wgrad.hip:
     pixel-contraction GEMM per tap with transposed LDS reads) when both channel counts are multiples of 128 -- every convolution of
@@ -199,7 +199,8 @@ class ConvAffineFunction(torch.autograd.Function):
                                                                weight.detach().to(torch.bfloat16), None, [stride, stride],
                                                                [padding, padding], [1, 1], False, [0, 0], 1, [False, True, False])
                 dw = (dw.float() * scale.view(-1, 1, 1, 1)).to(weight.dtype)
-        return dx, dw, None, None, (dz if has_res else None), None, None, None, None
+        dshift = dz.float().sum(dim=(0, 1, 2)) if ctx.needs_input_grad[3] else None      # a trained bias (input projections)
+        return dx, dw, None, dshift, (dz if has_res else None), None, None, None, None
 
 
 class ConvBNAct(torch.nn.Module):

@@ -130,3 +130,32 @@ def test_trainable_resnet_names_forward_and_gradients():
         # tensors as a whole must agree as well as PyTorch's own bf16 path does
         assert mine <= 1.5 * theirs + 1e-3 and cos >= 0.99, (n, mine, theirs, cos)
     print("worst mean weight-gradient error (of the tensor's maximum):", worst)
+
+
+def test_trainable_input_projection_forward_and_gradients():
+    """InputProjection (nn.Module, the reference's parameter names) against the inference form and fp32 autograd through the oracle's
+    op sequence: convolution weight, bias and GroupNorm parameters."""
+    from richsem_amd.backbone import InputProj, InputProjection
+    sdp = input_proj_state_dict(channels=(128, 256, 512), seed=3)
+    rng = np.random.default_rng(9)
+    feats = [torch.from_numpy(rng.normal(0, 1, (2, h, w, c)).astype(np.float32)).to(torch.bfloat16).cuda()
+             for (h, w), c in zip(((12, 20), (6, 10), (3, 5)), (128, 256, 512))]
+    mod = InputProjection(in_channels=(128, 256, 512)).cuda()
+    assert sorted(mod.state_dict().keys()) == sorted(sdp.keys())
+    mod.load_state_dict(sdp)
+    srcs, shapes = mod(feats)
+    ref_srcs, ref_shapes = InputProj(sdp)(feats)
+    assert shapes == ref_shapes
+    for a, b in zip(srcs, ref_srcs):
+        assert float((a - b).abs().max()) < 1e-5
+    gs = [torch.from_numpy(rng.normal(0, 1, tuple(s.shape)).astype(np.float32)) for s in srcs]
+    sum((s * g.cuda()).sum() for s, g in zip(srcs, gs)).backward()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sdp.items()}
+    with torch.enable_grad():
+        want = BO.input_proj.__wrapped__([f.permute(0, 3, 1, 2).float().cpu() for f in feats], sdr)
+        sum((w * g).sum() for w, g in zip(want, gs)).backward()
+    for k, p in mod.state_dict(keep_vars=True).items():
+        ref = sdr[k].grad
+        got = dict(mod.named_parameters())["layers." + k].grad.cpu()
+        s = float(ref.abs().max())
+        assert float((got - ref).abs().mean()) <= 6e-3 * s and float((got - ref).abs().max()) <= 6e-2 * s, (k, float((got - ref).abs().max()) / s)
