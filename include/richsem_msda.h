@@ -340,7 +340,7 @@ int msda_cls_max_scores(const void *x, int x_is_bf16, const uint16_t *packed, in
  *     x_0 = mean_t feat[k, :, t] + pos[0],  x_{t+1} = feat[k, :, t] + pos[t + 1]          (tokens, never materialised)
  *     a = softmax_t(u[k, h] . x_t),   z[k, h, :] = sum_t a_t x_t
  * and the caller finishes with Wv_h z[k, h] + bv_h and the output projection.
- * u, z (K, H, C); feat (K, C, T) as msda_roi_align_forward_* writes it; pos (T + 1, C); T <= 1024. */
+ * u, z (K, H, C); feat (K, C, T) as msda_roi_align_forward_* writes it; pos (T + 1, C); T <= 512. */
 int msda_attnpool_core_f32(const float *u, const float *feat, const float *pos, int K, int H, int C, int T, float *z,
                            msda_stream_t stream);
 int msda_attnpool_core_f64(const double *u, const double *feat, const double *pos, int K, int H, int C, int T, double *z,

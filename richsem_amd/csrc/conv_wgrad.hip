@@ -189,7 +189,7 @@ __global__ void conv_wgrad_reduce_kernel(const float *__restrict__ ws, float *__
 void wgrad_split(const WgradGeom &g, long long &split, long long &chunk)
 {
     const long long blocks_y = (long long)g.KH * g.KW * (g.Cout / kBM) * (g.Cin / kBN);
-    split = blocks_y >= 128 ? 1 : (512 + blocks_y - 1) / blocks_y;
+    split = blocks_y >= 128 ? 1 : (256 + blocks_y - 1) / blocks_y;
     const long long max_split = (g.P + 511) / 512;
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
@@ -230,7 +230,7 @@ int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, in
     if ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dw)) & 15) return MSDA_ERR_MISALIGNED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, (long long)N * Ho * Wo, 0};
-    if (g.P >= (1ll << 31) || (long long)N * H * W >= (1ll << 31)) return MSDA_ERR_TOO_LARGE;
+    if (g.P >= (1ll << 31) - (1 << 20) || (long long)N * H * W >= (1ll << 31)) return MSDA_ERR_TOO_LARGE;      // 32-bit pixel counters
     long long split;
     wgrad_split(g, split, g.chunk);
     const long long blocks_y = (long long)KH * KW * (Cout / kBM) * (Cin / kBN);

@@ -22,7 +22,7 @@
 namespace msda {
 
 constexpr int kAttnPoolThreads = 256;
-constexpr int kAttnPoolMaxT = 1024;
+constexpr int kAttnPoolMaxT = 512;       // (2 waves' worth of partial rows + scores in f64: 37 KB of the 64 KB a launch gets without opting in)
 
 template <typename T>
 __device__ __forceinline__ T attnpool_exp(T x);
