@@ -16,7 +16,7 @@ ERR_NAMES = {
     -4: "MSDA_ERR_TOO_LARGE", -5: "MSDA_ERR_MISALIGNED", -6: "MSDA_ERR_NO_DEVICE", -7: "MSDA_ERR_BAD_OPTION",
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/richsem_msda.h declares
 SYMBOLS = [
