@@ -35,8 +35,9 @@ def pack_w2_bf16(w2):
     return out
 
 
-def ffn_forward_bf16(x, w1, b1, w2_packed, b2, ln_weight, ln_bias, eps=1e-5):
-    """x (..., 256) bf16; w1 (d_ffn, 256) bf16; w2_packed from ``pack_w2_bf16``; biases / LayerNorm parameters float32."""
+def ffn_forward_bf16(x, w1, b1, w2_packed, b2, ln_weight, ln_bias, eps=1e-5, return_rstd=False):
+    """x (..., 256) bf16; w1 (d_ffn, 256) bf16; w2_packed from ``pack_w2_bf16``; biases / LayerNorm parameters float32.
+    ``return_rstd``: also the LayerNorm's 1 / sqrt(var + eps) per token (float32), which the backward needs."""
     if not x.is_cuda:
         raise RuntimeError("Not implemented on the CPU")
     assert x.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2_packed.dtype == torch.bfloat16
@@ -44,11 +45,25 @@ def ffn_forward_bf16(x, w1, b1, w2_packed, b2, ln_weight, ln_bias, eps=1e-5):
         assert t.dtype == torch.float32 and t.is_contiguous()
     x2 = x.contiguous().view(-1, x.shape[-1])
     out = torch.empty_like(x2)
+    rstd = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device) if return_rstd else None
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().msda_ffn_forward_bf16(
+        _lib.check(_lib.load().msda_ffn_forward_train_bf16(
             x2.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2_packed.data_ptr(), b2.data_ptr(), ln_weight.data_ptr(),
-            ln_bias.data_ptr(), float(eps), x2.shape[0], x2.shape[1], w1.shape[0], out.data_ptr(), _stream(x)))
-    return out.view(x.shape)
+            ln_bias.data_ptr(), float(eps), x2.shape[0], x2.shape[1], w1.shape[0], out.data_ptr(),
+            rstd.data_ptr() if rstd is not None else None, _stream(x)))
+    return (out.view(x.shape), rstd) if return_rstd else out.view(x.shape)
+
+
+def ffn_ln_backward_bf16(grad_out, out, rstd, ln_weight, ln_bias):
+    """First step of the backward (``msda_ffn_ln_backward_bf16``): -> (dz bf16 (tokens, 256), grad_ln_weight, grad_ln_bias, grad_b2)"""
+    g2, o2 = grad_out.contiguous().view(-1, 256), out.contiguous().view(-1, 256)
+    dz = torch.empty_like(o2)
+    sums = torch.empty(3, 256, dtype=torch.float32, device=o2.device)
+    with torch.cuda.device(o2.device):
+        _lib.check(_lib.load().msda_ffn_ln_backward_bf16(g2.data_ptr(), o2.data_ptr(), rstd.data_ptr(), ln_weight.data_ptr(),
+                                                         ln_bias.data_ptr(), o2.shape[0], 256, dz.data_ptr(), sums[0].data_ptr(),
+                                                         sums[1].data_ptr(), sums[2].data_ptr(), _stream(o2)))
+    return dz, sums[0], sums[1], sums[2]
 
 
 class FusedFFNFunction(Function):
@@ -56,32 +71,21 @@ class FusedFFNFunction(Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, ln_weight, ln_bias, eps):
-        out = ffn_forward_bf16(x, w1.contiguous(), b1, pack_w2_bf16(w2.contiguous()), b2, ln_weight, ln_bias, eps)
-        ctx.save_for_backward(x, w1, b1, w2, b2, ln_weight, out)
-        ctx.eps = eps
+        out, rstd = ffn_forward_bf16(x, w1.contiguous(), b1, pack_w2_bf16(w2.contiguous()), b2, ln_weight, ln_bias, eps, return_rstd=True)
+        ctx.save_for_backward(x, w1, b1, w2, ln_weight, ln_bias, out, rstd)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
-        x, w1, b1, w2, b2, ln_weight, out = ctx.saved_tensors
-        x2, g2 = x.reshape(-1, x.shape[-1]), grad_out.reshape(-1, x.shape[-1])
-        # recompute the hidden activation (bf16 GEMM) and the LayerNorm input
-        h = torch.relu(torch.addmm(b1.to(torch.bfloat16), x2, w1.t()))
-        y = (x2.float() + torch.addmm(b2.to(torch.bfloat16), h, w2.t()).float())
-        mean = y.mean(-1, keepdim=True)
-        rstd = torch.rsqrt(y.var(-1, unbiased=False, keepdim=True) + ctx.eps)
-        yhat = (y - mean) * rstd
-        g = g2.float()
-        grad_ln_w = (g * yhat).sum(0)
-        grad_ln_b = g.sum(0)
-        gy = g * ln_weight
-        gy = (gy - gy.mean(-1, keepdim=True) - yhat * (gy * yhat).mean(-1, keepdim=True)) * rstd     # LayerNorm backward
-        gyb = gy.to(torch.bfloat16)
-        grad_b2 = gy.sum(0)
-        grad_w2 = gyb.t() @ h
-        gh = (gyb @ w2) * (h > 0)
-        grad_b1 = gh.float().sum(0)
+        x, w1, b1, w2, ln_weight, ln_bias, out, rstd = ctx.saved_tensors
+        x2 = x.reshape(-1, x.shape[-1])
+        # LayerNorm backward + the three token sums in one kernel (yhat from the stored output, rstd from the forward)
+        dz, grad_ln_w, grad_ln_b, grad_b2 = ffn_ln_backward_bf16(grad_out.to(torch.bfloat16), out, rstd, ln_weight, ln_bias)
+        h = torch.relu(torch.addmm(b1.to(torch.bfloat16), x2, w1.t()))          # the hidden activation, recomputed (bf16 GEMM)
+        grad_w2 = dz.t() @ h
+        gh = torch.ops.aten.threshold_backward(dz @ w2, h, 0)                  # gradient at the ReLU's input
+        grad_b1 = gh.sum(0, dtype=torch.float32)
         grad_w1 = gh.t() @ x2
-        grad_x = (gy + (gh @ w1).float()).to(torch.bfloat16).view(x.shape)
+        grad_x = torch.addmm(dz, gh, w1).view(x.shape)                          # residual + first product's input gradient
         return grad_x, grad_w1, grad_b1, grad_w2, grad_b2, grad_ln_w, grad_ln_b, None
