@@ -1,0 +1,79 @@
+"""Weight gradient of a linear layer on the matrix cores: dW = dY^T X with the contraction over the tokens -- the product the library's
+transposed GEMM is slowest at (36 TFLOP/s at the MSDeformAttn projections' shape).  It is the convolution weight-gradient kernel
+(csrc/conv_wgrad.hip) on a 1 x 1 convolution over a 1 x T "image": natural [token][channel] tiles staged through LDS and read
+transposed.  Used by the bf16 module path for the four projections of MSDeformAttn (ops/modules/ms_deform_attn.py:52-56) and by the
+feed-forward block's backward."""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+
+def linear_wgrad_supported(out_features, in_features):
+    return out_features % 128 == 0 and in_features % 128 == 0
+
+
+def linear_wgrad_bf16(dy, x):
+    """dy (T, out_features), x (T, in_features), both bf16 and contiguous -> dW (out_features, in_features) float32"""
+    assert dy.is_cuda and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.dim() == 2 and x.dim() == 2
+    assert dy.shape[0] == x.shape[0]
+    dy, x = dy.contiguous(), x.contiguous()
+    T, cout = dy.shape
+    cin = x.shape[1]
+    L = _lib.load()
+    dw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
+    if T == 0:
+        return dw.zero_()
+    nb = ctypes.c_int64(0)
+    _lib.check(L.msda_conv_wgrad_workspace_bytes(1, 1, T, cin, cout, 1, 1, 1, 0, ctypes.byref(nb)))
+    ws = torch.empty(nb.value // 4, dtype=torch.float32, device=x.device) if nb.value else None
+    with torch.cuda.device(x.device):
+        _lib.check(L.msda_conv_wgrad_bf16(dy.data_ptr(), x.data_ptr(), 1, 1, T, cin, cout, 1, 1, 1, 0, dw.data_ptr(),
+                                          ws.data_ptr() if ws is not None else None, torch.cuda.current_stream(x.device).cuda_stream))
+    return dw
+
+
+class LinearBf16Function(torch.autograd.Function):
+    """``F.linear`` on bf16 activations with fp32 parameters (cast per call): the forward and the input gradient are the library's bf16
+    GEMMs, the weight gradient is :func:`linear_wgrad_bf16` (for layer sizes it supports and enough tokens to pay: the library's
+    transposed GEMM otherwise), the bias gradient a column sum.  Gradients come back in the parameters' dtype."""
+
+    MIN_TOKENS = 4096
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w16 = weight.to(torch.bfloat16)
+        ctx.save_for_backward(x, w16)
+        ctx.meta = (weight.dtype, bias.dtype if bias is not None else None)
+        # written into a tensor of the final shape (F.linear on a 3-d input returns a view, which a custom Function must not hand out
+        # when the caller may modify it in place -- the module's padding mask does)
+        out = torch.empty(x.shape[:-1] + (w16.shape[0],), dtype=torch.bfloat16, device=x.device)
+        x2 = x.reshape(-1, x.shape[-1])
+        if bias is not None:
+            torch.addmm(bias.to(torch.bfloat16), x2, w16.t(), out=out.view(-1, w16.shape[0]))
+        else:
+            torch.mm(x2, w16.t(), out=out.view(-1, w16.shape[0]))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w16 = ctx.saved_tensors
+        wdt, bdt = ctx.meta
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]).contiguous(), x.reshape(-1, x.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ w16).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            if linear_wgrad_supported(dy2.shape[1], x2.shape[1]) and dy2.shape[0] >= LinearBf16Function.MIN_TOKENS:
+                dw = linear_wgrad_bf16(dy2, x2.contiguous()).to(wdt)
+            else:
+                dw = (dy2.t() @ x2).to(wdt)
+        if bdt is not None and ctx.needs_input_grad[2]:
+            db = dy2.sum(0, dtype=torch.float32).to(bdt)
+        return dx, dw, db
+
+
+def linear_bf16(x, weight, bias=None):
+    return LinearBf16Function.apply(x, weight, bias)

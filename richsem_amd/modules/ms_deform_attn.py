@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions import MaskRows, MSDeformAttnFunction, MSDeformAttnFusedFunction
+from ..functions.linear import linear_bf16
 
 
 def _is_power_of_2(n):
@@ -83,19 +84,21 @@ class MSDeformAttn(nn.Module):
             # module's (fp32) parameters cast per call, value / output travel as bf16 through the operator's bf16 entry points,
             # locations and attention weights are formed and kept in fp32
             dt = query.dtype
-            cast = (lambda p: p.to(dt)) if dt == torch.bfloat16 else (lambda p: p)
-            value = F.linear(input_flatten.to(dt), cast(self.value_proj.weight), cast(self.value_proj.bias))
+            # (bf16: LinearBf16Function -- library GEMMs for the forward and the input gradient, the library's own MFMA kernel for the
+            # weight gradient, whose contraction runs over the tokens)
+            linear = linear_bf16 if dt == torch.bfloat16 else F.linear
+            value = linear(input_flatten.to(dt), self.value_proj.weight, self.value_proj.bias)
             if input_padding_mask is not None:
                 value = MaskRows.apply(value, input_padding_mask)
             # offsets and attention logits from ONE projection (the two weight matrices stacked: 256 -> 384 for RichSem)
             weight = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
             bias = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
-            qproj = F.linear(query, cast(weight), cast(bias))
+            qproj = linear(query, weight, bias)
             ref_dt = torch.float32 if dt == torch.bfloat16 else dt
             out = MSDeformAttnFusedFunction.apply(value.view(N, S, H, self.d_model // H), input_spatial_shapes,
                                                   input_level_start_index, qproj, reference_points.to(ref_dt), H, L, P,
                                                   self.im2col_step)
-            return F.linear(out, cast(self.output_proj.weight), cast(self.output_proj.bias))
+            return linear(out, self.output_proj.weight, self.output_proj.bias)
 
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:

@@ -109,3 +109,25 @@ def test_module_fused_path_equals_op_by_op_path_within_bf16():
     plain = m.to(torch.bfloat16)(src)
     assert fused.shape == src.shape and fused.dtype == torch.bfloat16
     assert float((fused.float() - plain.float()).abs().mean()) < 6e-3
+
+
+@pytest.mark.parametrize("tokens,cout,cin", [(5000, 256, 256), (4097, 384, 256), (4500, 256, 2048), (300, 128, 128)])
+def test_linear_weight_gradient_kernel(tokens, cout, cin):
+    """functions/linear.py: dW = dY^T X through the convolution weight-gradient kernel against fp32 on the same bf16 operands"""
+    from richsem_amd.functions.linear import linear_bf16, linear_wgrad_bf16
+    torch.manual_seed(tokens)
+    dy = torch.randn(tokens, cout, device="cuda").to(torch.bfloat16)
+    x = torch.randn(tokens, cin, device="cuda").to(torch.bfloat16)
+    want = dy.float().t() @ x.float()
+    got = linear_wgrad_bf16(dy, x)
+    assert got.dtype == torch.float32 and float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    # the autograd function around it: gradients in the parameters' dtype, equal to the op-by-op bf16 linear's within bf16
+    w = (torch.randn(cout, cin, device="cuda") * cin ** -0.5).requires_grad_(True)
+    b = torch.zeros(cout, device="cuda", requires_grad=True)
+    xin = x.clone().requires_grad_(True)
+    linear_bf16(xin, w, b).backward(dy)
+    wr, br, xr = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True), x.float().requires_grad_(True)
+    torch.nn.functional.linear(xr, wr.to(torch.bfloat16).float(), br).backward(dy.float())
+    assert w.grad.dtype == torch.float32 and b.grad.dtype == torch.float32 and xin.grad.dtype == torch.bfloat16
+    for got, ref in ((w.grad, wr.grad), (b.grad, br.grad), (xin.grad.float(), xr.grad)):
+        assert float((got - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
