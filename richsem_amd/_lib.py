@@ -112,7 +112,7 @@ def load():
     L.msda_conv_forward_bf16.restype = ci
     L.msda_conv_dgrad_bf16.argtypes = [vp, vp] + [ci] * 11 + [vp, vp]
     L.msda_conv_dgrad_bf16.restype = ci
-    L.msda_conv_wgrad_bf16.argtypes = [vp, vp] + [ci] * 9 + [vp, vp, vp]
+    L.msda_conv_wgrad_bf16.argtypes = [vp, vp] + [ci] * 9 + [vp, vp, vp, vp]
     L.msda_conv_wgrad_bf16.restype = ci
     L.msda_conv_wgrad_workspace_bytes.argtypes = [ci] * 9 + [ctypes.POINTER(i64)]
     L.msda_conv_wgrad_workspace_bytes.restype = ci

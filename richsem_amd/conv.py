@@ -192,7 +192,7 @@ class ConvAffineFunction(torch.autograd.Function):
                 ws = torch.empty(nb.value // 4, dtype=torch.float32, device=x.device) if nb.value else None
                 with torch.cuda.device(x.device):
                     _lib.check(L.msda_conv_wgrad_bf16(dz.data_ptr(), x.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, padding,
-                                                      dw4.data_ptr(), ws.data_ptr() if ws is not None else None, _stream(x.device)))
+                                                      dw4.data_ptr(), None, ws.data_ptr() if ws is not None else None, _stream(x.device)))
                 dw = (dw4 * scale.view(-1, 1, 1, 1)).permute(0, 3, 1, 2).to(weight.dtype)
             else:       # channel counts the wgrad kernel does not take (ResNet-50's layer2-4 never get here): MIOpen
                 _, dw, _ = torch.ops.aten.convolution_backward(dz.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2),

@@ -43,7 +43,7 @@ struct WgradGeom {
 __device__ __forceinline__ int lds_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__restrict__ dz, const uint16_t *__restrict__ x,
-                                                              float *__restrict__ dw, WgradGeom g)
+                                                              float *__restrict__ dw, float *__restrict__ dbias, WgradGeom g)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * kImageBytes];   // [buffer][A image | B image]
 
@@ -75,6 +75,9 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
     // one stage ahead in one register set (a second set -- two stages in flight -- spills 195 registers at the 256-register budget of
     // two workgroups per CU and doubles the run time; with 512 registers the kernel runs one wave per SIMD and gains nothing)
     u32x4 sa[4], sb[4];
+    // optional: the bias gradient sum_p dz[p][co], formed on the way by the workgroups of tap 0 / input block 0 (this thread: its 8 channels)
+    const bool want_bias = dbias != nullptr && tap == 0 && cib == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto fetch = [&]() {      // the next stage's rows; advances the row coordinates
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -104,6 +107,13 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
             const int off = lds_off(row0 + 16 * i, ch);
             *reinterpret_cast<u32x4 *>(lds[slot] + off) = sa[i];
             *reinterpret_cast<u32x4 *>(lds[slot] + kImageBytes + off) = sb[i];
+            if (want_bias) {      // (here, where the rows have arrived anyway: summing them at the load would wait for it)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __uint_as_float(sa[i][e] << 16);
+                    bsum[2 * e + 1] += __uint_as_float(sa[i][e] & 0xFFFF0000u);
+                }
+            }
         }
     };
 
@@ -158,6 +168,17 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
     // blockIdx.x writes its own slice of the output (the result itself when there is one chunk, else the workspace)
     const int taps = g.KH * g.KW;
     float *out = dw + (size_t)blockIdx.x * g.Cout * taps * g.Cin;
+    if (want_bias) {      // fold the 16 row groups (threads with equal ch) through LDS; chunk blockIdx.x writes its slice of dbias
+        float *red = reinterpret_cast<float *>(lds[0]);     // (the last barrier of the loop has passed: the images are free)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(row0 * 16 + ch) * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < kBM) {
+            float v = 0.f;
+            for (int r = 0; r < 16; ++r) v += red[(r * 16 + (tid >> 3)) * 8 + (tid & 7)];
+            dbias[(size_t)blockIdx.x * g.Cout + cob * kBM + tid] = v;
+        }
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -172,8 +193,15 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
 }
 
 // dw[i] = sum over the chunks' slices
-__global__ void conv_wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, long long n4, int split)
+__global__ void conv_wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, long long n4, int split,
+                                         const float *__restrict__ ws_bias, float *__restrict__ dbias, int cout)
 {
+    if (ws_bias && blockIdx.x == 0)
+        for (int c = threadIdx.x; c < cout; c += blockDim.x) {
+            float v = 0.f;
+            for (int s = 0; s < split; ++s) v += ws_bias[(size_t)s * cout + c];
+            dbias[c] = v;
+        }
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         float4 a = reinterpret_cast<const float4 *>(ws)[i];
         for (int s = 1; s < split; ++s) {
@@ -213,12 +241,12 @@ int msda_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int 
     WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, (long long)N * Ho * Wo, 0};
     long long split, chunk;
     wgrad_split(g, split, chunk);
-    *bytes = split > 1 ? (int64_t)split * Cout * KH * KW * Cin * (int64_t)sizeof(float) : 0;
+    *bytes = split > 1 ? (int64_t)split * ((int64_t)Cout * KH * KW * Cin + Cout) * (int64_t)sizeof(float) : 0;      // (+ bias partials)
     return MSDA_OK;
 }
 
 int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                         int pad, float *dw, void *workspace, msda_stream_t stream)
+                         int pad, float *dw, float *dbias, void *workspace, msda_stream_t stream)
 {
     if (!dz || !x || !dw) return MSDA_ERR_NULL_POINTER;
     if (N < 1 || H < 1 || W < 1 || Cin < kBN || Cin % kBN != 0 || Cout < kBM || Cout % kBM != 0 || KH < 1 || KW < 1 || KH > 16 || KW > 16 ||
@@ -237,14 +265,16 @@ int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, in
     const long long n_dw = (long long)Cout * KH * KW * Cin;
     if (split > 1 && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15))) return MSDA_ERR_NULL_POINTER;
     if (blocks_y > 65535) return MSDA_ERR_TOO_LARGE;
+    float *ws_bias = split > 1 ? static_cast<float *>(workspace) + split * n_dw : nullptr;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)split, (unsigned)blocks_y), dim3(kThreads), 0, st, dz, x,
-                       split > 1 ? static_cast<float *>(workspace) : dw, g);
+                       split > 1 ? static_cast<float *>(workspace) : dw, dbias ? (split > 1 ? ws_bias : dbias) : nullptr, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (split > 1) {
         const long long n4 = n_dw / 4;
         const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, static_cast<const float *>(workspace), dw, n4, (int)split);
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, static_cast<const float *>(workspace), dw, n4, (int)split,
+                           dbias ? ws_bias : nullptr, dbias, Cout);
     }
     e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;

@@ -20,13 +20,17 @@ from .. import _lib
 FUSED_FFN_MIN_TOKENS = 16384
 
 
-def _wgrad(dy, x):
+def _wgrad(dy, x, with_bias=False):
     """dW = dy^T x in bf16 (contraction over the tokens): the library's own MFMA kernel where it applies (functions/linear.py: 131 vs
     208 us at the encoder shape), else the library's transposed GEMM"""
     from .linear import LinearBf16Function, linear_wgrad_bf16, linear_wgrad_supported
     if linear_wgrad_supported(dy.shape[1], x.shape[1]) and dy.shape[0] >= LinearBf16Function.MIN_TOKENS:
+        if with_bias:
+            dw, db = linear_wgrad_bf16(dy, x.contiguous(), with_bias=True)
+            return dw.to(torch.bfloat16), db
         return linear_wgrad_bf16(dy, x.contiguous()).to(torch.bfloat16)
-    return dy.t() @ x
+    dw = dy.t() @ x
+    return (dw, dy.sum(0, dtype=torch.float32)) if with_bias else dw
 
 
 def _stream(t):
@@ -94,7 +98,6 @@ class FusedFFNFunction(Function):
         h = torch.relu(torch.addmm(b1.to(torch.bfloat16), x2, w1.t()))          # the hidden activation, recomputed (bf16 GEMM)
         grad_w2 = _wgrad(dz, h)
         gh = torch.ops.aten.threshold_backward(dz @ w2, h, 0)                  # gradient at the ReLU's input
-        grad_b1 = gh.sum(0, dtype=torch.float32)
-        grad_w1 = _wgrad(gh, x2)
+        grad_w1, grad_b1 = _wgrad(gh, x2, with_bias=True)
         grad_x = torch.addmm(dz, gh, w1).view(x.shape)                          # residual + first product's input gradient
         return grad_x, grad_w1, grad_b1, grad_w2, grad_b2, grad_ln_w, grad_ln_b, None

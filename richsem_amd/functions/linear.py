@@ -14,8 +14,9 @@ def linear_wgrad_supported(out_features, in_features):
     return out_features % 128 == 0 and in_features % 128 == 0
 
 
-def linear_wgrad_bf16(dy, x):
-    """dy (T, out_features), x (T, in_features), both bf16 and contiguous -> dW (out_features, in_features) float32"""
+def linear_wgrad_bf16(dy, x, with_bias=False):
+    """dy (T, out_features), x (T, in_features), both bf16 and contiguous -> dW (out_features, in_features) float32; ``with_bias``: also
+    the bias gradient sum_t dy[t] (out_features) float32, formed by the same kernel on the way"""
     assert dy.is_cuda and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.dim() == 2 and x.dim() == 2
     assert dy.shape[0] == x.shape[0]
     dy, x = dy.contiguous(), x.contiguous()
@@ -23,15 +24,17 @@ def linear_wgrad_bf16(dy, x):
     cin = x.shape[1]
     L = _lib.load()
     dw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if with_bias else None
     if T == 0:
-        return dw.zero_()
+        return (dw.zero_(), db.zero_()) if with_bias else dw.zero_()
     nb = ctypes.c_int64(0)
     _lib.check(L.msda_conv_wgrad_workspace_bytes(1, 1, T, cin, cout, 1, 1, 1, 0, ctypes.byref(nb)))
     ws = torch.empty(nb.value // 4, dtype=torch.float32, device=x.device) if nb.value else None
     with torch.cuda.device(x.device):
         _lib.check(L.msda_conv_wgrad_bf16(dy.data_ptr(), x.data_ptr(), 1, 1, T, cin, cout, 1, 1, 1, 0, dw.data_ptr(),
-                                          ws.data_ptr() if ws is not None else None, torch.cuda.current_stream(x.device).cuda_stream))
-    return dw
+                                          db.data_ptr() if db is not None else None, ws.data_ptr() if ws is not None else None,
+                                          torch.cuda.current_stream(x.device).cuda_stream))
+    return (dw, db) if with_bias else dw
 
 
 class LinearBf16Function(torch.autograd.Function):
@@ -65,12 +68,18 @@ class LinearBf16Function(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = (dy2 @ w16).view(x.shape)
+        want_b = bdt is not None and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if linear_wgrad_supported(dy2.shape[1], x2.shape[1]) and dy2.shape[0] >= LinearBf16Function.MIN_TOKENS:
-                dw = linear_wgrad_bf16(dy2, x2.contiguous()).to(wdt)
+                if want_b:
+                    dw, db = linear_wgrad_bf16(dy2, x2.contiguous(), with_bias=True)
+                    db = db.to(bdt)
+                else:
+                    dw = linear_wgrad_bf16(dy2, x2.contiguous())
+                dw = dw.to(wdt)
             else:
                 dw = (dy2.t() @ x2).to(wdt)
-        if bdt is not None and ctx.needs_input_grad[2]:
+        if want_b and db is None:
             db = dy2.sum(0, dtype=torch.float32).to(bdt)
         return dx, dw, db
 

@@ -32,5 +32,8 @@ for cout, cin in ((256, 256), (384, 256), (256, 2048), (2048, 256)):
     got = linear_wgrad_bf16(dy, x)
     err = float((got - want).abs().max() / want.abs().max())
     t1, t2 = timeit(lambda: linear_wgrad_bf16(dy, x)), timeit(lambda: dy.t() @ x)
+    t3, t4 = timeit(lambda: linear_wgrad_bf16(dy, x, with_bias=True)), timeit(lambda: dy.sum(0, dtype=torch.float32))
+    dwb, db = linear_wgrad_bf16(dy, x, with_bias=True)
+    eb = float((db - dy.float().sum(0)).abs().max() / dy.float().sum(0).abs().max())
     fl = 2.0 * T * cout * cin
-    print(f"dW ({cout} x {cin}), {T} tokens: kernel {t1:6.1f} us ({fl / t1 / 1e6:5.0f} TFLOP/s)  library bf16 {t2:6.1f} us   rel err vs fp32 {err:.1e}")
+    print(f"dW ({cout} x {cin}), {T} tokens: kernel {t1:6.1f} us ({fl / t1 / 1e6:5.0f} TFLOP/s)  library bf16 {t2:6.1f} us   rel err vs fp32 {err:.1e};  with the bias sum {t3:6.1f} us (err {eb:.1e}; torch column sum alone {t4:5.1f} us)")
