@@ -386,6 +386,13 @@ int msda_ffn_forward_train_bf16(const uint16_t *x, const uint16_t *w1, const flo
 int msda_ffn_ln_backward_bf16(const uint16_t *dy, const uint16_t *out, const float *rstd, const float *ln_weight, const float *ln_bias,
                               int tokens, int d_model, uint16_t *dz, float *grad_ln_weight, float *grad_ln_bias, float *grad_b2,
                               msda_stream_t stream);
+/* out = act(x W^T + b) for in_features = 256 on the matrix cores (csrc/lin256_mfma.hip; bf16 storage, fp32 accumulation): the two
+ * token-parallel products of the feed-forward block's backward.  msda_lin256_pack_bf16: W (out_features, 256) bf16 row-major -> the same
+ * number of elements in MFMA fragment order (out_features % 64 == 0).  epilogue 0: acc + bias (bias may be NULL); 1: relu(acc + bias);
+ * 2: acc where relu_mask > 0, else 0 (relu_mask (tokens, out_features) bf16: the forward's hidden activation).  16-byte aligned pointers. */
+int msda_lin256_pack_bf16(const uint16_t *w, int out_features, int in_features, uint16_t *packed, msda_stream_t stream);
+int msda_lin256_forward_bf16(const uint16_t *x, const uint16_t *packed_w, const float *bias, const uint16_t *relu_mask, int epilogue,
+                             int tokens, int in_features, int out_features, uint16_t *out, msda_stream_t stream);
 /* Diagnostic: non-NULL = the kernel adds up the shader clocks wave 0 of every workgroup spends per loop stage (wait for the
  * weight tile, barrier, first product, relu + conversion, second product) into 8 x 8 bytes per workgroup; NULL = off. */
 int msda_ffn_debug_stamps(void *device_buffer);

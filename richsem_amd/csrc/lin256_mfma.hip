@@ -1,0 +1,212 @@
+// lin256_mfma.hip -- out = act(x W^T + b) for a 256-wide input on the gfx950 matrix cores (bf16 storage, fp32 accumulation), with the
+// two epilogues the feed-forward block's backward needs (reference forward_ffn,
+// models/richsem/deformable_transformer.py:862-866, :940-944):
+//     relu:  h  = relu(x W1^T + b1)                    the hidden activation, recomputed in the backward
+//     mask:  gh = (dz W2) * (h > 0)                     gradient at the ReLU's input (W = W2^T, no bias)
+// (and the plain / biased form).  The library's GEMM runs these K = 256 shapes at ~220 TFLOP/s (210 us for 44646 x 256 x 2048).
+//
+// Structure of csrc/cls_mfma.hip / ffn_mfma.hip: transposed product, tokens on the lanes (mfma_f32_16x16x32_bf16); a wave owns 48 tokens
+// and keeps their x fragments (96 VGPRs) for the whole kernel; W streams once per workgroup through LDS in blocks of 64 output
+// channels (32 KB: 4 row tiles x 8 k-steps), double-buffered through registers, one barrier per block (96 MFMAs per wave).  Output
+// channels are permuted inside a block (row 4 q + i of tile u = channel 16 q + 4 u + i, msda_lin256_pack) so that a lane holds 16
+// consecutive channels of its token: 32-byte stores, whole 128-byte lines per token.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "../../include/richsem_msda.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int kD = 256;
+constexpr int kTokWave = 48, kWaves = 4, kTokWg = kTokWave * kWaves;
+constexpr int kFragShorts = 512;
+constexpr int kBlockRows = 64;                                  // output channels per LDS block
+constexpr int kBlockShorts = 4 * 8 * kFragShorts;              // 32 KB
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+{
+    const bf16x2_t p = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+// W (N x 256) bf16 row-major -> packed[block][k-step][tile u][lane][8]; lane (r = 4 q' + i, q) of tile u = output channel
+// 64 block + 16 q' + 4 u + i, input channels 32 step + 8 q + 0..7
+__global__ void lin256_pack_kernel(const uint16_t *__restrict__ w, uint16_t *__restrict__ packed, int N)
+{
+    const long long n = (long long)N * kD;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63), u = (int)((i >> 9) & 3), s = (int)((i >> 11) & 7), blk = (int)(i >> 14);
+        const int r = lane & 15, q = lane >> 4;
+        const int ch = kBlockRows * blk + 16 * (r >> 2) + 4 * u + (r & 3), k = 32 * s + 8 * q + j;
+        packed[i] = w[(long long)ch * kD + k];
+    }
+}
+
+// EPI 0: out = acc + bias;  1: out = relu(acc + bias);  2: out = acc * (mask > 0)
+template <int EPI>
+__global__ __launch_bounds__(kWaves * 64, 2)      // two workgroups per CU: one's stores / conversions under the other's MFMAs
+void lin256_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ packed, const float *__restrict__ bias,
+                   const uint16_t *__restrict__ mask, int T, int N, uint16_t *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) short wbuf[2][kBlockShorts];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int tok0 = blockIdx.x * kTokWg + wave * kTokWave;
+    // the output channels are split over gridDim.y workgroups (so that every CU holds two)
+    const int nb_all = N / kBlockRows;
+    const int b_lo = (int)((long long)nb_all * blockIdx.y / gridDim.y), b_hi = (int)((long long)nb_all * (blockIdx.y + 1) / gridDim.y);
+
+    bf16x8 xf[3][8];
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3) {
+        const int tok = min(tok0 + 16 * t3 + c, T - 1);
+        const uint16_t *row = x + (size_t)tok * kD + 8 * q;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) xf[t3][s] = *reinterpret_cast<const bf16x8 *>(row + 32 * s);
+    }
+
+    constexpr int kChunks = kBlockShorts * 2 / 16 / (kWaves * 64);      // 8 x 16 bytes per thread and block
+    u32x4 stage[kChunks];
+    auto fetch = [&](int b) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(packed + (size_t)b * kBlockShorts);
+#pragma unroll
+        for (int i = 0; i < kChunks; ++i) stage[i] = src[tid + i * (kWaves * 64)];
+    };
+    auto park = [&](int slot) {
+        u32x4 *dst = reinterpret_cast<u32x4 *>(wbuf[slot]);
+#pragma unroll
+        for (int i = 0; i < kChunks; ++i) dst[tid + i * (kWaves * 64)] = stage[i];
+    };
+    if (b_lo < b_hi) {
+        fetch(b_lo);
+        park(b_lo & 1);
+    }
+    __syncthreads();
+
+    for (int b = b_lo; b < b_hi; ++b) {
+        if (b + 1 < b_hi) fetch(b + 1);
+        // the mask rows of this block, requested before the products that hide their latency
+        u32x4 mreg[EPI == 2 ? 3 : 1][2];
+        if (EPI == 2) {
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+                const int tok = min(tok0 + 16 * t3 + c, T - 1);
+                const u32x4 *mp = reinterpret_cast<const u32x4 *>(mask + (size_t)tok * N + kBlockRows * b + 16 * q);
+                mreg[EPI == 2 ? t3 : 0][0] = mp[0];
+                mreg[EPI == 2 ? t3 : 0][1] = mp[1];
+            }
+        }
+        const short *wt = wbuf[b & 1];
+        f32x4 acc[3][4];
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[t3][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wt + (s * 4 + u) * kFragShorts + lane * 8);
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3) acc[t3][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xf[t3][s], acc[t3][u], 0, 0, 0);
+            }
+        // lane (c, q): channels 64 b + 16 q + (4 u + i) of token c
+        const int ch0 = kBlockRows * b + 16 * q;
+        float bb[16];
+        if (EPI != 2) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 v = bias ? *reinterpret_cast<const f32x4 *>(bias + ch0 + 4 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bb[4 * u + i] = v[i];
+            }
+        }
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) {
+            const int tok = tok0 + 16 * t3 + c;
+            if (tok >= T) continue;
+            float y[16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[4 * u + i] = acc[t3][u][i];
+            if (EPI == 2) {
+                const u32x4 m0 = mreg[EPI == 2 ? t3 : 0][0], m1 = mreg[EPI == 2 ? t3 : 0][1];
+                const unsigned mw[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (!(bf16_lo(mw[e]) > 0.f)) y[2 * e] = 0.f;
+                    if (!(bf16_hi(mw[e]) > 0.f)) y[2 * e + 1] = 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    y[e] += bb[e];
+                    if (EPI == 1) y[e] = fmaxf(y[e], 0.f);
+                }
+            }
+            u32x4 *op = reinterpret_cast<u32x4 *>(out + (size_t)tok * N + ch0);
+            op[0] = (u32x4){pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7])};
+            op[1] = (u32x4){pack_bf16(y[8], y[9]), pack_bf16(y[10], y[11]), pack_bf16(y[12], y[13]), pack_bf16(y[14], y[15])};
+        }
+        if (b + 1 < b_hi) park((b + 1) & 1);
+        __syncthreads();
+    }
+}
+
+template <int EPI>
+int launch_lin(const uint16_t *x, const uint16_t *packed, const float *bias, const uint16_t *mask, int T, int N, uint16_t *out,
+               hipStream_t st)
+{
+    const int gx = (T + kTokWg - 1) / kTokWg, nb = N / kBlockRows;
+    int gy = (512 + gx - 1) / gx;          // about two workgroups per CU
+    if (gy > nb) gy = nb;
+    if (gy > 8) gy = 8;
+    hipLaunchKernelGGL(lin256_kernel<EPI>, dim3(gx, gy), dim3(kWaves * 64), 0, st, x, packed, bias, mask, T, N, out);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msda_lin256_pack_bf16(const uint16_t *w, int out_features, int in_features, uint16_t *packed, msda_stream_t stream)
+{
+    if (!w || !packed) return MSDA_ERR_NULL_POINTER;
+    if (in_features != kD || out_features < kBlockRows || out_features % kBlockRows != 0) return MSDA_ERR_BAD_DIMS;
+    hipLaunchKernelGGL(lin256_pack_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), w, packed, out_features);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
+
+int msda_lin256_forward_bf16(const uint16_t *x, const uint16_t *packed_w, const float *bias, const uint16_t *relu_mask, int epilogue,
+                             int tokens, int in_features, int out_features, uint16_t *out, msda_stream_t stream)
+{
+    if (!x || !packed_w || !out) return MSDA_ERR_NULL_POINTER;
+    if (tokens < 0 || in_features != kD || out_features < kBlockRows || out_features % kBlockRows != 0 || epilogue < 0 || epilogue > 2)
+        return MSDA_ERR_BAD_DIMS;
+    if (epilogue == 2 && !relu_mask) return MSDA_ERR_NULL_POINTER;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed_w) | reinterpret_cast<uintptr_t>(out) |
+         reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(relu_mask)) & 15)
+        return MSDA_ERR_MISALIGNED;
+    if (tokens == 0) return MSDA_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (epilogue) {
+    case 0: return launch_lin<0>(x, packed_w, bias, nullptr, tokens, out_features, out, st);
+    case 1: return launch_lin<1>(x, packed_w, bias, nullptr, tokens, out_features, out, st);
+    default: return launch_lin<2>(x, packed_w, nullptr, relu_mask, tokens, out_features, out, st);
+    }
+}
+
+}  // extern "C"

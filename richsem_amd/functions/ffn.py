@@ -95,9 +95,17 @@ class FusedFFNFunction(Function):
         x2 = x.reshape(-1, x.shape[-1])
         # LayerNorm backward + the three token sums in one kernel (yhat from the stored output, rstd from the forward)
         dz, grad_ln_w, grad_ln_b, grad_b2 = ffn_ln_backward_bf16(grad_out.to(torch.bfloat16), out, rstd, ln_weight, ln_bias)
-        h = torch.relu(torch.addmm(b1.to(torch.bfloat16), x2, w1.t()))          # the hidden activation, recomputed (bf16 GEMM)
-        grad_w2 = _wgrad(dz, h)
-        gh = torch.ops.aten.threshold_backward(dz @ w2, h, 0)                  # gradient at the ReLU's input
+        # the two token-parallel products with K = 256 on the library's own kernel (csrc/lin256_mfma.hip: 81 / 114 us against 173 / 204 us
+        # for the library's GEMM + element-wise op): the hidden activation, recomputed, and the gradient at the ReLU's input
+        from .linear import lin256, lin256_pack
+        if w1.shape[0] % 64 == 0:
+            h = lin256(x2, lin256_pack(w1), b1, relu=True)
+            grad_w2 = _wgrad(dz, h)
+            gh = lin256(dz, lin256_pack(w2.t()), relu_mask=h)
+        else:
+            h = torch.relu(torch.addmm(b1.to(torch.bfloat16), x2, w1.t()))
+            grad_w2 = _wgrad(dz, h)
+            gh = torch.ops.aten.threshold_backward(dz @ w2, h, 0)
         grad_w1, grad_b1 = _wgrad(gh, x2, with_bias=True)
         grad_x = torch.addmm(dz, gh, w1).view(x.shape)                          # residual + first product's input gradient
         return grad_x, grad_w1, grad_b1, grad_w2, grad_b2, grad_ln_w, grad_ln_b, None

@@ -86,3 +86,32 @@ class LinearBf16Function(torch.autograd.Function):
 
 def linear_bf16(x, weight, bias=None):
     return LinearBf16Function.apply(x, weight, bias)
+
+
+def lin256_pack(weight):
+    """weight (out_features, 256) -> bf16 in the fragment order of ``lin256`` (csrc/lin256_mfma.hip); out_features % 64 == 0"""
+    w = weight.detach().to(torch.bfloat16).contiguous()
+    assert w.is_cuda and w.dim() == 2 and w.shape[1] == 256 and w.shape[0] % 64 == 0
+    packed = torch.empty_like(w)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().msda_lin256_pack_bf16(w.data_ptr(), w.shape[0], 256, packed.data_ptr(),
+                                                     torch.cuda.current_stream(w.device).cuda_stream))
+    return packed
+
+
+def lin256(x, packed_w, bias=None, relu=False, relu_mask=None):
+    """x (T, 256) bf16 -> (T, out_features) bf16: ``x W^T + bias`` (``relu``: with ReLU), or ``(x W^T) * (relu_mask > 0)`` when
+    ``relu_mask`` (T, out_features) bf16 is given (the gradient at a ReLU's input from the gradient at its output)"""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256
+    x = x.contiguous()
+    N = packed_w.shape[0]
+    out = torch.empty((x.shape[0], N), dtype=torch.bfloat16, device=x.device)
+    if relu_mask is not None:
+        assert relu_mask.shape == out.shape and relu_mask.dtype == torch.bfloat16 and relu_mask.is_contiguous() and bias is None
+    epi = 2 if relu_mask is not None else (1 if relu else 0)
+    b = bias.detach().float().contiguous() if bias is not None else None
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().msda_lin256_forward_bf16(x.data_ptr(), packed_w.data_ptr(), b.data_ptr() if b is not None else None,
+                                                        relu_mask.data_ptr() if relu_mask is not None else None, epi, x.shape[0], 256, N,
+                                                        out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream))
+    return out

@@ -131,3 +131,23 @@ def test_linear_weight_gradient_kernel(tokens, cout, cin):
     assert w.grad.dtype == torch.float32 and b.grad.dtype == torch.float32 and xin.grad.dtype == torch.bfloat16
     for got, ref in ((w.grad, wr.grad), (b.grad, br.grad), (xin.grad.float(), xr.grad)):
         assert float((got - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("tokens,n", [(1000, 2048), (193, 64), (47, 128), (4097, 1024)])
+def test_lin256_kernel(tokens, n):
+    """csrc/lin256_mfma.hip: relu(x W^T + b), x W^T + b and (x W^T) * (mask > 0) against fp32 on the same bf16 operands (one bf16
+    rounding of the result)"""
+    from richsem_amd.functions.linear import lin256, lin256_pack
+    torch.manual_seed(n + tokens)
+    x = torch.randn(tokens, 256, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(n, 256, device="cuda") / 16).to(torch.bfloat16)
+    b = torch.randn(n, device="cuda")
+    wp = lin256_pack(w)
+    lin = x.float() @ w.float().t()
+    for got, want in ((lin256(x, wp, b, relu=True), torch.relu(lin + b)), (lin256(x, wp, b), lin + b), (lin256(x, wp), lin)):
+        assert got.dtype == torch.bfloat16 and float((got.float() - want).abs().max()) <= 2 ** -7 * float(want.abs().max())
+    h = torch.relu(lin + b).to(torch.bfloat16)
+    got = lin256(x, wp, relu_mask=h)
+    want = lin * (h > 0)
+    assert float((got.float() - want).abs().max()) <= 2 ** -7 * float(want.abs().max())
+    assert bool(((got == 0) | (h > 0)).all())
