@@ -273,9 +273,29 @@ def ffn_row(n_img, dev):
 
     flop = 4.0 * T * D * Fh
     t_f, t_o = timeit(fused), timeit(ops)
+    # training: forward + backward through FusedFFNFunction (LayerNorm gradient kernel, K = 256 products on lin256_kernel, weight gradients
+    # on conv_wgrad_kernel, dx by the library) against autograd through the same block as PyTorch bf16 ops
+    from richsem_amd.functions import FusedFFNFunction
+    leaf = lambda t: t.detach().clone().requires_grad_(True)
+    xa, w1a, w2a, b1a, b2a, gwa, gba = (leaf(t) for t in (x, w1, w2, b1, b2, gw, gb))
+    go = torch.randn(T, D, device=dev, generator=g).to(torch.bfloat16)
+
+    def train_fused():
+        for p in (xa, w1a, w2a, b1a, b2a, gwa, gba):
+            p.grad = None
+        FusedFFNFunction.apply(xa, w1a, b1a, w2a, b2a, gwa, gba, 1e-5).backward(go)
+
+    def train_ops():
+        for p in (xa, w1a, w2a, b1a, b2a, gwa, gba):
+            p.grad = None
+        h = torch.relu(F.linear(xa, w1a, b1a.to(torch.bfloat16)))
+        F.layer_norm(xa + F.linear(h, w2a, b2a.to(torch.bfloat16)), (D,), gwa.to(torch.bfloat16), gba.to(torch.bfloat16)).backward(go)
+
+    t_tf, t_to = timeit(train_fused, 10), timeit(train_ops, 10)
     return {"what": "encoder feed-forward block forward (256 -> 2048 -> 256, relu, residual, LayerNorm), bf16, one HIP kernel; "
                     "outside the timed step", "hip_kernel": "ffn_fwd_kernel", "tokens": T, "flop": flop,
             "avg_launch_us": round(t_f * 1e6, 1),
+            "train_forward_backward_us": round(t_tf * 1e6, 1), "pytorch_bf16_autograd_forward_backward_us": round(t_to * 1e6, 1),
             "roofline": {"bound": "mfma", "achieved": round(flop / t_f / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(flop / t_f / 1e12 / 2500.0, 4)},
             "pytorch_bf16_ops_us": round(t_o * 1e6, 1)}
