@@ -604,7 +604,7 @@ def main(argv=None):
         if graph_ms is not None:
             line["graph_replay"] = {"what": "the same step (no collective) captured into one HIP graph and replayed; not `value`",
                                     "ms_per_step": round(graph_ms, 4), "img_per_s": round(n_total / (graph_ms * 1e-3), 3)}
-        if not args.no_ffn:
+        if not args.no_ffn and world == 1:      # (the rows beside the path are single-GPU measurements, like the CPU baseline)
             line["mfma_row"] = ffn_row(n_img, dev)
             line["mfma_rows"] = {"two_stage_class_score": cls_row(n_img, dev), "resnet50_forward": backbone_row(n_img, dev)}
         if world == 1 and not args.no_cpu_baseline:
