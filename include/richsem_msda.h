@@ -393,6 +393,13 @@ int msda_ffn_ln_backward_bf16(const uint16_t *dy, const uint16_t *out, const flo
 int msda_lin256_pack_bf16(const uint16_t *w, int out_features, int in_features, uint16_t *packed, msda_stream_t stream);
 int msda_lin256_forward_bf16(const uint16_t *x, const uint16_t *packed_w, const float *bias, const uint16_t *relu_mask, int epilogue,
                              int tokens, int in_features, int out_features, uint16_t *out, msda_stream_t stream);
+/* The same product for fp32 tensors at fp32-level accuracy (both operands split into bf16 hi + lo parts, three bf16 MFMAs per tile;
+ * csrc/lin256_mfma.hip): out (tokens, out_features) f32 = x (tokens, 256) f32 . W^T + bias.  msda_lin256_pack_f32: W (out_features, 256)
+ * f32 -> 2 * out_features * 256 uint16 (hi and lo parts in fragment order); out_features % 32 == 0.  The MSDeformAttn module's fp32
+ * projections (reference ops/modules/ms_deform_attn.py:52-56). */
+int msda_lin256_pack_f32(const float *w, int out_features, int in_features, uint16_t *packed, msda_stream_t stream);
+int msda_lin256_forward_f32(const float *x, const uint16_t *packed_w, const float *bias, int tokens, int in_features, int out_features,
+                            float *out, msda_stream_t stream);
 /* Diagnostic: non-NULL = the kernel adds up the shader clocks wave 0 of every workgroup spends per loop stage (wait for the
  * weight tile, barrier, first product, relu + conversion, second product) into 8 x 8 bytes per workgroup; NULL = off. */
 int msda_ffn_debug_stamps(void *device_buffer);

@@ -164,6 +164,120 @@ void lin256_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ 
     }
 }
 
+// ---- fp32 in / fp32 out at fp32-level accuracy: both operands split into bf16 hi + lo parts, hi.hi + lo_w.hi_x + hi_w.lo_x (the scheme
+// of csrc/cls_mfma.hip: three bf16 MFMAs instead of the fp32 MFMA's sixteen-fold cost) -- the MSDeformAttn module's fp32 projections
+// (reference ops/modules/ms_deform_attn.py:52-56, :94-100), which the library's fp32 GEMM runs at 80-100 TFLOP/s.
+constexpr int kF32BlockRows = 32;                                  // output channels per LDS block (2 row tiles, hi + lo parts)
+constexpr int kF32BlockShorts = 2 * 8 * 2 * kFragShorts;           // [part][k-step][tile][fragment]: 32 KB
+
+// W (N x 256) fp32 -> packed[block][part][k-step][tile u][lane][8] bf16; row 4 q' + i of tile u = channel 32 block + 8 q' + 4 u + i
+__global__ void lin256_pack_f32_kernel(const float *__restrict__ w, uint16_t *__restrict__ packed, int N)
+{
+    const long long n = (long long)N * kD;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63), u = (int)((i >> 9) & 1), s = (int)((i >> 10) & 7), blk = (int)(i >> 13);
+        const int r = lane & 15, q = lane >> 4;
+        const int ch = kF32BlockRows * blk + 8 * (r >> 2) + 4 * u + (r & 3), k = 32 * s + 8 * q + j;
+        const float v = w[(long long)ch * kD + k];
+        const unsigned hi = pack_bf16(v, 0.f) & 0xFFFFu;
+        const unsigned lo = pack_bf16(v - __uint_as_float(hi << 16), 0.f) & 0xFFFFu;
+        const long long base = (long long)blk * kF32BlockShorts + ((long long)(s * 2 + u) * 64 + lane) * 8 + j;
+        packed[base] = (uint16_t)hi;
+        packed[base + 8 * 2 * kFragShorts] = (uint16_t)lo;
+    }
+}
+
+__global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void lin256_f32_kernel(const float *__restrict__ x, const uint16_t *__restrict__ packed, const float *__restrict__ bias, int T, int N,
+                       float *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) short wbuf[2][kF32BlockShorts];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int tok0 = blockIdx.x * kTokWg + wave * kTokWave;
+    const int nb_all = N / kF32BlockRows;
+    const int b_lo = (int)((long long)nb_all * blockIdx.y / gridDim.y), b_hi = (int)((long long)nb_all * (blockIdx.y + 1) / gridDim.y);
+
+    bf16x8 xh[3][8], xl[3][8];
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3) {
+        const int tok = min(tok0 + 16 * t3 + c, T - 1);
+        const float *row = x + (size_t)tok * kD + 8 * q;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float4 a = *reinterpret_cast<const float4 *>(row + 32 * s), b = *reinterpret_cast<const float4 *>(row + 32 * s + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            u32x4 h, l;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                h[p] = pack_bf16(v[2 * p], v[2 * p + 1]);
+                l[p] = pack_bf16(v[2 * p] - bf16_lo(h[p]), v[2 * p + 1] - bf16_hi(h[p]));
+            }
+            xh[t3][s] = __builtin_bit_cast(bf16x8, h);
+            xl[t3][s] = __builtin_bit_cast(bf16x8, l);
+        }
+    }
+
+    constexpr int kChunks = kF32BlockShorts * 2 / 16 / (kWaves * 64);      // 8
+    u32x4 stage[kChunks];
+    auto fetch = [&](int b) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(packed + (size_t)b * kF32BlockShorts);
+#pragma unroll
+        for (int i = 0; i < kChunks; ++i) stage[i] = src[tid + i * (kWaves * 64)];
+    };
+    auto park = [&](int slot) {
+        u32x4 *dst = reinterpret_cast<u32x4 *>(wbuf[slot]);
+#pragma unroll
+        for (int i = 0; i < kChunks; ++i) dst[tid + i * (kWaves * 64)] = stage[i];
+    };
+    if (b_lo < b_hi) {
+        fetch(b_lo);
+        park(b_lo & 1);
+    }
+    __syncthreads();
+
+    for (int b = b_lo; b < b_hi; ++b) {
+        if (b + 1 < b_hi) fetch(b + 1);
+        const short *wt = wbuf[b & 1];
+        f32x4 acc[3][2];
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[t3][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(wt + (s * 2 + u) * kFragShorts + lane * 8);
+                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(wt + (16 + s * 2 + u) * kFragShorts + lane * 8);
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3) acc[t3][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[t3][s], acc[t3][u], 0, 0, 0);
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3) acc[t3][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[t3][s], acc[t3][u], 0, 0, 0);
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3) acc[t3][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[t3][s], acc[t3][u], 0, 0, 0);
+            }
+        // lane (c, q): channels 32 b + 8 q + (4 u + i) of token c: two 16-byte stores
+        const int ch0 = kF32BlockRows * b + 8 * q;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            b0 = *reinterpret_cast<const f32x4 *>(bias + ch0);
+            b1 = *reinterpret_cast<const f32x4 *>(bias + ch0 + 4);
+        }
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) {
+            const int tok = tok0 + 16 * t3 + c;
+            if (tok >= T) continue;
+            f32x4 *op = reinterpret_cast<f32x4 *>(out + (size_t)tok * N + ch0);
+            op[0] = acc[t3][0] + b0;
+            op[1] = acc[t3][1] + b1;
+        }
+        if (b + 1 < b_hi) park((b + 1) & 1);
+        __syncthreads();
+    }
+}
+
 template <int EPI>
 int launch_lin(const uint16_t *x, const uint16_t *packed, const float *bias, const uint16_t *mask, int T, int N, uint16_t *out,
                hipStream_t st)
@@ -207,6 +321,34 @@ int msda_lin256_forward_bf16(const uint16_t *x, const uint16_t *packed_w, const 
     case 1: return launch_lin<1>(x, packed_w, bias, nullptr, tokens, out_features, out, st);
     default: return launch_lin<2>(x, packed_w, nullptr, relu_mask, tokens, out_features, out, st);
     }
+}
+
+int msda_lin256_pack_f32(const float *w, int out_features, int in_features, uint16_t *packed, msda_stream_t stream)
+{
+    if (!w || !packed) return MSDA_ERR_NULL_POINTER;
+    if (in_features != kD || out_features < kF32BlockRows || out_features % kF32BlockRows != 0) return MSDA_ERR_BAD_DIMS;
+    hipLaunchKernelGGL(lin256_pack_f32_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), w, packed, out_features);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
+
+int msda_lin256_forward_f32(const float *x, const uint16_t *packed_w, const float *bias, int tokens, int in_features, int out_features,
+                            float *out, msda_stream_t stream)
+{
+    if (!x || !packed_w || !out) return MSDA_ERR_NULL_POINTER;
+    if (tokens < 0 || in_features != kD || out_features < kF32BlockRows || out_features % kF32BlockRows != 0) return MSDA_ERR_BAD_DIMS;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed_w) | reinterpret_cast<uintptr_t>(out) |
+         reinterpret_cast<uintptr_t>(bias)) & 15)
+        return MSDA_ERR_MISALIGNED;
+    if (tokens == 0) return MSDA_OK;
+    const int gx = (tokens + kTokWg - 1) / kTokWg, nb = out_features / kF32BlockRows;
+    int gy = 1;          // (one workgroup per CU: 1 wave per SIMD at its register count; 233 workgroups at the training shape)
+    if (gy > nb) gy = nb;
+    if (gy > 4) gy = 4;
+    hipLaunchKernelGGL(lin256_f32_kernel, dim3(gx, gy), dim3(kWaves * 64), 0, static_cast<hipStream_t>(stream), x, packed_w, bias, tokens,
+                       out_features, out);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
 }
 
 }  // extern "C"

@@ -115,3 +115,27 @@ def lin256(x, packed_w, bias=None, relu=False, relu_mask=None):
                                                         relu_mask.data_ptr() if relu_mask is not None else None, epi, x.shape[0], 256, N,
                                                         out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream))
     return out
+
+
+def lin256_f32_pack(weight):
+    """weight (out_features, 256) float32 -> bf16 hi + lo parts in the fragment order of ``lin256_f32``; out_features % 32 == 0"""
+    w = weight.detach().float().contiguous()
+    assert w.is_cuda and w.dim() == 2 and w.shape[1] == 256 and w.shape[0] % 32 == 0
+    packed = torch.empty(2 * w.numel(), dtype=torch.int16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().msda_lin256_pack_f32(w.data_ptr(), w.shape[0], 256, packed.data_ptr(),
+                                                    torch.cuda.current_stream(w.device).cuda_stream))
+    return packed
+
+
+def lin256_f32(x, packed_w, out_features, bias=None):
+    """x (T, 256) float32 -> x W^T + bias (T, out_features) float32 at fp32-level accuracy on bf16 MFMAs (three per tile)"""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 256
+    x = x.contiguous()
+    out = torch.empty((x.shape[0], out_features), dtype=torch.float32, device=x.device)
+    b = bias.detach().float().contiguous() if bias is not None else None
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().msda_lin256_forward_f32(x.data_ptr(), packed_w.data_ptr(), b.data_ptr() if b is not None else None,
+                                                       x.shape[0], 256, out_features, out.data_ptr(),
+                                                       torch.cuda.current_stream(x.device).cuda_stream))
+    return out

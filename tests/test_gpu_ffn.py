@@ -151,3 +151,18 @@ def test_lin256_kernel(tokens, n):
     want = lin * (h > 0)
     assert float((got.float() - want).abs().max()) <= 2 ** -7 * float(want.abs().max())
     assert bool(((got == 0) | (h > 0)).all())
+
+
+@pytest.mark.parametrize("tokens,n", [(1000, 256), (4097, 384), (50, 32)])
+def test_lin256_f32_split_kernel(tokens, n):
+    """fp32 in / out on bf16 MFMAs with hi + lo split operands: fp32-level accuracy (1e-5 of the output range against fp64)"""
+    from richsem_amd.functions.linear import lin256_f32, lin256_f32_pack
+    torch.manual_seed(n + tokens)
+    x = torch.randn(tokens, 256, device="cuda")
+    w = torch.randn(n, 256, device="cuda") / 16
+    b = torch.randn(n, device="cuda")
+    want = x.double() @ w.double().t() + b.double()
+    got = lin256_f32(x, lin256_f32_pack(w), n, b)
+    assert got.dtype == torch.float32 and float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    got0 = lin256_f32(x, lin256_f32_pack(w), n)
+    assert float((got0.double() - (want - b.double())).abs().max()) <= 1e-5 * float(want.abs().max())

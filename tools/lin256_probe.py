@@ -39,3 +39,16 @@ t2 = timeit(lambda: torch.relu(torch.addmm(b.bfloat16(), x, w.t())))
 t3 = timeit(lambda: lin256(x, wp, relu_mask=h))
 t4 = timeit(lambda: torch.ops.aten.threshold_backward(x @ w.t(), h, 0))
 print(f"h = relu(x W^T + b): kernel {t1:.1f} us ({fl / t1 / 1e6:.0f} TFLOP/s), library ops {t2:.1f} us;  gh = (x W^T) * (h > 0): kernel {t3:.1f} us, library ops {t4:.1f} us")
+
+from richsem_amd.functions.linear import lin256_f32, lin256_f32_pack   # noqa: E402
+xf = torch.randn(T, 256, device="cuda")
+for n in (256, 384):
+    wf = torch.randn(n, 256, device="cuda") / 16
+    bf = torch.randn(n, device="cuda")
+    pk = lin256_f32_pack(wf)
+    got = lin256_f32(xf, pk, n, bf)
+    want = (xf.double() @ wf.double().t() + bf.double())
+    lib = torch.nn.functional.linear(xf, wf, bf)
+    e1, e2 = float((got.double() - want).abs().max() / want.abs().max()), float((lib.double() - want).abs().max() / want.abs().max())
+    t1, t2 = timeit(lambda: lin256_f32(xf, pk, n, bf)), timeit(lambda: torch.nn.functional.linear(xf, wf, bf))
+    print(f"fp32 linear 256 -> {n}: split-bf16 kernel {t1:.1f} us (err {e1:.1e}), library fp32 {t2:.1f} us (err {e2:.1e})")
