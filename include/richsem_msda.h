@@ -341,11 +341,12 @@ int msda_cls_max_scores(const void *x, int x_is_bf16, const uint16_t *packed, in
  *     x_0 = mean_t feat[k, :, t] + pos[0],  x_{t+1} = feat[k, :, t] + pos[t + 1]          (tokens, never materialised)
  *     a = softmax_t(u[k, h] . x_t),   z[k, h, :] = sum_t a_t x_t
  * and the caller finishes with Wv_h z[k, h] + bv_h and the output projection.
- * u, z (K, H, C); feat (K, C, T) as msda_roi_align_forward_* writes it; pos (T + 1, C); T <= 512. */
-int msda_attnpool_core_f32(const float *u, const float *feat, const float *pos, int K, int H, int C, int T, float *z,
-                           msda_stream_t stream);
-int msda_attnpool_core_f64(const double *u, const double *feat, const double *pos, int K, int H, int C, int T, double *z,
-                           msda_stream_t stream);
+ * u, z (K, H, C), or (H, K, C) when head_major != 0; feat (K, C, T) as msda_roi_align_forward_* writes it; pos (T + 1, C);
+ * spos = u . pos^T, rows as u, T + 1 columns (one library GEMM of the caller's); T <= 256. */
+int msda_attnpool_core_f32(const float *u, const float *feat, const float *pos, const float *spos, int K, int H, int C, int T,
+                           int head_major, float *z, msda_stream_t stream);
+int msda_attnpool_core_f64(const double *u, const double *feat, const double *pos, const double *spos, int K, int H, int C, int T,
+                           int head_major, double *z, msda_stream_t stream);
 
 /* ---- the Hungarian matcher's cost blocks (reference models/richsem/matcher.py:49-78 with
  * util/box_ops.py:9-59) --------------------------------------------------------------------------------------------

@@ -94,7 +94,7 @@ def load():
         f.restype = ci
     for sfx in ("f32", "f64"):
         f = getattr(L, "msda_attnpool_core_" + sfx)
-        f.argtypes = [vp] * 3 + [ci] * 4 + [vp, vp]
+        f.argtypes = [vp] * 4 + [ci] * 5 + [vp, vp]
         f.restype = ci
     L.msda_cls_packed_elems.argtypes = [ci, ctypes.POINTER(i64)]
     L.msda_cls_packed_elems.restype = ci

@@ -22,7 +22,7 @@
 namespace msda {
 
 constexpr int kAttnPoolThreads = 256;
-constexpr int kAttnPoolMaxT = 512;       // (2 waves' worth of partial rows + scores in f64: 37 KB of the 64 KB a launch gets without opting in)
+constexpr int kAttnPoolMaxT = 256;       // (4 heads x (4 waves of partial rows + scores) in f64: 41 KB of the 64 KB a launch gets without opting in)
 
 template <typename T>
 __device__ __forceinline__ T attnpool_exp(T x);
@@ -31,88 +31,95 @@ __device__ __forceinline__ float attnpool_exp<float>(float x) { return expf(x); 
 template <>
 __device__ __forceinline__ double attnpool_exp<double>(double x) { return exp(x); }
 
-template <typename T>
+// HG heads per workgroup: the ROI's features (C x Tn, 400 KB at CLIP-RN50's size) are read once per HG heads instead of once per head
+// (HG = 1 made the kernel a stream of L2 reads: 25 MB per ROI)
+template <typename T, int HG>
 __global__ __launch_bounds__(kAttnPoolThreads) void attnpool_core_kernel(const T *__restrict__ u, const T *__restrict__ feat,
-                                                                          const T *__restrict__ pos, int H, int C, int Tn,
-                                                                          T *__restrict__ z)
+                                                                          const T *__restrict__ pos, const T *__restrict__ spos, int K,
+                                                                          int H, int C, int Tn, int head_major, T *__restrict__ z)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char attnpool_smem[];
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave, waves = kAttnPoolThreads / kWave;
     const int stride = Tn + 1;
-    T *part_f = reinterpret_cast<T *>(attnpool_smem);     // [waves][stride]: partial u . f_t at [1 + t]
-    T *part_p = part_f + waves * stride;                   // [waves][stride]: partial u . pos_t' at [t']
-    T *sc = part_p + waves * stride;                       // [stride]: scores, then attention weights
-    const int k = blockIdx.x / H, h = blockIdx.x % H;
-    const T *uh = u + ((int64_t)k * H + h) * C;
+    T *part_f = reinterpret_cast<T *>(attnpool_smem);     // [HG][waves][stride]: partial u . f_t at [1 + t]
+    T *sc = part_f + HG * waves * stride;                  // [HG][stride]: scores, then attention weights
+    const int groups = H / HG;
+    const int k = blockIdx.x / groups, h0 = (blockIdx.x % groups) * HG;
+    // u and z: (K, H, C), or (H, K, C) when head_major (what a batched product over the heads reads and writes without a transpose)
+    int64_t rows[HG];
+#pragma unroll
+    for (int g = 0; g < HG; ++g) rows[g] = head_major ? (int64_t)(h0 + g) * K + k : (int64_t)k * H + h0 + g;
     const T *fk = feat + (int64_t)k * C * Tn;
 
-    // lane = token, a wave takes every waves-th channel: u . f_t and u . pos_{t+1} side by side
+    // lane = token, a wave takes every waves-th channel: u_g . f_t for the HG heads (the positional part u . pos_t comes in as `spos`:
+    // a product the caller forms with one library GEMM -- read here per lane it would be one cache line per token and channel)
     for (int t0 = 0; t0 < Tn; t0 += kWave) {
         const int t = t0 + lane;
         if (t < Tn) {
-            T af = (T)0, ap = (T)0;
+            T af[HG];
+#pragma unroll
+            for (int g = 0; g < HG; ++g) af[g] = (T)0;
             for (int c = wave; c < C; c += waves) {
-                const T uc = uh[c];
-                af += uc * fk[(int64_t)c * Tn + t];
-                ap += uc * pos[(int64_t)(t + 1) * C + c];
+                const T f = fk[(int64_t)c * Tn + t];
+#pragma unroll
+                for (int g = 0; g < HG; ++g) af[g] += u[rows[g] * C + c] * f;
             }
-            part_f[wave * stride + 1 + t] = af;
-            part_p[wave * stride + 1 + t] = ap;
+#pragma unroll
+            for (int g = 0; g < HG; ++g) part_f[(g * waves + wave) * stride + 1 + t] = af[g];
         }
     }
-    {   // u . pos_0
-        T acc = (T)0;
-        for (int c = lane + wave * kWave; c < C; c += kAttnPoolThreads) acc += uh[c] * pos[c];
-        for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
-        if (lane == 0) part_p[wave * stride] = acc;
-    }
     __syncthreads();
-    // fold the waves' partial sums; the feature part stays in part_f's first row for the mean token's score
-    for (int t = threadIdx.x; t <= Tn; t += kAttnPoolThreads) {
-        T sf = (T)0, sp = (T)0;
-        for (int w = 0; w < waves; ++w) {
-            if (t > 0) sf += part_f[w * stride + t];
-            sp += part_p[w * stride + t];
+    // fold the waves' partial sums; the feature part stays in the group's first row for the mean token's score
+    for (int i = threadIdx.x; i < HG * stride; i += kAttnPoolThreads) {
+        const int g = i / stride, t = i - g * stride;
+        T sf = (T)0;
+        if (t > 0) {
+            for (int w = 0; w < waves; ++w) sf += part_f[(g * waves + w) * stride + t];
+            part_f[g * waves * stride + t] = sf;          // (wave 0's row of head g, entry t: read above by this thread only)
         }
-        if (t > 0) part_f[t] = sf;          // (row 0, entry t: read above by this thread only)
-        sc[t] = sf + sp;
+        sc[g * stride + t] = sf + spos[rows[g] * stride + t];
     }
     __syncthreads();
-    if (wave == 0) {   // score of the mean token: u . (mean_t f_t + pos_0) = mean_t (u . f_t) + u . pos_0
+    // one wave per head (round robin): score of the mean token -- u . (mean_t f_t + pos_0) = mean_t (u . f_t) + u . pos_0 -- and softmax
+    for (int g = wave; g < HG; g += waves) {
+        T *scg = sc + g * stride;
+        const T *pf = part_f + g * waves * stride;
         T m = (T)0;
-        for (int t = lane; t < Tn; t += kWave) m += part_f[1 + t];
+        for (int t = lane; t < Tn; t += kWave) m += pf[1 + t];
         for (int o = kWave / 2; o > 0; o >>= 1) m += __shfl_xor(m, o, kWave);
-        if (lane == 0) sc[0] += m / (T)Tn;
-    }
-    __syncthreads();
-    // softmax over the Tn + 1 scores (one wave)
-    if (wave == 0) {
-        T mx = -INFINITY;
-        for (int t = lane; t <= Tn; t += kWave) mx = fmax(mx, sc[t]);
+        const T s0 = scg[0] + m / (T)Tn;
+        T mx = s0;
+        for (int t = lane; t < Tn; t += kWave) mx = fmax(mx, scg[1 + t]);
         for (int o = kWave / 2; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, kWave));
         T sum = (T)0;
-        for (int t = lane; t <= Tn; t += kWave) {
-            const T e = attnpool_exp<T>(sc[t] - mx);
-            sc[t] = e;
+        for (int t = lane; t < Tn; t += kWave) {
+            const T e = attnpool_exp<T>(scg[1 + t] - mx);
+            scg[1 + t] = e;
             sum += e;
         }
         for (int o = kWave / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, kWave);
-        const T inv = (T)1 / sum;
-        for (int t = lane; t <= Tn; t += kWave) sc[t] *= inv;
+        const T e0 = attnpool_exp<T>(s0 - mx);
+        const T inv = (T)1 / (sum + e0);
+        for (int t = lane; t < Tn; t += kWave) scg[1 + t] *= inv;
+        if (lane == 0) scg[0] = e0 * inv;
     }
     __syncthreads();
-    // z[c] = a_0 (mean_t f[c, t] + pos_0[c]) + sum_t a_{t+1} (f[c, t] + pos_{t+1}[c]): one channel per thread
-    T *zh = z + ((int64_t)k * H + h) * C;
-    const T a0 = sc[0];
+    // z_g[c] = a_0 (mean_t f[c, t] + pos_0[c]) + sum_t a_{t+1} (f[c, t] + pos_{t+1}[c]): one channel per thread, the HG heads side by side
     for (int c = threadIdx.x; c < C; c += kAttnPoolThreads) {
-        const T *row = fk + (int64_t)c * Tn;
-        T mean = (T)0, acc = (T)0;
+        const T *frow = fk + (int64_t)c * Tn;
+        T mean = (T)0, acc[HG];
+#pragma unroll
+        for (int g = 0; g < HG; ++g) acc[g] = (T)0;
         for (int t = 0; t < Tn; ++t) {
-            const T f = row[t];
+            const T f = frow[t];
             mean += f;
-            acc += sc[1 + t] * (f + pos[(int64_t)(t + 1) * C + c]);
+            const T fp = f + pos[(int64_t)(t + 1) * C + c];
+#pragma unroll
+            for (int g = 0; g < HG; ++g) acc[g] += sc[g * stride + 1 + t] * fp;
         }
-        zh[c] = a0 * (mean / (T)Tn + pos[c]) + acc;
+        const T m0 = mean / (T)Tn + pos[c];
+#pragma unroll
+        for (int g = 0; g < HG; ++g) z[rows[g] * C + c] = sc[g * stride] * m0 + acc[g];
     }
 }
 

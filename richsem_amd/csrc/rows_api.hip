@@ -31,15 +31,24 @@ int matcher_cost_impl(const T *logits, const T *boxes, const int64_t *tgt_ids, c
 }
 
 template <typename T>
-int attnpool_core_impl(const T *u, const T *feat, const T *pos, int K, int H, int C, int Tn, T *z, msda_stream_t stream)
+int attnpool_core_impl(const T *u, const T *feat, const T *pos, const T *spos, int K, int H, int C, int Tn, int head_major, T *z,
+                       msda_stream_t stream)
 {
-    if (!u || !feat || !pos || !z) return MSDA_ERR_NULL_POINTER;
+    if (!u || !feat || !pos || !spos || !z) return MSDA_ERR_NULL_POINTER;
     if (K < 0 || H < 1 || C < 1 || Tn < 1 || Tn > msda::kAttnPoolMaxT) return MSDA_ERR_BAD_DIMS;
     if (K == 0) return MSDA_OK;
     if ((int64_t)K * H >= ((int64_t)1 << 31) || (int64_t)K * C * Tn >= ((int64_t)1 << 40)) return MSDA_ERR_TOO_LARGE;
-    const size_t lds = (size_t)(2 * (msda::kAttnPoolThreads / msda::kWave) + 1) * (Tn + 1) * sizeof(T);
-    hipLaunchKernelGGL(msda::attnpool_core_kernel<T>, dim3(K * H), dim3(msda::kAttnPoolThreads), lds, static_cast<hipStream_t>(stream), u,
-                       feat, pos, H, C, Tn, z);
+    const int waves = msda::kAttnPoolThreads / msda::kWave;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (H % 4 == 0) {
+        const size_t lds = (size_t)4 * (waves + 1) * (Tn + 1) * sizeof(T);
+        hipLaunchKernelGGL((msda::attnpool_core_kernel<T, 4>), dim3(K * (H / 4)), dim3(msda::kAttnPoolThreads), lds, st, u, feat, pos, spos, K,
+                           H, C, Tn, head_major, z);
+    } else {
+        const size_t lds = (size_t)(waves + 1) * (Tn + 1) * sizeof(T);
+        hipLaunchKernelGGL((msda::attnpool_core_kernel<T, 1>), dim3(K * H), dim3(msda::kAttnPoolThreads), lds, st, u, feat, pos, spos, K, H, C,
+                           Tn, head_major, z);
+    }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
 }
@@ -48,15 +57,15 @@ int attnpool_core_impl(const T *u, const T *feat, const T *pos, int K, int H, in
 
 extern "C" {
 
-int msda_attnpool_core_f32(const float *u, const float *feat, const float *pos, int K, int H, int C, int T, float *z,
-                           msda_stream_t stream)
+int msda_attnpool_core_f32(const float *u, const float *feat, const float *pos, const float *spos, int K, int H, int C, int T,
+                           int head_major, float *z, msda_stream_t stream)
 {
-    return attnpool_core_impl<float>(u, feat, pos, K, H, C, T, z, stream);
+    return attnpool_core_impl<float>(u, feat, pos, spos, K, H, C, T, head_major, z, stream);
 }
-int msda_attnpool_core_f64(const double *u, const double *feat, const double *pos, int K, int H, int C, int T, double *z,
-                           msda_stream_t stream)
+int msda_attnpool_core_f64(const double *u, const double *feat, const double *pos, const double *spos, int K, int H, int C, int T,
+                           int head_major, double *z, msda_stream_t stream)
 {
-    return attnpool_core_impl<double>(u, feat, pos, K, H, C, T, z, stream);
+    return attnpool_core_impl<double>(u, feat, pos, spos, K, H, C, T, head_major, z, stream);
 }
 
 int msda_matcher_cost_f32(const float *logits, const float *boxes, const int64_t *tgt_ids, const float *tgt_boxes,

@@ -42,20 +42,44 @@ class AttentionPool2d(nn.Module):
         if K == 0:
             return x.new_zeros(0, out_dim)
         feat = x.contiguous()
-        pos = self.positional_embedding.to(dt).contiguous()
-        x0 = feat.flatten(2).mean(dim=2) + pos[0]                                              # the query token (model.py:72)
-        q = torch.addmm(self.q_proj.bias.to(dt), x0, self.q_proj.weight.to(dt).t()) * (hd ** -0.5)   # (K, C), scaled as F.mha does
-        # u[k, h, :] = Wk_h^T q[k, h]: per head a (K, hd) x (hd, C) product
-        u = torch.bmm(q.view(K, H, hd).transpose(0, 1), self.k_proj.weight.to(dt).view(H, hd, C)).transpose(0, 1).contiguous()
+        d = self._derived(dt)
+        x0 = feat.flatten(2).mean(dim=2) + d["pos"][0]                                         # the query token (model.py:72)
+        q = torch.addmm(d["bq"], x0, d["wq_t"])                                                # (K, C), scaled as F.mha does
+        # u[h, k, :] = Wk_h^T q[k, h]: one batched product over the heads, (H, K, hd) x (H, hd, C) -> (H, K, C)
+        u = torch.bmm(q.view(K, H, hd).transpose(0, 1), d["wk_h"])
         z = torch.empty_like(u)
+        spos = torch.mm(u.view(H * K, C), d["pos_t"])                                          # u . pos_t for every (head, ROI): (H K, T + 1)
         fn = getattr(_lib.load(), "msda_attnpool_core_" + ("f32" if dt == torch.float32 else "f64"))
         with torch.cuda.device(x.device):
-            _lib.check(fn(u.data_ptr(), feat.data_ptr(), pos.data_ptr(), K, H, C, T, z.data_ptr(),
+            _lib.check(fn(u.data_ptr(), feat.data_ptr(), d["pos"].data_ptr(), spos.data_ptr(), K, H, C, T, 1, z.data_ptr(),
                           torch.cuda.current_stream(x.device).cuda_stream))
-        # o[k, h] = Wv_h z[k, h] + bv_h (the attention weights sum to one), then the output projection
-        o = torch.bmm(z.transpose(0, 1), self.v_proj.weight.to(dt).view(H, hd, C).transpose(1, 2)).transpose(0, 1).reshape(K, C)
-        o = o + self.v_proj.bias.to(dt)
-        return torch.addmm(self.c_proj.bias.to(dt), o, self.c_proj.weight.to(dt).t())
+        # o[k, h] = Wv_h z[h, k] (+ bv_h, folded into the output bias: the attention weights sum to one), then the output projection
+        o = torch.bmm(z, d["wv_ht"]).transpose(0, 1).reshape(K, C)
+        return torch.addmm(d["bc"], o, d["wc_t"])
+
+    def _derived(self, dt):
+        """per-dtype forms of the (frozen) parameters, rebuilt when a parameter has been modified: scaled query projection, per-head
+        views of the key / value projections, the output bias with the value bias folded in"""
+        ps = (self.positional_embedding, self.q_proj.weight, self.q_proj.bias, self.k_proj.weight, self.v_proj.weight, self.v_proj.bias,
+              self.c_proj.weight, self.c_proj.bias)
+        ver = (dt,) + tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_derived_ver", None) != ver:
+            C, H = self.q_proj.weight.shape[0], self.num_heads
+            hd = C // H
+            scale = hd ** -0.5
+            wc = self.c_proj.weight.detach().to(dt)
+            self._derived_cache = {
+                "pos": self.positional_embedding.detach().to(dt).contiguous(),
+                "pos_t": self.positional_embedding.detach().to(dt).t().contiguous(),
+                "wq_t": (self.q_proj.weight.detach().to(dt) * scale).t().contiguous(),
+                "bq": (self.q_proj.bias.detach().to(dt) * scale).contiguous(),
+                "wk_h": self.k_proj.weight.detach().to(dt).view(H, hd, C).contiguous(),
+                "wv_ht": self.v_proj.weight.detach().to(dt).view(H, hd, C).transpose(1, 2).contiguous(),
+                "wc_t": wc.t().contiguous(),
+                "bc": (self.c_proj.bias.detach().to(dt) + wc @ self.v_proj.bias.detach().to(dt)).contiguous(),
+            }
+            self._derived_ver = ver
+        return self._derived_cache
 
 
 @torch.no_grad()
