@@ -302,6 +302,12 @@ int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, con
                            const uint16_t *residual, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
                            uint16_t *out, msda_stream_t stream);
 
+/* Pooling on NHWC bf16 activations (nn.AvgPool2d(k) of the CLIP ResNet, clip/model.py:24, :36, :115; MaxPool2d(3, 2, 1) after
+ * torchvision's ResNet stem): is_max = 0: mean over k x k windows at `stride`, pad must be 0; is_max = 1: maximum with implicit -inf
+ * padding.  out (N, Ho, Wo, C) with Ho = (H + 2 pad - k) / stride + 1.  C % 8 == 0, 16-byte aligned pointers.  Forward only. */
+int msda_pool_nhwc_bf16(const uint16_t *x, int N, int H, int W, int C, int k, int stride, int pad, int is_max, uint16_t *out,
+                        msda_stream_t stream);
+
 /* Gradient of msda_conv_forward_bf16 w.r.t. its input (for the backbone's trained stages), by the same kernel: a stride-1
  * convolution of the output gradient -- read as if zero-upsampled by `stride` -- with the flipped, transposed weight.
  * dy (N, Ho, Wo, Cout) bf16 (already multiplied by the ReLU mask); packed_weight_t = msda_conv_pack_weight(w_t, Cin, Cout, KH, KW) with

@@ -13,7 +13,7 @@ add run in the convolution's epilogue, activations are NHWC bf16.  ``ResNet50Fro
 import torch
 import torch.nn.functional as F
 
-from .conv import ConvAffine, fold_bn, to_nhwc_bf16
+from .conv import ConvAffine, fold_bn, max_pool_nhwc, to_nhwc_bf16
 
 
 def _conv_bn(sd, conv, bn, dev, stride=1, padding=0, relu=True):
@@ -58,7 +58,7 @@ class ResNet50Frozen:
     @torch.no_grad()
     def __call__(self, images):
         x = self.stem(to_nhwc_bf16(images))
-        x = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()     # PyTorch op on the channels-last view
+        x = max_pool_nhwc(x, 3, 2, 1)
         outs = []
         for li, blocks in enumerate(self.layers, start=1):
             for blk in blocks:
@@ -192,7 +192,10 @@ class ResNet50(nn.Module):
 
     def forward(self, images):
         x = _conv_bn_act(to_nhwc_bf16(images), self.conv1, self.bn1, True)
-        x = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+        if x.requires_grad:      # an unfrozen stem (the reference's total_finetune): PyTorch's pooling, which has a backward
+            x = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+        else:                    # the default: stem and layer1 frozen (backbone.py:65-67), no gradient flows through the pool
+            x = max_pool_nhwc(x, 3, 2, 1)
         outs = []
         for li in range(1, 5):
             x = getattr(self, f"layer{li}")(x)

@@ -85,12 +85,25 @@ def set_tiling(co_tiles=0, pixel_tiles=0):
     _lib.check(_lib.load().msda_conv_set_tiling(int(co_tiles), int(pixel_tiles)))
 
 
+def _pool(x, k, stride, pad, is_max):
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[3] % 8 == 0
+    x = x.contiguous()
+    N, H, W, C = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((N, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().msda_pool_nhwc_bf16(x.data_ptr(), N, H, W, C, k, stride, pad, int(is_max), out.data_ptr(), _stream(x.device)))
+    return out
+
+
 def avg_pool_nhwc(x, k):
-    """nn.AvgPool2d(k) on an NHWC tensor (clip/model.py:24, :36, :115): plain PyTorch on the channels-last view"""
-    if k == 1:
-        return x
-    y = torch.nn.functional.avg_pool2d(x.permute(0, 3, 1, 2), k)
-    return y.permute(0, 2, 3, 1).contiguous()
+    """nn.AvgPool2d(k) on an NHWC bf16 tensor (clip/model.py:24, :36, :115): ``msda_pool_nhwc_bf16`` (fp32 sums, one rounding)"""
+    return x if k == 1 else _pool(x, k, k, 0, False)
+
+
+def max_pool_nhwc(x, k=3, stride=2, pad=1):
+    """nn.MaxPool2d(k, stride, pad) on an NHWC bf16 tensor (torchvision's ResNet stem)"""
+    return _pool(x, k, stride, pad, True)
 
 
 # ---- training: the same convolution with gradients ----------------------------------------------------------------------------------

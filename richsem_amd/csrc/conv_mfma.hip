@@ -287,6 +287,45 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
     }
 }
 
+// k x k pooling (stride s, padding p) on NHWC bf16: a thread owns 8 channels (16 bytes) of one output pixel.  MAX: maximum over the taps
+// inside the image (torch's MaxPool2d with implicit -inf padding); else the mean over all k * k taps, which must lie inside the image
+// (nn.AvgPool2d(k): stride k, no padding -- clip/model.py:24, :36, :115).
+template <bool MAX>
+__global__ __launch_bounds__(256) void pool_nhwc_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ out, int N, int H, int W, int C,
+                                                        int Ho, int Wo, int k, int stride, int pad)
+{
+    const int cv = C / 8;
+    const long long n = (long long)N * Ho * Wo * cv;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cv);
+        long long p = i / cv;
+        const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), b = (int)(p / ((long long)Wo * Ho));
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = MAX ? -__builtin_inff() : 0.f;
+        for (int kh = 0; kh < k; ++kh) {
+            const int hi = ho * stride + kh - pad;
+            if (hi < 0 || hi >= H) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int wi = wo * stride + kw - pad;
+                if (wi < 0 || wi >= W) continue;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(x + (((long long)b * H + hi) * W + wi) * C + 8 * c8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = bf16_lo(v[e]), hi2 = bf16_hi(v[e]);
+                    acc[2 * e] = MAX ? fmaxf(acc[2 * e], lo) : acc[2 * e] + lo;
+                    acc[2 * e + 1] = MAX ? fmaxf(acc[2 * e + 1], hi2) : acc[2 * e + 1] + hi2;
+                }
+            }
+        }
+        const float sc = MAX ? 1.f : 1.f / (float)(k * k);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf16(acc[2 * e] * sc, acc[2 * e + 1] * sc);
+        *reinterpret_cast<u32x4 *>(out + p * C + 8 * c8) = o;
+    }
+}
+
 struct ConvArgs {
     const uint16_t *x, *wpk;
     const float *scale, *shift;
@@ -409,6 +448,29 @@ int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, con
                      static_cast<hipStream_t>(stream)};
     if (small_c) return launch_ct<0>(a, ct, pt);
     return Cin % 64 == 0 ? launch_ct<2>(a, ct, pt) : launch_ct<1>(a, ct, pt);
+}
+
+/* Pooling on NHWC bf16 (the pools around the backbones' convolutions: nn.AvgPool2d(k) of the CLIP ResNet, clip/model.py:24, :36, :115;
+ * torchvision's MaxPool2d(3, 2, 1) after the ResNet stem).  is_max = 0: mean over k x k, stride, padding 0 (H, W multiples are not
+ * required: Ho = (H - k) / stride + 1); is_max = 1: maximum with implicit -inf padding `pad`.  C % 8 == 0.  Forward only. */
+int msda_pool_nhwc_bf16(const uint16_t *x, int N, int H, int W, int C, int k, int stride, int pad, int is_max, uint16_t *out,
+                        msda_stream_t stream)
+{
+    if (!x || !out) return MSDA_ERR_NULL_POINTER;
+    if (N < 1 || H < 1 || W < 1 || C < 8 || C % 8 != 0 || k < 1 || stride < 1 || pad < 0 || (!is_max && pad != 0) || pad >= k)
+        return MSDA_ERR_BAD_DIMS;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    if (Ho < 1 || Wo < 1) return MSDA_ERR_BAD_DIMS;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) return MSDA_ERR_MISALIGNED;
+    const long long n = (long long)N * Ho * Wo * (C / 8);
+    const int grid = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (is_max)
+        hipLaunchKernelGGL(pool_nhwc_kernel<true>, dim3(grid), dim3(256), 0, st, x, out, N, H, W, C, Ho, Wo, k, stride, pad);
+    else
+        hipLaunchKernelGGL(pool_nhwc_kernel<false>, dim3(grid), dim3(256), 0, st, x, out, N, H, W, C, Ho, Wo, k, stride, pad);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
 }
 
 /* Gradient of msda_conv_forward_bf16 w.r.t. its input, by the same kernel: a stride-1 convolution of the (zero-upsampled, for a

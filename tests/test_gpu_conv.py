@@ -143,3 +143,21 @@ def test_gradients_against_fp32_autograd(case, with_residual):
     close(wg.grad.cpu(), wr.grad, "dw")
     if with_residual:
         close(rg.grad.permute(0, 3, 1, 2).float().cpu(), rr.grad, "dres")
+
+
+@pytest.mark.parametrize("shape,k,stride,pad,is_max", [((2, 20, 30, 64), 2, 2, 0, False), ((1, 21, 33, 32), 2, 2, 0, False),
+                                                      ((2, 9, 9, 8), 3, 3, 0, False), ((2, 37, 41, 64), 3, 2, 1, True),
+                                                      ((1, 8, 8, 256), 3, 2, 1, True)])
+def test_pooling_kernels(shape, k, stride, pad, is_max):
+    """msda_pool_nhwc_bf16 against F.avg_pool2d / F.max_pool2d in fp32 on the same bf16 input (one rounding of the mean)"""
+    from richsem_amd.conv import _pool
+    torch.manual_seed(k)
+    x = torch.randn(*shape, device="cuda").to(torch.bfloat16)
+    got = _pool(x, k, stride, pad, is_max).permute(0, 3, 1, 2).float()
+    xn = x.permute(0, 3, 1, 2).float()
+    want = F.max_pool2d(xn, k, stride, pad) if is_max else F.avg_pool2d(xn, k, stride)
+    assert got.shape == want.shape
+    if is_max:
+        assert torch.equal(got, want)
+    else:
+        assert float((got - want).abs().max()) <= 2 ** -8 * float(want.abs().max())
