@@ -302,6 +302,12 @@ int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, con
                            const uint16_t *residual, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
                            uint16_t *out, msda_stream_t stream);
 
+/* GroupNorm with 8 channels per group on NHWC bf16 (nn.GroupNorm(32, 256) of the input projections, models/richsem/richsem.py:301,
+ * :307): x (N, HW, C) bf16 with C = 8 * groups; gamma, beta (C) f32; stats: N * (C / 8) * 2 doubles of device scratch; out_f32 and / or
+ * out_bf16 (N, HW, C), either may be NULL.  Sums of x and x^2 in fp32 per thread, combined in fp64.  Forward only. */
+int msda_groupnorm8_nhwc_bf16(const uint16_t *x, const float *gamma, const float *beta, float eps, int N, int HW, int C, double *stats,
+                              float *out_f32, uint16_t *out_bf16, msda_stream_t stream);
+
 /* Pooling on NHWC bf16 activations (nn.AvgPool2d(k) of the CLIP ResNet, clip/model.py:24, :36, :115; MaxPool2d(3, 2, 1) after
  * torchvision's ResNet stem): is_max = 0: mean over k x k windows at `stride`, pad must be 0; is_max = 1: maximum with implicit -inf
  * padding.  out (N, Ho, Wo, C) with Ho = (H + 2 pad - k) / stride + 1.  C % 8 == 0, 16-byte aligned pointers.  Forward only. */

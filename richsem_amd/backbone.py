@@ -13,7 +13,7 @@ add run in the convolution's epilogue, activations are NHWC bf16.  ``ResNet50Fro
 import torch
 import torch.nn.functional as F
 
-from .conv import ConvAffine, fold_bn, max_pool_nhwc, to_nhwc_bf16
+from .conv import ConvAffine, fold_bn, group_norm8_nhwc, max_pool_nhwc, to_nhwc_bf16
 
 
 def _conv_bn(sd, conv, bn, dev, stride=1, padding=0, relu=True):
@@ -98,9 +98,16 @@ class InputProj:
             else:
                 y = conv(prev)                                           # :606 (the previous projected level, after its norm)
             N, H, W, C = y.shape
-            g = F.group_norm(y.permute(0, 3, 1, 2).float(), self.groups, self.norms[l][0], self.norms[l][1], 1e-5)
-            prev = g.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
-            srcs.append(g.permute(0, 2, 3, 1).reshape(N, H * W, C).to(out_dtype))
+            if C == 8 * self.groups:      # RichSem's GroupNorm(32, 256): the library's kernel (one pixel's group = one 16-byte vector)
+                need_prev = l + 1 < len(self.convs) and l + 1 > n_stage
+                g32, prev = group_norm8_nhwc(y, self.norms[l][0], self.norms[l][1], 1e-5, want_f32=out_dtype != torch.bfloat16,
+                                             want_bf16=need_prev or out_dtype == torch.bfloat16)
+                tok = g32 if out_dtype != torch.bfloat16 else prev
+                srcs.append(tok.view(N, H * W, C).to(out_dtype))
+            else:
+                g = F.group_norm(y.permute(0, 3, 1, 2).float(), self.groups, self.norms[l][0], self.norms[l][1], 1e-5)
+                prev = g.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+                srcs.append(g.permute(0, 2, 3, 1).reshape(N, H * W, C).to(out_dtype))
             shapes.append((H, W))
         return srcs, shapes
 

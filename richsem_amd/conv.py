@@ -106,6 +106,22 @@ def max_pool_nhwc(x, k=3, stride=2, pad=1):
     return _pool(x, k, stride, pad, True)
 
 
+def group_norm8_nhwc(x, gamma, beta, eps=1e-5, want_f32=True, want_bf16=True):
+    """nn.GroupNorm(C // 8, C) on an NHWC bf16 tensor (N, H, W, C): -> (fp32 result or None, bf16 result or None), both (N, H, W, C)"""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[3] % 8 == 0
+    x = x.contiguous()
+    N, H, W, C = x.shape
+    stats = torch.empty(N * (C // 8) * 2, dtype=torch.float64, device=x.device)
+    o32 = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device) if want_f32 else None
+    o16 = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().msda_groupnorm8_nhwc_bf16(x.data_ptr(), g.data_ptr(), b.data_ptr(), float(eps), N, H * W, C, stats.data_ptr(),
+                                                         o32.data_ptr() if o32 is not None else None,
+                                                         o16.data_ptr() if o16 is not None else None, _stream(x.device)))
+    return o32, o16
+
+
 # ---- training: the same convolution with gradients ----------------------------------------------------------------------------------
 def _pack(w):
     L = _lib.load()

@@ -326,6 +326,79 @@ __global__ __launch_bounds__(256) void pool_nhwc_kernel(const uint16_t *__restri
     }
 }
 
+// GroupNorm over NHWC bf16 with 8 channels per group (nn.GroupNorm(32, 256) of the input projections, richsem.py:301, :307): a pixel's
+// group is one 16-byte vector.  Pass 1: sums of x and x^2 per (image, group) -- per-thread fp32 partials over a strip of pixels, folded
+// per workgroup and added as doubles; pass 2: (x - mean) * rstd * gamma + beta to fp32 and / or bf16.
+__global__ __launch_bounds__(256) void gn8_stats_kernel(const uint16_t *__restrict__ x, double *__restrict__ stats, int HW, int C)
+{
+    __shared__ float red[2][256];
+    const int groups = C / 8;
+    const int g = blockIdx.y, n = blockIdx.z;
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(x + ((long long)n * HW + p) * C + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = bf16_lo(v[e]), b = bf16_hi(v[e]);
+            s1 += a + b;
+            s2 += a * a + b * b;
+        }
+    }
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(stats + ((long long)n * groups + g) * 2, (double)red[0][0]);
+        atomicAdd(stats + ((long long)n * groups + g) * 2 + 1, (double)red[1][0]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn8_apply_kernel(const uint16_t *__restrict__ x, const double *__restrict__ stats,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta, float eps, int N,
+                                                        int HW, int C, float *__restrict__ out_f32, uint16_t *__restrict__ out_bf16)
+{
+    const int groups = C / 8;
+    const long long n_vec = (long long)N * HW * groups;
+    const double cnt = (double)HW * 8.0;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n_vec; i += gridDim.x * 256ll) {
+        const int g = (int)(i % groups);
+        const long long p = i / groups;
+        const int n = (int)(p / HW);
+        const double m = stats[((long long)n * groups + g) * 2] / cnt;
+        const double var = stats[((long long)n * groups + g) * 2 + 1] / cnt - m * m;
+        const float mean = (float)m, rstd = rsqrtf((float)(var > 0.0 ? var : 0.0) + eps);
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(x + p * C + 8 * g);
+        const f32x4 g0 = *reinterpret_cast<const f32x4 *>(gamma + 8 * g), g1 = *reinterpret_cast<const f32x4 *>(gamma + 8 * g + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(beta + 8 * g), b1 = *reinterpret_cast<const f32x4 *>(beta + 8 * g + 4);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[2 * e] = (bf16_lo(v[e]) - mean) * rstd;
+            y[2 * e + 1] = (bf16_hi(v[e]) - mean) * rstd;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[e] = y[e] * g0[e] + b0[e];
+            y[4 + e] = y[4 + e] * g1[e] + b1[e];
+        }
+        if (out_f32) {
+            f32x4 *o = reinterpret_cast<f32x4 *>(out_f32 + p * C + 8 * g);
+            o[0] = (f32x4){y[0], y[1], y[2], y[3]};
+            o[1] = (f32x4){y[4], y[5], y[6], y[7]};
+        }
+        if (out_bf16)
+            *reinterpret_cast<u32x4 *>(out_bf16 + p * C + 8 * g) =
+                (u32x4){pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7])};
+    }
+}
+
 struct ConvArgs {
     const uint16_t *x, *wpk;
     const float *scale, *shift;
@@ -448,6 +521,31 @@ int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, con
                      static_cast<hipStream_t>(stream)};
     if (small_c) return launch_ct<0>(a, ct, pt);
     return Cin % 64 == 0 ? launch_ct<2>(a, ct, pt) : launch_ct<1>(a, ct, pt);
+}
+
+/* GroupNorm with 8 channels per group on NHWC bf16 (nn.GroupNorm(32, 256) of the input projections, models/richsem/richsem.py:301, :307):
+ * x (N, H W, C) bf16, C = 8 * groups; gamma, beta (C) f32; stats: N * groups * 2 doubles of scratch (zeroed here); out_f32 and / or
+ * out_bf16 (N, H W, C), either may be NULL.  Forward only. */
+int msda_groupnorm8_nhwc_bf16(const uint16_t *x, const float *gamma, const float *beta, float eps, int N, int HW, int C, double *stats,
+                              float *out_f32, uint16_t *out_bf16, msda_stream_t stream)
+{
+    if (!x || !gamma || !beta || !stats || (!out_f32 && !out_bf16)) return MSDA_ERR_NULL_POINTER;
+    if (N < 1 || HW < 1 || C < 8 || C % 8 != 0 || C / 8 > 65535 || N > 65535) return MSDA_ERR_BAD_DIMS;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
+         reinterpret_cast<uintptr_t>(out_f32) | reinterpret_cast<uintptr_t>(out_bf16)) & 15)
+        return MSDA_ERR_MISALIGNED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int groups = C / 8;
+    hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * N * groups, st);
+    if (e != hipSuccess) return (int)e;
+    int strips = (HW + 2047) / 2048;
+    if (strips > 64) strips = 64;
+    hipLaunchKernelGGL(gn8_stats_kernel, dim3(strips, groups, N), dim3(256), 0, st, x, stats, HW, C);
+    const long long n_vec = (long long)N * HW * groups;
+    const int grid = (int)((n_vec + 255) / 256 < 65536 ? (n_vec + 255) / 256 : 65536);
+    hipLaunchKernelGGL(gn8_apply_kernel, dim3(grid), dim3(256), 0, st, x, stats, gamma, beta, eps, N, HW, C, out_f32, out_bf16);
+    e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
 }
 
 /* Pooling on NHWC bf16 (the pools around the backbones' convolutions: nn.AvgPool2d(k) of the CLIP ResNet, clip/model.py:24, :36, :115;

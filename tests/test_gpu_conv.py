@@ -161,3 +161,17 @@ def test_pooling_kernels(shape, k, stride, pad, is_max):
         assert torch.equal(got, want)
     else:
         assert float((got - want).abs().max()) <= 2 ** -8 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 20, 256), (1, 100, 168, 256), (3, 2, 3, 64)])
+def test_group_norm_kernel(shape):
+    """msda_groupnorm8_nhwc_bf16 against F.group_norm in fp32 on the same bf16 input"""
+    from richsem_amd.conv import group_norm8_nhwc
+    torch.manual_seed(shape[1])
+    x = (torch.randn(*shape, device="cuda") * 2 + 0.5).to(torch.bfloat16)
+    C = shape[3]
+    gamma, beta = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda")
+    want = F.group_norm(x.permute(0, 3, 1, 2).float(), C // 8, gamma, beta, 1e-5).permute(0, 2, 3, 1)
+    g32, g16 = group_norm8_nhwc(x, gamma, beta)
+    assert float((g32 - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert float((g16.float() - want).abs().max()) <= 2 ** -8 * float(want.abs().max())
