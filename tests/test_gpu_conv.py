@@ -5,6 +5,7 @@ are the summation order and the final rounding to bf16: 2^-8 relative per elemen
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -175,3 +176,35 @@ def test_group_norm_kernel(shape):
     g32, g16 = group_norm8_nhwc(x, gamma, beta)
     assert float((g32 - want).abs().max()) <= 2e-5 * float(want.abs().max())
     assert float((g16.float() - want).abs().max()) <= 2 ** -8 * float(want.abs().max())
+
+
+def test_random_shapes_forward_and_gradients():
+    """24 seeded random convolutions (kernel 1 / 3 / 5, stride 1 / 2, odd sizes, every channel class the kernels take) through
+    ConvAffineFunction against fp32 autograd: forward, input gradient, weight gradient (own kernel where C_in, C_out are multiples of
+    128), bias-free.  Catches edge handling (padding rows, chunk tails of the pixel split, strided transposed reads)."""
+    from richsem_amd.conv import ConvAffineFunction, to_nhwc_bf16
+    rng = np.random.default_rng(2024)
+    for trial in range(24):
+        k = int(rng.choice([1, 3, 5]))
+        stride = int(rng.choice([1, 2]))
+        pad = int(rng.integers(0, k // 2 + 1))
+        cin = int(rng.choice([32, 64, 96, 128, 256]))
+        cout = int(rng.choice([32, 64, 128, 256, 384]))
+        N, H, W = int(rng.integers(1, 4)), int(rng.integers(k, 40)), int(rng.integers(k, 40))
+        torch.manual_seed(trial)
+        x = torch.randn(N, cin, H, W).to(torch.bfloat16)
+        w = (torch.randn(cout, cin, k, k) * (cin * k * k) ** -0.5).to(torch.bfloat16).float()
+        scale, shift = 1 + 0.2 * torch.randn(cout), 0.3 * torch.randn(cout)
+        xr, wr = x.float().requires_grad_(True), w.clone().requires_grad_(True)
+        z = torch.relu(F.conv2d(xr, wr, stride=stride, padding=pad) * scale[None, :, None, None] + shift[None, :, None, None])
+        dy = torch.randn_like(z).to(torch.bfloat16)
+        z.backward(dy.float())
+        xg, wg = to_nhwc_bf16(x.cuda()).requires_grad_(True), w.cuda().requires_grad_(True)
+        y = ConvAffineFunction.apply(xg, wg, scale.cuda(), shift.cuda(), None, stride, pad, True)
+        y.backward(to_nhwc_bf16(dy.cuda()))
+        tag = (trial, N, H, W, cin, cout, k, stride, pad)
+        for got, want, name in ((y.permute(0, 3, 1, 2).float().cpu(), z.detach(), "y"), (xg.grad.permute(0, 3, 1, 2).float().cpu(), xr.grad, "dx"),
+                                (wg.grad.cpu(), wr.grad, "dw")):
+            s = float(want.abs().max()) + 1e-6
+            err = (got - want).abs()
+            assert float(err.max()) <= 3e-2 * s and float(err.mean()) <= 4e-3 * s, (tag, name, float(err.max()) / s, float(err.mean()) / s)
