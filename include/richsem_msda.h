@@ -387,18 +387,17 @@ int msda_matcher_cost_f64(const double *logits, const double *boxes, const int64
  *   w2_packed    linear2.weight (d_model, d_ffn) bf16 after msda_ffn_pack_w2_bf16 (a fixed permutation of the hidden
  *                columns inside every group of 32: repack whenever the weight changes);  b2 (d_model) f32
  *   ln_weight, ln_bias (d_model) f32, eps as nn.LayerNorm.  All pointers 16-byte aligned. */
-/* Training: the forward that also writes the LayerNorm's 1 / sqrt(var + eps) per token (rstd: `tokens` floats, may be NULL), and the
- * first step of the backward: from dy (gradient of out), out and rstd the gradient dz at the LayerNorm's input (= gradient of the
- * residual x and of the second product's output, bf16) and the token sums grad_ln_weight = sum dy * yhat, grad_ln_bias = sum dy,
- * grad_b2 = sum dz (f32, 256 each, zeroed by the call).  yhat is recovered as (out - ln_bias) / ln_weight: ln_weight must have no zero
- * entry.  The products of the backward (recomputed hidden activation, dH = dz W2, weight gradients, dx = dz + dHm W1) are the caller's
- * (library GEMMs in richsem_amd/functions/ffn.py). */
+/* Training: the forward that also writes the LayerNorm's 1 / sqrt(var + eps) per token (rstd: `tokens` floats) and its normalised input
+ * yhat = (y - mean) * rstd ((tokens, 256) bf16) -- either may be NULL -- and the first step of the backward: from dy (gradient of out),
+ * yhat and rstd the gradient dz at the LayerNorm's input (= gradient of the residual x and of the second product's output, bf16) and the
+ * token sums grad_ln_weight = sum dy * yhat, grad_ln_bias = sum dy, grad_b2 = sum dz (f32, 256 each, zeroed by the call).  The products
+ * of the backward are msda_lin256_forward_bf16 (recomputed hidden activation, dH with the ReLU mask), msda_conv_wgrad_bf16 (weight
+ * gradients) and one library GEMM (dx = dz + dHm W1), see richsem_amd/functions/ffn.py. */
 int msda_ffn_forward_train_bf16(const uint16_t *x, const uint16_t *w1, const float *b1, const uint16_t *w2_packed, const float *b2,
                                 const float *ln_weight, const float *ln_bias, float eps, int tokens, int d_model, int d_ffn,
-                                uint16_t *out, float *rstd, msda_stream_t stream);
-int msda_ffn_ln_backward_bf16(const uint16_t *dy, const uint16_t *out, const float *rstd, const float *ln_weight, const float *ln_bias,
-                              int tokens, int d_model, uint16_t *dz, float *grad_ln_weight, float *grad_ln_bias, float *grad_b2,
-                              msda_stream_t stream);
+                                uint16_t *out, float *rstd, uint16_t *yhat, msda_stream_t stream);
+int msda_ffn_ln_backward_bf16(const uint16_t *dy, const uint16_t *yhat, const float *rstd, const float *ln_weight, int tokens, int d_model,
+                              uint16_t *dz, float *grad_ln_weight, float *grad_ln_bias, float *grad_b2, msda_stream_t stream);
 /* out = act(x W^T + b) for in_features = 256 on the matrix cores (csrc/lin256_mfma.hip; bf16 storage, fp32 accumulation): the two
  * token-parallel products of the feed-forward block's backward.  msda_lin256_pack_bf16: W (out_features, 256) bf16 row-major -> the same
  * number of elements in MFMA fragment order (out_features % 64 == 0).  epilogue 0: acc + bias (bias may be NULL); 1: relu(acc + bias);

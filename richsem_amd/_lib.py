@@ -126,9 +126,9 @@ def load():
     L.msda_ffn_pack_w2_bf16.restype = ci
     L.msda_ffn_forward_bf16.argtypes = [vp] * 7 + [ctypes.c_float, ci, ci, ci, vp, vp]
     L.msda_ffn_forward_bf16.restype = ci
-    L.msda_ffn_forward_train_bf16.argtypes = [vp] * 7 + [ctypes.c_float, ci, ci, ci, vp, vp, vp]
+    L.msda_ffn_forward_train_bf16.argtypes = [vp] * 7 + [ctypes.c_float, ci, ci, ci, vp, vp, vp, vp]
     L.msda_ffn_forward_train_bf16.restype = ci
-    L.msda_ffn_ln_backward_bf16.argtypes = [vp] * 5 + [ci, ci] + [vp] * 5
+    L.msda_ffn_ln_backward_bf16.argtypes = [vp] * 4 + [ci, ci] + [vp] * 5
     L.msda_ffn_ln_backward_bf16.restype = ci
     L.msda_lin256_pack_bf16.argtypes = [vp, ci, ci, vp, vp]
     L.msda_lin256_pack_bf16.restype = ci

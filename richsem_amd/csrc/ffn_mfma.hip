@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 
 void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w1, const float *__restrict__ b1,
                     const uint16_t *__restrict__ w2p, const float *__restrict__ b2, const float *__restrict__ gamma,
                     const float *__restrict__ beta, float eps, int T, int F, uint16_t *__restrict__ out,
-                    unsigned long long *__restrict__ stamps, float *__restrict__ rstd_out)
+                    unsigned long long *__restrict__ stamps, float *__restrict__ rstd_out, uint16_t *__restrict__ yhat_out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     short *wbuf = reinterpret_cast<short *>(smem);                                          // [kRing][kTileFrags * kFragShorts]
@@ -320,13 +320,22 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
             for (int t = 0; t < 16; ++t) {
                 const int ch = 16 * t + 4 * q;
                 const f32x4 ga = *reinterpret_cast<const f32x4 *>(lgam + ch), be = *reinterpret_cast<const f32x4 *>(lbet + ch);
-                float y[4];
+                float y[4], yh[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] = (acc[ct][t][i] - mean) * rstd * ga[i] + be[i];
+                for (int i = 0; i < 4; ++i) {
+                    yh[i] = (acc[ct][t][i] - mean) * rstd;
+                    y[i] = yh[i] * ga[i] + be[i];
+                }
                 uint2 o;
                 o.x = pack_bf16(y[0], y[1]);
                 o.y = pack_bf16(y[2], y[3]);
                 *reinterpret_cast<uint2 *>(orow + ch) = o;
+                if (yhat_out) {      // training: the normalised pre-affine value, for the LayerNorm's backward
+                    uint2 h;
+                    h.x = pack_bf16(yh[0], yh[1]);
+                    h.y = pack_bf16(yh[2], yh[3]);
+                    *reinterpret_cast<uint2 *>(yhat_out + (size_t)tok * kD + ch) = h;
+                }
             }
         }
     }
@@ -334,32 +343,30 @@ void ffn_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__
 
 // ---- backward, first step: gradient at the LayerNorm's input ------------------------------------------------------------------------
 // out = yhat * gamma + beta with yhat = (y - mean) * rstd, y = x + W2 relu(W1 x + b1) + b2.  Given dy (gradient of out), out and rstd:
-//     yhat = (out - beta) / gamma          (recovered from the stored bf16 output: gamma must not be 0)
+//     yhat                                  (stored by the forward in bf16: recovering it as (out - beta) / gamma would amplify the
+//                                            output's rounding by |out / gamma| and fail for a zero gamma)
 //     g    = dy * gamma;   dz = rstd * (g - mean_c(g) - yhat * mean_c(g * yhat))          (= gradient of y: of the residual x, of b2, ...)
 //     dgamma += dy * yhat;  dbeta += dy;  db2 += dz                                         (summed over the tokens)
 // One token per wave and iteration (lane = 4 channels), sums over the tokens in registers, folded through LDS and added with atomics
 // (3 x 256 per workgroup) to the zeroed fp32 results.
-__global__ __launch_bounds__(256) void ffn_ln_backward_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ out,
-                                                              const float *__restrict__ rstd, const float *__restrict__ gamma,
-                                                              const float *__restrict__ beta, int T, uint16_t *__restrict__ dz,
+__global__ __launch_bounds__(256) void ffn_ln_backward_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ yhat,
+                                                              const float *__restrict__ rstd, const float *__restrict__ gamma, int T,
+                                                              uint16_t *__restrict__ dz,
                                                               float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ db2)
 {
     __shared__ float red[4][3][kD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ch = 4 * lane;
-    const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + ch), be = *reinterpret_cast<const f32x4 *>(beta + ch);
-    float inv_ga[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) inv_ga[i] = 1.f / ga[i];
+    const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + ch);
     float s_g[4] = {0.f, 0.f, 0.f, 0.f}, s_b[4] = {0.f, 0.f, 0.f, 0.f}, s_z[4] = {0.f, 0.f, 0.f, 0.f};
     for (int tok = blockIdx.x * 4 + wave; tok < T; tok += gridDim.x * 4) {
-        const uint2 d = *reinterpret_cast<const uint2 *>(dy + (size_t)tok * kD + ch), o = *reinterpret_cast<const uint2 *>(out + (size_t)tok * kD + ch);
+        const uint2 d = *reinterpret_cast<const uint2 *>(dy + (size_t)tok * kD + ch), o = *reinterpret_cast<const uint2 *>(yhat + (size_t)tok * kD + ch);
         const float dv[4] = {bf16_lo(d.x), bf16_hi(d.x), bf16_lo(d.y), bf16_hi(d.y)};
         const float ov[4] = {bf16_lo(o.x), bf16_hi(o.x), bf16_lo(o.y), bf16_hi(o.y)};
         float yh[4], g[4], a = 0.f, b = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            yh[i] = (ov[i] - be[i]) * inv_ga[i];
+            yh[i] = ov[i];
             g[i] = dv[i] * ga[i];
             a += g[i];
             b += g[i] * yh[i];
@@ -423,22 +430,22 @@ int msda_ffn_pack_w2_bf16(const uint16_t *w2, int d_model, int d_ffn, uint16_t *
     return e == hipSuccess ? MSDA_OK : (int)e;
 }
 
-/* msda_ffn_forward_bf16 that also writes the LayerNorm's 1 / sqrt(var + eps) per token (rstd, `tokens` floats; may be NULL): what the
- * backward needs besides x and out */
+/* msda_ffn_forward_bf16 that also writes what the backward needs besides x: the LayerNorm's 1 / sqrt(var + eps) per token (rstd, `tokens`
+ * floats) and its normalised input yhat = (y - mean) * rstd (tokens x 256 bf16); either may be NULL */
 int msda_ffn_forward_train_bf16(const uint16_t *x, const uint16_t *w1, const float *b1, const uint16_t *w2_packed, const float *b2,
                                 const float *ln_weight, const float *ln_bias, float eps, int tokens, int d_model, int d_ffn,
-                                uint16_t *out, float *rstd, msda_stream_t stream);
+                                uint16_t *out, float *rstd, uint16_t *yhat, msda_stream_t stream);
 
 int msda_ffn_forward_bf16(const uint16_t *x, const uint16_t *w1, const float *b1, const uint16_t *w2_packed, const float *b2,
                           const float *ln_weight, const float *ln_bias, float eps, int tokens, int d_model, int d_ffn,
                           uint16_t *out, msda_stream_t stream)
 {
-    return msda_ffn_forward_train_bf16(x, w1, b1, w2_packed, b2, ln_weight, ln_bias, eps, tokens, d_model, d_ffn, out, nullptr, stream);
+    return msda_ffn_forward_train_bf16(x, w1, b1, w2_packed, b2, ln_weight, ln_bias, eps, tokens, d_model, d_ffn, out, nullptr, nullptr, stream);
 }
 
 int msda_ffn_forward_train_bf16(const uint16_t *x, const uint16_t *w1, const float *b1, const uint16_t *w2_packed, const float *b2,
                                 const float *ln_weight, const float *ln_bias, float eps, int tokens, int d_model, int d_ffn,
-                                uint16_t *out, float *rstd, msda_stream_t stream)
+                                uint16_t *out, float *rstd, uint16_t *yhat, msda_stream_t stream)
 {
     if (!x || !w1 || !b1 || !w2_packed || !b2 || !ln_weight || !ln_bias || !out) return MSDA_ERR_NULL_POINTER;
     if (d_model != kD || d_ffn < kHT || d_ffn % kHT != 0 || d_ffn > kMaxFfn || tokens < 0) return MSDA_ERR_BAD_DIMS;
@@ -458,22 +465,21 @@ int msda_ffn_forward_train_bf16(const uint16_t *x, const uint16_t *w1, const flo
     }
     const int grid = (tokens + kTokWg - 1) / kTokWg;
     hipLaunchKernelGGL(ffn_fwd_kernel, dim3(grid), dim3(kWaves * 64), lds, static_cast<hipStream_t>(stream), x, w1, b1, w2_packed, b2,
-                       ln_weight, ln_bias, eps, tokens, d_ffn, out, g_ffn_stamps, rstd);
+                       ln_weight, ln_bias, eps, tokens, d_ffn, out, g_ffn_stamps, rstd, yhat);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
 }
 
-/* Backward, first step (see ffn_ln_backward_kernel): dy, out (tokens, 256) bf16; rstd (tokens) from msda_ffn_forward_train_bf16;
- * ln_weight (no zero entries), ln_bias (256) f32 -> dz (tokens, 256) bf16 = gradient at the LayerNorm's input, and the three
- * 256-vectors grad_ln_weight, grad_ln_bias, grad_b2 (f32, zeroed here). */
-int msda_ffn_ln_backward_bf16(const uint16_t *dy, const uint16_t *out, const float *rstd, const float *ln_weight, const float *ln_bias,
-                              int tokens, int d_model, uint16_t *dz, float *grad_ln_weight, float *grad_ln_bias, float *grad_b2,
-                              msda_stream_t stream)
+/* Backward, first step (see ffn_ln_backward_kernel): dy, yhat (tokens, 256) bf16; rstd (tokens), yhat from msda_ffn_forward_train_bf16;
+ * ln_weight (256) f32 -> dz (tokens, 256) bf16 = gradient at the LayerNorm's input, and the three 256-vectors grad_ln_weight,
+ * grad_ln_bias, grad_b2 (f32, zeroed here). */
+int msda_ffn_ln_backward_bf16(const uint16_t *dy, const uint16_t *yhat, const float *rstd, const float *ln_weight, int tokens, int d_model,
+                              uint16_t *dz, float *grad_ln_weight, float *grad_ln_bias, float *grad_b2, msda_stream_t stream)
 {
-    if (!dy || !out || !rstd || !ln_weight || !ln_bias || !dz || !grad_ln_weight || !grad_ln_bias || !grad_b2) return MSDA_ERR_NULL_POINTER;
+    if (!dy || !yhat || !rstd || !ln_weight || !dz || !grad_ln_weight || !grad_ln_bias || !grad_b2) return MSDA_ERR_NULL_POINTER;
     if (tokens < 0 || d_model != kD) return MSDA_ERR_BAD_DIMS;
-    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dz) |
-         reinterpret_cast<uintptr_t>(ln_weight) | reinterpret_cast<uintptr_t>(ln_bias)) & 15)
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(yhat) | reinterpret_cast<uintptr_t>(dz) |
+         reinterpret_cast<uintptr_t>(ln_weight)) & 15)
         return MSDA_ERR_MISALIGNED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (float *p : {grad_ln_weight, grad_ln_bias, grad_b2}) {
@@ -482,8 +488,8 @@ int msda_ffn_ln_backward_bf16(const uint16_t *dy, const uint16_t *out, const flo
     }
     if (tokens == 0) return MSDA_OK;
     const int grid = (tokens + 3) / 4 < 2048 ? (tokens + 3) / 4 : 2048;
-    hipLaunchKernelGGL(ffn_ln_backward_kernel, dim3(grid), dim3(256), 0, st, dy, out, rstd, ln_weight, ln_bias, tokens, dz, grad_ln_weight,
-                       grad_ln_bias, grad_b2);
+    hipLaunchKernelGGL(ffn_ln_backward_kernel, dim3(grid), dim3(256), 0, st, dy, yhat, rstd, ln_weight, tokens, dz, grad_ln_weight, grad_ln_bias,
+                       grad_b2);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
 }

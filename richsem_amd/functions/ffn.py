@@ -50,7 +50,8 @@ def pack_w2_bf16(w2):
 
 def ffn_forward_bf16(x, w1, b1, w2_packed, b2, ln_weight, ln_bias, eps=1e-5, return_rstd=False):
     """x (..., 256) bf16; w1 (d_ffn, 256) bf16; w2_packed from ``pack_w2_bf16``; biases / LayerNorm parameters float32.
-    ``return_rstd``: also the LayerNorm's 1 / sqrt(var + eps) per token (float32), which the backward needs."""
+    ``return_rstd``: also the LayerNorm's 1 / sqrt(var + eps) per token (float32) and its normalised input yhat (bf16), which the
+    backward needs."""
     if not x.is_cuda:
         raise RuntimeError("Not implemented on the CPU")
     assert x.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2_packed.dtype == torch.bfloat16
@@ -59,22 +60,23 @@ def ffn_forward_bf16(x, w1, b1, w2_packed, b2, ln_weight, ln_bias, eps=1e-5, ret
     x2 = x.contiguous().view(-1, x.shape[-1])
     out = torch.empty_like(x2)
     rstd = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device) if return_rstd else None
+    yhat = torch.empty_like(x2) if return_rstd else None
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().msda_ffn_forward_train_bf16(
             x2.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2_packed.data_ptr(), b2.data_ptr(), ln_weight.data_ptr(),
             ln_bias.data_ptr(), float(eps), x2.shape[0], x2.shape[1], w1.shape[0], out.data_ptr(),
-            rstd.data_ptr() if rstd is not None else None, _stream(x)))
-    return (out.view(x.shape), rstd) if return_rstd else out.view(x.shape)
+            rstd.data_ptr() if rstd is not None else None, yhat.data_ptr() if yhat is not None else None, _stream(x)))
+    return (out.view(x.shape), rstd, yhat) if return_rstd else out.view(x.shape)
 
 
-def ffn_ln_backward_bf16(grad_out, out, rstd, ln_weight, ln_bias):
+def ffn_ln_backward_bf16(grad_out, yhat, rstd, ln_weight):
     """First step of the backward (``msda_ffn_ln_backward_bf16``): -> (dz bf16 (tokens, 256), grad_ln_weight, grad_ln_bias, grad_b2)"""
-    g2, o2 = grad_out.contiguous().view(-1, 256), out.contiguous().view(-1, 256)
+    g2, o2 = grad_out.contiguous().view(-1, 256), yhat.contiguous().view(-1, 256)
     dz = torch.empty_like(o2)
     sums = torch.empty(3, 256, dtype=torch.float32, device=o2.device)
     with torch.cuda.device(o2.device):
         _lib.check(_lib.load().msda_ffn_ln_backward_bf16(g2.data_ptr(), o2.data_ptr(), rstd.data_ptr(), ln_weight.data_ptr(),
-                                                         ln_bias.data_ptr(), o2.shape[0], 256, dz.data_ptr(), sums[0].data_ptr(),
+                                                         o2.shape[0], 256, dz.data_ptr(), sums[0].data_ptr(),
                                                          sums[1].data_ptr(), sums[2].data_ptr(), _stream(o2)))
     return dz, sums[0], sums[1], sums[2]
 
@@ -84,17 +86,18 @@ class FusedFFNFunction(Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, ln_weight, ln_bias, eps):
-        out, rstd = ffn_forward_bf16(x, w1.contiguous(), b1, pack_w2_bf16(w2.contiguous()), b2, ln_weight, ln_bias, eps, return_rstd=True)
-        ctx.save_for_backward(x, w1, b1, w2, ln_weight, ln_bias, out, rstd)
+        out, rstd, yhat = ffn_forward_bf16(x, w1.contiguous(), b1, pack_w2_bf16(w2.contiguous()), b2, ln_weight, ln_bias, eps,
+                                           return_rstd=True)
+        ctx.save_for_backward(x, w1, b1, w2, ln_weight, yhat, rstd)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
-        x, w1, b1, w2, ln_weight, ln_bias, out, rstd = ctx.saved_tensors
+        x, w1, b1, w2, ln_weight, yhat, rstd = ctx.saved_tensors
         x2 = x.reshape(-1, x.shape[-1])
-        # LayerNorm backward + the three token sums in one kernel (yhat from the stored output, rstd from the forward)
-        dz, grad_ln_w, grad_ln_b, grad_b2 = ffn_ln_backward_bf16(grad_out.to(torch.bfloat16), out, rstd, ln_weight, ln_bias)
+        # LayerNorm backward + the three token sums in one kernel (yhat and rstd stored by the forward)
+        dz, grad_ln_w, grad_ln_b, grad_b2 = ffn_ln_backward_bf16(grad_out.to(torch.bfloat16), yhat, rstd, ln_weight)
         # the two token-parallel products with K = 256 on the library's own kernel (csrc/lin256_mfma.hip: 81 / 114 us against 173 / 204 us
         # for the library's GEMM + element-wise op): the hidden activation, recomputed, and the gradient at the ReLU's input
         from .linear import lin256, lin256_pack
