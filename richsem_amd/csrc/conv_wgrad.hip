@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
 void wgrad_split(const WgradGeom &g, long long &split, long long &chunk)
 {
     const long long blocks_y = (long long)g.KH * g.KW * (g.Cout / kBM) * (g.Cin / kBN);
-    split = blocks_y >= 128 ? 1 : (256 + blocks_y - 1) / blocks_y;
+    split = blocks_y >= 128 ? 1 : (512 + blocks_y - 1) / blocks_y;
     const long long max_split = (g.P + 511) / 512;
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
