@@ -236,12 +236,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
     }
 }
 
-// pixel chunks for a problem: 1 when the (tap, channel block) grid gives the chip a workgroup per CU by itself, else enough chunks
-// for about two per CU, of at least 512 pixels each
+// pixel chunks for a problem: enough for about two workgroups per CU (512) together with the (tap, channel block) grid, of at least
+// 512 pixels each (measured: 256 and 1024 workgroups are both slower on the linear layers' shapes; a grid of 144 blocks still gains from 4 chunks)
 void wgrad_split(const WgradGeom &g, long long &split, long long &chunk)
 {
     const long long blocks_y = (long long)g.KH * g.KW * (g.Cout / kBM) * (g.Cin / kBN);
-    split = blocks_y >= 128 ? 1 : (512 + blocks_y - 1) / blocks_y;
+    split = (512 + blocks_y - 1) / blocks_y;
     const long long max_split = (g.P + 511) / 512;
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
