@@ -199,13 +199,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
                                                                 const float *__restrict__ ws_bias, float *__restrict__ dbias, int cout)
 {
     __shared__ float4 red[4][64];
-    if (ws_bias && blockIdx.x == 0)
-        for (int c = threadIdx.x; c < cout; c += blockDim.x) {
-            float v = 0.f;
-            for (int s = 0; s < split; ++s) v += ws_bias[(size_t)s * cout + c];
-            dbias[c] = v;
-        }
     const int col = threadIdx.x & 63, phase = threadIdx.x >> 6;
+    if (ws_bias && (int)blockIdx.x * 64 < cout) {      // the bias partials: 64 channels per workgroup, the same four phases
+        __shared__ float bred[4][64];
+        const int c = blockIdx.x * 64 + col;
+        float v = 0.f;
+        if (c < cout)
+            for (int s = phase; s < split; s += 4) v += ws_bias[(size_t)s * cout + c];
+        bred[phase][col] = v;
+        __syncthreads();
+        if (phase == 0 && c < cout) dbias[c] = bred[0][col] + bred[1][col] + bred[2][col] + bred[3][col];
+    }
     for (long long i0 = (long long)blockIdx.x * 64; i0 < n4; i0 += (long long)gridDim.x * 64) {
         const long long i = i0 + col;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
