@@ -137,10 +137,15 @@ def _pack(w):
 class PackCache:
     """Packed forms of ONE convolution weight, owned by the module that owns the parameter (no global table: a freed tensor's address
     can come back with the same version counter): the forward weight and the flipped / transposed / scale-folded weight of the input
-    gradient, refreshed when the parameter (or the scale) has been modified in place -- i.e. after an optimizer step."""
+    gradient, refreshed when the parameter (or the scale) has been modified in place -- i.e. after an optimizer step, a
+    ``load_state_dict`` or any other in-place op that autograd's version counter sees.  Writes through ``param.data`` bypass that
+    counter: call :meth:`clear` after them."""
 
     def __init__(self):
         self._slots = {}
+
+    def clear(self):
+        self._slots.clear()
 
     def get(self, weight, scale, transposed):
         ver = (weight.data_ptr(), weight._version, scale.data_ptr() if transposed else 0, scale._version if transposed else 0,

@@ -159,3 +159,35 @@ def test_trainable_input_projection_forward_and_gradients():
         got = dict(mod.named_parameters())["layers." + k].grad.cpu()
         s = float(ref.abs().max())
         assert float((got - ref).abs().mean()) <= 6e-3 * s and float((got - ref).abs().max()) <= 6e-2 * s, (k, float((got - ref).abs().max()) / s)
+
+
+def test_packed_weights_follow_an_optimizer_step():
+    """the per-parameter cache of packed weights (conv.PackCache) must notice in-place updates: forward, SGD step, forward again"""
+    from richsem_amd.backbone import Bottleneck
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    blk = Bottleneck(128, 32, stride=1, downsample=True).cuda()
+    x = torch.randn(2, 9, 11, 128, device="cuda").to(torch.bfloat16)
+    opt = torch.optim.SGD([p for p in blk.parameters()], lr=0.5)
+
+    def reference(x):
+        xn = x.permute(0, 3, 1, 2).float()
+        def cb(t, conv, bn, relu, **kw):
+            s, b = bn.scale_shift()
+            y = F.conv2d(t, conv.weight.to(torch.bfloat16).float(), **kw) * s[None, :, None, None] + b[None, :, None, None]
+            return torch.relu(y) if relu else y
+        idt = cb(xn, blk.downsample[0], blk.downsample[1], False)
+        o = cb(xn, blk.conv1, blk.bn1, True).to(torch.bfloat16).float()
+        o = cb(o, blk.conv2, blk.bn2, True, padding=1).to(torch.bfloat16).float()
+        return torch.relu(cb(o, blk.conv3, blk.bn3, False) + idt.to(torch.bfloat16).float())
+
+    for step in range(2):
+        y = blk(x)
+        want = reference(x)
+        err = float((y.permute(0, 3, 1, 2).float() - want).abs().max()) / float(want.abs().max())
+        assert err < 3e-2, (step, err)
+        opt.zero_grad()
+        y.float().square().mean().backward()
+        before = blk.conv2.weight.detach().clone()
+        opt.step()
+        assert not torch.equal(before, blk.conv2.weight.detach())
