@@ -398,6 +398,13 @@ int msda_ffn_forward_train_bf16(const uint16_t *x, const uint16_t *w1, const flo
                                 uint16_t *out, float *rstd, uint16_t *yhat, msda_stream_t stream);
 int msda_ffn_ln_backward_bf16(const uint16_t *dy, const uint16_t *yhat, const float *rstd, const float *ln_weight, int tokens, int d_model,
                               uint16_t *dz, float *grad_ln_weight, float *grad_ln_bias, float *grad_b2, msda_stream_t stream);
+/* Residual add + LayerNorm of the transformer layers (reference deformable_transformer.py:876-877: src = norm1(src + dropout1(src2)),
+ * with the dropout inactive): out = LayerNorm(a + b) over 256 channels; a, b (b may be NULL), out (tokens, 256) bf16; ln_weight, ln_bias
+ * f32; rstd (tokens) f32 and yhat (tokens, 256) bf16 for the backward (either may be NULL), which is msda_ffn_ln_backward_bf16: its dz is
+ * the gradient of a and of b. */
+int msda_add_layernorm_forward_bf16(const uint16_t *a, const uint16_t *b, const float *ln_weight, const float *ln_bias, float eps, int tokens,
+                                    int d_model, uint16_t *out, float *rstd, uint16_t *yhat, msda_stream_t stream);
+
 /* out = act(x W^T + b) for in_features = 256 on the matrix cores (csrc/lin256_mfma.hip; bf16 storage, fp32 accumulation): the two
  * token-parallel products of the feed-forward block's backward.  msda_lin256_pack_bf16: W (out_features, 256) bf16 row-major -> the same
  * number of elements in MFMA fragment order (out_features % 64 == 0).  epilogue 0: acc + bias (bias may be NULL); 1: relu(acc + bias);

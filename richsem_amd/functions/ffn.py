@@ -112,3 +112,35 @@ class FusedFFNFunction(Function):
         grad_w1, grad_b1 = _wgrad(gh, x2, with_bias=True)
         grad_x = torch.addmm(dz, gh, w1).view(x.shape)                          # residual + first product's input gradient
         return grad_x, grad_w1, grad_b1, grad_w2, grad_b2, grad_ln_w, grad_ln_b, None
+
+
+class AddLayerNormFunction(Function):
+    """``LayerNorm(a + b)`` over 256 channels in bf16 (the layers' norm1 around the attention's residual, reference
+    deformable_transformer.py:876-877 with the dropout inactive) as one kernel forward (``msda_add_layernorm_forward_bf16``) and one
+    backward (``msda_ffn_ln_backward_bf16``): apply(a, b, ln_weight, ln_bias, eps); a, b bf16, the parameters float32."""
+
+    @staticmethod
+    def forward(ctx, a, b, ln_weight, ln_bias, eps):
+        a2, b2 = a.contiguous().view(-1, 256), b.contiguous().view(-1, 256)
+        out = torch.empty_like(a2)
+        need = any(ctx.needs_input_grad)
+        rstd = torch.empty(a2.shape[0], dtype=torch.float32, device=a.device) if need else None
+        yhat = torch.empty_like(a2) if need else None
+        w, bi = ln_weight.detach().float().contiguous(), ln_bias.detach().float().contiguous()
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.load().msda_add_layernorm_forward_bf16(
+                a2.data_ptr(), b2.data_ptr(), w.data_ptr(), bi.data_ptr(), float(eps), a2.shape[0], 256, out.data_ptr(),
+                rstd.data_ptr() if need else None, yhat.data_ptr() if need else None, _stream(a)))
+        if need:
+            ctx.save_for_backward(w, yhat, rstd)
+        ctx.meta = (a.shape, ln_weight.dtype, ln_bias.dtype)
+        return out.view(a.shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        w, yhat, rstd = ctx.saved_tensors
+        shape, wdt, bdt = ctx.meta
+        dz, gw, gb, _ = ffn_ln_backward_bf16(grad_out.to(torch.bfloat16), yhat, rstd, w)
+        dz = dz.view(shape)
+        return dz, dz, gw.to(wdt), gb.to(bdt), None

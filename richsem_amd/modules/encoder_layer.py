@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions.ffn import FUSED_FFN_MIN_TOKENS, FusedFFNFunction
+from ..functions.ffn import FUSED_FFN_MIN_TOKENS, AddLayerNormFunction, FusedFFNFunction
 from .ms_deform_attn import MSDeformAttn
 
 
@@ -71,6 +71,11 @@ class DeformableTransformerEncoderLayer(nn.Module):
         # (bfloat16 activations: the attention module runs its projections as bf16 GEMMs and the operator's bf16 entry points, with
         # fp32 locations / weights -- new capability: the reference has no half path; the LayerNorms compute in fp32 internally)
         src2 = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes, level_start_index, key_padding_mask)
-        src = F.layer_norm(src + self.dropout1(src2), (src.shape[-1],), self.norm1.weight.to(src.dtype), self.norm1.bias.to(src.dtype),
-                           self.norm1.eps)
+        if (self.fused_ffn and src.is_cuda and src.dtype == torch.bfloat16 and src.shape[-1] == 256
+                and not (self.training and self.dropout1.p > 0)):
+            # residual add + LayerNorm as one kernel each way (functions/ffn.py: AddLayerNormFunction)
+            src = AddLayerNormFunction.apply(src, src2, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        else:
+            src = F.layer_norm(src + self.dropout1(src2), (src.shape[-1],), self.norm1.weight.to(src.dtype), self.norm1.bias.to(src.dtype),
+                               self.norm1.eps)
         return self.forward_ffn(src)

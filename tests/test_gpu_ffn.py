@@ -166,3 +166,25 @@ def test_lin256_f32_split_kernel(tokens, n):
     assert got.dtype == torch.float32 and float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
     got0 = lin256_f32(x, lin256_f32_pack(w), n)
     assert float((got0.double() - (want - b.double())).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("tokens", [1, 1000, 4097])
+def test_add_layernorm_function(tokens):
+    """AddLayerNormFunction (residual add + LayerNorm, one kernel each way) against fp32 autograd of F.layer_norm(a + b) on the same bf16
+    inputs: output within one bf16 rounding, gradients at bf16 level"""
+    import torch.nn.functional as F
+    from richsem_amd.functions import AddLayerNormFunction
+    torch.manual_seed(tokens)
+    a = torch.randn(tokens, 256, device="cuda").to(torch.bfloat16)
+    b = (0.5 * torch.randn(tokens, 256, device="cuda")).to(torch.bfloat16)
+    w, bi = torch.rand(256, device="cuda") + 0.5, torch.randn(256, device="cuda")
+    go = torch.randn(tokens, 256, device="cuda").to(torch.bfloat16)
+    a1, b1, w1, bi1 = (t.clone().requires_grad_(True) for t in (a, b, w, bi))
+    out = AddLayerNormFunction.apply(a1, b1, w1, bi1, 1e-5)
+    out.backward(go)
+    a2, b2, w2, bi2 = (t.float().clone().requires_grad_(True) for t in (a, b, w, bi))
+    ref = F.layer_norm(a2 + b2, (256,), w2, bi2, 1e-5)
+    ref.backward(go.float())
+    assert float((out.float() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+    for got, want in ((a1.grad.float(), a2.grad), (b1.grad.float(), b2.grad), (w1.grad, w2.grad), (bi1.grad, bi2.grad)):
+        assert float((got - want).abs().max()) <= 2e-2 * float(want.abs().max()) + 1e-3
