@@ -327,10 +327,12 @@ int msda_conv_dgrad_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, in
  * output (ReLU mask applied); x (N, H, W, Cin) bf16; dw (Cout, KH, KW, Cin) fp32, every element written.  The pixels are split into
  * chunks where the (tap, channel block) grid alone cannot fill the chip; the chunks' partial sums go through `workspace`
  * (msda_conv_wgrad_workspace_bytes; may be NULL when that is 0) and a second kernel.  dbias (Cout) fp32, optional (NULL: not wanted):
- * sum over the output pixels of dz, formed on the way.  Cout % 128 == 0, Cin % 128 == 0. */
+ * sum over the output pixels of dz, formed on the way.  scale (Cout) fp32, optional: dw[co] is multiplied by scale[co] (the frozen affine
+ * that follows the convolution commutes with the pixel sum).  torch_layout != 0: dw is written as (Cout, Cin, KH, KW), nn.Conv2d's layout.
+ * Cout % 128 == 0, Cin % 128 == 0. */
 int msda_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t *bytes);
 int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                         int pad, float *dw, float *dbias, void *workspace, msda_stream_t stream);
+                         int pad, float *dw, float *dbias, const float *scale, int torch_layout, void *workspace, msda_stream_t stream);
 
 /* ---- two-stage query selection: row maxima of the class logits without the logits (reference
  * models/richsem/deformable_transformer.py:368-372 with the CLIP-text classifier models/richsem/richsem.py:176-184 in its shipped

@@ -116,7 +116,7 @@ def load():
     L.msda_pool_nhwc_bf16.restype = ci
     L.msda_groupnorm8_nhwc_bf16.argtypes = [vp, vp, vp, ctypes.c_float, ci, ci, ci, vp, vp, vp, vp]
     L.msda_groupnorm8_nhwc_bf16.restype = ci
-    L.msda_conv_wgrad_bf16.argtypes = [vp, vp] + [ci] * 9 + [vp, vp, vp, vp]
+    L.msda_conv_wgrad_bf16.argtypes = [vp, vp] + [ci] * 9 + [vp, vp, vp, ci, vp, vp]
     L.msda_conv_wgrad_bf16.restype = ci
     L.msda_conv_wgrad_workspace_bytes.argtypes = [ci] * 9 + [ctypes.POINTER(i64)]
     L.msda_conv_wgrad_workspace_bytes.restype = ci

@@ -219,15 +219,16 @@ class ConvAffineFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # the weight gradient is taken with dz and scaled per output channel afterwards (the affine's scale commutes with the sum)
             if Cout % 128 == 0 and Cin % 128 == 0 and not ConvAffineFunction.library_wgrad:
-                dw4 = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=x.device)
+                dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=x.device)      # nn.Conv2d's layout, scaled: final
                 L = _lib.load()
                 nb = ctypes.c_int64(0)
                 _lib.check(L.msda_conv_wgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, padding, ctypes.byref(nb)))
                 ws = torch.empty(nb.value // 4, dtype=torch.float32, device=x.device) if nb.value else None
                 with torch.cuda.device(x.device):
                     _lib.check(L.msda_conv_wgrad_bf16(dz.data_ptr(), x.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, padding,
-                                                      dw4.data_ptr(), None, ws.data_ptr() if ws is not None else None, _stream(x.device)))
-                dw = (dw4 * scale.view(-1, 1, 1, 1)).permute(0, 3, 1, 2).to(weight.dtype)
+                                                      dw.data_ptr(), None, scale.data_ptr(), 1, ws.data_ptr() if ws is not None else None,
+                                                      _stream(x.device)))
+                dw = dw.to(weight.dtype)
             else:       # channel counts the wgrad kernel does not take (ResNet-50's layer2-4 never get here): MIOpen
                 _, dw, _ = torch.ops.aten.convolution_backward(dz.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2),
                                                                weight.detach().to(torch.bfloat16), None, [stride, stride],

@@ -38,12 +38,14 @@ constexpr int kImageBytes = kStagePx * 256;   // one operand's stage: 64 rows of
 struct WgradGeom {
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
     long long P, chunk;     // output pixels; pixels per workgroup (multiple of kStagePx)
+    int torch_layout;       // final result as (C_out, C_in, KH, KW) (nn.Conv2d's) instead of (C_out, KH, KW, C_in)
 };
 
 __device__ __forceinline__ int lds_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__restrict__ dz, const uint16_t *__restrict__ x,
-                                                              float *__restrict__ dw, float *__restrict__ dbias, WgradGeom g)
+                                                              float *__restrict__ dw, float *__restrict__ dbias,
+                                                              const float *__restrict__ scale, int direct, WgradGeom g)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * kImageBytes];   // [buffer][A image | B image]
 
@@ -187,7 +189,11 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int co = cob * kBM + 16 * (4 * wm + a) + 4 * gI + i;
-                out[((long long)co * taps + tap) * g.Cin + ci] = acc[a][b][i];
+                if (direct)      // one chunk: the final result, scaled per output channel and in the layout asked for
+                    out[g.torch_layout ? ((long long)co * g.Cin + ci) * taps + tap : ((long long)co * taps + tap) * g.Cin + ci] =
+                        acc[a][b][i] * (scale ? scale[co] : 1.f);
+                else
+                    out[((long long)co * taps + tap) * g.Cin + ci] = acc[a][b][i];
             }
         }
 }
@@ -196,7 +202,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
 // p, p + 4, ... with the loads of several slices in flight; the first version -- one thread per element walking all slices -- took
 // longer than the products it follows: 31 us for 64 slices of 256 KB), folded through LDS.
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, long long n4, int split,
-                                                                const float *__restrict__ ws_bias, float *__restrict__ dbias, int cout)
+                                                                const float *__restrict__ ws_bias, float *__restrict__ dbias, int cout,
+                                                                const float *__restrict__ scale, int taps, int cin, int torch_layout)
 {
     __shared__ float4 red[4][64];
     const int col = threadIdx.x & 63, phase = threadIdx.x >> 6;
@@ -234,7 +241,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
             for (int p = 1; p < 4; ++p) {
                 r.x += red[p][col].x; r.y += red[p][col].y; r.z += red[p][col].z; r.w += red[p][col].w;
             }
-            reinterpret_cast<float4 *>(dw)[i] = r;
+            // element 4 i of the (C_out, taps, C_in) order: scale per output channel, final layout
+            const long long e0 = 4 * i;
+            const int co = (int)(e0 / ((long long)taps * cin));
+            if (scale) {
+                const float sc = scale[co];
+                r.x *= sc; r.y *= sc; r.z *= sc; r.w *= sc;
+            }
+            if (torch_layout && taps > 1) {
+                const int rem = (int)(e0 - (long long)co * taps * cin), tap = rem / cin, ci = rem - tap * cin;
+                float *d = dw + ((long long)co * cin + ci) * taps + tap;
+                d[0] = r.x; d[taps] = r.y; d[2 * taps] = r.z; d[3 * taps] = r.w;
+            } else {
+                reinterpret_cast<float4 *>(dw)[i] = r;
+            }
         }
         __syncthreads();
     }
@@ -266,7 +286,7 @@ int msda_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int 
         return MSDA_ERR_BAD_DIMS;
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     if (Ho < 1 || Wo < 1) return MSDA_ERR_BAD_DIMS;
-    WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, (long long)N * Ho * Wo, 0};
+    WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, (long long)N * Ho * Wo, 0, 0};
     long long split, chunk;
     wgrad_split(g, split, chunk);
     *bytes = split > 1 ? (int64_t)split * ((int64_t)Cout * KH * KW * Cin + Cout) * (int64_t)sizeof(float) : 0;      // (+ bias partials)
@@ -274,7 +294,7 @@ int msda_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int 
 }
 
 int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                         int pad, float *dw, float *dbias, void *workspace, msda_stream_t stream)
+                         int pad, float *dw, float *dbias, const float *scale, int torch_layout, void *workspace, msda_stream_t stream)
 {
     if (!dz || !x || !dw) return MSDA_ERR_NULL_POINTER;
     if (N < 1 || H < 1 || W < 1 || Cin < kBN || Cin % kBN != 0 || Cout < kBM || Cout % kBM != 0 || KH < 1 || KW < 1 || KH > 16 || KW > 16 ||
@@ -285,7 +305,7 @@ int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, in
     if ((long long)N * H * W * Cin >= (1ll << 40) || (long long)N * Ho * Wo * Cout >= (1ll << 40)) return MSDA_ERR_TOO_LARGE;
     if ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dw)) & 15) return MSDA_ERR_MISALIGNED;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, (long long)N * Ho * Wo, 0};
+    WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, (long long)N * Ho * Wo, 0, torch_layout};
     if (g.P >= (1ll << 31) - (1 << 20) || (long long)N * H * W >= (1ll << 31)) return MSDA_ERR_TOO_LARGE;      // 32-bit pixel counters
     long long split;
     wgrad_split(g, split, g.chunk);
@@ -295,14 +315,15 @@ int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, in
     if (blocks_y > 65535) return MSDA_ERR_TOO_LARGE;
     float *ws_bias = split > 1 ? static_cast<float *>(workspace) + split * n_dw : nullptr;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)split, (unsigned)blocks_y), dim3(kThreads), 0, st, dz, x,
-                       split > 1 ? static_cast<float *>(workspace) : dw, dbias ? (split > 1 ? ws_bias : dbias) : nullptr, g);
+                       split > 1 ? static_cast<float *>(workspace) : dw, dbias ? (split > 1 ? ws_bias : dbias) : nullptr, scale, split > 1 ? 0 : 1,
+                       g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (split > 1) {
         const long long n4 = n_dw / 4;
         const int grid = (int)((n4 + 63) / 64 < 8192 ? (n4 + 63) / 64 : 8192);
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, static_cast<const float *>(workspace), dw, n4, (int)split,
-                           dbias ? ws_bias : nullptr, dbias, Cout);
+                           dbias ? ws_bias : nullptr, dbias, Cout, scale, KH * KW, Cin, torch_layout);
     }
     e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;

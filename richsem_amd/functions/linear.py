@@ -32,7 +32,7 @@ def linear_wgrad_bf16(dy, x, with_bias=False):
     ws = torch.empty(nb.value // 4, dtype=torch.float32, device=x.device) if nb.value else None
     with torch.cuda.device(x.device):
         _lib.check(L.msda_conv_wgrad_bf16(dy.data_ptr(), x.data_ptr(), 1, 1, T, cin, cout, 1, 1, 1, 0, dw.data_ptr(),
-                                          db.data_ptr() if db is not None else None, ws.data_ptr() if ws is not None else None,
+                                          db.data_ptr() if db is not None else None, None, 0, ws.data_ptr() if ws is not None else None,
                                           torch.cuda.current_stream(x.device).cuda_stream))
     return (dw, db) if with_bias else dw
 

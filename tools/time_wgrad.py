@@ -69,7 +69,7 @@ def main():
         dx = torch.empty_like(x)
 
         def wgrad():
-            _lib.check(L.msda_conv_wgrad_bf16(dz.data_ptr(), x.data_ptr(), N, H, W, Cin, Cout, k, k, stride, pad, dw.data_ptr(), None, ws.data_ptr(), st))
+            _lib.check(L.msda_conv_wgrad_bf16(dz.data_ptr(), x.data_ptr(), N, H, W, Cin, Cout, k, k, stride, pad, dw.data_ptr(), None, None, 0, ws.data_ptr(), st))
 
         def dgrad():
             _lib.check(L.msda_conv_dgrad_bf16(dz.data_ptr(), pk.data_ptr(), N, Ho, Wo, Cout, Cin, k, k, stride, pad, H, W, dx.data_ptr(), st))
