@@ -139,3 +139,35 @@ def lin256_f32(x, packed_w, out_features, bias=None):
                                                        x.shape[0], 256, out_features, out.data_ptr(),
                                                        torch.cuda.current_stream(x.device).cuda_stream))
     return out
+
+
+class LinearBf16CachedFunction(torch.autograd.Function):
+    """:class:`LinearBf16Function` for a caller that keeps the bf16 casts of its parameters (and the concatenation of several layers'
+    parameters into one projection) across calls: ``apply(x, w16, b16, split, *params)`` computes ``x w16^T + b16`` and routes the
+    gradients to ``params`` = (weight, bias) or, with ``split`` = rows of the first layer, (weight_a, weight_b, bias_a, bias_b) -- the
+    two layers whose parameters ``w16`` / ``b16`` concatenate.  No cast or concatenation kernels per call."""
+
+    @staticmethod
+    def forward(ctx, x, w16, b16, split, *params):
+        ctx.save_for_backward(x, w16)
+        ctx.meta = (split, tuple(p.dtype for p in params))
+        out = torch.empty(x.shape[:-1] + (w16.shape[0],), dtype=torch.bfloat16, device=x.device)
+        torch.addmm(b16, x.reshape(-1, x.shape[-1]), w16.t(), out=out.view(-1, w16.shape[0]))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w16 = ctx.saved_tensors
+        split, dts = ctx.meta
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]).contiguous(), x.reshape(-1, x.shape[-1])
+        dx = (dy2 @ w16).view(x.shape) if ctx.needs_input_grad[0] else None
+        if linear_wgrad_supported(dy2.shape[1], x2.shape[1]) and dy2.shape[0] >= LinearBf16Function.MIN_TOKENS:
+            dw, db = linear_wgrad_bf16(dy2, x2.contiguous(), with_bias=True)
+        else:
+            dw, db = (dy2.t() @ x2).float(), dy2.sum(0, dtype=torch.float32)
+        if split is None:
+            grads = (dw.to(dts[0]), db.to(dts[1]))
+        else:
+            grads = (dw[:split].to(dts[0]), dw[split:].to(dts[1]), db[:split].to(dts[2]), db[split:].to(dts[3]))
+        return (dx, None, None, None) + grads

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions import MaskRows, MSDeformAttnFunction, MSDeformAttnFusedFunction
-from ..functions.linear import linear_bf16
+from ..functions.linear import LinearBf16CachedFunction
 
 
 def _is_power_of_2(n):
@@ -65,6 +65,21 @@ class MSDeformAttn(nn.Module):
             nn.init.xavier_uniform_(self.output_proj.weight)
             self.output_proj.bias.zero_()
 
+    def _bf16_params(self):
+        """bf16 forms of the projections' parameters (offsets and logits stacked into one 256 -> 384 projection), rebuilt when any of
+        them has been modified in place (optimizer step, load_state_dict)"""
+        ps = (self.value_proj.weight, self.value_proj.bias, self.sampling_offsets.weight, self.sampling_offsets.bias,
+              self.attention_weights.weight, self.attention_weights.bias, self.output_proj.weight, self.output_proj.bias)
+        ver = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_bf16_ver", None) != ver:
+            with torch.no_grad():
+                b16 = lambda t: t.detach().to(torch.bfloat16).contiguous()
+                self._bf16_cache = {
+                    "wv": b16(ps[0]), "bv": b16(ps[1]), "wq": b16(torch.cat((ps[2], ps[4]), 0)), "bq": b16(torch.cat((ps[3], ps[5]), 0)),
+                    "wo": b16(ps[6]), "bo": b16(ps[7])}
+            self._bf16_ver = ver
+        return self._bf16_cache
+
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
         """query (N, Lq, C); reference_points (N, Lq, L, 2|4) in [0,1] incl. padding; input_flatten (N, S, C);
@@ -84,21 +99,32 @@ class MSDeformAttn(nn.Module):
             # module's (fp32) parameters cast per call, value / output travel as bf16 through the operator's bf16 entry points,
             # locations and attention weights are formed and kept in fp32
             dt = query.dtype
-            # (bf16: LinearBf16Function -- library GEMMs for the forward and the input gradient, the library's own MFMA kernel for the
-            # weight gradient, whose contraction runs over the tokens)
-            linear = linear_bf16 if dt == torch.bfloat16 else F.linear
-            value = linear(input_flatten.to(dt), self.value_proj.weight, self.value_proj.bias)
+            if dt == torch.bfloat16:
+                # bf16: library GEMMs for the forward and the input gradient, the library's own MFMA kernel for the weight gradient (its
+                # contraction runs over the tokens); the bf16 casts of the parameters and the stacked offsets / logits projection are
+                # kept across calls (refreshed when a parameter changes)
+                c = self._bf16_params()
+                value = LinearBf16CachedFunction.apply(input_flatten.to(dt), c["wv"], c["bv"], None, self.value_proj.weight,
+                                                       self.value_proj.bias)
+                if input_padding_mask is not None:
+                    value = MaskRows.apply(value, input_padding_mask)
+                qproj = LinearBf16CachedFunction.apply(query, c["wq"], c["bq"], self.sampling_offsets.weight.shape[0],
+                                                       self.sampling_offsets.weight, self.attention_weights.weight,
+                                                       self.sampling_offsets.bias, self.attention_weights.bias)
+                out = MSDeformAttnFusedFunction.apply(value.view(N, S, H, self.d_model // H), input_spatial_shapes,
+                                                      input_level_start_index, qproj, reference_points.float(), H, L, P, self.im2col_step)
+                return LinearBf16CachedFunction.apply(out, c["wo"], c["bo"], None, self.output_proj.weight, self.output_proj.bias)
+            value = F.linear(input_flatten.to(dt), self.value_proj.weight, self.value_proj.bias)
             if input_padding_mask is not None:
                 value = MaskRows.apply(value, input_padding_mask)
             # offsets and attention logits from ONE projection (the two weight matrices stacked: 256 -> 384 for RichSem)
             weight = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
             bias = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
-            qproj = linear(query, weight, bias)
-            ref_dt = torch.float32 if dt == torch.bfloat16 else dt
+            qproj = F.linear(query, weight, bias)
             out = MSDeformAttnFusedFunction.apply(value.view(N, S, H, self.d_model // H), input_spatial_shapes,
-                                                  input_level_start_index, qproj, reference_points.to(ref_dt), H, L, P,
+                                                  input_level_start_index, qproj, reference_points.to(dt), H, L, P,
                                                   self.im2col_step)
-            return linear(out, self.output_proj.weight, self.output_proj.bias)
+            return F.linear(out, self.output_proj.weight, self.output_proj.bias)
 
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:
