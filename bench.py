@@ -53,12 +53,10 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 HIP_KERNELS = {
     ("fwd", 1): "fwd_direct_kernel",
     ("bwd", 1): "bwd_levelsum_kernel + bwd_direct_kernel",
-    ("fwd", 2): "tiled_gather_kernel<false",
-    ("bwd", 2): "tiled_scatter_sorted_kernel + tiled_gather_kernel<true",
-    ("bwd", 3): "psb_kernel + psb_far_kernel",
+    ("fwd", 2): "tiled_gather_kernel",
     ("bwd", 4): "rps_route_kernel<true> + rps_route_kernel<false> + rps_tile_kernel",
 }
-VARIANT_NAMES = {1: "direct", 2: "tiled", 3: "psb", 4: "routed"}
+VARIANT_NAMES = {1: "direct", 2: "tiled", 4: "routed"}
 
 
 def parse_args(argv=None):

@@ -79,26 +79,21 @@ const char *msda_last_error(void);
 
 /* Tuning / test hooks.  Keys:
  *   "fwd_variant"     0 = auto, 1 = direct gather kernel, 2 = LDS-window kernel (when applicable)
- *   "bwd_variant"     0 = auto, 1 = direct kernel (level-sum windows / row atomics), 2 = LDS-window kernels, 3 = pixel-
- *                     stationary kernel with candidate queries by geometry (opt-in only: slower), 4 = routed pixel-
- *                     stationary kernels (sampling points routed to output tiles in two exact passes; cost independent of
- *                     where the points fall).  2-4 apply to fp32, D = 32, L <= 4 (2 also needs Lq == S); otherwise the
- *                     call falls back to 1.
- *                     auto = for encoder-shaped fp32 calls the locality monitor (below) decides: window kernels while the
- *                     sampling points are local, direct forward / routed backward otherwise; other calls: direct kernels
+ *   "bwd_variant"     0 = auto, 1 = direct kernel (level-sum windows / row atomics), 4 = routed pixel-stationary kernels
+ *                     (sampling points routed to output tiles in two exact passes, every pixel of grad_value written once with
+ *                     plain stores; cost independent of where the points fall; fp32 / bf16 storage, D = 32, L <= 4, any Lq;
+ *                     otherwise the call falls back to 1).  auto = routed for encoder-shaped calls (Lq == S), direct for the rest
  *   "locality_monitor"  1 (default) = in auto mode the window forward kernel counts the points that miss their window on the
  *                     first 2 calls of a (problem shape, sampling_loc buffer) and on every 64th after; the count comes back
  *                     by an asynchronous copy and is read on a later call (no call waits, nothing is probed during graph
- *                     capture, up to 8 probes in flight).  Until a share is known: direct forward, routed backward.
- *                     Share > 8 % -> direct forward, share > 1.5 % -> routed backward (crossovers measured on MI355X,
- *                     profiles/r02_locality.md).  0 = auto always takes the window kernels when they apply.  Setting it
- *                     forgets what was learnt.  "locality_share_ppm" (get only): last measured share in parts per
- *                     million, -1 = none.
+ *                     capture, up to 8 probes in flight).  Share > 8 % -> direct forward (crossover measured on MI355X,
+ *                     profiles/r02_locality.md).  0 = auto always takes the window forward kernel when it applies.  Setting
+ *                     it forgets what was learnt.  "locality_share_ppm" (get only): last measured share in parts per
+ *                     million, -1 = none.  (The backward needs no monitor.)
  *   "rps_tile"        routed backward: largest tile side + 1 (4..16, default 16: tile + one row / column <= 256 pixels)
  *   "rps_max_chunks"  routed backward: chunks of 2048 points one workgroup takes before a tile's points are dealt over
  *                     several workgroups (default 12)
  *   "rps_route_wgs"   routed backward: workgroups per CU of the route passes (default 4)
- *   "psb_margin", "psb_tile", "psb_max_chunks", "psb_coarse_px"   geometry of bwd_variant 3
  *   "levelsum_lds_kb" level-sum window size in KB (8..150, default 150 = one workgroup per CU)
  *   "bwd_direct_cpl"  channels per lane of the direct backward kernel (0 = auto, 1, 2, 4)
  *   "tile_region"     side of an LDS-window region, in pixels of the finest level (default 20)
@@ -109,10 +104,7 @@ const char *msda_last_error(void);
  *                     in an f64 LDS window by its own kernel and written once.  Calls with Lq*P <= 2^20 whose levels fit 16 windows
  *                     hand over ALL levels: no global atomics, no zero-fill, sums exact to fp32 rounding whatever the order.  Otherwise only
  *                     levels that fit LDS whole and receive >= 2 sampling points per pixel.  0 = off (row atomics only)
- *   "tile_accum"      grad_value of the window path: 2 = sorted (segmented) reduction, fp32 sums (default);
- *                     0 = f64 LDS-atomic window; 1 = per-pixel block-floating-point window on 32-bit integer LDS atomics
  *   "tile_persist"    persistent workgroups walking the work items (default 512 = 2 per CU; 0 = one workgroup per item)
- *   "bwd_gather_halves"  1 = backward location/attention gradients on channel halves (default 0)
  *   "tile_debug"      diagnostic bits (stage-stamp kernel selection)
  * Unknown key or value out of range -> MSDA_ERR_BAD_OPTION.  Options change speed, never results. */
 int msda_set_option(const char *key, int value);

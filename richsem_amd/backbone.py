@@ -211,43 +211,42 @@ class ResNet50(nn.Module):
         return outs
 
 
-class InputProjection(nn.Module):
-    """Trainable form of the input projections (richsem.py:295-310): ``nn.ModuleList`` of ``nn.Sequential(conv, GroupNorm(32, hidden))``
-    under the reference's parameter names (``{l}.0.weight``, ``{l}.0.bias``, ``{l}.1.weight``, ``{l}.1.bias`` -- load the model's
-    ``input_proj.*`` entries with the prefix stripped).  The convolutions run ConvAffineFunction (bias = the epilogue's shift, with its
-    gradient), the GroupNorm is PyTorch's on the NHWC tensor's channels-first view.  ``forward(features)`` as :class:`InputProj`."""
+class _ProjConv(nn.Module):
+    """the convolution of one input projection under nn.Conv2d's parameter names (``weight``, ``bias``)"""
+
+    def __init__(self, cin, cout, k, stride, padding):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        nn.init.xavier_uniform_(self.weight, gain=1)           # richsem.py:385-387
+        self.stride, self.padding, self.pack_cache = stride, padding, PackCache()
+
+
+class InputProjection(nn.ModuleList):
+    """Trainable form of the input projections (richsem.py:295-310): an ``nn.ModuleList`` of ``nn.Sequential(conv, GroupNorm(32, hidden))``
+    like the reference's ``input_proj``, so the parameter names are the reference's natively (``{l}.0.weight``, ``{l}.0.bias``,
+    ``{l}.1.weight``, ``{l}.1.bias``) -- as the root module and nested (``model.input_proj = InputProjection()`` gives
+    ``input_proj.{l}.0.weight``: a reference checkpoint loads with ``strict=True``).  The convolutions run ConvAffineFunction (bias =
+    the epilogue's shift, with its gradient), the GroupNorm is PyTorch's on the NHWC tensor's channels-first view.
+    ``forward(features)`` as :class:`InputProj`."""
 
     def __init__(self, in_channels=(512, 1024, 2048), hidden=256, num_levels=4, groups=32):
-        super().__init__()
-
-        class _Conv(nn.Module):
-            def __init__(self, cin, cout, k, stride, padding):
-                super().__init__()
-                self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
-                self.bias = nn.Parameter(torch.zeros(cout))
-                nn.init.xavier_uniform_(self.weight, gain=1)           # richsem.py:385-387
-                self.stride, self.padding, self.pack_cache = stride, padding, PackCache()
-
         layers = []
         for l in range(num_levels):
             if l < len(in_channels):
-                conv = _Conv(in_channels[l], hidden, 1, 1, 0)
+                conv = _ProjConv(in_channels[l], hidden, 1, 1, 0)
             else:
-                conv = _Conv(in_channels[-1] if l == len(in_channels) else hidden, hidden, 3, 2, 1)
+                conv = _ProjConv(in_channels[-1] if l == len(in_channels) else hidden, hidden, 3, 2, 1)
             layers.append(nn.Sequential(conv, nn.GroupNorm(groups, hidden)))
-        self.layers = nn.ModuleList(layers)
+        super().__init__(layers)
         self.n_stage = len(in_channels)
-        self.register_buffer("_one", torch.ones(hidden), persistent=False)
-
-    def state_dict(self, *args, **kwargs):
-        return {k[len("layers."):]: v for k, v in super().state_dict(*args, **kwargs).items()}
-
-    def load_state_dict(self, sd, strict=True):
-        return super().load_state_dict({"layers." + k: v for k, v in sd.items()}, strict=strict)
+        self._one = None          # the epilogue's unit scale: made on first use on the input's device (not a parameter, not a buffer)
 
     def forward(self, features, out_dtype=torch.float32):
         srcs, shapes, prev = [], [], None
-        for l, (conv, norm) in enumerate(self.layers):
+        if self._one is None or self._one.device != features[0].device:
+            self._one = torch.ones(self[0][0].weight.shape[0], device=features[0].device)
+        for l, (conv, norm) in enumerate(self):
             x = features[l] if l < self.n_stage else (features[-1] if l == self.n_stage else prev)
             y = ConvAffineFunction.apply(x, conv.weight, self._one, conv.bias, None, conv.stride, conv.padding, False, conv.pack_cache)
             N, H, W, C = y.shape

@@ -253,6 +253,16 @@ class ConvBNAct(torch.nn.Module):
         self.stride, self.padding, self.relu = stride, padding, relu
         self._pack_cache = PackCache()
 
+    def scale_shift(self):
+        """the frozen affine, folded once and again only after the buffers changed (a fresh tensor per call would defeat the
+        PackCache's key, or -- at a recycled address -- alias a stale scale-folded weight)"""
+        ver = (self.bn_weight._version, self.bn_bias._version, self.running_mean._version, self.running_var._version,
+               self.bn_weight.data_ptr())
+        if getattr(self, "_folded_ver", None) != ver:
+            self._folded = fold_bn(self.bn_weight, self.bn_bias, self.running_mean, self.running_var, 1e-5)
+            self._folded_ver = ver
+        return self._folded
+
     def forward(self, x, residual=None):
-        scale, shift = fold_bn(self.bn_weight, self.bn_bias, self.running_mean, self.running_var, 1e-5)
+        scale, shift = self.scale_shift()
         return ConvAffineFunction.apply(x, self.weight, scale, shift, residual, self.stride, self.padding, self.relu, self._pack_cache)

@@ -21,7 +21,6 @@
 #include "msda_dn.h"
 #include "msda_topk.h"
 #include "msda_roi.h"
-#include "msda_psb.h"
 #include "msda_rps.h"
 #include "msda_tiled.h"
 
@@ -88,20 +87,15 @@ struct ProfileScope {
 
 
 // ---- locality monitor -----------------------------------------------------------------------------------
-// The LDS-window kernels win only while most sampling points fall into the window of their query's region; the share
+// The LDS-window FORWARD kernel wins only while most sampling points fall into the window of their query's region; the share
 // that does not ("general share") is a property of the DATA (how far the network's offsets reach).  Measured on MI355X
 // (tools/locality_sweep2.sh, call E; profiles/r02_locality.md): the window forward -- which finishes the points that miss
-// their window per point, after the item -- beats the direct forward up to a share of ~8 % (sigma ~4.5 px); the window backward
-// beats the routed backward only up to ~1 % (sigma ~2 px: 376 us both; at 1 px 372 vs 374), and the routed backward, whose cost
-// does not depend on the distribution, beats the direct backward everywhere.  In automatic mode the library therefore lets the window
-// forward kernel count its general points now and then (one atomic per wave), brings the count back with an
-// asynchronous copy + event on the caller's stream, and reads it on a LATER call once the event has completed -- no
-// call ever waits.  Nothing is probed while the stream is being captured into a graph.
-constexpr float kFwdShareMax = 0.08f, kBwdShareMax = 0.23f;
-// Backward: above this share of window misses the routed kernels (msda_rps.h), whose cost does not depend on where the points
-// fall, beat the window kernels (MI355X, call E: window 372 / 405 / 485 / 2190 us at sigma 1 / 3 / 4 px / uniform, routed 374 /
-// 375 / 375 / 447)
-constexpr float kBwdRoutedShare = 0.015f;
+// their window per point, after the item -- beats the direct forward up to a share of ~8 % (sigma ~4.5 px).  In automatic mode
+// the library therefore lets the window forward kernel count its general points now and then (one atomic per wave), brings the
+// count back with an asynchronous copy + event on the caller's stream, and reads it on a LATER call once the event has completed
+// -- no call ever waits.  Nothing is probed while the stream is being captured into a graph.  (The backward needs no monitor: the
+// routed kernels of msda_rps.h cost the same wherever the points fall.)
+constexpr float kFwdShareMax = 0.08f;
 constexpr unsigned kProbeWarmCalls = 2, kProbeEvery = 64;   // per (shape, sampling_loc buffer)
 constexpr int kMaxDevices = 64;
 std::atomic<int> g_monitor_on{1};
@@ -223,20 +217,6 @@ void monitor_finish_probe(Monitor *mo, double points, hipStream_t stream, bool l
         mo->slot[i].points = points;
     }
     mo->mu.unlock();
-}
-
-// 2 = window kernels, 4 = routed kernels (when the caller can take them, else it falls back by itself), 1 = direct
-int monitor_choose_bwd(Monitor *mo, uint64_t key, hipStream_t stream)
-{
-    if (!mo || !g_monitor_on.load()) return 2;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(stream, &cap);
-    std::lock_guard<std::mutex> lock(mo->mu);
-    if (cap == hipStreamCaptureStatusNone) monitor_poll(*mo);
-    const auto it = mo->table.find(key);
-    // no verdict yet (the first step of a layer): the routed kernels, which cost the same wherever the points fall
-    if (it == mo->table.end() || !it->second.known) return 4;
-    return it->second.share > kBwdRoutedShare ? 4 : 2;
 }
 
 struct Problem {
@@ -385,12 +365,9 @@ int direct_grid(const msda::DirectGeom &g)
     return msda::kXcds * ((pairs + msda::kXcds - 1) / msda::kXcds) * g.ntiles;
 }
 
-// ---- pixel-stationary backward (msda_psb.h): workspace and launch ------------------------------------------------------
-// The kernel needs a few words of device memory (work-queue heads, far-point counter) and a list for the far points.
-// Kept per (device, stream): calls on one stream are ordered, so they can share it; calls on different streams cannot.
-struct PsbWorkspace {
-    unsigned *ctr = nullptr, *far = nullptr;
-    size_t far_cap = 0;
+// ---- library-owned device memory, per (device, stream): calls on one stream are ordered, so they can share it; calls on
+// different streams cannot.  Nothing is allocated while the stream is being captured.
+struct Workspace {
     float *gv32 = nullptr;   // bf16 backward: fp32 accumulation buffer for grad_value (rounded to bf16 once)
     size_t gv32_cap = 0;
     unsigned *rps_bins = nullptr;            // routed backward: queue heads (32 words), bin_count, bin_fill, bin_start (+1) -- laid
@@ -400,33 +377,9 @@ struct PsbWorkspace {
     size_t rps_entries_cap = 0;
     bool rps_dirty = false;                  // a failed launch may have left the bin counters non-zero
 };
-std::mutex g_psb_mu;
-std::map<std::pair<int, hipStream_t>, PsbWorkspace> g_psb_ws;
+std::mutex g_ws_mu;
+std::map<std::pair<int, hipStream_t>, Workspace> g_ws;
 int g_cu_count[kMaxDevices] = {0};
-
-bool psb_workspace(hipStream_t stream, size_t far_cap, PsbWorkspace &out)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    std::lock_guard<std::mutex> lock(g_psb_mu);
-    PsbWorkspace &ws = g_psb_ws[std::make_pair(dev, stream)];
-    if (!ws.ctr || ws.far_cap < far_cap) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(stream, &cap);
-        if (cap != hipStreamCaptureStatusNone) return false;   // no allocation while the stream is being captured
-        if (!ws.ctr && hipMalloc(reinterpret_cast<void **>(&ws.ctr), 64) != hipSuccess) { (void)hipGetLastError(); ws.ctr = nullptr; return false; }
-        if (ws.far_cap < far_cap || !ws.far) {
-            if (ws.far) (void)hipFree(ws.far);   // (waits for the work that may still use it)
-            ws.far = nullptr;
-            ws.far_cap = 0;
-            const size_t want = far_cap < 16 ? 16 : far_cap;
-            if (hipMalloc(reinterpret_cast<void **>(&ws.far), want * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
-            ws.far_cap = want;
-        }
-    }
-    out = ws;
-    return true;
-}
 
 int cu_count()
 {
@@ -440,55 +393,15 @@ int cu_count()
     return g_cu_count[dev];
 }
 
-// total chunk-phases per (image, head) a plan costs: what decides whether walking every query for every tile is affordable
-int64_t psb_cost(const msda::PsbPlan &pl, const Problem &pb)
-{
-    int64_t phases = 0;
-    for (int l = 0; l < pb.L; ++l) {
-        const msda::PsbLevel &v = pl.g.lv[l];
-        if (pl.g.encoder && v.mg >= 0) { phases += (int64_t)v.nty * v.ntx * 4; continue; }   // ~3-4 chunks per tile by geometry
-        phases += (int64_t)v.nty * v.ntx * ((pb.Lq + msda::kPsbQC - 1) / msda::kPsbQC);
-    }
-    return phases;
-}
-
-// returns hipErrorNotSupported when the plan does not apply or no workspace can be had right now
-hipError_t launch_bwd_psb(const Problem &pb, const float *value, const float *loc, const float *aw, const float *grad_out,
-                          float *grad_value, float *grad_loc, float *grad_aw, hipStream_t stream, bool forced)
-{
-    msda::PsbPlan pl = msda::plan_psb(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(), pb.lsi.data());
-    if (!pl.ok) return hipErrorNotSupported;
-    if (!forced && psb_cost(pl, pb) > 1200) return hipErrorNotSupported;
-    if ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_value)) & 15)
-        return hipErrorNotSupported;
-    if (reinterpret_cast<uintptr_t>(grad_loc) & 7) return hipErrorNotSupported;
-    PsbWorkspace ws;
-    if (!psb_workspace(stream, pl.far_cap, ws)) return hipErrorNotSupported;
-    pl.g.ctr = ws.ctr;
-    pl.g.far_list = ws.far;
-    pl.g.stamps = msda::tiled_options().stamps;
-    auto kern = pb.P == 4 ? &msda::psb_kernel<true> : &msda::psb_kernel<false>;
-    hipError_t e = msda::set_lds_limit(reinterpret_cast<const void *>(kern), sizeof(msda::PsbLds));
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(msda::psb_prep_kernel, dim3(128), dim3(256), 0, stream, grad_value, pl.g);
-    const int grid = (cu_count() / msda::kXcds) * msda::kXcds;
-    hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 8), dim3(msda::kPsbThreads), sizeof(msda::PsbLds), stream, value, loc, aw,
-                       grad_out, grad_value, grad_loc, grad_aw, pl.g);
-    if (pl.far_cap)
-        hipLaunchKernelGGL(msda::psb_far_kernel, dim3(512), dim3(256), 0, stream, value, loc, aw, grad_out, grad_value,
-                           grad_loc, grad_aw, pl.g);
-    return hipGetLastError();
-}
-
 // ---- routed pixel-stationary backward (msda_rps.h) ---------------------------------------------------------------------------
 // The bin counters are zero between calls (the scan kernel re-zeroes them after reading them), so that no call has to clear
 // them first: they are cleared when allocated and after a launch error.
-bool rps_workspace(hipStream_t stream, size_t n_bins, size_t n_entries, PsbWorkspace &out)
+bool rps_workspace(hipStream_t stream, size_t n_bins, size_t n_entries, Workspace &out)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
-    std::lock_guard<std::mutex> lock(g_psb_mu);
-    PsbWorkspace &ws = g_psb_ws[std::make_pair(dev, stream)];
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    Workspace &ws = g_ws[std::make_pair(dev, stream)];
     if (ws.rps_bins_n < n_bins || ws.rps_entries_cap < n_entries || ws.rps_dirty) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(stream, &cap);
@@ -524,8 +437,8 @@ void rps_mark_dirty(hipStream_t stream)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
-    std::lock_guard<std::mutex> lock(g_psb_mu);
-    g_psb_ws[std::make_pair(dev, stream)].rps_dirty = true;
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    g_ws[std::make_pair(dev, stream)].rps_dirty = true;
 }
 
 // returns hipErrorNotSupported when the plan does not apply or no workspace can be had right now.
@@ -541,7 +454,7 @@ hipError_t launch_bwd_rps(const Problem &pb, const TV *value, const float *loc, 
         return hipErrorNotSupported;
     if (reinterpret_cast<uintptr_t>(grad_acc) & 15) return hipErrorNotSupported;
     if ((reinterpret_cast<uintptr_t>(grad_loc) | reinterpret_cast<uintptr_t>(loc)) & 7) return hipErrorNotSupported;
-    PsbWorkspace ws;
+    Workspace ws;
     if (!rps_workspace(stream, (size_t)pl.g.nbins, pl.max_entries, ws)) return hipErrorNotSupported;
     pl.g.ctr = ws.rps_bins;
     pl.g.bin_count = ws.rps_bins + 32;   // (line-aligned)
@@ -586,18 +499,6 @@ hipError_t try_bwd_rps<float>(const Problem &pb, const float *value, const float
                               float *grad_value, float *grad_loc, float *grad_aw, hipStream_t stream)
 {
     return launch_bwd_rps<float>(pb, value, loc, aw, grad_out, grad_value, grad_value, grad_loc, grad_aw, stream);
-}
-
-template <typename T>
-hipError_t try_bwd_psb(const Problem &, const T *, const T *, const T *, const T *, T *, T *, T *, hipStream_t, bool)
-{
-    return hipErrorNotSupported;
-}
-template <>
-hipError_t try_bwd_psb<float>(const Problem &pb, const float *value, const float *loc, const float *aw, const float *grad_out,
-                              float *grad_value, float *grad_loc, float *grad_aw, hipStream_t stream, bool forced)
-{
-    return launch_bwd_psb(pb, value, loc, aw, grad_out, grad_value, grad_loc, grad_aw, stream, forced);
 }
 
 template <typename T>
@@ -678,54 +579,17 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
     hipError_t e = hipSuccess;
     auto zero_grad_value = [&]() { return hipMemsetAsync(grad_value, 0, sizeof(T) * (size_t)N * S * M * D, stream); };
 
-    int variant = g_bwd_variant.load();
-    // pixel-stationary backward (msda_psb.h): opt-in (bwd_variant = 3).  Measured on MI355X it does not beat the window kernels
-    // (call E: 505 vs 382 us; call Dd: 126 vs 85 us), so the automatic choice never takes it.
-    if (variant == 3) {
-        ProfileScope prof(1, 3, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
-        e = try_bwd_psb<T>(pb, value, loc, aw, grad_out, grad_value, grad_loc, grad_aw, stream, true);
-        if (e == hipSuccess) return MSDA_OK;
-        prof.cancel();
-        if (e != hipErrorNotSupported) return hip_fail(e, "launch of the pixel-stationary backward kernels");
-        e = hipSuccess;
-    }
-    if (variant == 4) {   // routed pixel-stationary backward (msda_rps.h)
+    // Kernel choice: the routed pixel-stationary kernels (msda_rps.h: no float atomics, no zero-fill, cost independent of where
+    // the points fall) for encoder-shaped fp32 calls at D = 32 (bwd_variant 4 forces them for any Lq, 1 forces the direct path);
+    // everything else -- other D, f64, decoder shapes -- runs the level-sum + direct kernels below.
+    const int variant = g_bwd_variant.load();
+    if (variant == 4 || (variant == 0 && Lq == S)) {
         ProfileScope prof(1, 4, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
         e = try_bwd_rps<T>(pb, value, loc, aw, grad_out, grad_value, grad_loc, grad_aw, stream);
         if (e == hipSuccess) return MSDA_OK;
         prof.cancel();
         if (e != hipErrorNotSupported) return hip_fail(e, "launch of the routed backward kernels");
         e = hipSuccess;
-    }
-    if (variant == 3 || variant == 4) variant = 0;
-    if (variant == 0 && Lq == S) {   // automatic, encoder-shaped: window kernels while the points are local, routed kernels otherwise
-        const int pick = monitor_choose_bwd(monitor_for_current_device(), problem_key(N, S, M, L, P, pb.shapes.data(), loc), stream);
-        if (pick == 4) {
-            ProfileScope prof(1, 4, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
-            e = try_bwd_rps<T>(pb, value, loc, aw, grad_out, grad_value, grad_loc, grad_aw, stream);
-            if (e == hipSuccess) return MSDA_OK;
-            prof.cancel();
-            if (e != hipErrorNotSupported) return hip_fail(e, "launch of the routed backward kernels");
-            e = hipSuccess;
-            variant = 1;   // not applicable here: the direct kernels take spread points better than the windows do
-        } else {
-            variant = 2;
-        }
-    }
-    if (variant != 1 && msda::tiled_bwd_applicable<T>(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(),
-                                                     pb.lsi.data(), value, grad_out, grad_value)) {
-        if (variant == 0) variant = 2;   // (automatic choice for encoder-shaped calls was made above)
-        if (variant == 2) {
-            if ((e = zero_grad_value()) != hipSuccess) return hip_fail(e, "zero-fill of grad_value");
-            {
-                ProfileScope prof(1, 2, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
-                e = msda::launch_bwd_tiled<T>(value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw, pb.N,
-                                              pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(), pb.lsi.data(),
-                                              stream);
-            }
-            if (e != hipSuccess) return hip_fail(e, "launch of the tiled backward kernel");
-            return MSDA_OK;
-        }
     }
 
     // Levels summed in LDS by their own kernel (msda_levelsum.h) are taken away from the atomics below; when that is ALL
@@ -773,8 +637,8 @@ bool bf16_scratch(hipStream_t stream, size_t n_floats, float **out)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
-    std::lock_guard<std::mutex> lock(g_psb_mu);
-    PsbWorkspace &ws = g_psb_ws[std::make_pair(dev, stream)];
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    Workspace &ws = g_ws[std::make_pair(dev, stream)];
     if (ws.gv32_cap < n_floats) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(stream, &cap);
@@ -888,10 +752,8 @@ int backward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const i
     };
 
     int variant = g_bwd_variant.load();
-    if (variant != 1 && variant != 3 && is_aligned(value, 8) && is_aligned(grad_out, 8) && is_aligned(grad_value, 8)) {
-        // automatic: for bf16 storage the routed kernels beat the window kernels at every spread of the sampling points (MI355X,
-        // call E: 369 / 359 / 396 us at the init pattern / sigma 4 px / uniform against 397 / 570 / 2170: the rows they
-        // request per point are half as wide), so encoder-shaped calls take them whatever the locality monitor says
+    if (variant != 1 && is_aligned(value, 8) && is_aligned(grad_out, 8) && is_aligned(grad_value, 8)) {
+        // automatic: encoder-shaped calls take the routed kernels (as in fp32; the rows they request per point are half as wide)
         if (variant == 0) variant = Lq == S ? 4 : 1;
         float *gv32 = nullptr;
         if (variant == 4 && D == msda::kRpsD && bf16_scratch(stream, n_value, &gv32)) {
@@ -904,19 +766,6 @@ int backward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const i
             }
             if (e == hipSuccess) return MSDA_OK;
             if (e != hipErrorNotSupported) return hip_fail(e, "launch of the routed backward kernels (bf16)");
-        }
-        if (variant == 4) variant = 1;
-        if (variant == 2 && msda::plan_bwd_gather(N, S, M, D, L, Lq, P, pb.shapes.data(), pb.lsi.data()).ok &&
-            msda::plan_scatter_sorted(N, S, M, D, L, Lq, P, pb.shapes.data(), pb.lsi.data()).ok && bf16_scratch(stream, n_value, &gv32)) {
-            if ((e = hipMemsetAsync(gv32, 0, sizeof(float) * n_value, stream)) != hipSuccess) return hip_fail(e, "zero-fill of the fp32 scratch");
-            {
-                ProfileScope prof(1, 2, 2, N, S, M, D, L, Lq, P, stream);
-                e = msda::launch_bwd_tiled_tv<msda::bf16_t>(value, loc, aw, grad_out, gv32, grad_loc, grad_aw, N, S, M, D, L, Lq, P,
-                                                           pb.shapes.data(), pb.lsi.data(), stream);
-                if (e == hipSuccess) e = finish_from_scratch(gv32);
-            }
-            if (e == hipSuccess) return MSDA_OK;
-            if (e != hipErrorNotSupported) return hip_fail(e, "launch of the tiled backward kernels (bf16)");
         }
     }
 
@@ -1075,21 +924,15 @@ const char *msda_last_error(void) { return g_err; }
 int msda_set_option(const char *key, int value)
 {
     if (key && !strcmp(key, "fwd_variant") && value >= 0 && value <= 2) { g_fwd_variant = value; return MSDA_OK; }
-    if (key && !strcmp(key, "bwd_variant") && value >= 0 && value <= 4) { g_bwd_variant = value; return MSDA_OK; }
+    if (key && !strcmp(key, "bwd_variant") && (value == 0 || value == 1 || value == 4)) { g_bwd_variant = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_tile") && value >= 4 && value <= 16) { msda::rps_options().tile = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_max_chunks") && value >= 1 && value <= 4096) { msda::rps_options().max_chunks = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_route_wgs") && value >= 1 && value <= 64) { msda::rps_options().route_wgs = value; return MSDA_OK; }
-    if (key && !strcmp(key, "psb_margin") && value >= 0 && value <= 64) { msda::psb_options().margin = value; return MSDA_OK; }
-    if (key && !strcmp(key, "psb_tile") && value >= 4 && value <= 23) { msda::psb_options().tile = value; return MSDA_OK; }
-    if (key && !strcmp(key, "psb_max_chunks") && value >= 1 && value <= 4096) { msda::psb_options().max_chunks = value; return MSDA_OK; }
-    if (key && !strcmp(key, "psb_coarse_px") && value >= 0 && value <= 1000000) { msda::psb_options().coarse_px = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_direct_cpl") && (value == 0 || value == 1 || value == 2 || value == 4)) { g_bwd_cpl = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_region") && value >= 4 && value <= 64) { msda::tiled_options().region_px = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_margin") && value >= 0 && value <= 32) { msda::tiled_options().margin = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_debug") && value >= 0 && value <= 255) { msda::tiled_options().dbg = value; return MSDA_OK; }
-    if (key && !strcmp(key, "tile_accum") && value >= 0 && value <= 2) { msda::tiled_options().accum = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_persist") && value >= 0 && value <= 65536) { msda::tiled_options().persist = value; return MSDA_OK; }
-    if (key && !strcmp(key, "bwd_gather_halves") && (value == 0 || value == 1)) { msda::tiled_options().bwd_halves = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_levelsum") && (value == 0 || value == 1)) { g_levelsum = value; return MSDA_OK; }
     if (key && !strcmp(key, "levelsum_lds_kb") && value >= 8 && value <= 150) { msda::levelsum_lds_kb() = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_grow") && (value == 0 || value == 1)) { msda::tiled_options().grow = value; return MSDA_OK; }
@@ -1115,15 +958,9 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "rps_tile")) { *value = msda::rps_options().tile; return MSDA_OK; }
     if (key && !strcmp(key, "rps_max_chunks")) { *value = msda::rps_options().max_chunks; return MSDA_OK; }
     if (key && !strcmp(key, "rps_route_wgs")) { *value = msda::rps_options().route_wgs; return MSDA_OK; }
-    if (key && !strcmp(key, "psb_margin")) { *value = msda::psb_options().margin; return MSDA_OK; }
-    if (key && !strcmp(key, "psb_tile")) { *value = msda::psb_options().tile; return MSDA_OK; }
-    if (key && !strcmp(key, "psb_max_chunks")) { *value = msda::psb_options().max_chunks; return MSDA_OK; }
-    if (key && !strcmp(key, "psb_coarse_px")) { *value = msda::psb_options().coarse_px; return MSDA_OK; }
     if (key && !strcmp(key, "tile_region")) { *value = msda::tiled_options().region_px; return MSDA_OK; }
     if (key && !strcmp(key, "tile_margin")) { *value = msda::tiled_options().margin; return MSDA_OK; }
-    if (key && !strcmp(key, "tile_accum")) { *value = msda::tiled_options().accum; return MSDA_OK; }
     if (key && !strcmp(key, "tile_persist")) { *value = msda::tiled_options().persist; return MSDA_OK; }
-    if (key && !strcmp(key, "bwd_gather_halves")) { *value = msda::tiled_options().bwd_halves; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_levelsum")) { *value = g_levelsum; return MSDA_OK; }
     if (key && !strcmp(key, "levelsum_lds_kb")) { *value = msda::levelsum_lds_kb(); return MSDA_OK; }
     if (key && !strcmp(key, "tile_grow")) { *value = msda::tiled_options().grow; return MSDA_OK; }

@@ -88,7 +88,8 @@ struct RpsLds {
     unsigned long long stamp_last, stamp_acc[14];
     int offs[kRpsMaxPx + 4];            // histogram, then exclusive prefix
     RpsEnt ent[kRpsChunk];              // sorted points of the chunk, then their corner dots; plane of the final fold
-    RpsRec meta[kRpsChunk];             // the routed records in the same order (for the gradient combine); plane of the final fold
+    RpsRec meta[kRpsChunk];             // the routed records in ARRIVAL order (for the gradient combine); plane of the final fold
+    unsigned short slot[kRpsChunk];     // arrival index -> sorted slot (where the point's four corner dots are found)
     // value rows of the tile + apron, double-buffered: the rows of the NEXT work item are fetched while the last chunk's
     // gradients are written.  The current buffer is the third plane of the final fold.
     float vtile[2][kRpsMaxPx * kRpsD];
@@ -564,7 +565,12 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
             for (int i = tid; i <= npx; i += kRpsThreads) S->offs[i] = 0;
             int pbase[2], pos[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) pos[u] = -1;
+            for (int u = 0; u < 2; ++u) {
+                pos[u] = -1;
+                // the record stays in the order the route pass wrote it: neighbouring lanes hold neighbouring points of a query, and the
+                // gradient stores of stage (5) -- taken in this order -- fall into 16 / 32 contiguous bytes per (query, level)
+                S->meta[u * kRpsThreads + tid] = n_rec[u];
+            }
             __syncthreads();
             RPS_STAMP(1)
 #pragma unroll
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
                     const unsigned qp = n_rec[u].code & ((1u << kRpsQpBits) - 1u);
                     const int q = P4 ? (int)(qp >> 2) : (int)(qp / (unsigned)P);
                     S->ent[e] = RpsEnt{n_rec[u].lh, n_rec[u].lw, n_rec[u].a, (bq0 + q) * g.M + m};
-                    S->meta[e] = n_rec[u];
+                    S->slot[u * kRpsThreads + tid] = (unsigned short)e;
                 }
             __syncthreads();
             RPS_STAMP(4)
@@ -624,6 +630,9 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
                     // the grid lies outside the map or belongs to a point this tile does not form gradients for)
                     const int lr = my_p / gw, lc = my_p - lr * gw;
                     const int r0 = max(lr - 1, 0) * gw, c0 = max(lc - 1, 0);
+#define RPS_ROW(ITEM, ROW) ROW.load(grad_out + (int64_t)(ITEM) * kRpsD, c_lo, c_hi);
+#define RPS_COEF(E) (*reinterpret_cast<const RpsCoef *>(S->ent + (E)))
+                    const int e_last = e1 - 1;
                     rps_v2f v[4][4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -655,9 +664,6 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
                     // software pipeline: while point e is reduced, the grad_out row of point e + 1 is in flight and the row index
                     // of point e + 2 is being read (the chain entry -> row address -> row is what a list walk waits for).  Only the
                     // row index is read ahead; fractions and weight are read when the point is reduced (registers).
-#define RPS_ROW(ITEM, ROW) ROW.load(grad_out + (int64_t)(ITEM) * kRpsD, c_lo, c_hi);
-#define RPS_COEF(E) (*reinterpret_cast<const RpsCoef *>(S->ent + (E)))
-                    const int e_last = e1 - 1;
                     int itA = S->ent[e].item, itB = S->ent[min(e + 1, e_last)].item;
                     RpsRow<TV> gA, gB;
                     RPS_ROW(itA, gA)
@@ -695,14 +701,14 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
                 fetch_rows(nit);   // ... and so do the next item's value rows (their buffer was last read in the previous fold)
             }
 
-            // ---- (5) gradients of the points this tile owns: one lane per record, in list order -------------------------------------
+            // ---- (5) gradients of the points this tile owns: one lane per record, in arrival order ----------------------------------
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int e = u * kRpsThreads + tid;
-                if (e < n_here) {
-                    const RpsRec r = S->meta[e];
+                const int k = u * kRpsThreads + tid;
+                if (k < n_here) {
+                    const RpsRec r = S->meta[k];
                     if (r.code >> 31) {
-                        float4 d = *reinterpret_cast<const float4 *>(S->ent + e);
+                        float4 d = *reinterpret_cast<const float4 *>(S->ent + S->slot[k]);
                         const unsigned in = r.code >> 27;
                         if (!(in & 1u)) d.x = 0.f;
                         if (!(in & 2u)) d.y = 0.f;

@@ -1,25 +1,22 @@
-// msda_tiled.h -- LDS-window MSDeformAttn kernels for gfx950, for encoder-shaped calls
-// (queries = the pixels of the pyramid, Lq == S; D = 32 fp32; L <= 4): the shape that carries
+// msda_tiled.h -- LDS-window MSDeformAttn FORWARD kernel for gfx950, for encoder-shaped calls
+// (queries = the pixels of the pyramid, Lq == S; D = 32 fp32 or bf16 storage; L <= 4): the shape that carries
 // >95 % of the path's bytes (call "E").
 //
 // Why: in an encoder call every query samples around its own position, at every level.  The direct
-// kernels fetch each of the 64 bilinear corners of a (query, head) from L2 (2.9 GB of 128-B row
-// requests per call, L2-rate bound at ~180 us) and add each corner's gradient with a global float
-// atomic (2.9 GB of atomics, chip-rate bound at ~2.3 ms).  Here a workgroup owns ONE image REGION
-// of ONE (image, head) pair:
-//   * its queries are the pixels of every level whose centre falls in the region (~16x16 level-0
-//     pixels -> ~340 queries), so they share their sampling neighbourhoods;
+// kernel fetches each of the 64 bilinear corners of a (query, head) from L2 (2.9 GB of 128-B row
+// requests per call).  Here a workgroup owns ONE image REGION of ONE (image, head) pair:
+//   * its queries are the pixels of every level whose centre falls in the region (~20x19 level-0
+//     pixels), so they share their sampling neighbourhoods;
 //   * per level it stages the window (region footprint +- margin) of the value slice in LDS --
-//     128 B per pixel, filled with whole-row 16-B loads -- and gathers the corners from LDS;
-//   * backward accumulates grad_value into an LDS window with LDS float atomics and flushes each
-//     touched pixel ONCE per region with a 128-B-row global atomic, instead of once per corner.
-// The window is only a cache: every corner is tested against it and corners outside (large learned
-// offsets, samples near the map border) fall back to global loads / global atomics, so results
-// are exact for ARBITRARY sampling locations; only speed depends on locality.
+//     64 B per pixel and channel half, filled with whole-row 16-B loads -- and gathers the corners from LDS.
+// The window is only a cache: every corner is tested against it and points that miss it (large learned
+// offsets) are finished per point from global memory after the item, so results are exact for ARBITRARY
+// sampling locations; only speed depends on locality (msda_api.hip's locality monitor switches to the direct kernel).
 // The query <-> region assignment is pure geometry on the level sizes; it needs the call to be
 // encoder-shaped only to be profitable, never to be correct.
+// (The backward of encoder-shaped calls is msda_rps.h: routed, pixel-stationary, no windows.)
 //
-// Semantics: identical to msda_direct.h (spec: reference ms_deform_im2col_cuda.cuh:33-159, 237-403).
+// Semantics: identical to msda_direct.h (spec: reference ms_deform_im2col_cuda.cuh:33-84, 237-299).
 #pragma once
 
 #include <atomic>
@@ -35,18 +32,10 @@ constexpr int kTL = 4;               // levels supported by the tiled kernels
 constexpr int kTD = 32;              // channels per head
 constexpr int kMaxRegionQueries = 512;
 constexpr int kMaxGrid = 24;         // region rows / columns covered by the host-made geometry tables
-// Gather kernels (forward; backward location / attention gradients): a workgroup works on ONE CHANNEL HALF at a time
-// -- 16 channels = 64 B per window pixel -- so that its LDS stays under half a CU's and two workgroups share a CU: one
-// waits on its window fill (HBM-paced) while the other gathers.
-constexpr int kFwdGC = 16;           // forward: channels per workgroup (a channel half), 4 lanes per query, 512 threads
+// A workgroup works on ONE CHANNEL HALF at a time -- 16 channels = 64 B per window pixel -- so that its LDS stays under half a
+// CU's and two workgroups share a CU: one waits on its window fill (HBM-paced) while the other gathers.
+constexpr int kFwdGC = 16;           // channels per workgroup (a channel half), 4 lanes per query, 512 threads
 constexpr int kFwdLdsBudget = 75 * 1024;   // + header < 80 KiB: two workgroups per CU
-// Backward location / attention gradients need all 32 channels of a sample at once: 8 lanes per query, 1024 threads,
-// one workgroup per CU (two 16-channel passes with a read-modify-write of the per-point results measured slower).
-constexpr int kBwdGC = 32;
-constexpr int kBwdCPL = 8;            // backward gather: channels per lane (4 lanes per query)
-constexpr int kBwdLdsBudget = 152 * 1024;   // region 20 fits its finest-level window in one phase
-// ... alternatively on channel halves like the forward (two workgroups per CU, the first half's per-point results kept
-// in registers): needs one level per work item and P <= 4 (tile option "bwd_gather_halves")   // three phases = three independent workgroups per region (measured faster than two)
 // Lane layout of the gather kernels: GC channels per workgroup pass, CPL channels per lane (4 or 8), so GL = GC/CPL lanes
 // per query; QPG queries per lane group so that one pass over k covers the largest region (kMaxRegionQueries).
 template <int GC, int CPL>
@@ -57,12 +46,6 @@ struct GatherCfg {
     static constexpr int kGroups = kThreads / GL;            // queries in flight per pass over k
     static constexpr int QPG = 512 / kGroups;                // = kMaxRegionQueries / kGroups
 };
-// Scatter kernel (backward grad_value): 16 channels x f64 = 128 B per window pixel, one workgroup per CU.
-constexpr int kTiledThreads = 1024;
-constexpr int kSD = 16;              // channels per scatter workgroup (two workgroups per region: channel halves)
-constexpr int kScatterGroups = kTiledThreads / kSD;   // 16-lane groups, one query each
-constexpr int kLdsBudgetBytes = 152 * 1024;           // windows; the header takes the rest
-constexpr int kScatterBatch = 2;                      // queries per group whose operands are fetched together
 
 struct TiledGeom {
     int N, S, M, Lq, L, P;
@@ -136,11 +119,9 @@ static_assert(sizeof(TileHeader) % 16 == 0, "windows must stay 16-byte aligned b
 struct TiledOptions {
     std::atomic<int> region_px{20};   // finest-level pixels per region side (swept on MI355X: 20 beats 16 by ~15 %; larger does not fit LDS)
     std::atomic<int> margin{6};
-    std::atomic<int> bwd_halves{0};   // backward location/attention gradients: 0 = 32 channels at once (faster as measured), 1 = two 16-channel passes
     std::atomic<int> persist{512};    // 0 = one workgroup per work item; n > 0 = at most n workgroups (n/2 for the 1024-thread kernels)
                                       // walking the items (2 x 256 CUs by default: no per-item launch ramp)
     std::atomic<int> grow{1};         // 1 = windows grow into the LDS their phase leaves unused (per-level margins)
-    std::atomic<int> accum{2};        // grad_value: 0 = f64 LDS atomic window, 1 = integer block-floating-point window, 2 = sorted reduction
     std::atomic<int> dbg{0};
     std::atomic<unsigned long long *> stamps{nullptr};
     std::atomic<unsigned *> stats{nullptr};   // diagnostic override of the locality counter (msda_debug_stats)
@@ -157,7 +138,6 @@ struct TiledPlan {
     TiledGeom g{};
     size_t lds_bytes = 0;
     int grid = 0;
-    int max_px = 0;   // integer-accumulation scatter: largest single-level window
     int max_q = 0;    // most queries in one region
 };
 
@@ -382,9 +362,9 @@ struct LevelCtx {
     int H, W, wr0, wc0, nwr, nwc, lds_base /* float index of the window */, base_row /* element offset of value[b, start, m, 0] */;
 };
 
-// ---- forward, and the location / attention gradients of backward ------------------------------------------
-// 8 lanes x 4 channels per query; lane i of each quad resolves sampling point pc+i and the quad shares it by
-// DPP broadcast.  BWD = false: out.  BWD = true: grad_loc, grad_attn (grad_value is the scatter kernel's job).
+// ---- forward ------------------------------------------------------------------------------------------------
+// 4 lanes x 4 channels per query; lane i of each quad resolves sampling point pc+i and the quad shares it by
+// DPP broadcast.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Sum over the 4 lanes of a query (one quad) with DPP only: no LDS crossbar, no barrier.
@@ -407,15 +387,6 @@ __device__ __forceinline__ void lds_corners(const float *win, int nwc, int j, in
         v[2][n] = *reinterpret_cast<const float4 *>(p + nwc * GC + 4 * n);
         v[3][n] = *reinterpret_cast<const float4 *>(p + nwc * GC + GC + 4 * n);
     }
-}
-
-// Sum over the GL lanes of a query: the quad, plus the neighbouring quad (row_half_mirror) when a query spans 8 lanes.
-template <int GL>
-__device__ __forceinline__ float query_sum(float v)
-{
-    v = quad_sum(v);
-    if (GL == 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
-    return v;
 }
 
 // General point (a corner outside the window): corners from global memory, zero outside the map.
@@ -442,38 +413,6 @@ __device__ __forceinline__ void fwd_accumulate(float w1, float w2, float w3, flo
     acc_hi += w1 * (v2f){v1.z, v1.w} + w2 * (v2f){v2.z, v2.w} + w3 * (v2f){v3.z, v3.w} + w4 * (v2f){v4.z, v4.w};
 }
 
-// Backward location / attention gradients of one point are three channel sums that are all linear in the four
-// "corner dots"  D_k = sum_c grad_out[c] * v_k[c]:
-//   grad_attn = w1*D1 + w2*D2 + w3*D3 + w4*D4,  d/dlw = hh*(D2-D1) + lh*(D4-D3),  d/dlh = hw*(D3-D1) + lw*(D4-D2)
-// so a lane only forms the four dots over its 4 channels (8 packed FMAs); the dots are summed over the query's lanes and
-// combined with the bilinear coefficients afterwards.
-template <int NV>
-__device__ __forceinline__ void corner_dots(const float4 (&gq)[NV], const float4 (&v)[4][NV], float &d1, float &d2, float &d3,
-                                            float &d4)
-{
-    v2f t[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        t[c] = (v2f){gq[0].x, gq[0].y} * (v2f){v[c][0].x, v[c][0].y} + (v2f){gq[0].z, gq[0].w} * (v2f){v[c][0].z, v[c][0].w};
-#pragma unroll
-        for (int n = 1; n < NV; ++n)
-            t[c] += (v2f){gq[n].x, gq[n].y} * (v2f){v[c][n].x, v[c][n].y} + (v2f){gq[n].z, gq[n].w} * (v2f){v[c][n].z, v[c][n].w};
-    }
-    d1 = t[0].x + t[0].y;
-    d2 = t[1].x + t[1].y;
-    d3 = t[2].x + t[2].y;
-    d4 = t[3].x + t[3].y;
-}
-
-__device__ __forceinline__ void combine_dots(float lh, float lw, float d1, float d2, float d3, float d4, float &s_a,
-                                             float &s_w, float &s_h)
-{
-    const float hh = 1.f - lh, hw = 1.f - lw;
-    s_a = hh * hw * d1 + hh * lw * d2 + lh * hw * d3 + lh * lw * d4;
-    s_w = hh * (d2 - d1) + lh * (d4 - d3);
-    s_h = hw * (d3 - d1) + lw * (d4 - d2);
-}
-
 // This lane's sampling point (lane i of the quad holds point i of the level's first four) for each of the quad's
 // queries.  Loaded one level AHEAD of its use, so the global-memory latency hides behind the window fill / the
 // previous level's gather.
@@ -496,42 +435,21 @@ __device__ __forceinline__ void load_level_ops(const float *__restrict__ loc, co
     }
 }
 
-// backward: a per-point result of this channel half; the second half adds to what the first half stored (same lane,
-// same address, program order).
-template <bool ACC>
-__device__ __forceinline__ void store_point_grads(float *__restrict__ grad_loc, float *__restrict__ grad_aw, unsigned pt,
-                                                  float s_a, float gx, float gy)
-{
-    float2 *pl = reinterpret_cast<float2 *>(grad_loc + 2u * pt);
-    if (ACC) {
-        const float2 o = *pl;
-        grad_aw[pt] += s_a;
-        *pl = make_float2(o.x + gx, o.y + gy);
-    } else {
-        grad_aw[pt] = s_a;
-        *pl = make_float2(gx, gy);
-    }
-}
-
 // One sampled level for the kGatherQPG queries of a quad.  P4 = the level has exactly 4 points (RichSem): no
 // point-count checks in the unrolled body.  Hot path = in-window points: one wave-divergent branch per point and
 // straight-line LDS reads + packed FMAs.  Points with a corner outside the window are rare; they are handled
 // afterwards in ONE run-time loop per query (not unrolled), with shuffles instead of DPP.
-// MODE (backward): 0 = all 32 channels in one pass: store the per-point results; 1 = first channel half: keep them in
-// `part` (lane i of the quad keeps point i); 2 = second channel half: add `part` and store.
-template <bool BWD, bool P4, int MODE, int GC, int CPL, typename TV>
+template <bool P4, int GC, int CPL, typename TV>
 __device__ __forceinline__ void gather_level(
     const TV *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ aw, const float *win,
     const LevelCtx &lc, int row_elems, int P_, int j, int chan, const unsigned (&pt0)[GatherCfg<GC, CPL>::QPG],
     const bool (&live)[GatherCfg<GC, CPL>::QPG], const LevelOps<GatherCfg<GC, CPL>::QPG> &pre,
-    v2f (&acc_lo)[GatherCfg<GC, CPL>::QPG], v2f (&acc_hi)[GatherCfg<GC, CPL>::QPG],
-    const float4 (&gq)[GatherCfg<GC, CPL>::QPG][GatherCfg<GC, CPL>::NV], float (&part)[GatherCfg<GC, CPL>::QPG][3],
-    float *__restrict__ grad_loc, float *__restrict__ grad_aw, unsigned &n_general, const int lvl,
+    v2f (&acc_lo)[GatherCfg<GC, CPL>::QPG], v2f (&acc_hi)[GatherCfg<GC, CPL>::QPG], unsigned &n_general, const int lvl,
     unsigned (&miss)[GatherCfg<GC, CPL>::QPG])
 {
-    constexpr bool defer = !BWD && P4 && GatherCfg<GC, CPL>::GL == 4;
-    constexpr int kGatherQPG = GatherCfg<GC, CPL>::QPG, NV = GatherCfg<GC, CPL>::NV, GL = GatherCfg<GC, CPL>::GL;
-    static_assert(BWD || NV == 1, "the forward keeps its accumulators for four channels per lane");
+    constexpr bool defer = P4 && GatherCfg<GC, CPL>::GL == 4;
+    constexpr int kGatherQPG = GatherCfg<GC, CPL>::QPG, NV = GatherCfg<GC, CPL>::NV;
+    static_assert(NV == 1, "the accumulators hold four channels per lane");
     const int P = P4 ? 4 : P_;
     for (int pc = 0; pc < P; pc += 4) {
         const int myp = pc + (j & 3);
@@ -565,40 +483,17 @@ __device__ __forceinline__ void gather_level(
             // per wave iteration
             if (defer && mode == -2) miss[k] |= 1u << (lvl * 4 + (j & 3));
             const float hh = 1.f - lh, hw = 1.f - lw;
-            // forward broadcasts finished weights; backward needs lh, lw and the attention weight separately
             const float w1 = hh * hw * a, w2 = hh * lw * a, w3 = lh * hw * a, w4 = lh * lw * a;
             bool any_slow = false;
-            float ps_a = 0.f, ps_x = 0.f, ps_y = 0.f;   // backward: this lane's point (lane i <-> point pc + i)
 #define MSDA_POINT(I)                                                                                                 \
     if (P4 || pc + I < P) {                                                                                            \
         const int m_ = quad_bcast_i<I>(mode);                                                                          \
         any_slow |= m_ == -2;                                                                                          \
-        if (!BWD) {                                                                                                    \
-            if (m_ >= 0) {                                                                                             \
-                float4 v[4][NV];                                                                                       \
-                lds_corners<GC, NV>(win, lc.nwc, j, m_, v);                                                            \
-                fwd_accumulate(quad_bcast_f<I>(w1), quad_bcast_f<I>(w2), quad_bcast_f<I>(w3), quad_bcast_f<I>(w4),     \
-                               v[0][0], v[1][0], v[2][0], v[3][0], acc_lo[k], acc_hi[k]);                              \
-            }                                                                                                          \
-        } else {                                                                                                       \
-            float d1 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f, s_a, s_w, s_h;                                               \
-            if (m_ >= 0) {                                                                                             \
-                float4 v[4][NV];                                                                                       \
-                lds_corners<GC, NV>(win, lc.nwc, j, m_, v);                                                            \
-                corner_dots<NV>(gq[k], v, d1, d2, d3, d4);                                                             \
-            }                                                                                                          \
-            d1 = query_sum<GL>(d1);                                                                                    \
-            d2 = query_sum<GL>(d2);                                                                                    \
-            d3 = query_sum<GL>(d3);                                                                                    \
-            d4 = query_sum<GL>(d4);                                                                                    \
-            combine_dots(quad_bcast_f<I>(lh), quad_bcast_f<I>(lw), d1, d2, d3, d4, s_a, s_w, s_h);                     \
-            /* lane I of the quad keeps point I (dropped / general points: zeros here, general ones redone below); */  \
-            /* the four points are stored together after the loop: one 16-B and one 32-B segment per query */          \
-            if (j == I) {                                                                                              \
-                ps_a = s_a;                                                                                            \
-                ps_x = (float)lc.W * s_w * a;                                                                          \
-                ps_y = (float)lc.H * s_h * a;                                                                          \
-            }                                                                                                          \
+        if (m_ >= 0) {                                                                                                 \
+            float4 v[4][NV];                                                                                           \
+            lds_corners<GC, NV>(win, lc.nwc, j, m_, v);                                                                \
+            fwd_accumulate(quad_bcast_f<I>(w1), quad_bcast_f<I>(w2), quad_bcast_f<I>(w3), quad_bcast_f<I>(w4),         \
+                           v[0][0], v[1][0], v[2][0], v[3][0], acc_lo[k], acc_hi[k]);                                  \
         }                                                                                                              \
     }
             MSDA_POINT(0)
@@ -606,16 +501,6 @@ __device__ __forceinline__ void gather_level(
             MSDA_POINT(2)
             MSDA_POINT(3)
 #undef MSDA_POINT
-            if (BWD && j < 4 && (P4 || pc + j < P)) {
-                if (MODE == 1) {
-                    part[k][0] = ps_a;
-                    part[k][1] = ps_x;
-                    part[k][2] = ps_y;
-                } else {
-                    store_point_grads<false>(grad_loc, grad_aw, pt0[k] + pc + j, ps_a + (MODE == 2 ? part[k][0] : 0.f),
-                                             ps_x + (MODE == 2 ? part[k][1] : 0.f), ps_y + (MODE == 2 ? part[k][2] : 0.f));
-                }
-            }
             if (!defer && any_slow) {   // uniform over the quad; rare
                 // A wave steps through this body whenever ONE of its lanes holds a general point, so the body is kept short:
                 // the owner lane resolves its point once, the quad receives corner offsets and coefficients by DPP
@@ -632,37 +517,10 @@ __device__ __forceinline__ void gather_level(
         const int o0 = quad_bcast_i<I>(o[0]), o1 = quad_bcast_i<I>(o[1]), o2 = quad_bcast_i<I>(o[2]),                  \
                   o3 = quad_bcast_i<I>(o[3]);                                                                          \
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
-        float4 v[4][NV];                                                                                               \
-        _Pragma("unroll") for (int n = 0; n < NV; ++n)                                                                 \
-        {                                                                                                              \
-            v[0][n] = o0 >= 0 ? ld4(value + o0 + chan + 4 * n) : z;                                                    \
-            v[1][n] = o1 >= 0 ? ld4(value + o1 + chan + 4 * n) : z;                                                    \
-            v[2][n] = o2 >= 0 ? ld4(value + o2 + chan + 4 * n) : z;                                                    \
-            v[3][n] = o3 >= 0 ? ld4(value + o3 + chan + 4 * n) : z;                                                    \
-        }                                                                                                              \
-        if (!BWD) {                                                                                                    \
-            fwd_accumulate(quad_bcast_f<I>(w1), quad_bcast_f<I>(w2), quad_bcast_f<I>(w3), quad_bcast_f<I>(w4), v[0][0], \
-                           v[1][0], v[2][0], v[3][0], acc_lo[k], acc_hi[k]);                                           \
-        } else {                                                                                                       \
-            float d1, d2, d3, d4, s_a, s_w, s_h;                                                                       \
-            corner_dots<NV>(gq[k], v, d1, d2, d3, d4);                                                                 \
-            d1 = query_sum<GL>(d1);                                                                                    \
-            d2 = query_sum<GL>(d2);                                                                                    \
-            d3 = query_sum<GL>(d3);                                                                                    \
-            d4 = query_sum<GL>(d4);                                                                                    \
-            combine_dots(quad_bcast_f<I>(lh), quad_bcast_f<I>(lw), d1, d2, d3, d4, s_a, s_w, s_h);                     \
-            /* the fast pass gave this point zeros: add ours on top (first half: in `part`, else in memory) */         \
-            if (j == I) {                                                                                              \
-                const float gx_ = (float)lc.W * s_w * a, gy_ = (float)lc.H * s_h * a;                                  \
-                if (MODE == 1) {                                                                                       \
-                    part[k][0] += s_a;                                                                                 \
-                    part[k][1] += gx_;                                                                                 \
-                    part[k][2] += gy_;                                                                                 \
-                } else {                                                                                               \
-                    store_point_grads<true>(grad_loc, grad_aw, pt0[k] + pc + I, s_a, gx_, gy_);                        \
-                }                                                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
+        const float4 v0_ = o0 >= 0 ? ld4(value + o0 + chan) : z, v1_ = o1 >= 0 ? ld4(value + o1 + chan) : z;           \
+        const float4 v2_ = o2 >= 0 ? ld4(value + o2 + chan) : z, v3_ = o3 >= 0 ? ld4(value + o3 + chan) : z;           \
+        fwd_accumulate(quad_bcast_f<I>(w1), quad_bcast_f<I>(w2), quad_bcast_f<I>(w3), quad_bcast_f<I>(w4), v0_, v1_,   \
+                       v2_, v3_, acc_lo[k], acc_hi[k]);                                                                \
     }
                 MSDA_SLOW(0)
                 MSDA_SLOW(1)
@@ -674,16 +532,13 @@ __device__ __forceinline__ void gather_level(
     }
 }
 
-// Forward (BWD = false): workgroup = (image, head, region, channel half); accumulates over the LDS phases in registers.
-// Backward (BWD = true): workgroup = (image, head, region, LDS phase); runs the two channel halves one after the other
-// (the per-point gradients are sums over all 32 channels).
-// TV = storage type of value / grad_out / out (float, or bf16_t: converted at the loads / the store; the LDS windows and
-// all arithmetic are fp32 either way)
-template <bool BWD, bool P4, int GC, int CPL, typename TV = float>
+// Workgroup = (image, head, region, channel half); accumulates over the LDS phases in registers.
+// TV = storage type of value / out (float, or bf16_t: converted at the loads / the store; the LDS windows and all arithmetic
+// are fp32 either way)
+template <bool P4, int GC, int CPL, typename TV = float>
 __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled_gather_kernel(
-    const TV *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ aw,
-    const TV *__restrict__ grad_out, TV *__restrict__ out, float *__restrict__ grad_loc,
-    float *__restrict__ grad_aw, const TiledGeom g)
+    const TV *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ aw, TV *__restrict__ out,
+    const TiledGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TileHeader *hdr = reinterpret_cast<TileHeader *>(smem);
@@ -702,7 +557,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
     // call and 10 (the whole finest-level window in one batch) ~8 us -- deeper batches only queue up behind the L2
     constexpr int kFillBatch = 4;
     constexpr int kHalves = kTD / GC;                        // channel passes per region
-    const int nsub = BWD ? g.nphases : kHalves;
+    constexpr int nsub = kHalves;
     // Persistent form: the grid may be smaller than the number of work items; a workgroup then walks the items
     // vb = blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8, so vb keeps the workgroup's XCD).
     const int n_items = kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.GY * g.GX * nsub;
@@ -734,28 +589,16 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
         acc_lo[k] = acc_hi[k] = (v2f){0.f, 0.f};
     }
 
-    // backward on channel halves keeps the first half's per-point results here; it then needs one level per work item and
-    // at most four points per level (host-enforced)
-    float part[kGatherQPG][3];
-    unsigned miss[kGatherQPG];   // forward: bit (level*4 + point) = that point of query k missed its window (this lane's point only)
+    unsigned miss[kGatherQPG];   // bit (level*4 + point) = that point of query k missed its window (this lane's point only)
 #pragma unroll
-    for (int k = 0; k < kGatherQPG; ++k) {
-        part[k][0] = part[k][1] = part[k][2] = 0.f;
-        miss[k] = 0u;
-    }
-    constexpr bool defer = !BWD && P4 && GL == 4;   // (compile-time: the in-loop general path is not even compiled into this kernel)
-    const int ph_begin = BWD ? sub : 0, ph_end = BWD ? ph_begin + 1 : g.nphases;
-    const int half_begin = BWD ? 0 : sub, half_end = BWD ? kHalves : sub + 1;
+    for (int k = 0; k < kGatherQPG; ++k) miss[k] = 0u;
+    constexpr bool defer = P4 && GL == 4;   // (compile-time: the in-loop general path is not even compiled into this kernel)
+    const int ph_end = g.nphases;
     int st = 2;
-    for (int half = half_begin; half < half_end; ++half) {
+    {
+        const int half = sub;
         const int chan = half * GC + CPL * j;   // this lane's first channel inside the head
-        float4 gq[kGatherQPG][NV];               // backward: grad_out of the group's queries, this lane's channels
-#pragma unroll
-        for (int k = 0; k < kGatherQPG; ++k)
-#pragma unroll
-            for (int n = 0; n < NV; ++n)
-                gq[k][n] = BWD ? ld4(grad_out + item[k] * (unsigned)kTD + chan + 4 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int ph = ph_begin; ph < ph_end; ++ph) {
+        for (int ph = 0; ph < ph_end; ++ph) {
             // levels of this phase are consecutive: [lb, le)
             int lb = g.L, le = 0;
             for (int l = 0; l < g.L; ++l)
@@ -807,24 +650,17 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                 unsigned pt0[kGatherQPG];
 #pragma unroll
                 for (int k = 0; k < kGatherQPG; ++k) pt0[k] = item[k] * (unsigned)LP + (unsigned)(l * g.P);
-                if (!BWD || kHalves == 1)
-                    gather_level<BWD, P4, 0, GC, CPL, TV>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw, n_general, l, miss);
-                else if (half == 0)
-                    gather_level<BWD, P4, 1, GC, CPL, TV>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw, n_general, l, miss);
-                else
-                    gather_level<BWD, P4, 2, GC, CPL, TV>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo,
-                                                 acc_hi, gq, part, grad_loc, grad_aw, n_general, l, miss);
+                gather_level<P4, GC, CPL, TV>(value, loc, aw, win, lc, row_elems, g.P, j, chan, pt0, live, cur, acc_lo, acc_hi, n_general, l,
+                                              miss);
             }
-            // the next fill overwrites the windows (forward, last phase: the barrier below, which also tells whether any point
-            // of the workgroup missed its window, takes this one's place)
-            if (BWD || !defer || ph + 1 < ph_end || half + 1 < half_end) __syncthreads();
+            // the next fill overwrites the windows (last phase: the barrier below, which also tells whether any point of the
+            // workgroup missed its window, takes this one's place)
+            if (!defer || ph + 1 < ph_end) __syncthreads();
             stamp<2>(g, st++);
         }
     }
 
-    if (!BWD && defer) {
+    if (defer) {
         // ---- points that missed their window: collected per query, then done by 4-lane groups (4 channels per lane of this
         //      channel half) straight from global memory -- every lane works on a missed point, nobody idles beside one.  The
         //      partial rows come back through LDS (the windows are free now) and the owners add them before they store. -------
@@ -885,7 +721,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
         }
     }
     stamp<2>(g, st++);
-    if (!BWD) {
+    {
         const int chan = sub * GC + 4 * j;
 #pragma unroll
         for (int k = 0; k < kGatherQPG; ++k)
@@ -901,652 +737,6 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
     }
 }
 
-// ---- backward: grad_value ---------------------------------------------------------------------------------
-// gfx950 facts this kernel is built on (measured, tools/lds_atomic_bench.hip): the LDS float atomic ds_add_f32 is
-// serialised (120-190 CU cycles per wave-instruction) while ds_add_f64 is native (about 5), and global float atomics
-// run at ~1.3 TB/s only as whole row segments.  So the window accumulates in f64 (which also makes the in-window sum
-// exact to f32 precision whatever the order), a workgroup takes one CHANNEL HALF of a region (16 channels x 8 B =
-// 128 B per pixel, the same LDS geometry as the gather kernels) and every touched pixel is flushed once.
-// 16 lanes per query (4 quads): lane i of every quad resolves sampling point i of the current level and the quad shares
-// it by DPP broadcast; each lane owns one channel of the half.  Persistent workgroups walk (region, channel half, phase).
-__global__ __launch_bounds__(kTiledThreads) void tiled_scatter_kernel(
-    const float *__restrict__ loc, const float *__restrict__ aw, const float *__restrict__ grad_out,
-    float *__restrict__ grad_value, const TiledGeom g)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    TileHeader *hdr = reinterpret_cast<TileHeader *>(smem);
-    double *win = reinterpret_cast<double *>(smem + sizeof(TileHeader));
-
-    // (channel half, phase) of a region = the fastest-varying part of the XCD-local index: the workgroups of one
-    // region run back to back on one XCD and share loc / attn / grad_out in its L2
-    const int nsub = (kTD / kSD) * g.nphases;
-    const int n_items = kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.GY * g.GX * nsub;
-    for (int vb = blockIdx.x; vb < n_items; vb += gridDim.x) {   // persistent form, see tiled_gather_kernel
-    int pair, rs;
-    if (!decode_block(vb, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) continue;
-    const int region = rs / nsub, sub = rs - region * nsub;
-    const int half = sub % (kTD / kSD);
-    const int b = pair / g.M, m = pair - b * g.M;
-    const int gy = region / g.GX, gx = region - gy * g.GX;
-    stamp<1>(g, 0);
-    const int nq = build_header(hdr, g, gy, gx);
-    stamp<1>(g, 1);
-
-    const int tid = threadIdx.x;
-    const int j = tid & (kSD - 1), grp = tid / kSD;
-    const int row_elems = g.M * kTD;
-    const int LP = g.L * g.P;
-    const int ch0 = m * kTD + half * kSD;   // first channel of this workgroup inside a pixel row
-    {
-        const int ph = sub / (kTD / kSD);   // one LDS phase per workgroup: the phases of a region are independent here
-        // ---- clear this phase's accumulation windows ---------------------------------------------------------
-        int phase_px = 0;
-        for (int l = 0; l < g.L; ++l)
-            if (uni(hdr->phase[l]) == ph) phase_px = uni(hdr->lds_px[l]) + uni(hdr->r[l].nwr) * uni(hdr->r[l].nwc);
-        for (int i = tid; i < phase_px * (kSD / 2); i += kTiledThreads)
-            reinterpret_cast<double2 *>(win)[i] = make_double2(0.0, 0.0);
-        __syncthreads();
-        stamp<1>(g, 2);
-
-        // ---- accumulate: a query = 16 lanes (4 quads); lane i of every quad resolves point i of the current level and the
-        //      quad shares it by DPP broadcast (no LDS records); kScatterBatch queries per group are fetched together ---------
-        for (int i0 = grp; i0 < nq; i0 += kScatterBatch * kScatterGroups) {
-            unsigned items[kScatterBatch];
-            float gks[kScatterBatch];
-#pragma unroll
-            for (int u = 0; u < kScatterBatch; ++u) {
-                const int i = i0 + u * kScatterGroups;
-                items[u] = (unsigned)((b * g.Lq + hdr->qid[i < nq ? i : i0]) * g.M + m);   // clamped; masked below
-                gks[u] = grad_out[items[u] * (unsigned)kTD + half * kSD + j];
-            }
-            for (int l = 0; l < g.L; ++l) {
-                if (uni(hdr->phase[l]) != ph) continue;
-                const int H = uni(hdr->H[l]), W = uni(hdr->W[l]);
-                const int wr0 = uni(hdr->r[l].wr0), wc0 = uni(hdr->r[l].wc0), nwr = uni(hdr->r[l].nwr), nwc = uni(hdr->r[l].nwc);
-                const int ldsl = uni(hdr->lds_px[l]);
-                const int base_l = (b * g.S + uni(hdr->start[l])) * row_elems + ch0;
-                const int row2 = nwc * kSD;   // f64 elements between vertically adjacent window pixels
-                for (int pc = 0; pc < g.P; pc += 4) {
-                    const int myp = pc + (j & 3);
-                    const bool pv = myp < g.P;
-                    float2 xys[kScatterBatch];
-                    float as[kScatterBatch];
-#pragma unroll
-                    for (int u = 0; u < kScatterBatch; ++u) {
-                        const unsigned pt = items[u] * (unsigned)LP + (unsigned)(l * g.P + (pv ? myp : 0));
-                        xys[u] = *reinterpret_cast<const float2 *>(loc + 2u * pt);
-                        as[u] = aw[pt];
-                    }
-#pragma unroll
-                    for (int u = 0; u < kScatterBatch; ++u) {
-                        if (i0 + u * kScatterGroups >= nq) break;   // uniform over the 16-lane group
-                        const float gk = gks[u];
-                        // resolve this lane's point: base >= 0: LDS f64 index of corner (h_low, w_low), all four corners in the
-                        // window (apron included); -1: nothing; -2: general point with per-corner targets t[]
-                        int base = -1, t0 = -1, t1 = -1, t2 = -1, t3 = -1;
-                        float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
-                        const float h_im = xys[u].y * (float)H - 0.5f, w_im = xys[u].x * (float)W - 0.5f;
-                        if (pv && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-                            const float hf = floorf(h_im), wf = floorf(w_im);
-                            const int h_low = (int)hf, w_low = (int)wf;
-                            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-                            w0 = hh * hw * as[u];
-                            w1 = hh * lw * as[u];
-                            w2 = lh * hw * as[u];
-                            w3 = lh * lw * as[u];
-                            const int rr = h_low - wr0, cc = w_low - wc0;
-                            const bool r0 = rr >= 0 && rr < nwr, r1 = rr + 1 >= 0 && rr + 1 < nwr;
-                            const bool c0 = cc >= 0 && cc < nwc, c1 = cc + 1 >= 0 && cc + 1 < nwc;
-                            const int lbase = (ldsl + rr * nwc + cc) * kSD;
-                            if (r0 && r1 && c0 && c1) {
-                                base = lbase;
-                            } else {
-                                base = -2;
-                                const bool top = h_low >= 0, bot = h_low + 1 <= H - 1, lef = w_low >= 0, rig = w_low + 1 <= W - 1;
-                                const int gbase = base_l + (h_low * W + w_low) * row_elems;
-                                if (top && lef) t0 = (r0 && c0) ? lbase : -gbase - 2;
-                                if (top && rig) t1 = (r0 && c1) ? lbase + kSD : -(gbase + row_elems) - 2;
-                                if (bot && lef) t2 = (r1 && c0) ? lbase + row2 : -(gbase + W * row_elems) - 2;
-                                if (bot && rig) t3 = (r1 && c1) ? lbase + row2 + kSD : -(gbase + W * row_elems + row_elems) - 2;
-                            }
-                        }
-#define MSDA_SC_ONE(I)                                                                                                 \
-    if (pc + I < g.P) {                                                                                                 \
-        const int base_ = quad_bcast_i<I>(base);                                                                        \
-        const float v0 = quad_bcast_f<I>(w0) * gk, v1 = quad_bcast_f<I>(w1) * gk;                                       \
-        const float v2 = quad_bcast_f<I>(w2) * gk, v3 = quad_bcast_f<I>(w3) * gk;                                       \
-        if (base_ >= 0) {                                                                                               \
-            double *p0 = win + base_ + j, *p1 = p0 + row2;                                                              \
-            atomicAdd(p0, (double)v0);                                                                                  \
-            atomicAdd(p0 + kSD, (double)v1);                                                                            \
-            atomicAdd(p1, (double)v2);                                                                                  \
-            atomicAdd(p1 + kSD, (double)v3);                                                                            \
-        } else if (base_ == -2) {                                                                                       \
-            const int tt[4] = {quad_bcast_i<I>(t0), quad_bcast_i<I>(t1), quad_bcast_i<I>(t2), quad_bcast_i<I>(t3)};     \
-            const float vv[4] = {v0, v1, v2, v3};                                                                       \
-            _Pragma("unroll") for (int cn = 0; cn < 4; ++cn)                                                            \
-            {                                                                                                           \
-                if (tt[cn] >= 0)                                                                                        \
-                    atomicAdd(win + tt[cn] + j, (double)vv[cn]);                                                        \
-                else if (tt[cn] < -1)                                                                                   \
-                    atomicAdd(grad_value + (-(tt[cn] + 2)) + j, vv[cn]);                                                \
-            }                                                                                                           \
-        }                                                                                                               \
-    }
-                        MSDA_SC_ONE(0)
-                        MSDA_SC_ONE(1)
-                        MSDA_SC_ONE(2)
-                        MSDA_SC_ONE(3)
-#undef MSDA_SC_ONE
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        stamp<1>(g, 3);
-
-        // ---- flush: every touched pixel once, 64-B row segments of global float atomics --------------------------------
-        for (int l = 0; l < g.L; ++l) {
-            if (uni(hdr->phase[l]) != ph) continue;
-            const int fr0 = uni(hdr->r[l].wr0), fc0 = uni(hdr->r[l].wc0), fnc = uni(hdr->r[l].nwc);
-            const int npx = uni(hdr->r[l].nwr) * fnc, Wl = uni(hdr->W[l]);
-            float *dst = grad_value + (int64_t)(b * g.S + uni(hdr->start[l])) * row_elems + ch0 + j;
-            const double *src = win + (int64_t)uni(hdr->lds_px[l]) * kSD + j;
-            const int Hl = uni(hdr->H[l]);
-            for (int px = grp; px < npx; px += kScatterGroups) {
-                const float v = (float)src[px * kSD];
-                const int rr = px / fnc, cc = px - rr * fnc;
-                const int row = fr0 + rr, col = fc0 + cc;
-                if (v != 0.f && row >= 0 && row < Hl && col >= 0 && col < Wl)
-                    atomicAdd(dst + (int64_t)(row * Wl + col) * row_elems, v);
-            }
-        }
-        __syncthreads();
-        stamp<1>(g, 4);
-    }
-    }
-}
-
-// ---- backward: grad_value, integer accumulation ("block floating point per pixel") --------------------------------------
-// ds_add_u32 costs ~2.6 CU cycles per wave instruction against ~13 for ds_add_f64 under this kernel's bank conflicts, and a
-// 32-bit accumulator holds all 32 channels of a pixel in 128 B, so one workgroup serves a whole (region, level).  To make
-// integer accumulation safe for any input, every window pixel gets ITS OWN scale:
-//   pass 0  gmax[q] = max_c |grad_out[q, c]| for the region's queries
-//   pass 1  one thread per (query, point): resolve the point once, park it as a record in LDS, and per in-window corner
-//           update cnt[pixel] += 1 and maxc[pixel] = max(maxc, |bilinear * attn| * gmax[q]) with integer LDS atomics
-//           (non-negative floats order like their bit patterns)
-//   scale   2^30 / (cnt * maxc): the quantised contributions of a pixel can never overflow 32 bits; the records'
-//           weights are multiplied by their destination pixel's scale
-//   pass 2  replay: acc[pixel][channel] += round(weight * grad_out[q, channel])   (ds_add_u32, one channel per lane)
-//   flush   acc / scale, one 128-B row global float atomic per touched in-map pixel
-// Error per pixel-channel <= cnt^2 * maxc / 2^31 in the worst case, ~sqrt(cnt) * cnt * maxc * 2^-32 typically: for 64
-// contributions 2e-6 / 1e-7 of the pixel's largest contribution -- float32-class -- and the in-window sum is bitwise
-// reproducible (integer sums do not depend on order).  Points with a corner outside the window use global float atomics.
-constexpr int kBfpGroups = kTiledThreads / kTD;          // 32-lane groups, one query each
-constexpr int kBfpPxBytes = kTD * 4 + 8;                 // int32 x 32 channels + {maxc | scale, cnt | 1/scale}
-constexpr int kBfpBatch = 4;                             // queries per group whose grad_out rows are fetched together
-
-struct alignas(4) BfpRec {   // one sampling point of one of the region's queries, resolved in pass 1
-    int base;     // >= 0: window pixel of corner (h_low, w_low), all four corners inside the window (incl. apron);
-                  //   -1: nothing to do;  -2: general point, resolved again (per corner) when replayed
-    float w[4];   // bilinear weight x attention weight (x destination pixel scale after the scale step)
-};
-
-// Per-corner targets of a general point: window pixel (>= 0), -(global element offset) - 2, or -1.
-__device__ __forceinline__ void bfp_general_targets(float x, float y, int H, int W, int wr0, int wc0, int nwr, int nwc,
-                                                    int lds_px, int base_row, int row_elems, int t[4])
-{
-    t[0] = t[1] = t[2] = t[3] = -1;
-    const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
-    if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) return;
-    const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-    const int rr = h_low - wr0, cc = w_low - wc0;
-    const bool r0 = rr >= 0 && rr < nwr, r1 = rr + 1 >= 0 && rr + 1 < nwr;
-    const bool c0 = cc >= 0 && cc < nwc, c1 = cc + 1 >= 0 && cc + 1 < nwc;
-    const bool top = h_low >= 0, bot = h_low + 1 <= H - 1, lef = w_low >= 0, rig = w_low + 1 <= W - 1;
-    const int lbase = lds_px + rr * nwc + cc;
-    const int gbase = base_row + (h_low * W + w_low) * row_elems;
-    if (top && lef) t[0] = (r0 && c0) ? lbase : -gbase - 2;
-    if (top && rig) t[1] = (r0 && c1) ? lbase + 1 : -(gbase + row_elems) - 2;
-    if (bot && lef) t[2] = (r1 && c0) ? lbase + nwc : -(gbase + W * row_elems) - 2;
-    if (bot && rig) t[3] = (r1 && c1) ? lbase + nwc + 1 : -(gbase + W * row_elems + row_elems) - 2;
-}
-
-template <bool P4>
-__global__ __launch_bounds__(kTiledThreads) void tiled_scatter_bfp_kernel(
-    const float *__restrict__ loc, const float *__restrict__ aw, const float *__restrict__ grad_out,
-    float *__restrict__ grad_value, const TiledGeom g, const int max_phase_px)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    TileHeader *hdr = reinterpret_cast<TileHeader *>(smem);
-    int *acc = reinterpret_cast<int *>(smem + sizeof(TileHeader));                       // [px][32]
-    unsigned *maxc = reinterpret_cast<unsigned *>(acc + (size_t)max_phase_px * kTD);     // pass 1: max bits; then scale
-    unsigned *cnt = maxc + max_phase_px;                                                  // pass 1: count; then 1/scale
-    BfpRec *recs = reinterpret_cast<BfpRec *>(cnt + max_phase_px);                        // [query][point]
-
-    const int tid = threadIdx.x;
-    const int j = tid & (kTD - 1), grp = tid / kTD;
-    const int row_elems = g.M * kTD;
-    const int LP = g.L * g.P;
-    const int nsub = g.nphases;   // one level per phase
-    const int n_items = kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.GY * g.GX * nsub;
-    for (int vb = blockIdx.x; vb < n_items; vb += gridDim.x) {   // persistent form, see tiled_gather_kernel
-        int pair, rs;
-        if (!decode_block(vb, g.N * g.M, g.GY * g.GX * nsub, pair, rs)) continue;
-        const int region = rs / nsub, lv = rs - region * nsub;   // lv: the level this item scatters into
-        const int b = pair / g.M, m = pair - b * g.M;
-        const int gy = region / g.GX, gx = region - gy * g.GX;
-        stamp<1>(g, 0);
-        const int nq = build_header(hdr, g, gy, gx);
-        stamp<1>(g, 1);
-
-        const int H = uni(hdr->H[lv]), W = uni(hdr->W[lv]), nwc = uni(hdr->r[lv].nwc), nwr = uni(hdr->r[lv].nwr);
-        const int wr0 = uni(hdr->r[lv].wr0), wc0 = uni(hdr->r[lv].wc0);
-        const int npx = nwr * nwc;   // the window starts at LDS pixel 0 (one level per phase)
-        const int base_row = (b * g.S + uni(hdr->start[lv])) * row_elems + m * kTD;
-
-        for (int i = tid; i < npx * (kTD / 4); i += kTiledThreads) reinterpret_cast<int4 *>(acc)[i] = make_int4(0, 0, 0, 0);
-        for (int i = tid; i < npx; i += kTiledThreads) { maxc[i] = 0u; cnt[i] = 0u; }
-
-        // ---- pass 0: gmax[q]; 8 lanes x 4 channels per query, 128 queries per sweep -----------------------------------
-        for (int i = tid >> 3; i < nq; i += kTiledThreads / 8) {
-            const unsigned item = (unsigned)((b * g.Lq + hdr->qid[i]) * g.M + m);
-            const float4 v = *reinterpret_cast<const float4 *>(grad_out + item * (unsigned)kTD + 4u * (tid & 7));
-            float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-            mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xF, 0xF, true)));
-            mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x4E, 0xF, 0xF, true)));
-            mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x141, 0xF, 0xF, true)));
-            if ((tid & 7) == 0) hdr->gmax[i] = mx;
-        }
-        __syncthreads();
-        stamp<1>(g, 2);
-
-        // ---- pass 1: one thread per (query, point): record + per-pixel count / largest possible contribution ---------------------
-        for (int idx = tid; idx < nq * g.P; idx += kTiledThreads) {
-            const int qi = idx / g.P, pp = idx - qi * g.P;
-            const unsigned item = (unsigned)((b * g.Lq + hdr->qid[qi]) * g.M + m);
-            const unsigned pt = item * (unsigned)LP + (unsigned)(lv * g.P + pp);
-            const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
-            const float a = aw[pt];
-            BfpRec r;
-            r.base = -1;
-            r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0.f;
-            const float h_im = xy.y * (float)H - 0.5f, w_im = xy.x * (float)W - 0.5f;
-            if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-                const float hf = floorf(h_im), wf = floorf(w_im);
-                const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-                r.w[0] = hh * hw * a;
-                r.w[1] = hh * lw * a;
-                r.w[2] = lh * hw * a;
-                r.w[3] = lh * lw * a;
-                const int rr = (int)hf - wr0, cc = (int)wf - wc0;
-                const bool inside = rr >= 0 && rr + 1 < nwr && cc >= 0 && cc + 1 < nwc;
-                r.base = inside ? rr * nwc + cc : -2;
-                const float gm = hdr->gmax[qi];
-                int t[4];
-                if (inside) {
-                    t[0] = r.base; t[1] = r.base + 1; t[2] = r.base + nwc; t[3] = r.base + nwc + 1;
-                } else {
-                    bfp_general_targets(xy.x, xy.y, H, W, wr0, wc0, nwr, nwc, 0, 0, row_elems, t);
-                }
-#pragma unroll
-                for (int cn = 0; cn < 4; ++cn)
-                    if (t[cn] >= 0) {
-                        atomicMax(maxc + t[cn], __float_as_uint(fabsf(r.w[cn]) * gm));
-                        atomicAdd(cnt + t[cn], 1u);
-                    }
-            }
-            recs[idx] = r;
-        }
-        __syncthreads();
-        // ---- per-pixel scale; a non-finite bound (inf / nan in grad_out or attn) poisons the pixel instead of hiding it ------
-        for (int i = tid; i < npx; i += kTiledThreads) {
-            const float bound = (float)cnt[i] * __uint_as_float(maxc[i]);
-            const bool ok = bound > 0.f && bound < 3.0e38f;
-            maxc[i] = __float_as_uint(ok ? 1073741824.f / bound : 0.f);
-            cnt[i] = __float_as_uint(bound > 0.f || bound != bound ? bound * (1.f / 1073741824.f) : 0.f);
-        }
-        __syncthreads();
-        const float *scale = reinterpret_cast<const float *>(maxc);
-        // fold the destination pixels' scales into the weights of the in-window records
-        for (int idx = tid; idx < nq * g.P; idx += kTiledThreads) {
-            const int base = recs[idx].base;
-            if (base >= 0) {
-                recs[idx].w[0] *= scale[base];
-                recs[idx].w[1] *= scale[base + 1];
-                recs[idx].w[2] *= scale[base + nwc];
-                recs[idx].w[3] *= scale[base + nwc + 1];
-            }
-        }
-        __syncthreads();
-        stamp<1>(g, 3);
-
-        // ---- pass 2: replay; 32 lanes = 32 channels of one query, kBfpBatch queries' grad_out rows fetched together ------------
-        for (int i0 = grp; i0 < nq; i0 += kBfpBatch * kBfpGroups) {
-            float gs[kBfpBatch];
-#pragma unroll
-            for (int u = 0; u < kBfpBatch; ++u) {
-                const int i = i0 + u * kBfpGroups;
-                const unsigned item = (unsigned)((b * g.Lq + hdr->qid[i < nq ? i : i0]) * g.M + m);
-                gs[u] = grad_out[item * (unsigned)kTD + j];
-            }
-#pragma unroll
-            for (int u = 0; u < kBfpBatch; ++u) {
-                const int i = i0 + u * kBfpGroups;
-                if (i >= nq) break;   // uniform over the 32-lane group
-                const float gk = gs[u];
-                const int np = P4 ? 4 : g.P;
-                BfpRec rq[4];
-                if (P4) {   // the four records of the query are read together: one LDS latency per query, not per point
-#pragma unroll
-                    for (int pp = 0; pp < 4; ++pp) rq[pp] = recs[i * 4 + pp];
-                }
-#pragma unroll
-                for (int pp = 0; pp < (P4 ? 4 : 16); ++pp) {
-                    if (!P4 && pp >= np) break;
-                    const BfpRec r = P4 ? rq[pp & 3] : recs[i * g.P + pp];   // same address in all 32 lanes: LDS broadcast
-                    if (r.base >= 0) {
-                        int *a0 = acc + r.base * kTD + j, *a1 = a0 + nwc * kTD;
-                        atomicAdd(a0, __float2int_rn(r.w[0] * gk));
-                        atomicAdd(a0 + kTD, __float2int_rn(r.w[1] * gk));
-                        atomicAdd(a1, __float2int_rn(r.w[2] * gk));
-                        atomicAdd(a1 + kTD, __float2int_rn(r.w[3] * gk));
-                    } else if (r.base == -2) {   // rare: a corner outside the window
-                        const unsigned item = (unsigned)((b * g.Lq + hdr->qid[i]) * g.M + m);
-                        const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * (item * (unsigned)LP + (unsigned)(lv * g.P + pp)));
-                        int t[4];
-                        bfp_general_targets(xy.x, xy.y, H, W, wr0, wc0, nwr, nwc, 0, base_row, row_elems, t);
-#pragma unroll
-                        for (int cn = 0; cn < 4; ++cn) {
-                            if (t[cn] >= 0)
-                                atomicAdd(acc + t[cn] * kTD + j, __float2int_rn(r.w[cn] * scale[t[cn]] * gk));
-                            else if (t[cn] < -1)
-                                atomicAdd(grad_value + (-(t[cn] + 2)) + j, r.w[cn] * gk);
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        stamp<1>(g, 4);
-
-        // ---- flush: de-quantise, one 128-B row of global float atomics per touched in-map pixel ---------------------------------
-        {
-            const float *inv = reinterpret_cast<const float *>(cnt);
-            float *dst = grad_value + (int64_t)(b * g.S + uni(hdr->start[lv])) * row_elems + m * kTD + j;
-            for (int px = grp; px < npx; px += kBfpGroups) {
-                const int q = acc[px * kTD + j];
-                const float iv = inv[px];
-                const int rr = px / nwc, cc = px - rr * nwc;
-                const int row = wr0 + rr, col = wc0 + cc;
-                const bool poisoned = !(iv == iv) || fabsf(iv) > 3.0e38f;   // non-finite bound: keep the result non-finite
-                if ((q != 0 || poisoned) && row >= 0 && row < H && col >= 0 && col < W)
-                    atomicAdd(dst + (int64_t)(row * W + col) * row_elems, poisoned ? iv : (float)q * iv);
-            }
-        }
-        stamp<1>(g, 5);
-        __syncthreads();   // the next item rebuilds the header and clears the window
-    }
-}
-
-// ---- backward: grad_value by sorted (segmented) reduction -- no floating-point LDS atomics ---------------------------------------
-// Work item = (image, head, region), all 32 channels, its levels one after the other.  Instead of adding every corner of every
-// sampling point into an LDS window with a float atomic (the f64 kernel above is bound by the ds_add_f64 issue rate), every
-// (point, corner) pair becomes an 8-byte ENTRY {query, weight} that is sorted -- with integer LDS atomics, one lane per point,
-// not per channel -- into the list of its destination pixel, and every output pixel then sums its list in registers:
-//   header + A  once per region: geometry, query list, grad_out rows of the region's queries -> LDS (gcache)
-//   per level (the next level's sampling locations / attention weights are fetched during the current level's E):
-//   B  one thread per (query, point): resolve; each in-map corner of an in-window point takes a rank in its pixel's list
-//      (ds_add_rtn_u32); points with a corner outside the window go to a side list
-//   C  exclusive scan of the per-pixel counts -> list offsets;  D  entries written to their sorted slots
-//   E  8 lanes x 4 channels per output pixel: acc += w * gcache[q] over the pixel's list, four entries in flight; the wave
-//      then hands its 8 pixel rows over through LDS, re-reads them one channel per lane and adds whole 128-B rows to
-//      grad_value (two rows per global atomic instruction)
-//   F  side list: 32 lanes per point, row atomics straight to global memory (as the direct kernel)
-// Sums are fp32 like the reference's; their order inside a list follows the atomic ranks (run-to-run variation at the
-// rounding level, as with the reference's float atomics).
-// What the step costs was measured per stage and per level (tools/stage_stamps.py): E is bound by instruction issue and LDS
-// traffic per list entry, which is why the entries are per pixel (one 8-B read, no corner / bucket arithmetic in the loop).
-constexpr int kSortMaxPx = 1280;            // largest single-level window (pixels) the kernel takes
-constexpr int kSortMaxPts = kMaxRegionQueries * 4;
-
-struct alignas(8) SortRec {
-    int q;     // index of the query inside the region (row of gcache)
-    float w;   // bilinear weight x attention weight of the corner that is this pixel
-};
-
-struct SortLds {   // after the TileHeader
-    float gcache[kMaxRegionQueries * kTD];
-    int offs[kSortMaxPx + 4];               // histogram, then exclusive prefix (offs[npx] = total)
-    SortRec sorted[4 * kSortMaxPts];        // one entry per (point, corner), grouped by destination pixel
-    unsigned short genlist[kSortMaxPts];    // points with a corner outside the window (index of the point in the region)
-    float stage[16][8 * kTD];               // step E: per wave, the 8 pixel rows it hands to the row atomics
-    int stage_row[16][8];                   //         and their element offsets in grad_value (-1 = not a map pixel)
-    int wave_tot[16];
-    int ngen;
-    int pad[3];
-};
-static_assert(sizeof(TileHeader) + sizeof(SortLds) <= 160 * 1024, "sorted scatter: LDS budget");
-static_assert(kSortMaxPts <= 65536, "genlist holds 16-bit point indices");
-
-// TV = storage type of grad_out.  grad_value is always accumulated in fp32 (bf16 mode: an fp32 scratch buffer, rounded once).
-template <typename TV = float>
-__global__ __launch_bounds__(kTiledThreads) void tiled_scatter_sorted_kernel(
-    const float *__restrict__ loc, const float *__restrict__ aw, const TV *__restrict__ grad_out,
-    float *__restrict__ grad_value, const TiledGeom g)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    TileHeader *hdr = reinterpret_cast<TileHeader *>(smem);
-    SortLds *S = reinterpret_cast<SortLds *>(smem + sizeof(TileHeader));
-
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    const int row_elems = g.M * kTD;
-    const int LP = g.L * g.P;
-    // work item = (image, head, region); its levels go through the tables one after the other, so the header and the
-    // grad_out rows are set up once per region and the next level's operands are fetched while the current level is reduced
-    const int n_items = kXcds * ((g.N * g.M + kXcds - 1) / kXcds) * g.GY * g.GX;
-    for (int vb = blockIdx.x; vb < n_items; vb += gridDim.x) {   // persistent form, see tiled_gather_kernel
-        int pair, region;
-        if (!decode_block(vb, g.N * g.M, g.GY * g.GX, pair, region)) continue;
-        const int b = pair / g.M, m = pair - b * g.M;
-        const int gy = region / g.GX, gx = region - gy * g.GX;
-        stamp<1>(g, 0);
-        const int nq = build_header(hdr, g, gy, gx);
-        stamp<1>(g, 1);
-        // this thread's (up to) two sampling points per level: (query, point) = idx / P, idx % P
-        unsigned pt_base[2];
-        bool pt_live[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = tid + u * kTiledThreads;
-            pt_live[u] = idx < nq * g.P;
-            const int qi = pt_live[u] ? idx / g.P : 0, pp = pt_live[u] ? idx - qi * g.P : 0;
-            pt_base[u] = (unsigned)((b * g.Lq + hdr->qid[qi]) * g.M + m) * (unsigned)LP + (unsigned)pp;
-        }
-        float2 nxt_xy[2];
-        float nxt_a[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {   // level 0
-            nxt_xy[u] = *reinterpret_cast<const float2 *>(loc + 2u * pt_base[u]);
-            nxt_a[u] = aw[pt_base[u]];
-        }
-        // ---- A: grad_out rows -> LDS ------------------------------------------------------------------------------
-        for (int i = tid >> 3; i < nq; i += kTiledThreads / 8) {
-            const unsigned item = (unsigned)((b * g.Lq + hdr->qid[i]) * g.M + m);
-            *reinterpret_cast<float4 *>(S->gcache + i * kTD + 4 * (tid & 7)) = ld4(grad_out + item * (unsigned)kTD + 4u * (tid & 7));
-        }
-        for (int lv = 0; lv < g.L; ++lv) {
-        const int H = uni(hdr->H[lv]), W = uni(hdr->W[lv]), nwc = uni(hdr->r[lv].nwc), nwr = uni(hdr->r[lv].nwr);
-        const int wr0 = uni(hdr->r[lv].wr0), wc0 = uni(hdr->r[lv].wc0);
-        const int npx = nwr * nwc;
-        const int base_row = (b * g.S + uni(hdr->start[lv])) * row_elems + m * kTD;
-        for (int i = tid; i <= npx; i += kTiledThreads) S->offs[i] = 0;   // clear the histogram
-        if (tid == 0) S->ngen = 0;
-        float2 cur_xy[2];
-        float cur_a[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            cur_xy[u] = nxt_xy[u];
-            cur_a[u] = nxt_a[u];
-            if (lv + 1 < g.L) {   // in flight until the next level's step B
-                nxt_xy[u] = *reinterpret_cast<const float2 *>(loc + 2u * (pt_base[u] + (unsigned)((lv + 1) * g.P)));
-                nxt_a[u] = aw[pt_base[u] + (unsigned)((lv + 1) * g.P)];
-            }
-        }
-        __syncthreads();
-
-        // ---- B: resolve; every corner of an in-window point takes a rank in the list of its destination pixel ------------
-        int r_pix[2];
-        int r_rank[2][4];
-        float r_w[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = tid + u * kTiledThreads;
-            r_pix[u] = -1;
-            if (pt_live[u]) {
-                const float2 xy = cur_xy[u];
-                const float a = cur_a[u];
-                const float h_im = xy.y * (float)H - 0.5f, w_im = xy.x * (float)W - 0.5f;
-                if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-                    const float hf = floorf(h_im), wf = floorf(w_im);
-                    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-                    const int rr = (int)hf - wr0, cc = (int)wf - wc0;
-                    if (rr >= 0 && rr + 1 < nwr && cc >= 0 && cc + 1 < nwc) {   // all four corners in the window (apron incl.)
-                        r_pix[u] = rr * nwc + cc;
-                        r_w[u][0] = hh * hw * a;
-                        r_w[u][1] = hh * lw * a;
-                        r_w[u][2] = lh * hw * a;
-                        r_w[u][3] = lh * lw * a;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            // corners on the apron (outside the map) are dropped here: their pixels are never flushed
-                            const int row = (int)hf + (k >> 1), col = (int)wf + (k & 1);
-                            const bool in_map = row >= 0 && row < H && col >= 0 && col < W;
-                            r_rank[u][k] = in_map ? atomicAdd(&S->offs[r_pix[u] + (k >> 1) * nwc + (k & 1)], 1) : -1;
-                        }
-                    } else {
-                        S->genlist[atomicAdd(&S->ngen, 1)] = (unsigned short)idx;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        stamp<1>(g, 2);
-
-        // ---- C: exclusive scan of the histogram (two entries per thread; kSortMaxPx <= 2 * 1024) --------------------------------
-        {
-            const int e0 = 2 * tid, e1 = 2 * tid + 1;
-            const int c0 = e0 < npx ? S->offs[e0] : 0, c1 = e1 < npx ? S->offs[e1] : 0;
-            int incl = c0 + c1;
-#pragma unroll
-            for (int d = 1; d < kWave; d <<= 1) {
-                const int t = __shfl_up(incl, d, kWave);
-                if (lane >= d) incl += t;
-            }
-            if (lane == kWave - 1) S->wave_tot[wave] = incl;
-            __syncthreads();
-            int base = 0;
-#pragma unroll
-            for (int w = 0; w < kTiledThreads / kWave; ++w) base += w < wave ? S->wave_tot[w] : 0;
-            const int excl = base + incl - (c0 + c1);
-            if (e0 <= npx) S->offs[e0] = excl;                 // e0 == npx / e1 == npx write the total (sentinel)
-            if (e1 <= npx) S->offs[e1] = excl + c0;
-        }
-        __syncthreads();
-        // ---- D: records to their sorted slots -----------------------------------------------------------------------------------
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (r_pix[u] >= 0) {
-                const int qi = (tid + u * kTiledThreads) / g.P;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (r_rank[u][k] >= 0)
-                        S->sorted[S->offs[r_pix[u] + (k >> 1) * nwc + (k & 1)] + r_rank[u][k]] = SortRec{qi, r_w[u][k]};
-            }
-        __syncthreads();
-        stamp<1>(g, 3);
-
-        // ---- E: per output pixel, 8 lanes x 4 channels; then transpose to one channel per lane and add rows ---------------------
-        {
-            const int j8 = lane & 7, grp8 = tid >> 3;
-            for (int px0 = 0; px0 < npx; px0 += kTiledThreads / 8) {   // wave-uniform trip count
-                const int px = px0 + grp8;
-                const int rr = px / nwc, cc = px - rr * nwc;
-                const int row = wr0 + rr, col = wc0 + cc;
-                const bool valid = px < npx && row >= 0 && row < H && col >= 0 && col < W;
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid) {
-                    const int e1 = S->offs[px + 1];
-                    int e = S->offs[px];
-                    // several entries in flight: the entry -> gcache row dependency is the latency chain of this loop
-                    for (; e + 3 < e1; e += 4) {
-                        SortRec r[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) r[u] = S->sorted[e + u];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const float4 gv = *reinterpret_cast<const float4 *>(S->gcache + r[u].q * kTD + 4 * j8);
-                            acc.x += r[u].w * gv.x;
-                            acc.y += r[u].w * gv.y;
-                            acc.z += r[u].w * gv.z;
-                            acc.w += r[u].w * gv.w;
-                        }
-                    }
-                    for (; e < e1; ++e) {
-                        const SortRec r = S->sorted[e];
-                        const float4 gv = *reinterpret_cast<const float4 *>(S->gcache + r.q * kTD + 4 * j8);
-                        acc.x += r.w * gv.x;
-                        acc.y += r.w * gv.y;
-                        acc.z += r.w * gv.z;
-                        acc.w += r.w * gv.w;
-                    }
-                }
-                // hand-over through LDS: the lane group writes its pixel's 32 channels, then the wave re-reads one channel per
-                // lane so that each global atomic instruction adds two whole 128-B rows (same-wave LDS traffic is in order;
-                // the barriers only stop compiler motion)
-                *reinterpret_cast<float4 *>(S->stage[wave] + (lane >> 3) * kTD + 4 * j8) = acc;
-                if (j8 == 0) S->stage_row[wave][lane >> 3] = valid ? base_row + (row * W + col) * row_elems : -1;
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {   // lower / upper half-wave: pixel slot 2r / 2r + 1
-                    const int slot = 2 * r + (lane >> 5);
-                    const float v = S->stage[wave][slot * kTD + (lane & 31)];
-                    const int ro = S->stage_row[wave][slot];
-                    if (ro >= 0 && v != 0.f) atomicAdd(grad_value + ro + (lane & 31), v);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        stamp<1>(g, 4);
-
-        // ---- F: points with a corner outside the window: row atomics straight to global memory ----------------------------------
-        {
-            const int j = tid & (kTD - 1), grp32 = tid / kTD;
-            const int ngen = S->ngen;
-            for (int gi = grp32; gi < ngen; gi += kTiledThreads / kTD) {
-                const int idx = S->genlist[gi];
-                const int qi = idx / g.P, pp = idx - qi * g.P;
-                const unsigned item = (unsigned)((b * g.Lq + hdr->qid[qi]) * g.M + m);
-                const unsigned pt = item * (unsigned)LP + (unsigned)(lv * g.P + pp);
-                const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
-                const float a = aw[pt];
-                int o[4];
-                float lh, lw;
-                resolve_point<float>(xy.x, xy.y, H, W, base_row, row_elems, o, lh, lw);
-                const float hh = 1.f - lh, hw = 1.f - lw;
-                const float gk = S->gcache[qi * kTD + j] * a;
-                const float ww[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-#pragma unroll
-                for (int cn = 0; cn < 4; ++cn)
-                    if (o[cn] >= 0) atomicAdd(grad_value + o[cn] + j, ww[cn] * gk);
-            }
-        }
-        stamp<1>(g, 5);
-        __syncthreads();   // the next level clears the tables; the next item rebuilds the header
-        }
-    }
-}
-
 // ---- host entry points ----------------------------------------------------------------------------------------------
 inline TiledPlan plan_gather(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
 {
@@ -1557,79 +747,6 @@ inline TiledPlan plan_gather(int N, int S, int M, int D, int L, int Lq, int P, c
     if (pl.ok && pl.lds_bytes < fix) pl.lds_bytes = fix;
     return pl;
 }
-inline TiledPlan plan_bwd_gather(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
-{
-    if (tiled_options().bwd_halves && P <= 4) {   // channel halves: forward geometry, one level per work item
-        TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin,
-                                  kFwdLdsBudget, kFwdGC * (int)sizeof(float));
-        if (pl.ok) {
-            int max_px = 0;
-            for (int gy = 0; gy < pl.g.GY; ++gy)
-                for (int gx = 0; gx < pl.g.GX; ++gx)
-                    for (int l = 0; l < L; ++l) {
-                        const LevelRect r = level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin_l[l]);
-                        max_px = r.nwr * r.nwc > max_px ? r.nwr * r.nwc : max_px;
-                    }
-            for (int l = 0; l < L; ++l) pl.g.phase[l] = l;
-            pl.g.nphases = L;
-            pl.lds_bytes = sizeof(TileHeader) + (size_t)max_px * kFwdGC * sizeof(float);
-            pl.max_px = kFwdGC;   // marks the channel-half configuration
-        }
-        return pl;
-    }
-    TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin, kBwdLdsBudget,
-                              kBwdGC * (int)sizeof(float));
-    pl.max_px = kBwdGC;
-    return pl;
-}
-inline TiledPlan plan_scatter_bfp(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
-{
-    // LDS: header + window (136 B per pixel) + one 20-B record per (query, point) of the region, within 160 KiB
-    const int budget = 160 * 1024 - (int)sizeof(TileHeader) - 256;
-    TiledPlan pl = plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin, budget,
-                              kBfpPxBytes, P * (int)sizeof(BfpRec));
-    if (pl.ok) {   // one level per phase = per work item; every window starts at LDS pixel 0
-        int max_px = 0;
-        for (int gy = 0; gy < pl.g.GY; ++gy)
-            for (int gx = 0; gx < pl.g.GX; ++gx)
-                for (int l = 0; l < L; ++l) {
-                    const LevelRect r = level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin_l[l]);
-                    max_px = r.nwr * r.nwc > max_px ? r.nwr * r.nwc : max_px;
-                }
-        for (int l = 0; l < L; ++l) pl.g.phase[l] = l;
-        pl.g.nphases = L;
-        pl.lds_bytes = sizeof(TileHeader) + (size_t)max_px * kBfpPxBytes + (size_t)pl.max_q * P * sizeof(BfpRec);
-        pl.grid = pl.grid;   // per (pair, region); the launch multiplies by the number of levels
-        pl.max_px = max_px;
-    }
-    return pl;
-}
-inline TiledPlan plan_scatter_sorted(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
-{
-    TiledPlan pl;
-    if (P > 4) return pl;   // two (query, point) records per thread
-    pl = plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin, kSortMaxPx * 4, 4);
-    if (pl.ok) {
-        int max_px = 0;
-        for (int gy = 0; gy < pl.g.GY; ++gy)
-            for (int gx = 0; gx < pl.g.GX; ++gx)
-                for (int l = 0; l < L; ++l) {
-                    const LevelRect r = level_rect(pl.g.H[l], pl.g.W[l], gy, gx, pl.g.GY, pl.g.GX, pl.g.margin_l[l]);
-                    max_px = r.nwr * r.nwc > max_px ? r.nwr * r.nwc : max_px;
-                }
-        if (max_px > kSortMaxPx) { pl.ok = false; return pl; }
-        for (int l = 0; l < L; ++l) pl.g.phase[l] = l;
-        pl.g.nphases = L;
-        pl.lds_bytes = sizeof(TileHeader) + sizeof(SortLds);
-    }
-    return pl;
-}
-inline TiledPlan plan_scatter(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes, const int64_t *lsi)
-{
-    return plan_tiled(N, S, M, D, L, Lq, P, shapes, lsi, tiled_options().region_px, tiled_options().margin, kLdsBudgetBytes,
-                      kSD * (int)sizeof(double));
-}
-
 template <typename T>
 bool tiled_fwd_applicable(int, int, int, int, int, int, int, const int64_t *, const int64_t *, const T *, const T *)
 {
@@ -1641,23 +758,6 @@ inline bool tiled_fwd_applicable<float>(int N, int S, int M, int D, int L, int L
 {
     if ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(out)) & 15) return false;
     return plan_gather(N, S, M, D, L, Lq, P, shapes, lsi).ok;
-}
-
-template <typename T>
-bool tiled_bwd_applicable(int, int, int, int, int, int, int, const int64_t *, const int64_t *, const T *, const T *,
-                          const T *)
-{
-    return false;
-}
-template <>
-inline bool tiled_bwd_applicable<float>(int N, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes,
-                                        const int64_t *lsi, const float *value, const float *grad_out,
-                                        const float *grad_value)
-{
-    if ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(grad_out) |
-         reinterpret_cast<uintptr_t>(grad_value)) & 15)
-        return false;
-    return plan_bwd_gather(N, S, M, D, L, Lq, P, shapes, lsi).ok && plan_scatter(N, S, M, D, L, Lq, P, shapes, lsi).ok;
 }
 
 // Persistent grid size: at most `cap` workgroups, a multiple of 8 (XCD affinity), and with cap/8 coprime to the number of
@@ -1693,7 +793,7 @@ inline hipError_t set_lds_limit(const void *fn, size_t bytes)
     return e;
 }
 
-// TV = float or bf16_t (storage of value / out / grad_out); loc / attn and their gradients are fp32
+// TV = float or bf16_t (storage of value / out); loc / attn are fp32
 template <typename TV>
 inline hipError_t launch_fwd_tiled_tv(const TV *value, const float *loc, const float *aw, TV *out, int N, int S, int M, int D,
                                       int L, int Lq, int P, const int64_t *shapes_h, const int64_t *lsi_h,
@@ -1702,12 +802,11 @@ inline hipError_t launch_fwd_tiled_tv(const TV *value, const float *loc, const f
     TiledPlan pl = plan_gather(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
     if (!pl.ok) return hipErrorInvalidValue;
     if (general_points) pl.g.stats = general_points;   // locality monitor (msda_api.hip); else the diagnostic override
-    auto kern = P == 4 ? &tiled_gather_kernel<false, true, kFwdGC, 4, TV> : &tiled_gather_kernel<false, false, kFwdGC, 4, TV>;
+    auto kern = P == 4 ? &tiled_gather_kernel<true, kFwdGC, 4, TV> : &tiled_gather_kernel<false, kFwdGC, 4, TV>;
     hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pl.lds_bytes);
     if (e != hipSuccess) return e;
     const int grid = persistent_grid(pl.grid * (kTD / kFwdGC), tiled_options().persist, kTD / kFwdGC);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdGC == 16 ? 512 : 1024), pl.lds_bytes, stream, value, loc, aw,
-                       (const TV *)nullptr, out, (float *)nullptr, (float *)nullptr, pl.g);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdGC == 16 ? 512 : 1024), pl.lds_bytes, stream, value, loc, aw, out, pl.g);
     return hipGetLastError();
 }
 
@@ -1724,89 +823,6 @@ inline hipError_t launch_fwd_tiled<float>(const float *value, const int64_t *, c
                                           hipStream_t stream)
 {
     return launch_fwd_tiled_tv<float>(value, loc, aw, out, N, S, M, D, L, Lq, P, shapes_h, lsi_h, general_points, stream);
-}
-
-// grad_value_f32: where grad_value is accumulated (pre-zeroed by the caller): the output itself for fp32, an fp32 scratch
-// buffer for bf16 storage.  The f64-window and integer-window scatter variants exist for fp32 storage only.
-template <typename TV>
-inline hipError_t launch_bwd_tiled_tv(const TV *value, const float *loc, const float *aw, const TV *grad_out,
-                                      float *grad_value_f32, float *grad_loc, float *grad_aw, int N, int S, int M, int D,
-                                      int L, int Lq, int P, const int64_t *shapes_h, const int64_t *lsi_h, hipStream_t stream);
-
-template <>
-inline hipError_t launch_bwd_tiled_tv<bf16_t>(const bf16_t *value, const float *loc, const float *aw, const bf16_t *grad_out,
-                                              float *grad_value_f32, float *grad_loc, float *grad_aw, int N, int S, int M,
-                                              int D, int L, int Lq, int P, const int64_t *shapes_h, const int64_t *lsi_h,
-                                              hipStream_t stream)
-{
-    const TiledPlan pg = plan_bwd_gather(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
-    const TiledPlan pso = plan_scatter_sorted(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
-    if (!pg.ok || !pso.ok || pg.max_px == kFwdGC) return hipErrorNotSupported;
-    auto kern = P == 4 ? &tiled_gather_kernel<true, true, kBwdGC, kBwdCPL, bf16_t> : &tiled_gather_kernel<true, false, kBwdGC, kBwdCPL, bf16_t>;
-    hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pg.lds_bytes);
-    if (e == hipSuccess) e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_sorted_kernel<bf16_t>), pso.lds_bytes);
-    if (e != hipSuccess) return e;
-    const int sgrid = persistent_grid(pso.grid, tiled_options().persist / 2, 1);
-    hipLaunchKernelGGL(tiled_scatter_sorted_kernel<bf16_t>, dim3(sgrid), dim3(kTiledThreads), pso.lds_bytes, stream, loc, aw,
-                       grad_out, grad_value_f32, pso.g);
-    const int ggrid = persistent_grid(pg.grid * pg.g.nphases, tiled_options().persist / 2, pg.g.nphases);
-    hipLaunchKernelGGL(kern, dim3(ggrid), dim3(1024), pg.lds_bytes, stream, value, loc, aw, grad_out, (bf16_t *)nullptr,
-                       grad_loc, grad_aw, pg.g);
-    return hipGetLastError();
-}
-
-template <typename T>
-hipError_t launch_bwd_tiled(const T *, const int64_t *, const int64_t *, const T *, const T *, const T *, T *, T *, T *,
-                            int, int, int, int, int, int, int, const int64_t *, const int64_t *, hipStream_t)
-{
-    return hipErrorNotSupported;
-}
-template <>
-inline hipError_t launch_bwd_tiled<float>(const float *value, const int64_t *, const int64_t *, const float *loc,
-                                          const float *aw, const float *grad_out, float *grad_value, float *grad_loc,
-                                          float *grad_aw, int N, int S, int M, int D, int L, int Lq, int P,
-                                          const int64_t *shapes_h, const int64_t *lsi_h, hipStream_t stream)
-{
-    const TiledPlan pg = plan_bwd_gather(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
-    const TiledPlan ps = plan_scatter(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
-    if (!pg.ok || !ps.ok) return hipErrorInvalidValue;
-    const size_t lds_scatter = ps.lds_bytes;
-    const bool halves = pg.max_px == kFwdGC;
-    auto kern = halves ? (P == 4 ? &tiled_gather_kernel<true, true, kFwdGC, 4> : &tiled_gather_kernel<true, false, kFwdGC, 4>)
-                       : (P == 4 ? &tiled_gather_kernel<true, true, kBwdGC, kBwdCPL> : &tiled_gather_kernel<true, false, kBwdGC, kBwdCPL>);
-    hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pg.lds_bytes);
-    if (e == hipSuccess) e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_kernel), lds_scatter);
-    if (e != hipSuccess) return e;
-    // grad_value (pre-zeroed by the caller of this function): LDS accumulation + one flush per touched pixel
-    const TiledPlan pb = plan_scatter_bfp(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
-    const TiledPlan pso = plan_scatter_sorted(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
-    if (tiled_options().accum == 2 && pso.ok) {
-        e = set_lds_limit(reinterpret_cast<const void *>(&tiled_scatter_sorted_kernel<float>), pso.lds_bytes);
-        if (e != hipSuccess) return e;
-        const int sgrid = persistent_grid(pso.grid, tiled_options().persist / 2, 1);
-        hipLaunchKernelGGL(tiled_scatter_sorted_kernel<float>, dim3(sgrid), dim3(kTiledThreads), pso.lds_bytes, stream, loc, aw,
-                           grad_out, grad_value, pso.g);
-    } else if (tiled_options().accum == 1 && pb.ok) {
-        auto skern = P == 4 ? &tiled_scatter_bfp_kernel<true> : &tiled_scatter_bfp_kernel<false>;
-        e = set_lds_limit(reinterpret_cast<const void *>(skern), pb.lds_bytes);
-        if (e != hipSuccess) return e;
-        const int sgrid = persistent_grid(pb.grid * pb.g.nphases, tiled_options().persist / 2, pb.g.nphases);
-        hipLaunchKernelGGL(skern, dim3(sgrid), dim3(kTiledThreads), pb.lds_bytes, stream, loc, aw, grad_out,
-                           grad_value, pb.g, pb.max_px);
-    } else {
-        const int sgrid = persistent_grid(ps.grid * (kTD / kSD) * ps.g.nphases, tiled_options().persist / 2,
-                                          (kTD / kSD) * ps.g.nphases);
-        hipLaunchKernelGGL(tiled_scatter_kernel, dim3(sgrid), dim3(kTiledThreads), lds_scatter, stream, loc, aw, grad_out,
-                           grad_value, ps.g);
-    }
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    // grad_sampling_loc, grad_attn_weight: gather from LDS windows of value
-    const int ggrid = persistent_grid(pg.grid * pg.g.nphases, halves ? tiled_options().persist.load() : tiled_options().persist.load() / 2,
-                                      pg.g.nphases);
-    hipLaunchKernelGGL(kern, dim3(ggrid), dim3(halves ? 512 : 1024), pg.lds_bytes, stream, value, loc, aw, grad_out,
-                       (float *)nullptr, grad_loc, grad_aw, pg.g);
-    return hipGetLastError();
 }
 
 }  // namespace msda

@@ -162,12 +162,24 @@ class LinearBf16CachedFunction(torch.autograd.Function):
         split, dts = ctx.meta
         dy2, x2 = dy.reshape(-1, dy.shape[-1]).contiguous(), x.reshape(-1, x.shape[-1])
         dx = (dy2 @ w16).view(x.shape) if ctx.needs_input_grad[0] else None
-        if linear_wgrad_supported(dy2.shape[1], x2.shape[1]) and dy2.shape[0] >= LinearBf16Function.MIN_TOKENS:
-            dw, db = linear_wgrad_bf16(dy2, x2.contiguous(), with_bias=True)
-        else:
-            dw, db = (dy2.t() @ x2).float(), dy2.sum(0, dtype=torch.float32)
+        need = ctx.needs_input_grad[4:]
+        if not any(need):          # frozen projections, or only the input gradient is wanted: no token contraction at all
+            return (dx, None, None, None) + (None,) * len(dts)
+        nw = 1 if split is None else 2
+        want_w, want_b = any(need[:nw]), any(need[nw:])
+        dw = db = None
+        if want_w and linear_wgrad_supported(dy2.shape[1], x2.shape[1]) and dy2.shape[0] >= LinearBf16Function.MIN_TOKENS:
+            if want_b:
+                dw, db = linear_wgrad_bf16(dy2, x2.contiguous(), with_bias=True)
+            else:
+                dw = linear_wgrad_bf16(dy2, x2.contiguous())
+        elif want_w:
+            dw = (dy2.t() @ x2).float()
+        if want_b and db is None:
+            db = dy2.sum(0, dtype=torch.float32)
         if split is None:
-            grads = (dw.to(dts[0]), db.to(dts[1]))
+            grads = (dw, db)
         else:
-            grads = (dw[:split].to(dts[0]), dw[split:].to(dts[1]), db[:split].to(dts[2]), db[split:].to(dts[3]))
-        return (dx, None, None, None) + grads
+            grads = (dw[:split] if dw is not None else None, dw[split:] if dw is not None else None,
+                     db[:split] if db is not None else None, db[split:] if db is not None else None)
+        return (dx, None, None, None) + tuple(g.to(dt) if g is not None and n else None for g, dt, n in zip(grads, dts, need))

@@ -63,9 +63,12 @@ class DeformableTransformerEncoderLayer(nn.Module):
             return FusedFFNFunction.apply(src, self.linear1.weight.to(torch.bfloat16), self.linear1.bias.float(),
                                           self.linear2.weight.to(torch.bfloat16), self.linear2.bias.float(),
                                           self.norm2.weight.float(), self.norm2.bias.float(), self.norm2.eps)
+        # op-by-op sequence (fp32, or bf16 activations with fp32 master parameters: the parameters are cast to the input's type)
         act = {"relu": F.relu, "gelu": F.gelu}[self.activation]
-        src2 = self.linear2(self.dropout2(act(self.linear1(src))))
-        return self.norm2(src + self.dropout3(src2))
+        dt = src.dtype
+        h = self.dropout2(act(F.linear(src, self.linear1.weight.to(dt), self.linear1.bias.to(dt))))
+        src2 = F.linear(h, self.linear2.weight.to(dt), self.linear2.bias.to(dt))
+        return F.layer_norm(src + self.dropout3(src2), (src.shape[-1],), self.norm2.weight.to(dt), self.norm2.bias.to(dt), self.norm2.eps)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, key_padding_mask=None):
         # (bfloat16 activations: the attention module runs its projections as bf16 GEMMs and the operator's bf16 entry points, with

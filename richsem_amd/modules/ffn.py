@@ -37,7 +37,9 @@ class FFN(nn.Module):
             return FusedFFNFunction.apply(src, self.linear1.weight.to(torch.bfloat16), self.linear1.bias.float(),
                                           self.linear2.weight.to(torch.bfloat16), self.linear2.bias.float(),
                                           self.norm.weight.float(), self.norm.bias.float(), self.norm.eps)
+        # op-by-op sequence (fp32, or bf16 activations with fp32 master parameters: the parameters are cast to the input's type)
         act = {"relu": F.relu, "gelu": F.gelu}[self.activation]
-        h = F.dropout(act(self.linear1(src)), self.dropout_p, self.training)
-        src = src + F.dropout(self.linear2(h), self.dropout_p, self.training)
-        return self.norm(src)
+        dt = src.dtype
+        h = F.dropout(act(F.linear(src, self.linear1.weight.to(dt), self.linear1.bias.to(dt))), self.dropout_p, self.training)
+        src = src + F.dropout(F.linear(h, self.linear2.weight.to(dt), self.linear2.bias.to(dt)), self.dropout_p, self.training)
+        return F.layer_norm(src, (src.shape[-1],), self.norm.weight.to(dt), self.norm.bias.to(dt), self.norm.eps)

@@ -41,6 +41,7 @@ class MSDeformAttn(nn.Module):
         # True (default): one GEMM for offsets + attention logits, softmax / location arithmetic / padding mask in the library's
         # own kernels (functions/fused.py).  False: the reference's op-by-op sequence.  Same parameters, same results.
         self.fused = True
+        self._bf16_ver = self._bf16_cache = None
 
         self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
         self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
@@ -64,10 +65,22 @@ class MSDeformAttn(nn.Module):
             self.value_proj.bias.zero_()
             nn.init.xavier_uniform_(self.output_proj.weight)
             self.output_proj.bias.zero_()
+        self.invalidate_bf16_cache()
+
+    def invalidate_bf16_cache(self):
+        """Drop the cached bf16 forms of the parameters.  They are refreshed by themselves after every in-place update autograd's
+        version counter sees (optimizer steps, ``load_state_dict``, ``copy_``); writes THROUGH ``param.data`` (``constant_(w.data, ...)``,
+        some third-party optimizers, manual EMA / weight surgery) bypass that counter: call this after them."""
+        self._bf16_ver = None
+        self._bf16_cache = None
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate_bf16_cache()
 
     def _bf16_params(self):
         """bf16 forms of the projections' parameters (offsets and logits stacked into one 256 -> 384 projection), rebuilt when any of
-        them has been modified in place (optimizer step, load_state_dict)"""
+        them has been modified in place (optimizer step, load_state_dict; see :meth:`invalidate_bf16_cache` for ``.data`` writes)"""
         ps = (self.value_proj.weight, self.value_proj.bias, self.sampling_offsets.weight, self.sampling_offsets.bias,
               self.attention_weights.weight, self.attention_weights.bias, self.output_proj.weight, self.output_proj.bias)
         ver = tuple((p.data_ptr(), p._version) for p in ps)

@@ -156,7 +156,7 @@ def test_trainable_input_projection_forward_and_gradients():
         sum((w * g).sum() for w, g in zip(want, gs)).backward()
     for k, p in mod.state_dict(keep_vars=True).items():
         ref = sdr[k].grad
-        got = dict(mod.named_parameters())["layers." + k].grad.cpu()
+        got = dict(mod.named_parameters())[k].grad.cpu()
         s = float(ref.abs().max())
         assert float((got - ref).abs().mean()) <= 6e-3 * s and float((got - ref).abs().max()) <= 6e-2 * s, (k, float((got - ref).abs().max()) / s)
 

@@ -26,7 +26,7 @@ CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 
                if not os.path.basename(p).startswith(("module_", "attnpool_", "clip_resnet_")))
 # 1 = direct kernels, 2 = LDS-window kernels, 3 = pixel-stationary backward (candidates by geometry), 4 = routed
 # pixel-stationary backward -- each where applicable, else the direct kernels
-VARIANTS = [1, 2, 3, 4]
+VARIANTS = [0, 1, 2, 4]   # 0 automatic; forward: 1 direct, 2 LDS windows; backward: 1 direct (+ level-sum), 4 routed
 
 
 def dev(a):
@@ -50,8 +50,9 @@ def _restore_variants():
 
 
 def run_gpu(z, variant=0):
-    _lib.set_option("fwd_variant", min(variant, 2))
-    _lib.set_option("bwd_variant", variant)
+    """variant: 0 automatic; 1 direct kernels; 2 window forward + routed backward; 4 direct forward + routed backward"""
+    _lib.set_option("fwd_variant", {0: 0, 1: 1, 2: 2, 4: 1}[variant])
+    _lib.set_option("bwd_variant", {0: 0, 1: 1, 2: 4, 4: 4}[variant])
     v, sh, ls, loc, aw, go = (dev(z[k]) for k in ("value", "shapes", "lsi", "loc", "aw", "grad_out"))
     out = MSDA.ms_deform_attn_forward(v, sh, ls, loc, aw, 64)
     gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, ls, loc, aw, go.contiguous(), 64)
@@ -263,19 +264,17 @@ def test_full_size_properties(which, n_images):
     # kernel variants agree
     res = {}
     for variant in VARIANTS:
-        _lib.set_option("fwd_variant", min(variant, 2))
-        _lib.set_option("bwd_variant", variant)
+        _lib.set_option("fwd_variant", {0: 0, 1: 1, 2: 2, 4: 1}[variant])
+        _lib.set_option("bwd_variant", {0: 0, 1: 1, 2: 4, 4: 4}[variant])
         res[variant] = (f(t["value"]),) + tuple(MSDA.ms_deform_attn_backward(
             t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64))
-    for other in (2, 3, 4):
+    for other in (0, 2, 4):
         for a, b in zip(res[1], res[other]):
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-3)
 
 
 @pytest.mark.parametrize("opts", [
-    {"tile_accum": 1},                       # integer (block floating point) grad_value accumulator
     {"tile_persist": 0},                     # one workgroup per work item instead of persistent workgroups
-    {"bwd_gather_halves": 1},                # backward gather on channel halves
     {"tile_region": 12, "tile_margin": 3},   # small windows: many samples take the general (global) path
     {"tile_margin": 0},
     {"tile_grow": 0},                        # every level exactly tile_margin (default: windows grow into spare LDS)
@@ -302,27 +301,6 @@ def test_window_kernel_options_do_not_change_results(which, opts):
             _lib.set_option(k, v)
 
 
-def test_integer_accumulator_error_is_float32_class():
-    """tile_accum=1 (per-pixel block floating point): error of grad_value against the f64 oracle stays within a few
-    float32 ulps of the tensor's scale -- same class as float atomics -- also with a 1000:1 spread of gradient
-    magnitudes between queries."""
-    call = W.shrunk(W.call_E(2), 4)
-    t = W.make_inputs(call, "init", seed=33)
-    scale = torch.ones(call.N, call.Lq, 1)
-    scale[:, ::7] = 1000.0
-    t["grad_out"] = t["grad_out"] * scale
-    z = {k: v.numpy() for k, v in t.items()}
-    ogv, _, _ = O.backward(z["value"].astype(np.float64), z["shapes"], z["lsi"], z["loc"].astype(np.float64),
-                           z["aw"].astype(np.float64), z["grad_out"].astype(np.float64))
-    errs = {}
-    for accum in (0, 1):
-        _lib.set_option("tile_accum", accum)
-        _, gv, _, _ = run_gpu(z, 2)
-        errs[accum] = rel_err(gv, ogv)
-    _lib.set_option("tile_accum", 0)
-    assert errs[0] < 2e-6 and errs[1] < 2e-5, errs
-
-
 # ---- locality monitor (automatic kernel choice follows the data) ---------------------------------------------------
 def _variants_of(fn, n=1):
     _lib.profile_enable(8)
@@ -334,11 +312,11 @@ def _variants_of(fn, n=1):
     return [r["variant"] for r in recs]
 
 
-@pytest.mark.parametrize("loc_mode,expect,expect_bwd", [("init", 2, 2), ("uniform", 1, 4)])
+@pytest.mark.parametrize("loc_mode,expect,expect_bwd", [("init", 2, 4), ("uniform", 1, 4)])
 def test_locality_monitor_picks_kernels_by_data(loc_mode, expect, expect_bwd):
-    """Auto mode: the window kernels stay on a local sampling pattern; on a scattered one the forward gives way to the
-    direct kernel and the backward to the routed kernels (after the first probe has come back); results match the oracle
-    either way."""
+    """Auto mode: the window forward kernel stays on a local sampling pattern and gives way to the direct kernel on a scattered
+    one (after the first probe has come back); the backward of an encoder-shaped call is the routed kernels either way; results
+    match the oracle."""
     call = W.shrunk(W.call_E(2), 2)
     z = W.make_inputs(call, loc_mode, seed=11)
     t = {k: v.cuda() for k, v in z.items()}
@@ -365,7 +343,7 @@ def test_locality_monitor_picks_kernels_by_data(loc_mode, expect, expect_bwd):
     assert rel_err(out, oo) < tf
     assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg
     _lib.set_option("locality_monitor", 0)
-    assert _variants_of(fwd) == [2] and _variants_of(bwd) == [2]
+    assert _variants_of(fwd) == [2] and _variants_of(bwd) == [4]
     _lib.set_option("locality_monitor", 1)
 
 
@@ -441,13 +419,12 @@ def test_random_problems_against_oracle(seed):
     oo = O.forward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"])
     ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
     tf, tg = tols(np.float32)
-    for variant in (0, 2, 3, 4):
+    for variant in (0, 1, 2, 4):
         out, gv, gl, ga = run_gpu(z, variant)
         assert rel_err(out, oo) < tf, (variant, z["value"].shape, z["loc"].shape)
         assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg, (variant, z["value"].shape)
 
 
-# ---- pixel-stationary backward (msda_psb.h) ----------------------------------------------------------------------------
 def _profiled_variants(fn):
     _lib.profile_enable(8)
     fn()
@@ -455,73 +432,6 @@ def _profiled_variants(fn):
     recs = _lib.profile_collect()
     _lib.profile_enable(0)
     return [(r["kind"], r["variant"]) for r in recs]
-
-
-@pytest.mark.parametrize("opts", [
-    {},                                              # defaults
-    {"psb_margin": 0},                               # nearly every point of the fine levels is "far": list + direct method
-    {"psb_margin": 2},
-    {"psb_margin": 12, "psb_tile": 9},               # small tiles, wide candidate rectangles
-    {"psb_max_chunks": 1},                           # every tile split into slabs: atomic flush of pre-zeroed levels
-    {"psb_coarse_px": 0},                            # margins on every level
-    {"psb_coarse_px": 1000000},                      # no margins at all: every query is a candidate of every tile
-])
-@pytest.mark.parametrize("which,scale", [("E", 4), ("Em", 4), ("E", 2), ("Dd", 1)])
-def test_pixel_stationary_backward_options(which, scale, opts):
-    """The tile / margin / slab geometry decides who computes what, never the result."""
-    base = {"E": W.call_E, "Dd": W.call_Dd, "Em": W.call_Em}[which](2)
-    call = W.shrunk(base, scale) if scale > 1 else base
-    defaults = {k: _lib.get_option(k) for k in opts}
-    try:
-        for k, v in opts.items():
-            _lib.set_option(k, v)
-        for loc_mode in ("init", "sigma4", "uniform"):
-            if which == "E" and scale == 2 and loc_mode == "uniform" and opts.get("psb_margin", 6) < 6:
-                continue
-            t = W.make_inputs(call, loc_mode, seed=31)
-            t["loc"][0, :7] = t["loc"][0, :7] * 3.0 - 1.0     # some dropped samples and border corners
-            z = {k: v.numpy() for k, v in t.items()}
-            _lib.set_option("bwd_variant", 3)
-            v, sh, ls, loc, aw, go = (dev(z[k]) for k in ("value", "shapes", "lsi", "loc", "aw", "grad_out"))
-            res = {}
-
-            def bwd():
-                gv = torch.full_like(v, float("nan"))
-                res["g"] = MSDA.ms_deform_attn_backward(v, sh, ls, loc, aw, go, 64)
-            ran = _profiled_variants(bwd)
-            if not (which == "Dd" and ("psb_tile" in opts or "psb_max_chunks" in opts)):   # (work table too small: falls back)
-                assert ran == [("bwd", 3)], "the pixel-stationary kernel must be the one that ran"
-            gv, gl, ga = res["g"]
-            ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
-            tf, tg = tols(np.float32)
-            assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg, (loc_mode, opts)
-    finally:
-        for k, v in defaults.items():
-            _lib.set_option(k, v)
-
-
-def test_pixel_stationary_backward_overwrites_poisoned_outputs():
-    """No zero-fill is needed: every element of the three gradients is written (C ABI, poisoned caller buffers)."""
-    lib = _lib.load()
-    for call in (W.shrunk(W.call_E(2), 4), W.call_Dd(2)):
-        t = {k: v.cuda() for k, v in W.make_inputs(call, "sigma4", seed=9).items()}
-        N, S, M, D, L, Lq, P = call.N, call.S, call.M, call.D, call.L, call.Lq, call.P
-        sh, ls = t["shapes"].cpu().numpy(), t["lsi"].cpu().numpy()
-        _lib.set_option("bwd_variant", 3)
-        outs = []
-        for poison in (float("nan"), 321.0):
-            gv = torch.full_like(t["value"], poison)
-            gl = torch.full_like(t["loc"], poison)
-            ga = torch.full_like(t["aw"], poison)
-            _lib.check(lib.msda_backward_f32(t["value"].data_ptr(), t["shapes"].data_ptr(), t["lsi"].data_ptr(),
-                                             t["loc"].data_ptr(), t["aw"].data_ptr(), t["grad_out"].data_ptr(), N, S, M,
-                                             D, L, Lq, P, 64, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(),
-                                             sh.ctypes.data, ls.ctypes.data, torch.cuda.current_stream().cuda_stream))
-            torch.cuda.synchronize()
-            outs.append((gv, gl, ga))
-        for a, b in zip(*outs):
-            assert torch.isfinite(a).all()
-            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
 
 
 # ---- routed pixel-stationary backward (msda_rps.h) ------------------------------------------------------------------------

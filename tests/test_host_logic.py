@@ -179,3 +179,31 @@ def test_dn_group_count_matches_the_restated_reference_arithmetic():
     for i in range(pad):
         for j in range(pad):
             assert m[i, j] == (i // gp != j // gp)                   # denoising groups cannot see each other
+
+
+def test_input_projection_carries_the_reference_names_when_nested():
+    """richsem.py:295-310 keeps the projections as ``self.input_proj = nn.ModuleList([nn.Sequential(conv, GroupNorm), ...])``: nested
+    under that attribute the trainable mirror must produce / accept ``input_proj.{l}.{0,1}.{weight,bias}`` with strict=True"""
+    from richsem_amd.backbone import InputProjection
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.input_proj = InputProjection(in_channels=(16, 32, 64), hidden=32, num_levels=4, groups=4)
+
+    m = Model()
+    want = {f"input_proj.{l}.{i}.{n}" for l in range(4) for i in (0, 1) for n in ("weight", "bias")}
+    assert set(m.state_dict().keys()) == want
+    # a reference-named checkpoint (shapes of nn.Conv2d / nn.GroupNorm) loads with strict=True and lands in the parameters
+    ref = {}
+    for l, (cin, k) in enumerate(((16, 1), (32, 1), (64, 1), (64, 3))):
+        ref[f"input_proj.{l}.0.weight"] = torch.full((32, cin, k, k), float(l + 1))
+        ref[f"input_proj.{l}.0.bias"] = torch.full((32,), 0.5 * l)
+        ref[f"input_proj.{l}.1.weight"] = torch.full((32,), 2.0 + l)
+        ref[f"input_proj.{l}.1.bias"] = torch.full((32,), -1.0 * l)
+    missing, unexpected = m.load_state_dict(ref, strict=True)
+    assert not missing and not unexpected
+    assert float(m.input_proj[3][0].weight[0, 0, 0, 0]) == 4.0 and float(m.input_proj[2][1].bias[0]) == -2.0
+    # and as the root module the keys are the list's own
+    assert set(InputProjection(in_channels=(16,), hidden=32, num_levels=2, groups=4).state_dict().keys()) == \
+        {f"{l}.{i}.{n}" for l in range(2) for i in (0, 1) for n in ("weight", "bias")}

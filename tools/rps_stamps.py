@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Tuning aid: per-stage shader-clock shares of the pixel-stationary backward kernel (msda_debug_stamps)."""
+"""Tuning aid: per-stage shader-clock shares of the routed backward tile kernel (msda_debug_stamps)."""
 import argparse
 import ctypes
 import os
@@ -12,24 +12,17 @@ sys.path.insert(0, ROOT)
 from richsem_amd import _lib, workload as W   # noqa: E402
 from richsem_amd import MultiScaleDeformableAttention as MSDA   # noqa: E402
 
-NAMES = ["item header + value rows", "grad_out loads + clear + decode next", "resolve + ranks + gcache write", "scan",
-         "placement", "reduce (partial sums)", "corner dots", "combine", "fold + flush", "queue tail"]
-
+NAMES = ["item header + value rows", "entries + locations", "ranks", "scan", "placement", "reduce + dots", "combine", "fold + flush", "queue tail", "-"]
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--call", default="E")
     ap.add_argument("--loc", default="init")
     ap.add_argument("--opt", action="append", default=[])
-    ap.add_argument("--variant", type=int, default=4)
     args = ap.parse_args()
     lib = _lib.load()
     _lib.set_option("locality_monitor", 0)
-    _lib.set_option("bwd_variant", args.variant)
-    global NAMES
-    if args.variant == 4:
-        NAMES = ["item header + value rows", "entries + locations", "ranks", "scan", "placement", "reduce + dots", "combine",
-                 "fold + flush", "queue tail", "-"]
+    _lib.set_option("bwd_variant", 4)
     for kv in args.opt:
         k, v = kv.split("=")
         _lib.set_option(k, int(v))

@@ -15,7 +15,7 @@ call = W.call_E(2)
 for mode in ("init", "sigma4", "uniform"):
     t = W.make_inputs(call, mode, seed=0, device="cuda")
     v, go = t["value"].to(torch.bfloat16), t["grad_out"].to(torch.bfloat16)
-    for variant in (2, 4, 1):
+    for variant in (4, 1):
         _lib.set_option("bwd_variant", variant)
         fn = lambda: MSDA.ms_deform_attn_backward(v, t["shapes"], t["lsi"], t["loc"], t["aw"], go, 64)
         for _ in range(3):

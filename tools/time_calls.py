@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--calls", default="E,Dd")
     ap.add_argument("--loc", default="init,sigma4,uniform")
     ap.add_argument("--fwd", default="")
-    ap.add_argument("--bwd", default="0,2,3")
+    ap.add_argument("--bwd", default="1,4")
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--sets", type=int, default=4, help="distinct tensor sets cycled through (cache residency)")
