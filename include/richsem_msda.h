@@ -91,9 +91,10 @@ const char *msda_last_error(void);
  *                     it forgets what was learnt.  "locality_share_ppm" (get only): last measured share in parts per
  *                     million, -1 = none.  (The backward needs no monitor.)
  *   "rps_tile"        routed backward: largest tile side + 1 (4..16, default 16: tile + one row / column <= 256 pixels)
- *   "rps_max_chunks"  routed backward: chunks of 2048 points one workgroup takes before a tile's points are dealt over
+ *   "rps_max_chunks"  routed backward: chunks of 1536 points one workgroup takes before a tile's points are dealt over
  *                     several workgroups (default 12)
  *   "rps_route_wgs"   routed backward: workgroups per CU of the route passes (default 4)
+ *   "rps_seg_shift"   routed backward: a pixel's list is walked in units of at most 2^n sampling points (3..11, default 4)
  *   "levelsum_lds_kb" level-sum window size in KB (8..150, default 150 = one workgroup per CU)
  *   "bwd_direct_cpl"  channels per lane of the direct backward kernel (0 = auto, 1, 2, 4)
  *   "tile_region"     side of an LDS-window region, in pixels of the finest level (default 20)

@@ -421,11 +421,11 @@ bool rps_workspace(hipStream_t stream, size_t n_bins, size_t n_entries, Workspac
             if (hipMemsetAsync(ws.rps_bins, 0, ws.rps_bins_cap * sizeof(unsigned), stream) != hipSuccess) { (void)hipGetLastError(); return false; }
             ws.rps_dirty = false;
         }
-        if (ws.rps_entries_cap < n_entries) {
+        if (ws.rps_entries_cap < n_entries) {   // (+ the tile kernel's scratch lines behind the records)
             if (ws.rps_entries) (void)hipFree(ws.rps_entries);
             ws.rps_entries = nullptr;
             ws.rps_entries_cap = 0;
-            if (hipMalloc(reinterpret_cast<void **>(&ws.rps_entries), n_entries * sizeof(msda::RpsRec)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (hipMalloc(reinterpret_cast<void **>(&ws.rps_entries), n_entries * sizeof(msda::RpsRec) + msda::kRpsDummyBytes) != hipSuccess) { (void)hipGetLastError(); return false; }
             ws.rps_entries_cap = n_entries;
         }
     }
@@ -461,6 +461,7 @@ hipError_t launch_bwd_rps(const Problem &pb, const TV *value, const float *loc, 
     pl.g.bin_fill = pl.g.bin_count + ws.rps_bins_n * msda::kRpsPad;
     pl.g.bin_start = pl.g.bin_fill + ws.rps_bins_n * msda::kRpsPad;
     pl.g.entries = ws.rps_entries;
+    pl.g.dummy = reinterpret_cast<float *>(ws.rps_entries + ws.rps_entries_cap);
     pl.g.stamps = msda::tiled_options().stamps;
     pl.g.dbg = msda::tiled_options().dbg;
     auto kern = pb.P == 4 ? &msda::rps_tile_kernel<true, TV> : &msda::rps_tile_kernel<false, TV>;
@@ -476,7 +477,7 @@ hipError_t launch_bwd_rps(const Problem &pb, const TV *value, const float *loc, 
     hipLaunchKernelGGL(msda::rps_scan_kernel, dim3(1), dim3(1024), 0, stream, pl.g);
     hipLaunchKernelGGL(msda::rps_route_kernel<false>, dim3(rgrid), dim3(msda::kRpsRouteThreads), 0, stream, loc, aw, grad_acc, grad_loc,
                        grad_aw, pl.g);
-    const int grid = (cu_count() / msda::kXcds) * msda::kXcds * (1024 / msda::kRpsThreads);   // persistent: one workgroup per CU
+    const int grid = (cu_count() / msda::kXcds) * msda::kXcds;   // persistent: one workgroup per CU (its LDS is most of a CU's)
     hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 8), dim3(msda::kRpsThreads), sizeof(msda::RpsLds), stream, value, grad_out,
                        grad_value, grad_acc, grad_loc, grad_aw, pl.g);
     if constexpr (!std::is_same<TV, float>::value) {
@@ -928,6 +929,7 @@ int msda_set_option(const char *key, int value)
     if (key && !strcmp(key, "rps_tile") && value >= 4 && value <= 16) { msda::rps_options().tile = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_max_chunks") && value >= 1 && value <= 4096) { msda::rps_options().max_chunks = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_route_wgs") && value >= 1 && value <= 64) { msda::rps_options().route_wgs = value; return MSDA_OK; }
+    if (key && !strcmp(key, "rps_seg_shift") && value >= 3 && value <= 11) { msda::rps_options().seg_shift = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_direct_cpl") && (value == 0 || value == 1 || value == 2 || value == 4)) { g_bwd_cpl = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_region") && value >= 4 && value <= 64) { msda::tiled_options().region_px = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_margin") && value >= 0 && value <= 32) { msda::tiled_options().margin = value; return MSDA_OK; }
@@ -958,6 +960,7 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "rps_tile")) { *value = msda::rps_options().tile; return MSDA_OK; }
     if (key && !strcmp(key, "rps_max_chunks")) { *value = msda::rps_options().max_chunks; return MSDA_OK; }
     if (key && !strcmp(key, "rps_route_wgs")) { *value = msda::rps_options().route_wgs; return MSDA_OK; }
+    if (key && !strcmp(key, "rps_seg_shift")) { *value = msda::rps_options().seg_shift; return MSDA_OK; }
     if (key && !strcmp(key, "tile_region")) { *value = msda::tiled_options().region_px; return MSDA_OK; }
     if (key && !strcmp(key, "tile_margin")) { *value = msda::tiled_options().margin; return MSDA_OK; }
     if (key && !strcmp(key, "tile_persist")) { *value = msda::tiled_options().persist; return MSDA_OK; }

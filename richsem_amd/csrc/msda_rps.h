@@ -6,15 +6,18 @@
 // level), and a tile's workgroup pulls in exactly the sampling points that land on it.
 //
 //   route   (rps_route_kernel, two passes: count, then place at exact offsets)  one lane per sampling point: where does
-//           its corner (h_low, w_low) fall?  The point is appended -- 8 bytes: point index, position in the tile -- to the
+//           its corner (h_low, w_low) fall?  The point is appended -- a 16-byte record: position code, bilinear fractions,
+//           attention weight -- to the
 //           bin of that tile, and to the bin of the tile below / right of it when its lower / right corners cross the
 //           tile's edge.  Bins are exact (count -> scan -> place): no capacity guess, no overflow path.
 //   reduce  (rps_tile_kernel)  a workgroup takes a tile: its value rows (+ a one-pixel apron) go to LDS; the bin is
-//           walked in chunks of 2048 points: one lane per point re-derives the bilinear fractions, the points are
-//           sorted by the pixel under their corner (integer LDS atomics: count, scan, place), and eight lanes x four
-//           channels walk each pixel's list:  four partial sums (one per corner) += w * grad_out[q]  and the four
+//           walked in chunks of 1536 points: the points are sorted by the pixel under their corner (integer LDS
+//           atomics: count, scan, place), every pixel's list is cut into units of at most 16 points, and a quad (four
+//           lanes x eight channels) walks a unit:  four partial sums (one per corner) += w * grad_out[q]  and the four
 //           "corner dots" <grad_out[q], value[corner]> that grad_sampling_loc / grad_attn_weight are linear in.
-//           The partial sums stay in registers for the whole tile and are folded (pixel = BR + BL' + TR' + TL') once.
+//           A unit's partial sums are added to the tile's f64 sums in LDS (ds_add_f64, the native LDS float atomic
+//           of gfx950), so units -- not pixels -- are what the waves share out: a chunk's walk takes as long as its
+//           points need, not as long as its longest list.
 //
 // grad_value is written with plain stores, once per pixel -- no float atomics, no zero-fill, fp32 sums as in the
 // reference -- and value is read once.  Nothing depends on WHERE the points fall: uniform-random locations cost the same
@@ -31,13 +34,20 @@
 
 namespace msda {
 
-constexpr int kRpsThreads = 1024;              // (two 512-thread workgroups per CU with 128-pixel tiles measured slower: 479 vs 420 us)
-constexpr int kRpsMaxPx = kRpsThreads / 4;      // tile + one row / column: one quad (4 lanes x 8 channels) per base pixel
-constexpr int kRpsChunk = 2 * kRpsThreads;      // sampling points per chunk
+constexpr int kRpsThreads = 768;               // 12 waves = 3 per SIMD, 168 registers per lane (1024 threads at 128 registers spilled; 512 threads: same speed)
+constexpr int kRpsWaves = kRpsThreads / 64;
+constexpr int kRpsMaxPx = 256;                  // pixel grid of a tile (tile + one row / column): bound by LDS (f64 sums + value rows)
+constexpr int kRpsPpq = (kRpsMaxPx + kRpsThreads / 4 - 1) / (kRpsThreads / 4);   // pixels per quad where a quad stands for a pixel
+constexpr int kRpsRpl = 2;                      // records per lane and chunk
+constexpr int kRpsChunk = kRpsRpl * kRpsThreads;   // sampling points per chunk
+constexpr int kRpsSumStride = 36;               // doubles per pixel of the f64 sums (see RpsLds)
+constexpr int kRpsSegShift = 3;                 // a pixel's list is walked in segments ("units") of at most 8 points
+constexpr int kRpsMaxSegs = kRpsMaxPx + (kRpsChunk >> kRpsSegShift);   // units of a chunk: <= lists + points / 8
 constexpr int kRpsMaxL = 4;
 constexpr int kRpsMaxUnits = 448;
 constexpr int kRpsD = 32;
 constexpr int kRpsPad = 32;                     // atomically updated counters sit on lines of their own
+constexpr int kRpsDummyWgs = 2048, kRpsDummyBytes = kRpsDummyWgs * 1024;   // 1 KB per workgroup: 16 B per lane of a wave
 constexpr int kRpsQpBits = 19;                  // entry code: query * P + point below this bit (plan: Lq * P < 2^19)
 
 struct RpsLevel {
@@ -69,6 +79,9 @@ struct RpsGeom {
     unsigned *bin_start;    // [nbins + 1]        exclusive prefix
     unsigned *bin_fill;     // [nbins * kRpsPad]  place-pass cursors
     struct RpsRec *entries;         // one 16-byte record per (point, bin it was routed to)
+    int seg_shift;                  // a pixel's list is walked in units of at most 1 << seg_shift points (>= kRpsSegShift)
+    float *dummy;                   // kRpsDummyBytes of scratch: where the lanes that have nothing to store send their stores
+                                    // (every store instruction is then issued unconditionally: see rps_tile_kernel)
     unsigned long long *stamps;     // diagnostic runs only (msda_debug_stamps)
     int dbg;                        // diagnostic: bits 4..6 = 1 + level -> only that level's tiles do any work (wrong results)
 };
@@ -84,15 +97,19 @@ struct RpsCoef {
 struct RpsLds {
     int item_slot[2];                   // work-queue draws (current / next), double-buffered
     int wave_tot[16];
-    int pad[2];
+    int n_segs, pad[3];
     unsigned long long stamp_last, stamp_acc[14];
-    int offs[kRpsMaxPx + 4];            // histogram, then exclusive prefix
-    RpsEnt ent[kRpsChunk];              // sorted points of the chunk, then their corner dots; plane of the final fold
-    RpsRec meta[kRpsChunk];             // the routed records in ARRIVAL order (for the gradient combine); plane of the final fold
+    int offs[kRpsMaxPx + 4];            // histogram, then exclusive prefix: where a base pixel's list starts
+    unsigned short seg[kRpsMaxSegs + 16];   // walk units of the chunk: list | segment of the list << 8
+    RpsEnt ent[kRpsChunk];              // sorted points of the chunk, then their corner dots
+    RpsRec meta[kRpsChunk];             // the routed records in ARRIVAL order (for the gradient combine)
     unsigned short slot[kRpsChunk];     // arrival index -> sorted slot (where the point's four corner dots are found)
-    // value rows of the tile + apron, double-buffered: the rows of the NEXT work item are fetched while the last chunk's
-    // gradients are written.  The current buffer is the third plane of the final fold.
-    float vtile[2][kRpsMaxPx * kRpsD];
+    // grad_value of the tile's pixel grid: f64 sums (ds_add_f64), stored once per work item.  A pixel's row is 36 doubles and
+    // channel 4*j + i of a half sits in slot 4*i + j: the four lanes of a quad then add to four consecutive doubles, and the
+    // 16 quads of a wave -- consecutive pixels, usually -- spread over all 32 bank pairs (a 256-B row stride would put every
+    // quad on the same banks: 16-way conflicts on every atomic)
+    double sum[kRpsMaxPx * kRpsSumStride];
+    float vtile[kRpsMaxPx * kRpsD];     // value rows of the pixel grid
 };
 static_assert(sizeof(RpsLds) <= 160 * 1024, "rps: LDS budget");
 
@@ -228,7 +245,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         float at[kRpsMaxL];
 #pragma unroll
         for (int l = 0; l < kRpsMaxL; ++l) {
-            xy[l] = live && l < g.L && !(g.dbg & 4) ? *reinterpret_cast<const float2 *>(loc + 2u * (pt0 + (unsigned)(l * P))) : make_float2((g.dbg & 4) ? 0.001f * (float)(q & 511) : -4.f, (g.dbg & 4) ? 0.3f : -4.f);
+            xy[l] = live && l < g.L ? *reinterpret_cast<const float2 *>(loc + 2u * (pt0 + (unsigned)(l * P))) : make_float2(-4.f, -4.f);
             at[l] = !COUNT && live && l < g.L ? aw[pt0 + (unsigned)(l * P)] : 0.f;
         }
         __syncthreads();
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
             inmap[l] = t.inmap;
             const int ob = t.bin[0];
             const unsigned long long vote = __ballot(ob >= 0);
-            if (vote && !(g.dbg & 2)) {   // (uniform)
+            if (vote) {   // (uniform)
                 const int ld = __ffsll((long long)vote) - 1;
                 const int lb = __shfl(ob, ld, kWave);
                 const unsigned long long match = __ballot(ob == lb);
@@ -286,7 +303,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
             const unsigned c = hist[i];
             if (c) {
                 const size_t gb = (size_t)pair * B + i;
-                if (COUNT) { if (!(g.dbg & 1)) atomicAdd(g.bin_count + gb * kRpsPad, c); }
+                if (COUNT) atomicAdd(g.bin_count + gb * kRpsPad, c);
                 else base[i] = g.bin_start[gb] + atomicAdd(g.bin_fill + gb * kRpsPad, c);
             }
         }
@@ -407,23 +424,25 @@ struct RpsRow<bf16_t> {
     }
 };
 
-// Work decomposition: a QUAD (4 lanes x 8 channels) walks the list of one base pixel of the tile: four partial sums
-// (32 registers per lane) and -- while the list is walked -- the value rows of the pixel's four corners.  Packed fp32
-// arithmetic (v_pk_fma_f32) throughout: the kernel is bound by vector instruction issue (measured: VALU busy ~60 %,
-// one quad-cycle per instruction), so every FMA carries two channels and the per-point overhead (weights, the dot
-// reduction, the entry read) is shared by 8 channels per lane instead of 4.
-// List p stays on quad p, whose partial sums live in registers across the chunks of a tile.
-// Everything a work item needs from memory is requested while the previous one is still being reduced: the queue is drawn
-// two items ahead, the bin bounds of the next item are requested at the start of the current one, its first chunk of records and its value rows
-// (into the second value buffer) while the last chunk's gradients are written.
-// Registers are the scarce resource (128 at 1024 threads, ~110 of them in the list walk): work-item geometry is kept
-// uniform (SGPRs), per-lane positions are recomputed where needed, prefetches are unconditional loads from clamped addresses
-// (a conditional load ends in a register copy right behind it -- and with it a wait for the data).
+// Work decomposition: a QUAD (4 lanes x 8 channels) walks one unit -- at most 16 points of one base pixel's list -- with four
+// partial sums (32 registers per lane) and the value rows of the pixel's four corners in registers, packed fp32 arithmetic
+// (v_pk_fma_f32) throughout: every FMA carries two channels and the per-point overhead (weights, the dot reduction, the
+// entry read) is shared by 8 channels per lane.  After its unit the quad adds the partial sums to the tile's f64 sums in LDS
+// and takes the next unit (the waves take groups of 16 units in turn).  Measured before this structure (MI355X, call E,
+// init pattern): with ONE quad per pixel and the sums kept in registers for the whole tile, a chunk's walk lasted as long as
+// its longest list -- 2.3 to 3 times the mean list, and a quarter of the quads had no list at all -- so the walk ran at
+// 23 % of its lanes' capacity.
+// Everything a work item needs from memory is requested early: the queue is drawn two items ahead, the bin bounds of the
+// next item are requested at the start of the current one, its first chunk of records while the last chunk's gradients are
+// formed, the value rows at the start of the item (they are needed only by the walk, two stages later).
+// Stores are issued by every lane unconditionally (lanes with nothing to store write to the workgroup's scratch line): the
+// compiler can then count them, and a wait for an older load is s_waitcnt vmcnt(n), not vmcnt(0) -- which would hold the
+// wave until every scattered store has retired (vector-memory operations retire in order).
 // TV: storage type of value / grad_out / grad_value (float, or bf16_t with fp32 arithmetic).  grad_acc: where the levels whose
 // tiles are shared by several workgroups are accumulated with fp32 atomics -- grad_value itself for TV = float, an fp32 scratch
 // image of it for bf16 (rounded by rps_round_kernel afterwards).
 template <bool P4, typename TV = float>
-__global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
+__global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kernel(
     const TV *__restrict__ value, const TV *__restrict__ grad_out, TV *__restrict__ grad_value, float *__restrict__ grad_acc,
     float *__restrict__ grad_loc, float *__restrict__ grad_aw, const RpsGeom g)
 {
@@ -441,6 +460,7 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
     const int pairs = g.N * g.M;
     const int xq = blockIdx.x & (kXcds - 1);   // blocks equal mod 8 share an XCD (observed; speed only)
     const int n_items = g.nunits * g.ppx;
+    float *const dummy_w = g.dummy + (size_t)(blockIdx.x & (kRpsDummyWgs - 1)) * 256;   // this workgroup's 1 KB of scratch
     if (g.stamps && tid == 0) {
         for (int i = 0; i < 14; ++i) S->stamp_acc[i] = 0;
         S->stamp_last = __builtin_amdgcn_s_memtime();
@@ -490,29 +510,40 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
             }
         }
     };
-    RpsRec n_rec[2];   // this lane's two records of the chunk in flight (lanes past the end of the bin: a copy of its last record)
+    RpsRec n_rec[kRpsRpl];   // this lane's two records of the chunk in flight (lanes past the end of the bin: a copy of its last record)
     auto fetch_recs = [&](unsigned first_, int n_, int ch) {
         const unsigned first = (unsigned)rps_uni((int)first_);
         const int n = rps_uni(n_);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < kRpsRpl; ++u) {
             const int k = ch * kRpsChunk + u * kRpsThreads + tid;
             n_rec[u] = g.entries[n > 0 ? first + (unsigned)min(k, n - 1) : 0u];
         }
     };
-    // value rows of a work item's pixel grid: 32 B per lane.  Quads without a pixel, and pixels beyond the map, fetch a clamped
-    // (valid) row: nothing reads the former, and corners outside the map are masked where the gradients are formed.
-    float4 nv0, nv1;
+    // value rows of a work item's pixel grid: 32 B per lane and pixel, pixels `quad` and `quad + 192` (the second only where
+    // the grid has that many).  Pixels beyond the map fetch a clamped (valid) row: corners outside the map are masked where the
+    // gradients are formed.
+    float4 nv[kRpsPpq][2];
     auto fetch_rows = [&](const Item &it) {
-        const int gr_ = min(quad / it.gw, it.R1 - it.R0), gc_ = quad % it.gw;
-        const int prow_ = min(it.R0 + gr_, it.H - 1), pcol_ = min(it.C0 + gc_, it.W - 1);
-        const TV *src = value + ((int64_t)(it.b * g.S + g.lv[it.l].start + prow_ * it.W + pcol_) * g.M + it.m) * kRpsD;
-        nv0 = ld4(src + c_lo);
-        nv1 = ld4(src + c_hi);
+#pragma unroll
+        for (int r = 0; r < kRpsPpq; ++r) {
+            const int px = min(quad + r * (kRpsThreads / 4), max(it.npx - 1, 0));
+            const int gr_ = px / it.gw, gc_ = px - gr_ * it.gw;
+            const int prow_ = min(it.R0 + gr_, it.H - 1), pcol_ = min(it.C0 + gc_, it.W - 1);
+            const TV *src = value + ((int64_t)(it.b * g.S + g.lv[it.l].start + prow_ * it.W + pcol_) * g.M + it.m) * kRpsD;
+            nv[r][0] = ld4(src + c_lo);
+            nv[r][1] = ld4(src + c_hi);
+        }
     };
-    auto store_rows = [&](int buf) {
-        *reinterpret_cast<float4 *>(S->vtile[buf] + quad * kRpsD + c_lo) = nv0;
-        *reinterpret_cast<float4 *>(S->vtile[buf] + quad * kRpsD + c_hi) = nv1;
+    auto store_rows = [&]() {
+#pragma unroll
+        for (int r = 0; r < kRpsPpq; ++r) {
+            const int px = quad + r * (kRpsThreads / 4);
+            if (px < kRpsMaxPx) {
+                *reinterpret_cast<float4 *>(S->vtile + px * kRpsD + c_lo) = nv[r][0];
+                *reinterpret_cast<float4 *>(S->vtile + px * kRpsD + c_hi) = nv[r][1];
+            }
+        }
     };
 
     unsigned draw = 0;   // (thread 0) the queue draw in flight
@@ -529,8 +560,6 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
     n_ent = rps_uni(n_ent);
     fetch_recs(e_first, n_ent, 0);
     Item it = item_geom(item_id);
-    fetch_rows(it);
-    store_rows(0);
     int par = 0;
 
     while (item_id < n_items) {
@@ -541,31 +570,28 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         const int l = it.l, b = it.b, m = it.m, H = it.H, W = it.W, R0 = it.R0, R1 = it.R1, C0 = it.C0, C1 = it.C1, gw = it.gw;
         const int npx = it.npx;
         const int n_chunks = it.live ? (n_ent + kRpsChunk - 1) / kRpsChunk : 0;
-        const bool has_px = quad < npx;
         const int bq0 = b * g.Lq;
-        float *vt = S->vtile[par];
-        // ---- four partial sums of one base pixel (one per corner), 8 channels per lane ---------------------------------------
-        rps_v2f acc[4][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[k][c] = (rps_v2f){0.f, 0.f};
+        float *const vt = S->vtile;
+        // the item's value rows travel while its f64 sums are cleared and its first chunk is sorted (the list walk needs them)
+        fetch_rows(it);
+        for (int i = tid; i < kRpsMaxPx * kRpsSumStride / 2; i += kRpsThreads)
+            reinterpret_cast<double2 *>(S->sum)[i] = make_double2(0.0, 0.0);
         __syncthreads();
         const int next_id = rps_uni(S->item_slot[par ^ 1]);
         unsigned next_first;
         int next_n;
         bin_range(next_id, next_first, next_n);   // (made uniform where first used: that waits for the two loads)
         const Item nit = item_geom(next_id);
-        const int my_p = quad;   // the base pixel whose list this quad walks
+        store_rows();   // (read only behind the barriers of the first chunk's sort; an empty bin reads nothing)
         RPS_STAMP(0)
 
         for (int ch = 0; ch < n_chunks; ++ch) {
             const int n_here = min(kRpsChunk, n_ent - ch * kRpsChunk);
             // ---- (1) this lane's two points of the chunk: rank in the list of their base pixel -----------------------------------
             for (int i = tid; i <= npx; i += kRpsThreads) S->offs[i] = 0;
-            int pbase[2], pos[2];
+            int pbase[kRpsRpl], pos[kRpsRpl];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < kRpsRpl; ++u) {
                 pos[u] = -1;
                 // the record stays in the order the route pass wrote it: neighbouring lanes hold neighbouring points of a query, and the
                 // gradient stores of stage (5) -- taken in this order -- fall into 16 / 32 contiguous bytes per (query, level)
@@ -574,19 +600,21 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
             __syncthreads();
             RPS_STAMP(1)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < kRpsRpl; ++u) {
                 pbase[u] = (int)((n_rec[u].code >> kRpsQpBits) & 0xFFu);
                 if (u * kRpsThreads + tid < n_here) pos[u] = atomicAdd(&S->offs[pbase[u]], 1);
             }
             __syncthreads();
             RPS_STAMP(2)
 
-            // ---- (2) exclusive scan of the per-list counts (<= 256: one per thread of the first 4 waves) --------------------------
+            // ---- (2) exclusive scan of the per-list counts (<= 256: one per thread of the first 4 waves) and of the lists' unit
+            //      counts, both in one packed word (count | units << 16); every list writes its units -------------------------------
             {
-                int c = 0, incl = 0;
+                int c = 0, v = 0, incl = 0;
                 if (tid < kRpsMaxPx) {
                     c = tid < npx ? S->offs[tid] : 0;
-                    incl = c;
+                    v = c | ((c + (1 << g.seg_shift) - 1) >> g.seg_shift) << 16;
+                    incl = v;
 #pragma unroll
                     for (int d = 1; d < kWave; d <<= 1) {
                         const int t = __shfl_up(incl, d, kWave);
@@ -599,9 +627,14 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
                     int base = 0;
 #pragma unroll
                     for (int w = 0; w < kRpsMaxPx / kWave; ++w) base += w < wave ? S->wave_tot[w] : 0;
-                    const int excl = base + incl - c;
-                    if (tid <= npx) S->offs[tid] = excl;      // tid == npx: the total (c = 0 there)
-                    if (tid == kRpsMaxPx - 1 && npx == kRpsMaxPx) S->offs[npx] = base + incl;
+                    const int excl = base + incl - v;
+                    if (tid <= npx) S->offs[tid] = excl & 0xFFFF;      // tid == npx: the total (c = 0 there)
+                    if (tid == kRpsMaxPx - 1) {
+                        if (npx == kRpsMaxPx) S->offs[npx] = (base + incl) & 0xFFFF;
+                        S->n_segs = (base + incl) >> 16;
+                    }
+                    const int u0 = excl >> 16, nu = v >> 16;
+                    for (int sgm = 0; sgm < nu; ++sgm) S->seg[u0 + sgm] = (unsigned short)(tid | sgm << 8);
                 }
             }
             __syncthreads();
@@ -609,7 +642,7 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
 
             // ---- (3) records to their sorted slots ------------------------------------------------------------------------------------
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < kRpsRpl; ++u)
                 if (pos[u] >= 0) {
                     const int e = pos[u] + S->offs[pbase[u]];
                     const unsigned qp = n_rec[u].code & ((1u << kRpsQpBits) - 1u);
@@ -620,19 +653,20 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
             __syncthreads();
             RPS_STAMP(4)
 
-            // ---- (4) every quad walks a list: four partial sums and four corner dots per point; grad_out rows straight from
-            //      global memory, software-pipelined ---------------------------------------------------------------------------------
-            if (has_px) {
-                int e = S->offs[my_p];
-                const int e1 = S->offs[my_p + 1];
-                if (e < e1) {
+            // ---- (4) the waves take groups of 16 units in turn; a quad walks its unit: four partial sums and four corner dots per
+            //      point, grad_out rows straight from global memory, software-pipelined; then the sums go to the tile's f64 sums ----
+            const int n_segs = rps_uni(S->n_segs);
+            for (int u0 = wave * 16; u0 < n_segs; u0 += kRpsWaves * 16) {   // (uniform)
+                const int un = u0 + (lane >> 2);
+                if (un < n_segs) {
+                    const unsigned sc = S->seg[un];
+                    const int my_p = (int)(sc & 0xFFu);
+                    int e = S->offs[my_p] + (int)((sc >> 8) << g.seg_shift);
+                    const int e1 = min(e + (1 << g.seg_shift), S->offs[my_p + 1]);
                     // value rows of the four corner pixels (clamped into the grid: a corner above / left of row / column 0 of
                     // the grid lies outside the map or belongs to a point this tile does not form gradients for)
                     const int lr = my_p / gw, lc = my_p - lr * gw;
                     const int r0 = max(lr - 1, 0) * gw, c0 = max(lc - 1, 0);
-#define RPS_ROW(ITEM, ROW) ROW.load(grad_out + (int64_t)(ITEM) * kRpsD, c_lo, c_hi);
-#define RPS_COEF(E) (*reinterpret_cast<const RpsCoef *>(S->ent + (E)))
-                    const int e_last = e1 - 1;
                     rps_v2f v[4][4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -642,6 +676,11 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
                         v[k][0] = (rps_v2f){a0.x, a0.y}; v[k][1] = (rps_v2f){a0.z, a0.w};
                         v[k][2] = (rps_v2f){a1.x, a1.y}; v[k][3] = (rps_v2f){a1.z, a1.w};
                     }
+                    rps_v2f acc[4][4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[k][c] = (rps_v2f){0.f, 0.f};
 #define RPS_POINT(EN, ROW, E)                                                                                                    \
     {                                                                                                                            \
         const float hh = 1.f - EN.lh, hw = 1.f - EN.lw, ha = hh * EN.a, la = EN.lh * EN.a;                                       \
@@ -662,8 +701,11 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
         reinterpret_cast<float *>(S->ent + (E))[j4] = rps_quad_transpose_sum(d[0], d[1], d[2], d[3], j4);                        \
     }
                     // software pipeline: while point e is reduced, the grad_out row of point e + 1 is in flight and the row index
-                    // of point e + 2 is being read (the chain entry -> row address -> row is what a list walk waits for).  Only the
+                    // of point e + 2 is being read (the chain entry -> row address -> row is what a walk waits for).  Only the
                     // row index is read ahead; fractions and weight are read when the point is reduced (registers).
+#define RPS_ROW(ITEM, ROW) ROW.load(grad_out + (int64_t)(ITEM) * kRpsD, c_lo, c_hi);
+#define RPS_COEF(E) (*reinterpret_cast<const RpsCoef *>(S->ent + (E)))
+                    const int e_last = e1 - 1;
                     int itA = S->ent[e].item, itB = S->ent[min(e + 1, e_last)].item;
                     RpsRow<TV> gA, gB;
                     RPS_ROW(itA, gA)
@@ -688,110 +730,95 @@ __global__ __launch_bounds__(kRpsThreads, 1024 / 256) void rps_tile_kernel(
 #undef RPS_COEF
 #undef RPS_ROW
 #undef RPS_POINT
-                }
-            }
-            __syncthreads();
-            RPS_STAMP(5)
-            // the next chunk -- or the first chunk of the next work item -- travels while the gradients are written (requested
-            // only now: held across the list walk, the eight registers would spill)
-            const bool last_chunk = ch + 1 == n_chunks;
-            if (!last_chunk) fetch_recs(e_first, n_ent, ch + 1);
-            else {
-                fetch_recs(next_first, next_n, 0);
-                fetch_rows(nit);   // ... and so do the next item's value rows (their buffer was last read in the previous fold)
-            }
-
-            // ---- (5) gradients of the points this tile owns: one lane per record, in arrival order ----------------------------------
+                    // the unit's partial sums to the tile's f64 sums: corner k of base pixel p is pixel p-gw-1 / p-gw / p-1 / p of
+                    // the pixel grid, where that pixel exists (else it lies outside the map or in the tile above / to the left)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int k = u * kRpsThreads + tid;
-                if (k < n_here) {
-                    const RpsRec r = S->meta[k];
-                    if (r.code >> 31) {
-                        float4 d = *reinterpret_cast<const float4 *>(S->ent + S->slot[k]);
-                        const unsigned in = r.code >> 27;
-                        if (!(in & 1u)) d.x = 0.f;
-                        if (!(in & 2u)) d.y = 0.f;
-                        if (!(in & 4u)) d.z = 0.f;
-                        if (!(in & 8u)) d.w = 0.f;
-                        const float lh = r.lh, lw = r.lw, hh = 1.f - lh, hw = 1.f - lw;
-                        const float s_a = hh * hw * d.x + hh * lw * d.y + lh * hw * d.z + lh * lw * d.w;
-                        const float s_w = hh * (d.y - d.x) + lh * (d.w - d.z);
-                        const float s_h = hw * (d.z - d.x) + lw * (d.w - d.y);
-                        const unsigned qp = r.code & ((1u << kRpsQpBits) - 1u);
-                        const unsigned q = P4 ? qp >> 2 : qp / (unsigned)P, pp = qp - q * (unsigned)P;
-                        const unsigned pt = (unsigned)((bq0 + (int)q) * g.M + m) * (unsigned)LP + (unsigned)(l * P) + pp;
-                        grad_aw[pt] = s_a;
-                        *reinterpret_cast<float2 *>(grad_loc + 2u * pt) = make_float2((float)W * s_w * r.a, (float)H * s_h * r.a);
+                    for (int k = 0; k < 4; ++k) {
+                        const bool ok = (k >= 2 || lr >= 1) && ((k & 1) || lc >= 1);
+                        if (ok) {
+                            double *dst = S->sum + (my_p - (k < 2 ? gw : 0) - ((k & 1) ? 0 : 1)) * kRpsSumStride + j4;
+                            atomicAdd(dst, (double)acc[k][0].x);
+                            atomicAdd(dst + 4, (double)acc[k][0].y);
+                            atomicAdd(dst + 8, (double)acc[k][1].x);
+                            atomicAdd(dst + 12, (double)acc[k][1].y);
+                            atomicAdd(dst + 16, (double)acc[k][2].x);
+                            atomicAdd(dst + 20, (double)acc[k][2].y);
+                            atomicAdd(dst + 24, (double)acc[k][3].x);
+                            atomicAdd(dst + 28, (double)acc[k][3].y);
+                        }
                     }
                 }
             }
-            if (last_chunk) store_rows(par ^ 1);
+            // the next chunk -- or the first chunk of the next work item -- is requested now, behind the walk (held across it,
+            // the eight registers would spill) and AHEAD of this chunk's gradient stores
+            const bool last_chunk = ch + 1 == n_chunks;
+            if (!last_chunk) fetch_recs(e_first, n_ent, ch + 1);
+            else fetch_recs(next_first, next_n, 0);
+            __syncthreads();
+            RPS_STAMP(5)
+
+            // ---- (5) gradients of the points this tile owns: one lane per record, in arrival order; four store instructions issued
+            //      by every lane (see the kernel's header) ---------------------------------------------------------------------------
+            float ga_[kRpsRpl], gx_[kRpsRpl], gy_[kRpsRpl];
+            unsigned pt_[kRpsRpl];
+            bool mine_[kRpsRpl];
+#pragma unroll
+            for (int u = 0; u < kRpsRpl; ++u) {
+                const int k = min(u * kRpsThreads + tid, n_here - 1);
+                const RpsRec r = S->meta[k];
+                float4 d = *reinterpret_cast<const float4 *>(S->ent + S->slot[k]);
+                const unsigned in = r.code >> 27;
+                if (!(in & 1u)) d.x = 0.f;
+                if (!(in & 2u)) d.y = 0.f;
+                if (!(in & 4u)) d.z = 0.f;
+                if (!(in & 8u)) d.w = 0.f;
+                const float lh = r.lh, lw = r.lw, hh = 1.f - lh, hw = 1.f - lw;
+                const float s_a = hh * hw * d.x + hh * lw * d.y + lh * hw * d.z + lh * lw * d.w;
+                const float s_w = hh * (d.y - d.x) + lh * (d.w - d.z);
+                const float s_h = hw * (d.z - d.x) + lw * (d.w - d.y);
+                const unsigned qp = r.code & ((1u << kRpsQpBits) - 1u);
+                const unsigned q = P4 ? qp >> 2 : qp / (unsigned)P, pp = qp - q * (unsigned)P;
+                pt_[u] = (unsigned)((bq0 + (int)q) * g.M + m) * (unsigned)LP + (unsigned)(l * P) + pp;
+                mine_[u] = u * kRpsThreads + tid < n_here && (r.code >> 31);
+                ga_[u] = s_a;
+                gx_[u] = (float)W * s_w * r.a;
+                gy_[u] = (float)H * s_h * r.a;
+            }
+#pragma unroll
+            for (int u = 0; u < kRpsRpl; ++u) {
+                *(mine_[u] ? grad_aw + pt_[u] : dummy_w + lane) = ga_[u];
+                *(mine_[u] ? reinterpret_cast<float2 *>(grad_loc + 2u * pt_[u]) : reinterpret_cast<float2 *>(dummy_w) + lane) = make_float2(gx_[u], gy_[u]);
+            }
             // (the next chunk clears the histogram now -- its last reader was the list walk -- and rewrites the entries only
             // after three more barriers)
             RPS_STAMP(6)
         }
-        if (n_chunks == 0) {   // (an empty bin: nothing was fetched ahead)
-            fetch_recs(next_first, next_n, 0);
-            fetch_rows(nit);
-            store_rows(par ^ 1);
-        }
-        // ---- fold the partial sums: pixel x of the pixel grid = BR[x] + BL[x+1] + TR[x+gw] + TL[x+gw+1] of the base grid.  BR[x]
-        //      is this quad's own; the other three go through three LDS planes (entries, records and value rows are done with) ----
+        if (n_chunks == 0) fetch_recs(next_first, next_n, 0);   // (an empty bin: nothing was fetched ahead)
+        // ---- the tile's sums to grad_value: one 128-B row per pixel (two pixels per quad) ------------------------------------------
         __syncthreads();
-        {
-            float *plane[3] = {reinterpret_cast<float *>(S->ent), reinterpret_cast<float *>(S->meta), vt};   // TL, TR, BL
-            if (has_px) {
+        if (!g.lv[l].atomic) {   // (uniform)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    *reinterpret_cast<float4 *>(plane[k] + my_p * kRpsD + c_lo) = make_float4(acc[k][0].x, acc[k][0].y, acc[k][1].x, acc[k][1].y);
-                    *reinterpret_cast<float4 *>(plane[k] + my_p * kRpsD + c_hi) = make_float4(acc[k][2].x, acc[k][2].y, acc[k][3].x, acc[k][3].y);
-                }
+            for (int r = 0; r < kRpsPpq; ++r) {
+                const int px = quad + r * (kRpsThreads / 4);
+                const int pxc = min(px, kRpsMaxPx - 1);
+                const int gr = pxc / gw, gc = pxc - gr * gw;
+                const int prow = R0 + gr, pcol = C0 + gc;
+                const bool in_tile = px < npx && prow < R1 && pcol < C1;
+                const double *src = S->sum + pxc * kRpsSumStride + j4;
+                const int64_t px_off = ((int64_t)(b * g.S + g.lv[l].start + prow * W + pcol) * g.M + m) * kRpsD;
+                TV *const dst = in_tile ? grad_value + px_off : reinterpret_cast<TV *>(dummy_w) + 4 * lane - c_lo;
+                st4(dst + c_lo, make_float4((float)src[0], (float)src[4], (float)src[8], (float)src[12]));
+                st4(in_tile ? dst + c_hi : dst + c_lo, make_float4((float)src[16], (float)src[20], (float)src[24], (float)src[28]));
             }
-            __syncthreads();
-            float4 o0 = make_float4(acc[3][0].x, acc[3][0].y, acc[3][1].x, acc[3][1].y);
-            float4 o1 = make_float4(acc[3][2].x, acc[3][2].y, acc[3][3].x, acc[3][3].y);
-            const int gr = quad / gw, gc = quad - gr * gw;
-            const int prow = R0 + gr, pcol = C0 + gc;
-            const int64_t px_off = ((int64_t)(b * g.S + g.lv[l].start + prow * W + pcol) * g.M + m) * kRpsD;   // (+ c_lo / c_hi)
-            if (has_px) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    // BL: x + 1; TR: x + gw; TL: x + gw + 1 -- where those base pixels exist
-                    const int src = quad + (k == 2 || k == 0 ? 1 : 0) + (k < 2 ? gw : 0);
-                    const bool ok = (k == 1 || gc + 1 < gw) && (k == 2 || gr + 1 <= R1 - R0);
-                    if (ok) {
-                        const float4 t0 = *reinterpret_cast<const float4 *>(plane[k] + src * kRpsD + c_lo);
-                        const float4 t1 = *reinterpret_cast<const float4 *>(plane[k] + src * kRpsD + c_hi);
-                        o0.x += t0.x; o0.y += t0.y; o0.z += t0.z; o0.w += t0.w;
-                        o1.x += t1.x; o1.y += t1.y; o1.z += t1.z; o1.w += t1.w;
-                    }
-                }
-            }
-            // ---- flush the tile: one 128-B row per pixel ------------------------------------------------------------------------
-            const bool in_tile = has_px && prow < R1 && pcol < C1;
-            if (!g.lv[l].atomic) {
-                if (in_tile) {
-                    st4(grad_value + px_off + c_lo, o0);
-                    st4(grad_value + px_off + c_hi, o1);
-                }
-            } else if (n_chunks > 0) {
-                // several workgroups share the tile: hand the rows over through LDS and add them one channel per lane, so that
-                // a wave instruction adds two whole 128-B rows (32-B atomic segments run ~4x slower)
-                __syncthreads();
-                float *stage = reinterpret_cast<float *>(S->ent);
-                if (has_px) {
-                    *reinterpret_cast<float4 *>(stage + quad * kRpsD + c_lo) = o0;
-                    *reinterpret_cast<float4 *>(stage + quad * kRpsD + c_hi) = o1;
-                }
-                __syncthreads();
-                const int c32 = tid & 31;
-                const int64_t tile_base = ((int64_t)(b * g.S + g.lv[l].start) * g.M + m) * kRpsD + c32;
-                for (int p = tid >> 5; p < npx; p += kRpsThreads / 32) {
-                    const int pr = p / gw, row = R0 + pr, col = C0 + (p - pr * gw);
-                    const float x = stage[p * kRpsD + c32];
-                    if (row < R1 && col < C1 && x != 0.f) atomicAdd(grad_acc + tile_base + (int64_t)(row * W + col) * row_elems, x);
-                }
+        } else if (n_chunks > 0) {
+            // several workgroups share the tile: its rows are ADDED to the (pre-zeroed) level, one channel per lane, so that a wave
+            // instruction adds two whole 128-B rows (32-B atomic segments run ~4x slower)
+            const int c32 = tid & 31;
+            const int64_t tile_base = ((int64_t)(b * g.S + g.lv[l].start) * g.M + m) * kRpsD + c32;
+            for (int p = tid >> 5; p < npx; p += kRpsThreads / 32) {
+                const int pr = p / gw, row = R0 + pr, col = C0 + (p - pr * gw);
+                const float x = (float)S->sum[p * kRpsSumStride + (c32 & 16) + 4 * (c32 & 3) + ((c32 & 15) >> 2)];
+                if (row < R1 && col < C1 && x != 0.f) atomicAdd(grad_acc + tile_base + (int64_t)(row * W + col) * row_elems, x);
             }
         }
         __syncthreads();
@@ -826,9 +853,11 @@ __global__ __launch_bounds__(256) void rps_round_kernel(const float *__restrict_
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 struct RpsOptions {
-    std::atomic<int> tile{16};         // largest tile side + 1 (tile + one row / column <= 256 pixels)
+    std::atomic<int> tile{16};         // largest tile side + 1 (tile + one row / column <= kRpsMaxPx = 256 pixels)
     std::atomic<int> max_chunks{12};   // expected chunks of one workgroup before a tile is split into slabs (MI355X, call E: 6 -> 12 = 463 -> 447 us on uniform locations, equal at the init pattern)
     std::atomic<int> route_wgs{4};     // route passes: workgroups per CU (persistent over the query blocks)
+    std::atomic<int> seg_shift{4};     // units of the list walk: at most 1 << seg_shift points of a pixel's list (3..11; MI355X,
+                                       // call E, list walk: 8 -> 315 k cycles per workgroup, 16 -> 301 k, 32 -> 330 k, whole lists -> 347 k)
 };
 inline RpsOptions &rps_options()
 {
@@ -858,6 +887,7 @@ inline RpsPlan plan_rps(int N, int S, int M, int D, int L, int Lq, int P, const 
     if (n_pts >= ((int64_t)1 << 31) || (int64_t)Lq * P >= ((int64_t)1 << kRpsQpBits)) return pl;
     RpsGeom &g = pl.g;
     g.N = N; g.S = S; g.M = M; g.Lq = Lq; g.L = L; g.P = P;
+    g.seg_shift = std::max(kRpsSegShift, std::min(11, rps_options().seg_shift.load()));
     g.ppx = (N * M + kXcds - 1) / kXcds;
     const int tmax = std::max(1, rps_options().tile.load() - 1), max_chunks = std::max(1, rps_options().max_chunks.load());
     struct U { unsigned code; int64_t cost; };
