@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RICHSEM_MSDA_ABI_VERSION 4
+#define RICHSEM_MSDA_ABI_VERSION 5
 
 /* Return codes: 0 = success; negative = argument error detected on the host (nothing was
  * launched); positive = hipError_t reported by the runtime. */
@@ -403,10 +403,32 @@ int msda_add_layernorm_forward_bf16(const uint16_t *a, const uint16_t *b, const 
 /* out = act(x W^T + b) for in_features = 256 on the matrix cores (csrc/lin256_mfma.hip; bf16 storage, fp32 accumulation): the two
  * token-parallel products of the feed-forward block's backward.  msda_lin256_pack_bf16: W (out_features, 256) bf16 row-major -> the same
  * number of elements in MFMA fragment order (out_features % 64 == 0).  epilogue 0: acc + bias (bias may be NULL); 1: relu(acc + bias);
- * 2: acc where relu_mask > 0, else 0 (relu_mask (tokens, out_features) bf16: the forward's hidden activation).  16-byte aligned pointers. */
+ * 2: acc where relu_mask > 0, else 0 (relu_mask (tokens, out_features) bf16: the forward's hidden activation); 3: acc + bias with the
+ * rows of masked tokens zeroed (relu_mask then points to `tokens` bytes, non-zero = masked: MSDeformAttn's value projection with its
+ * padding mask, ops/modules/ms_deform_attn.py:94-96).  16-byte aligned pointers (the byte mask of epilogue 3: any alignment). */
 int msda_lin256_pack_bf16(const uint16_t *w, int out_features, int in_features, uint16_t *packed, msda_stream_t stream);
 int msda_lin256_forward_bf16(const uint16_t *x, const uint16_t *packed_w, const float *bias, const uint16_t *relu_mask, int epilogue,
                              int tokens, int in_features, int out_features, uint16_t *out, msda_stream_t stream);
+/* Several 256 -> 256 layers stacked into one product (out_features = 256 * layers, W and bias concatenated along the outputs): out is
+ * `layers` separate contiguous (tokens, 256) matrices, one after the other; row_mask (tokens bytes, non-zero = zero that token's rows)
+ * may be NULL.  The decoder's cross-attention value projections of all its layers: the memory is read once. */
+int msda_lin256_forward_stacked_bf16(const uint16_t *x, const uint16_t *packed_w, const float *bias, const uint8_t *row_mask, int tokens,
+                                     int in_features, int out_features, uint16_t *out, msda_stream_t stream);
+/* Masked multi-head self-attention of the decoder's queries (csrc/attn_mfma.hip; reference: nn.MultiheadAttention of
+ * DeformableTransformerDecoderLayer, models/richsem/deformable_transformer.py:907, :974-978): softmax(q k^T / sqrt(32) + mask) v per
+ * (image, head), head dimension 32, bf16 storage, fp32 softmax -- new capability (the reference runs torch's fp32 attention).
+ * Sequence-first tokens: token (i, b) is row i * bs + b of q / k / v (`ld*` elements apart, a head's 32 channels at column 32 h);
+ * out / dout (nq, bs, heads * 32) contiguous; lse (bs * heads, ceil32(nq)) f32: log2-sum-exp per query, written by the forward, read by
+ * the backward; mask_bits (nq, ceil(nq / 32)) uint32: bit j of word (q, kb) set = query q must not attend to key 32 kb + j;
+ * maskt_bits the same of the transposed mask (both NULL = no mask); workspace: msda_attn_workspace_bytes(nq, bs, heads) bytes.
+ * 16-byte aligned pointers, ld* multiples of 8.  Every element of out / dq / dk / dv is written. */
+int64_t msda_attn_workspace_bytes(int nq, int bs, int heads);
+int msda_attn_forward_bf16(const uint16_t *q, int ldq, const uint16_t *k, int ldk, const uint16_t *v, int ldv, const uint32_t *mask_bits,
+                           int nq, int bs, int heads, uint16_t *out, float *lse, void *workspace, msda_stream_t stream);
+int msda_attn_backward_bf16(const uint16_t *q, int ldq, const uint16_t *k, int ldk, const uint16_t *v, int ldv, const uint16_t *out,
+                            const uint16_t *dout, const float *lse, const uint32_t *mask_bits, const uint32_t *maskt_bits, int nq, int bs,
+                            int heads, uint16_t *dq, int lddq, uint16_t *dk, int lddk, uint16_t *dv, int lddv, void *workspace,
+                            msda_stream_t stream);
 /* The same product for fp32 tensors at fp32-level accuracy (both operands split into bf16 hi + lo parts, three bf16 MFMAs per tile;
  * csrc/lin256_mfma.hip): out (tokens, out_features) f32 = x (tokens, 256) f32 . W^T + bias.  msda_lin256_pack_f32: W (out_features, 256)
  * f32 -> 2 * out_features * 256 uint16 (hi and lo parts in fragment order); out_features % 32 == 0.  The MSDeformAttn module's fp32

@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "librichsem_msda.so")
-SOURCES = ["msda_api.hip", "ffn_mfma.hip", "rows_api.hip", "cls_mfma.hip", "conv_mfma.hip", "conv_wgrad.hip", "lin256_mfma.hip"]
+SOURCES = ["msda_api.hip", "ffn_mfma.hip", "rows_api.hip", "cls_mfma.hip", "conv_mfma.hip", "conv_wgrad.hip", "lin256_mfma.hip", "attn_mfma.hip"]
 def _headers():
     """every header the library is built from: csrc/*.h and include/*.h (globbed, so a new kernel header can never be
     forgotten by the staleness check)"""

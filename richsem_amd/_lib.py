@@ -16,7 +16,7 @@ ERR_NAMES = {
     -4: "MSDA_ERR_TOO_LARGE", -5: "MSDA_ERR_MISALIGNED", -6: "MSDA_ERR_NO_DEVICE", -7: "MSDA_ERR_BAD_OPTION",
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/richsem_msda.h declares
 SYMBOLS = [
@@ -28,7 +28,8 @@ SYMBOLS = [
     "msda_prep_forward_bf16", "msda_prep_backward_bf16",
     "msda_mask_rows_f32", "msda_mask_rows_f64", "msda_mask_rows_bf16",
     "msda_dn_indices_i64", "msda_dn_attn_mask_u8", "msda_topk_f32", "msda_roi_align_forward_f32", "msda_roi_align_forward_f64",
-    "msda_ffn_pack_w2_bf16", "msda_ffn_forward_bf16", "msda_ffn_debug_stamps", "msda_ffn_forward_train_bf16", "msda_ffn_ln_backward_bf16", "msda_add_layernorm_forward_bf16", "msda_lin256_pack_bf16", "msda_lin256_forward_bf16", "msda_lin256_pack_f32", "msda_lin256_forward_f32",
+    "msda_ffn_pack_w2_bf16", "msda_ffn_forward_bf16", "msda_ffn_debug_stamps", "msda_ffn_forward_train_bf16", "msda_ffn_ln_backward_bf16", "msda_add_layernorm_forward_bf16", "msda_lin256_pack_bf16", "msda_lin256_forward_bf16", "msda_lin256_pack_f32", "msda_lin256_forward_f32", "msda_lin256_forward_stacked_bf16",
+    "msda_attn_workspace_bytes", "msda_attn_forward_bf16", "msda_attn_backward_bf16",
     "msda_matcher_cost_f32", "msda_matcher_cost_f64", "msda_attnpool_core_f32", "msda_attnpool_core_f64",
     "msda_cls_packed_elems", "msda_cls_pack", "msda_cls_max_scores",
     "msda_conv_set_tiling", "msda_conv_packed_elems", "msda_conv_pack_weight", "msda_conv_forward_bf16", "msda_conv_dgrad_bf16", "msda_pool_nhwc_bf16", "msda_groupnorm8_nhwc_bf16", "msda_conv_wgrad_workspace_bytes", "msda_conv_wgrad_bf16",
@@ -140,6 +141,14 @@ def load():
     L.msda_lin256_pack_f32.restype = ci
     L.msda_lin256_forward_f32.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp]
     L.msda_lin256_forward_f32.restype = ci
+    L.msda_lin256_forward_stacked_bf16.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp]
+    L.msda_lin256_forward_stacked_bf16.restype = ci
+    L.msda_attn_workspace_bytes.argtypes = [ci, ci, ci]
+    L.msda_attn_workspace_bytes.restype = ctypes.c_int64
+    L.msda_attn_forward_bf16.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, vp, vp, vp, vp]
+    L.msda_attn_forward_bf16.restype = ci
+    L.msda_attn_backward_bf16.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp, vp]
+    L.msda_attn_backward_bf16.restype = ci
     for sfx in ("f32", "f64", "bf16"):
         f = getattr(L, "msda_forward_" + sfx)
         f.argtypes = [vp] * 5 + [ci] * 8 + [vp, vp, vp, vp]

@@ -51,11 +51,13 @@ __global__ void lin256_pack_kernel(const uint16_t *__restrict__ w, uint16_t *__r
     }
 }
 
-// EPI 0: out = acc + bias;  1: out = relu(acc + bias);  2: out = acc * (mask > 0)
+// EPI 0: out = acc + bias;  1: out = relu(acc + bias);  2: out = acc * (mask > 0);  3: out = acc + bias, rows with a non-zero byte in
+// the row mask (`mask` read as one uint8 per token: the padding mask of MSDeformAttn's value projection,
+// ops/modules/ms_deform_attn.py:94-96) zeroed
 template <int EPI>
 __global__ __launch_bounds__(kWaves * 64, 2)      // two workgroups per CU: one's stores / conversions under the other's MFMAs
 void lin256_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ packed, const float *__restrict__ bias,
-                   const uint16_t *__restrict__ mask, int T, int N, uint16_t *__restrict__ out)
+                   const uint16_t *__restrict__ mask, int T, int N, uint16_t *__restrict__ out, long long chunk_elems)
 {
     __shared__ __attribute__((aligned(16))) short wbuf[2][kBlockShorts];
 
@@ -149,13 +151,18 @@ void lin256_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ 
                     if (!(bf16_hi(mw[e]) > 0.f)) y[2 * e + 1] = 0.f;
                 }
             } else {
+                const bool dead = EPI == 3 && reinterpret_cast<const uint8_t *>(mask)[tok] != 0;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     y[e] += bb[e];
                     if (EPI == 1) y[e] = fmaxf(y[e], 0.f);
+                    if (EPI == 3 && dead) y[e] = 0.f;
                 }
             }
-            u32x4 *op = reinterpret_cast<u32x4 *>(out + (size_t)tok * N + ch0);
+            // chunk_elems != 0: the output is N / 256 separate (T, 256) matrices, chunk_elems apart (several 256-wide layers stacked
+            // into one product, each with a contiguous result of its own)
+            u32x4 *op = reinterpret_cast<u32x4 *>(chunk_elems ? out + (size_t)(ch0 >> 8) * chunk_elems + (size_t)tok * 256 + (ch0 & 255)
+                                                              : out + (size_t)tok * N + ch0);
             op[0] = (u32x4){pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7])};
             op[1] = (u32x4){pack_bf16(y[8], y[9]), pack_bf16(y[10], y[11]), pack_bf16(y[12], y[13]), pack_bf16(y[14], y[15])};
         }
@@ -280,13 +287,13 @@ void lin256_f32_kernel(const float *__restrict__ x, const uint16_t *__restrict__
 
 template <int EPI>
 int launch_lin(const uint16_t *x, const uint16_t *packed, const float *bias, const uint16_t *mask, int T, int N, uint16_t *out,
-               hipStream_t st)
+               hipStream_t st, long long chunk_elems = 0)
 {
     const int gx = (T + kTokWg - 1) / kTokWg, nb = N / kBlockRows;
     int gy = (512 + gx - 1) / gx;          // about two workgroups per CU
     if (gy > nb) gy = nb;
     if (gy > 8) gy = 8;
-    hipLaunchKernelGGL(lin256_kernel<EPI>, dim3(gx, gy), dim3(kWaves * 64), 0, st, x, packed, bias, mask, T, N, out);
+    hipLaunchKernelGGL(lin256_kernel<EPI>, dim3(gx, gy), dim3(kWaves * 64), 0, st, x, packed, bias, mask, T, N, out, chunk_elems);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
 }
@@ -308,19 +315,35 @@ int msda_lin256_forward_bf16(const uint16_t *x, const uint16_t *packed_w, const 
                              int tokens, int in_features, int out_features, uint16_t *out, msda_stream_t stream)
 {
     if (!x || !packed_w || !out) return MSDA_ERR_NULL_POINTER;
-    if (tokens < 0 || in_features != kD || out_features < kBlockRows || out_features % kBlockRows != 0 || epilogue < 0 || epilogue > 2)
+    if (tokens < 0 || in_features != kD || out_features < kBlockRows || out_features % kBlockRows != 0 || epilogue < 0 || epilogue > 3)
         return MSDA_ERR_BAD_DIMS;
-    if (epilogue == 2 && !relu_mask) return MSDA_ERR_NULL_POINTER;
+    if (epilogue >= 2 && !relu_mask) return MSDA_ERR_NULL_POINTER;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed_w) | reinterpret_cast<uintptr_t>(out) |
-         reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(relu_mask)) & 15)
+         reinterpret_cast<uintptr_t>(bias) | (epilogue == 2 ? reinterpret_cast<uintptr_t>(relu_mask) : 0)) & 15)
         return MSDA_ERR_MISALIGNED;
     if (tokens == 0) return MSDA_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (epilogue) {
     case 0: return launch_lin<0>(x, packed_w, bias, nullptr, tokens, out_features, out, st);
     case 1: return launch_lin<1>(x, packed_w, bias, nullptr, tokens, out_features, out, st);
-    default: return launch_lin<2>(x, packed_w, nullptr, relu_mask, tokens, out_features, out, st);
+    case 2: return launch_lin<2>(x, packed_w, nullptr, relu_mask, tokens, out_features, out, st);
+    default: return launch_lin<3>(x, packed_w, bias, relu_mask, tokens, out_features, out, st);
     }
+}
+
+int msda_lin256_forward_stacked_bf16(const uint16_t *x, const uint16_t *packed_w, const float *bias, const uint8_t *row_mask, int tokens,
+                                     int in_features, int out_features, uint16_t *out, msda_stream_t stream)
+{
+    if (!x || !packed_w || !out) return MSDA_ERR_NULL_POINTER;
+    if (tokens < 0 || in_features != kD || out_features < 256 || out_features % 256 != 0) return MSDA_ERR_BAD_DIMS;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed_w) | reinterpret_cast<uintptr_t>(out) |
+         reinterpret_cast<uintptr_t>(bias)) & 15)
+        return MSDA_ERR_MISALIGNED;
+    if (tokens == 0) return MSDA_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long chunk = (long long)tokens * 256;
+    if (row_mask) return launch_lin<3>(x, packed_w, bias, reinterpret_cast<const uint16_t *>(row_mask), tokens, out_features, out, st, chunk);
+    return launch_lin<0>(x, packed_w, bias, nullptr, tokens, out_features, out, st, chunk);
 }
 
 int msda_lin256_pack_f32(const float *w, int out_features, int in_features, uint16_t *packed, msda_stream_t stream)

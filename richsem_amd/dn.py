@@ -56,7 +56,9 @@ def prepare_dn_layout(known_num, dn_number, num_queries, use_cdn=True, add_gt=Fa
         negative_idx = positive_idx + total
         if use_cdn:
             group_pad = single_pad * 2
-        else:   # dn_components.py:144-151: the negative halves are dropped
+        else:   # dn_components.py:144-151: the negative halves are dropped; positive_idx now selects the padded slots of the
+            # positive halves (single_pad per group), the caller applies it to the padded query tensors
+            positive_idx = (torch.arange(single_pad, dtype=torch.int64, device=dev)[None, :] + grp * (single_pad * 2)).flatten()
             pad_size = pad_size // 2
             group_pad = single_pad
         tgt = pad_size + num_queries

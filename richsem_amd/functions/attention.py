@@ -1,0 +1,102 @@
+"""Masked multi-head self-attention of the decoder's queries on the library's MFMA kernels (csrc/attn_mfma.hip; SURVEY.md section 8
+row a9): what ``nn.MultiheadAttention`` computes between its input and output projections in
+``DeformableTransformerDecoderLayer.forward_sa`` (reference models/richsem/deformable_transformer.py:974-978) --
+``softmax(q k^T / sqrt(head_dim) + mask) v`` per (image, head) -- forward and backward, bf16 storage, fp32 softmax, head dimension 32,
+sequence-first tensors.  The (nq, nq) score matrix never exists; the boolean mask (True = not allowed, the reference's convention)
+travels as bits.  There is no CPU path.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _lib
+
+_MASK_CACHE = {}
+
+
+def mask_bits(mask):
+    """(nq, nq) bool, True = masked -> (bits (nq, nkb) int32: bit j of word (q, kb) = mask[q, 32 kb + j]; the same of the transposed
+    mask), kept for as long as the mask tensor is unchanged (the six layers of the decoder pass the same tensor)"""
+    key = (mask.data_ptr(), mask._version, tuple(mask.shape), mask.device)
+    hit = _MASK_CACHE.get("last")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    assert mask.dtype == torch.bool and mask.dim() == 2 and mask.shape[0] == mask.shape[1]
+    nq = mask.shape[0]
+    nkb = (nq + 31) // 32
+    w = (1 << torch.arange(32, device=mask.device, dtype=torch.int64))
+
+    def to_i32(m):
+        v = (torch.zeros((nq, nkb * 32), dtype=torch.int64, device=mask.device))
+        v[:, :nq] = m
+        s = (v.view(nq, nkb, 32) * w).sum(-1)
+        s = torch.where(s >= 2 ** 31, s - 2 ** 32, s)
+        return s.to(torch.int32).contiguous()
+
+    val = (to_i32(mask), to_i32(mask.t()))
+    _MASK_CACHE["last"] = (key, val)
+    return val
+
+
+def _check_strides(t, bs):
+    assert t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == bs * t.stride(1), \
+        "attention: sequence-first (nq, bs, C) bf16 tensors whose tokens are evenly strided"
+    return t.stride(1)
+
+
+def _ws(nq, bs, heads, device):
+    n = _lib.load().msda_attn_workspace_bytes(nq, bs, heads)
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+class MaskedSelfAttentionFunction(Function):
+    """apply(qk, v, mask, n_heads): qk (nq, bs, 2 C) bf16 -- queries in [..., :C], keys in [..., C:], the output of ONE stacked
+    projection -- v (nq, bs, C) bf16, mask (nq, nq) bool (True = masked) or None -> (nq, bs, C) bf16"""
+
+    @staticmethod
+    def forward(ctx, qk, v, mask, n_heads):
+        if not qk.is_cuda:
+            raise RuntimeError("Not implemented on the CPU")
+        nq, bs, c2 = qk.shape
+        C = c2 // 2
+        assert C == n_heads * 32 and v.shape == (nq, bs, C), "attention kernels: head dimension 32"
+        qk, v = qk.contiguous(), v.contiguous()
+        bits = mask_bits(mask) if mask is not None else (None, None)
+        nqp = (nq + 31) // 32 * 32
+        out = torch.empty((nq, bs, C), dtype=torch.bfloat16, device=qk.device)
+        lse = torch.empty((bs * n_heads, nqp), dtype=torch.float32, device=qk.device)
+        ws = _ws(nq, bs, n_heads, qk.device)
+        esz = 2
+        with torch.cuda.device(qk.device):
+            _lib.check(_lib.load().msda_attn_forward_bf16(
+                qk.data_ptr(), c2, qk.data_ptr() + C * esz, c2, v.data_ptr(), C, bits[0].data_ptr() if bits[0] is not None else None,
+                nq, bs, n_heads, out.data_ptr(), lse.data_ptr(), ws.data_ptr(), torch.cuda.current_stream(qk.device).cuda_stream))
+        ctx.save_for_backward(qk, v, out, lse, *(b for b in bits if b is not None))
+        ctx.meta = (n_heads, mask is not None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        saved = ctx.saved_tensors
+        qk, v, out, lse = saved[:4]
+        n_heads, has_mask = ctx.meta
+        bits = saved[4:6] if has_mask else (None, None)
+        nq, bs, c2 = qk.shape
+        C = c2 // 2
+        dout = dout.contiguous()
+        dqk, dv = torch.empty_like(qk), torch.empty_like(v)
+        ws = _ws(nq, bs, n_heads, qk.device)
+        with torch.cuda.device(qk.device):
+            _lib.check(_lib.load().msda_attn_backward_bf16(
+                qk.data_ptr(), c2, qk.data_ptr() + C * 2, c2, v.data_ptr(), C, out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                bits[0].data_ptr() if has_mask else None, bits[1].data_ptr() if has_mask else None, nq, bs, n_heads,
+                dqk.data_ptr(), c2, dqk.data_ptr() + C * 2, c2, dv.data_ptr(), C, ws.data_ptr(),
+                torch.cuda.current_stream(qk.device).cuda_stream))
+        return dqk, dv, None, None
+
+
+def masked_self_attention(qk, v, mask, n_heads):
+    return MaskedSelfAttentionFunction.apply(qk, v, mask, n_heads)

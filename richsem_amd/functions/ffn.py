@@ -114,6 +114,57 @@ class FusedFFNFunction(Function):
         return grad_x, grad_w1, grad_b1, grad_w2, grad_b2, grad_ln_w, grad_ln_b, None
 
 
+def add_layernorm_forward_bf16(a2, b2, ln_weight32, ln_bias32, eps, need_backward=True):
+    """LayerNorm(a2 + b2) over 256 channels, (tokens, 256) bf16 -> out, and (for the backward) rstd (tokens) f32, yhat (tokens, 256) bf16"""
+    out = torch.empty_like(a2)
+    rstd = torch.empty(a2.shape[0], dtype=torch.float32, device=a2.device) if need_backward else None
+    yhat = torch.empty_like(a2) if need_backward else None
+    with torch.cuda.device(a2.device):
+        _lib.check(_lib.load().msda_add_layernorm_forward_bf16(
+            a2.data_ptr(), b2.data_ptr(), ln_weight32.data_ptr(), ln_bias32.data_ptr(), float(eps), a2.shape[0], 256, out.data_ptr(),
+            rstd.data_ptr() if need_backward else None, yhat.data_ptr() if need_backward else None, _stream(a2)))
+    return out, rstd, yhat
+
+
+class FFNSmallFunction(Function):
+    """The feed-forward block ``LayerNorm(x + linear2(relu(linear1(x))))`` for FEW tokens (the decoder's ~2 k queries, where the
+    one-kernel forward of :class:`FusedFFNFunction` leaves most CUs idle): first product with bias + ReLU on ``lin256``, second
+    product (K = d_ffn) on the library's bf16 GEMM, residual + LayerNorm as one kernel; backward: LayerNorm gradient + token sums in
+    one kernel, the gradient at the ReLU's input on ``lin256`` (mask epilogue), weight gradients as transposed GEMMs.
+    ``apply(x, pk1, w2_16, w2t_packed, eps, w1, b1, w2, b2, ln_weight, ln_bias)``: ``pk1`` = pack_linear256 of linear1, ``w2_16`` =
+    linear2.weight in bf16, ``w2t_packed`` = lin256_pack of its transpose (kept by the caller); the last six are the parameters the
+    gradients go to."""
+
+    @staticmethod
+    def forward(ctx, x, pk1, w2_16, w2t_packed, eps, w1, b1, w2, b2, ln_weight, ln_bias):
+        from .linear import lin256
+        x2 = x.reshape(-1, 256).contiguous()
+        h = lin256(x2, pk1["packed"], pk1["b32"], relu=True)
+        y = torch.addmm(b2.detach().to(torch.bfloat16), h, w2_16.t())
+        lw, lb = ln_weight.detach().float().contiguous(), ln_bias.detach().float().contiguous()
+        out, rstd, yhat = add_layernorm_forward_bf16(x2, y, lw, lb, eps)
+        ctx.save_for_backward(x2, h, yhat, rstd, lw, w2t_packed, pk1["w16"])
+        ctx.meta = (x.shape, tuple(p.dtype for p in (w1, b1, w2, b2, ln_weight, ln_bias)))
+        return out.view(x.shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        from .linear import lin256
+        x2, h, yhat, rstd, lw, w2t_packed, w1_16 = ctx.saved_tensors
+        shape, dts = ctx.meta
+        dz, g_lnw, g_lnb, g_b2 = ffn_ln_backward_bf16(grad_out.to(torch.bfloat16), yhat, rstd, lw)
+        need = ctx.needs_input_grad
+        g_w2 = _wgrad(dz, h).to(dts[2]) if need[7] else None
+        gh = lin256(dz, w2t_packed, relu_mask=h)
+        g_w1 = g_b1 = None
+        if need[5] or need[6]:
+            g_w1, g_b1 = _wgrad(gh, x2, with_bias=True)
+            g_w1, g_b1 = g_w1.to(dts[0]), g_b1.to(dts[1])
+        dx = torch.addmm(dz, gh, w1_16).view(shape) if need[0] else None
+        return dx, None, None, None, None, g_w1, g_b1, g_w2, g_b2.to(dts[3]), g_lnw.to(dts[4]), g_lnb.to(dts[5])
+
+
 class AddLayerNormFunction(Function):
     """``LayerNorm(a + b)`` over 256 channels in bf16 (the layers' norm1 around the attention's residual, reference
     deformable_transformer.py:876-877 with the dropout inactive) as one kernel forward (``msda_add_layernorm_forward_bf16``) and one

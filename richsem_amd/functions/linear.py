@@ -99,20 +99,27 @@ def lin256_pack(weight):
     return packed
 
 
-def lin256(x, packed_w, bias=None, relu=False, relu_mask=None):
+def lin256(x, packed_w, bias=None, relu=False, relu_mask=None, row_mask=None):
     """x (T, 256) bf16 -> (T, out_features) bf16: ``x W^T + bias`` (``relu``: with ReLU), or ``(x W^T) * (relu_mask > 0)`` when
-    ``relu_mask`` (T, out_features) bf16 is given (the gradient at a ReLU's input from the gradient at its output)"""
+    ``relu_mask`` (T, out_features) bf16 is given (the gradient at a ReLU's input from the gradient at its output), or
+    ``x W^T + bias`` with the rows of masked tokens zeroed when ``row_mask`` (T,) bool is given (MSDeformAttn's value projection
+    with its padding mask, ops/modules/ms_deform_attn.py:94-96)"""
     assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256
     x = x.contiguous()
     N = packed_w.shape[0]
     out = torch.empty((x.shape[0], N), dtype=torch.bfloat16, device=x.device)
     if relu_mask is not None:
         assert relu_mask.shape == out.shape and relu_mask.dtype == torch.bfloat16 and relu_mask.is_contiguous() and bias is None
+    aux = relu_mask
     epi = 2 if relu_mask is not None else (1 if relu else 0)
-    b = bias.detach().float().contiguous() if bias is not None else None
+    if row_mask is not None:
+        assert relu_mask is None and not relu and row_mask.dtype == torch.bool and row_mask.numel() == x.shape[0]
+        aux, epi = row_mask.contiguous().view(torch.uint8), 3
+    b = bias if bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and not bias.requires_grad) \
+        else bias.detach().float().contiguous()
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().msda_lin256_forward_bf16(x.data_ptr(), packed_w.data_ptr(), b.data_ptr() if b is not None else None,
-                                                        relu_mask.data_ptr() if relu_mask is not None else None, epi, x.shape[0], 256, N,
+                                                        aux.data_ptr() if aux is not None else None, epi, x.shape[0], 256, N,
                                                         out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream))
     return out
 
@@ -183,3 +190,154 @@ class LinearBf16CachedFunction(torch.autograd.Function):
             grads = (dw[:split] if dw is not None else None, dw[split:] if dw is not None else None,
                      db[:split] if db is not None else None, db[split:] if db is not None else None)
         return (dx, None, None, None) + tuple(g.to(dt) if g is not None and n else None for g, dt, n in zip(grads, dts, need))
+
+
+class VersionCache:
+    """A derived form of a few parameters (bf16 casts, packed weights, stacked projections) kept across calls and rebuilt when one of
+    them has been modified in place (optimizer step, ``load_state_dict``, ``copy_``: whatever bumps autograd's version counter).  Writes
+    THROUGH ``param.data`` bypass that counter: call :meth:`clear` after them."""
+
+    def __init__(self):
+        self._ver = self._val = None
+
+    def clear(self):
+        self._ver = self._val = None
+
+    def get(self, params, build):
+        ver = tuple((p.data_ptr(), p._version) for p in params)
+        if ver != self._ver:
+            with torch.no_grad():
+                self._val = build()
+            self._ver = ver
+        return self._val
+
+
+def pack_linear256(weights, biases):
+    """The forms :class:`Lin256Function` runs a (stack of) ``nn.Linear(256, n_i)`` from: the weights concatenated along the output
+    dimension as bf16 (``w16``, for the input gradient), in lin256's fragment order (``packed``), the transposed weight packed the
+    same way when the stack is 256 wide (``packed_t``: the input gradient is then a K = 256 product too), and the float32 bias."""
+    w = torch.cat([t.detach() for t in weights], 0) if len(weights) > 1 else weights[0].detach()
+    b = torch.cat([t.detach() for t in biases], 0) if len(biases) > 1 else biases[0].detach()
+    w16 = w.to(torch.bfloat16).contiguous()
+    n = w16.shape[0]
+    assert w16.shape[1] == 256 and n % 64 == 0
+    return {"w16": w16, "packed": lin256_pack(w16), "packed_t": lin256_pack(w16.t().contiguous()) if n == 256 else None,
+            "b32": b.float().contiguous(), "rows": [int(t.shape[0]) for t in weights]}
+
+
+def _mask_rows_(t, mask):
+    """zero the rows of ``t`` (T, C) bf16 where ``mask`` (T,) bool is set, in place (only those rows are touched)"""
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.load().msda_mask_rows_bf16(t.data_ptr(), mask.view(torch.uint8).data_ptr(), mask.numel(), t.numel() // mask.numel(),
+                                                   torch.cuda.current_stream(t.device).cuda_stream))
+    return t
+
+
+class Lin256Function(torch.autograd.Function):
+    """``x W^T + b`` for a 256-wide bf16 input on the library's own MFMA kernel (csrc/lin256_mfma.hip): forward, and the input gradient
+    too when the layer is 256 -> 256 (else the library's bf16 GEMM); the weight / bias gradients on the weight-gradient kernel where
+    there are enough tokens to pay (functions/linear.py: linear_wgrad_bf16), else the library's transposed GEMM.
+    ``apply(x, pk, row_mask, *params)``: ``pk`` from :func:`pack_linear256` (kept by the caller in a :class:`VersionCache`);
+    ``row_mask`` (tokens,) bool or None zeroes the rows of masked tokens in the kernel's epilogue (and their gradient);
+    ``params`` = the weights then the biases of the stacked layers, to which the gradients are routed."""
+
+    @staticmethod
+    def forward(ctx, x, pk, row_mask, *params):
+        x2 = x.reshape(-1, 256)
+        out = lin256(x2, pk["packed"], pk["b32"], row_mask=row_mask.reshape(-1) if row_mask is not None else None)
+        ctx.save_for_backward(x, row_mask)
+        ctx.pk, ctx.dts = pk, tuple(p.dtype for p in params)
+        return out.view(x.shape[:-1] + (out.shape[-1],))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, row_mask = ctx.saved_tensors
+        pk, dts = ctx.pk, ctx.dts
+        n = pk["w16"].shape[0]
+        dy2 = dy.reshape(-1, n)
+        if row_mask is not None:      # (a copy: the incoming gradient is not ours to modify)
+            dy2 = _mask_rows_(dy2.clone(memory_format=torch.contiguous_format), row_mask.reshape(-1))
+        elif not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        x2 = x.reshape(-1, 256)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (lin256(dy2, pk["packed_t"]) if pk["packed_t"] is not None else dy2 @ pk["w16"]).view(x.shape)
+        need = ctx.needs_input_grad[3:]
+        nl = len(pk["rows"])
+        grads = [None] * (2 * nl)
+        if any(need):
+            want_w, want_b = any(need[:nl]), any(need[nl:])
+            dw = db = None
+            if want_w and linear_wgrad_supported(n, 256) and dy2.shape[0] >= LinearBf16Function.MIN_TOKENS:
+                if want_b:
+                    dw, db = linear_wgrad_bf16(dy2, x2.contiguous(), with_bias=True)
+                else:
+                    dw = linear_wgrad_bf16(dy2, x2.contiguous())
+            elif want_w:
+                dw = (dy2.t() @ x2).float()
+            if want_b and db is None:
+                db = dy2.sum(0, dtype=torch.float32)
+            r0 = 0
+            for i, r in enumerate(pk["rows"]):
+                if need[i] and dw is not None:
+                    grads[i] = dw[r0:r0 + r].to(dts[i])
+                if need[nl + i] and db is not None:
+                    grads[nl + i] = db[r0:r0 + r].to(dts[nl + i])
+                r0 += r
+        return (dx, None, None) + tuple(grads)
+
+
+class StackedValueProjFunction(torch.autograd.Function):
+    """Several 256 -> 256 layers applied to ONE input in one product (``msda_lin256_forward_stacked_bf16``): the cross-attention value
+    projections of all decoder layers (modules/decoder.py).  ``apply(x, pk, row_mask, *weights, *biases)`` -> a tuple of contiguous
+    (..., 256) tensors, one per layer; the backward stacks the layers' gradients once and runs ONE input-gradient product (K = 256 x
+    layers) and ONE weight-gradient product."""
+
+    @staticmethod
+    def forward(ctx, x, pk, row_mask, *params):
+        x2 = x.reshape(-1, 256).contiguous()
+        nl = len(pk["rows"])
+        out = torch.empty((nl,) + x.shape[:-1] + (256,), dtype=torch.bfloat16, device=x.device)
+        m8 = row_mask.reshape(-1).contiguous().view(torch.uint8) if row_mask is not None else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().msda_lin256_forward_stacked_bf16(
+                x2.data_ptr(), pk["packed"].data_ptr(), pk["b32"].data_ptr(), m8.data_ptr() if m8 is not None else None, x2.shape[0], 256,
+                256 * nl, out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream))
+        ctx.save_for_backward(x2, row_mask)
+        ctx.pk, ctx.dts, ctx.shape = pk, tuple(p.dtype for p in params), x.shape
+        return tuple(out.unbind(0))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *dys):
+        x2, row_mask = ctx.saved_tensors
+        pk, dts = ctx.pk, ctx.dts
+        nl = len(pk["rows"])
+        T = x2.shape[0]
+        zero = None
+        cols = []
+        for dy in dys:       # (a layer whose output took no part in the loss hands over None)
+            if dy is None:
+                zero = torch.zeros((T, 256), dtype=torch.bfloat16, device=x2.device) if zero is None else zero
+                cols.append(zero)
+            else:
+                cols.append(dy.reshape(T, 256))
+        dy_all = torch.cat(cols, 1)                                   # (T, 256 * layers): one copy, then two products
+        if row_mask is not None:
+            _mask_rows_(dy_all, row_mask.reshape(-1))
+        dx = (dy_all @ pk["w16"]).view(ctx.shape) if ctx.needs_input_grad[0] else None
+        need = ctx.needs_input_grad[3:]
+        grads = [None] * (2 * nl)
+        if any(need):
+            if linear_wgrad_supported(256 * nl, 256) and T >= LinearBf16Function.MIN_TOKENS:
+                dw, db = linear_wgrad_bf16(dy_all, x2, with_bias=True)
+            else:
+                dw, db = (dy_all.t() @ x2).float(), dy_all.sum(0, dtype=torch.float32)
+            for i in range(nl):
+                if need[i]:
+                    grads[i] = dw[256 * i:256 * (i + 1)].to(dts[i])
+                if need[nl + i]:
+                    grads[nl + i] = db[256 * i:256 * (i + 1)].to(dts[nl + i])
+        return (dx, None, None) + tuple(grads)

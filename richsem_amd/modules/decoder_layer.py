@@ -6,16 +6,25 @@ attention:
     tgt = norm1(tgt + dropout1(cross_attn(tgt + query_pos, reference boxes, memory, shapes, ...)))  MSDeformAttn, 4-d references
     tgt = norm3(tgt + dropout4(linear2(dropout3(activation(linear1(tgt))))))                        feed-forward block
 
-Sequence-first tensors (nq, bs, d_model) like the reference.  Same parameter names (``cross_attn.*``, ``self_attn.*``,
-``norm1..3``, ``linear1/2``), so a reference checkpoint loads unchanged.  ``cross_attn`` runs on the HIP kernels (decoder-shaped
-calls: direct forward, level-sum + direct backward); the feed-forward block is the MFMA kernel for bfloat16 input with relu and no
-active dropout, else the reference's op-by-op sequence; the self-attention is PyTorch's.
+Sequence-first tensors (nq, bs, d_model) like the reference.  Same parameter names (``cross_attn.*``, ``self_attn.in_proj_weight``
+/ ``in_proj_bias`` / ``out_proj.*``, ``norm1..3``, ``linear1/2``), so a reference checkpoint loads unchanged.
+
+Two paths:
+  * float32 / float64 activations: the reference's op sequence with ``cross_attn`` on the HIP kernels (what the reference-generated
+    fixtures of tests/golden/layer_decoder_f64.npz pin);
+  * bfloat16 activations, d_model = 256, relu, no active dropout (new capability: the reference has no half path) -- every product on
+    the library's kernels: q/k and v projections, the attention's output projection, the cross-attention's projections and the
+    feed-forward block's first product on ``csrc/lin256_mfma.hip``; the masked self-attention as one kernel each way
+    (``csrc/attn_mfma.hip``); residual + LayerNorm fused (``AddLayerNormFunction``); the cross-attention's value can be handed in by
+    the decoder, which projects the memory for all its layers at once (modules/decoder.py).
 """
 import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions.ffn import FUSED_FFN_MIN_TOKENS, FusedFFNFunction
+from ..functions.attention import masked_self_attention
+from ..functions.ffn import AddLayerNormFunction, FFNSmallFunction
+from ..functions.linear import Lin256Function, VersionCache, lin256_pack, pack_linear256
 from .ms_deform_attn import MSDeformAttn
 
 
@@ -34,40 +43,97 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.dropout4 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
-        self.fused_ffn = True
-        self.fused_min_tokens = FUSED_FFN_MIN_TOKENS   # below it the op sequence is faster (functions/ffn.py)
+        self.n_heads = n_heads
+        self.fused = True                 # False: bfloat16 input takes the op-by-op sequence too (parameters cast per call)
+        self._packs = VersionCache()
 
     @staticmethod
     def with_pos_embed(tensor, pos):
         return tensor if pos is None else tensor + pos
 
+    # ---- the library-kernel path (bfloat16) ---------------------------------------------------------------------------------------
+    def _fast(self, tgt):
+        drop = self.training and max(self.dropout1.p, self.dropout2.p, self.dropout3.p, self.dropout4.p, self.self_attn.dropout) > 0
+        return (self.fused and tgt.is_cuda and tgt.dtype == torch.bfloat16 and tgt.shape[-1] == 256 and self.activation == "relu"
+                and not drop and self.linear1.out_features % 64 == 0 and self.self_attn.in_proj_weight is not None)
+
+    def invalidate_bf16_cache(self):
+        """after writes through ``param.data`` (see functions/linear.py: VersionCache)"""
+        self._packs.clear()
+        self.cross_attn.invalidate_bf16_cache()
+
+    def _lin_packs(self):
+        a = self.self_attn
+        ps = (a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, self.linear1.weight, self.linear1.bias,
+              self.linear2.weight, self.linear2.bias)
+
+        def build():
+            w, b = a.in_proj_weight, a.in_proj_bias
+            return {"qk": pack_linear256([w[:512]], [b[:512]]), "v": pack_linear256([w[512:]], [b[512:]]),
+                    "o": pack_linear256([a.out_proj.weight], [a.out_proj.bias]),
+                    "w1": pack_linear256([self.linear1.weight], [self.linear1.bias]),
+                    "w2_16": self.linear2.weight.detach().to(torch.bfloat16).contiguous(),
+                    "w2t": lin256_pack(self.linear2.weight.detach().to(torch.bfloat16).t().contiguous())}
+        return self._packs.get(ps, build)
+
+    def _forward_fast(self, tgt, query_pos, reference_points, memory, memory_mask, lsi, shapes, attn_mask, value):
+        pk = self._lin_packs()
+        a = self.self_attn
+        w, b = a.in_proj_weight, a.in_proj_bias
+        qpos = query_pos.to(torch.bfloat16) if query_pos is not None else None
+        # self-attention (:974-978)
+        q_in = tgt if qpos is None else tgt + qpos
+        qk = Lin256Function.apply(q_in, pk["qk"], None, w[:512], b[:512])
+        v = Lin256Function.apply(tgt, pk["v"], None, w[512:], b[512:])
+        att = masked_self_attention(qk, v, attn_mask, self.n_heads)
+        tgt2 = Lin256Function.apply(att, pk["o"], None, a.out_proj.weight, a.out_proj.bias)
+        tgt = AddLayerNormFunction.apply(tgt, tgt2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        # cross-attention (:1017-1022): batch-first views of the sequence-first tensors
+        q_in = (tgt if qpos is None else tgt + qpos).transpose(0, 1).contiguous()
+        ref = reference_points.transpose(0, 1).contiguous()
+        if value is None:
+            value = self.cross_attn.project_value(memory.transpose(0, 1), memory_mask)
+        tgt2 = self.cross_attn.forward_from_value(q_in, ref, value, shapes, lsi).transpose(0, 1).contiguous()
+        tgt = AddLayerNormFunction.apply(tgt, tgt2, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        # feed-forward block (:940-944)
+        return FFNSmallFunction.apply(tgt, pk["w1"], pk["w2_16"], pk["w2t"], self.norm3.eps, self.linear1.weight, self.linear1.bias,
+                                      self.linear2.weight, self.linear2.bias, self.norm3.weight, self.norm3.bias)
+
+    # ---- the reference's op sequence --------------------------------------------------------------------------------------------
     def forward_ffn(self, tgt):
-        drop = self.training and (self.dropout3.p > 0 or self.dropout4.p > 0)
-        if (self.fused_ffn and tgt.is_cuda and tgt.dtype == torch.bfloat16 and self.activation == "relu" and not drop
-                and tgt.shape[-1] == 256 and self.linear1.out_features % 32 == 0 and self.linear1.out_features <= 4096
-                and tgt.numel() // tgt.shape[-1] >= self.fused_min_tokens):
-            return FusedFFNFunction.apply(tgt, self.linear1.weight.to(torch.bfloat16), self.linear1.bias.float(),
-                                          self.linear2.weight.to(torch.bfloat16), self.linear2.bias.float(),
-                                          self.norm3.weight.float(), self.norm3.bias.float(), self.norm3.eps)
         act = {"relu": F.relu, "gelu": F.gelu}[self.activation]
-        tgt2 = self.linear2(self.dropout3(act(self.linear1(tgt))))
-        return self.norm3(tgt + self.dropout4(tgt2))
+        dt = tgt.dtype
+        h = self.dropout3(act(F.linear(tgt, self.linear1.weight.to(dt), self.linear1.bias.to(dt))))
+        tgt2 = F.linear(h, self.linear2.weight.to(dt), self.linear2.bias.to(dt))
+        return F.layer_norm(tgt + self.dropout4(tgt2), (tgt.shape[-1],), self.norm3.weight.to(dt), self.norm3.bias.to(dt), self.norm3.eps)
 
     def forward_sa(self, tgt, tgt_query_pos=None, self_attn_mask=None):
         q = k = self.with_pos_embed(tgt, tgt_query_pos)
-        tgt2 = self.self_attn(q, k, tgt, attn_mask=self_attn_mask)[0]
-        return self.norm2(tgt + self.dropout2(tgt2))
+        a, dt = self.self_attn, tgt.dtype
+        if dt == a.in_proj_weight.dtype:
+            tgt2 = a(q, k, tgt, attn_mask=self_attn_mask)[0]
+        else:   # bf16 activations with fp32 master parameters, op by op
+            tgt2 = F.multi_head_attention_forward(q, k, tgt, a.embed_dim, a.num_heads, a.in_proj_weight.to(dt), a.in_proj_bias.to(dt), None, None,
+                                                  False, a.dropout, a.out_proj.weight.to(dt), a.out_proj.bias.to(dt), training=self.training,
+                                                  attn_mask=self_attn_mask, need_weights=False)[0]
+        dt = tgt.dtype
+        return F.layer_norm(tgt + self.dropout2(tgt2), (tgt.shape[-1],), self.norm2.weight.to(dt), self.norm2.bias.to(dt), self.norm2.eps)
 
     def forward_ca(self, tgt, tgt_query_pos, tgt_reference_points, memory, memory_key_padding_mask, memory_level_start_index,
                    memory_spatial_shapes):
         tgt2 = self.cross_attn(self.with_pos_embed(tgt, tgt_query_pos).transpose(0, 1), tgt_reference_points.transpose(0, 1).contiguous(),
                                memory.transpose(0, 1), memory_spatial_shapes, memory_level_start_index,
                                memory_key_padding_mask).transpose(0, 1)
-        return self.norm1(tgt + self.dropout1(tgt2))
+        dt = tgt.dtype
+        return F.layer_norm(tgt + self.dropout1(tgt2), (tgt.shape[-1],), self.norm1.weight.to(dt), self.norm1.bias.to(dt), self.norm1.eps)
 
     def forward(self, tgt, tgt_query_pos=None, tgt_query_sine_embed=None, tgt_key_padding_mask=None, tgt_reference_points=None,
                 memory=None, memory_key_padding_mask=None, memory_level_start_index=None, memory_spatial_shapes=None,
-                memory_pos=None, self_attn_mask=None, cross_attn_mask=None):
+                memory_pos=None, self_attn_mask=None, cross_attn_mask=None, value=None):
+        """the reference's signature (:1026-1043) plus ``value``: the cross-attention's projected memory when the caller has it"""
+        if self._fast(tgt):
+            return self._forward_fast(tgt, tgt_query_pos, tgt_reference_points, memory, memory_key_padding_mask, memory_level_start_index,
+                                      memory_spatial_shapes, self_attn_mask, value)
         tgt = self.forward_sa(tgt, tgt_query_pos, self_attn_mask)
         tgt = self.forward_ca(tgt, tgt_query_pos, tgt_reference_points, memory, memory_key_padding_mask, memory_level_start_index,
                               memory_spatial_shapes)

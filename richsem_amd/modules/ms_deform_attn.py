@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions import MaskRows, MSDeformAttnFunction, MSDeformAttnFusedFunction
-from ..functions.linear import LinearBf16CachedFunction
+from ..functions.linear import Lin256Function, LinearBf16CachedFunction, VersionCache, pack_linear256
 
 
 def _is_power_of_2(n):
@@ -42,6 +42,7 @@ class MSDeformAttn(nn.Module):
         # own kernels (functions/fused.py).  False: the reference's op-by-op sequence.  Same parameters, same results.
         self.fused = True
         self._bf16_ver = self._bf16_cache = None
+        self._packs = VersionCache()      # lin256 forms of the four projections (d_model = 256)
 
         self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
         self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
@@ -73,6 +74,8 @@ class MSDeformAttn(nn.Module):
         some third-party optimizers, manual EMA / weight surgery) bypass that counter: call this after them."""
         self._bf16_ver = None
         self._bf16_cache = None
+        if hasattr(self, "_packs"):
+            self._packs.clear()
 
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
@@ -93,6 +96,30 @@ class MSDeformAttn(nn.Module):
             self._bf16_ver = ver
         return self._bf16_cache
 
+    def _lin256_packs(self):
+        ps = (self.value_proj.weight, self.value_proj.bias, self.sampling_offsets.weight, self.sampling_offsets.bias,
+              self.attention_weights.weight, self.attention_weights.bias, self.output_proj.weight, self.output_proj.bias)
+        return self._packs.get(ps, lambda: {"v": pack_linear256([ps[0]], [ps[1]]), "q": pack_linear256([ps[2], ps[4]], [ps[3], ps[5]]),
+                                            "o": pack_linear256([ps[6]], [ps[7]])})
+
+    def project_value(self, input_flatten, input_padding_mask=None):
+        """bf16, d_model = 256: ``value_proj(input_flatten)`` with the rows of padded pixels zeroed (reference :94-96), (N, S, C)"""
+        pk = self._lin256_packs()
+        mask = input_padding_mask.contiguous() if input_padding_mask is not None else None
+        return Lin256Function.apply(input_flatten.to(torch.bfloat16), pk["v"], mask, self.value_proj.weight, self.value_proj.bias)
+
+    def forward_from_value(self, query, reference_points, value, input_spatial_shapes, input_level_start_index):
+        """bf16, d_model = 256: the module's forward behind the value projection (reference :97-114) -- for callers that project the
+        memory for several layers at once (richsem_amd/modules/decoder.py)"""
+        N, S = value.shape[0], value.shape[1]
+        H, L, P = self.n_heads, self.n_levels, self.n_points
+        pk = self._lin256_packs()
+        qproj = Lin256Function.apply(query.to(torch.bfloat16), pk["q"], None, self.sampling_offsets.weight, self.attention_weights.weight,
+                                     self.sampling_offsets.bias, self.attention_weights.bias)
+        out = MSDeformAttnFusedFunction.apply(value.reshape(N, S, H, self.d_model // H), input_spatial_shapes, input_level_start_index,
+                                              qproj, reference_points.float(), H, L, P, self.im2col_step)
+        return Lin256Function.apply(out, pk["o"], None, self.output_proj.weight, self.output_proj.bias)
+
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
         """query (N, Lq, C); reference_points (N, Lq, L, 2|4) in [0,1] incl. padding; input_flatten (N, S, C);
@@ -112,10 +139,16 @@ class MSDeformAttn(nn.Module):
             # module's (fp32) parameters cast per call, value / output travel as bf16 through the operator's bf16 entry points,
             # locations and attention weights are formed and kept in fp32
             dt = query.dtype
+            if dt == torch.bfloat16 and self.d_model == 256 and (H * L * P * 3) % 64 == 0:
+                # bf16, d_model = 256 (RichSem): the four projections on the library's own MFMA kernel (csrc/lin256_mfma.hip: K = 256) --
+                # value_proj with the padding mask in its epilogue, offsets + logits as ONE 256 -> 384 projection, output_proj; their
+                # input gradients on the same kernel where the layer is 256 -> 256, the weight gradients on the weight-gradient kernel
+                return self.forward_from_value(query, reference_points, self.project_value(input_flatten, input_padding_mask),
+                                               input_spatial_shapes, input_level_start_index)
             if dt == torch.bfloat16:
-                # bf16: library GEMMs for the forward and the input gradient, the library's own MFMA kernel for the weight gradient (its
-                # contraction runs over the tokens); the bf16 casts of the parameters and the stacked offsets / logits projection are
-                # kept across calls (refreshed when a parameter changes)
+                # bf16, other widths: library GEMMs for the forward and the input gradient, the library's own MFMA kernel for the weight
+                # gradient (its contraction runs over the tokens); the bf16 casts of the parameters and the stacked offsets / logits
+                # projection are kept across calls (refreshed when a parameter changes)
                 c = self._bf16_params()
                 value = LinearBf16CachedFunction.apply(input_flatten.to(dt), c["wv"], c["bv"], None, self.value_proj.weight,
                                                        self.value_proj.bias)

@@ -1,6 +1,6 @@
 """GPU (-m gpu): the integer part of the denoising set-up (reference dn_components.py:27-61,
-131-179) -- device tensors of richsem_amd/dn.py against the numpy restatement oracle/dn_oracle.py, BIT-EXACT (int64 / bool).
-(The oracle is a restatement of the source text only: parity unpinned, see its header.)"""
+131-179) -- device tensors of richsem_amd/dn.py against the numpy restatement oracle/dn_oracle.py and against outputs of the
+reference's own prepare_for_cdn (tests/golden/dn_prepare_for_cdn.npz), BIT-EXACT (int64 / bool)."""
 import numpy as np
 import pytest
 import torch
@@ -34,6 +34,28 @@ def test_layout_is_bit_exact(known_num, dn_number, num_queries, use_cdn):
         assert a.dtype == np.int64 and a.shape == want[k].shape and np.array_equal(a, want[k]), k
     m = got["attn_mask"]
     assert m.dtype == torch.bool and np.array_equal(m.cpu().numpy(), want["attn_mask"])
+
+
+def test_layout_against_the_reference_fixture():
+    """the device tensors against what the reference's own prepare_for_cdn returned (tests/golden/make_golden_layers.py)"""
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "dn_prepare_for_cdn.npz"))
+    n = len([k for k in z.files if k.endswith(".counts")])
+    for ci in range(n):
+        pre = f"c{ci}."
+        counts = [int(c) for c in z[pre + "counts"]]
+        dn_number, use_cdn, add_gt, nq = (int(v) for v in z[pre + "args"])
+        got = prepare_dn_layout(counts, dn_number, nq, bool(use_cdn), bool(add_gt))
+        assert [got["pad_size"], got["num_dn_group"]] == z[pre + "meta"].tolist(), ci
+        assert np.array_equal(got["attn_mask"].cpu().numpy(), z[pre + "attn_mask"]), ci
+        full = got["single_pad"] * 2 * got["num_dn_group"]
+        filled = torch.zeros((len(counts), full), dtype=torch.bool, device="cuda")
+        if got["known_bid"].numel():
+            filled[got["known_bid"], got["map_known_indice"]] = True       # dn_components.py:140-142
+        if not use_cdn:
+            filled = filled[:, got["positive_idx"]]                          # :145-149
+        assert np.array_equal(filled.cpu().numpy(), z[pre + "filled"]), ci
 
 
 def test_add_gt_and_group_count_follow_the_reference_arithmetic():

@@ -1,0 +1,237 @@
+"""GPU (-m gpu): the transformer layers against fixtures generated from the REFERENCE's own classes
+(tests/golden/make_golden_layers.py: DeformableTransformerEncoderLayer, DeformableTransformerDecoderLayer and TransformerDecoder of
+models/richsem/deformable_transformer.py, fp64, the operator bound to the reference's pure-PyTorch core): outputs, input gradients and
+every parameter gradient.  The bf16 paths (new capability, no reference) are held to the fp32 path of the same module -- which the
+fixtures pin -- at bf16 tolerance; the attention kernels to the softmax definition in fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _fix(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    t = {k: torch.from_numpy(z[k]).cuda() for k in z.files if not k.startswith("param.")}
+    sd = {k[len("param."):]: torch.from_numpy(z[k]).cuda() for k in z.files if k.startswith("param.") and not k.endswith(".grad")}
+    gr = {k[len("param."):-len(".grad")]: torch.from_numpy(z[k]).cuda() for k in z.files if k.startswith("param.") and k.endswith(".grad")}
+    return t, sd, gr
+
+
+def _rel(a, b):
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-300)
+
+
+def _check_params(mod, gr, tol):
+    got = dict(mod.named_parameters())
+    assert set(got) == set(gr), set(got) ^ set(gr)
+    for k, want in gr.items():
+        assert got[k].grad is not None, k
+        assert _rel(got[k].grad, want) < tol, (k, _rel(got[k].grad, want))
+
+
+def test_encoder_layer_against_the_reference_class():
+    from richsem_amd.modules import DeformableTransformerEncoderLayer, get_reference_points
+    t, sd, gr = _fix("layer_encoder_f64")
+    layer = DeformableTransformerEncoderLayer(64, 96, dropout=0.0, activation="relu", n_levels=4, n_heads=2, n_points=4).cuda().double()
+    assert set(layer.state_dict()) == set(sd)
+    layer.load_state_dict(sd, strict=True)
+    ref = get_reference_points(t["shapes"].tolist(), t["valid_ratios"], "cuda")          # the encoder's own :512-525
+    assert _rel(ref.double(), t["reference_points"]) < 1e-6
+    src, pos = t["src"].clone().requires_grad_(True), t["pos"].clone().requires_grad_(True)
+    out = layer(src, pos, t["reference_points"], t["shapes"], t["lsi"], t["mask"])
+    assert _rel(out, t["out"]) < 1e-10
+    out.backward(t["grad_out"])
+    assert _rel(src.grad, t["grad_src"]) < 1e-9 and _rel(pos.grad, t["grad_pos"]) < 1e-9
+    _check_params(layer, gr, 1e-9)
+
+
+def test_decoder_layer_against_the_reference_class():
+    from richsem_amd.modules import DeformableTransformerDecoderLayer
+    t, sd, gr = _fix("layer_decoder_f64")
+    layer = DeformableTransformerDecoderLayer(64, 96, dropout=0.0, activation="relu", n_levels=4, n_heads=2, n_points=4).cuda().double()
+    assert set(layer.state_dict()) == set(sd)
+    layer.load_state_dict(sd, strict=True)
+    tgt, qpos, mem = (t[k].clone().requires_grad_(True) for k in ("tgt", "query_pos", "memory"))
+    out = layer(tgt=tgt, tgt_query_pos=qpos, tgt_reference_points=t["reference_points"], memory=mem, memory_key_padding_mask=t["memory_mask"],
+                memory_level_start_index=t["lsi"], memory_spatial_shapes=t["shapes"], self_attn_mask=t["attn_mask"])
+    assert _rel(out, t["out"]) < 1e-10
+    out.backward(t["grad_out"])
+    assert _rel(tgt.grad, t["grad_tgt"]) < 1e-9 and _rel(qpos.grad, t["grad_query_pos"]) < 1e-9 and _rel(mem.grad, t["grad_memory"]) < 1e-9
+    _check_params(layer, gr, 1e-9)
+
+
+def test_decoder_stack_against_the_reference_class():
+    """TransformerDecoder.forward: sine embedding, ref_point_head, three layers, iterative box refinement with detached boxes"""
+    from richsem_amd.modules import MLP, DeformableTransformerDecoderLayer, TransformerDecoder
+    t, sd, gr = _fix("decoder_stack_f64")
+    layer = DeformableTransformerDecoderLayer(64, 96, dropout=0.0, activation="relu", n_levels=4, n_heads=2, n_points=4)
+    dec = TransformerDecoder(layer, 3, torch.nn.LayerNorm(64), d_model=64, query_dim=4, num_feature_levels=4)
+    dec.bbox_embed = torch.nn.ModuleList([MLP(64, 64, 4, 3) for _ in range(3)])
+    dec = dec.cuda().double()
+    assert set(dec.state_dict()) == set(sd)
+    dec.load_state_dict(sd, strict=True)
+    tgt, mem, refu = (t[k].clone().requires_grad_(True) for k in ("tgt", "memory", "refpoints_unsigmoid"))
+    hs, refs = dec(tgt=tgt, memory=mem, tgt_mask=t["attn_mask"], memory_key_padding_mask=t["memory_mask"], refpoints_unsigmoid=refu,
+                   level_start_index=t["lsi"], spatial_shapes=t["shapes"], valid_ratios=t["valid_ratios"])
+    hs, refs = torch.stack(hs), torch.stack(refs)
+    # (the sine embedding's frequencies 10000 ** (2 (i // 2) / 128) are float32 in the reference, utils.py:145-146; the fixture took that
+    # power on the CPU, here it is the GPU's: one float32 ulp apart, ~1e-9 after the ref_point_head)
+    assert _rel(hs, t["hs"]) < 2e-8 and _rel(refs, t["refs"]) < 2e-8
+    ((hs * t["grad_hs"]).sum() + (refs * t["grad_refs"]).sum()).backward()
+    assert _rel(tgt.grad, t["grad_tgt"]) < 1e-7 and _rel(mem.grad, t["grad_memory"]) < 1e-7 and _rel(refu.grad, t["grad_refpoints"]) < 1e-7
+    _check_params(dec, gr, 1e-7)
+
+
+# ---- the attention kernels (csrc/attn_mfma.hip) against the definition -------------------------------------------------------------
+def _attention_reference(qk, v, mask, heads):
+    nq, bs, c2 = qk.shape
+    C = c2 // 2
+    q, k = qk[..., :C].float(), qk[..., C:].float()
+    split = lambda x: x.reshape(nq, bs, heads, 32).permute(1, 2, 0, 3)          # (bs, heads, nq, 32)
+    s = split(q) @ split(k).transpose(-1, -2) / 32 ** 0.5
+    if mask is not None:
+        s = s.masked_fill(mask[None, None], float("-inf"))
+    return (torch.softmax(s, -1) @ split(v.float())).permute(2, 0, 1, 3).reshape(nq, bs, C)
+
+
+@pytest.mark.parametrize("nq,bs,heads,masked", [(1092, 2, 8, True), (37, 1, 2, True), (64, 3, 1, False), (100, 2, 4, True), (1, 1, 1, False),
+                                                 (900, 2, 8, False)])
+def test_attention_kernels_against_the_definition(nq, bs, heads, masked):
+    from richsem_amd.functions.attention import masked_self_attention
+    g = torch.Generator(device="cuda").manual_seed(nq * 7 + heads)
+    C = heads * 32
+    qk = (torch.randn(nq, bs, 2 * C, device="cuda", generator=g) * 1.5).to(torch.bfloat16)
+    v = torch.randn(nq, bs, C, device="cuda", generator=g).to(torch.bfloat16)
+    mask = None
+    if masked:          # a denoising-style block mask plus random holes; every query keeps itself
+        mask = torch.rand(nq, nq, device="cuda", generator=g) < 0.3
+        mask[nq // 3:, : nq // 3] = True
+        mask.fill_diagonal_(False)
+    go = torch.randn(nq, bs, C, device="cuda", generator=g).to(torch.bfloat16)
+    a, b = qk.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    out = masked_self_attention(a, b, mask, heads)
+    out.backward(go)
+    ar, br = qk.float().requires_grad_(True), v.float().requires_grad_(True)
+    want = _attention_reference(ar, br, mask, heads)
+    want.backward(go.float())
+    scale = lambda x: float(x.abs().max()) + 1e-12
+    assert out.dtype == torch.bfloat16 and float((out.float() - want).abs().max()) < 2e-2 * scale(want)
+    assert float((a.grad.float() - ar.grad).abs().max()) < 3e-2 * scale(ar.grad), float((a.grad.float() - ar.grad).abs().max()) / scale(ar.grad)
+    assert float((b.grad.float() - br.grad).abs().max()) < 3e-2 * scale(br.grad)
+    assert float((a.grad.float() - ar.grad).abs().mean()) < 4e-3 * scale(ar.grad)
+
+
+def test_lin256_row_mask_and_stacked_projection():
+    from richsem_amd.functions.linear import StackedValueProjFunction, Lin256Function, pack_linear256
+    torch.manual_seed(3)
+    T = 1000
+    x = torch.randn(2, T // 2, 256, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    ws = [torch.nn.Parameter(torch.randn(256, 256, device="cuda") * 0.05) for _ in range(3)]
+    bs_ = [torch.nn.Parameter(torch.randn(256, device="cuda") * 0.1) for _ in range(3)]
+    mask = torch.zeros(2, T // 2, dtype=torch.bool, device="cuda")
+    mask[1, 7:40] = True
+    outs = StackedValueProjFunction.apply(x, pack_linear256(ws, bs_), mask, *ws, *bs_)
+    gos = [torch.randn(2, T // 2, 256, device="cuda").to(torch.bfloat16) for _ in range(3)]
+    sum((o.float() * g.float()).sum() for o, g in zip(outs, gos)).backward()
+    xr = x.detach().float().requires_grad_(True)
+    wr = [w.detach().to(torch.bfloat16).float().requires_grad_(True) for w in ws]
+    br = [b.detach().clone().requires_grad_(True) for b in bs_]
+    want = [torch.nn.functional.linear(xr, w, b).masked_fill(mask[..., None], 0.0) for w, b in zip(wr, br)]
+    sum((o * g.float()).sum() for o, g in zip(want, gos)).backward()
+    for o, w_ in zip(outs, want):
+        assert o.is_contiguous() and float((o.float() - w_).abs().max()) < 2e-2 * float(w_.abs().max())
+        assert float(o[1, 7:40].abs().max()) == 0.0
+    assert float((x.grad.float() - xr.grad).abs().max()) < 3e-2 * float(xr.grad.abs().max())
+    for w, w2, b, b2 in zip(ws, wr, bs_, br):
+        assert float((w.grad - w2.grad).abs().max()) < 3e-2 * float(w2.grad.abs().max())
+        assert float((b.grad - b2.grad).abs().max()) < 3e-2 * float(b2.grad.abs().max())
+    # the single projection with the mask in its epilogue
+    y = Lin256Function.apply(x.detach(), pack_linear256(ws[:1], bs_[:1]), mask, ws[0], bs_[0])
+    assert float((y.float() - want[0].detach()).abs().max()) < 2e-2 * float(want[0].abs().max())
+
+
+def _decoder_pair(layers=2):
+    from richsem_amd.modules import MLP, DeformableTransformerDecoderLayer, TransformerDecoder
+    torch.manual_seed(11)
+    layer = DeformableTransformerDecoderLayer(256, 512, dropout=0.0, activation="relu", n_levels=4, n_heads=8, n_points=4)
+    dec = TransformerDecoder(layer, layers, torch.nn.LayerNorm(256), d_model=256)
+    dec.bbox_embed = torch.nn.ModuleList([MLP(256, 256, 4, 3) for _ in range(layers)])
+    dec = dec.cuda()
+    with torch.no_grad():
+        for l in dec.layers:
+            l.cross_attn.sampling_offsets.weight.normal_(0, 0.01)
+            l.cross_attn.attention_weights.weight.normal_(0, 0.05)
+    return dec
+
+
+def test_bf16_decoder_on_the_library_kernels_is_close_to_its_fp32_path():
+    """the bf16 decoder (lin256 projections, attention kernels, stacked value projection, fused add + LayerNorm, small-token FFN) against the
+    same module's fp32 path -- the op sequence the reference-generated fixtures above pin -- on a shrunk decoder-shaped call"""
+    from richsem_amd import workload as W
+    call = W.shrunk(W.call_Dd(2), 4)
+    shapes, lsi = W.level_tensors(call, "cuda")
+    dec = _decoder_pair()
+    nq, bs, S = 150, call.N, call.S
+    g = torch.Generator(device="cuda").manual_seed(5)
+    tgt = torch.randn(nq, bs, 256, device="cuda", generator=g)
+    mem = torch.randn(S, bs, 256, device="cuda", generator=g)
+    refu = torch.randn(nq, bs, 4, device="cuda", generator=g)
+    vr = torch.rand(bs, 4, 2, device="cuda", generator=g) * 0.2 + 0.8
+    mmask = torch.zeros(bs, S, dtype=torch.bool, device="cuda")
+    mmask[1, -9:] = True
+    amask = torch.zeros(nq, nq, dtype=torch.bool, device="cuda")
+    amask[40:, :40] = True
+    amask[:20, 20:40] = True
+    amask[20:40, :20] = True
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        a, m = tgt.detach().clone().to(dt).requires_grad_(True), mem.detach().clone().to(dt).requires_grad_(True)
+        r = refu.detach().clone().requires_grad_(True)
+        hs, refs = dec(tgt=a, memory=m, tgt_mask=amask, memory_key_padding_mask=mmask, refpoints_unsigmoid=r, level_start_index=lsi,
+                       spatial_shapes=shapes, valid_ratios=vr)
+        hs, refs = torch.stack(hs).float(), torch.stack(refs).float()
+        (hs.square().mean() + refs.square().mean()).backward()
+        res[dt] = (hs.detach(), refs.detach(), a.grad.float(), m.grad.float(), {k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None})
+        dec.zero_grad()
+    (h32, r32, ga32, gm32, gp32), (h16, r16, ga16, gm16, gp16) = res[torch.float32], res[torch.bfloat16]
+    close = lambda x, y, tol: float((x - y).abs().mean()) <= tol * (float(y.abs().mean()) + 1e-12)
+    assert close(h16, h32, 3e-2) and close(r16, r32, 2e-2)
+    assert close(ga16, ga32, 0.12) and close(gm16, gm32, 0.12)
+    bad = [k for k in gp32 if gp32[k].abs().mean() > 0 and not close(gp16[k].float(), gp32[k], 0.25)]
+    assert not bad, bad
+
+
+def test_bf16_layer_follows_an_optimizer_step():
+    """the kept bf16 / packed forms of the parameters (VersionCache) must notice in-place updates: forward, SGD step, forward again --
+    for the attention module's cache and for the decoder layer's"""
+    from richsem_amd import workload as W
+    from richsem_amd.modules import MSDeformAttn
+    call = W.shrunk(W.call_Dd(2), 4)
+    shapes, lsi = W.level_tensors(call, "cuda")
+    torch.manual_seed(4)
+    mod = MSDeformAttn(256, 4, 8, 4).cuda()
+    ref_mod = MSDeformAttn(256, 4, 8, 4).cuda()
+    q = torch.randn(call.N, 50, 256, device="cuda").to(torch.bfloat16)
+    src = torch.randn(call.N, call.S, 256, device="cuda").to(torch.bfloat16)
+    rp = torch.rand(call.N, 50, 4, 4, device="cuda") * 0.4 + 0.2
+    opt = torch.optim.SGD(mod.parameters(), lr=0.5)
+    for step in range(2):
+        out = mod(q, rp, src, shapes, lsi, None)
+        ref_mod.load_state_dict(mod.state_dict())          # a fresh module: nothing cached
+        want = ref_mod(q, rp, src, shapes, lsi, None)
+        assert torch.equal(out, want), step
+        opt.zero_grad()
+        out.float().square().mean().backward()
+        before = mod.value_proj.weight.detach().clone()
+        opt.step()
+        assert not torch.equal(before, mod.value_proj.weight.detach())
+    # a write through .data is invisible to the version counter: invalidate_bf16_cache() is the documented way
+    mod.value_proj.weight.data.mul_(0.5)
+    mod.invalidate_bf16_cache()
+    ref_mod.load_state_dict(mod.state_dict())
+    assert torch.equal(mod(q, rp, src, shapes, lsi, None), ref_mod(q, rp, src, shapes, lsi, None))

@@ -121,75 +121,6 @@ def test_fused_path_float32_full_size_encoder_call():
         assert float((x - y).abs().max()) <= 2e-4 * float(y.abs().max()) + 1e-7
 
 
-# ---- encoder layer mirror (reference deformable_transformer.py:825-881) -------------------------------------------------------
-def _reference_layer_forward(layer, src, pos, ref, shapes, lsi, mask):
-    """the reference layer's forward, op by op, on the same parameters (fp64: the operator's f64 kernels inside self_attn)"""
-    import torch.nn.functional as F
-    src2 = layer.self_attn(src + pos, ref, src, shapes, lsi, mask)
-    src = F.layer_norm(src + src2, (src.shape[-1],), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
-    h = F.relu(F.linear(src, layer.linear1.weight, layer.linear1.bias))
-    return F.layer_norm(src + F.linear(h, layer.linear2.weight, layer.linear2.bias), (src.shape[-1],), layer.norm2.weight,
-                        layer.norm2.bias, layer.norm2.eps)
-
-
-def test_encoder_layer_fp64_equals_the_reference_sequence_and_bf16_is_close():
-    from richsem_amd.modules import DeformableTransformerEncoderLayer, get_reference_points
-    from richsem_amd import workload as W
-    torch.manual_seed(1)
-    call = W.shrunk(W.call_E(2), 4)
-    shapes, lsi = W.level_tensors(call, "cuda")
-    layer = DeformableTransformerEncoderLayer(256, 2048, dropout=0.0, n_levels=call.L, n_heads=call.M, n_points=call.P).cuda().double()
-    with torch.no_grad():
-        layer.self_attn.sampling_offsets.weight.normal_(0, 0.02)
-        layer.self_attn.attention_weights.weight.normal_(0, 0.1)
-    src = torch.randn(call.N, call.S, 256, device="cuda", dtype=torch.float64)
-    pos = 0.1 * torch.randn_like(src)
-    valid = torch.ones(call.N, call.L, 2, device="cuda", dtype=torch.float64)
-    ref = get_reference_points(shapes.tolist(), valid.float(), "cuda").double()
-    assert ref.shape == (call.N, call.S, call.L, 2) and float(ref.min()) > 0 and float(ref.max()) < 1
-    out = layer(src, pos, ref, shapes, lsi, None)
-    want = _reference_layer_forward(layer, src, pos, ref, shapes, lsi, None)
-    assert rel(out, want.detach().cpu().numpy()) < 1e-12
-    # the same layer in bf16: fp32 attention on bf16 activations, the feed-forward block as one MFMA kernel
-    l16 = DeformableTransformerEncoderLayer(256, 2048, dropout=0.0, n_levels=call.L, n_heads=call.M, n_points=call.P).cuda()
-    l16.load_state_dict({k: v.float() for k, v in layer.state_dict().items()})
-    l16.fused_min_tokens = 0          # the shrunk call is below the size from which the layer takes the one-kernel block by itself
-    o16 = l16(src.to(torch.bfloat16), pos.to(torch.bfloat16), ref.float(), shapes, lsi, None)
-    assert o16.dtype == torch.bfloat16
-    assert float((o16.double() - want).abs().mean()) < 1.5e-2
-
-
-def test_decoder_layer_fp64_equals_the_reference_sequence():
-    """reference deformable_transformer.py:944-1066 with module_seq ['sa', 'ca', 'ffn'], decoder_sa_type 'sa'"""
-    import torch.nn.functional as F
-    from richsem_amd.modules import DeformableTransformerDecoderLayer
-    from richsem_amd import workload as W
-    torch.manual_seed(2)
-    call = W.shrunk(W.call_Dd(2), 4)
-    shapes, lsi = W.level_tensors(call, "cuda")
-    nq, bs = call.Lq, call.N
-    layer = DeformableTransformerDecoderLayer(256, 2048, dropout=0.0, n_levels=call.L, n_heads=call.M, n_points=call.P).cuda().double()
-    with torch.no_grad():
-        layer.cross_attn.sampling_offsets.weight.normal_(0, 0.02)
-        layer.cross_attn.attention_weights.weight.normal_(0, 0.1)
-    f = lambda *s: torch.randn(*s, device="cuda", dtype=torch.float64)
-    tgt, qpos, memory = f(nq, bs, 256), 0.1 * f(nq, bs, 256), f(call.S, bs, 256)
-    boxes = torch.rand(nq, bs, 4, device="cuda", dtype=torch.float64) * 0.5 + 0.25
-    refs = boxes[:, :, None, :].expand(nq, bs, call.L, 4).contiguous()           # sigmoid boxes x valid ratios (all ones here)
-    mask = torch.zeros(nq, nq, dtype=torch.bool, device="cuda")
-    mask[: nq // 4, nq // 4:] = True                                             # a denoising-style block mask
-    out = layer(tgt, qpos, None, None, refs, memory, None, lsi, shapes, None, mask, None)
-    # the reference's three blocks, op by op, on the same parameters
-    q = tgt + qpos
-    t = F.layer_norm(tgt + layer.self_attn(q, q, tgt, attn_mask=mask)[0], (256,), layer.norm2.weight, layer.norm2.bias)
-    ca = layer.cross_attn((t + qpos).transpose(0, 1), refs.transpose(0, 1).contiguous(), memory.transpose(0, 1), shapes, lsi, None)
-    t = F.layer_norm(t + ca.transpose(0, 1), (256,), layer.norm1.weight, layer.norm1.bias)
-    h = F.relu(F.linear(t, layer.linear1.weight, layer.linear1.bias))
-    want = F.layer_norm(t + F.linear(h, layer.linear2.weight, layer.linear2.bias), (256,), layer.norm3.weight, layer.norm3.bias)
-    assert out.shape == (nq, bs, 256)
-    assert rel(out, want.detach().cpu().numpy()) < 1e-12
-
-
 @pytest.mark.parametrize("ref_dim", [2, 4])
 def test_module_bf16_path_close_to_fp32(ref_dim):
     """bf16 activations through the fused path (bf16 GEMMs, msda_prep_*_bf16, the operator's bf16 entry points) against the

@@ -11,7 +11,7 @@ from oracle import msda_oracle as O
 from conftest import GOLDEN
 
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-               if not os.path.basename(p).startswith(("module_", "attnpool_", "clip_resnet_")))
+               if not os.path.basename(p).startswith(("module_", "attnpool_", "clip_resnet_", "layer_", "decoder_stack", "dn_")))
 
 
 def rel_err(a, b):
@@ -92,3 +92,22 @@ def test_oracle_adjoint_identity():
     lhs = float((out * z["grad_out"]).sum())
     rhs = float((z["value"] * gv).sum())
     assert abs(lhs - rhs) < 1e-10 * max(1.0, abs(lhs))
+
+
+def test_dn_oracle_matches_the_reference_prepare_for_cdn():
+    """oracle/dn_oracle.py against outputs of the reference's own prepare_for_cdn (tests/golden/make_golden_layers.py): the
+    attention mask, pad_size, the group count and the slots of the padded query tensors it fills, bit for bit -- ragged batches,
+    an image without boxes, use_cdn on / off, add_gt, group counts that round to one"""
+    from oracle import dn_oracle
+    z = np.load(os.path.join(GOLDEN, "dn_prepare_for_cdn.npz"))
+    n = len([k for k in z.files if k.endswith(".counts")])
+    assert n >= 8
+    for ci in range(n):
+        pre = f"c{ci}."
+        counts = [int(c) for c in z[pre + "counts"]]
+        dn_number, use_cdn, add_gt, nq = (int(v) for v in z[pre + "args"])
+        got = dn_oracle.prepare_for_cdn_indices(counts, dn_number, nq, bool(use_cdn), bool(add_gt))
+        assert [got["pad_size"], got["num_dn_group"]] == z[pre + "meta"].tolist(), ci
+        assert got["attn_mask"].shape == z[pre + "attn_mask"].shape and np.array_equal(got["attn_mask"], z[pre + "attn_mask"]), ci
+        assert list(z[pre + "query_shape"]) == [len(counts), got["pad_size"], 4], ci
+        assert np.array_equal(got["filled"], z[pre + "filled"]), ci
