@@ -33,7 +33,11 @@ Also on the JSON line:
                 launch duration, measured live by HIP events recorded by the library around that call's kernels on the
                 stream they are launched on, inside the timed region; peak = HBM3E 8 TB/s.
   cpu_baseline  the CPU oracle (oracle/msda_oracle.c, OpenMP) timed on this box's host cores on a bounded sample:
-                one E and one Dd forward+backward, scaled to the 6+6 calls of a step (rank 0, N=1 only).
+                one E and one Dd forward+backward, scaled to the 6+6 calls of a step (rank 0, N=1 only); `grid_sample` inside it =
+                the reference's own CPU path (F.grid_sample formulation, oracle/msda_torch_oracle.py) timed the same way.
+  full_step     ONE composed training step on the library's rows (bench_step.py: backbone ... criterion, forward + backward):
+                eager ms / img/s, per-section times, and the same step replayed as a HIP graph with GPU ms per row.  Beside
+                `value`, never it (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -72,6 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-bf16", action="store_true", help="skip the extra bf16 pass")
     ap.add_argument("--no-ffn", action="store_true", help="skip the feed-forward (MFMA) row beside the path")
     ap.add_argument("--no-graph", action="store_true", help="skip the graph-replay variant of the step")
+    ap.add_argument("--no-full-step", action="store_true", help="skip the composed training step (bench_step.py) beside the path")
     ap.add_argument("--fwd-variant", type=int, default=0)
     ap.add_argument("--bwd-variant", type=int, default=0)
     return ap.parse_args(argv)
@@ -138,10 +143,12 @@ def self_launch(args, argv):
     return proc.returncode
 
 
-def measured_traffic(hip_kernels):
-    """HBM bytes per launch of the given HIP kernels from the latest committed PMC summary (profiles/*_traffic.json,
-    made by profiles/summarize.py from separate rocprofv3 --pmc passes), or None.  The counters cannot be read from
-    inside this process; the number is attached so that it sits next to the algorithmic bytes it is compared with."""
+def measured_traffic(hip_kernels, dtype):
+    """HBM bytes per launch of the given HIP kernels IN THE GIVEN VALUE DTYPE ("f32" | "bf16") from the latest committed PMC summary
+    (profiles/*_traffic.json, made by profiles/summarize.py from separate rocprofv3 --pmc passes), or None.  The counters cannot be
+    read from inside this process; the number is attached so that it sits next to the algorithmic bytes it is compared with.  A
+    kernel instantiated per value type carries the type as its last template argument ("..., float>" / "..., __hip_bfloat16>"); the
+    route kernels are not typed and match either."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if not files:
@@ -153,7 +160,9 @@ def measured_traffic(hip_kernels):
     total, found = 0, 0
     for want in hip_kernels.split(" + "):
         want = want.strip().rstrip(">")   # "tiled_gather_kernel<false" matches "...tiled_gather_kernel<false, true, 16>"
-        hits = [v for k, v in table.items() if want in k and v["hbm_bytes_est"] > 0]
+        mine, other = ("__hip_bfloat16>", "float>") if dtype == "bf16" else ("float>", "__hip_bfloat16>")
+        hits = [v for k, v in table.items() if want in k and v["hbm_bytes_est"] > 0
+                and (mine in k.split("|")[0] or other not in k.split("|")[0])]
         if hits:
             total += max(h["hbm_bytes_est"] for h in hits)   # E-sized launch of that kernel
             found += 1
@@ -225,13 +234,45 @@ def cpu_baseline(calls, n_images):
             parts.append(f"{call.name} fwd+bwd {best * 1e3:.0f} ms x{reps} @{threads}t")
         out[label] = n_images / step_s
     O.set_threads(1)
-    return {"value": round(out["all"], 4), "unit": "img/s", "cores": cores, "kind": "port",
+    gs = grid_sample_baseline(calls, n_images, cores)
+    return {"value": round(out["all"], 4), "unit": "img/s", "cores": cores, "kind": "port", "grid_sample": gs,
             "value_1thread": round(out["one"], 5), "cpu_model": cpu_model(),
             "build": "gcc -O3 -march=native -ffp-contract=off -fopenmp (built on this box)" if native else
                      "gcc -O3 -mavx2 -ffp-contract=off -fopenmp (portable build; no compiler on this box)",
             "sample": "oracle/msda_oracle.c (OpenMP), loc-init, one fwd+bwd per distinct call scaled to the 6+6 "
                       "calls of a step; min of 5 runs after a warm-up at all cores, min of 2 at 1 thread: "
                       + ", ".join(parts)}
+
+
+def grid_sample_baseline(calls, n_images, cores):
+    """The reference's OWN CPU path for the op -- ``ms_deform_attn_core_pytorch`` (functions/ms_deform_attn_func.py:41-61: one
+    F.grid_sample per level + weighted sum), restated in oracle/msda_torch_oracle.py -- forward + autograd backward on the host's cores:
+    what a user of the reference without its CUDA extension gets.  One run per distinct call after a warm-up, scaled like the oracle."""
+    import torch
+    from oracle import msda_torch_oracle as T
+    from richsem_amd import workload as W
+    old = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        step_s, parts = 0.0, []
+        for call, reps in calls:
+            t = W.make_inputs(call, "init", seed=0)
+            args = (t["value"], t["shapes"], t["loc"], t["aw"], t["grad_out"])
+            best = float("inf")
+            for i in range(3 if call.Lq < 5000 else 2):      # the first pass is the warm-up
+                t0 = time.perf_counter()
+                T.forward_backward(*args)
+                dt = time.perf_counter() - t0
+                if i > 0:
+                    best = min(best, dt)
+            step_s += reps * best
+            parts.append(f"{call.name} fwd+bwd {best * 1e3:.0f} ms x{reps}")
+        return {"value": round(n_images / step_s, 4), "unit": "img/s", "cores": cores, "kind": "reference CPU path restated "
+                "(torch F.grid_sample + autograd, oracle/msda_torch_oracle.py)", "sample": ", ".join(parts)}
+    except Exception as e:      # noqa: BLE001 -- an extra leg must never take the benchmark line down
+        return {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    finally:
+        torch.set_num_threads(old)
 
 
 # ---- the measured loop -----------------------------------------------------------------------------------------------
@@ -564,7 +605,7 @@ def main(argv=None):
             dom = max(kernels, key=lambda k: k["total_ms"])
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "hip_kernels": dom["hip_kernels"],
                         "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom["hip_kernels"]),
+                        "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom["hip_kernels"], "bf16" if mode == "bf16" else "f32"),
                         "alg_bytes_per_launch": dom["alg_bytes"], "avg_launch_us": dom["avg_us"]}
             out = {"value": round(n_total / (res["elapsed"] / args.steps), 3),
                    "ms_per_step": round(res["elapsed"] / args.steps * 1e3, 4), "roofline": roofline, "kernels": kernels}
@@ -605,6 +646,14 @@ def main(argv=None):
         if not args.no_ffn and world == 1:      # (the rows beside the path are single-GPU measurements, like the CPU baseline)
             line["mfma_row"] = ffn_row(n_img, dev)
             line["mfma_rows"] = {"two_stage_class_score": cls_row(n_img, dev), "resnet50_forward": backbone_row(n_img, dev)}
+        if world == 1 and not args.no_full_step:      # the composed training step on the library's rows; beside `value`, never it
+            layers.clear()                             # (the path's 12 resident tensor sets are not needed any more)
+            torch.cuda.empty_cache()
+            try:
+                import bench_step
+                line["full_step"] = bench_step.run(n_img, dev, steps=5, warmup=3)
+            except Exception as e:      # noqa: BLE001
+                line["full_step"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(calls, n_img)
         else:

@@ -1,0 +1,437 @@
+"""A composed RichSem training step on richsem_amd's rows, for bench.py's ``full_step`` line.
+
+NOT a model framework: the tier this repository is built to covers the operator and the rows around it, not RichSem's model assembly
+(out of scope).  This file chains those rows the way the reference chains them --
+``engine.py:44-114`` -> ``models/richsem/richsem.py:581-774`` -> ``deformable_transformer.py:273-463`` -- at the tensor sizes of
+BASELINE.json configs[1] (2 x 800 x 1333 images padded to 1344, R50 4-scale, 900 queries + denoising groups of 12 boxes, 1204 classes,
+frozen CLIP-RN50 teacher), with synthetic seeded weights and a compact criterion (the reference's SetCriterion stays host Python by
+``north_star``; what is here reproduces its tensor work: Hungarian matching of 6 decoder outputs + the two-stage output, sigmoid focal
+classification loss, L1 + GIoU box losses on the matched pairs and on the denoising queries, KL distillation against the teacher's
+box logits), so that ONE number covers a whole forward + backward of the path:
+
+    ResNet-50 (layer2-4 trained) -> input projections -> 6 encoder layers -> two-stage class score + top-900 -> denoising layout ->
+    6 decoder layers (+ box refinement) -> class / box / distillation heads -> frozen teacher -> ROIAlign -> attention pool ->
+    matcher -> losses -> backward through all of it.
+
+bf16 activations wherever the library has a bf16 path (backbone, encoder, decoder), fp32 master parameters.  The optimizer step and
+the data pipeline are not part of it (and not part of this repository's scope).
+"""
+import math
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from richsem_amd import workload as W
+from richsem_amd.backbone import InputProjection, ResNet50
+from richsem_amd.clip_resnet import ModifiedResNetTeacher
+from richsem_amd.dn import prepare_dn_layout
+from richsem_amd.matcher import HungarianMatcher
+from richsem_amd.modules import (MLP, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, TransformerDecoder,
+                                 clip_box_targets, get_reference_points, inverse_sigmoid)
+from richsem_amd.two_stage import ClassScorer
+
+NUM_CLASSES, NUM_QUERIES, DN_NUMBER, PROJ = 1204, 900, 100, 1024
+
+
+# ---- small helpers of the reference, restated (host-side torch ops) -----------------------------------------------------------------
+def box_cxcywh_to_xyxy(x):
+    cx, cy, w, h = x.unbind(-1)
+    return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1)
+
+
+def giou_pairs(a, b):
+    """generalised IoU of matched pairs (util/box_ops.py:41-64 on the diagonal), xyxy boxes"""
+    area = lambda t: (t[:, 2] - t[:, 0]) * (t[:, 3] - t[:, 1])
+    lt, rb = torch.max(a[:, :2], b[:, :2]), torch.min(a[:, 2:], b[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, 0] * wh[:, 1]                 # (not .prod(-1): its backward reads a zero count back to the host)
+    union = area(a) + area(b) - inter
+    iou = inter / (union + 1e-6)
+    hw = (torch.max(a[:, 2:], b[:, 2:]) - torch.min(a[:, :2], b[:, :2])).clamp(min=0)
+    hull = hw[:, 0] * hw[:, 1]
+    return iou - (hull - union) / (hull + 1e-6)
+
+
+def sigmoid_focal_loss(logits, pos_index, num_boxes, alpha=0.25, gamma=2.0):
+    """models/richsem/utils.py:82-108 (gamma = 2) for one-hot targets given as the index tuple of their ones: the value of
+    ``(ce * (1 - p_t) ** 2 * alpha_t).mean(1).sum() / num_boxes`` -- the all-negative formula over every entry plus the difference at the
+    positive entries, so that the (N, nq, 1204) one-hot tensor and its dozen element-wise passes are never formed"""
+    assert gamma == 2.0
+    p = logits.sigmoid()
+    neg = ((1 - alpha) * p * p * F.softplus(logits)).sum()
+    x, q = logits[pos_index], p[pos_index]
+    pos = (alpha * (1 - q) ** 2 * F.softplus(-x) - (1 - alpha) * q * q * F.softplus(x)).sum()
+    return (neg + pos) / logits.shape[1] / num_boxes
+
+
+def sine_position(mask, num_pos_feats=128, temperature=20.0):
+    """PositionEmbeddingSineHW (models/richsem/position_encoding.py:46-92, temperatureH = temperatureW = 20, normalize): (N, H, W) bool
+    padding mask -> (N, H * W, 256)"""
+    not_mask = ~mask
+    y_embed, x_embed = not_mask.cumsum(1, dtype=torch.float32), not_mask.cumsum(2, dtype=torch.float32)
+    eps, scale = 1e-6, 2 * math.pi
+    y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
+    x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32, device=mask.device)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_pos_feats)
+    px, py = x_embed[:, :, :, None] / dim_t, y_embed[:, :, :, None] / dim_t
+    px = torch.stack((px[:, :, :, 0::2].sin(), px[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    py = torch.stack((py[:, :, :, 0::2].sin(), py[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((py, px), dim=3).flatten(1, 2)
+
+
+def gen_encoder_output_proposals(memory, memory_padding_mask, shapes):
+    """models/richsem/utils.py:10-65: per-pixel anchor boxes (unsigmoided) and the memory with invalid positions zeroed"""
+    N = memory.shape[0]
+    proposals, cur = [], 0
+    for lvl, (H_, W_) in enumerate(shapes):
+        m = memory_padding_mask[:, cur:cur + H_ * W_].view(N, H_, W_, 1)
+        valid_H, valid_W = (~m[:, :, 0, 0]).sum(1), (~m[:, 0, :, 0]).sum(1)
+        gy, gx = torch.meshgrid(torch.linspace(0, H_ - 1, H_, dtype=torch.float32, device=memory.device),
+                                torch.linspace(0, W_ - 1, W_, dtype=torch.float32, device=memory.device), indexing="ij")
+        grid = torch.cat([gx.unsqueeze(-1), gy.unsqueeze(-1)], -1)
+        scale = torch.cat([valid_W.unsqueeze(-1), valid_H.unsqueeze(-1)], 1).view(N, 1, 1, 2)
+        grid = (grid.unsqueeze(0).expand(N, -1, -1, -1) + 0.5) / scale
+        wh = torch.ones_like(grid) * 0.05 * (2.0 ** lvl)
+        proposals.append(torch.cat((grid, wh), -1).view(N, -1, 4))
+        cur += H_ * W_
+    out = torch.cat(proposals, 1)
+    valid = ((out > 0.01) & (out < 0.99)).all(-1, keepdim=True)
+    out = torch.log(out / (1 - out))
+    out = out.masked_fill(memory_padding_mask.unsqueeze(-1), float("inf")).masked_fill(~valid, float("inf"))
+    mem = memory.masked_fill(memory_padding_mask.unsqueeze(-1), 0.0).masked_fill(~valid, 0.0)
+    return mem, out
+
+
+class Step(nn.Module):
+    """the rows with their (synthetic) parameters; ``forward`` = model forward + criterion, returns the loss and section times"""
+
+    def __init__(self, n_img=2, height=800, width=1333, boxes_per_image=12, seed=0, dev="cuda"):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.n_img, self.H, self.Wimg, self.K = n_img, height, width, boxes_per_image
+        self.Wpad = (width + 31) // 32 * 32
+        self.backbone = ResNet50()
+        self.backbone.load_state_dict(W.resnet50_state_dict(seed=seed + 1))
+        self.input_proj = InputProjection()
+        enc = DeformableTransformerEncoderLayer(256, 2048, dropout=0.0, n_levels=4, n_heads=8, n_points=4)
+        self.encoder = nn.ModuleList([enc] + [type(enc)(256, 2048, dropout=0.0, n_levels=4, n_heads=8, n_points=4) for _ in range(5)])
+        self.level_embed = nn.Parameter(torch.randn(4, 256))
+        self.enc_output, self.enc_output_norm = nn.Linear(256, 256), nn.LayerNorm(256)
+        self.enc_out_bbox_embed = MLP(256, 256, 4, 3)
+        self.tgt_embed = nn.Embedding(NUM_QUERIES, 256)
+        self.label_enc = nn.Embedding(NUM_CLASSES + 1, 256)
+        dec = DeformableTransformerDecoderLayer(256, 2048, dropout=0.0, n_levels=4, n_heads=8, n_points=4)
+        self.decoder = TransformerDecoder(dec, 6, nn.LayerNorm(256), d_model=256)
+        self.decoder.bbox_embed = nn.ModuleList([MLP(256, 256, 4, 3) for _ in range(6)])
+        # the CLIP-space classifier (richsem.py:38-205): visual projection (trained), distillation projection (trained), frozen text side
+        self.dino_visual_proj = nn.Linear(256, PROJ, bias=False)
+        self.proj_dino_hs = nn.Linear(256, PROJ)
+        self.register_buffer("text_embed", torch.randn(NUM_CLASSES, PROJ))
+        self.register_buffer("logit_scale", torch.tensor(math.log(1 / 0.07)))
+        for m in list(self.encoder) + list(self.decoder.layers):
+            att = m.self_attn if hasattr(m.self_attn, "sampling_offsets") else m.cross_attn
+            with torch.no_grad():
+                att.sampling_offsets.weight.normal_(0, 0.01)
+                att.attention_weights.weight.normal_(0, 0.05)
+        self.to(dev)
+        self.teacher = ModifiedResNetTeacher(W.clip_rn50_state_dict(seed=seed + 2), heads=32)      # frozen: not a sub-module
+        self.matcher = HungarianMatcher(cost_class=2.0, cost_bbox=5.0, cost_giou=2.0)
+        self.scorer = ClassScorer(2)
+        self.times = {}
+        self.timing = True
+        self.stop_at = None       # (tools/capture_probe.py: end the step after this section with a surrogate loss)
+
+    # synthetic LVIS-shaped batch
+    def batch(self, seed=0):
+        g = torch.Generator().manual_seed(42 + seed)
+        N, dev = self.n_img, self.level_embed.device
+        images = torch.zeros(N, 3, self.H, self.Wpad)
+        images[..., :self.Wimg] = torch.randn(N, 3, self.H, self.Wimg, generator=g)
+        mask = torch.zeros(N, self.H, self.Wpad, dtype=torch.bool)
+        mask[..., self.Wimg:] = True
+        targets = []
+        for _ in range(N):
+            cxcy, wh = torch.rand(self.K, 2, generator=g) * 0.6 + 0.2, torch.rand(self.K, 2, generator=g) * 0.35 + 0.05
+            targets.append({"boxes": torch.cat((cxcy, wh), 1).to(dev), "labels": torch.randint(1, 1204, (self.K,), generator=g).to(dev),
+                            "size": torch.tensor([float(self.H), float(self.Wimg)], device=dev)})
+        return images.to(dev), mask.to(dev), targets
+
+    def _mark(self, name):
+        if not self.timing:       # (timing events cannot be recorded while the stream is being captured)
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self._events.append((name, ev))
+
+    def class_logits(self, hs):
+        """CLIPAlign.forward / forward_hs (richsem.py:182-205)"""
+        f = F.linear(hs, self.dino_visual_proj.weight.to(hs.dtype))
+        f = f / f.norm(dim=-1, keepdim=True)
+        t = self.text_embed / self.text_embed.norm(dim=-1, keepdim=True)
+        return (self.logit_scale.exp() * (f @ t.to(f.dtype).t())).float()
+
+    @torch.no_grad()
+    def prepare(self, mask, targets):
+        """what depends on the batch's geometry only (level shapes, padding masks, valid ratios, encoder reference points, denoising
+        layout) and on the frozen text side (the two-stage scorer's packed operand): built once per batch shape -- a few small
+        launches and host -> device copies a trainer repeats per step; kept out of the step so that it can be captured into a graph"""
+        dev = mask.device
+        shapes = list(W.pyramid_shapes(self.H, self.Wpad))
+        masks = [F.interpolate(mask[None].float(), size=s).to(torch.bool)[0] for s in shapes]
+        spatial = torch.tensor(shapes, dtype=torch.int64, device=dev)
+        st = {"shapes": shapes, "masks": masks, "spatial": spatial,
+              "lsi": torch.cat((spatial.new_zeros(1), spatial.prod(1).cumsum(0)[:-1])),
+              "mask_flat": torch.cat([m.flatten(1) for m in masks], 1),
+              "valid_ratios": torch.stack([torch.stack([(~m[:, 0, :]).sum(1) / m.shape[2], (~m[:, :, 0]).sum(1) / m.shape[1]], -1)
+                                           for m in masks], 1).float()}
+        st["ref"] = get_reference_points(shapes, st["valid_ratios"], dev)
+        st["known_num"] = [len(t["labels"]) for t in targets]
+        st["lay"] = prepare_dn_layout(st["known_num"], DN_NUMBER, NUM_QUERIES, use_cdn=True)
+        st["scale"] = self.logit_scale.detach().clone()
+        self.scorer.prepare(self.dino_visual_proj.weight, self.text_embed, self.logit_scale)      # (once per weight update)
+        self.static = st
+        return st
+
+    def forward(self, images, mask, targets, indices=None):
+        self._events = []
+        self._mark("start")
+        N, dev = images.shape[0], images.device
+        st = self.static
+        shapes, masks, spatial, lsi, mask_flat, valid_ratios = (st[k] for k in ("shapes", "masks", "spatial", "lsi", "mask_flat", "valid_ratios"))
+        # ---- backbone + input projections (richsem.py:581-612) -------------------------------------------------------------------
+        feats = self.backbone(images)
+        self._mark("backbone")
+        if self.stop_at == "backbone":
+            return sum(f.float().sum() for f in feats)
+        srcs, got_shapes = self.input_proj(feats, out_dtype=torch.bfloat16)
+        assert got_shapes == shapes
+        pos = [sine_position(m) + self.level_embed[l].view(1, 1, -1) for l, m in enumerate(masks)]
+        src = torch.cat(srcs, 1)
+        pos_flat = torch.cat(pos, 1).to(torch.bfloat16)
+        self._mark("input_proj")
+        if self.stop_at == "input_proj":
+            return src.float().sum() + pos_flat.float().sum()
+        # ---- encoder (deformable_transformer.py:319) -------------------------------------------------------------------------------
+        ref = st["ref"]
+        memory = src
+        for layer in self.encoder:
+            memory = layer(memory, pos_flat, ref, spatial, lsi, mask_flat)
+        self._mark("encoder")
+        if self.stop_at == "encoder":
+            return memory.float().sum()
+        # ---- two-stage query selection (:352-380) ----------------------------------------------------------------------------------
+        mem_f = memory.float()
+        output_memory, output_proposals = gen_encoder_output_proposals(mem_f, mask_flat, shapes)
+        output_memory = self.enc_output_norm(self.enc_output(output_memory))
+        topk = self.scorer.topk_proposals(output_memory, NUM_QUERIES)                                  # no logit tensor (two_stage.py)
+        coord_unselected = self.enc_out_bbox_embed(output_memory) + output_proposals
+        refpoint_undetach = torch.gather(coord_unselected, 1, topk[..., None].expand(-1, -1, 4))
+        tgt_undetach = torch.gather(output_memory, 1, topk[..., None].expand(-1, -1, 256))
+        interm = {"pred_logits": self.class_logits(tgt_undetach), "pred_boxes": refpoint_undetach.sigmoid()}
+        self._mark("two_stage")
+        if self.stop_at == "two_stage":
+            return interm['pred_logits'].sum() + interm['pred_boxes'].sum()
+        # ---- denoising queries (dn_components.py:11-193): layout on the library's kernels, noise as torch ops -----------------------
+        known_num, lay = st["known_num"], st["lay"]
+        pad, groups = lay["pad_size"], lay["num_dn_group"]
+        labels, boxes = torch.cat([t["labels"] for t in targets]), torch.cat([t["boxes"] for t in targets])
+        known_labels, known_boxes = labels.repeat(2 * groups), boxes.repeat(2 * groups, 1)
+        p = torch.rand(known_labels.shape, device=dev)
+        noised = torch.where(p < 0.25, torch.randint(0, NUM_CLASSES, known_labels.shape, device=dev), known_labels)
+        xyxy = box_cxcywh_to_xyxy(known_boxes)
+        diff = torch.cat((known_boxes[:, 2:] / 2, known_boxes[:, 2:] / 2), 1)
+        sign = torch.randint(0, 2, xyxy.shape, device=dev).float() * 2 - 1
+        rand_part = torch.rand(xyxy.shape, device=dev)
+        neg = (torch.arange(known_labels.numel(), device=dev) // labels.numel()) % 2 == 1
+        rand_part = torch.where(neg[:, None], rand_part + 1.0, rand_part) * sign
+        xyxy = (xyxy + rand_part * diff).clamp(0.0, 1.0)
+        nb = torch.cat(((xyxy[:, :2] + xyxy[:, 2:]) / 2, xyxy[:, 2:] - xyxy[:, :2]), 1)
+        q_label = torch.zeros(N, pad, 256, device=dev)
+        q_bbox = torch.zeros(N, pad, 4, device=dev)
+        q_label[lay["known_bid"], lay["map_known_indice"]] = self.label_enc(noised)
+        q_bbox[lay["known_bid"], lay["map_known_indice"]] = inverse_sigmoid(nb)
+        tgt = torch.cat((q_label, self.tgt_embed.weight[None].expand(N, -1, -1)), 1)                   # embed_init_tgt
+        refpoints = torch.cat((q_bbox, refpoint_undetach.detach()), 1)
+        self._mark("dn")
+        if self.stop_at == "dn":
+            return tgt.sum() + refpoints.sum() + interm['pred_logits'].sum() + interm['pred_boxes'].sum()
+        # ---- decoder (:427) -----------------------------------------------------------------------------------------------------------
+        hs, refs = self.decoder(tgt=tgt.transpose(0, 1).to(torch.bfloat16), memory=memory.transpose(0, 1), tgt_mask=lay["attn_mask"],
+                                memory_key_padding_mask=mask_flat, refpoints_unsigmoid=refpoints.transpose(0, 1), level_start_index=lsi,
+                                spatial_shapes=spatial, valid_ratios=valid_ratios)
+        self._mark("decoder")
+        if self.stop_at == "decoder":
+            return sum(h.float().sum() for h in hs) + sum(r.sum() for r in refs) + interm['pred_logits'].sum() + interm['pred_boxes'].sum()
+        # ---- heads (richsem.py:705-733) -------------------------------------------------------------------------------------------------
+        hs_stack = torch.stack(hs)                                                                     # (6, N, pad + 900, 256)
+        coords = torch.stack([(self.decoder.bbox_embed[l](hs[l]).float() + inverse_sigmoid(refs[l])).sigmoid() for l in range(6)])
+        logits = self.class_logits(hs_stack)                                                           # (6, N, 1092, 1204)
+        clip_hs = F.linear(hs[-1], self.proj_dino_hs.weight.to(hs[-1].dtype), self.proj_dino_hs.bias.to(hs[-1].dtype))
+        clip_hs = clip_hs / clip_hs.norm(dim=-1, keepdim=True)
+        tn = self.text_embed / self.text_embed.norm(dim=-1, keepdim=True)
+        clip_logits = (self.logit_scale.exp() * (clip_hs @ tn.to(clip_hs.dtype).t())).float()          # (N, 1092, 1204)
+        self._mark("heads")
+        if self.stop_at == "heads":
+            return coords.sum() + logits.sum() + clip_logits.sum() + interm['pred_logits'].sum() + interm['pred_boxes'].sum()
+        # ---- frozen teacher -> ROIAlign -> attention pool -> text logits (richsem.py:614-629, :741-768) ----------------------------------
+        with torch.no_grad():
+            _, fmap = self.teacher(images, ret_sp=True)
+            _, t_logits = clip_box_targets(fmap, targets, self.teacher.attnpool, self.text_embed, st["scale"])
+        self._mark("teacher")
+        # ---- matcher (matcher.py:30-78, one host copy for the 7 outputs) -------------------------------------------------------------------
+        outs = [{"pred_logits": logits[l][:, pad:], "pred_boxes": coords[l][:, pad:]} for l in range(6)] + [interm]
+        if indices is None:
+            indices = self.matcher.match_many(outs, targets)
+        self.last_indices = indices
+        self._mark("matcher")
+        # ---- criterion (richsem.py:1124-1306, compact) --------------------------------------------------------------------------------------
+        num_boxes = float(max(sum(known_num), 1))
+        tgt_boxes_all = [t["boxes"] for t in targets]
+        loss = logits.new_zeros(())
+        for o, idx in zip(outs, indices):
+            bi = torch.cat([torch.full_like(s, b) for b, (s, _) in enumerate(idx)]).to(dev)
+            si = torch.cat([s for s, _ in idx]).to(dev)
+            tl = torch.cat([t["labels"][j.to(dev)] for t, (_, j) in zip(targets, idx)])
+            tb = torch.cat([tbx[j.to(dev)] for tbx, (_, j) in zip(tgt_boxes_all, idx)])
+            pb = o["pred_boxes"][bi, si]
+            loss = loss + sigmoid_focal_loss(o["pred_logits"], (bi, si, tl), num_boxes) * o["pred_logits"].shape[1]
+            loss = loss + 5.0 * (pb - tb).abs().sum() / num_boxes
+            loss = loss + 2.0 * (1 - giou_pairs(box_cxcywh_to_xyxy(pb), box_cxcywh_to_xyxy(tb))).sum() / num_boxes
+        # denoising part: the positive slots reconstruct their boxes and labels (dn_components.py / richsem.py:1163-1193)
+        single = lay["single_pad"]
+        pos_slots = (torch.arange(groups, device=dev)[:, None] * 2 * single + torch.arange(single, device=dev)[None]).flatten()
+        for l in range(6):
+            dl, db = logits[l][:, :pad][:, pos_slots], coords[l][:, :pad][:, pos_slots]                # every image has `single` boxes here
+            tlab = torch.stack([t["labels"] for t in targets]).repeat(1, groups)
+            tbx = torch.stack(tgt_boxes_all).repeat(1, groups, 1)
+            nbx = num_boxes * groups
+            bi_, si_ = torch.meshgrid(torch.arange(N, device=dev), torch.arange(dl.shape[1], device=dev), indexing="ij")
+            loss = loss + sigmoid_focal_loss(dl, (bi_.reshape(-1), si_.reshape(-1), tlab.reshape(-1)), nbx) * dl.shape[1]
+            loss = loss + 5.0 * (db - tbx).abs().sum() / nbx
+            loss = loss + 2.0 * (1 - giou_pairs(box_cxcywh_to_xyxy(db.reshape(-1, 4)), box_cxcywh_to_xyxy(tbx.reshape(-1, 4)))).sum() / nbx
+        # distillation: KL of the matched queries' CLIP logits against the teacher's box logits (richsem.py:1255-1300)
+        idx = indices[5]
+        bi = torch.cat([torch.full_like(s, b) for b, (s, _) in enumerate(idx)]).to(dev)
+        si = torch.cat([s for s, _ in idx]).to(dev) + pad
+        tgt_l = torch.cat([tl[j.to(dev)] for tl, (_, j) in zip(t_logits, idx)]).float()
+        loss = loss + 0.5 * F.kl_div(F.log_softmax(clip_logits[bi, si], -1), F.softmax(tgt_l, -1), reduction="batchmean")
+        self._mark("criterion")
+        return loss
+
+    def section_ms(self):
+        """ms per forward section of the last step (events recorded on the current stream)"""
+        torch.cuda.synchronize()
+        out, prev = {}, self._events[0][1]
+        for name, ev in self._events[1:]:
+            out[name] = prev.elapsed_time(ev)
+            prev = ev
+        return out
+
+
+def run(n_img, dev, steps=5, warmup=2, graph=True):
+    """time `steps` composed steps (forward + loss + backward); returns the dict bench.py attaches as ``full_step``"""
+    model = Step(n_img=n_img, dev=dev)
+    images, mask, targets = model.batch()
+    model.prepare(mask, targets)
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def step(indices=None):
+        for p in params:
+            p.grad = None
+        loss = model(images, mask, targets, indices)
+        fwd = None
+        if model.timing:
+            fwd = torch.cuda.Event(enable_timing=True)
+            fwd.record()
+        loss.backward()
+        return loss, fwd
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    rows, totals, bwds = {}, [], []
+    for _ in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        loss, fwd = step()
+        b.record()
+        torch.cuda.synchronize()
+        totals.append(a.elapsed_time(b))
+        bwds.append(fwd.elapsed_time(b))
+        for k, v in model.section_ms().items():
+            rows.setdefault(k, []).append(v)
+    ms = sum(totals) / len(totals)
+    out = {"what": "ONE composed training step on the library's rows at configs[1] sizes: ResNet-50 (layer2-4 trained) -> input projections "
+                   "-> 6 encoder layers -> two-stage score + top-900 -> denoising layout -> 6 decoder layers -> heads -> frozen CLIP-RN50 "
+                   "teacher -> ROIAlign -> attention pool -> matcher -> losses, forward + backward, bf16 activations / fp32 parameters; "
+                   "synthetic weights and batch; no optimizer step, no data pipeline (bench_step.py)",
+           "ms": round(ms, 2), "img_per_s": round(n_img / (ms * 1e-3), 2), "loss": float(loss.detach()),
+           "forward_rows_ms": {k: round(sum(v) / len(v), 3) for k, v in rows.items()},
+           "backward_ms": round(sum(bwds) / len(bwds), 2)}
+    if not graph:
+        return out
+    # the device part as a captured graph: the assignment of the last eager step held fixed (the matcher's host round trip cannot be captured)
+    import gc
+    indices = [[(i.to(dev), j.to(dev)) for i, j in idx] for idx in model.last_indices]      # (no host -> device copies in the capture)
+    del loss, fwd, a, b             # (with the eager steps' timing events / loss still alive, ending the capture crashes in this ROCm build)
+    gc.collect()
+    model.timing = False
+
+    def replay_ms(stop_at):
+        """capture the step cut off after section `stop_at` (None: all of it) into a HIP graph; ms per replay"""
+        model.stop_at = stop_at
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                step(indices)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step(indices)
+        g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    try:
+        rep = replay_ms(None)
+        out["graph_replay"] = {"ms": round(rep, 2), "img_per_s": round(n_img / (rep * 1e-3), 2),
+                               "note": "forward + backward captured once into a HIP graph and replayed, the Hungarian assignment of the last "
+                                       "eager step held fixed (its host round trip cannot be captured)"}
+        # GPU time per row, forward + backward: replay time of the step cut off after each section (a surrogate loss = the sum of the
+        # section's outputs), differenced; "criterion" = the rest (teacher + matcher-less losses and their backward into the heads)
+        prev, table = 0.0, {}
+        for name in ("backbone", "input_proj", "encoder", "two_stage", "dn", "decoder", "heads"):
+            t = replay_ms(name)
+            table[name] = round(t - prev, 2)
+            prev = t
+        table["teacher+criterion"] = round(rep - prev, 2)
+        out["graph_replay"]["rows_fwd_bwd_ms"] = table
+    except Exception as e:      # a capture failure must not take the bench line down
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        out.setdefault("graph_replay", {})["error"] = f"{type(e).__name__}: {str(e)[:300]}"
+    finally:
+        model.stop_at = None
+    return out
+
+
+if __name__ == "__main__":
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--images", type=int, default=2)
+    ap.add_argument("--no-graph", action="store_true", help="eager steps only (the form profiled for profiles/*_step_kernels.md)")
+    a_ = ap.parse_args()
+    print(json.dumps(run(a_.images, torch.device("cuda", 0), a_.steps, a_.warmup, graph=not a_.no_graph), indent=1))

@@ -417,17 +417,17 @@ int msda_lin256_forward_stacked_bf16(const uint16_t *x, const uint16_t *packed_w
 /* Masked multi-head self-attention of the decoder's queries (csrc/attn_mfma.hip; reference: nn.MultiheadAttention of
  * DeformableTransformerDecoderLayer, models/richsem/deformable_transformer.py:907, :974-978): softmax(q k^T / sqrt(32) + mask) v per
  * (image, head), head dimension 32, bf16 storage, fp32 softmax -- new capability (the reference runs torch's fp32 attention).
- * Sequence-first tokens: token (i, b) is row i * bs + b of q / k / v (`ld*` elements apart, a head's 32 channels at column 32 h);
- * out / dout (nq, bs, heads * 32) contiguous; lse (bs * heads, ceil32(nq)) f32: log2-sum-exp per query, written by the forward, read by
+ * Token (i, b) is row i * bs + b of q / k / v (sequence-first, batch_first = 0) or row b * nq + i (batch_first = 1), `ld*` elements
+ * apart, a head's 32 channels at column 32 h; out / dout the same rows, heads * 32 wide, contiguous; lse (bs * heads, ceil32(nq)) f32: log2-sum-exp per query, written by the forward, read by
  * the backward; mask_bits (nq, ceil(nq / 32)) uint32: bit j of word (q, kb) set = query q must not attend to key 32 kb + j;
  * maskt_bits the same of the transposed mask (both NULL = no mask); workspace: msda_attn_workspace_bytes(nq, bs, heads) bytes.
  * 16-byte aligned pointers, ld* multiples of 8.  Every element of out / dq / dk / dv is written. */
 int64_t msda_attn_workspace_bytes(int nq, int bs, int heads);
 int msda_attn_forward_bf16(const uint16_t *q, int ldq, const uint16_t *k, int ldk, const uint16_t *v, int ldv, const uint32_t *mask_bits,
-                           int nq, int bs, int heads, uint16_t *out, float *lse, void *workspace, msda_stream_t stream);
+                           int nq, int bs, int batch_first, int heads, uint16_t *out, float *lse, void *workspace, msda_stream_t stream);
 int msda_attn_backward_bf16(const uint16_t *q, int ldq, const uint16_t *k, int ldk, const uint16_t *v, int ldv, const uint16_t *out,
                             const uint16_t *dout, const float *lse, const uint32_t *mask_bits, const uint32_t *maskt_bits, int nq, int bs,
-                            int heads, uint16_t *dq, int lddq, uint16_t *dk, int lddk, uint16_t *dv, int lddv, void *workspace,
+                            int batch_first, int heads, uint16_t *dq, int lddq, uint16_t *dk, int lddk, uint16_t *dv, int lddv, void *workspace,
                             msda_stream_t stream);
 /* The same product for fp32 tensors at fp32-level accuracy (both operands split into bf16 hi + lo parts, three bf16 MFMAs per tile;
  * csrc/lin256_mfma.hip): out (tokens, out_features) f32 = x (tokens, 256) f32 . W^T + bias.  msda_lin256_pack_f32: W (out_features, 256)

@@ -145,9 +145,9 @@ def load():
     L.msda_lin256_forward_stacked_bf16.restype = ci
     L.msda_attn_workspace_bytes.argtypes = [ci, ci, ci]
     L.msda_attn_workspace_bytes.restype = ctypes.c_int64
-    L.msda_attn_forward_bf16.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, vp, vp, vp, vp]
+    L.msda_attn_forward_bf16.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp]
     L.msda_attn_forward_bf16.restype = ci
-    L.msda_attn_backward_bf16.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp, vp]
+    L.msda_attn_backward_bf16.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp, vp]
     L.msda_attn_backward_bf16.restype = ci
     for sfx in ("f32", "f64", "bf16"):
         f = getattr(L, "msda_forward_" + sfx)

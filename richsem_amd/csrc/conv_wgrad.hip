@@ -266,7 +266,9 @@ void wgrad_split(const WgradGeom &g, long long &split, long long &chunk)
 {
     const long long blocks_y = (long long)g.KH * g.KW * (g.Cout / kBM) * (g.Cin / kBN);
     split = (512 + blocks_y - 1) / blocks_y;
-    const long long max_split = (g.P + 511) / 512;
+    // (few pixels -- the decoder's ~2 k tokens: chunks of 128, or 20 workgroups would each walk 512 pixels one stage after the other)
+    const long long min_chunk = g.P >= 16384 ? 512 : 128;
+    const long long max_split = (g.P + min_chunk - 1) / min_chunk;
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
     chunk = ((g.P + split - 1) / split + kStagePx - 1) / kStagePx * kStagePx;

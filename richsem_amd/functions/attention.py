@@ -40,41 +40,36 @@ def mask_bits(mask):
     return val
 
 
-def _check_strides(t, bs):
-    assert t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == bs * t.stride(1), \
-        "attention: sequence-first (nq, bs, C) bf16 tensors whose tokens are evenly strided"
-    return t.stride(1)
-
-
 def _ws(nq, bs, heads, device):
     n = _lib.load().msda_attn_workspace_bytes(nq, bs, heads)
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
 class MaskedSelfAttentionFunction(Function):
-    """apply(qk, v, mask, n_heads): qk (nq, bs, 2 C) bf16 -- queries in [..., :C], keys in [..., C:], the output of ONE stacked
-    projection -- v (nq, bs, C) bf16, mask (nq, nq) bool (True = masked) or None -> (nq, bs, C) bf16"""
+    """apply(qk, v, mask, n_heads, batch_first): qk (nq, bs, 2 C) bf16 [or (bs, nq, 2 C) with ``batch_first``] -- queries in
+    [..., :C], keys in [..., C:], the output of ONE stacked projection -- v the same with C channels, mask (nq, nq) bool (True =
+    masked) or None -> the attention's output in v's layout"""
 
     @staticmethod
-    def forward(ctx, qk, v, mask, n_heads):
+    def forward(ctx, qk, v, mask, n_heads, batch_first=False):
         if not qk.is_cuda:
             raise RuntimeError("Not implemented on the CPU")
-        nq, bs, c2 = qk.shape
+        (bs, nq, c2) = qk.shape if batch_first else (qk.shape[1], qk.shape[0], qk.shape[2])
         C = c2 // 2
-        assert C == n_heads * 32 and v.shape == (nq, bs, C), "attention kernels: head dimension 32"
+        assert C == n_heads * 32 and v.shape == qk.shape[:2] + (C,), "attention kernels: head dimension 32"
         qk, v = qk.contiguous(), v.contiguous()
         bits = mask_bits(mask) if mask is not None else (None, None)
         nqp = (nq + 31) // 32 * 32
-        out = torch.empty((nq, bs, C), dtype=torch.bfloat16, device=qk.device)
+        out = torch.empty_like(v)
         lse = torch.empty((bs * n_heads, nqp), dtype=torch.float32, device=qk.device)
         ws = _ws(nq, bs, n_heads, qk.device)
         esz = 2
         with torch.cuda.device(qk.device):
             _lib.check(_lib.load().msda_attn_forward_bf16(
                 qk.data_ptr(), c2, qk.data_ptr() + C * esz, c2, v.data_ptr(), C, bits[0].data_ptr() if bits[0] is not None else None,
-                nq, bs, n_heads, out.data_ptr(), lse.data_ptr(), ws.data_ptr(), torch.cuda.current_stream(qk.device).cuda_stream))
+                nq, bs, int(batch_first), n_heads, out.data_ptr(), lse.data_ptr(), ws.data_ptr(), torch.cuda.current_stream(qk.device).cuda_stream))
         ctx.save_for_backward(qk, v, out, lse, *(b for b in bits if b is not None))
-        ctx.meta = (n_heads, mask is not None)
+        ctx.meta = (n_heads, mask is not None, batch_first, nq, bs)
         return out
 
     @staticmethod
@@ -82,9 +77,9 @@ class MaskedSelfAttentionFunction(Function):
     def backward(ctx, dout):
         saved = ctx.saved_tensors
         qk, v, out, lse = saved[:4]
-        n_heads, has_mask = ctx.meta
+        n_heads, has_mask, batch_first, nq, bs = ctx.meta
         bits = saved[4:6] if has_mask else (None, None)
-        nq, bs, c2 = qk.shape
+        c2 = qk.shape[2]
         C = c2 // 2
         dout = dout.contiguous()
         dqk, dv = torch.empty_like(qk), torch.empty_like(v)
@@ -92,11 +87,11 @@ class MaskedSelfAttentionFunction(Function):
         with torch.cuda.device(qk.device):
             _lib.check(_lib.load().msda_attn_backward_bf16(
                 qk.data_ptr(), c2, qk.data_ptr() + C * 2, c2, v.data_ptr(), C, out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                bits[0].data_ptr() if has_mask else None, bits[1].data_ptr() if has_mask else None, nq, bs, n_heads,
+                bits[0].data_ptr() if has_mask else None, bits[1].data_ptr() if has_mask else None, nq, bs, int(batch_first), n_heads,
                 dqk.data_ptr(), c2, dqk.data_ptr() + C * 2, c2, dv.data_ptr(), C, ws.data_ptr(),
                 torch.cuda.current_stream(qk.device).cuda_stream))
-        return dqk, dv, None, None
+        return dqk, dv, None, None, None
 
 
-def masked_self_attention(qk, v, mask, n_heads):
-    return MaskedSelfAttentionFunction.apply(qk, v, mask, n_heads)
+def masked_self_attention(qk, v, mask, n_heads, batch_first=False):
+    return MaskedSelfAttentionFunction.apply(qk, v, mask, n_heads, batch_first)

@@ -42,7 +42,7 @@ class LinearBf16Function(torch.autograd.Function):
     GEMMs, the weight gradient is :func:`linear_wgrad_bf16` (for layer sizes it supports and enough tokens to pay: the library's
     transposed GEMM otherwise), the bias gradient a column sum.  Gradients come back in the parameters' dtype."""
 
-    MIN_TOKENS = 4096
+    MIN_TOKENS = 1024
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -225,6 +225,18 @@ def pack_linear256(weights, biases):
             "b32": b.float().contiguous(), "rows": [int(t.shape[0]) for t in weights]}
 
 
+def pack_linear256_padded(weight, bias):
+    """:func:`pack_linear256` for a layer with fewer than 64 outputs (the box heads' 256 -> 4): the weight padded with zero rows to 64;
+    the caller takes the first ``out_features`` columns of the result"""
+    n = weight.shape[0]
+    w = torch.zeros((64, 256), dtype=weight.dtype, device=weight.device)
+    b = torch.zeros(64, dtype=bias.dtype, device=bias.device)
+    w[:n], b[:n] = weight.detach(), bias.detach()
+    pk = pack_linear256([w], [b])
+    pk["rows"] = [n]
+    return pk
+
+
 def _mask_rows_(t, mask):
     """zero the rows of ``t`` (T, C) bf16 where ``mask`` (T,) bool is set, in place (only those rows are touched)"""
     with torch.cuda.device(t.device):
@@ -237,25 +249,27 @@ class Lin256Function(torch.autograd.Function):
     """``x W^T + b`` for a 256-wide bf16 input on the library's own MFMA kernel (csrc/lin256_mfma.hip): forward, and the input gradient
     too when the layer is 256 -> 256 (else the library's bf16 GEMM); the weight / bias gradients on the weight-gradient kernel where
     there are enough tokens to pay (functions/linear.py: linear_wgrad_bf16), else the library's transposed GEMM.
-    ``apply(x, pk, row_mask, *params)``: ``pk`` from :func:`pack_linear256` (kept by the caller in a :class:`VersionCache`);
-    ``row_mask`` (tokens,) bool or None zeroes the rows of masked tokens in the kernel's epilogue (and their gradient);
-    ``params`` = the weights then the biases of the stacked layers, to which the gradients are routed."""
+    ``apply(x, pk, row_mask, relu, *params)``: ``pk`` from :func:`pack_linear256` (kept by the caller in a :class:`VersionCache`);
+    ``row_mask`` (tokens,) bool or None zeroes the rows of masked tokens in the kernel's epilogue (and their gradient); ``relu``: the
+    ReLU in the epilogue as well; ``params`` = the weights then the biases of the stacked layers, to which the gradients are routed."""
 
     @staticmethod
-    def forward(ctx, x, pk, row_mask, *params):
+    def forward(ctx, x, pk, row_mask, relu, *params):
         x2 = x.reshape(-1, 256)
-        out = lin256(x2, pk["packed"], pk["b32"], row_mask=row_mask.reshape(-1) if row_mask is not None else None)
-        ctx.save_for_backward(x, row_mask)
+        out = lin256(x2, pk["packed"], pk["b32"], relu=bool(relu), row_mask=row_mask.reshape(-1) if row_mask is not None else None)
+        ctx.save_for_backward(x, row_mask, out if relu else None)
         ctx.pk, ctx.dts = pk, tuple(p.dtype for p in params)
         return out.view(x.shape[:-1] + (out.shape[-1],))
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        x, row_mask = ctx.saved_tensors
+        x, row_mask, out = ctx.saved_tensors
         pk, dts = ctx.pk, ctx.dts
         n = pk["w16"].shape[0]
         dy2 = dy.reshape(-1, n)
+        if out is not None:           # gradient at the ReLU's input
+            dy2 = torch.ops.aten.threshold_backward(dy2.contiguous(), out, 0)
         if row_mask is not None:      # (a copy: the incoming gradient is not ours to modify)
             dy2 = _mask_rows_(dy2.clone(memory_format=torch.contiguous_format), row_mask.reshape(-1))
         elif not dy2.is_contiguous():
@@ -264,7 +278,7 @@ class Lin256Function(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = (lin256(dy2, pk["packed_t"]) if pk["packed_t"] is not None else dy2 @ pk["w16"]).view(x.shape)
-        need = ctx.needs_input_grad[3:]
+        need = ctx.needs_input_grad[4:]
         nl = len(pk["rows"])
         grads = [None] * (2 * nl)
         if any(need):
@@ -286,7 +300,7 @@ class Lin256Function(torch.autograd.Function):
                 if need[nl + i] and db is not None:
                     grads[nl + i] = db[r0:r0 + r].to(dts[nl + i])
                 r0 += r
-        return (dx, None, None) + tuple(grads)
+        return (dx, None, None, None) + tuple(grads)
 
 
 class StackedValueProjFunction(torch.autograd.Function):

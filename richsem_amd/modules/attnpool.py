@@ -86,12 +86,13 @@ class AttentionPool2d(nn.Module):
 def clip_box_targets(clip_features, targets, attnpool, text_embed, logit_scale, patch_size=32, grid_size=7):
     """richsem.py:745-761: per image the CLIP embedding (``clip_prompt``) and the text logits (``clip_logits``) of its ground-truth
     boxes.  clip_features (N, C, H/32, W/32) from the frozen teacher; targets: list of dicts with "boxes" (cxcywh, normalised),
-    "size" (h, w) and "labels"; text_embed (classes, output_dim); logit_scale: the CLIP parameter (log of the scale).
+    "size" (h, w) and "labels"; text_embed (classes, output_dim); logit_scale: the CLIP parameter (log of the scale; a tensor on the
+    features' device keeps the call free of host -> device copies, so that it can be captured into a HIP graph).
     Returns (list of prompts, list of logits), split per image as the reference stores them into the targets."""
     dt, dev = clip_features.dtype, clip_features.device
     coord = torch.cat([t["boxes"] for t in targets]).to(dt)
     if len(coord):
-        scale = torch.cat([t["size"][[1, 0, 1, 0]][None].expand(len(t["boxes"]), -1) for t in targets]).to(dt)
+        scale = torch.cat([t["size"].flip(0).repeat(2)[None].expand(len(t["boxes"]), -1) for t in targets]).to(dt)
         cx, cy, w, h = coord.unbind(-1)
         xyxy = scale * torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)     # util/box_ops.py:9-13
         bidx = torch.cat([torch.full((len(t["boxes"]),), float(b), device=dev, dtype=dt) for b, t in enumerate(targets)])

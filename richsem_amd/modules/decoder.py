@@ -22,7 +22,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions.linear import StackedValueProjFunction, VersionCache, pack_linear256
+from ..functions.linear import (Lin256Function, LinearBf16CachedFunction, StackedValueProjFunction, VersionCache, pack_linear256,
+                                pack_linear256_padded)
 
 
 def inverse_sigmoid(x, eps=1e-3):
@@ -37,10 +38,43 @@ class MLP(nn.Module):
         h = [hidden_dim] * (num_layers - 1)
         self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
 
+        self._packs = VersionCache()
+
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.bfloat16:
+            return self._forward_bf16(x)
         for i, layer in enumerate(self.layers):
             y = F.linear(x, layer.weight.to(x.dtype), layer.bias.to(x.dtype))
             x = F.relu(y) if i < self.num_layers - 1 else y
+        return x
+
+    def _forward_bf16(self, x):
+        """bf16 activations, fp32 master parameters: the bf16 / packed forms of the parameters are kept across calls; layers with 256
+        inputs run on csrc/lin256_mfma.hip (ReLU in the epilogue; a layer with fewer than 64 outputs padded to 64), the others on the
+        library's bf16 GEMM; weight and bias gradients on the weight-gradient kernel, straight into the parameters' dtype"""
+        ps = [p for layer in self.layers for p in (layer.weight, layer.bias)]
+
+        def build():
+            forms = []
+            for layer in self.layers:
+                w, b = layer.weight, layer.bias
+                if w.shape[1] == 256 and w.shape[0] % 64 == 0:
+                    forms.append(("lin256", pack_linear256([w], [b])))
+                elif w.shape[1] == 256 and w.shape[0] < 64:
+                    forms.append(("lin256pad", pack_linear256_padded(w, b)))
+                else:
+                    forms.append(("gemm", (w.detach().to(torch.bfloat16).contiguous(), b.detach().to(torch.bfloat16).contiguous())))
+            return forms
+        forms = self._packs.get(ps, build)
+        for i, (layer, (kind, f)) in enumerate(zip(self.layers, forms)):
+            relu = i < self.num_layers - 1
+            if kind == "lin256":
+                x = Lin256Function.apply(x, f, None, relu, layer.weight, layer.bias)
+            elif kind == "lin256pad":
+                x = Lin256Function.apply(x, f, None, relu, layer.weight, layer.bias)[..., :layer.weight.shape[0]]
+            else:
+                x = LinearBf16CachedFunction.apply(x, f[0], f[1], None, layer.weight, layer.bias)
+                x = F.relu(x) if relu else x
         return x
 
 
@@ -90,16 +124,43 @@ class TransformerDecoder(nn.Module):
         mask = memory_key_padding_mask.contiguous() if memory_key_padding_mask is not None else None
         return StackedValueProjFunction.apply(mem.contiguous(), pk, mask, *ws, *bs_)     # one (N, S, 256) tensor per layer
 
+    def _forward_fast(self, tgt, memory, tgt_mask, memory_key_padding_mask, refpoints_unsigmoid, level_start_index, spatial_shapes,
+                      valid_ratios):
+        """bf16: the same computation on BATCH-first tensors throughout (the reference transposes every layer's cross-attention in
+        and out, :1017-1020; its results are handed out batch-first anyway, :818-821), the memory projected once for all layers"""
+        values = self._project_memory(memory, memory_key_padding_mask)
+        x = tgt.transpose(0, 1).contiguous()                                           # (bs, nq, C)
+        reference_points = refpoints_unsigmoid.transpose(0, 1).sigmoid()               # (bs, nq, 4)
+        ref_points = [reference_points]
+        intermediate = []
+        vr = torch.cat([valid_ratios, valid_ratios], -1)[:, None] if reference_points.shape[-1] == 4 else valid_ratios[:, None]   # (bs, 1, L, 4)
+        nw, nb = self.norm.weight.to(torch.bfloat16), self.norm.bias.to(torch.bfloat16)
+        for layer_id, layer in enumerate(self.layers):
+            reference_points_input = (reference_points[:, :, None] * vr.to(reference_points.dtype)).contiguous()                    # (bs, nq, L, 4)
+            query_sine_embed = gen_sineembed_for_position(reference_points_input[:, :, 0, :], self.d_model // 2)
+            query_pos = self.ref_point_head(query_sine_embed.to(torch.bfloat16))
+            x = layer.forward_batch_first(x, query_pos, reference_points_input.float(), values[layer_id], level_start_index, spatial_shapes,
+                                          tgt_mask)
+            if self.bbox_embed is not None:
+                delta_unsig = self.bbox_embed[layer_id](x).to(reference_points.dtype)
+                new_reference_points = (delta_unsig + inverse_sigmoid(reference_points)).sigmoid()
+                reference_points = new_reference_points.detach()
+                ref_points.append(new_reference_points)
+            intermediate.append(F.layer_norm(x, (x.shape[-1],), nw, nb, self.norm.eps))
+        return [intermediate, ref_points]
+
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None, memory_key_padding_mask=None, pos=None,
                 refpoints_unsigmoid=None, level_start_index=None, spatial_shapes=None, valid_ratios=None):
         """tgt (nq, bs, C); memory (S, bs, C); refpoints_unsigmoid (nq, bs, 4); valid_ratios (bs, L, 2).  Returns the reference's
         ``[[norm(layer output) (bs, nq, C) per layer], [reference boxes (bs, nq, 4): initial + one per layer]]``."""
+        fast = all(layer._fast(tgt) for layer in self.layers) and memory.dtype == torch.bfloat16 and self.norm is not None
+        if fast:
+            return self._forward_fast(tgt, memory, tgt_mask, memory_key_padding_mask, refpoints_unsigmoid, level_start_index,
+                                      spatial_shapes, valid_ratios)
         output = tgt
         intermediate = []
         reference_points = refpoints_unsigmoid.sigmoid()
         ref_points = [reference_points]
-        fast = all(layer._fast(output) for layer in self.layers) and memory.dtype == torch.bfloat16
-        values = self._project_memory(memory, memory_key_padding_mask) if fast else [None] * self.num_layers
         vr = torch.cat([valid_ratios, valid_ratios], -1)[None, :] if reference_points.shape[-1] == 4 else valid_ratios[None, :]
         for layer_id, layer in enumerate(self.layers):
             reference_points_input = reference_points[:, :, None] * vr.to(reference_points.dtype)              # (nq, bs, L, 4) :726-731
@@ -108,8 +169,7 @@ class TransformerDecoder(nn.Module):
             output = layer(tgt=output, tgt_query_pos=query_pos, tgt_query_sine_embed=query_sine_embed,
                            tgt_key_padding_mask=tgt_key_padding_mask, tgt_reference_points=reference_points_input, memory=memory,
                            memory_key_padding_mask=memory_key_padding_mask, memory_level_start_index=level_start_index,
-                           memory_spatial_shapes=spatial_shapes, memory_pos=pos, self_attn_mask=tgt_mask, cross_attn_mask=memory_mask,
-                           value=values[layer_id])
+                           memory_spatial_shapes=spatial_shapes, memory_pos=pos, self_attn_mask=tgt_mask, cross_attn_mask=memory_mask)
             if self.bbox_embed is not None:                                                                    # :779-804
                 reference_before_sigmoid = inverse_sigmoid(reference_points)
                 delta_unsig = self.bbox_embed[layer_id](output).to(reference_points.dtype)

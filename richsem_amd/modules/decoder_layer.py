@@ -76,28 +76,35 @@ class DeformableTransformerDecoderLayer(nn.Module):
                     "w2t": lin256_pack(self.linear2.weight.detach().to(torch.bfloat16).t().contiguous())}
         return self._packs.get(ps, build)
 
-    def _forward_fast(self, tgt, query_pos, reference_points, memory, memory_mask, lsi, shapes, attn_mask, value):
+    def forward_batch_first(self, x, query_pos, reference_points, value, lsi, shapes, attn_mask):
+        """the bf16 library-kernel path on BATCH-first tensors (no transposes between its blocks): x, query_pos (bs, nq, 256) bf16,
+        reference_points (bs, nq, L, 4) float32, value = the cross-attention's projected memory (bs, S, 256) bf16 -> (bs, nq, 256)"""
         pk = self._lin_packs()
         a = self.self_attn
         w, b = a.in_proj_weight, a.in_proj_bias
-        qpos = query_pos.to(torch.bfloat16) if query_pos is not None else None
         # self-attention (:974-978)
-        q_in = tgt if qpos is None else tgt + qpos
-        qk = Lin256Function.apply(q_in, pk["qk"], None, w[:512], b[:512])
-        v = Lin256Function.apply(tgt, pk["v"], None, w[512:], b[512:])
-        att = masked_self_attention(qk, v, attn_mask, self.n_heads)
-        tgt2 = Lin256Function.apply(att, pk["o"], None, a.out_proj.weight, a.out_proj.bias)
-        tgt = AddLayerNormFunction.apply(tgt, tgt2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        # cross-attention (:1017-1022): batch-first views of the sequence-first tensors
-        q_in = (tgt if qpos is None else tgt + qpos).transpose(0, 1).contiguous()
-        ref = reference_points.transpose(0, 1).contiguous()
+        q_in = x if query_pos is None else x + query_pos
+        qk = Lin256Function.apply(q_in, pk["qk"], None, False, w[:512], b[:512])
+        v = Lin256Function.apply(x, pk["v"], None, False, w[512:], b[512:])
+        att = masked_self_attention(qk, v, attn_mask, self.n_heads, batch_first=True)
+        x2 = Lin256Function.apply(att, pk["o"], None, False, a.out_proj.weight, a.out_proj.bias)
+        x = AddLayerNormFunction.apply(x, x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        # cross-attention (:1017-1022)
+        q_in = x if query_pos is None else x + query_pos
+        x2 = self.cross_attn.forward_from_value(q_in, reference_points, value, shapes, lsi)
+        x = AddLayerNormFunction.apply(x, x2, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        # feed-forward block (:940-944)
+        return FFNSmallFunction.apply(x, pk["w1"], pk["w2_16"], pk["w2t"], self.norm3.eps, self.linear1.weight, self.linear1.bias,
+                                      self.linear2.weight, self.linear2.bias, self.norm3.weight, self.norm3.bias)
+
+    def _forward_fast(self, tgt, query_pos, reference_points, memory, memory_mask, lsi, shapes, attn_mask, value):
+        """sequence-first in and out (the reference's layout) around :meth:`forward_batch_first`"""
         if value is None:
             value = self.cross_attn.project_value(memory.transpose(0, 1), memory_mask)
-        tgt2 = self.cross_attn.forward_from_value(q_in, ref, value, shapes, lsi).transpose(0, 1).contiguous()
-        tgt = AddLayerNormFunction.apply(tgt, tgt2, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        # feed-forward block (:940-944)
-        return FFNSmallFunction.apply(tgt, pk["w1"], pk["w2_16"], pk["w2t"], self.norm3.eps, self.linear1.weight, self.linear1.bias,
-                                      self.linear2.weight, self.linear2.bias, self.norm3.weight, self.norm3.bias)
+        qpos = query_pos.to(torch.bfloat16).transpose(0, 1).contiguous() if query_pos is not None else None
+        out = self.forward_batch_first(tgt.transpose(0, 1).contiguous(), qpos, reference_points.transpose(0, 1).contiguous(), value, lsi,
+                                       shapes, attn_mask)
+        return out.transpose(0, 1).contiguous()
 
     # ---- the reference's op sequence --------------------------------------------------------------------------------------------
     def forward_ffn(self, tgt):

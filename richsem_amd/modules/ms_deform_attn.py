@@ -106,7 +106,7 @@ class MSDeformAttn(nn.Module):
         """bf16, d_model = 256: ``value_proj(input_flatten)`` with the rows of padded pixels zeroed (reference :94-96), (N, S, C)"""
         pk = self._lin256_packs()
         mask = input_padding_mask.contiguous() if input_padding_mask is not None else None
-        return Lin256Function.apply(input_flatten.to(torch.bfloat16), pk["v"], mask, self.value_proj.weight, self.value_proj.bias)
+        return Lin256Function.apply(input_flatten.to(torch.bfloat16), pk["v"], mask, False, self.value_proj.weight, self.value_proj.bias)
 
     def forward_from_value(self, query, reference_points, value, input_spatial_shapes, input_level_start_index):
         """bf16, d_model = 256: the module's forward behind the value projection (reference :97-114) -- for callers that project the
@@ -114,11 +114,11 @@ class MSDeformAttn(nn.Module):
         N, S = value.shape[0], value.shape[1]
         H, L, P = self.n_heads, self.n_levels, self.n_points
         pk = self._lin256_packs()
-        qproj = Lin256Function.apply(query.to(torch.bfloat16), pk["q"], None, self.sampling_offsets.weight, self.attention_weights.weight,
+        qproj = Lin256Function.apply(query.to(torch.bfloat16), pk["q"], None, False, self.sampling_offsets.weight, self.attention_weights.weight,
                                      self.sampling_offsets.bias, self.attention_weights.bias)
         out = MSDeformAttnFusedFunction.apply(value.reshape(N, S, H, self.d_model // H), input_spatial_shapes, input_level_start_index,
                                               qproj, reference_points.float(), H, L, P, self.im2col_step)
-        return Lin256Function.apply(out, pk["o"], None, self.output_proj.weight, self.output_proj.bias)
+        return Lin256Function.apply(out, pk["o"], None, False, self.output_proj.weight, self.output_proj.bias)
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
@@ -128,7 +128,12 @@ class MSDeformAttn(nn.Module):
         N, Lq, _ = query.shape
         S = input_flatten.shape[1]
         H, L, P = self.n_heads, self.n_levels, self.n_points
-        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == S
+        if input_flatten.is_cuda:      # the reference's assert (ms_deform_attn.py:99) on the cached host mirror: no stream synchronisation per call
+            from ..MultiScaleDeformableAttention import _host_mirror
+            hs = _host_mirror(input_spatial_shapes, input_level_start_index)[0]
+            assert int((hs[:, 0] * hs[:, 1]).sum()) == S
+        else:
+            assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == S
 
         if (self.fused and query.is_cuda and query.dtype in (torch.float32, torch.float64, torch.bfloat16) and L * P <= 64
                 and L <= 16):

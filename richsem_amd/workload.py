@@ -203,3 +203,41 @@ def resnet50_state_dict(seed=0, width=64, layers=(3, 4, 6, 3)):
                 bn(p + "downsample.1", planes * 4)
             inplanes = planes * 4
     return sd
+
+
+def clip_rn50_state_dict(seed=0, layers=(3, 4, 6, 3), width=64, heads=32, out_dim=1024, res=224):
+    """A CLIP ``ModifiedResNet`` state_dict (clip/model.py:94-167: three-convolution stem, anti-aliased bottlenecks, attention pool) with
+    seeded synthetic values that keep the activations at unit scale -- the frozen teacher of the composed bench step (no checkpoint can
+    be fetched here)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = torch.randn(co, ci, k, k, generator=g) * (1.5 / (ci * k * k)) ** 0.5
+
+    def bn(name, c):
+        sd[name + ".weight"] = torch.rand(c, generator=g) * 0.6 + 0.7
+        sd[name + ".bias"] = torch.randn(c, generator=g) * 0.2
+        sd[name + ".running_mean"] = torch.randn(c, generator=g) * 0.2
+        sd[name + ".running_var"] = torch.rand(c, generator=g) + 0.5
+
+    conv("conv1", width // 2, 3, 3); bn("bn1", width // 2)
+    conv("conv2", width // 2, width // 2, 3); bn("bn2", width // 2)
+    conv("conv3", width, width // 2, 3); bn("bn3", width)
+    inplanes = width
+    for li, (n, planes) in enumerate(zip(layers, (width, width * 2, width * 4, width * 8)), start=1):
+        for b in range(n):
+            p = f"layer{li}.{b}."
+            stride = 2 if (li > 1 and b == 0) else 1
+            conv(p + "conv1", planes, inplanes, 1); bn(p + "bn1", planes)
+            conv(p + "conv2", planes, planes, 3); bn(p + "bn2", planes)
+            conv(p + "conv3", planes * 4, planes, 1); bn(p + "bn3", planes * 4)
+            if stride > 1 or inplanes != planes * 4:
+                conv(p + "downsample.0", planes * 4, inplanes, 1); bn(p + "downsample.1", planes * 4)
+            inplanes = planes * 4
+    C = width * 32
+    sd["attnpool.positional_embedding"] = torch.randn((res // 32) ** 2 + 1, C, generator=g) * C ** -0.5
+    for n, o in (("k", C), ("q", C), ("v", C), ("c", out_dim)):
+        sd[f"attnpool.{n}_proj.weight"] = torch.randn(o, C, generator=g) * C ** -0.5
+        sd[f"attnpool.{n}_proj.bias"] = torch.randn(o, generator=g) * 0.1
+    return sd

@@ -99,9 +99,10 @@ def _attention_reference(qk, v, mask, heads):
     return (torch.softmax(s, -1) @ split(v.float())).permute(2, 0, 1, 3).reshape(nq, bs, C)
 
 
+@pytest.mark.parametrize("batch_first", [False, True])
 @pytest.mark.parametrize("nq,bs,heads,masked", [(1092, 2, 8, True), (37, 1, 2, True), (64, 3, 1, False), (100, 2, 4, True), (1, 1, 1, False),
                                                  (900, 2, 8, False)])
-def test_attention_kernels_against_the_definition(nq, bs, heads, masked):
+def test_attention_kernels_against_the_definition(nq, bs, heads, masked, batch_first):
     from richsem_amd.functions.attention import masked_self_attention
     g = torch.Generator(device="cuda").manual_seed(nq * 7 + heads)
     C = heads * 32
@@ -114,7 +115,11 @@ def test_attention_kernels_against_the_definition(nq, bs, heads, masked):
         mask.fill_diagonal_(False)
     go = torch.randn(nq, bs, C, device="cuda", generator=g).to(torch.bfloat16)
     a, b = qk.clone().requires_grad_(True), v.clone().requires_grad_(True)
-    out = masked_self_attention(a, b, mask, heads)
+    if batch_first:      # the same tokens, stored (bs, nq, C)
+        a_, b_ = a.transpose(0, 1).contiguous(), b.transpose(0, 1).contiguous()
+        out = masked_self_attention(a_, b_, mask, heads, batch_first=True).transpose(0, 1)
+    else:
+        out = masked_self_attention(a, b, mask, heads)
     out.backward(go)
     ar, br = qk.float().requires_grad_(True), v.float().requires_grad_(True)
     want = _attention_reference(ar, br, mask, heads)
@@ -151,7 +156,7 @@ def test_lin256_row_mask_and_stacked_projection():
         assert float((w.grad - w2.grad).abs().max()) < 3e-2 * float(w2.grad.abs().max())
         assert float((b.grad - b2.grad).abs().max()) < 3e-2 * float(b2.grad.abs().max())
     # the single projection with the mask in its epilogue
-    y = Lin256Function.apply(x.detach(), pack_linear256(ws[:1], bs_[:1]), mask, ws[0], bs_[0])
+    y = Lin256Function.apply(x.detach(), pack_linear256(ws[:1], bs_[:1]), mask, False, ws[0], bs_[0])
     assert float((y.float() - want[0].detach()).abs().max()) < 2e-2 * float(want[0].abs().max())
 
 

@@ -18,12 +18,11 @@ from richsem_amd import _lib, workload as W
 from richsem_amd import MultiScaleDeformableAttention as MSDA
 from richsem_amd.functions import MSDeformAttnFunction
 
-from conftest import GOLDEN
+from conftest import GOLDEN, OP_CASES
 
 pytestmark = pytest.mark.gpu
 
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-               if not os.path.basename(p).startswith(("module_", "attnpool_", "clip_resnet_")))
+CASES = OP_CASES
 # 1 = direct kernels, 2 = LDS-window kernels, 3 = pixel-stationary backward (candidates by geometry), 4 = routed
 # pixel-stationary backward -- each where applicable, else the direct kernels
 VARIANTS = [0, 1, 2, 4]   # 0 automatic; forward: 1 direct, 2 LDS windows; backward: 1 direct (+ level-sum), 4 routed
