@@ -55,18 +55,6 @@ def giou_pairs(a, b):
     return iou - (hull - union) / (hull + 1e-6)
 
 
-def sigmoid_focal_loss(logits, pos_index, num_boxes, alpha=0.25, gamma=2.0):
-    """models/richsem/utils.py:82-108 (gamma = 2) for one-hot targets given as the index tuple of their ones: the value of
-    ``(ce * (1 - p_t) ** 2 * alpha_t).mean(1).sum() / num_boxes`` -- the all-negative formula over every entry plus the difference at the
-    positive entries, so that the (N, nq, 1204) one-hot tensor and its dozen element-wise passes are never formed"""
-    assert gamma == 2.0
-    p = logits.sigmoid()
-    neg = ((1 - alpha) * p * p * F.softplus(logits)).sum()
-    x, q = logits[pos_index], p[pos_index]
-    pos = (alpha * (1 - q) ** 2 * F.softplus(-x) - (1 - alpha) * q * q * F.softplus(x)).sum()
-    return (neg + pos) / logits.shape[1] / num_boxes
-
-
 def sine_position(mask, num_pos_feats=128, temperature=20.0):
     """PositionEmbeddingSineHW (models/richsem/position_encoding.py:46-92, temperatureH = temperatureW = 20, normalize): (N, H, W) bool
     padding mask -> (N, H * W, 256)"""
@@ -288,31 +276,51 @@ class Step(nn.Module):
             indices = self.matcher.match_many(outs, targets)
         self.last_indices = indices
         self._mark("matcher")
-        # ---- criterion (richsem.py:1124-1306, compact) --------------------------------------------------------------------------------------
+        # ---- criterion (richsem.py:1124-1306, compact): the same per-output sums as the reference's loop over the 6 + 1 outputs, formed
+        #      over the STACKED decoder outputs in one pass (a loop of ~40 small launches per output is what an eager trainer pays) --------
         num_boxes = float(max(sum(known_num), 1))
         tgt_boxes_all = [t["boxes"] for t in targets]
-        loss = logits.new_zeros(())
-        for o, idx in zip(outs, indices):
-            bi = torch.cat([torch.full_like(s, b) for b, (s, _) in enumerate(idx)]).to(dev)
-            si = torch.cat([s for s, _ in idx]).to(dev)
-            tl = torch.cat([t["labels"][j.to(dev)] for t, (_, j) in zip(targets, idx)])
-            tb = torch.cat([tbx[j.to(dev)] for tbx, (_, j) in zip(tgt_boxes_all, idx)])
-            pb = o["pred_boxes"][bi, si]
-            loss = loss + sigmoid_focal_loss(o["pred_logits"], (bi, si, tl), num_boxes) * o["pred_logits"].shape[1]
-            loss = loss + 5.0 * (pb - tb).abs().sum() / num_boxes
-            loss = loss + 2.0 * (1 - giou_pairs(box_cxcywh_to_xyxy(pb), box_cxcywh_to_xyxy(tb))).sum() / num_boxes
+        nl = logits.shape[0]
+
+        def matched(idx_list):       # per output: (batch index, query index, target label, target box) of its matched pairs
+            bi = torch.cat([torch.full_like(s, b) for idx in idx_list for b, (s, _) in enumerate(idx)]).to(dev)
+            si = torch.cat([s for idx in idx_list for s, _ in idx]).to(dev)
+            tl = torch.cat([t["labels"][j.to(dev)] for idx in idx_list for t, (_, j) in zip(targets, idx)])
+            tb = torch.cat([tbx[j.to(dev)] for idx in idx_list for tbx, (_, j) in zip(tgt_boxes_all, idx)])
+            li = torch.cat([torch.full((sum(len(s) for s, _ in idx),), k, dtype=torch.int64, device=dev) for k, idx in enumerate(idx_list)])
+            return li, bi, si, tl, tb
+
+        def box_losses(pb, tb, norm):
+            return (5.0 * (pb - tb).abs().sum() + 2.0 * (1 - giou_pairs(box_cxcywh_to_xyxy(pb), box_cxcywh_to_xyxy(tb))).sum()) / norm
+
+        alpha = 0.25
+        p_all = logits.sigmoid()
+        neg_all = (1 - alpha) * p_all * p_all * F.softplus(logits)                                    # the all-negative focal term
+
+        def focal_pos(x, q):         # what a positive entry contributes instead of its negative term
+            return (alpha * (1 - q) ** 2 * F.softplus(-x) - (1 - alpha) * q * q * F.softplus(x)).sum()
+
+        # matched part of the six decoder outputs
+        li, bi, si, tl, tb = matched(indices[:nl])
+        sel = (li, bi, si + pad, tl)
+        loss = (neg_all[:, :, pad:].sum() + focal_pos(logits[sel], p_all[sel])) / num_boxes
+        loss = loss + box_losses(coords[li, bi, si + pad], tb, num_boxes)
+        # the intermediate (two-stage) output
+        _, bi, si, tl, tb = matched(indices[nl:])
+        il = interm["pred_logits"]
+        ip = il.sigmoid()
+        loss = loss + (((1 - alpha) * ip * ip * F.softplus(il)).sum() + focal_pos(il[bi, si, tl], ip[bi, si, tl])) / num_boxes
+        loss = loss + box_losses(interm["pred_boxes"][bi, si], tb, num_boxes)
         # denoising part: the positive slots reconstruct their boxes and labels (dn_components.py / richsem.py:1163-1193)
         single = lay["single_pad"]
         pos_slots = (torch.arange(groups, device=dev)[:, None] * 2 * single + torch.arange(single, device=dev)[None]).flatten()
-        for l in range(6):
-            dl, db = logits[l][:, :pad][:, pos_slots], coords[l][:, :pad][:, pos_slots]                # every image has `single` boxes here
-            tlab = torch.stack([t["labels"] for t in targets]).repeat(1, groups)
-            tbx = torch.stack(tgt_boxes_all).repeat(1, groups, 1)
-            nbx = num_boxes * groups
-            bi_, si_ = torch.meshgrid(torch.arange(N, device=dev), torch.arange(dl.shape[1], device=dev), indexing="ij")
-            loss = loss + sigmoid_focal_loss(dl, (bi_.reshape(-1), si_.reshape(-1), tlab.reshape(-1)), nbx) * dl.shape[1]
-            loss = loss + 5.0 * (db - tbx).abs().sum() / nbx
-            loss = loss + 2.0 * (1 - giou_pairs(box_cxcywh_to_xyxy(db.reshape(-1, 4)), box_cxcywh_to_xyxy(tbx.reshape(-1, 4)))).sum() / nbx
+        tlab = torch.stack([t["labels"] for t in targets]).repeat(1, groups)                            # (N, groups * single)
+        tbx = torch.stack(tgt_boxes_all).repeat(1, groups, 1)
+        nbx = num_boxes * groups
+        dl, dp, db = logits[:, :, pos_slots], p_all[:, :, pos_slots], coords[:, :, pos_slots]          # every image has `single` boxes here
+        hot = tlab[None, :, :, None].expand(nl, -1, -1, 1)
+        loss = loss + (neg_all[:, :, pos_slots].sum() + focal_pos(dl.gather(3, hot), dp.gather(3, hot))) / nbx
+        loss = loss + box_losses(db.reshape(-1, 4), tbx[None].expand(nl, -1, -1, -1).reshape(-1, 4), nbx)
         # distillation: KL of the matched queries' CLIP logits against the teacher's box logits (richsem.py:1255-1300)
         idx = indices[5]
         bi = torch.cat([torch.full_like(s, b) for b, (s, _) in enumerate(idx)]).to(dev)
@@ -332,9 +340,10 @@ class Step(nn.Module):
         return out
 
 
-def run(n_img, dev, steps=5, warmup=2, graph=True):
+def run(n_img, dev, steps=5, warmup=2, graph=True, stop_at=None):
     """time `steps` composed steps (forward + loss + backward); returns the dict bench.py attaches as ``full_step``"""
     model = Step(n_img=n_img, dev=dev)
+    model.stop_at = stop_at      # (profiling aid: the step cut off after a section, see tools/step_sections.sh)
     images, mask, targets = model.batch()
     model.prepare(mask, targets)
     params = [p for p in model.parameters() if p.requires_grad]
@@ -433,5 +442,6 @@ if __name__ == "__main__":
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--images", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true", help="eager steps only (the form profiled for profiles/*_step_kernels.md)")
+    ap.add_argument("--stop-at", default=None, help="profiling aid: cut the step off after this section (implies --no-graph)")
     a_ = ap.parse_args()
-    print(json.dumps(run(a_.images, torch.device("cuda", 0), a_.steps, a_.warmup, graph=not a_.no_graph), indent=1))
+    print(json.dumps(run(a_.images, torch.device("cuda", 0), a_.steps, a_.warmup, graph=not (a_.no_graph or a_.stop_at), stop_at=a_.stop_at), indent=1))

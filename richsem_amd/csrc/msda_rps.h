@@ -83,7 +83,7 @@ struct RpsGeom {
     float *dummy;                   // kRpsDummyBytes of scratch: where the lanes that have nothing to store send their stores
                                     // (every store instruction is then issued unconditionally: see rps_tile_kernel)
     unsigned long long *stamps;     // diagnostic runs only (msda_debug_stamps)
-    int dbg;                        // diagnostic: bits 4..6 = 1 + level -> only that level's tiles do any work (wrong results)
+    int dbg;                        // diagnostic: bits 4..6 = 1 + level -> only that level's tiles do any work (wrong results); bit 3: walk units in list order (A/B of the length classes)
 };
 
 struct alignas(16) RpsEnt {   // one sampling point in the list of its base pixel; overwritten by its four corner dots
@@ -98,6 +98,7 @@ struct RpsLds {
     int item_slot[2];                   // work-queue draws (current / next), double-buffered
     int wave_tot[16];
     int n_segs, pad[3];
+    int uhist[16];                      // walk units per (wave of the scan, length class), longest class first
     unsigned long long stamp_last, stamp_acc[14];
     int offs[kRpsMaxPx + 4];            // histogram, then exclusive prefix: where a base pixel's list starts
     unsigned short seg[kRpsMaxSegs + 16];   // walk units of the chunk: list | segment of the list << 8
@@ -561,6 +562,7 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
     fetch_recs(e_first, n_ent, 0);
     Item it = item_geom(item_id);
     int par = 0;
+    fetch_rows(it);
 
     while (item_id < n_items) {
         if (tid == 0) {
@@ -572,8 +574,7 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
         const int n_chunks = it.live ? (n_ent + kRpsChunk - 1) / kRpsChunk : 0;
         const int bq0 = b * g.Lq;
         float *const vt = S->vtile;
-        // the item's value rows travel while its f64 sums are cleared and its first chunk is sorted (the list walk needs them)
-        fetch_rows(it);
+        // (the item's value rows were requested before the previous item's sums were stored -- before the loop for the first item)
         for (int i = tid; i < kRpsMaxPx * kRpsSumStride / 2; i += kRpsThreads)
             reinterpret_cast<double2 *>(S->sum)[i] = make_double2(0.0, 0.0);
         __syncthreads();
@@ -609,18 +610,39 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
 
             // ---- (2) exclusive scan of the per-list counts (<= 256: one per thread of the first 4 waves) and of the lists' unit
             //      counts, both in one packed word (count | units << 16); every list writes its units -------------------------------
+            //      The units are listed by LENGTH CLASS, longest first: a wave walks 16 units side by side for as long as the longest
+            //      of them, so units of like length (four classes) go together (lists vary from 1 to 16+ points around a mean of ~6).
             {
-                int c = 0, v = 0, incl = 0;
+                const int sh = g.seg_shift;      // a unit's length -> quarter of the full length it falls into -> slot (0 = longest)
+                int c = 0, v = 0, incl = 0, n_full = 0, part = 0, pslot = 0, n0 = 0, incl0 = 0, rank = 0, mycnt = 0;
                 if (tid < kRpsMaxPx) {
                     c = tid < npx ? S->offs[tid] : 0;
-                    v = c | ((c + (1 << g.seg_shift) - 1) >> g.seg_shift) << 16;
+                    v = c | ((c + (1 << sh) - 1) >> sh) << 16;
+                    n_full = c >> sh;
+                    part = c & ((1 << sh) - 1);
+                    pslot = part ? ((g.dbg & 8) ? 0 : 3 - ((part - 1) >> (sh - 2))) : -1;   // (dbg 8: A/B, units in list order)
+                    n0 = n_full + (pslot == 0 ? 1 : 0);      // this list's units of slot 0: its full ones, then a nearly full last one
                     incl = v;
+                    incl0 = n0;
 #pragma unroll
                     for (int d = 1; d < kWave; d <<= 1) {
-                        const int t = __shfl_up(incl, d, kWave);
-                        if (lane >= d) incl += t;
+                        const int t = __shfl_up(incl, d, kWave), t0 = __shfl_up(incl0, d, kWave);
+                        if (lane >= d) {
+                            incl += t;
+                            incl0 += t0;
+                        }
                     }
                     if (lane == kWave - 1) S->wave_tot[wave] = incl;
+                    // the wave's count per slot (lane k keeps slot k's) and this list's rank among the wave's units of its slot
+                    mycnt = __shfl(incl0, kWave - 1, kWave);
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) {
+                        const unsigned long long bk = __ballot(pslot == k);
+                        if (pslot == k) rank = __popcll(bk & lt);
+                        if (lane == k) mycnt = __popcll(bk);
+                    }
+                    if (lane < 4) S->uhist[wave * 4 + lane] = mycnt;
                 }
                 __syncthreads();
                 if (tid < kRpsMaxPx) {
@@ -633,8 +655,26 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                         if (npx == kRpsMaxPx) S->offs[npx] = (base + incl) & 0xFFFF;
                         S->n_segs = (base + incl) >> 16;
                     }
-                    const int u0 = excl >> 16, nu = v >> 16;
-                    for (int sgm = 0; sgm < nu; ++sgm) S->seg[u0 + sgm] = (unsigned short)(tid | sgm << 8);
+                    // where this wave's units of slot `lane` start: the slots before it of all waves + this slot of the waves before
+                    int tot = 0, mine_before = 0;
+#pragma unroll
+                    for (int w = 0; w < kRpsMaxPx / kWave; ++w) {
+                        const int x = S->uhist[w * 4 + (lane & 3)];
+                        tot += x;
+                        mine_before += w < wave ? x : 0;
+                    }
+                    int pre = tot;
+#pragma unroll
+                    for (int d = 1; d < 4; d <<= 1) {
+                        const int t = __shfl_up(pre, d, kWave);
+                        if ((lane & 3) >= d) pre += t;
+                    }
+                    const int sb = pre - tot + mine_before;
+                    const int at0 = __shfl(sb, 0, kWave) + incl0 - n0;
+                    const int atp = __shfl(sb, pslot & 3, kWave) + rank;
+                    for (int sgm = 0; sgm < n_full; ++sgm) S->seg[at0 + sgm] = (unsigned short)(tid | sgm << 8);
+                    if (pslot == 0) S->seg[at0 + n_full] = (unsigned short)(tid | n_full << 8);
+                    else if (pslot > 0) S->seg[atp] = (unsigned short)(tid | n_full << 8);
                 }
             }
             __syncthreads();
@@ -794,6 +834,9 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
             RPS_STAMP(6)
         }
         if (n_chunks == 0) fetch_recs(next_first, next_n, 0);   // (an empty bin: nothing was fetched ahead)
+        // the NEXT item's value rows are requested now and travel while this item's sums are stored and the next item's are cleared
+        // (they are parked in LDS behind the next item's first barrier)
+        fetch_rows(nit);
         // ---- the tile's sums to grad_value: one 128-B row per pixel (two pixels per quad) ------------------------------------------
         __syncthreads();
         if (!g.lv[l].atomic) {   // (uniform)
