@@ -28,6 +28,7 @@ from richsem_amd import workload as W
 from richsem_amd.backbone import InputProjection, ResNet50
 from richsem_amd.clip_resnet import ModifiedResNetTeacher
 from richsem_amd.dn import prepare_dn_layout
+from richsem_amd.functions.linear import Lin256Function, VersionCache, pack_linear256
 from richsem_amd.matcher import HungarianMatcher
 from richsem_amd.modules import (MLP, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, TransformerDecoder,
                                  clip_box_targets, get_reference_points, inverse_sigmoid)
@@ -71,15 +72,16 @@ def sine_position(mask, num_pos_feats=128, temperature=20.0):
     return torch.cat((py, px), dim=3).flatten(1, 2)
 
 
-def gen_encoder_output_proposals(memory, memory_padding_mask, shapes):
-    """models/richsem/utils.py:10-65: per-pixel anchor boxes (unsigmoided) and the memory with invalid positions zeroed"""
-    N = memory.shape[0]
+def encoder_output_proposals(memory_padding_mask, shapes):
+    """models/richsem/utils.py:10-65, the part that depends on the batch's geometry only: per-pixel anchor boxes (unsigmoided, +inf at
+    padded / out-of-range positions) and the (N, S, 1) mask of the positions whose memory is zeroed"""
+    N, dev = memory_padding_mask.shape[0], memory_padding_mask.device
     proposals, cur = [], 0
     for lvl, (H_, W_) in enumerate(shapes):
         m = memory_padding_mask[:, cur:cur + H_ * W_].view(N, H_, W_, 1)
         valid_H, valid_W = (~m[:, :, 0, 0]).sum(1), (~m[:, 0, :, 0]).sum(1)
-        gy, gx = torch.meshgrid(torch.linspace(0, H_ - 1, H_, dtype=torch.float32, device=memory.device),
-                                torch.linspace(0, W_ - 1, W_, dtype=torch.float32, device=memory.device), indexing="ij")
+        gy, gx = torch.meshgrid(torch.linspace(0, H_ - 1, H_, dtype=torch.float32, device=dev),
+                                torch.linspace(0, W_ - 1, W_, dtype=torch.float32, device=dev), indexing="ij")
         grid = torch.cat([gx.unsqueeze(-1), gy.unsqueeze(-1)], -1)
         scale = torch.cat([valid_W.unsqueeze(-1), valid_H.unsqueeze(-1)], 1).view(N, 1, 1, 2)
         grid = (grid.unsqueeze(0).expand(N, -1, -1, -1) + 0.5) / scale
@@ -89,9 +91,8 @@ def gen_encoder_output_proposals(memory, memory_padding_mask, shapes):
     out = torch.cat(proposals, 1)
     valid = ((out > 0.01) & (out < 0.99)).all(-1, keepdim=True)
     out = torch.log(out / (1 - out))
-    out = out.masked_fill(memory_padding_mask.unsqueeze(-1), float("inf")).masked_fill(~valid, float("inf"))
-    mem = memory.masked_fill(memory_padding_mask.unsqueeze(-1), 0.0).masked_fill(~valid, 0.0)
-    return mem, out
+    zeroed = memory_padding_mask.unsqueeze(-1) | ~valid
+    return out.masked_fill(zeroed, float("inf")), zeroed
 
 
 class Step(nn.Module):
@@ -130,6 +131,7 @@ class Step(nn.Module):
         self.matcher = HungarianMatcher(cost_class=2.0, cost_bbox=5.0, cost_giou=2.0)
         self.scorer = ClassScorer(2)
         self.times = {}
+        self._eo_pack = VersionCache()
         self.timing = True
         self.stop_at = None       # (tools/capture_probe.py: end the step after this section with a surrogate loss)
 
@@ -177,6 +179,10 @@ class Step(nn.Module):
               "valid_ratios": torch.stack([torch.stack([(~m[:, 0, :]).sum(1) / m.shape[2], (~m[:, :, 0]).sum(1) / m.shape[1]], -1)
                                            for m in masks], 1).float()}
         st["ref"] = get_reference_points(shapes, st["valid_ratios"], dev)
+        st["pos_sine"] = torch.cat([sine_position(m) for m in masks], 1)                               # (N, S, 256): the masks' part of pos
+        level_of = torch.cat([torch.full((h * w,), l, dtype=torch.int64, device=dev) for l, (h, w) in enumerate(shapes)])
+        st["level_onehot"] = F.one_hot(level_of, len(shapes)).float()      # (S, L): the level embedding as a product (its backward a 4-row GEMM, not 22 k serialised row adds)
+        st["proposals"], st["zeroed"] = encoder_output_proposals(st["mask_flat"], shapes)
         st["known_num"] = [len(t["labels"]) for t in targets]
         st["lay"] = prepare_dn_layout(st["known_num"], DN_NUMBER, NUM_QUERIES, use_cdn=True)
         st["scale"] = self.logit_scale.detach().clone()
@@ -197,9 +203,8 @@ class Step(nn.Module):
             return sum(f.float().sum() for f in feats)
         srcs, got_shapes = self.input_proj(feats, out_dtype=torch.bfloat16)
         assert got_shapes == shapes
-        pos = [sine_position(m) + self.level_embed[l].view(1, 1, -1) for l, m in enumerate(masks)]
         src = torch.cat(srcs, 1)
-        pos_flat = torch.cat(pos, 1).to(torch.bfloat16)
+        pos_flat = (st["pos_sine"] + st["level_onehot"] @ self.level_embed).to(torch.bfloat16)           # sine part + level embedding (:596-612)
         self._mark("input_proj")
         if self.stop_at == "input_proj":
             return src.float().sum() + pos_flat.float().sum()
@@ -212,13 +217,15 @@ class Step(nn.Module):
         if self.stop_at == "encoder":
             return memory.float().sum()
         # ---- two-stage query selection (:352-380) ----------------------------------------------------------------------------------
-        mem_f = memory.float()
-        output_memory, output_proposals = gen_encoder_output_proposals(mem_f, mask_flat, shapes)
-        output_memory = self.enc_output_norm(self.enc_output(output_memory))
+        eo = self.enc_output
+        pk = self._eo_pack.get((eo.weight, eo.bias), lambda: pack_linear256([eo.weight], [eo.bias]))
+        output_memory = Lin256Function.apply(memory.masked_fill(st["zeroed"], 0.0), pk, None, False, eo.weight, eo.bias)   # bf16, lin256
+        output_memory = F.layer_norm(output_memory, (256,), self.enc_output_norm.weight.to(torch.bfloat16),
+                                     self.enc_output_norm.bias.to(torch.bfloat16), self.enc_output_norm.eps)
         topk = self.scorer.topk_proposals(output_memory, NUM_QUERIES)                                  # no logit tensor (two_stage.py)
-        coord_unselected = self.enc_out_bbox_embed(output_memory) + output_proposals
+        coord_unselected = self.enc_out_bbox_embed(output_memory).float() + st["proposals"]
         refpoint_undetach = torch.gather(coord_unselected, 1, topk[..., None].expand(-1, -1, 4))
-        tgt_undetach = torch.gather(output_memory, 1, topk[..., None].expand(-1, -1, 256))
+        tgt_undetach = torch.gather(output_memory, 1, topk[..., None].expand(-1, -1, 256)).float()
         interm = {"pred_logits": self.class_logits(tgt_undetach), "pred_boxes": refpoint_undetach.sigmoid()}
         self._mark("two_stage")
         if self.stop_at == "two_stage":

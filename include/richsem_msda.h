@@ -300,6 +300,11 @@ int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, con
  * out_bf16 (N, HW, C), either may be NULL.  Sums of x and x^2 in fp32 per thread, combined in fp64.  Forward only. */
 int msda_groupnorm8_nhwc_bf16(const uint16_t *x, const float *gamma, const float *beta, float eps, int N, int HW, int C, double *stats,
                               float *out_f32, uint16_t *out_bf16, msda_stream_t stream);
+/* Its backward (the trainable input projections): x, dy (N, HW, C) bf16; stats as the forward left them; bstats: N * (C / 8) * 16 doubles
+ * of device scratch; dx (N, HW, C) bf16; dgamma, dbeta (C) f32, either may be NULL.  Replaces autograd's GroupNorm backward on the
+ * channels-first fp32 view (three permuting copies and five kernels per level). */
+int msda_groupnorm8_backward_nhwc_bf16(const uint16_t *x, const uint16_t *dy, const float *gamma, float eps, int N, int HW, int C,
+                                       const double *stats, double *bstats, uint16_t *dx, float *dgamma, float *dbeta, msda_stream_t stream);
 
 /* Pooling on NHWC bf16 activations (nn.AvgPool2d(k) of the CLIP ResNet, clip/model.py:24, :36, :115; MaxPool2d(3, 2, 1) after
  * torchvision's ResNet stem): is_max = 0: mean over k x k windows at `stride`, pad must be 0; is_max = 1: maximum with implicit -inf

@@ -32,7 +32,7 @@ SYMBOLS = [
     "msda_attn_workspace_bytes", "msda_attn_forward_bf16", "msda_attn_backward_bf16",
     "msda_matcher_cost_f32", "msda_matcher_cost_f64", "msda_attnpool_core_f32", "msda_attnpool_core_f64",
     "msda_cls_packed_elems", "msda_cls_pack", "msda_cls_max_scores",
-    "msda_conv_set_tiling", "msda_conv_packed_elems", "msda_conv_pack_weight", "msda_conv_forward_bf16", "msda_conv_dgrad_bf16", "msda_pool_nhwc_bf16", "msda_groupnorm8_nhwc_bf16", "msda_conv_wgrad_workspace_bytes", "msda_conv_wgrad_bf16",
+    "msda_conv_set_tiling", "msda_conv_packed_elems", "msda_conv_pack_weight", "msda_conv_forward_bf16", "msda_conv_dgrad_bf16", "msda_pool_nhwc_bf16", "msda_groupnorm8_nhwc_bf16", "msda_groupnorm8_backward_nhwc_bf16", "msda_conv_wgrad_workspace_bytes", "msda_conv_wgrad_bf16",
 ]
 
 
@@ -117,6 +117,8 @@ def load():
     L.msda_pool_nhwc_bf16.restype = ci
     L.msda_groupnorm8_nhwc_bf16.argtypes = [vp, vp, vp, ctypes.c_float, ci, ci, ci, vp, vp, vp, vp]
     L.msda_groupnorm8_nhwc_bf16.restype = ci
+    L.msda_groupnorm8_backward_nhwc_bf16.argtypes = [vp, vp, vp, ctypes.c_float, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+    L.msda_groupnorm8_backward_nhwc_bf16.restype = ci
     L.msda_conv_wgrad_bf16.argtypes = [vp, vp] + [ci] * 9 + [vp, vp, vp, ci, vp, vp]
     L.msda_conv_wgrad_bf16.restype = ci
     L.msda_conv_wgrad_workspace_bytes.argtypes = [ci] * 9 + [ctypes.POINTER(i64)]

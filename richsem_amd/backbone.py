@@ -115,7 +115,7 @@ class InputProj:
 # ---- trainable form (forward + backward on the library's kernels) -----------------------------------------------------------------
 from torch import nn                                         # noqa: E402
 
-from .conv import ConvAffineFunction, PackCache              # noqa: E402
+from .conv import ConvAffineFunction, GroupNorm8Function, PackCache              # noqa: E402
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -227,7 +227,8 @@ class InputProjection(nn.ModuleList):
     like the reference's ``input_proj``, so the parameter names are the reference's natively (``{l}.0.weight``, ``{l}.0.bias``,
     ``{l}.1.weight``, ``{l}.1.bias``) -- as the root module and nested (``model.input_proj = InputProjection()`` gives
     ``input_proj.{l}.0.weight``: a reference checkpoint loads with ``strict=True``).  The convolutions run ConvAffineFunction (bias =
-    the epilogue's shift, with its gradient), the GroupNorm is PyTorch's on the NHWC tensor's channels-first view.
+    the epilogue's shift, with its gradient), the GroupNorm(32, 256) the library's NHWC kernels with their backward (conv.GroupNorm8Function;
+    other group sizes: PyTorch's on the channels-first view).
     ``forward(features)`` as :class:`InputProj`."""
 
     def __init__(self, in_channels=(512, 1024, 2048), hidden=256, num_levels=4, groups=32):
@@ -250,8 +251,12 @@ class InputProjection(nn.ModuleList):
             x = features[l] if l < self.n_stage else (features[-1] if l == self.n_stage else prev)
             y = ConvAffineFunction.apply(x, conv.weight, self._one, conv.bias, None, conv.stride, conv.padding, False, conv.pack_cache)
             N, H, W, C = y.shape
-            g = norm(y.permute(0, 3, 1, 2).float())
-            prev = g.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
-            srcs.append(g.permute(0, 2, 3, 1).reshape(N, H * W, C).to(out_dtype))
+            if C == 8 * norm.num_groups and out_dtype == torch.bfloat16:      # the shipped GroupNorm(32, 256), bf16 consumers: the library's kernels, forward and backward, on NHWC bf16
+                prev = GroupNorm8Function.apply(y, norm.weight, norm.bias, norm.eps)
+                srcs.append(prev.reshape(N, H * W, C).to(out_dtype))
+            else:
+                g = norm(y.permute(0, 3, 1, 2).float())
+                prev = g.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+                srcs.append(g.permute(0, 2, 3, 1).reshape(N, H * W, C).to(out_dtype))
             shapes.append((H, W))
         return srcs, shapes

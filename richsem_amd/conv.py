@@ -122,6 +122,41 @@ def group_norm8_nhwc(x, gamma, beta, eps=1e-5, want_f32=True, want_bf16=True):
     return o32, o16
 
 
+class GroupNorm8Function(torch.autograd.Function):
+    """nn.GroupNorm(C // 8, C) on an NHWC bf16 tensor with its gradients on the library's kernels (``msda_groupnorm8_nhwc_bf16`` /
+    ``msda_groupnorm8_backward_nhwc_bf16``): bf16 in, bf16 out, fp32 / fp64 statistics; ``apply(x (N, H, W, C), gamma, beta, eps)``"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[3] % 8 == 0
+        x = x.contiguous()
+        N, H, W, C = x.shape
+        stats = torch.empty(N * (C // 8) * 2, dtype=torch.float64, device=x.device)
+        out = torch.empty_like(x)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().msda_groupnorm8_nhwc_bf16(x.data_ptr(), g.data_ptr(), b.data_ptr(), float(eps), N, H * W, C, stats.data_ptr(),
+                                                             None, out.data_ptr(), _stream(x.device)))
+        ctx.save_for_backward(x, g, stats)
+        ctx.eps, ctx.dts = float(eps), (gamma.dtype, beta.dtype)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, g, stats = ctx.saved_tensors
+        N, H, W, C = x.shape
+        dy = dy.to(torch.bfloat16).contiguous()
+        dx = torch.empty_like(x)
+        dgb = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        bstats = torch.empty(N * (C // 8) * 16, dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().msda_groupnorm8_backward_nhwc_bf16(x.data_ptr(), dy.data_ptr(), g.data_ptr(), ctx.eps, N, H * W, C,
+                                                                      stats.data_ptr(), bstats.data_ptr(), dx.data_ptr(), dgb[0].data_ptr(),
+                                                                      dgb[1].data_ptr(), _stream(x.device)))
+        return dx, dgb[0].to(ctx.dts[0]), dgb[1].to(ctx.dts[1]), None
+
+
 # ---- training: the same convolution with gradients ----------------------------------------------------------------------------------
 def _pack(w):
     L = _lib.load()

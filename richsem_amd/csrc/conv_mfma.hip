@@ -399,6 +399,91 @@ __global__ __launch_bounds__(256) void gn8_apply_kernel(const uint16_t *__restri
     }
 }
 
+// GroupNorm(8 channels per group) backward, pass 1: per (image, group) the per-channel sums  sum_p dy  and  sum_p dy * xhat  (xhat from
+// the forward's statistics), 16 values, added in fp64 to bstats[(n, g)][16]
+__global__ __launch_bounds__(256) void gn8_bwd_stats_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy,
+                                                            const double *__restrict__ stats, float eps, double *__restrict__ bstats, int HW,
+                                                            int C)
+{
+    const int groups = C / 8;
+    const int g = blockIdx.y, n = blockIdx.z;
+    const double cnt = (double)HW * 8.0;
+    const double m = stats[((long long)n * groups + g) * 2] / cnt;
+    const double var = stats[((long long)n * groups + g) * 2 + 1] / cnt - m * m;
+    const float mean = (float)m, rstd = rsqrtf((float)(var > 0.0 ? var : 0.0) + eps);
+    float s[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+        const long long at = ((long long)n * HW + p) * C + 8 * g;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(x + at), d = *reinterpret_cast<const u32x4 *>(dy + at);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d0 = bf16_lo(d[e]), d1 = bf16_hi(d[e]);
+            s[2 * e] += d0;
+            s[2 * e + 1] += d1;
+            s[8 + 2 * e] += d0 * ((bf16_lo(v[e]) - mean) * rstd);
+            s[8 + 2 * e + 1] += d1 * ((bf16_hi(v[e]) - mean) * rstd);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float t = s[e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(bstats + ((long long)n * groups + g) * 16 + e, (double)t);
+    }
+}
+
+// pass 2:  dx = rstd * (gamma dy - (A + xhat B) / m)  with  A = sum_c gamma_c sum_p dy,  B = sum_c gamma_c sum_p dy xhat  of the group;
+// workgroup 0 also writes  dgamma_c = sum_n sum_p dy xhat,  dbeta_c = sum_n sum_p dy
+__global__ __launch_bounds__(256) void gn8_bwd_apply_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy,
+                                                            const double *__restrict__ stats, const double *__restrict__ bstats,
+                                                            const float *__restrict__ gamma, float eps, int N, int HW, int C,
+                                                            uint16_t *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    const int groups = C / 8;
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += 256) {
+            double a = 0.0, b = 0.0;
+            for (int n = 0; n < N; ++n) {
+                a += bstats[((long long)n * groups + c / 8) * 16 + (c & 7)];
+                b += bstats[((long long)n * groups + c / 8) * 16 + 8 + (c & 7)];
+            }
+            if (dbeta) dbeta[c] = (float)a;
+            if (dgamma) dgamma[c] = (float)b;
+        }
+    const long long n_vec = (long long)N * HW * groups;
+    const double cnt = (double)HW * 8.0;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n_vec; i += gridDim.x * 256ll) {
+        const int g = (int)(i % groups);
+        const long long p = i / groups;
+        const int n = (int)(p / HW);
+        const double m = stats[((long long)n * groups + g) * 2] / cnt;
+        const double var = stats[((long long)n * groups + g) * 2 + 1] / cnt - m * m;
+        const float mean = (float)m, rstd = rsqrtf((float)(var > 0.0 ? var : 0.0) + eps);
+        const f32x4 g0 = *reinterpret_cast<const f32x4 *>(gamma + 8 * g), g1 = *reinterpret_cast<const f32x4 *>(gamma + 8 * g + 4);
+        const double *bs = bstats + ((long long)n * groups + g) * 16;
+        double A = 0.0, B = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            A += (double)g0[e] * bs[e] + (double)g1[e] * bs[4 + e];
+            B += (double)g0[e] * bs[8 + e] + (double)g1[e] * bs[12 + e];
+        }
+        const float a = (float)(A / cnt), b = (float)(B / cnt);
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(x + p * C + 8 * g), d = *reinterpret_cast<const u32x4 *>(dy + p * C + 8 * g);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ga = e < 2 ? g0[2 * e] : g1[2 * e - 4], gb = e < 2 ? g0[2 * e + 1] : g1[2 * e - 3];
+            o[2 * e] = rstd * (ga * bf16_lo(d[e]) - a - (bf16_lo(v[e]) - mean) * rstd * b);
+            o[2 * e + 1] = rstd * (gb * bf16_hi(d[e]) - a - (bf16_hi(v[e]) - mean) * rstd * b);
+        }
+        *reinterpret_cast<u32x4 *>(dx + p * C + 8 * g) =
+            (u32x4){pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+    }
+}
+
 struct ConvArgs {
     const uint16_t *x, *wpk;
     const float *scale, *shift;
@@ -544,6 +629,29 @@ int msda_groupnorm8_nhwc_bf16(const uint16_t *x, const float *gamma, const float
     const long long n_vec = (long long)N * HW * groups;
     const int grid = (int)((n_vec + 255) / 256 < 65536 ? (n_vec + 255) / 256 : 65536);
     hipLaunchKernelGGL(gn8_apply_kernel, dim3(grid), dim3(256), 0, st, x, stats, gamma, beta, eps, N, HW, C, out_f32, out_bf16);
+    e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
+
+/* Backward of msda_groupnorm8_nhwc_bf16: x, dy (N, HW, C) bf16; stats as the forward left them; bstats: N * (C / 8) * 16 doubles of
+ * device scratch (zeroed here); dx (N, HW, C) bf16; dgamma, dbeta (C) f32 (either may be NULL). */
+int msda_groupnorm8_backward_nhwc_bf16(const uint16_t *x, const uint16_t *dy, const float *gamma, float eps, int N, int HW, int C,
+                                       const double *stats, double *bstats, uint16_t *dx, float *dgamma, float *dbeta, msda_stream_t stream)
+{
+    if (!x || !dy || !gamma || !stats || !bstats || !dx) return MSDA_ERR_NULL_POINTER;
+    if (N < 1 || HW < 1 || C < 8 || C % 8 != 0 || C / 8 > 65535 || N > 65535) return MSDA_ERR_BAD_DIMS;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx)) & 15)
+        return MSDA_ERR_MISALIGNED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int groups = C / 8;
+    hipError_t e = hipMemsetAsync(bstats, 0, sizeof(double) * 16 * N * groups, st);
+    if (e != hipSuccess) return (int)e;
+    int strips = (HW + 2047) / 2048;
+    if (strips > 64) strips = 64;
+    hipLaunchKernelGGL(gn8_bwd_stats_kernel, dim3(strips, groups, N), dim3(256), 0, st, x, dy, stats, eps, bstats, HW, C);
+    const long long n_vec = (long long)N * HW * groups;
+    const int grid = (int)((n_vec + 255) / 256 < 65536 ? (n_vec + 255) / 256 : 65536);
+    hipLaunchKernelGGL(gn8_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, x, dy, stats, bstats, gamma, eps, N, HW, C, dx, dgamma, dbeta);
     e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
 }

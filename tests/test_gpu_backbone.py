@@ -191,3 +191,25 @@ def test_packed_weights_follow_an_optimizer_step():
         before = blk.conv2.weight.detach().clone()
         opt.step()
         assert not torch.equal(before, blk.conv2.weight.detach())
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 25, 42, 256), (1, 7, 9, 64), (2, 100, 168, 256)])
+def test_group_norm8_function_matches_autograd(N, H, W, C):
+    """GroupNorm(C // 8, C) forward + backward on the library's NHWC kernels against F.group_norm (fp32 autograd) on the same bf16 inputs"""
+    import torch.nn.functional as F
+    from richsem_amd.conv import GroupNorm8Function
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.randn(N, H, W, C, device="cuda", generator=g) * 2 + 0.5).to(torch.bfloat16).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, device="cuda", generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, device="cuda", generator=g)).requires_grad_(True)
+    dy = torch.randn(N, H, W, C, device="cuda", generator=g).to(torch.bfloat16)
+    out = GroupNorm8Function.apply(x, gamma, beta, 1e-5)
+    out.backward(dy)
+    xr = x.detach().float().requires_grad_(True)
+    gr, br = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    ref = F.group_norm(xr.permute(0, 3, 1, 2), C // 8, gr, br, 1e-5).permute(0, 2, 3, 1)
+    ref.backward(dy.float())
+    assert (out.float() - ref).abs().max() <= 2 ** -7 * ref.abs().max()                     # one bf16 rounding of the result
+    assert (x.grad.float() - xr.grad).abs().max() <= 2 ** -7 * xr.grad.abs().max()
+    assert (gamma.grad - gr.grad).abs().max() <= 2e-4 * gr.grad.abs().max()
+    assert (beta.grad - br.grad).abs().max() <= 2e-4 * br.grad.abs().max()
