@@ -1,2 +1,3 @@
 cd ${GRAFT_REPO_ROOT:-.}
-for f in "" "--no-overlap"; do echo "== $f"; timeout -k 10 600 python bench_step.py $f > gpurun_out/full_step.log 2>&1; grep -v Warning gpurun_out/full_step.log | grep "\"ms\"\|img_per_s\|teacher\|Error\|error" | head -12; done
+timeout -k 10 900 python -m pytest tests/test_gpu_conv.py tests/test_gpu_backbone.py tests/test_gpu_ffn.py tests/test_gpu_layers.py tests/test_gpu_module.py -x -q 2>&1 | tail -3
+timeout -k 10 600 python bench_step.py > gpurun_out/full_step.log 2>&1; grep -v Warning gpurun_out/full_step.log | grep -v "^ \"what" | tail -32
