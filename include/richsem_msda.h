@@ -266,6 +266,19 @@ int msda_dn_attn_mask_u8(uint8_t *mask, int64_t tgt_size, int64_t pad_size, int6
  * descending order; equal scores lowest index first.  n <= 36864, k <= 1024 (one workgroup holds a row in LDS). */
 int msda_topk_f32(const float *scores, int rows, int n, int k, int64_t *indices, float *values, msda_stream_t stream);
 
+/* The decoder's positional query embedding, gen_sineembed_for_position (models/richsem/utils.py:142-168) in one launch (the reference:
+ * ~15 element-wise ops per decoder layer): boxes (tokens, >= dims) f32 (x, y[, w, h]) with a row stride of ld floats; out (tokens,
+ * dims * pe_dim) bf16 in the reference's order (y, x[, w, h]), channel 2k = sin, 2k + 1 = cos of coordinate * 2 pi /
+ * temperature^(2k / pe_dim).  dims = 2 | 4, pe_dim even.  No gradient (the boxes it is applied to are detached, :779-804). */
+/* The decoder's box update, y = sigmoid(delta + inverse_sigmoid(ref)) (models/richsem/deformable_transformer.py:779-804,
+ * richsem.py:705-715; inverse_sigmoid of util/misc.py:605-609 with its eps) as one launch, and its gradient w.r.t. delta
+ * (grad_y * y * (1 - y)) as one more: delta / grad_delta (n) bf16 or f32, ref, y, grad_y (n) f32.  ref is taken as a constant (the
+ * reference detaches it between layers). */
+int msda_box_refine_forward(const void *delta, int delta_is_bf16, const float *ref, float eps, int64_t n, float *y, msda_stream_t stream);
+int msda_box_refine_backward(const float *grad_y, const float *y, int64_t n, void *grad_delta, int delta_is_bf16, msda_stream_t stream);
+
+int msda_sine_embed_bf16(const float *boxes, int ld, int tokens, int dims, int pe_dim, float temperature, uint16_t *out, msda_stream_t stream);
+
 /* ROIAlign forward (reference models/richsem/richsem.py:750, :878:
  * detectron2.layers.ROIAlign(output_size, spatial_scale, sampling_ratio = 0, aligned = True) on the frozen CLIP feature map).
  * input (N, C, H, W) contiguous; rois (K, 5) = (batch index, x1, y1, x2, y2) in input pixels; output (K, C, pooled_h, pooled_w).

@@ -2,6 +2,7 @@
 // include/richsem_msda.h): the matcher's cost blocks (section 8f rank 4), the attention-pool core (rank 3).  A translation unit of its own so that the operator's
 // kernels (msda_api.hip) are not rebuilt with it.  Error reporting: return codes only (msda_last_error covers msda_api.hip's calls).
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
 
 #include <algorithm>
 #include <cstdint>
@@ -53,9 +54,95 @@ int attnpool_core_impl(const T *u, const T *feat, const T *pos, const T *spos, i
     return e == hipSuccess ? MSDA_OK : (int)e;
 }
 
+// gen_sineembed_for_position (models/richsem/utils.py:142-168): one thread per (token, pair of channels) writes sin | cos of
+// coordinate * 2 pi / T^(2 i / pe_dim) as a packed pair of bf16
+__global__ __launch_bounds__(256) void sine_embed_kernel(const float *__restrict__ boxes, int ld, int tokens, int dims, int pe_dim,
+                                                         float log2_temperature, unsigned *__restrict__ out)
+{
+    const int half = pe_dim / 2, per_tok = dims * half;
+    const long long n = (long long)tokens * per_tok;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+        const int t = (int)(i / per_tok), r = (int)(i - (long long)t * per_tok);
+        const int part = r / half, k = r - part * half;                 // output block `part` = (y, x, w, h); channels 2k, 2k + 1
+        const int src = part < 2 ? 1 - part : part;                      // ... of the box's (x, y, w, h)
+        const float v = boxes[(long long)t * ld + src] * 6.283185307179586f;
+        const float p = v * exp2f(-log2_temperature * (float)(2 * k) / (float)pe_dim);
+        const __hip_bfloat16 a = __float2bfloat16(sinf(p)), b = __float2bfloat16(cosf(p));
+        out[i] = (unsigned)__bfloat16_as_ushort(a) | (unsigned)__bfloat16_as_ushort(b) << 16;
+    }
+}
+
+// the decoder's box update (deformable_transformer.py:779-804 / richsem.py:705-715): y = sigmoid(delta + inverse_sigmoid(ref)) with
+// inverse_sigmoid(r) = log(max(clamp(r, 0, 1), eps) / max(1 - clamp(r, 0, 1), eps)) (util/misc.py:605-609); and its gradient w.r.t. delta
+template <bool BF16>
+__global__ __launch_bounds__(256) void box_refine_kernel(const void *__restrict__ delta, const float *__restrict__ ref, float eps, long long n,
+                                                         float *__restrict__ out)
+{
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+        const float d = BF16 ? __bfloat162float(static_cast<const __hip_bfloat16 *>(delta)[i]) : static_cast<const float *>(delta)[i];
+        const float r = fminf(fmaxf(ref[i], 0.f), 1.f);
+        const float u = d + logf(fmaxf(r, eps) / fmaxf(1.f - r, eps));
+        out[i] = 1.f / (1.f + expf(-u));
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void box_refine_grad_kernel(const float *__restrict__ gy, const float *__restrict__ y, long long n,
+                                                              void *__restrict__ gdelta)
+{
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+        const float v = gy[i] * y[i] * (1.f - y[i]);
+        if (BF16) static_cast<__hip_bfloat16 *>(gdelta)[i] = __float2bfloat16(v);
+        else static_cast<float *>(gdelta)[i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+/* y = sigmoid(delta + inverse_sigmoid(ref)): delta (n) bf16 or f32, ref (n) f32, y (n) f32 */
+int msda_box_refine_forward(const void *delta, int delta_is_bf16, const float *ref, float eps, int64_t n, float *y, msda_stream_t stream)
+{
+    if (!delta || !ref || !y) return MSDA_ERR_NULL_POINTER;
+    if (n < 1) return MSDA_ERR_BAD_DIMS;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    if (delta_is_bf16)
+        hipLaunchKernelGGL(box_refine_kernel<true>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), delta, ref, eps, (long long)n, y);
+    else
+        hipLaunchKernelGGL(box_refine_kernel<false>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), delta, ref, eps, (long long)n, y);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
+
+/* grad_delta = grad_y * y * (1 - y), written in delta's type */
+int msda_box_refine_backward(const float *grad_y, const float *y, int64_t n, void *grad_delta, int delta_is_bf16, msda_stream_t stream)
+{
+    if (!grad_y || !y || !grad_delta) return MSDA_ERR_NULL_POINTER;
+    if (n < 1) return MSDA_ERR_BAD_DIMS;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    if (delta_is_bf16)
+        hipLaunchKernelGGL(box_refine_grad_kernel<true>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), grad_y, y, (long long)n, grad_delta);
+    else
+        hipLaunchKernelGGL(box_refine_grad_kernel<false>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), grad_y, y, (long long)n, grad_delta);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
+
+/* the decoder's positional query embedding: boxes (tokens, >= dims) f32 with row stride ld (floats), dims = 2 | 4 -> out (tokens,
+ * dims * pe_dim) bf16 */
+int msda_sine_embed_bf16(const float *boxes, int ld, int tokens, int dims, int pe_dim, float temperature, uint16_t *out, msda_stream_t stream)
+{
+    if (!boxes || !out) return MSDA_ERR_NULL_POINTER;
+    if (tokens < 1 || (dims != 2 && dims != 4) || ld < dims || pe_dim < 2 || (pe_dim & 1) || !(temperature > 0.f)) return MSDA_ERR_BAD_DIMS;
+    if (reinterpret_cast<uintptr_t>(out) & 3) return MSDA_ERR_MISALIGNED;
+    const long long n = (long long)tokens * dims * (pe_dim / 2);
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(sine_embed_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), boxes, ld, tokens, dims, pe_dim,
+                       log2f(temperature), reinterpret_cast<unsigned *>(out));
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
 
 int msda_attnpool_core_f32(const float *u, const float *feat, const float *pos, const float *spos, int K, int H, int C, int T,
                            int head_major, float *z, msda_stream_t stream)

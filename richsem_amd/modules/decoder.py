@@ -96,6 +96,63 @@ def gen_sineembed_for_position(pos_tensor, pe_dim=128):
     return torch.cat(parts, dim=2)
 
 
+class BoxRefineFunction(torch.autograd.Function):
+    """``(delta + inverse_sigmoid(ref)).sigmoid()`` (deformable_transformer.py:779-804, richsem.py:705-715) for a constant ``ref`` as
+    one launch each way (``msda_box_refine_forward / _backward``): delta bf16 or fp32 on the GPU, ref fp32 -> fp32 boxes"""
+
+    @staticmethod
+    def forward(ctx, delta, ref, eps):
+        from .. import _lib
+        d, r = delta.contiguous(), ref.detach().float().contiguous()
+        y = torch.empty(d.shape, dtype=torch.float32, device=d.device)
+        with torch.cuda.device(d.device):
+            _lib.check(_lib.load().msda_box_refine_forward(d.data_ptr(), int(d.dtype == torch.bfloat16), r.data_ptr(), float(eps), d.numel(),
+                                                          y.data_ptr(), torch.cuda.current_stream(d.device).cuda_stream))
+        ctx.save_for_backward(y)
+        ctx.dt = d.dtype
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        from .. import _lib
+        y, = ctx.saved_tensors
+        gy = gy.float().contiguous()
+        gd = torch.empty(y.shape, dtype=ctx.dt, device=y.device)
+        with torch.cuda.device(y.device):
+            _lib.check(_lib.load().msda_box_refine_backward(gy.data_ptr(), y.data_ptr(), y.numel(), gd.data_ptr(), int(ctx.dt == torch.bfloat16),
+                                                           torch.cuda.current_stream(y.device).cuda_stream))
+        return gd, None, None
+
+
+def refine_boxes(delta, ref, eps=1e-3):
+    """``(delta + inverse_sigmoid(ref)).sigmoid()``: on the library's kernel where ``ref`` carries no gradient (the decoder detaches it),
+    the reference's op sequence otherwise"""
+    if delta.is_cuda and delta.dtype in (torch.bfloat16, torch.float32) and not (ref.requires_grad and torch.is_grad_enabled()) \
+            and delta.shape == ref.shape:
+        return BoxRefineFunction.apply(delta, ref, eps)
+    return (delta.to(ref.dtype) + inverse_sigmoid(ref, eps)).sigmoid()
+
+
+def sine_embed_bf16(boxes, pe_dim=128):
+    """:func:`gen_sineembed_for_position` of detached boxes (..., 2 | 4) f32 on the GPU -> (..., pe_dim * 2 | 4) bf16 in one launch
+    (``msda_sine_embed_bf16``); no gradient (the decoder applies it to detached boxes)"""
+    from .. import _lib
+    b = boxes.detach()
+    dims = b.shape[-1]
+    # rows at a uniform stride are read in place (the level-0 slice of the (bs, nq, L, 4) boxes: stride L * 4); anything else is copied
+    uniform = b.dtype == torch.float32 and b.dim() >= 2 and b.stride(-1) == 1 and all(
+        b.stride(i) == b.stride(i + 1) * b.shape[i + 1] for i in range(b.dim() - 2))
+    if not uniform:
+        b = b.float().contiguous()
+    ld, rows = (b.stride(-2), b.numel() // dims) if b.dim() >= 2 else (dims, 1)
+    out = torch.empty(b.shape[:-1] + (dims * pe_dim,), dtype=torch.bfloat16, device=b.device)
+    with torch.cuda.device(b.device):
+        _lib.check(_lib.load().msda_sine_embed_bf16(b.data_ptr(), ld, rows, dims, pe_dim, 10000.0, out.data_ptr(),
+                                                   torch.cuda.current_stream(b.device).cuda_stream))
+    return out
+
+
 class TransformerDecoder(nn.Module):
     def __init__(self, decoder_layer, num_layers, norm=None, d_model=256, query_dim=4, num_feature_levels=4):
         super().__init__()
@@ -137,13 +194,15 @@ class TransformerDecoder(nn.Module):
         nw, nb = self.norm.weight.to(torch.bfloat16), self.norm.bias.to(torch.bfloat16)
         for layer_id, layer in enumerate(self.layers):
             reference_points_input = (reference_points[:, :, None] * vr.to(reference_points.dtype)).contiguous()                    # (bs, nq, L, 4)
-            query_sine_embed = gen_sineembed_for_position(reference_points_input[:, :, 0, :], self.d_model // 2)
-            query_pos = self.ref_point_head(query_sine_embed.to(torch.bfloat16))
+            if reference_points_input.requires_grad:      # (not in the shipped flow: the boxes are detached between layers, :779-804)
+                query_sine_embed = gen_sineembed_for_position(reference_points_input[:, :, 0, :], self.d_model // 2).to(torch.bfloat16)
+            else:
+                query_sine_embed = sine_embed_bf16(reference_points_input[:, :, 0, :], self.d_model // 2)
+            query_pos = self.ref_point_head(query_sine_embed)
             x = layer.forward_batch_first(x, query_pos, reference_points_input.float(), values[layer_id], level_start_index, spatial_shapes,
                                           tgt_mask)
             if self.bbox_embed is not None:
-                delta_unsig = self.bbox_embed[layer_id](x).to(reference_points.dtype)
-                new_reference_points = (delta_unsig + inverse_sigmoid(reference_points)).sigmoid()
+                new_reference_points = refine_boxes(self.bbox_embed[layer_id](x), reference_points)
                 reference_points = new_reference_points.detach()
                 ref_points.append(new_reference_points)
             intermediate.append(F.layer_norm(x, (x.shape[-1],), nw, nb, self.norm.eps))

@@ -240,3 +240,37 @@ def test_bf16_layer_follows_an_optimizer_step():
     mod.invalidate_bf16_cache()
     ref_mod.load_state_dict(mod.state_dict())
     assert torch.equal(mod(q, rp, src, shapes, lsi, None), ref_mod(q, rp, src, shapes, lsi, None))
+
+
+@pytest.mark.parametrize("dims", [2, 4])
+def test_sine_embed_kernel_matches_the_mirror(dims):
+    """msda_sine_embed_bf16 (one launch) against gen_sineembed_for_position (the reference's op sequence, fp32) to one bf16 rounding,
+    on contiguous boxes and on the level-0 slice of the (bs, nq, L, dims) boxes the decoder hands it"""
+    from richsem_amd.modules.decoder import gen_sineembed_for_position, sine_embed_bf16
+    g = torch.Generator(device="cuda").manual_seed(3)
+    full = torch.rand(2, 137, 4, dims, device="cuda", generator=g)
+    for boxes in (full[:, :, 0, :], full[:, :, 0, :].contiguous()):
+        got = sine_embed_bf16(boxes, 128).float()
+        ref = gen_sineembed_for_position(boxes.contiguous(), 128)
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max() <= 2 ** -8 + 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_refine_boxes_kernel_matches_the_op_sequence(dt):
+    """msda_box_refine_* against (delta + inverse_sigmoid(ref)).sigmoid() and its autograd gradient, incl. boxes at / beyond 0 and 1"""
+    from richsem_amd.modules.decoder import inverse_sigmoid, refine_boxes
+    g = torch.Generator(device="cuda").manual_seed(9)
+    ref = torch.rand(2, 300, 4, device="cuda", generator=g)
+    ref[0, :5] = torch.tensor([0.0, 1.0, 1e-4, 1 - 1e-4], device="cuda")
+    ref[1, 0] = torch.tensor([-0.1, 1.2, 0.5, 0.5], device="cuda")
+    delta = (torch.randn(2, 300, 4, device="cuda", generator=g)).to(dt).requires_grad_(True)
+    gy = torch.randn(2, 300, 4, device="cuda", generator=g)
+    y = refine_boxes(delta, ref)
+    y.backward(gy)
+    d2 = delta.detach().clone().requires_grad_(True)
+    y2 = (d2.float() + inverse_sigmoid(ref)).sigmoid()
+    y2.backward(gy)
+    assert y.dtype == torch.float32 and (y - y2).abs().max() < 2e-6
+    tol = 2e-6 if dt == torch.float32 else 2 ** -8
+    assert (delta.grad.float() - d2.grad.float()).abs().max() <= tol * max(1.0, float(d2.grad.float().abs().max()))

@@ -29,6 +29,29 @@ def timeit(fn, reps):
     return a.elapsed_time(b) / reps * 1e3
 
 
+def timeit_graph(fn, reps):
+    """the same work captured once into a HIP graph and replayed: GPU time without the host's launch gaps"""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=10)
@@ -57,10 +80,11 @@ def main():
                 q.grad = None
             layer(tgt=t, tgt_query_pos=qpos.to(dt), tgt_reference_points=refp, memory=m, memory_level_start_index=lsi,
                   memory_spatial_shapes=shapes, self_attn_mask=amask).backward(go.to(dt))
-        return timeit(step, args.reps)
+        return (timeit(step, args.reps), timeit_graph(step, args.reps)) if dt == torch.bfloat16 else timeit(step, args.reps)
 
-    t16 = run_layer(torch.bfloat16)
-    msg = f"decoder layer forward + backward, {nq} queries x {bs} images, {call.S} memory tokens: bf16 on the library's kernels {t16:.0f} us"
+    t16, g16 = run_layer(torch.bfloat16)
+    msg = (f"decoder layer forward + backward, {nq} queries x {bs} images, {call.S} memory tokens: bf16 on the library's kernels {t16:.0f} us "
+           f"eager, {g16:.0f} us replayed as a HIP graph")
     if args.only != "bf16":
         msg += f"; fp32 with the fused attention module {run_layer(torch.float32):.0f} us; fp32 op-by-op {run_layer(torch.float32, False):.0f} us"
     print(msg, flush=True)
@@ -78,10 +102,11 @@ def main():
                 q.grad = None
             hs, refs = dec(tgt=t, memory=m, tgt_mask=amask, refpoints_unsigmoid=refu, level_start_index=lsi, spatial_shapes=shapes, valid_ratios=vr)
             (torch.stack(hs).float().square().mean() + torch.stack(refs).square().mean()).backward()
-        return timeit(step, args.reps)
+        return (timeit(step, args.reps), timeit_graph(step, args.reps)) if dt == torch.bfloat16 else timeit(step, args.reps)
 
-    s16 = run_stack(torch.bfloat16)
-    msg = f"six-layer decoder forward + backward: bf16 on the library's kernels {s16:.0f} us ({s16 / 6:.0f} us per layer)"
+    s16, sg16 = run_stack(torch.bfloat16)
+    msg = (f"six-layer decoder forward + backward: bf16 on the library's kernels {s16:.0f} us eager ({s16 / 6:.0f} us per layer), "
+           f"{sg16:.0f} us as a HIP graph ({sg16 / 6:.0f} us per layer)")
     if args.only != "bf16":
         msg += f"; fp32 {run_stack(torch.float32):.0f} us"
     print(msg, flush=True)
