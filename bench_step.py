@@ -30,7 +30,7 @@ from richsem_amd.clip_resnet import ModifiedResNetTeacher
 from richsem_amd.dn import prepare_dn_layout
 from richsem_amd.functions.linear import Lin256Function, VersionCache, pack_linear256
 from richsem_amd.matcher import HungarianMatcher
-from richsem_amd.modules import (MLP, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, TransformerDecoder,
+from richsem_amd.modules import (MLP, refine_boxes, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, TransformerDecoder,
                                  clip_box_targets, get_reference_points, inverse_sigmoid)
 from richsem_amd.two_stage import ClassScorer
 
@@ -263,7 +263,7 @@ class Step(nn.Module):
             return sum(h.float().sum() for h in hs) + sum(r.sum() for r in refs) + interm['pred_logits'].sum() + interm['pred_boxes'].sum()
         # ---- heads (richsem.py:705-733) -------------------------------------------------------------------------------------------------
         hs_stack = torch.stack(hs)                                                                     # (6, N, pad + 900, 256)
-        coords = torch.stack([(self.decoder.bbox_embed[l](hs[l]).float() + inverse_sigmoid(refs[l])).sigmoid() for l in range(6)])
+        coords = torch.stack([refine_boxes(self.decoder.bbox_embed[l](hs[l]), refs[l]) for l in range(6)])      # richsem.py:705-715
         logits = self.class_logits(hs_stack)                                                           # (6, N, 1092, 1204)
         clip_hs = F.linear(hs[-1], self.proj_dino_hs.weight.to(hs[-1].dtype), self.proj_dino_hs.bias.to(hs[-1].dtype))
         clip_hs = clip_hs / clip_hs.norm(dim=-1, keepdim=True)

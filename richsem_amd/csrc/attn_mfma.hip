@@ -23,6 +23,8 @@
 
 #include "../../include/richsem_msda.h"
 
+extern "C" int msda_note_error(int code, const char *entry);      // msda_api.hip: sets msda_last_error()
+
 namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -377,9 +379,9 @@ int msda_attn_forward_bf16(const uint16_t *q, int ldq, const uint16_t *k, int ld
                            int nq, int bs, int batch_first, int heads, uint16_t *out, float *lse, void *workspace, msda_stream_t stream)
 {
     const Tok tk = batch_first ? Tok{1, nq} : Tok{bs, 1};
-    if (!q || !k || !v || !out || !lse || !workspace) return MSDA_ERR_NULL_POINTER;
-    if (nq <= 0 || bs <= 0 || heads <= 0 || bad_ld(ldq, heads) || bad_ld(ldk, heads) || bad_ld(ldv, heads)) return MSDA_ERR_BAD_DIMS;
-    if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(out) || misaligned(lse) || misaligned(workspace)) return MSDA_ERR_MISALIGNED;
+    if (!q || !k || !v || !out || !lse || !workspace) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (nq <= 0 || bs <= 0 || heads <= 0 || bad_ld(ldq, heads) || bad_ld(ldk, heads) || bad_ld(ldv, heads)) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(out) || misaligned(lse) || misaligned(workspace)) return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nkb = (nq + 31) / 32, nqp = nkb * 32;
     uint16_t *vt = static_cast<uint16_t *>(workspace);
@@ -396,14 +398,14 @@ int msda_attn_backward_bf16(const uint16_t *q, int ldq, const uint16_t *k, int l
                             msda_stream_t stream)
 {
     const Tok tk = batch_first ? Tok{1, nq} : Tok{bs, 1};
-    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !workspace) return MSDA_ERR_NULL_POINTER;
-    if ((mask_bits == nullptr) != (maskt_bits == nullptr)) return MSDA_ERR_NULL_POINTER;
+    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !workspace) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if ((mask_bits == nullptr) != (maskt_bits == nullptr)) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     if (nq <= 0 || bs <= 0 || heads <= 0 || bad_ld(ldq, heads) || bad_ld(ldk, heads) || bad_ld(ldv, heads) || bad_ld(lddq, heads) ||
         bad_ld(lddk, heads) || bad_ld(lddv, heads))
-        return MSDA_ERR_BAD_DIMS;
+        return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(out) || misaligned(dout) || misaligned(dq) || misaligned(dk) ||
         misaligned(dv) || misaligned(workspace) || misaligned(lse))
-        return MSDA_ERR_MISALIGNED;
+        return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nkb = (nq + 31) / 32, nqp = nkb * 32;
     const size_t tsz = (size_t)bs * heads * kHd * nqp;

@@ -30,6 +30,8 @@
 
 #include "../../include/richsem_msda.h"
 
+extern "C" int msda_note_error(int code, const char *entry);      // msda_api.hip: sets msda_last_error()
+
 namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -216,16 +218,16 @@ extern "C" {
 
 int msda_cls_packed_elems(int classes, int64_t *elems)
 {
-    if (!elems) return MSDA_ERR_NULL_POINTER;
-    if (classes < 1 || classes > kMaxClasses) return MSDA_ERR_BAD_DIMS;
+    if (!elems) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (classes < 1 || classes > kMaxClasses) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     *elems = (int64_t)((classes + 15) / 16 + kD / 16) * kTileShorts;
     return MSDA_OK;
 }
 
 int msda_cls_pack(const float *G, int classes, const float *A, int d_model, uint16_t *packed, msda_stream_t stream)
 {
-    if (!G || !A || !packed) return MSDA_ERR_NULL_POINTER;
-    if (classes < 1 || classes > kMaxClasses || d_model != kD) return MSDA_ERR_BAD_DIMS;
+    if (!G || !A || !packed) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (classes < 1 || classes > kMaxClasses || d_model != kD) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     const int n_tiles = (classes + 15) / 16 + kD / 16;
     hipLaunchKernelGGL(cls_pack_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), G, classes, A, packed, n_tiles);
     const hipError_t e = hipGetLastError();
@@ -235,9 +237,9 @@ int msda_cls_pack(const float *G, int classes, const float *A, int d_model, uint
 int msda_cls_max_scores(const void *x, int x_is_bf16, const uint16_t *packed, int tokens, int d_model, int classes, float scale, int parts,
                         float *scores, msda_stream_t stream)
 {
-    if (!x || !packed || !scores) return MSDA_ERR_NULL_POINTER;
-    if (tokens < 0 || d_model != kD || classes < 1 || classes > kMaxClasses || (parts != 1 && parts != 2)) return MSDA_ERR_BAD_DIMS;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed)) & 15) return MSDA_ERR_MISALIGNED;
+    if (!x || !packed || !scores) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (tokens < 0 || d_model != kD || classes < 1 || classes > kMaxClasses || (parts != 1 && parts != 2)) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed)) & 15) return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     if (tokens == 0) return MSDA_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (x_is_bf16)

@@ -30,6 +30,8 @@
 
 #include "../../include/richsem_msda.h"
 
+extern "C" int msda_note_error(int code, const char *entry);      // msda_api.hip: sets msda_last_error()
+
 namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -553,7 +555,7 @@ int msda_conv_set_tiling(int co_tiles, int pixel_tiles)
 {
     if ((co_tiles != 0 && co_tiles != 1 && co_tiles != 2 && co_tiles != 4 && co_tiles != 8 && co_tiles != 16) || pixel_tiles < 0 ||
         pixel_tiles > 3)
-        return MSDA_ERR_BAD_OPTION;
+        return msda_note_error(MSDA_ERR_BAD_OPTION, __func__);
     g_force_ct = co_tiles;
     g_force_pt = pixel_tiles;
     return MSDA_OK;
@@ -561,17 +563,17 @@ int msda_conv_set_tiling(int co_tiles, int pixel_tiles)
 
 int msda_conv_packed_elems(int Cout, int Cin, int KH, int KW, int64_t *elems)
 {
-    if (!elems) return MSDA_ERR_NULL_POINTER;
-    if (Cout < 16 || Cout % 16 != 0 || Cin < 1 || KH < 1 || KW < 1 || KH > 16 || KW > 16) return MSDA_ERR_BAD_DIMS;
+    if (!elems) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (Cout < 16 || Cout % 16 != 0 || Cin < 1 || KH < 1 || KW < 1 || KH > 16 || KW > 16) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     const int64_t K = (int64_t)KH * KW * Cin;
-    if (Cin % 32 != 0 && K > 512) return MSDA_ERR_BAD_DIMS;      // few-channel inputs only (table of 512 entries)
+    if (Cin % 32 != 0 && K > 512) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);      // few-channel inputs only (table of 512 entries)
     *elems = (int64_t)Cout * ((K + 31) / 32 * 32);
     return MSDA_OK;
 }
 
 int msda_conv_pack_weight(const float *weight, int Cout, int Cin, int KH, int KW, uint16_t *packed, msda_stream_t stream)
 {
-    if (!weight || !packed) return MSDA_ERR_NULL_POINTER;
+    if (!weight || !packed) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     int64_t n = 0;
     const int rc = msda_conv_packed_elems(Cout, Cin, KH, KW, &n);
     if (rc != MSDA_OK) return rc;
@@ -585,18 +587,18 @@ int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, con
                            const uint16_t *residual, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
                            uint16_t *out, msda_stream_t stream)
 {
-    if (!x || !packed_weight || !scale || !shift || !out) return MSDA_ERR_NULL_POINTER;
+    if (!x || !packed_weight || !scale || !shift || !out) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     int64_t n = 0;
     const int rc = msda_conv_packed_elems(Cout, Cin, KH, KW, &n);
     if (rc != MSDA_OK) return rc;
-    if (N < 1 || H < 1 || W < 1 || stride < 1 || pad < 0) return MSDA_ERR_BAD_DIMS;
+    if (N < 1 || H < 1 || W < 1 || stride < 1 || pad < 0) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    if (Ho < 1 || Wo < 1) return MSDA_ERR_BAD_DIMS;
-    if ((long long)N * H * W * Cin >= (1ll << 40) || (long long)N * Ho * Wo * Cout >= (1ll << 40)) return MSDA_ERR_TOO_LARGE;
+    if (Ho < 1 || Wo < 1) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    if ((long long)N * H * W * Cin >= (1ll << 40) || (long long)N * Ho * Wo * Cout >= (1ll << 40)) return msda_note_error(MSDA_ERR_TOO_LARGE, __func__);
     const bool small_c = Cin % 32 != 0;
     if ((reinterpret_cast<uintptr_t>(packed_weight) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
          reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(residual) | (small_c ? 0 : reinterpret_cast<uintptr_t>(x))) & 15)
-        return MSDA_ERR_MISALIGNED;
+        return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     int ct, pt;
     choose_tiling((long long)N * Ho * Wo, Cout, KH * KW * Cin, ct, pt);
     const int fct = g_force_ct.load(), fpt = g_force_pt.load();
@@ -614,11 +616,11 @@ int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, con
 int msda_groupnorm8_nhwc_bf16(const uint16_t *x, const float *gamma, const float *beta, float eps, int N, int HW, int C, double *stats,
                               float *out_f32, uint16_t *out_bf16, msda_stream_t stream)
 {
-    if (!x || !gamma || !beta || !stats || (!out_f32 && !out_bf16)) return MSDA_ERR_NULL_POINTER;
-    if (N < 1 || HW < 1 || C < 8 || C % 8 != 0 || C / 8 > 65535 || N > 65535) return MSDA_ERR_BAD_DIMS;
+    if (!x || !gamma || !beta || !stats || (!out_f32 && !out_bf16)) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (N < 1 || HW < 1 || C < 8 || C % 8 != 0 || C / 8 > 65535 || N > 65535) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
          reinterpret_cast<uintptr_t>(out_f32) | reinterpret_cast<uintptr_t>(out_bf16)) & 15)
-        return MSDA_ERR_MISALIGNED;
+        return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int groups = C / 8;
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * N * groups, st);
@@ -638,10 +640,10 @@ int msda_groupnorm8_nhwc_bf16(const uint16_t *x, const float *gamma, const float
 int msda_groupnorm8_backward_nhwc_bf16(const uint16_t *x, const uint16_t *dy, const float *gamma, float eps, int N, int HW, int C,
                                        const double *stats, double *bstats, uint16_t *dx, float *dgamma, float *dbeta, msda_stream_t stream)
 {
-    if (!x || !dy || !gamma || !stats || !bstats || !dx) return MSDA_ERR_NULL_POINTER;
-    if (N < 1 || HW < 1 || C < 8 || C % 8 != 0 || C / 8 > 65535 || N > 65535) return MSDA_ERR_BAD_DIMS;
+    if (!x || !dy || !gamma || !stats || !bstats || !dx) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (N < 1 || HW < 1 || C < 8 || C % 8 != 0 || C / 8 > 65535 || N > 65535) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx)) & 15)
-        return MSDA_ERR_MISALIGNED;
+        return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int groups = C / 8;
     hipError_t e = hipMemsetAsync(bstats, 0, sizeof(double) * 16 * N * groups, st);
@@ -662,12 +664,12 @@ int msda_groupnorm8_backward_nhwc_bf16(const uint16_t *x, const uint16_t *dy, co
 int msda_pool_nhwc_bf16(const uint16_t *x, int N, int H, int W, int C, int k, int stride, int pad, int is_max, uint16_t *out,
                         msda_stream_t stream)
 {
-    if (!x || !out) return MSDA_ERR_NULL_POINTER;
+    if (!x || !out) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     if (N < 1 || H < 1 || W < 1 || C < 8 || C % 8 != 0 || k < 1 || stride < 1 || pad < 0 || (!is_max && pad != 0) || pad >= k)
-        return MSDA_ERR_BAD_DIMS;
+        return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
-    if (Ho < 1 || Wo < 1) return MSDA_ERR_BAD_DIMS;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) return MSDA_ERR_MISALIGNED;
+    if (Ho < 1 || Wo < 1) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     const long long n = (long long)N * Ho * Wo * (C / 8);
     const int grid = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -686,17 +688,17 @@ int msda_pool_nhwc_bf16(const uint16_t *x, int N, int H, int W, int C, int k, in
 int msda_conv_dgrad_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW,
                          int stride, int pad, int H, int W, uint16_t *dx, msda_stream_t stream)
 {
-    if (!dy || !packed_weight_t || !dx) return MSDA_ERR_NULL_POINTER;
+    if (!dy || !packed_weight_t || !dx) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     if (N < 1 || Ho < 1 || Wo < 1 || H < 1 || W < 1 || Cout < 32 || Cout % 32 != 0 || Cin < 16 || Cin % 16 != 0 || KH < 1 || KW < 1 ||
         KH > 16 || KW > 16 || stride < 1 || pad < 0 || pad > KH - 1 || pad > KW - 1)
-        return MSDA_ERR_BAD_DIMS;
-    if ((H + 2 * pad - KH) / stride + 1 != Ho || (W + 2 * pad - KW) / stride + 1 != Wo) return MSDA_ERR_BAD_DIMS;
-    if ((long long)N * H * W * Cin >= (1ll << 40) || (long long)N * Ho * Wo * Cout >= (1ll << 40)) return MSDA_ERR_TOO_LARGE;
+        return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    if ((H + 2 * pad - KH) / stride + 1 != Ho || (W + 2 * pad - KW) / stride + 1 != Wo) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    if ((long long)N * H * W * Cin >= (1ll << 40) || (long long)N * Ho * Wo * Cout >= (1ll << 40)) return msda_note_error(MSDA_ERR_TOO_LARGE, __func__);
     if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(packed_weight_t) | reinterpret_cast<uintptr_t>(dx)) & 15)
-        return MSDA_ERR_MISALIGNED;
+        return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     // as a forward call: input dy with Cout channels, output dx with Cin channels and H x W pixels, padding KH - 1 - pad
     // (KH == KW is not required: the column padding is KW - 1 - pad, see below), virtual input upsampled by `stride`
-    if (KH - 1 - pad != KW - 1 - pad) return MSDA_ERR_BAD_DIMS;      // one padding value in the kernel's geometry: square kernels
+    if (KH - 1 - pad != KW - 1 - pad) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);      // one padding value in the kernel's geometry: square kernels
     int ct, pt;
     choose_tiling((long long)N * H * W, Cin, KH * KW * Cout, ct, pt);
     const ConvArgs a{dy, packed_weight_t, nullptr, nullptr, nullptr, dx, ConvGeom{N, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, KH - 1 - pad, stride},

@@ -23,6 +23,8 @@
 
 #include "../../include/richsem_msda.h"
 
+extern "C" int msda_note_error(int code, const char *entry);      // msda_api.hip: sets msda_last_error()
+
 namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -282,12 +284,12 @@ extern "C" {
 /* bytes of workspace msda_conv_wgrad_bf16 needs for a problem (0: none) */
 int msda_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t *bytes)
 {
-    if (!bytes) return MSDA_ERR_NULL_POINTER;
+    if (!bytes) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     if (N < 1 || H < 1 || W < 1 || Cin < kBN || Cin % kBN != 0 || Cout < kBM || Cout % kBM != 0 || KH < 1 || KW < 1 || KH > 16 || KW > 16 ||
         stride < 1 || pad < 0)
-        return MSDA_ERR_BAD_DIMS;
+        return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    if (Ho < 1 || Wo < 1) return MSDA_ERR_BAD_DIMS;
+    if (Ho < 1 || Wo < 1) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, (long long)N * Ho * Wo, 0, 0};
     long long split, chunk;
     wgrad_split(g, split, chunk);
@@ -298,23 +300,23 @@ int msda_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int 
 int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                          int pad, float *dw, float *dbias, const float *scale, int torch_layout, void *workspace, msda_stream_t stream)
 {
-    if (!dz || !x || !dw) return MSDA_ERR_NULL_POINTER;
+    if (!dz || !x || !dw) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     if (N < 1 || H < 1 || W < 1 || Cin < kBN || Cin % kBN != 0 || Cout < kBM || Cout % kBM != 0 || KH < 1 || KW < 1 || KH > 16 || KW > 16 ||
         stride < 1 || pad < 0)
-        return MSDA_ERR_BAD_DIMS;
+        return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    if (Ho < 1 || Wo < 1) return MSDA_ERR_BAD_DIMS;
-    if ((long long)N * H * W * Cin >= (1ll << 40) || (long long)N * Ho * Wo * Cout >= (1ll << 40)) return MSDA_ERR_TOO_LARGE;
-    if ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dw)) & 15) return MSDA_ERR_MISALIGNED;
+    if (Ho < 1 || Wo < 1) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    if ((long long)N * H * W * Cin >= (1ll << 40) || (long long)N * Ho * Wo * Cout >= (1ll << 40)) return msda_note_error(MSDA_ERR_TOO_LARGE, __func__);
+    if ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dw)) & 15) return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     hipStream_t st = static_cast<hipStream_t>(stream);
     WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, (long long)N * Ho * Wo, 0, torch_layout};
-    if (g.P >= (1ll << 31) - (1 << 20) || (long long)N * H * W >= (1ll << 31)) return MSDA_ERR_TOO_LARGE;      // 32-bit pixel counters
+    if (g.P >= (1ll << 31) - (1 << 20) || (long long)N * H * W >= (1ll << 31)) return msda_note_error(MSDA_ERR_TOO_LARGE, __func__);      // 32-bit pixel counters
     long long split;
     wgrad_split(g, split, g.chunk);
     const long long blocks_y = (long long)KH * KW * (Cout / kBM) * (Cin / kBN);
     const long long n_dw = (long long)Cout * KH * KW * Cin;
-    if (split > 1 && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15))) return MSDA_ERR_NULL_POINTER;
-    if (blocks_y > 65535) return MSDA_ERR_TOO_LARGE;
+    if (split > 1 && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15))) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (blocks_y > 65535) return msda_note_error(MSDA_ERR_TOO_LARGE, __func__);
     float *ws_bias = split > 1 ? static_cast<float *>(workspace) + split * n_dw : nullptr;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)split, (unsigned)blocks_y), dim3(kThreads), 0, st, dz, x,
                        split > 1 ? static_cast<float *>(workspace) : dw, dbias ? (split > 1 ? ws_bias : dbias) : nullptr, scale, split > 1 ? 0 : 1,

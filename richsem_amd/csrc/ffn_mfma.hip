@@ -36,6 +36,8 @@
 
 #include "../../include/richsem_msda.h"
 
+extern "C" int msda_note_error(int code, const char *entry);      // msda_api.hip: sets msda_last_error()
+
 namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -475,8 +477,8 @@ int msda_ffn_debug_stamps(void *device_buffer)
 
 int msda_ffn_pack_w2_bf16(const uint16_t *w2, int d_model, int d_ffn, uint16_t *w2_packed, msda_stream_t stream)
 {
-    if (!w2 || !w2_packed) return MSDA_ERR_NULL_POINTER;
-    if (d_model != kD || d_ffn < kHT || d_ffn % kHT != 0 || d_ffn > kMaxFfn) return MSDA_ERR_BAD_DIMS;
+    if (!w2 || !w2_packed) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (d_model != kD || d_ffn < kHT || d_ffn % kHT != 0 || d_ffn > kMaxFfn) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     const long long n = (long long)d_model * d_ffn;
     hipLaunchKernelGGL(pack_w2_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), w2, w2_packed, n);
     const hipError_t e = hipGetLastError();
@@ -500,17 +502,17 @@ int msda_ffn_forward_train_bf16(const uint16_t *x, const uint16_t *w1, const flo
                                 const float *ln_weight, const float *ln_bias, float eps, int tokens, int d_model, int d_ffn,
                                 uint16_t *out, float *rstd, uint16_t *yhat, msda_stream_t stream)
 {
-    if (!x || !w1 || !b1 || !w2_packed || !b2 || !ln_weight || !ln_bias || !out) return MSDA_ERR_NULL_POINTER;
-    if (d_model != kD || d_ffn < kHT || d_ffn % kHT != 0 || d_ffn > kMaxFfn || tokens < 0) return MSDA_ERR_BAD_DIMS;
+    if (!x || !w1 || !b1 || !w2_packed || !b2 || !ln_weight || !ln_bias || !out) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (d_model != kD || d_ffn < kHT || d_ffn % kHT != 0 || d_ffn > kMaxFfn || tokens < 0) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2_packed) |
          reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(b2) |
          reinterpret_cast<uintptr_t>(ln_weight) | reinterpret_cast<uintptr_t>(ln_bias)) & 15)
-        return MSDA_ERR_MISALIGNED;
+        return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     if (tokens == 0) return MSDA_OK;
     const size_t lds = ffn_lds_bytes(d_ffn);
     static std::atomic<bool> raised[64];   // per device: the dynamic-LDS limit is a property of (function, device)
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MSDA_ERR_NO_DEVICE;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return msda_note_error(MSDA_ERR_NO_DEVICE, __func__);
     if (!raised[dev].load()) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
@@ -529,11 +531,11 @@ int msda_ffn_forward_train_bf16(const uint16_t *x, const uint16_t *w1, const flo
 int msda_ffn_ln_backward_bf16(const uint16_t *dy, const uint16_t *yhat, const float *rstd, const float *ln_weight, int tokens, int d_model,
                               uint16_t *dz, float *grad_ln_weight, float *grad_ln_bias, float *grad_b2, msda_stream_t stream)
 {
-    if (!dy || !yhat || !rstd || !ln_weight || !dz || !grad_ln_weight || !grad_ln_bias || !grad_b2) return MSDA_ERR_NULL_POINTER;
-    if (tokens < 0 || d_model != kD) return MSDA_ERR_BAD_DIMS;
+    if (!dy || !yhat || !rstd || !ln_weight || !dz || !grad_ln_weight || !grad_ln_bias || !grad_b2) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (tokens < 0 || d_model != kD) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(yhat) | reinterpret_cast<uintptr_t>(dz) |
          reinterpret_cast<uintptr_t>(ln_weight)) & 15)
-        return MSDA_ERR_MISALIGNED;
+        return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (float *p : {grad_ln_weight, grad_ln_bias, grad_b2}) {
         const hipError_t e = hipMemsetAsync(p, 0, kD * sizeof(float), st);
@@ -552,11 +554,11 @@ int msda_ffn_ln_backward_bf16(const uint16_t *dy, const uint16_t *yhat, const fl
 int msda_add_layernorm_forward_bf16(const uint16_t *a, const uint16_t *b, const float *ln_weight, const float *ln_bias, float eps, int tokens,
                                     int d_model, uint16_t *out, float *rstd, uint16_t *yhat, msda_stream_t stream)
 {
-    if (!a || !ln_weight || !ln_bias || !out) return MSDA_ERR_NULL_POINTER;
-    if (tokens < 0 || d_model != kD) return MSDA_ERR_BAD_DIMS;
+    if (!a || !ln_weight || !ln_bias || !out) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (tokens < 0 || d_model != kD) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(yhat) |
          reinterpret_cast<uintptr_t>(ln_weight) | reinterpret_cast<uintptr_t>(ln_bias)) & 15)
-        return MSDA_ERR_MISALIGNED;
+        return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     if (tokens == 0) return MSDA_OK;
     const int grid = (tokens + 3) / 4 < 4096 ? (tokens + 3) / 4 : 4096;
     hipLaunchKernelGGL(add_layernorm_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, ln_weight, ln_bias, eps, tokens,

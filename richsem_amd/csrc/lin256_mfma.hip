@@ -16,6 +16,8 @@
 
 #include "../../include/richsem_msda.h"
 
+extern "C" int msda_note_error(int code, const char *entry);      // msda_api.hip: sets msda_last_error()
+
 namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -304,8 +306,8 @@ extern "C" {
 
 int msda_lin256_pack_bf16(const uint16_t *w, int out_features, int in_features, uint16_t *packed, msda_stream_t stream)
 {
-    if (!w || !packed) return MSDA_ERR_NULL_POINTER;
-    if (in_features != kD || out_features < kBlockRows || out_features % kBlockRows != 0) return MSDA_ERR_BAD_DIMS;
+    if (!w || !packed) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (in_features != kD || out_features < kBlockRows || out_features % kBlockRows != 0) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     hipLaunchKernelGGL(lin256_pack_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), w, packed, out_features);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
@@ -314,13 +316,13 @@ int msda_lin256_pack_bf16(const uint16_t *w, int out_features, int in_features, 
 int msda_lin256_forward_bf16(const uint16_t *x, const uint16_t *packed_w, const float *bias, const uint16_t *relu_mask, int epilogue,
                              int tokens, int in_features, int out_features, uint16_t *out, msda_stream_t stream)
 {
-    if (!x || !packed_w || !out) return MSDA_ERR_NULL_POINTER;
+    if (!x || !packed_w || !out) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     if (tokens < 0 || in_features != kD || out_features < kBlockRows || out_features % kBlockRows != 0 || epilogue < 0 || epilogue > 3)
-        return MSDA_ERR_BAD_DIMS;
-    if (epilogue >= 2 && !relu_mask) return MSDA_ERR_NULL_POINTER;
+        return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    if (epilogue >= 2 && !relu_mask) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed_w) | reinterpret_cast<uintptr_t>(out) |
          reinterpret_cast<uintptr_t>(bias) | (epilogue == 2 ? reinterpret_cast<uintptr_t>(relu_mask) : 0)) & 15)
-        return MSDA_ERR_MISALIGNED;
+        return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     if (tokens == 0) return MSDA_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (epilogue) {
@@ -334,11 +336,11 @@ int msda_lin256_forward_bf16(const uint16_t *x, const uint16_t *packed_w, const 
 int msda_lin256_forward_stacked_bf16(const uint16_t *x, const uint16_t *packed_w, const float *bias, const uint8_t *row_mask, int tokens,
                                      int in_features, int out_features, uint16_t *out, msda_stream_t stream)
 {
-    if (!x || !packed_w || !out) return MSDA_ERR_NULL_POINTER;
-    if (tokens < 0 || in_features != kD || out_features < 256 || out_features % 256 != 0) return MSDA_ERR_BAD_DIMS;
+    if (!x || !packed_w || !out) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (tokens < 0 || in_features != kD || out_features < 256 || out_features % 256 != 0) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed_w) | reinterpret_cast<uintptr_t>(out) |
          reinterpret_cast<uintptr_t>(bias)) & 15)
-        return MSDA_ERR_MISALIGNED;
+        return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     if (tokens == 0) return MSDA_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long long chunk = (long long)tokens * 256;
@@ -348,8 +350,8 @@ int msda_lin256_forward_stacked_bf16(const uint16_t *x, const uint16_t *packed_w
 
 int msda_lin256_pack_f32(const float *w, int out_features, int in_features, uint16_t *packed, msda_stream_t stream)
 {
-    if (!w || !packed) return MSDA_ERR_NULL_POINTER;
-    if (in_features != kD || out_features < kF32BlockRows || out_features % kF32BlockRows != 0) return MSDA_ERR_BAD_DIMS;
+    if (!w || !packed) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (in_features != kD || out_features < kF32BlockRows || out_features % kF32BlockRows != 0) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     hipLaunchKernelGGL(lin256_pack_f32_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), w, packed, out_features);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
@@ -358,11 +360,11 @@ int msda_lin256_pack_f32(const float *w, int out_features, int in_features, uint
 int msda_lin256_forward_f32(const float *x, const uint16_t *packed_w, const float *bias, int tokens, int in_features, int out_features,
                             float *out, msda_stream_t stream)
 {
-    if (!x || !packed_w || !out) return MSDA_ERR_NULL_POINTER;
-    if (tokens < 0 || in_features != kD || out_features < kF32BlockRows || out_features % kF32BlockRows != 0) return MSDA_ERR_BAD_DIMS;
+    if (!x || !packed_w || !out) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (tokens < 0 || in_features != kD || out_features < kF32BlockRows || out_features % kF32BlockRows != 0) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed_w) | reinterpret_cast<uintptr_t>(out) |
          reinterpret_cast<uintptr_t>(bias)) & 15)
-        return MSDA_ERR_MISALIGNED;
+        return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     if (tokens == 0) return MSDA_OK;
     const int gx = (tokens + kTokWg - 1) / kTokWg, nb = out_features / kF32BlockRows;
     int gy = 1;          // (one workgroup per CU: 1 wave per SIMD at its register count; 233 workgroups at the training shape)

@@ -37,6 +37,22 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+}  // namespace
+
+// Error note of the library's other translation units (conv / ffn / lin256 / cls / attn / rows): "<entry point>: <class of error>", so
+// that msda_last_error() after a failed call names the call and is never a stale message of an earlier one.  Not part of the C ABI.
+extern "C" __attribute__((visibility("hidden"))) int msda_note_error(int code, const char *entry)
+{
+    const char *what = code == MSDA_ERR_NULL_POINTER ? "null pointer argument"
+                     : code == MSDA_ERR_BAD_DIMS     ? "dimension out of the supported range (see include/richsem_msda.h)"
+                     : code == MSDA_ERR_MISALIGNED   ? "pointer not aligned as required"
+                     : code == MSDA_ERR_TOO_LARGE    ? "problem too large for 32-bit indexing"
+                                                     : "error";
+    return fail(code, "%s: %s", entry, what);
+}
+
+namespace {
+
 int hip_fail(hipError_t e, const char *what)
 {
     snprintf(g_err, sizeof(g_err), "%s: %s (hipError %d)", what, hipGetErrorString(e), (int)e);

@@ -1,6 +1,6 @@
 // rows_api.hip -- C ABI of the rows around the operator that SURVEY.md section 8 marks "next" (declared in
 // include/richsem_msda.h): the matcher's cost blocks (section 8f rank 4), the attention-pool core (rank 3).  A translation unit of its own so that the operator's
-// kernels (msda_api.hip) are not rebuilt with it.  Error reporting: return codes only (msda_last_error covers msda_api.hip's calls).
+// kernels (msda_api.hip) are not rebuilt with it.  Error reporting: return codes + msda_note_error() (msda_api.hip), so msda_last_error() names the failed call.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 
@@ -8,6 +8,8 @@
 #include <cstdint>
 
 #include "../../include/richsem_msda.h"
+
+extern "C" int msda_note_error(int code, const char *entry);      // msda_api.hip: sets msda_last_error()
 #include "msda_attnpool.h"
 #include "msda_matcher.h"
 
@@ -18,12 +20,12 @@ int matcher_cost_impl(const T *logits, const T *boxes, const int64_t *tgt_ids, c
                       int Q, int C, int64_t n_targets, double w_class, double w_bbox, double w_giou, double alpha, T *cost,
                       msda_stream_t stream)
 {
-    if (!logits || !boxes || !tgt_offsets || !cost) return MSDA_ERR_NULL_POINTER;
-    if (B < 1 || Q < 0 || C < 1 || n_targets < 0) return MSDA_ERR_BAD_DIMS;
-    if (n_targets > 0 && (!tgt_ids || !tgt_boxes)) return MSDA_ERR_NULL_POINTER;
+    if (!logits || !boxes || !tgt_offsets || !cost) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (B < 1 || Q < 0 || C < 1 || n_targets < 0) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    if (n_targets > 0 && (!tgt_ids || !tgt_boxes)) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     const int64_t total = (int64_t)Q * n_targets;
     if (total == 0) return MSDA_OK;
-    if (total >= ((int64_t)1 << 40)) return MSDA_ERR_TOO_LARGE;
+    if (total >= ((int64_t)1 << 40)) return msda_note_error(MSDA_ERR_TOO_LARGE, __func__);
     const int grid = (int)std::min<int64_t>((total + 255) / 256, 16384);
     hipLaunchKernelGGL(msda::matcher_cost_kernel<T>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), logits, boxes, tgt_ids,
                        tgt_boxes, tgt_offsets, B, Q, C, (T)w_class, (T)w_bbox, (T)w_giou, (T)alpha, cost);
@@ -35,10 +37,10 @@ template <typename T>
 int attnpool_core_impl(const T *u, const T *feat, const T *pos, const T *spos, int K, int H, int C, int Tn, int head_major, T *z,
                        msda_stream_t stream)
 {
-    if (!u || !feat || !pos || !spos || !z) return MSDA_ERR_NULL_POINTER;
-    if (K < 0 || H < 1 || C < 1 || Tn < 1 || Tn > msda::kAttnPoolMaxT) return MSDA_ERR_BAD_DIMS;
+    if (!u || !feat || !pos || !spos || !z) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (K < 0 || H < 1 || C < 1 || Tn < 1 || Tn > msda::kAttnPoolMaxT) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     if (K == 0) return MSDA_OK;
-    if ((int64_t)K * H >= ((int64_t)1 << 31) || (int64_t)K * C * Tn >= ((int64_t)1 << 40)) return MSDA_ERR_TOO_LARGE;
+    if ((int64_t)K * H >= ((int64_t)1 << 31) || (int64_t)K * C * Tn >= ((int64_t)1 << 40)) return msda_note_error(MSDA_ERR_TOO_LARGE, __func__);
     const int waves = msda::kAttnPoolThreads / msda::kWave;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (H % 4 == 0) {
@@ -104,8 +106,8 @@ extern "C" {
 /* y = sigmoid(delta + inverse_sigmoid(ref)): delta (n) bf16 or f32, ref (n) f32, y (n) f32 */
 int msda_box_refine_forward(const void *delta, int delta_is_bf16, const float *ref, float eps, int64_t n, float *y, msda_stream_t stream)
 {
-    if (!delta || !ref || !y) return MSDA_ERR_NULL_POINTER;
-    if (n < 1) return MSDA_ERR_BAD_DIMS;
+    if (!delta || !ref || !y) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (n < 1) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     if (delta_is_bf16)
         hipLaunchKernelGGL(box_refine_kernel<true>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), delta, ref, eps, (long long)n, y);
@@ -118,8 +120,8 @@ int msda_box_refine_forward(const void *delta, int delta_is_bf16, const float *r
 /* grad_delta = grad_y * y * (1 - y), written in delta's type */
 int msda_box_refine_backward(const float *grad_y, const float *y, int64_t n, void *grad_delta, int delta_is_bf16, msda_stream_t stream)
 {
-    if (!grad_y || !y || !grad_delta) return MSDA_ERR_NULL_POINTER;
-    if (n < 1) return MSDA_ERR_BAD_DIMS;
+    if (!grad_y || !y || !grad_delta) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (n < 1) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     if (delta_is_bf16)
         hipLaunchKernelGGL(box_refine_grad_kernel<true>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), grad_y, y, (long long)n, grad_delta);
@@ -133,9 +135,9 @@ int msda_box_refine_backward(const float *grad_y, const float *y, int64_t n, voi
  * dims * pe_dim) bf16 */
 int msda_sine_embed_bf16(const float *boxes, int ld, int tokens, int dims, int pe_dim, float temperature, uint16_t *out, msda_stream_t stream)
 {
-    if (!boxes || !out) return MSDA_ERR_NULL_POINTER;
-    if (tokens < 1 || (dims != 2 && dims != 4) || ld < dims || pe_dim < 2 || (pe_dim & 1) || !(temperature > 0.f)) return MSDA_ERR_BAD_DIMS;
-    if (reinterpret_cast<uintptr_t>(out) & 3) return MSDA_ERR_MISALIGNED;
+    if (!boxes || !out) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (tokens < 1 || (dims != 2 && dims != 4) || ld < dims || pe_dim < 2 || (pe_dim & 1) || !(temperature > 0.f)) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    if (reinterpret_cast<uintptr_t>(out) & 3) return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     const long long n = (long long)tokens * dims * (pe_dim / 2);
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(sine_embed_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), boxes, ld, tokens, dims, pe_dim,

@@ -106,3 +106,18 @@ def test_im2col_step_contract_matches_reference(lib):
     for N, step in [(6, 4), (5, 2), (7, 3), (64 * 3 + 1, 64)]:
         assert _call_forward(lib, (N, 30, 2, 4, 2, 5, 2), shapes, lsi, im2col_step=step) == -3
         assert f"batch({N}) must divide im2col_step({min(N, step)})" in _lib.last_error()
+
+
+def test_error_notes_of_the_other_translation_units_name_the_call():
+    """A failed argument check in the conv / lin256 / ffn / cls / attn / rows entry points leaves "<entry point>: <class of error>" in
+    msda_last_error() (no GPU needed: the checks come before any launch)."""
+    from richsem_amd import _lib
+    L = _lib.load()
+    n = ctypes.c_int64(0)
+    rc = L.msda_conv_wgrad_workspace_bytes(1, 8, 8, 100, 128, 1, 1, 1, 0, ctypes.byref(n))        # C_in not a multiple of 128
+    assert rc != 0
+    with pytest.raises(RuntimeError, match="msda_conv_wgrad_workspace_bytes.*dimension"):
+        _lib.check(rc)
+    rc = L.msda_sine_embed_bf16(None, 4, 1, 4, 128, 10000.0, None, None)
+    with pytest.raises(RuntimeError, match="msda_sine_embed_bf16.*null pointer"):
+        _lib.check(rc)

@@ -274,3 +274,30 @@ def test_refine_boxes_kernel_matches_the_op_sequence(dt):
     assert y.dtype == torch.float32 and (y - y2).abs().max() < 2e-6
     tol = 2e-6 if dt == torch.float32 else 2 ** -8
     assert (delta.grad.float() - d2.grad.float()).abs().max() <= tol * max(1.0, float(d2.grad.float().abs().max()))
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_bf16_layers_on_small_inputs_and_with_dropout(dropout):
+    """bf16 activations with fp32 parameters below the fused kernels' token thresholds (DEFAULT thresholds) and with dropout active in
+    train mode: the op-by-op paths must cast the parameters (they used to raise a dtype mismatch)"""
+    from richsem_amd.modules import DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, get_reference_points
+    torch.manual_seed(0)
+    shapes_l = [(12, 16), (6, 8), (3, 4), (2, 2)]
+    shapes = torch.tensor(shapes_l, dtype=torch.int64, device="cuda")
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S, N = int(shapes.prod(1).sum()), 2
+    enc = DeformableTransformerEncoderLayer(256, 512, dropout=dropout, n_levels=4, n_heads=8, n_points=4).cuda().train()
+    dec = DeformableTransformerDecoderLayer(256, 512, dropout=dropout, n_levels=4, n_heads=8, n_points=4).cuda().train()
+    src = torch.randn(N, S, 256, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    pos = torch.randn(N, S, 256, device="cuda").to(torch.bfloat16)
+    vr = torch.ones(N, 4, 2, device="cuda")
+    mem = enc(src, pos, get_reference_points(shapes_l, vr, "cuda"), shapes, lsi, None)
+    assert mem.dtype == torch.bfloat16 and torch.isfinite(mem.float()).all()
+    nq = 20
+    tgt = torch.randn(nq, N, 256, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    out = dec(tgt=tgt, tgt_query_pos=torch.randn(nq, N, 256, device="cuda").to(torch.bfloat16),
+              tgt_reference_points=torch.rand(nq, N, 4, 4, device="cuda") * 0.5 + 0.2, memory=mem.transpose(0, 1),
+              memory_level_start_index=lsi, memory_spatial_shapes=shapes)
+    assert out.dtype == torch.bfloat16 and torch.isfinite(out.float()).all()
+    out.float().square().mean().backward()
+    assert src.grad is not None and tgt.grad is not None and torch.isfinite(src.grad.float()).all()
