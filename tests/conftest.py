@@ -35,3 +35,16 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _library_options_from_env():
+    """RICHSEM_MSDA_OPTS="key=value,key=value": tuning options applied before every test (a whole-suite run of a non-default kernel shape,
+    e.g. rps_lanes_per_point=2); the tests' own set_option calls still win where they set the same key"""
+    opts = os.environ.get("RICHSEM_MSDA_OPTS", "")
+    if opts:
+        from richsem_amd import _lib
+        for kv in opts.split(","):
+            k, v = kv.split("=")
+            _lib.set_option(k.strip(), int(v))
+    yield
