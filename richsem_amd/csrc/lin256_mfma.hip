@@ -292,7 +292,11 @@ int launch_lin(const uint16_t *x, const uint16_t *packed, const float *bias, con
                hipStream_t st, long long chunk_elems = 0)
 {
     const int gx = (T + kTokWg - 1) / kTokWg, nb = N / kBlockRows;
-    int gy = (512 + gx - 1) / gx;          // about two workgroups per CU
+    // the output-channel blocks are split over gy workgroup rows so that the grid is ONE resident wave of workgroups (two per CU on 256
+    // CUs): rounding up instead (3 rows for the encoder's 233 token blocks) made a second, mostly empty wave, dealt 4 blocks of a 256-wide
+    // output as 1 + 1 + 2 and read x a third time -- 22.3 -> 18.5 us at 44646 x 256 -> 256, 63 -> 54.5 us at -> 1536, 81 -> 75 us at -> 2048
+    int gy = 512 / gx;
+    if (gy < 1) gy = 1;
     if (gy > nb) gy = nb;
     if (gy > 8) gy = 8;
     hipLaunchKernelGGL(lin256_kernel<EPI>, dim3(gx, gy), dim3(kWaves * 64), 0, st, x, packed, bias, mask, T, N, out, chunk_elems);
