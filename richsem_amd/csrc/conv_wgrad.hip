@@ -262,12 +262,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
     }
 }
 
-// pixel chunks for a problem: enough for about two workgroups per CU (512) together with the (tap, channel block) grid, of at least
+// pixel chunks for a problem: at most two workgroups per CU (512: one resident wave) together with the (tap, channel block) grid, of at least
 // 512 pixels each (measured: 256 and 1024 workgroups are both slower on the linear layers' shapes; a grid of 144 blocks still gains from 4 chunks)
 void wgrad_split(const WgradGeom &g, long long &split, long long &chunk)
 {
     const long long blocks_y = (long long)g.KH * g.KW * (g.Cout / kBM) * (g.Cin / kBN);
-    split = (512 + blocks_y - 1) / blocks_y;
+    split = 512 / blocks_y;      // rounded DOWN (measured: the ResNet shape set 432-437 -> 410 us, layer3's 3 x 3 43 -> 34.5 us): 512 workgroups are resident (two per CU); 540 would run as a full wave + a wave of 28
     // (few pixels -- the decoder's ~2 k tokens: chunks of 128, or 20 workgroups would each walk 512 pixels one stage after the other)
     const long long min_chunk = g.P >= 16384 ? 512 : 128;
     const long long max_split = (g.P + min_chunk - 1) / min_chunk;
