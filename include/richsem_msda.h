@@ -308,6 +308,16 @@ int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, con
                            const uint16_t *residual, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
                            uint16_t *out, msda_stream_t stream);
 
+/* The same with a k split for problems that leave most of the chip idle (few output pixels, long k: ResNet-50's layer4 3 x 3 at batch 2,
+ * the stride-2 projection of C5): msda_conv_forward_workspace_bytes reports how many bytes of ZEROED device memory (an fp32 image of the
+ * output) the split needs -- 0 where the problem is not split --, msda_conv_forward_ws_bf16 takes them (or NULL: no split): the k
+ * slices add their raw sums there and a second kernel applies the epilogue.  Results differ from the unsplit call by fp32 summation
+ * order only. */
+int msda_conv_forward_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t *bytes);
+int msda_conv_forward_ws_bf16(const uint16_t *x, const uint16_t *packed_weight, const float *scale, const float *shift,
+                              const uint16_t *residual, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
+                              uint16_t *out, void *workspace, msda_stream_t stream);
+
 /* GroupNorm with 8 channels per group on NHWC bf16 (nn.GroupNorm(32, 256) of the input projections, models/richsem/richsem.py:301,
  * :307): x (N, HW, C) bf16 with C = 8 * groups; gamma, beta (C) f32; stats: N * (C / 8) * 2 doubles of device scratch; out_f32 and / or
  * out_bf16 (N, HW, C), either may be NULL.  Sums of x and x^2 in fp32 per thread, combined in fp64.  Forward only. */
@@ -332,6 +342,11 @@ int msda_pool_nhwc_bf16(const uint16_t *x, int N, int H, int W, int C, int k, in
  * Cout % 32 == 0, Cin % 16 == 0, pad <= KH - 1. */
 int msda_conv_dgrad_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW,
                          int stride, int pad, int H, int W, uint16_t *dx, msda_stream_t stream);
+
+/* ... and its k-split form (see msda_conv_forward_ws_bf16; k = KH KW C_out here, the image is dx's) */
+int msda_conv_dgrad_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride, int pad, int H, int W, int64_t *bytes);
+int msda_conv_dgrad_ws_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW,
+                            int stride, int pad, int H, int W, uint16_t *dx, void *workspace, msda_stream_t stream);
 
 /* Gradient of msda_conv_forward_bf16 w.r.t. its weight (csrc/conv_wgrad.hip): dw[co][kh][kw][ci] = sum over output pixels of
  * dz[n, ho, wo, co] * x[n, ho stride + kh - pad, wo stride + kw - pad, ci].  dz (N, Ho, Wo, Cout) bf16 = gradient at the CONVOLUTION's

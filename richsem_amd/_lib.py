@@ -32,7 +32,7 @@ SYMBOLS = [
     "msda_attn_workspace_bytes", "msda_attn_forward_bf16", "msda_attn_backward_bf16",
     "msda_matcher_cost_f32", "msda_matcher_cost_f64", "msda_attnpool_core_f32", "msda_attnpool_core_f64",
     "msda_cls_packed_elems", "msda_cls_pack", "msda_cls_max_scores",
-    "msda_conv_set_tiling", "msda_conv_packed_elems", "msda_conv_pack_weight", "msda_conv_forward_bf16", "msda_conv_dgrad_bf16", "msda_pool_nhwc_bf16", "msda_groupnorm8_nhwc_bf16", "msda_groupnorm8_backward_nhwc_bf16", "msda_conv_wgrad_workspace_bytes", "msda_conv_wgrad_bf16",
+    "msda_conv_set_tiling", "msda_conv_packed_elems", "msda_conv_pack_weight", "msda_conv_forward_bf16", "msda_conv_dgrad_bf16", "msda_conv_forward_workspace_bytes", "msda_conv_forward_ws_bf16", "msda_conv_dgrad_workspace_bytes", "msda_conv_dgrad_ws_bf16", "msda_pool_nhwc_bf16", "msda_groupnorm8_nhwc_bf16", "msda_groupnorm8_backward_nhwc_bf16", "msda_conv_wgrad_workspace_bytes", "msda_conv_wgrad_bf16",
 ]
 
 
@@ -119,6 +119,14 @@ def load():
     L.msda_conv_forward_bf16.restype = ci
     L.msda_conv_dgrad_bf16.argtypes = [vp, vp] + [ci] * 11 + [vp, vp]
     L.msda_conv_dgrad_bf16.restype = ci
+    L.msda_conv_forward_workspace_bytes.argtypes = [ci] * 9 + [vp]
+    L.msda_conv_forward_workspace_bytes.restype = ci
+    L.msda_conv_forward_ws_bf16.argtypes = [vp] * 5 + [ci] * 10 + [vp, vp, vp]
+    L.msda_conv_forward_ws_bf16.restype = ci
+    L.msda_conv_dgrad_workspace_bytes.argtypes = [ci] * 11 + [vp]
+    L.msda_conv_dgrad_workspace_bytes.restype = ci
+    L.msda_conv_dgrad_ws_bf16.argtypes = [vp, vp] + [ci] * 11 + [vp, vp, vp]
+    L.msda_conv_dgrad_ws_bf16.restype = ci
     L.msda_pool_nhwc_bf16.argtypes = [vp] + [ci] * 8 + [vp, vp]
     L.msda_pool_nhwc_bf16.restype = ci
     L.msda_groupnorm8_nhwc_bf16.argtypes = [vp, vp, vp, ctypes.c_float, ci, ci, ci, vp, vp, vp, vp]

@@ -30,6 +30,13 @@ def to_nchw(x_nhwc, dtype=torch.float32):
     return x_nhwc.permute(0, 3, 1, 2).to(dtype).contiguous()
 
 
+def _ksplit_workspace(fn, dims, device):
+    """zeroed fp32 workspace for a k-split convolution call, or None where the library does not split the problem"""
+    nb = ctypes.c_int64(0)
+    _lib.check(fn(*dims, ctypes.byref(nb)))
+    return torch.zeros(nb.value // 4, dtype=torch.float32, device=device) if nb.value else None
+
+
 class ConvAffine:
     """One convolution + affine (+ residual) (+ ReLU).  ``weight`` (C_out, C_in, KH, KW) as nn.Conv2d stores it; ``scale`` / ``shift``
     (C_out) fp32 (``None``: identity / zero).  C_out must be a multiple of 16; C_in a multiple of 32, or KH KW C_in <= 512 (the
@@ -73,10 +80,13 @@ class ConvAffine:
             assert residual.shape == out.shape and residual.dtype == torch.bfloat16
             residual = residual.contiguous()
         with torch.cuda.device(x.device):
-            _lib.check(_lib.load().msda_conv_forward_bf16(
+            L = _lib.load()
+            ws = _ksplit_workspace(L.msda_conv_forward_workspace_bytes, (N, H, W, self.Cin, self.Cout, self.KH, self.KW, self.stride, self.pad),
+                                   x.device)
+            _lib.check(L.msda_conv_forward_ws_bf16(
                 x.data_ptr(), self.packed.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
                 residual.data_ptr() if residual is not None else None, N, H, W, self.Cin, self.Cout, self.KH, self.KW, self.stride,
-                self.pad, int(self.relu), out.data_ptr(), _stream(x.device)))
+                self.pad, int(self.relu), out.data_ptr(), ws.data_ptr() if ws is not None else None, _stream(x.device)))
         return out
 
 
@@ -225,9 +235,12 @@ class ConvAffineFunction(torch.autograd.Function):
         res = residual.contiguous() if residual is not None else None
         packed = _packed_for(weight, scale, False, cache)
         with torch.cuda.device(x.device):
-            _lib.check(_lib.load().msda_conv_forward_bf16(
+            L = _lib.load()
+            ws = _ksplit_workspace(L.msda_conv_forward_workspace_bytes, (N, H, W, Cin, Cout, KH, KW, stride, padding), x.device)
+            _lib.check(L.msda_conv_forward_ws_bf16(
                 x.data_ptr(), packed.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr() if res is not None else None,
-                N, H, W, Cin, Cout, KH, KW, stride, padding, int(relu), out.data_ptr(), _stream(x.device)))
+                N, H, W, Cin, Cout, KH, KW, stride, padding, int(relu), out.data_ptr(), ws.data_ptr() if ws is not None else None,
+                _stream(x.device)))
         ctx.save_for_backward(x, weight, scale, out if relu else None)
         ctx.cfg = (stride, padding, relu, residual is not None, cache)
         return out
@@ -249,8 +262,11 @@ class ConvAffineFunction(torch.autograd.Function):
             packed_t = _packed_for(weight, scale, True, cache)
             dx = torch.empty_like(x)
             with torch.cuda.device(x.device):
-                _lib.check(_lib.load().msda_conv_dgrad_bf16(dz.data_ptr(), packed_t.data_ptr(), N, dz.shape[1], dz.shape[2], Cout, Cin, KH,
-                                                            KW, stride, padding, H, W, dx.data_ptr(), _stream(x.device)))
+                L = _lib.load()
+                ws = _ksplit_workspace(L.msda_conv_dgrad_workspace_bytes, (N, dz.shape[1], dz.shape[2], Cout, Cin, KH, KW, stride, padding, H, W),
+                                       x.device)
+                _lib.check(L.msda_conv_dgrad_ws_bf16(dz.data_ptr(), packed_t.data_ptr(), N, dz.shape[1], dz.shape[2], Cout, Cin, KH, KW, stride,
+                                                     padding, H, W, dx.data_ptr(), ws.data_ptr() if ws is not None else None, _stream(x.device)))
         if ctx.needs_input_grad[1]:
             # the weight gradient is taken with dz and scaled per output channel afterwards (the affine's scale commutes with the sum)
             if Cout % 128 == 0 and Cin % 128 == 0 and not ConvAffineFunction.library_wgrad:

@@ -94,16 +94,16 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, uint16_t *__restri
 
 // MODE 0: few-channel input (fragments gathered element by element through a table); 1: C_in % 32 == 0, one k-step per barrier;
 // 2: C_in % 64 == 0, two k-steps (one 32-byte load per lane and pixel) per barrier.
-template <int CO_TILES, int PT, int MODE>
+template <int CO_TILES, int PT, int MODE, bool KSPLIT = false>
 __global__ __launch_bounds__(kWaves * 64)
 void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wpk, const float *__restrict__ scale,
                      const float *__restrict__ shift, const uint16_t *__restrict__ residual, uint16_t *__restrict__ out, ConvGeom g,
-                     int relu)
+                     int relu, float *__restrict__ ksum)
 {
     constexpr bool SMALLC = MODE == 0;
     constexpr int KT = MODE == 2 ? 2 : 1;
     constexpr int G = CO_TILES >= 4 ? 4 : CO_TILES;          // == conv_group(C_out): the host only launches matching shapes
-    __shared__ __attribute__((aligned(16))) short wbuf[2][KT * CO_TILES * kFragShorts];
+    __shared__ __attribute__((aligned(16))) short wbuf[2][KT * CO_TILES * kFragShorts + (KSPLIT ? 64 : 0)];      // (+ 2 x 128 B: the k-slice epilogue's padded tile)
     __shared__ unsigned lut[SMALLC ? 512 : 1];     // k -> kh << 20 | kw << 12 | ci   (0xFFFFFFFF: padding)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -208,20 +208,23 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
         }
     };
 
+    // k split (few pixels, long k: layer4's 3 x 3, the stride-2 projection of C5): slice blockIdx.z of gridDim.z takes iterations
+    // [s0, s1) and ADDS its raw sums to the zeroed fp32 image `ksum`; conv_ksum_finish_kernel applies the epilogue
+    const int s0 = !KSPLIT ? 0 : (int)((long long)S * blockIdx.z / gridDim.z), s1 = !KSPLIT ? S : (int)((long long)S * (blockIdx.z + 1) / gridDim.z);
     bf16x8 bcur[KT][PT], bnext[KT][PT];
-    int kh = 0, kw = 0, cb = 0;
+    int cb = !KSPLIT ? 0 : s0 % cpb, kh = !KSPLIT ? 0 : (s0 / cpb) / g.KW, kw = !KSPLIT ? 0 : (s0 / cpb) % g.KW;
     if (SMALLC) __syncthreads();      // the table
-    gather(0, 0, 0, bnext);
-    fetch(0);
+    gather(kh, kw, cb, bnext);
+    fetch(s0);
     park(0);
     __syncthreads();
 
-    for (int s = 0; s < S; ++s) {
+    for (int s = s0; s < s1; ++s) {
 #pragma unroll
         for (int h = 0; h < KT; ++h)
 #pragma unroll
             for (int t3 = 0; t3 < PT; ++t3) bcur[h][t3] = bnext[h][t3];
-        if (s + 1 < S) {
+        if (s + 1 < s1) {
             if (++cb == cpb && !SMALLC) {
                 cb = 0;
                 if (++kw == g.KW) { kw = 0; ++kh; }
@@ -229,7 +232,7 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
             fetch(s + 1);
             gather(kh, kw, cb, bnext);
         }
-        const short *wt = wbuf[s & 1];
+        const short *wt = wbuf[(s - s0) & 1];
 #pragma unroll
         for (int h = 0; h < KT; ++h)
 #pragma unroll
@@ -238,8 +241,30 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
 #pragma unroll
                 for (int t3 = 0; t3 < PT; ++t3) acc[t3][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[h][t3], acc[t3][t], 0, 0, 0);
             }
-        if (s + 1 < S) park((s + 1) & 1);
+        if (s + 1 < s1) park((s + 1 - s0) & 1);
         __syncthreads();
+    }
+
+    if constexpr (KSPLIT) {      // a k slice (host: MODE 2, PT 1): raw sums to the fp32 image, as whole lines
+        // A lane holds 4 G consecutive channels of ONE pixel: adding them from there would be 64 single-float atomics on 64 different
+        // lines per instruction (measured: layer4's 3 x 3 55 -> 218 us).  The wave's 16 x (16 CO_TILES) tile goes through LDS (the weight
+        // buffers are free now) and comes back with the lanes along the channels: one instruction adds 256 contiguous bytes of a pixel.
+        constexpr int CH = 16 * CO_TILES, LD = CH + 1;
+        static_assert(PT == 1 && MODE == 2 && 2 * (KT * CO_TILES * kFragShorts + 64) * 2 >= kWaves * 16 * LD * 4, "k split: tile does not fit the weight buffers");
+        float *tile = reinterpret_cast<float *>(&wbuf[0][0]) + wave * (16 * LD);
+#pragma unroll
+        for (int grp = 0; grp < CO_TILES / G; ++grp)
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tile[c * LD + 16 * G * grp + 4 * G * q + 4 * u + i] = acc[0][grp * G + u][i];
+        __syncthreads();
+        for (int px = 0; px < 16; ++px) {
+            const long long p = pix0 + px;
+            if (p >= P) break;      // (uniform per wave)
+            for (int ch = lane; ch < CH; ch += 64) atomicAdd(ksum + p * g.Cout + co0 + ch, tile[px * LD + ch]);
+        }
+        return;
     }
 
     // epilogue: lane (c, q) holds, for every group of G tiles, the 4 G consecutive channels co0 + 16 G grp + 4 G q + (4 u + i) of pixel c
@@ -486,6 +511,36 @@ __global__ __launch_bounds__(256) void gn8_bwd_apply_kernel(const uint16_t *__re
     }
 }
 
+// epilogue of a k-split convolution: out = act(scale * ksum + shift (+ residual)), 8 channels per thread
+__global__ __launch_bounds__(256) void conv_ksum_finish_kernel(const float *__restrict__ ksum, const float *__restrict__ scale,
+                                                               const float *__restrict__ shift, const uint16_t *__restrict__ residual,
+                                                               uint16_t *__restrict__ out, long long P, int Cout, int relu)
+{
+    const int cv = Cout / 8;
+    const long long n = P * cv;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+        const int co = 8 * (int)(i % cv);
+        const long long at = (i / cv) * Cout + co;
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(ksum + at), a1 = *reinterpret_cast<const f32x4 *>(ksum + at + 4);
+        float y[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = fmaf(y[e], scale ? scale[co + e] : 1.f, shift ? shift[co + e] : 0.f);
+        if (residual) {
+            const u32x4 r = *reinterpret_cast<const u32x4 *>(residual + at);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[2 * e] += bf16_lo(r[e]);
+                y[2 * e + 1] += bf16_hi(r[e]);
+            }
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = fmaxf(y[e], 0.f);
+        }
+        *reinterpret_cast<u32x4 *>(out + at) = (u32x4){pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7])};
+    }
+}
+
 struct ConvArgs {
     const uint16_t *x, *wpk;
     const float *scale, *shift;
@@ -494,15 +549,29 @@ struct ConvArgs {
     ConvGeom g;
     int relu;
     hipStream_t stream;
+    float *ksum = nullptr;      // zeroed (P, C_out) fp32 image for a k split, or nullptr
+    int nz = 1;                 // k slices
 };
 
 template <int CO_TILES, int PT, int MODE>
 int launch_conv(const ConvArgs &a)
 {
     const long long P = (long long)a.g.N * a.g.Ho * a.g.Wo;
-    const dim3 grid((unsigned)((P + kWaves * 16 * PT - 1) / (kWaves * 16 * PT)), (unsigned)(a.g.Cout / (16 * CO_TILES)));
-    hipLaunchKernelGGL((conv_fwd_kernel<CO_TILES, PT, MODE>), grid, dim3(kWaves * 64), 0, a.stream, a.x, a.wpk, a.scale, a.shift,
-                       a.residual, a.out, a.g, a.relu);
+    const bool split = a.ksum != nullptr && a.nz > 1 && MODE == 2 && PT == 1;
+    const dim3 grid((unsigned)((P + kWaves * 16 * PT - 1) / (kWaves * 16 * PT)), (unsigned)(a.g.Cout / (16 * CO_TILES)), split ? a.nz : 1);
+    if constexpr (MODE == 2 && PT == 1) {
+        if (split)
+            hipLaunchKernelGGL((conv_fwd_kernel<CO_TILES, PT, MODE, true>), grid, dim3(kWaves * 64), 0, a.stream, a.x, a.wpk, a.scale, a.shift,
+                               a.residual, a.out, a.g, a.relu, a.ksum);
+    }
+    if (!split)
+        hipLaunchKernelGGL((conv_fwd_kernel<CO_TILES, PT, MODE>), grid, dim3(kWaves * 64), 0, a.stream, a.x, a.wpk, a.scale, a.shift,
+                           a.residual, a.out, a.g, a.relu, nullptr);
+    if (split) {
+        const long long n = P * (a.g.Cout / 8);
+        hipLaunchKernelGGL(conv_ksum_finish_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, a.stream,
+                           a.ksum, a.scale, a.shift, a.residual, a.out, P, a.g.Cout, a.relu);
+    }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
 }
@@ -546,6 +615,20 @@ void choose_tiling(long long P, int Cout, int K, int &ct, int &pt)
     pt = (K >= 288 && n_wg(ct, 1) > 2048) ? 3 : 1;
 }
 
+// k slices for a problem at the chosen tiling: only where the (pixel, channel) grid leaves most of the chip idle and the k loop is
+// long -- about three workgroups per CU in all, at least 8 iterations per slice (0 / 1: no split)
+int choose_ksplit(long long P, int Cout, int Cin, int KH, int KW, int ct, int pt)
+{
+    if (Cin % 64 != 0 || pt != 1) return 1;      // (the kernel's k-slice epilogue: two k-steps per barrier, one pixel tile per wave)
+    const long long wgs = ((P + 64 * pt - 1) / (64 * pt)) * (Cout / (16 * ct));
+    const int S = KH * KW * (Cin / 64);
+    if (wgs > 64 || S < 64) return 1;      // (measured: with 264 or 528 workgroups -- layer4's / layer3's shapes -- the split only adds its zero-fill, atomics and second launch)
+    long long nz = (768 + wgs / 2) / wgs;
+    if (nz > S / 8) nz = S / 8;
+    if (nz > 16) nz = 16;
+    return nz < 2 ? 1 : (int)nz;
+}
+
 }  // namespace
 
 extern "C" {
@@ -583,9 +666,35 @@ int msda_conv_pack_weight(const float *weight, int Cout, int Cin, int KH, int KW
     return e == hipSuccess ? MSDA_OK : (int)e;
 }
 
+/* bytes of zeroed fp32 workspace with which msda_conv_forward_ws_bf16 splits the k loop of this problem (0: it does not) */
+int msda_conv_forward_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t *bytes)
+{
+    if (!bytes) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    int64_t n = 0;
+    const int rc = msda_conv_packed_elems(Cout, Cin, KH, KW, &n);
+    if (rc != MSDA_OK) return rc;
+    if (N < 1 || H < 1 || W < 1 || stride < 1 || pad < 0) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    if (Ho < 1 || Wo < 1) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    int ct, pt;
+    choose_tiling((long long)N * Ho * Wo, Cout, KH * KW * Cin, ct, pt);
+    *bytes = choose_ksplit((long long)N * Ho * Wo, Cout, Cin, KH, KW, ct, pt) > 1 ? (int64_t)N * Ho * Wo * Cout * (int64_t)sizeof(float) : 0;
+    return MSDA_OK;
+}
+
 int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, const float *scale, const float *shift,
                            const uint16_t *residual, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
                            uint16_t *out, msda_stream_t stream)
+{
+    return msda_conv_forward_ws_bf16(x, packed_weight, scale, shift, residual, N, H, W, Cin, Cout, KH, KW, stride, pad, relu, out, nullptr,
+                                     stream);
+}
+
+/* msda_conv_forward_bf16 with an optional workspace: `workspace` = msda_conv_forward_workspace_bytes() bytes of ZEROED device memory
+ * (the k loop is then split over several workgroups that add their sums there, and a second kernel applies the epilogue), or NULL */
+int msda_conv_forward_ws_bf16(const uint16_t *x, const uint16_t *packed_weight, const float *scale, const float *shift,
+                              const uint16_t *residual, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
+                              uint16_t *out, void *workspace, msda_stream_t stream)
 {
     if (!x || !packed_weight || !scale || !shift || !out) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     int64_t n = 0;
@@ -604,8 +713,13 @@ int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, con
     const int fct = g_force_ct.load(), fpt = g_force_pt.load();
     if (fct && (Cout / 16) % fct == 0 && fct % conv_group(Cout) == 0) ct = fct;
     if (fpt) pt = fpt;
-    const ConvArgs a{x, packed_weight, scale, shift, residual, out, ConvGeom{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, 1}, relu,
-                     static_cast<hipStream_t>(stream)};
+    ConvArgs a{x, packed_weight, scale, shift, residual, out, ConvGeom{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, 1}, relu,
+               static_cast<hipStream_t>(stream)};
+    if (workspace && !fct && !fpt) {
+        if (reinterpret_cast<uintptr_t>(workspace) & 15) return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
+        a.nz = choose_ksplit((long long)N * Ho * Wo, Cout, Cin, KH, KW, ct, pt);
+        a.ksum = a.nz > 1 ? static_cast<float *>(workspace) : nullptr;
+    }
     if (small_c) return launch_ct<0>(a, ct, pt);
     return Cin % 64 == 0 ? launch_ct<2>(a, ct, pt) : launch_ct<1>(a, ct, pt);
 }
@@ -688,6 +802,26 @@ int msda_pool_nhwc_bf16(const uint16_t *x, int N, int H, int W, int C, int k, in
 int msda_conv_dgrad_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW,
                          int stride, int pad, int H, int W, uint16_t *dx, msda_stream_t stream)
 {
+    return msda_conv_dgrad_ws_bf16(dy, packed_weight_t, N, Ho, Wo, Cout, Cin, KH, KW, stride, pad, H, W, dx, nullptr, stream);
+}
+
+/* bytes of zeroed fp32 workspace with which msda_conv_dgrad_ws_bf16 splits the k loop (k = KH KW C_out here) of this problem (0: none) */
+int msda_conv_dgrad_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride, int pad, int H, int W, int64_t *bytes)
+{
+    if (!bytes) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (N < 1 || Ho < 1 || Wo < 1 || H < 1 || W < 1 || Cout < 32 || Cout % 32 != 0 || Cin < 16 || Cin % 16 != 0 || KH < 1 || KW < 1 ||
+        KH > 16 || KW > 16 || stride < 1 || pad < 0)
+        return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    int ct, pt;
+    choose_tiling((long long)N * H * W, Cin, KH * KW * Cout, ct, pt);
+    *bytes = choose_ksplit((long long)N * H * W, Cin, Cout, KH, KW, ct, pt) > 1 ? (int64_t)N * H * W * Cin * (int64_t)sizeof(float) : 0;
+    return MSDA_OK;
+}
+
+/* msda_conv_dgrad_bf16 with an optional ZEROED workspace of msda_conv_dgrad_workspace_bytes() bytes (k split), or NULL */
+int msda_conv_dgrad_ws_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW,
+                            int stride, int pad, int H, int W, uint16_t *dx, void *workspace, msda_stream_t stream)
+{
     if (!dy || !packed_weight_t || !dx) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     if (N < 1 || Ho < 1 || Wo < 1 || H < 1 || W < 1 || Cout < 32 || Cout % 32 != 0 || Cin < 16 || Cin % 16 != 0 || KH < 1 || KW < 1 ||
         KH > 16 || KW > 16 || stride < 1 || pad < 0 || pad > KH - 1 || pad > KW - 1)
@@ -701,8 +835,13 @@ int msda_conv_dgrad_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, in
     if (KH - 1 - pad != KW - 1 - pad) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);      // one padding value in the kernel's geometry: square kernels
     int ct, pt;
     choose_tiling((long long)N * H * W, Cin, KH * KW * Cout, ct, pt);
-    const ConvArgs a{dy, packed_weight_t, nullptr, nullptr, nullptr, dx, ConvGeom{N, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, KH - 1 - pad, stride},
-                     0, static_cast<hipStream_t>(stream)};
+    ConvArgs a{dy, packed_weight_t, nullptr, nullptr, nullptr, dx, ConvGeom{N, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, KH - 1 - pad, stride},
+               0, static_cast<hipStream_t>(stream)};
+    if (workspace) {
+        if (reinterpret_cast<uintptr_t>(workspace) & 15) return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
+        a.nz = choose_ksplit((long long)N * H * W, Cin, Cout, KH, KW, ct, pt);
+        a.ksum = a.nz > 1 ? static_cast<float *>(workspace) : nullptr;
+    }
     return Cout % 64 == 0 ? launch_ct<2>(a, ct, pt) : launch_ct<1>(a, ct, pt);
 }
 

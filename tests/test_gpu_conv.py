@@ -29,6 +29,8 @@ CASES = [  # N, H, W, Cin, Cout, k, stride, pad
     (3, 1, 1, 64, 96, 1, 1, 0),          # C_out = 96: three blocks of 32
     (2, 5, 6, 32, 48, 3, 1, 1),          # C_out = 48: three blocks of 16
     (1, 50, 84, 1024, 256, 1, 1, 0),     # input_proj shape of C4 (richsem.py:295-303)
+    (2, 25, 42, 2048, 256, 3, 2, 1),     # the extra level's stride-2 projection of C5 (richsem.py:304-310): 36 workgroups, k = 18432 -> k split
+    (1, 13, 21, 512, 512, 3, 1, 1),      # layer4-like 3 x 3 on few pixels -> k split
 ]
 
 
@@ -104,7 +106,24 @@ GRAD_CASES = [  # N, H, W, Cin, Cout, k, stride, pad
     (3, 7, 9, 128, 256, 1, 1, 0),
     (1, 11, 13, 256, 512, 1, 2, 0),
     (2, 30, 41, 128, 128, 3, 1, 1),      # 2460 pixels: several pixel chunks per tap (split-K atomics)
+    (1, 13, 21, 512, 512, 3, 1, 1),      # few pixels, long k: forward AND input gradient take the k-split form
 ]
+
+
+def test_k_split_is_taken_where_expected():
+    """the two shapes above that are meant to exercise the k-split path do (msda_conv_*_workspace_bytes > 0), a well-filled one does not"""
+    import ctypes
+    from richsem_amd import _lib
+    L = _lib.load()
+    nb = ctypes.c_int64(0)
+    _lib.check(L.msda_conv_forward_workspace_bytes(2, 25, 42, 2048, 256, 3, 3, 2, 1, ctypes.byref(nb)))
+    assert nb.value == 2 * 13 * 21 * 256 * 4
+    _lib.check(L.msda_conv_forward_workspace_bytes(1, 13, 21, 512, 512, 3, 3, 1, 1, ctypes.byref(nb)))
+    assert nb.value == 13 * 21 * 512 * 4
+    _lib.check(L.msda_conv_dgrad_workspace_bytes(1, 13, 21, 512, 512, 3, 3, 1, 1, 13, 21, ctypes.byref(nb)))
+    assert nb.value == 13 * 21 * 512 * 4
+    _lib.check(L.msda_conv_forward_workspace_bytes(2, 100, 168, 128, 512, 1, 1, 1, 0, ctypes.byref(nb)))
+    assert nb.value == 0
 
 
 @pytest.mark.parametrize("case", GRAD_CASES, ids=[str(c) for c in GRAD_CASES])
