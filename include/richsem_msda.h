@@ -270,6 +270,12 @@ int msda_topk_f32(const float *scores, int rows, int n, int k, int64_t *indices,
  * ~15 element-wise ops per decoder layer): boxes (tokens, >= dims) f32 (x, y[, w, h]) with a row stride of ld floats; out (tokens,
  * dims * pe_dim) bf16 in the reference's order (y, x[, w, h]), channel 2k = sin, 2k + 1 = cos of coordinate * 2 pi /
  * temperature^(2k / pe_dim).  dims = 2 | 4, pe_dim even.  No gradient (the boxes it is applied to are detached, :779-804). */
+/* Backward of a 256 -> n linear layer with n <= 8 (the last layer of the box heads, MLP(256, 256, 4, 3): models/richsem/utils.py:110-122,
+ * deformable_transformer.py:779-804): dy (T, n) bf16 contiguous, x (T, 256) bf16, w (n, 256) f32 -> dx (T, 256) bf16 (or NULL), dw (n, 256)
+ * f32, db (n) f32 (or NULL): two streaming kernels instead of three GEMMs with a 4-wide operand. */
+int msda_narrow_linear_backward_bf16(const uint16_t *dy, const uint16_t *x, const float *w, int T, int n, uint16_t *dx, float *dw, float *db,
+                                     msda_stream_t stream);
+
 /* The decoder's box update, y = sigmoid(delta + inverse_sigmoid(ref)) (models/richsem/deformable_transformer.py:779-804,
  * richsem.py:705-715; inverse_sigmoid of util/misc.py:605-609 with its eps) as one launch, and its gradient w.r.t. delta
  * (grad_y * y * (1 - y)) as one more: delta / grad_delta (n) bf16 or f32, ref, y, grad_y (n) f32.  ref is taken as a constant (the

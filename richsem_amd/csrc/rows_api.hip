@@ -99,9 +99,77 @@ __global__ __launch_bounds__(256) void box_refine_grad_kernel(const float *__res
     }
 }
 
+// Backward of a 256 -> n linear layer with n <= 8 (the box heads' last layer, 256 -> 4): the input gradient is an n-term sum per channel,
+// the weight gradient n x 256 token sums -- streams of x / dx, not GEMMs (the library's GEMM takes 150 us for the 44646-token one, padded to 64).
+__global__ __launch_bounds__(256) void narrow_linear_dx_kernel(const uint16_t *__restrict__ dy, const float *__restrict__ w, int T, int n,
+                                                               uint16_t *__restrict__ dx)
+{
+    __shared__ float ws[8 * 256];
+    for (int i = threadIdx.x; i < n * 256; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const long long total = (long long)T * 32;      // a thread: one token, 8 channels
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+        const long long t = i >> 5;
+        const int c0 = 8 * (int)(i & 31);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < n; ++j) {
+            const float d = __uint_as_float((unsigned)dy[t * n + j] << 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(d, ws[j * 256 + c0 + e], acc[e]);
+        }
+        unsigned o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(acc[2 * e])) | (unsigned)__bfloat16_as_ushort(__float2bfloat16(acc[2 * e + 1])) << 16;
+        *reinterpret_cast<uint4 *>(dx + t * 256 + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dw[j][c] += sum over the workgroup's tokens of dy[t][j] x[t][c] (thread = channel c), db[j] likewise (threads j < n)
+__global__ __launch_bounds__(256) void narrow_linear_dw_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x, int T, int n,
+                                                               int chunk, float *__restrict__ dw, float *__restrict__ db)
+{
+    const int c = threadIdx.x;
+    const long long t0 = (long long)blockIdx.x * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (long long t = t0; t < t1; ++t) {
+        const float xv = __uint_as_float((unsigned)x[t * 256 + c] << 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < n) acc[j] = fmaf(__uint_as_float((unsigned)dy[t * n + j] << 16), xv, acc[j]);
+        if (c < n) bsum += __uint_as_float((unsigned)dy[t * n + c] << 16);
+    }
+    for (int j = 0; j < n; ++j) atomicAdd(dw + j * 256 + c, acc[j]);
+    if (db && c < n) atomicAdd(db + c, bsum);
+}
+
 }  // namespace
 
 extern "C" {
+
+/* Backward of y = x W^T + b for a 256 -> n layer, n <= 8: dy (T, n) bf16 contiguous, x (T, 256) bf16, w (n, 256) f32 -> dx (T, 256) bf16
+ * (or NULL), dw (n, 256) f32 and db (n) f32 (or NULL), both overwritten */
+int msda_narrow_linear_backward_bf16(const uint16_t *dy, const uint16_t *x, const float *w, int T, int n, uint16_t *dx, float *dw, float *db,
+                                     msda_stream_t stream)
+{
+    if (!dy || !x || !w || !dw) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (T < 1 || n < 1 || n > 8) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    if ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(x)) & 15) return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * n * 256, st);
+    if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, sizeof(float) * n, st);
+    if (e != hipSuccess) return (int)e;
+    if (dx) {
+        const long long total = (long long)T * 32;
+        hipLaunchKernelGGL(narrow_linear_dx_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st, dy,
+                           w, T, n, dx);
+    }
+    const int chunk = T >= 65536 ? 256 : (T >= 8192 ? 128 : 32);
+    hipLaunchKernelGGL(narrow_linear_dw_kernel, dim3((unsigned)((T + chunk - 1) / chunk)), dim3(256), 0, st, dy, x, T, n, chunk, dw, db);
+    e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
 
 /* y = sigmoid(delta + inverse_sigmoid(ref)): delta (n) bf16 or f32, ref (n) f32, y (n) f32 */
 int msda_box_refine_forward(const void *delta, int delta_is_bf16, const float *ref, float eps, int64_t n, float *y, msda_stream_t stream)

@@ -237,6 +237,40 @@ def pack_linear256_padded(weight, bias):
     return pk
 
 
+class Lin256NarrowFunction(torch.autograd.Function):
+    """``x W^T + b`` for a 256 -> n layer with n <= 8 (the box heads' 256 -> 4): forward on csrc/lin256_mfma.hip with the weight padded to
+    64 rows (``pk`` from :func:`pack_linear256_padded`), of which the first n columns are handed out; backward as two streaming kernels
+    (``msda_narrow_linear_backward_bf16``) -- not the three GEMMs with a zero-padded 64-wide gradient that autograd's slice would feed.
+    ``apply(x, pk, weight, bias)`` -> (..., n) bf16"""
+
+    @staticmethod
+    def forward(ctx, x, pk, weight, bias):
+        x2 = x.reshape(-1, 256)
+        n = weight.shape[0]
+        out = lin256(x2, pk["packed"], pk["b32"])[:, :n].contiguous()
+        ctx.save_for_backward(x2, weight)
+        ctx.shape, ctx.dts = x.shape, (weight.dtype, bias.dtype)
+        return out.view(x.shape[:-1] + (n,))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        n, T = weight.shape[0], x2.shape[0]
+        dy2 = dy.reshape(T, n).to(torch.bfloat16).contiguous()
+        x2 = x2.contiguous()
+        w32 = weight.detach().float().contiguous()
+        dx = torch.empty((T, 256), dtype=torch.bfloat16, device=x2.device) if ctx.needs_input_grad[0] else None
+        dwb = torch.empty(n * 256 + 8, dtype=torch.float32, device=x2.device)
+        with torch.cuda.device(x2.device):
+            _lib.check(_lib.load().msda_narrow_linear_backward_bf16(
+                dy2.data_ptr(), x2.data_ptr(), w32.data_ptr(), T, n, dx.data_ptr() if dx is not None else None, dwb.data_ptr(),
+                dwb[n * 256:].data_ptr(), torch.cuda.current_stream(x2.device).cuda_stream))
+        dw, db = dwb[:n * 256].view(n, 256), dwb[n * 256:n * 256 + n]
+        return (dx.view(ctx.shape) if dx is not None else None, None, dw.to(ctx.dts[0]) if ctx.needs_input_grad[2] else None,
+                db.to(ctx.dts[1]) if ctx.needs_input_grad[3] else None)
+
+
 def _mask_rows_(t, mask):
     """zero the rows of ``t`` (T, C) bf16 where ``mask`` (T,) bool is set, in place (only those rows are touched)"""
     with torch.cuda.device(t.device):

@@ -22,7 +22,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions.linear import (Lin256Function, LinearBf16CachedFunction, StackedValueProjFunction, VersionCache, pack_linear256,
+from ..functions.linear import (Lin256Function, Lin256NarrowFunction, LinearBf16CachedFunction, StackedValueProjFunction, VersionCache, pack_linear256,
                                 pack_linear256_padded)
 
 
@@ -70,6 +70,8 @@ class MLP(nn.Module):
             relu = i < self.num_layers - 1
             if kind == "lin256":
                 x = Lin256Function.apply(x, f, None, relu, layer.weight, layer.bias)
+            elif kind == "lin256pad" and layer.weight.shape[0] <= 8 and not relu:
+                x = Lin256NarrowFunction.apply(x, f, layer.weight, layer.bias)
             elif kind == "lin256pad":
                 x = Lin256Function.apply(x, f, None, relu, layer.weight, layer.bias)[..., :layer.weight.shape[0]]
             else:

@@ -301,3 +301,25 @@ def test_bf16_layers_on_small_inputs_and_with_dropout(dropout):
     assert out.dtype == torch.bfloat16 and torch.isfinite(out.float()).all()
     out.float().square().mean().backward()
     assert src.grad is not None and tgt.grad is not None and torch.isfinite(src.grad.float()).all()
+
+
+@pytest.mark.parametrize("T", [2184, 44646, 37])
+def test_narrow_linear_function_matches_autograd(T):
+    """Lin256NarrowFunction (256 -> 4: forward on lin256 with a padded weight, backward on the two streaming kernels) against F.linear in
+    fp32 autograd on the same bf16 inputs"""
+    from richsem_amd.functions.linear import Lin256NarrowFunction, pack_linear256_padded
+    g = torch.Generator(device="cuda").manual_seed(T)
+    x = torch.randn(T, 256, device="cuda", generator=g).to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(4, 256, device="cuda", generator=g) / 16).requires_grad_(True)
+    b = torch.randn(4, device="cuda", generator=g).requires_grad_(True)
+    dy = torch.randn(T, 4, device="cuda", generator=g).to(torch.bfloat16)
+    y = Lin256NarrowFunction.apply(x, pack_linear256_padded(w, b), w, b)
+    y.backward(dy)
+    xr, br = x.detach().float().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)      # (the forward multiplies with the bf16-rounded weight)
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(dy.float())
+    assert (y.float() - yr).abs().max() <= 2 ** -7 * yr.abs().max()
+    assert (x.grad.float() - xr.grad).abs().max() <= 2 ** -7 * xr.grad.abs().max()
+    assert (w.grad - wr.grad).abs().max() <= 1e-3 * wr.grad.abs().max()
+    assert (b.grad - br.grad).abs().max() <= 1e-3 * br.grad.abs().max()
