@@ -58,7 +58,7 @@ HIP_KERNELS = {
     ("fwd", 1): "fwd_direct_kernel",
     ("bwd", 1): "bwd_levelsum_kernel + bwd_direct_kernel",
     ("fwd", 2): "tiled_gather_kernel",
-    ("bwd", 4): "rps_route_kernel<true> + rps_route_kernel<false> + rps_tile_kernel",
+    ("bwd", 4): "rps_route_kernel + rps_tile_kernel",
 }
 VARIANT_NAMES = {1: "direct", 2: "tiled", 4: "routed"}
 

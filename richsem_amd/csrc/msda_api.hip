@@ -389,6 +389,8 @@ struct Workspace {
     unsigned *rps_bins = nullptr;            // routed backward: queue heads (32 words), bin_count, bin_fill, bin_start (+1) -- laid
     size_t rps_bins_cap = 0;                 // out by the CAPACITY in bins, so that bin_count stays where it is (and zero)
     size_t rps_bins_n = 0;                   // capacity in bins
+    uint2 *rps_runs = nullptr;               // [cap] the bins' run tables (nbins x max_runs)
+    size_t rps_runs_cap = 0;
     msda::RpsRec *rps_entries = nullptr;     // [cap] routed records
     size_t rps_entries_cap = 0;
     bool rps_dirty = false;                  // a failed launch may have left the bin counters non-zero
@@ -412,13 +414,13 @@ int cu_count()
 // ---- routed pixel-stationary backward (msda_rps.h) ---------------------------------------------------------------------------
 // The bin counters are zero between calls (the scan kernel re-zeroes them after reading them), so that no call has to clear
 // them first: they are cleared when allocated and after a launch error.
-bool rps_workspace(hipStream_t stream, size_t n_bins, size_t n_entries, Workspace &out)
+bool rps_workspace(hipStream_t stream, size_t n_bins, size_t n_runs, size_t n_entries, Workspace &out)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     std::lock_guard<std::mutex> lock(g_ws_mu);
     Workspace &ws = g_ws[std::make_pair(dev, stream)];
-    if (ws.rps_bins_n < n_bins || ws.rps_entries_cap < n_entries || ws.rps_dirty) {
+    if (ws.rps_bins_n < n_bins || ws.rps_runs_cap < n_runs || ws.rps_entries_cap < n_entries || ws.rps_dirty) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(stream, &cap);
         if (cap != hipStreamCaptureStatusNone) return false;   // no allocation while the stream is being captured
@@ -436,6 +438,14 @@ bool rps_workspace(hipStream_t stream, size_t n_bins, size_t n_entries, Workspac
         if (ws.rps_dirty) {
             if (hipMemsetAsync(ws.rps_bins, 0, ws.rps_bins_cap * sizeof(unsigned), stream) != hipSuccess) { (void)hipGetLastError(); return false; }
             ws.rps_dirty = false;
+        }
+        if (ws.rps_runs_cap < n_runs) {
+            if (ws.rps_runs) (void)hipFree(ws.rps_runs);
+            ws.rps_runs = nullptr;
+            ws.rps_runs_cap = 0;
+            const size_t want = n_runs + n_runs / 2 + 1024;
+            if (hipMalloc(reinterpret_cast<void **>(&ws.rps_runs), want * sizeof(uint2)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            ws.rps_runs_cap = want;
         }
         if (ws.rps_entries_cap < n_entries) {   // (+ the tile kernel's scratch lines behind the records)
             if (ws.rps_entries) (void)hipFree(ws.rps_entries);
@@ -471,11 +481,13 @@ hipError_t launch_bwd_rps(const Problem &pb, const TV *value, const float *loc, 
     if (reinterpret_cast<uintptr_t>(grad_acc) & 15) return hipErrorNotSupported;
     if ((reinterpret_cast<uintptr_t>(grad_loc) | reinterpret_cast<uintptr_t>(loc)) & 7) return hipErrorNotSupported;
     Workspace ws;
-    if (!rps_workspace(stream, (size_t)pl.g.nbins, pl.max_entries, ws)) return hipErrorNotSupported;
+    const size_t n_runs = (size_t)pl.g.nbins * (size_t)pl.g.max_runs;
+    if (n_runs * sizeof(uint2) > ((size_t)256 << 20)) return hipErrorNotSupported;      // (run tables of a quarter GB: not a shape this path is for)
+    if (!rps_workspace(stream, (size_t)pl.g.nbins, n_runs, pl.max_entries, ws)) return hipErrorNotSupported;
     pl.g.ctr = ws.rps_bins;
-    pl.g.bin_count = ws.rps_bins + 32;   // (line-aligned)
-    pl.g.bin_fill = pl.g.bin_count + ws.rps_bins_n * msda::kRpsPad;
-    pl.g.bin_start = pl.g.bin_fill + ws.rps_bins_n * msda::kRpsPad;
+    pl.g.bin_state = reinterpret_cast<unsigned long long *>(ws.rps_bins + 32);   // (line-aligned; one per 128-B line)
+    pl.g.runs = ws.rps_runs;
+    pl.g.entries_cap = (unsigned)std::min<size_t>(ws.rps_entries_cap, 0xFFFFFFFFu);
     pl.g.entries = ws.rps_entries;
     pl.g.dummy = reinterpret_cast<float *>(ws.rps_entries + ws.rps_entries_cap);
     pl.g.stamps = msda::tiled_options().stamps;
@@ -488,11 +500,8 @@ hipError_t launch_bwd_rps(const Problem &pb, const TV *value, const float *loc, 
     const int qpb = qpw * (msda::kRpsRouteThreads / msda::kWave);
     const int64_t r_items = (int64_t)pb.N * pb.M * ((pb.Lq + qpb - 1) / qpb);
     const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(r_items, (int64_t)msda::rps_options().route_wgs.load() * cu_count()));
-    hipLaunchKernelGGL(msda::rps_route_kernel<true>, dim3(rgrid), dim3(msda::kRpsRouteThreads), 0, stream, loc, aw, grad_acc, grad_loc,
-                       grad_aw, pl.g);
-    hipLaunchKernelGGL(msda::rps_scan_kernel, dim3(1), dim3(1024), 0, stream, pl.g);
-    hipLaunchKernelGGL(msda::rps_route_kernel<false>, dim3(rgrid), dim3(msda::kRpsRouteThreads), 0, stream, loc, aw, grad_acc, grad_loc,
-                       grad_aw, pl.g);
+    hipLaunchKernelGGL(msda::rps_route_kernel, dim3(rgrid), dim3(msda::kRpsRouteThreads), 0, stream, loc, aw, grad_acc, grad_loc, grad_aw,
+                       pl.g);
     const int grid = (cu_count() / msda::kXcds) * msda::kXcds;   // persistent: one workgroup per CU (its LDS is most of a CU's)
     hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 8), dim3(msda::kRpsThreads), sizeof(msda::RpsLds), stream, value, grad_out,
                        grad_value, grad_acc, grad_loc, grad_aw, pl.g);

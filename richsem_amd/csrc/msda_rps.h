@@ -48,6 +48,7 @@ constexpr int kRpsMaxUnits = 448;
 constexpr int kRpsD = 32;
 constexpr int kRpsPad = 32;                     // atomically updated counters sit on lines of their own
 constexpr int kRpsDummyWgs = 2048, kRpsDummyBytes = kRpsDummyWgs * 1024;   // 1 KB per workgroup: 16 B per lane of a wave
+constexpr int kRpsMaxRuns = 256;               // runs per bin the tile kernel can index (2 KB of LDS): Lq <= 256 x 128 queries
 constexpr int kRpsQpBits = 19;                  // entry code: query * P + point below this bit (plan: Lq * P < 2^19)
 
 struct RpsLevel {
@@ -74,10 +75,12 @@ struct RpsGeom {
     int bins_per_pair, nbins;
     RpsLevel lv[kRpsMaxL];
     unsigned units[kRpsMaxUnits];   // level | ty << 2 | tx << 8 | slab << 14 | nslab << 22, heaviest first
-    unsigned *ctr;          // workspace: [0..7] per-XCD queue heads (reset by the count pass)
-    unsigned *bin_count;    // [nbins * kRpsPad]  points per bin (count pass); one counter per 128-B line; zero between calls
-    unsigned *bin_start;    // [nbins + 1]        exclusive prefix
-    unsigned *bin_fill;     // [nbins * kRpsPad]  place-pass cursors
+    unsigned *ctr;          // workspace: [0..7] per-XCD queue heads (reset by the route pass)
+    unsigned long long *bin_state;   // [nbins], one per 128-B line (stride kRpsPad / 2): records of the bin (low word) | runs (high word); zero between calls
+    uint2 *runs;            // [nbins * max_runs] a bin's runs in the record pool: {first record, position of the run inside the bin}
+    int max_runs;           // runs a bin can get = query blocks of a pair (every route work item adds at most one run to a bin)
+    unsigned entries_cap;   // records the pool holds (4 x points: exact worst case); indices are clamped to it, so that counters left
+                            // dirty by an aborted call can give wrong results but never an access outside the pool
     struct RpsRec *entries;         // one 16-byte record per (point, bin it was routed to)
     int seg_shift;                  // a pixel's list is walked in units of at most 1 << seg_shift points (>= kRpsSegShift)
     float *dummy;                   // kRpsDummyBytes of scratch: where the lanes that have nothing to store send their stores
@@ -99,6 +102,7 @@ struct RpsLds {
     int wave_tot[16];
     int n_segs, pad[3];
     int uhist[16];                      // walk units per (wave of the scan, length class), longest class first
+    uint2 runs[kRpsMaxRuns];            // the work item's bin as the route pass left it: {first record, position inside the bin} per run
     unsigned long long stamp_last, stamp_acc[14];
     int offs[kRpsMaxPx + 4];            // histogram, then exclusive prefix: where a base pixel's list starts
     unsigned short seg[kRpsMaxSegs + 16];   // walk units of the chunk: list | segment of the list << 8
@@ -193,29 +197,31 @@ __device__ __forceinline__ RpsTarget rps_targets(float x, float y, const RpsLeve
     return t;
 }
 
-// Route pass.  A workgroup takes a block of consecutive queries of one (image, head); lane = (query, point), levels one
-// after the other.  The workgroup first sorts out its own points in LDS -- a histogram over the pair's bins; the value an
-// LDS atomic returns is the point's rank among the workgroup's points of that bin -- and then talks to global memory once
-// per (workgroup, bin):
-//   COUNT = true   bin_count[bin] += the workgroup's count; dropped samples get their (zero) gradients here; the levels
-//                  flushed with atomics later are zeroed in grad_value; the tile kernel's queue heads are reset.
-//   COUNT = false  one returning atomic per (workgroup, bin) reserves a run in the bin; every lane then writes its 16-byte
-//                  entries -- position code, bilinear fractions, attention weight -- at run start + rank.
-// Lanes of a wave usually share the owner bin (neighbouring queries, neighbouring points): they are matched with one
-// ballot and served by a single LDS atomic; the others take one each.
+// Route pass (ONE pass: no counting pass, no prefix pass).  A workgroup takes a block of consecutive queries of one (image, head);
+// lane = (query, point), levels one after the other.  It first sorts out its own points in LDS -- a histogram over the pair's bins;
+// the value an LDS atomic returns is the point's rank among the workgroup's points of that bin -- lays them out in ITS stretch of the
+// record pool (its bins' records lie one after the other there: a "run" per bin), tells every bin it touched
+// where its run is -- one 64-bit atomic per (workgroup, bin) adds the run's length to the bin's record count and one to its run count,
+// and what it returns is the run's slot in the bin's run table and the run's position inside the bin -- and writes its 16-byte entries
+// (position code, bilinear fractions, attention weight) at run start + rank.  The tile kernel reads a bin as the list of its runs.
+// Also here: dropped samples get their (zero) gradients; the levels flushed with atomics later are zeroed in grad_value; the tile
+// kernel's queue heads are reset.
+// Lanes of a wave usually share the owner bin (neighbouring queries, neighbouring points): they are matched with one ballot and
+// served by a single LDS atomic; the others take one each.
 constexpr int kRpsRouteThreads = 512;
+static_assert(kRpsMaxUnits <= kRpsRouteThreads, "route pass: one thread per bin of a pair");
 
-template <bool COUNT>
 __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float *__restrict__ loc, const float *__restrict__ aw,
                                                                      float *__restrict__ grad_value, float *__restrict__ grad_loc,
                                                                      float *__restrict__ grad_aw, const RpsGeom g)
 {
     __shared__ unsigned hist[kRpsMaxUnits], base[kRpsMaxUnits];
+    __shared__ unsigned wtot[kRpsRouteThreads / kWave];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int B = g.bins_per_pair;
-    if (COUNT) {
+    {
         const int gtid = blockIdx.x * blockDim.x + tid, gsz = gridDim.x * blockDim.x;
-        if (gtid < 16) g.ctr[gtid] = 0u;
+        if (gtid < 8) g.ctr[gtid] = 0u;
         const int row4 = g.M * kRpsD / 4;   // float4 per pixel
         for (int l = 0; l < g.L; ++l) {
             if (!g.lv[l].atomic) continue;
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
 #pragma unroll
         for (int l = 0; l < kRpsMaxL; ++l) {
             xy[l] = live && l < g.L ? *reinterpret_cast<const float2 *>(loc + 2u * (pt0 + (unsigned)(l * P))) : make_float2(-4.f, -4.f);
-            at[l] = !COUNT && live && l < g.L ? aw[pt0 + (unsigned)(l * P)] : 0.f;
+            at[l] = live && l < g.L ? aw[pt0 + (unsigned)(l * P)] : 0.f;
         }
         __syncthreads();
         // ---- A: ranks inside the workgroup ---------------------------------------------------------------------------------------
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
             t.bin[0] = t.bin[1] = t.bin[2] = t.bin[3] = -1;
             t.valid = true;
             if (live) t = rps_targets(xy[l].x, xy[l].y, v, rps_uni(qb % v.nslab));
-            if (COUNT && live && !t.valid) {   // dropped sample: zero gradients
+            if (live && !t.valid) {   // dropped sample: zero gradients
                 const unsigned pt = pt0 + (unsigned)(l * P);
                 grad_aw[pt] = 0.f;
                 *reinterpret_cast<float2 *>(grad_loc + 2u * pt) = make_float2(0.f, 0.f);
@@ -299,80 +305,54 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
                 }
         }
         __syncthreads();
-        // ---- B: one global atomic per (workgroup, bin) ---------------------------------------------------------------------------
-        for (int i = tid; i < B; i += kRpsRouteThreads) {
-            const unsigned c = hist[i];
-            if (c) {
-                const size_t gb = (size_t)pair * B + i;
-                if (COUNT) atomicAdd(g.bin_count + gb * kRpsPad, c);
-                else base[i] = g.bin_start[gb] + atomicAdd(g.bin_fill + gb * kRpsPad, c);
-            }
+        // ---- B: the workgroup's runs: exclusive prefix over its bins' counts (one bin per thread), room in the pool, one 64-bit
+        //      atomic per (workgroup, bin) ---------------------------------------------------------------------------------------------
+        const unsigned cnt = tid < B ? hist[tid] : 0u;
+        unsigned incl = cnt;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const unsigned t = (unsigned)__shfl_up((int)incl, d, kWave);
+            if (lane >= d) incl += t;
         }
-        if (!COUNT) {
-            // ---- C: entries to their slots --------------------------------------------------------------------------------------
+        if (lane == kWave - 1) wtot[wave] = incl;
+        __syncthreads();
+        unsigned before = 0u;
 #pragma unroll
-            for (int l = 0; l < kRpsMaxL; ++l) {
-                if (l >= g.L) continue;
-                unsigned r = own_rank[l];
-                if (lead[l] >= 0) {
-                    const unsigned rl = (unsigned)__shfl((int)r, lead[l], kWave);
-                    if (matched[l] && lane != lead[l]) r += rl;
-                }
-                if (word[l][0] != ~0u) word[l][0] |= r << 9;
-            }
-            __syncthreads();
-            const unsigned qp = (unsigned)((live ? q : 0) * P + pp);
-#pragma unroll
-            for (int l = 0; l < kRpsMaxL; ++l)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned w = word[l][k];
-                    if (w != ~0u) {
-                        const unsigned slot = base[w & 511u] + ((w >> 9) & 16383u);
-                        const unsigned code = qp | (w >> 23) << kRpsQpBits | (k == 0 ? inmap[l] << 27 | 0x80000000u : 0u);
-                        g.entries[slot] = RpsRec{code, lh[l], lw[l], at[l]};
-                    }
-                }
+        for (int w = 0; w < kRpsRouteThreads / kWave; ++w) before += w < wave ? wtot[w] : 0u;
+        // (every work item has its own stretch of the record pool, sized for its worst case -- 4 bins per point --: no cursor to share,
+        // and the pool's capacity is the exact bound it always had: 4 x the points of all work items)
+        if (cnt) {
+            const size_t gb = (size_t)pair * B + tid;
+            const unsigned first = (unsigned)item * (unsigned)(qpb * LP * 4) + before + incl - cnt;
+            const unsigned long long old = atomicAdd(g.bin_state + gb * (kRpsPad / 2), (1ull << 32) | (unsigned long long)cnt);
+            g.runs[gb * (size_t)g.max_runs + (size_t)min((unsigned)(old >> 32), (unsigned)g.max_runs - 1u)] = make_uint2(first, (unsigned)old);
+            base[tid] = first;
         }
+        // ---- C: entries to their slots ------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int l = 0; l < kRpsMaxL; ++l) {
+            if (l >= g.L) continue;
+            unsigned r = own_rank[l];
+            if (lead[l] >= 0) {
+                const unsigned rl = (unsigned)__shfl((int)r, lead[l], kWave);
+                if (matched[l] && lane != lead[l]) r += rl;
+            }
+            if (word[l][0] != ~0u) word[l][0] |= r << 9;
+        }
+        __syncthreads();
+        const unsigned qp = (unsigned)((live ? q : 0) * P + pp);
+#pragma unroll
+        for (int l = 0; l < kRpsMaxL; ++l)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned w = word[l][k];
+                if (w != ~0u) {
+                    const unsigned slot = min(base[w & 511u] + ((w >> 9) & 16383u), g.entries_cap - 1u);
+                    const unsigned code = qp | (w >> 23) << kRpsQpBits | (k == 0 ? inmap[l] << 27 | 0x80000000u : 0u);
+                    g.entries[slot] = RpsRec{code, lh[l], lw[l], at[l]};
+                }
+            }
         __syncthreads();   // hist / base are reused by the next item
-    }
-}
-
-// Exclusive prefix of the bin counts (one workgroup; a few thousand bins).  Leaves the counters zeroed for the next call
-// and the place-pass cursors zeroed for this one.
-__global__ __launch_bounds__(1024) void rps_scan_kernel(const RpsGeom g)
-{
-    __shared__ unsigned wave_tot[16];
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    const int per = (g.nbins + 1023) / 1024;
-    const int i0 = tid * per, i1 = min(g.nbins, i0 + per);
-    constexpr int kKeep = 4;   // counts kept in registers (all of them for the usual few thousand bins)
-    unsigned keep[kKeep];
-    unsigned s = 0;
-#pragma unroll
-    for (int k = 0; k < kKeep; ++k) {
-        keep[k] = i0 + k < i1 ? g.bin_count[(size_t)(i0 + k) * kRpsPad] : 0u;
-        s += keep[k];
-    }
-    for (int i = i0 + kKeep; i < i1; ++i) s += g.bin_count[(size_t)i * kRpsPad];
-    unsigned incl = s;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const unsigned t = __shfl_up(incl, d, kWave);
-        if (lane >= d) incl += t;
-    }
-    if (lane == kWave - 1) wave_tot[wave] = incl;
-    __syncthreads();
-    unsigned run = incl - s;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) run += w < wave ? wave_tot[w] : 0u;
-    if (tid == 1023) g.bin_start[g.nbins] = run + s;
-    for (int i = i0; i < i1; ++i) {
-        const unsigned c = i - i0 < kKeep ? keep[min(i - i0, kKeep - 1)] : g.bin_count[(size_t)i * kRpsPad];
-        g.bin_start[i] = run;
-        run += c;
-        g.bin_count[(size_t)i * kRpsPad] = 0u;
-        g.bin_fill[(size_t)i * kRpsPad] = 0u;
     }
 }
 
@@ -496,29 +476,47 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
         it.npx = it.live ? (it.R1 - it.R0 + 1) * it.gw : 0;
         return it;
     };
-    // bin of a work item: first record and number of records (0 for ids past the table or pairs past the batch)
-    auto bin_range = [&](int id, unsigned &first, int &n) {
-        first = 0;
+    // bin of a work item: its index, number of records and number of runs (0 records for ids past the table or pairs past the batch)
+    auto bin_range = [&](int id, unsigned &bin_, int &n, int &nr) {
+        bin_ = 0xFFFFFFFFu;      // (no bin)
         n = 0;
+        nr = 0;
         if (id < n_items) {
             const unsigned unit = g.units[id / g.ppx];
             const int pair = xq + kXcds * (id % g.ppx);
             if (pair < pairs) {
                 const int l = unit & 3, ty = (unit >> 2) & 63, tx = (unit >> 8) & 63, slab = (unit >> 14) & 255, nslab = (unit >> 22) & 255;
-                const int bin = pair * g.bins_per_pair + g.lv[l].bin0 + (ty * g.lv[l].ntx + tx) * nslab + slab;
-                first = g.bin_start[bin];
-                n = (int)(g.bin_start[bin + 1] - first);
+                bin_ = (unsigned)(pair * g.bins_per_pair + g.lv[l].bin0 + (ty * g.lv[l].ntx + tx) * nslab + slab);
+                const unsigned long long st = g.bin_state[(size_t)bin_ * (kRpsPad / 2)];
+                n = (int)min((unsigned)st, 0x7FFFFFFFu);
+                nr = (int)min((unsigned)(st >> 32), (unsigned)min(g.max_runs, kRpsMaxRuns));
             }
         }
     };
-    RpsRec n_rec[kRpsRpl];   // this lane's two records of the chunk in flight (lanes past the end of the bin: a copy of its last record)
-    auto fetch_recs = [&](unsigned first_, int n_, int ch) {
-        const unsigned first = (unsigned)rps_uni((int)first_);
-        const int n = rps_uni(n_);
+    // a bin's run table: global -> registers (one run per lane) -> LDS
+    uint2 run_reg = make_uint2(0u, 0u);
+    auto load_runs = [&](unsigned bin_, int nr) {
+        const int i = min(tid, max(rps_uni(nr) - 1, 0));
+        const unsigned b_ = (unsigned)rps_uni((int)bin_);
+        run_reg = g.runs[(size_t)(b_ == 0xFFFFFFFFu ? 0u : b_) * g.max_runs + i];
+    };
+    auto park_runs = [&]() {
+        if (tid < kRpsMaxRuns) S->runs[tid] = run_reg;
+    };
+    RpsRec n_rec[kRpsRpl];   // this lane's records of the chunk in flight (lanes past the end of the bin: a copy of its last record)
+    auto fetch_recs = [&](int n_, int nr_, int ch) {      // (the bin's run table is in LDS)
+        const int n = rps_uni(n_), nr = rps_uni(nr_);
 #pragma unroll
         for (int u = 0; u < kRpsRpl; ++u) {
-            const int k = ch * kRpsChunk + u * kRpsThreads + tid;
-            n_rec[u] = g.entries[n > 0 ? first + (unsigned)min(k, n - 1) : 0u];
+            const unsigned k = (unsigned)min(ch * kRpsChunk + u * kRpsThreads + tid, max(n - 1, 0));
+            int r = 0;      // the last run that starts at or before record k of the bin (the runs' positions ascend with their slots)
+#pragma unroll
+            for (int step = kRpsMaxRuns / 2; step > 0; step >>= 1) {
+                const int cand = r + step;
+                if (cand < nr && S->runs[cand].y <= k) r = cand;
+            }
+            const uint2 run = S->runs[r];
+            n_rec[u] = g.entries[n > 0 ? min(run.x + (k - run.y), g.entries_cap - 1u) : 0u];
         }
     };
     // value rows of a work item's pixel grid: 32 B per lane and pixel, pixels `quad` and `quad + 192` (the second only where
@@ -554,12 +552,16 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
     }
     __syncthreads();
     int item_id = rps_uni(S->item_slot[0]);
-    unsigned e_first;
-    int n_ent;
-    bin_range(item_id, e_first, n_ent);
-    e_first = (unsigned)rps_uni((int)e_first);
+    unsigned e_bin;
+    int n_ent, n_runs;
+    bin_range(item_id, e_bin, n_ent, n_runs);
+    e_bin = (unsigned)rps_uni((int)e_bin);
     n_ent = rps_uni(n_ent);
-    fetch_recs(e_first, n_ent, 0);
+    n_runs = rps_uni(n_runs);
+    load_runs(e_bin, n_runs);
+    park_runs();
+    __syncthreads();
+    fetch_recs(n_ent, n_runs, 0);
     Item it = item_geom(item_id);
     int par = 0;
     fetch_rows(it);
@@ -579,9 +581,9 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
             reinterpret_cast<double2 *>(S->sum)[i] = make_double2(0.0, 0.0);
         __syncthreads();
         const int next_id = rps_uni(S->item_slot[par ^ 1]);
-        unsigned next_first;
-        int next_n;
-        bin_range(next_id, next_first, next_n);   // (made uniform where first used: that waits for the two loads)
+        unsigned next_bin;
+        int next_n, next_runs;
+        bin_range(next_id, next_bin, next_n, next_runs);   // (made uniform where first used: that waits for the loads)
         const Item nit = item_geom(next_id);
         store_rows();   // (read only behind the barriers of the first chunk's sort; an empty bin reads nothing)
         RPS_STAMP(0)
@@ -792,9 +794,11 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
             // the next chunk -- or the first chunk of the next work item -- is requested now, behind the walk (held across it,
             // the eight registers would spill) and AHEAD of this chunk's gradient stores
             const bool last_chunk = ch + 1 == n_chunks;
-            if (!last_chunk) fetch_recs(e_first, n_ent, ch + 1);
-            else fetch_recs(next_first, next_n, 0);
+            if (!last_chunk) fetch_recs(n_ent, n_runs, ch + 1);
+            else load_runs(next_bin, next_runs);      // (the next item's run table: parked in LDS behind the barrier, its records
+                                                      // requested where the sums are stored)
             __syncthreads();
+            if (last_chunk) park_runs();
             RPS_STAMP(5)
 
             // ---- (5) gradients of the points this tile owns: one lane per record, in arrival order; four store instructions issued
@@ -833,12 +837,18 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
             // after three more barriers)
             RPS_STAMP(6)
         }
-        if (n_chunks == 0) fetch_recs(next_first, next_n, 0);   // (an empty bin: nothing was fetched ahead)
+        if (n_chunks == 0) {   // (an empty bin: nothing was requested ahead)
+            load_runs(next_bin, next_runs);
+            __syncthreads();
+            park_runs();
+        }
         // the NEXT item's value rows are requested now and travel while this item's sums are stored and the next item's are cleared
         // (they are parked in LDS behind the next item's first barrier)
         fetch_rows(nit);
         // ---- the tile's sums to grad_value: one 128-B row per pixel (two pixels per quad) ------------------------------------------
         __syncthreads();
+        fetch_recs(next_n, next_runs, 0);      // the next item's first chunk (its run table is in LDS now) travels under the stores below
+        if (tid == 0 && e_bin != 0xFFFFFFFFu) g.bin_state[(size_t)e_bin * (kRpsPad / 2)] = 0ull;      // this bin is consumed: its counter is zero for the next call
         if (!g.lv[l].atomic) {   // (uniform)
 #pragma unroll
             for (int r = 0; r < kRpsPpq; ++r) {
@@ -867,8 +877,9 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
         __syncthreads();
         RPS_STAMP(7)
         item_id = next_id;
-        e_first = (unsigned)rps_uni((int)next_first);
+        e_bin = (unsigned)rps_uni((int)next_bin);
         n_ent = rps_uni(next_n);
+        n_runs = rps_uni(next_runs);
         it = nit;
         par ^= 1;
     }
@@ -927,7 +938,7 @@ inline RpsPlan plan_rps(int N, int S, int M, int D, int L, int Lq, int P, const 
     }
     if (!tiles_s || pre != S) return pl;   // tiles must not overlap in grad_value
     const int64_t n_pts = (int64_t)N * Lq * M * L * P;
-    if (n_pts >= ((int64_t)1 << 31) || (int64_t)Lq * P >= ((int64_t)1 << kRpsQpBits)) return pl;
+    if (n_pts >= ((int64_t)1 << 30) || (int64_t)Lq * P >= ((int64_t)1 << kRpsQpBits)) return pl;      // (4 x points: 32-bit record indices)
     RpsGeom &g = pl.g;
     g.N = N; g.S = S; g.M = M; g.Lq = Lq; g.L = L; g.P = P;
     g.seg_shift = std::max(kRpsSegShift, std::min(11, rps_options().seg_shift.load()));
@@ -968,7 +979,13 @@ inline RpsPlan plan_rps(int N, int S, int M, int D, int L, int Lq, int P, const 
     for (int i = 0; i < g.nunits; ++i) g.units[i] = units[i].code;
     g.bins_per_pair = bins;
     g.nbins = bins * N * M;
-    pl.max_entries = (size_t)n_pts * 4;
+    // runs a bin can get: one per route work item of its pair (the route pass's block of queries: 16 queries per wave at P <= 4)
+    const int qpw = P <= 4 ? 16 : (P <= 8 ? 8 : (P <= 16 ? 4 : (P <= 32 ? 2 : 1)));
+    g.max_runs = (Lq + qpw * 8 - 1) / (qpw * 8);
+    if (g.max_runs > kRpsMaxRuns) return pl;      // (the tile kernel keeps a bin's run table in LDS)
+    // the record pool: a stretch per route work item (pair, block of qpw x 8 queries), each for the worst case of 4 bins per point
+    pl.max_entries = (size_t)N * M * g.max_runs * (size_t)(qpw * 8) * L * P * 4;
+    if (pl.max_entries >= ((size_t)1 << 32)) return pl;
     pl.ok = true;
     return pl;
 }
