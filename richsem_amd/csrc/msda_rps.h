@@ -321,13 +321,8 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         for (int w = 0; w < kRpsRouteThreads / kWave; ++w) before += w < wave ? wtot[w] : 0u;
         // (every work item has its own stretch of the record pool, sized for its worst case -- 4 bins per point --: no cursor to share,
         // and the pool's capacity is the exact bound it always had: 4 x the points of all work items)
-        if (cnt) {
-            const size_t gb = (size_t)pair * B + tid;
-            const unsigned first = (unsigned)item * (unsigned)(qpb * LP * 4) + before + incl - cnt;
-            const unsigned long long old = atomicAdd(g.bin_state + gb * (kRpsPad / 2), (1ull << 32) | (unsigned long long)cnt);
-            g.runs[gb * (size_t)g.max_runs + (size_t)min((unsigned)(old >> 32), (unsigned)g.max_runs - 1u)] = make_uint2(first, (unsigned)old);
-            base[tid] = first;
-        }
+        const unsigned first = (unsigned)item * (unsigned)(qpb * LP * 4) + before + incl - cnt;
+        if (cnt) base[tid] = first;      // (known without asking anybody: the entries below do not wait for the bins' counters)
         // ---- C: entries to their slots ------------------------------------------------------------------------------------------
 #pragma unroll
         for (int l = 0; l < kRpsMaxL; ++l) {
@@ -352,6 +347,12 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
                     g.entries[slot] = RpsRec{code, lh[l], lw[l], at[l]};
                 }
             }
+        // ---- D: the runs are announced to their bins; nothing in this work item waits for what the atomics return but the table entry
+        if (cnt) {
+            const size_t gb = (size_t)pair * B + tid;
+            const unsigned long long old = atomicAdd(g.bin_state + gb * (kRpsPad / 2), (1ull << 32) | (unsigned long long)cnt);
+            g.runs[gb * (size_t)g.max_runs + (size_t)min((unsigned)(old >> 32), (unsigned)g.max_runs - 1u)] = make_uint2(first, (unsigned)old);
+        }
         __syncthreads();   // hist / base are reused by the next item
     }
 }
