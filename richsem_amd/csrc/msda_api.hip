@@ -386,8 +386,8 @@ int direct_grid(const msda::DirectGeom &g)
 struct Workspace {
     float *gv32 = nullptr;   // bf16 backward: fp32 accumulation buffer for grad_value (rounded to bf16 once)
     size_t gv32_cap = 0;
-    unsigned *rps_bins = nullptr;            // routed backward: queue heads (32 words), bin_count, bin_fill, bin_start (+1) -- laid
-    size_t rps_bins_cap = 0;                 // out by the CAPACITY in bins, so that bin_count stays where it is (and zero)
+    unsigned *rps_bins = nullptr;            // routed backward: queue heads (32 words), then one 64-bit (records | runs) counter per
+    size_t rps_bins_cap = 0;                 // bin on a 128-byte line of its own
     size_t rps_bins_n = 0;                   // capacity in bins
     uint2 *rps_runs = nullptr;               // [cap] the bins' run tables (nbins x max_runs)
     size_t rps_runs_cap = 0;
@@ -412,7 +412,7 @@ int cu_count()
 }
 
 // ---- routed pixel-stationary backward (msda_rps.h) ---------------------------------------------------------------------------
-// The bin counters are zero between calls (the scan kernel re-zeroes them after reading them), so that no call has to clear
+// The bin counters are zero between calls (the tile kernel zeroes a bin's counter when it has consumed the bin), so that no call has to clear
 // them first: they are cleared when allocated and after a launch error.
 bool rps_workspace(hipStream_t stream, size_t n_bins, size_t n_runs, size_t n_entries, Workspace &out)
 {
@@ -426,7 +426,7 @@ bool rps_workspace(hipStream_t stream, size_t n_bins, size_t n_runs, size_t n_en
         if (cap != hipStreamCaptureStatusNone) return false;   // no allocation while the stream is being captured
         if (ws.rps_bins_n < n_bins) {
             const size_t cap_n = n_bins + n_bins / 2 + 64;
-            const size_t want_bins = 32 + (2 * msda::kRpsPad + 1) * cap_n + 8;
+            const size_t want_bins = 32 + (size_t)msda::kRpsPad * cap_n + 8;
             if (ws.rps_bins) (void)hipFree(ws.rps_bins);
             ws.rps_bins = nullptr;
             ws.rps_bins_cap = ws.rps_bins_n = 0;
@@ -784,7 +784,7 @@ int backward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const i
         float *gv32 = nullptr;
         if (variant == 4 && D == msda::kRpsD && bf16_scratch(stream, n_value, &gv32)) {
             // routed kernels: plain bf16 stores for the levels a workgroup owns alone; the levels shared by several workgroups are
-            // accumulated in the fp32 scratch (zeroed by the count pass) and rounded once
+            // accumulated in the fp32 scratch (zeroed by the route pass) and rounded once
             {
                 ProfileScope prof(1, 4, 2, N, S, M, D, L, Lq, P, stream);
                 e = launch_bwd_rps<msda::bf16_t>(pb, value, loc, aw, grad_out, grad_value, gv32, grad_loc, grad_aw, stream);

@@ -5,11 +5,12 @@
 // chip's atomic rate.  Here the OUTPUT owns the work: grad_value is cut into tiles of <= 18x19 pixels per (image, head,
 // level), and a tile's workgroup pulls in exactly the sampling points that land on it.
 //
-//   route   (rps_route_kernel, two passes: count, then place at exact offsets)  one lane per sampling point: where does
-//           its corner (h_low, w_low) fall?  The point is appended -- a 16-byte record: position code, bilinear fractions,
-//           attention weight -- to the
-//           bin of that tile, and to the bin of the tile below / right of it when its lower / right corners cross the
-//           tile's edge.  Bins are exact (count -> scan -> place): no capacity guess, no overflow path.
+//   route   (rps_route_kernel, ONE pass)  one lane per sampling point: where does its corner (h_low, w_low) fall?  The point is
+//           appended -- a 16-byte record: position code, bilinear fractions, attention weight -- to the bin of that tile, and to
+//           the bin of the tile below / right of it when its lower / right corners cross the tile's edge.  A workgroup (128
+//           queries of one (image, head)) writes the records of each bin it touches as one RUN inside its own stretch of the
+//           record pool and announces the run to the bin with one 64-bit atomic (records | runs): a bin is the list of its runs.
+//           No counting pass, no prefix pass, no capacity guess, no overflow path.
 //   reduce  (rps_tile_kernel)  a workgroup takes a tile: its value rows (+ a one-pixel apron) go to LDS; the bin is
 //           walked in chunks of 1536 points: the points are sorted by the pixel under their corner (integer LDS
 //           atomics: count, scan, place), every pixel's list is cut into units of at most 16 points, and a quad (four

@@ -77,9 +77,9 @@ def test_concurrent_callers_on_their_own_streams():
 
 
 def test_routed_backward_replays_from_a_graph():
-    """The routed backward keeps device state between calls (bin counters that its scan kernel leaves zeroed, a workspace per
-    stream): captured on a stream that has run it before, the graph must reproduce the eager result on every replay, also
-    with a call of another geometry in between."""
+    """The routed backward keeps device state between calls (per-bin (records, runs) counters that the tile kernel zeroes when it has
+    consumed a bin, run tables and a record pool per stream): captured on a stream that has run it before, the graph must reproduce the
+    eager result on every replay, also with a call of another geometry in between."""
     call = W.shrunk(W.call_E(2), 2)
     t = W.make_inputs(call, "uniform", seed=11, device="cuda")
     other = W.make_inputs(W.shrunk(W.call_E(2), 4), "sigma4", seed=12, device="cuda")
@@ -106,5 +106,26 @@ def test_routed_backward_replays_from_a_graph():
                 MSDA.ms_deform_attn_backward(other["value"], other["shapes"], other["lsi"], other["loc"], other["aw"],
                                              other["grad_out"], 64)
             torch.cuda.synchronize()
+    finally:
+        _lib.set_option("bwd_variant", 0)
+
+
+def test_routed_backward_state_survives_changing_shapes():
+    """calls of three different geometries (different bin counts, run-table strides and pool stretches) in turn, twice: every one must
+    match the oracle -- a counter a call left non-zero, or a run table read at the wrong stride, would show in the next call"""
+    from oracle import msda_oracle as O
+    _lib.set_option("bwd_variant", 4)
+    try:
+        calls = [W.shrunk(W.call_E(2), 4), W.shrunk(W.call_E(1), 2), W.shrunk(W.call_E(2), 3)]
+        sets = [W.make_inputs(c, mode, seed=20 + i, device="cuda") for i, (c, mode) in enumerate(zip(calls, ("uniform", "init", "sigma4")))]
+        refs = []
+        for t in sets:
+            z = {k: v.cpu().numpy() for k, v in t.items() if k in ("value", "shapes", "lsi", "loc", "aw", "grad_out")}
+            refs.append(O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"]))
+        for rep in range(2):
+            for t, ref in zip(sets, refs):
+                got = MSDA.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64)
+                for a, b in zip(got, ref):
+                    assert _close(a, torch.from_numpy(b).cuda(), 2e-4), rep
     finally:
         _lib.set_option("bwd_variant", 0)
