@@ -494,3 +494,26 @@ def test_routed_backward_overwrites_poisoned_outputs():
         for a, b in zip(*outs):
             assert torch.isfinite(a).all()
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_routed_backward_falls_back_beyond_its_run_table():
+    """more query blocks per (image, head) than a bin's run table holds (Lq > 256 x 128): the routed plan does not apply and the call
+    takes the direct kernels -- same results, no error"""
+    N, M, D, L, P, Lq = 1, 1, 32, 1, 4, 256 * 128 + 300
+    shapes = torch.as_tensor([(24, 30)], dtype=torch.long)
+    lsi = torch.as_tensor([0])
+    gen = torch.Generator().manual_seed(77)
+    value, loc, aw, go = _recipe(N, 24 * 30, M, D, Lq, L, P, gen, torch.float32)
+    z = dict(value=value.numpy(), shapes=shapes.numpy(), lsi=lsi.numpy(), loc=loc.numpy(), aw=aw.numpy(), grad_out=go.numpy())
+    _lib.set_option("bwd_variant", 4)
+    v, sh, ls, lc, a, g = (dev(z[k]) for k in ("value", "shapes", "lsi", "loc", "aw", "grad_out"))
+    res = {}
+
+    def bwd():
+        res["g"] = MSDA.ms_deform_attn_backward(v, sh, ls, lc, a, g, 64)
+    ran = _profiled_variants(bwd)
+    assert ran == [("bwd", 1)], ran
+    ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
+    tf, tg = tols(np.float32)
+    gv, gl, ga = res["g"]
+    assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg
