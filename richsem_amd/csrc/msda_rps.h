@@ -129,6 +129,19 @@ __device__ __forceinline__ float rps_group8_sum(float v)
 
 __device__ __forceinline__ int rps_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Inclusive prefix sum over the 64 lanes of a wave in six DPP adds (shifts inside a row of 16, then the rows' last lanes broadcast to the
+// rows behind them): the shuffle form goes through the LDS crossbar six times (ds_bpermute), this one stays in the vector pipe.
+__device__ __forceinline__ int rps_wave_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);    // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);    // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 #define RPS_STAMP(i)                                                                   \
     if (g.stamps && threadIdx.x == 0) {                                                \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();                  \
@@ -309,12 +322,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         // ---- B: the workgroup's runs: exclusive prefix over its bins' counts (one bin per thread), room in the pool, one 64-bit
         //      atomic per (workgroup, bin) ---------------------------------------------------------------------------------------------
         const unsigned cnt = tid < B ? hist[tid] : 0u;
-        unsigned incl = cnt;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const unsigned t = (unsigned)__shfl_up((int)incl, d, kWave);
-            if (lane >= d) incl += t;
-        }
+        const unsigned incl = (unsigned)rps_wave_scan((int)cnt);
         if (lane == kWave - 1) wtot[wave] = incl;
         __syncthreads();
         unsigned before = 0u;
@@ -626,16 +634,8 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                     part = c & ((1 << sh) - 1);
                     pslot = part ? ((g.dbg & 8) ? 0 : 3 - ((part - 1) >> (sh - 2))) : -1;   // (dbg 8: A/B, units in list order)
                     n0 = n_full + (pslot == 0 ? 1 : 0);      // this list's units of slot 0: its full ones, then a nearly full last one
-                    incl = v;
-                    incl0 = n0;
-#pragma unroll
-                    for (int d = 1; d < kWave; d <<= 1) {
-                        const int t = __shfl_up(incl, d, kWave), t0 = __shfl_up(incl0, d, kWave);
-                        if (lane >= d) {
-                            incl += t;
-                            incl0 += t0;
-                        }
-                    }
+                    incl = rps_wave_scan(v);
+                    incl0 = rps_wave_scan(n0);
                     if (lane == kWave - 1) S->wave_tot[wave] = incl;
                     // the wave's count per slot (lane k keeps slot k's) and this list's rank among the wave's units of its slot
                     mycnt = __shfl(incl0, kWave - 1, kWave);
