@@ -638,7 +638,7 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                     incl0 = rps_wave_scan(n0);
                     if (lane == kWave - 1) S->wave_tot[wave] = incl;
                     // the wave's count per slot (lane k keeps slot k's) and this list's rank among the wave's units of its slot
-                    mycnt = __shfl(incl0, kWave - 1, kWave);
+                    mycnt = __builtin_amdgcn_readlane(incl0, kWave - 1);
                     const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
                     for (int k = 1; k < 4; ++k) {
@@ -659,23 +659,23 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                         if (npx == kRpsMaxPx) S->offs[npx] = (base + incl) & 0xFFFF;
                         S->n_segs = (base + incl) >> 16;
                     }
-                    // where this wave's units of slot `lane` start: the slots before it of all waves + this slot of the waves before
-                    int tot = 0, mine_before = 0;
+                    // where this wave's units of slot k start: the slots before k of all waves + slot k of the waves before this one --
+                    // every lane forms the four values itself from the 16 counts (broadcast reads; no cross-lane traffic)
+                    int sbk[4], run_ = 0;
 #pragma unroll
-                    for (int w = 0; w < kRpsMaxPx / kWave; ++w) {
-                        const int x = S->uhist[w * 4 + (lane & 3)];
-                        tot += x;
-                        mine_before += w < wave ? x : 0;
-                    }
-                    int pre = tot;
+                    for (int k = 0; k < 4; ++k) {
+                        int tot = 0, mine_before = 0;
 #pragma unroll
-                    for (int d = 1; d < 4; d <<= 1) {
-                        const int t = __shfl_up(pre, d, kWave);
-                        if ((lane & 3) >= d) pre += t;
+                        for (int w = 0; w < kRpsMaxPx / kWave; ++w) {
+                            const int x = S->uhist[w * 4 + k];
+                            tot += x;
+                            mine_before += w < wave ? x : 0;
+                        }
+                        sbk[k] = run_ + mine_before;
+                        run_ += tot;
                     }
-                    const int sb = pre - tot + mine_before;
-                    const int at0 = __shfl(sb, 0, kWave) + incl0 - n0;
-                    const int atp = __shfl(sb, pslot & 3, kWave) + rank;
+                    const int at0 = sbk[0] + incl0 - n0;
+                    const int atp = (pslot == 1 ? sbk[1] : (pslot == 2 ? sbk[2] : sbk[3])) + rank;
                     for (int sgm = 0; sgm < n_full; ++sgm) S->seg[at0 + sgm] = (unsigned short)(tid | sgm << 8);
                     if (pslot == 0) S->seg[at0 + n_full] = (unsigned short)(tid | n_full << 8);
                     else if (pslot > 0) S->seg[atp] = (unsigned short)(tid | n_full << 8);
