@@ -1,10 +1,11 @@
 """TEST INFRASTRUCTURE (oracle) -- numpy restatement of the reference's matching cost, never imported by the product.
 
 Follows models/richsem/matcher.py:49-78 (HungarianMatcher.forward) and util/box_ops.py:9-59 (box_cxcywh_to_xyxy, box_iou,
-generalized_box_iou; torchvision's box_area is (x1 - x0) * (y1 - y0)).  **Parity unpinned**: the reference module imports
-util.box_ops, which imports torchvision (absent from the image), and the reference holds no test or fixture for the matcher; this
-file follows the source text only.  tests/test_oracle_matcher.py additionally checks it against the same formula written with
-torch CPU ops (torch.cdist, sigmoid, ...), which pins the arithmetic of everything but box_area.
+generalized_box_iou; torchvision's box_area is (x1 - x0) * (y1 - y0)).  **PINNED** (round 3): tests/golden/matcher_hungarian.npz holds the
+cost blocks the reference's own HungarianMatcher handed to scipy and the assignments it returned (tests/golden/make_golden_matcher.py
+executes the reference's matcher.py and box_ops functions; the one third-party function they need, torchvision.ops.boxes.box_area --
+torchvision is absent from the image --, is restated there from its published definition); tests/test_oracle_matcher.py holds this file
+to them (1e-12 in fp64, 2e-5 in fp32, equal assignments) and, as before, to the same formula written with torch CPU ops.
 """
 import numpy as np
 from scipy.optimize import linear_sum_assignment

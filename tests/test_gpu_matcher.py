@@ -1,5 +1,5 @@
 """GPU (-m gpu): the matcher's cost blocks (msda_matcher_cost_*) against the numpy oracle
-(oracle/matcher_oracle.py: reference models/richsem/matcher.py:49-78; parity unpinned, see its header) and the mirror class's
+(oracle/matcher_oracle.py: reference models/richsem/matcher.py:49-78; pinned by tests/golden/matcher_hungarian.npz, see its header), that fixture, and the mirror class's
 assignments against the oracle's."""
 import os
 import sys
@@ -91,3 +91,26 @@ def test_errors_and_edges():
     got = cost_blocks(torch.from_numpy(logits).cuda(), torch.from_numpy(boxes).cuda(), plan, 2.0, 5.0, 2.0, 0.25).cpu().numpy()
     block = got[: logits.shape[1] * len(labels[0])].reshape(logits.shape[1], -1)
     assert np.isnan(block[:, 1]).all() and not np.isnan(np.delete(block, 1, axis=1)).any()
+
+
+def test_mirror_equals_the_reference_matcher_fixture():
+    """richsem_amd.matcher.HungarianMatcher on the GPU against tests/golden/matcher_hungarian.npz: the cost blocks the reference's
+    HungarianMatcher handed to scipy (to 1e-12 / 2e-5) and the assignments it returned (equal)"""
+    from richsem_amd.matcher import CostPlan, HungarianMatcher, cost_blocks
+    from tests.test_oracle_matcher import _fixture_cases
+    for tag, tol, logits, boxes, labels, tboxes, offs, blocks, idx in _fixture_cases():
+        tdt = torch.float64 if tag == "f64" else torch.float32
+        targets = to_targets(labels, tboxes, "cuda", tdt)
+        plan = CostPlan(targets, torch.device("cuda"), tdt)
+        got = cost_blocks(torch.from_numpy(logits).cuda(), torch.from_numpy(boxes).cuda(), plan, W["cost_class"], W["cost_bbox"],
+                          W["cost_giou"], 0.25).cpu().numpy()
+        nq = logits.shape[1]
+        for b, want in enumerate(blocks):
+            block = got[nq * offs[b]: nq * offs[b + 1]].reshape(nq, -1)
+            assert block.shape == want.shape
+            if want.size:
+                assert np.abs(block - want).max() <= tol * max(np.abs(want).max(), 1.0), tag
+        res = HungarianMatcher(**W, focal_alpha=0.25)({"pred_logits": torch.from_numpy(logits).cuda(), "pred_boxes": torch.from_numpy(boxes).cuda()},
+                                                     targets)
+        for (gi, gj), (wi, wj) in zip(res, idx):
+            assert gi.tolist() == wi.tolist() and gj.tolist() == wj.tolist(), tag

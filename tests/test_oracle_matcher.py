@@ -113,3 +113,32 @@ def _worker(rank, world, port):
 def test_num_boxes_and_loss_log_two_gloo_ranks():
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _fixture_cases():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "matcher_hungarian.npz"))
+    for tag, tol in (("f64", 1e-12), ("f32", 2e-5)):
+        sizes = z[f"{tag}.sizes"].tolist()
+        offs = np.concatenate(([0], np.cumsum(sizes)))
+        labels = [z[f"{tag}.labels"][offs[b]:offs[b + 1]] for b in range(len(sizes))]
+        tboxes = [z[f"{tag}.tgt_boxes"][offs[b]:offs[b + 1]] for b in range(len(sizes))]
+        blocks = [z[f"{tag}.block{b}"] for b in range(len(sizes))]
+        idx = [(z[f"{tag}.idx_i{b}"], z[f"{tag}.idx_j{b}"]) for b in range(len(sizes))]
+        yield tag, tol, z[f"{tag}.logits"], z[f"{tag}.boxes"], labels, tboxes, offs, blocks, idx
+
+
+def test_oracle_equals_the_reference_matcher_fixture():
+    """oracle/matcher_oracle.py against tests/golden/matcher_hungarian.npz: the cost blocks the REFERENCE's HungarianMatcher handed to
+    scipy and the assignments it returned (tests/golden/make_golden_matcher.py: the reference's matcher.py and box_ops functions,
+    executed with torchvision's box_area restated) -- ragged targets, an image without targets, fp64 and fp32"""
+    for tag, tol, logits, boxes, labels, tboxes, offs, blocks, idx in _fixture_cases():
+        full = MO.cost_matrix(logits, boxes, np.concatenate(labels), np.concatenate(tboxes), cost_class=2.0, cost_bbox=5.0, cost_giou=2.0,
+                              focal_alpha=0.25)
+        for b, want in enumerate(blocks):
+            got = full[b][:, offs[b]:offs[b + 1]]
+            assert got.shape == want.shape and got.dtype == want.dtype
+            if want.size:
+                assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1.0), tag
+        res = MO.match(logits, boxes, labels, tboxes, cost_class=2.0, cost_bbox=5.0, cost_giou=2.0)
+        for (gi, gj), (wi, wj) in zip(res, idx):
+            assert gi.tolist() == wi.tolist() and gj.tolist() == wj.tolist(), tag
