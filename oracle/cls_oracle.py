@@ -2,8 +2,11 @@
 
 Follows models/richsem/richsem.py:176-184 (the classifier's forward with a bias-free linear ``dino_visual_proj``, :75-83) and
 models/richsem/deformable_transformer.py:368-372 (row maximum, top-k), written the plain way: project, normalise, multiply with the
-normalised text embeddings, scale, take the maximum.  **Parity unpinned**: richsem.py imports clip / torchvision / detectron2 at module
-level (absent from the image) and the reference holds no fixture for this step; the oracle follows the source text."""
+normalised text embeddings, scale, take the maximum.  **PINNED** (round 3): tests/golden/cls_clipalign.npz was produced by the reference's
+own ``CLIPAlign.forward`` (the class cut out of richsem.py with ``ast`` -- the module imports clip / torchvision / detectron2, absent from
+the image -- and given seeded ``dino_visual_proj`` / ``text_embed`` / ``logit_scale``; tests/golden/make_golden_cls.py) followed by the
+reference's ``.max(-1)[0]`` and ``torch.topk``; tests/test_oracle_cls.py holds this file to it (1e-12 in fp64, 2e-5 in fp32, identical
+selection)."""
 import numpy as np
 
 

@@ -88,3 +88,25 @@ def test_errors():
     with pytest.raises(RuntimeError, match="float32 / bfloat16"):
         sc.max_logits(torch.zeros(1, 256, device="cuda", dtype=torch.float64))
     assert sc.max_logits(torch.zeros(0, 256, device="cuda")).shape == (0,)
+
+
+def test_scorer_equals_the_reference_classifier_fixture():
+    """ClassScorer (one MFMA kernel + the top-k kernel) against tests/golden/cls_clipalign.npz, produced by the reference's own
+    CLIPAlign.forward followed by .max(-1)[0] and torch.topk (deformable_transformer.py:368-372): scores to the fp32-level tolerance of
+    the split-bf16 product, selections equal except among scores within that tolerance of the k-th"""
+    from tests.test_oracle_cls import cases
+    for tag, _, c in cases():
+        mem = torch.from_numpy(c["memory"]).float().cuda()
+        sc = scorer(c["proj_weight"].astype(np.float32), c["text_embed"].astype(np.float32), float(c["logit_scale"]), 2)
+        got = sc.max_logits(mem).cpu().numpy()
+        want = c["scores"].astype(np.float64)
+        spread = np.abs(want).max()
+        assert np.abs(got - want).max() <= 2e-5 * spread, tag
+        k = c["topk"].shape[1]
+        idx = sc.topk_proposals(mem, k).cpu().numpy()
+        for b in range(idx.shape[0]):
+            a, r = set(idx[b].tolist()), set(c["topk"][b].tolist())
+            kth = want[b][c["topk"][b][-1]]
+            for i in a ^ r:
+                assert abs(want[b][i] - kth) <= 4e-5 * spread
+            assert len(a ^ r) <= 4
