@@ -207,3 +207,16 @@ def test_input_projection_carries_the_reference_names_when_nested():
     # and as the root module the keys are the list's own
     assert set(InputProjection(in_channels=(16,), hidden=32, num_levels=2, groups=4).state_dict().keys()) == \
         {f"{l}.{i}.{n}" for l in range(2) for i in (0, 1) for n in ("weight", "bias")}
+
+
+def test_fold_bn_matches_the_reference_frozen_batchnorm():
+    """richsem_amd.conv.fold_bn (the scale / shift every backbone convolution's epilogue applies) against the reference's own
+    FrozenBatchNorm2d.forward (tests/golden/make_golden_frozenbn.py -> frozenbn_fold.npz)"""
+    import os
+    import numpy as np
+    from richsem_amd.conv import fold_bn
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frozenbn_fold.npz"))
+    t = {k: torch.from_numpy(z[k]) for k in z.files}
+    scale, shift = fold_bn(t["weight"], t["bias"], t["running_mean"], t["running_var"])
+    y = t["x"] * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    assert torch.allclose(y, t["y"], rtol=1e-6, atol=1e-6)
