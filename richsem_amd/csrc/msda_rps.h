@@ -575,6 +575,7 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
     Item it = item_geom(item_id);
     int par = 0;
     fetch_rows(it);
+    for (int i = tid; i < kRpsMaxPx * kRpsSumStride / 2; i += kRpsThreads) reinterpret_cast<double2 *>(S->sum)[i] = make_double2(0.0, 0.0);
 
     while (item_id < n_items) {
         if (tid == 0) {
@@ -586,9 +587,8 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
         const int n_chunks = it.live ? (n_ent + kRpsChunk - 1) / kRpsChunk : 0;
         const int bq0 = b * g.Lq;
         float *const vt = S->vtile;
-        // (the item's value rows were requested before the previous item's sums were stored -- before the loop for the first item)
-        for (int i = tid; i < kRpsMaxPx * kRpsSumStride / 2; i += kRpsThreads)
-            reinterpret_cast<double2 *>(S->sum)[i] = make_double2(0.0, 0.0);
+        // (the item's value rows were requested before the previous item's sums were stored -- before the loop for the first item;
+        // the f64 sums are zero: cleared before the loop, and by the lanes that read them out at the end of every item)
         __syncthreads();
         const int next_id = rps_uni(S->item_slot[par ^ 1]);
         unsigned next_bin;
@@ -859,11 +859,13 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                 const int gr = pxc / gw, gc = pxc - gr * gw;
                 const int prow = R0 + gr, pcol = C0 + gc;
                 const bool in_tile = px < npx && prow < R1 && pcol < C1;
-                const double *src = S->sum + pxc * kRpsSumStride + j4;
+                double *src = S->sum + pxc * kRpsSumStride + j4;
                 const int64_t px_off = ((int64_t)(b * g.S + g.lv[l].start + prow * W + pcol) * g.M + m) * kRpsD;
                 TV *const dst = in_tile ? grad_value + px_off : reinterpret_cast<TV *>(dummy_w) + 4 * lane - c_lo;
                 st4(dst + c_lo, make_float4((float)src[0], (float)src[4], (float)src[8], (float)src[12]));
                 st4(in_tile ? dst + c_hi : dst + c_lo, make_float4((float)src[16], (float)src[20], (float)src[24], (float)src[28]));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) src[4 * k] = 0.0;      // (read out: zero for the next work item)
             }
         } else if (n_chunks > 0) {
             // several workgroups share the tile: its rows are ADDED to the (pre-zeroed) level, one channel per lane, so that a wave
@@ -872,7 +874,9 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
             const int64_t tile_base = ((int64_t)(b * g.S + g.lv[l].start) * g.M + m) * kRpsD + c32;
             for (int p = tid >> 5; p < npx; p += kRpsThreads / 32) {
                 const int pr = p / gw, row = R0 + pr, col = C0 + (p - pr * gw);
-                const float x = (float)S->sum[p * kRpsSumStride + (c32 & 16) + 4 * (c32 & 3) + ((c32 & 15) >> 2)];
+                double *const sp = S->sum + p * kRpsSumStride + (c32 & 16) + 4 * (c32 & 3) + ((c32 & 15) >> 2);
+                const float x = (float)*sp;
+                *sp = 0.0;
                 if (row < R1 && col < C1 && x != 0.f) atomicAdd(grad_acc + tile_base + (int64_t)(row * W + col) * row_elems, x);
             }
         }
