@@ -134,6 +134,10 @@ class Step(nn.Module):
         self._eo_pack = VersionCache()
         self.timing = True
         self.stop_at = None       # (tools/capture_probe.py: end the step after this section with a surrogate loss)
+        # bfloat16: the library's bf16 rows (the step bench.py times).  float32: the SAME parameters through the reference's op sequence in
+        # fp32 from the input projections on (PyTorch ops around the operator's fp32 entry points; the backbone stays on the bf16
+        # convolution kernels, its output is cast) -- the yardstick of tests/test_gpu_step.py
+        self.act_dtype = torch.bfloat16
 
     # synthetic LVIS-shaped batch
     def batch(self, seed=0):
@@ -190,7 +194,9 @@ class Step(nn.Module):
         self.static = st
         return st
 
-    def forward(self, images, mask, targets, indices=None):
+    def forward(self, images, mask, targets, indices=None, topk=None):
+        """``indices``: the matcher's assignment held fixed (graph capture, A/B tests); ``topk``: the two-stage selection held fixed"""
+        adt = self.act_dtype
         self._events = []
         self._mark("start")
         N, dev = images.shape[0], images.device
@@ -201,10 +207,10 @@ class Step(nn.Module):
         self._mark("backbone")
         if self.stop_at == "backbone":
             return sum(f.float().sum() for f in feats)
-        srcs, got_shapes = self.input_proj(feats, out_dtype=torch.bfloat16)
+        srcs, got_shapes = self.input_proj(feats, out_dtype=adt)
         assert got_shapes == shapes
         src = torch.cat(srcs, 1)
-        pos_flat = (st["pos_sine"] + st["level_onehot"] @ self.level_embed).to(torch.bfloat16)           # sine part + level embedding (:596-612)
+        pos_flat = (st["pos_sine"] + st["level_onehot"] @ self.level_embed).to(adt)           # sine part + level embedding (:596-612)
         self._mark("input_proj")
         if self.stop_at == "input_proj":
             return src.float().sum() + pos_flat.float().sum()
@@ -218,11 +224,16 @@ class Step(nn.Module):
             return memory.float().sum()
         # ---- two-stage query selection (:352-380) ----------------------------------------------------------------------------------
         eo = self.enc_output
-        pk = self._eo_pack.get((eo.weight, eo.bias), lambda: pack_linear256([eo.weight], [eo.bias]))
-        output_memory = Lin256Function.apply(memory.masked_fill(st["zeroed"], 0.0), pk, None, False, eo.weight, eo.bias)   # bf16, lin256
-        output_memory = F.layer_norm(output_memory, (256,), self.enc_output_norm.weight.to(torch.bfloat16),
-                                     self.enc_output_norm.bias.to(torch.bfloat16), self.enc_output_norm.eps)
-        topk = self.scorer.topk_proposals(output_memory, NUM_QUERIES)                                  # no logit tensor (two_stage.py)
+        if adt == torch.bfloat16:
+            pk = self._eo_pack.get((eo.weight, eo.bias), lambda: pack_linear256([eo.weight], [eo.bias]))
+            output_memory = Lin256Function.apply(memory.masked_fill(st["zeroed"], 0.0), pk, None, False, eo.weight, eo.bias)   # bf16, lin256
+        else:
+            output_memory = eo(memory.masked_fill(st["zeroed"], 0.0))
+        output_memory = F.layer_norm(output_memory, (256,), self.enc_output_norm.weight.to(adt), self.enc_output_norm.bias.to(adt),
+                                     self.enc_output_norm.eps)
+        if topk is None:
+            topk = self.scorer.topk_proposals(output_memory, NUM_QUERIES)                              # no logit tensor (two_stage.py)
+        self.last_topk = topk
         coord_unselected = self.enc_out_bbox_embed(output_memory).float() + st["proposals"]
         refpoint_undetach = torch.gather(coord_unselected, 1, topk[..., None].expand(-1, -1, 4))
         tgt_undetach = torch.gather(output_memory, 1, topk[..., None].expand(-1, -1, 256)).float()
@@ -255,7 +266,7 @@ class Step(nn.Module):
         if self.stop_at == "dn":
             return tgt.sum() + refpoints.sum() + interm['pred_logits'].sum() + interm['pred_boxes'].sum()
         # ---- decoder (:427) -----------------------------------------------------------------------------------------------------------
-        hs, refs = self.decoder(tgt=tgt.transpose(0, 1).to(torch.bfloat16), memory=memory.transpose(0, 1), tgt_mask=lay["attn_mask"],
+        hs, refs = self.decoder(tgt=tgt.transpose(0, 1).to(adt), memory=memory.transpose(0, 1), tgt_mask=lay["attn_mask"],
                                 memory_key_padding_mask=mask_flat, refpoints_unsigmoid=refpoints.transpose(0, 1), level_start_index=lsi,
                                 spatial_shapes=spatial, valid_ratios=valid_ratios)
         self._mark("decoder")
@@ -366,20 +377,31 @@ def run(n_img, dev, steps=5, warmup=2, graph=True, stop_at=None):
         loss.backward()
         return loss, fwd
 
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
+    # Everything -- warm-up, the timed eager steps, the capture -- runs on ONE side stream (round 4).  An autograd graph pins every
+    # parameter's AccumulateGrad node to the stream it was built on; round 3 built the eager steps on the default stream and captured on
+    # another one with the last step's `loss` still referenced: the engine then synchronises the capture stream with the foreign stream
+    # inside the capture ("AccumulateGrad node's stream does not match ..."), and this ROCm build segfaults in hipStreamEndCapture instead
+    # of failing the capture (tools/capture_crash_probe.py, profiles/r04_capture_probe.txt: only the variants that keep `loss` alive crash,
+    # and none does when the eager phase already ran on the capture stream).  The library's workspaces are per (device, stream) as well:
+    # a capture on a cold stream records the fallback kernels (round 3's 31.0 ms against 27.1 ms on the warmed stream).
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
     rows, totals, bwds = {}, [], []
-    for _ in range(steps):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        loss, fwd = step()
-        b.record()
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            step()
         torch.cuda.synchronize()
-        totals.append(a.elapsed_time(b))
-        bwds.append(fwd.elapsed_time(b))
-        for k, v in model.section_ms().items():
-            rows.setdefault(k, []).append(v)
+        for _ in range(steps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            loss, fwd = step()
+            b.record()
+            torch.cuda.synchronize()
+            totals.append(a.elapsed_time(b))
+            bwds.append(fwd.elapsed_time(b))
+            for k, v in model.section_ms().items():
+                rows.setdefault(k, []).append(v)
+    torch.cuda.current_stream().wait_stream(side)
     ms = sum(totals) / len(totals)
     out = {"what": "ONE composed training step on the library's rows at configs[1] sizes: ResNet-50 (layer2-4 trained) -> input projections "
                    "-> 6 encoder layers -> two-stage score + top-900 -> denoising layout -> 6 decoder layers -> heads -> frozen CLIP-RN50 "
@@ -391,24 +413,18 @@ def run(n_img, dev, steps=5, warmup=2, graph=True, stop_at=None):
     if not graph:
         return out
     # the device part as a captured graph: the assignment of the last eager step held fixed (the matcher's host round trip cannot be captured)
-    import gc
     indices = [[(i.to(dev), j.to(dev)) for i, j in idx] for idx in model.last_indices]      # (no host -> device copies in the capture)
-    del loss, fwd, a, b             # (with the eager steps' timing events / loss still alive, ending the capture crashes in this ROCm build)
-    gc.collect()
     model.timing = False
 
     def replay_ms(stop_at):
         """capture the step cut off after section `stop_at` (None: all of it) into a HIP graph; ms per replay"""
         model.stop_at = stop_at
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
+        with torch.cuda.stream(side):
             for _ in range(2):
                 step(indices)
-        torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, stream=side):      # the stream that was warmed up
             step(indices)
         g.replay()
         torch.cuda.synchronize()

@@ -394,6 +394,11 @@ struct Workspace {
     msda::RpsRec *rps_entries = nullptr;     // [cap] routed records
     size_t rps_entries_cap = 0;
     bool rps_dirty = false;                  // a failed launch may have left the bin counters non-zero
+    // Buffers outgrown by a later, larger call are RETIRED, not freed: a HIP graph captured earlier on this stream holds their raw
+    // addresses (kernel arguments), and a replay after a hipFree would read and write freed memory.  They live until the process ends;
+    // growth is geometric (x 1.5), so the retired total stays below twice the live size.
+    std::vector<void *> retired;
+    void retire(void *p) { if (p) retired.push_back(p); }
 };
 std::mutex g_ws_mu;
 std::map<std::pair<int, hipStream_t>, Workspace> g_ws;
@@ -427,7 +432,7 @@ bool rps_workspace(hipStream_t stream, size_t n_bins, size_t n_runs, size_t n_en
         if (ws.rps_bins_n < n_bins) {
             const size_t cap_n = n_bins + n_bins / 2 + 64;
             const size_t want_bins = 32 + (size_t)msda::kRpsPad * cap_n + 8;
-            if (ws.rps_bins) (void)hipFree(ws.rps_bins);
+            ws.retire(ws.rps_bins);
             ws.rps_bins = nullptr;
             ws.rps_bins_cap = ws.rps_bins_n = 0;
             if (hipMalloc(reinterpret_cast<void **>(&ws.rps_bins), want_bins * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -440,7 +445,7 @@ bool rps_workspace(hipStream_t stream, size_t n_bins, size_t n_runs, size_t n_en
             ws.rps_dirty = false;
         }
         if (ws.rps_runs_cap < n_runs) {
-            if (ws.rps_runs) (void)hipFree(ws.rps_runs);
+            ws.retire(ws.rps_runs);
             ws.rps_runs = nullptr;
             ws.rps_runs_cap = 0;
             const size_t want = n_runs + n_runs / 2 + 1024;
@@ -448,11 +453,12 @@ bool rps_workspace(hipStream_t stream, size_t n_bins, size_t n_runs, size_t n_en
             ws.rps_runs_cap = want;
         }
         if (ws.rps_entries_cap < n_entries) {   // (+ the tile kernel's scratch lines behind the records)
-            if (ws.rps_entries) (void)hipFree(ws.rps_entries);
+            ws.retire(ws.rps_entries);
             ws.rps_entries = nullptr;
             ws.rps_entries_cap = 0;
-            if (hipMalloc(reinterpret_cast<void **>(&ws.rps_entries), n_entries * sizeof(msda::RpsRec) + msda::kRpsDummyBytes) != hipSuccess) { (void)hipGetLastError(); return false; }
-            ws.rps_entries_cap = n_entries;
+            const size_t want = n_entries + n_entries / 2;
+            if (hipMalloc(reinterpret_cast<void **>(&ws.rps_entries), want * sizeof(msda::RpsRec) + msda::kRpsDummyBytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+            ws.rps_entries_cap = want;
         }
     }
     out = ws;
@@ -500,9 +506,15 @@ hipError_t launch_bwd_rps(const Problem &pb, const TV *value, const float *loc, 
     const int qpb = qpw * (msda::kRpsRouteThreads / msda::kWave);
     const int64_t r_items = (int64_t)pb.N * pb.M * ((pb.Lq + qpb - 1) / qpb);
     const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(r_items, (int64_t)msda::rps_options().route_wgs.load() * cu_count()));
-    hipLaunchKernelGGL(msda::rps_route_kernel, dim3(rgrid), dim3(msda::kRpsRouteThreads), 0, stream, loc, aw, grad_acc, grad_loc, grad_aw,
-                       pl.g);
+    hipLaunchKernelGGL(msda::rps_route_kernel, dim3(rgrid), dim3(msda::kRpsRouteThreads), (size_t)pl.g.lut_n * sizeof(unsigned), stream, loc, aw,
+                       grad_acc, grad_loc, grad_aw, pl.g);
     const int grid = (cu_count() / msda::kXcds) * msda::kXcds;   // persistent: one workgroup per CU (its LDS is most of a CU's)
+#ifdef RPS_ROUTE_ABLATION
+    if (pl.g.dbg & 0x300) {      // diagnostic: route-pass ablations -- the records are not what the tile kernel expects; wrong results
+        rps_mark_dirty(stream);
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 8), dim3(msda::kRpsThreads), sizeof(msda::RpsLds), stream, value, grad_out,
                        grad_value, grad_acc, grad_loc, grad_aw, pl.g);
     if constexpr (!std::is_same<TV, float>::value) {
@@ -669,11 +681,12 @@ bool bf16_scratch(hipStream_t stream, size_t n_floats, float **out)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(stream, &cap);
         if (cap != hipStreamCaptureStatusNone) return false;
-        if (ws.gv32) (void)hipFree(ws.gv32);
+        ws.retire(ws.gv32);      // (not freed: an earlier capture on this stream may hold the address)
         ws.gv32 = nullptr;
         ws.gv32_cap = 0;
-        if (hipMalloc(reinterpret_cast<void **>(&ws.gv32), n_floats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
-        ws.gv32_cap = n_floats;
+        const size_t want = n_floats + n_floats / 2;
+        if (hipMalloc(reinterpret_cast<void **>(&ws.gv32), want * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
+        ws.gv32_cap = want;
     }
     *out = ws.gv32;
     return true;
@@ -958,7 +971,7 @@ int msda_set_option(const char *key, int value)
     if (key && !strcmp(key, "bwd_direct_cpl") && (value == 0 || value == 1 || value == 2 || value == 4)) { g_bwd_cpl = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_region") && value >= 4 && value <= 64) { msda::tiled_options().region_px = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_margin") && value >= 0 && value <= 32) { msda::tiled_options().margin = value; return MSDA_OK; }
-    if (key && !strcmp(key, "tile_debug") && value >= 0 && value <= 255) { msda::tiled_options().dbg = value; return MSDA_OK; }
+    if (key && !strcmp(key, "tile_debug") && value >= 0 && value <= 65535) { msda::tiled_options().dbg = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_persist") && value >= 0 && value <= 65536) { msda::tiled_options().persist = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_levelsum") && (value == 0 || value == 1)) { g_levelsum = value; return MSDA_OK; }
     if (key && !strcmp(key, "levelsum_lds_kb") && value >= 8 && value <= 150) { msda::levelsum_lds_kb() = value; return MSDA_OK; }

@@ -83,11 +83,13 @@ struct RpsGeom {
     unsigned entries_cap;   // records the pool holds (4 x points: exact worst case); indices are clamped to it, so that counters left
                             // dirty by an aborted call can give wrong results but never an access outside the pool
     struct RpsRec *entries;         // one 16-byte record per (point, bin it was routed to)
+    int lut_r[kRpsMaxL], lut_c[kRpsMaxL], lut_n;      // route pass: where the levels' row / column tables start in LDS, their total length
     int seg_shift;                  // a pixel's list is walked in units of at most 1 << seg_shift points (>= kRpsSegShift)
     float *dummy;                   // kRpsDummyBytes of scratch: where the lanes that have nothing to store send their stores
                                     // (every store instruction is then issued unconditionally: see rps_tile_kernel)
     unsigned long long *stamps;     // diagnostic runs only (msda_debug_stamps)
-    int dbg;                        // diagnostic: bits 4..6 = 1 + level -> only that level's tiles do any work (wrong results); bit 3: walk units in list order (A/B of the length classes)
+    int dbg;                        // diagnostic: bits 4..6 = 1 + level -> only that level's tiles do any work (wrong results); bit 3: walk units in list order (A/B of the length classes);
+                                    // bits 8..9, builds with -DRPS_ROUTE_ABLATION only: route-pass ablations (the tile kernel is not launched): 256 no record stores, 512 4-byte records
 };
 
 struct alignas(16) RpsEnt {   // one sampling point in the list of its base pixel; overwritten by its four corner dots
@@ -149,66 +151,32 @@ __device__ __forceinline__ int rps_wave_scan(int v)
         S->stamp_last = now_;                                                          \
     }
 
-// The one place where a sampling position is turned into pixel coordinates: route and reduce must agree bit for bit.
-struct RpsPos {
-    float h_im, w_im;
-    int h_low, w_low;
-    bool valid;
-};
-__device__ __forceinline__ RpsPos rps_position(float x, float y, int H, int W)
+// Where a sampling position falls, per level, comes from two small tables in LDS (round 4) -- one entry per base row r = h_low + 1 in
+// [0, H] and one per base column c = w_low + 1 in [0, W] -- instead of ~35 vector instructions of tile arithmetic per point and level
+// (the route pass is bound by instruction issue: ~2400 instructions per wave and work item before, profiles/r04_route_ablation.md):
+//   row entry     gr (bits 0..4) | down << 5 | inr << 6 | (ty * ntx * nslab) << 8
+//   column entry  gc (bits 0..4) | right << 5 | inc << 6 | (tx * nslab) << 8 | gw << 17 | gw2 << 22
+// gr / gc: base-grid row / column inside the owner tile; down / right: the point's lower / right corners belong to the next tile;
+// inr / inc: bit 0 = upper / left corner inside the map, bit 1 = lower / right corner inside the map; gw: width of the owner tile's
+// grid; gw2: width of the right neighbour's grid.  The tile grid is the one the host plans (RpsLevel) and the tile kernel's work items use.
+__device__ __forceinline__ unsigned rps_lut_row(const RpsLevel &v, int r)
 {
-    RpsPos p;
-    p.h_im = y * (float)H - 0.5f;
-    p.w_im = x * (float)W - 0.5f;
-    p.valid = p.h_im > -1.f && p.w_im > -1.f && p.h_im < (float)H && p.w_im < (float)W;
-    p.h_low = (int)floorf(p.h_im);
-    p.w_low = (int)floorf(p.w_im);
-    return p;
+    const int h_low = r - 1, br = max(h_low, 0);
+    const int ty = (int)(((float)br + 0.5f) * v.inv_TH);
+    const int R0 = ty * v.TH, R1 = min(v.H, R0 + v.TH);
+    const unsigned gr = (unsigned)(h_low - R0 + 1), down = h_low == R1 - 1 && R1 < v.H ? 1u : 0u;
+    const unsigned inr = (h_low >= 0 ? 1u : 0u) | (h_low + 1 < v.H ? 2u : 0u);
+    return gr | down << 5 | inr << 6 | (unsigned)(ty * v.ntx * v.nslab) << 8;
 }
-
-// One sampling point at one level: the bins (pair-local ids) it is appended to and its position inside each tile.
-struct RpsTarget {
-    int bin[4];           // [0] owner tile, [1] tile below, [2] tile to the right, [3] below-right; -1 = none
-    unsigned pbase[4];    // base-grid index inside that tile
-    unsigned inmap;       // corners inside the map (owner entry): bit 0 TL, 1 TR, 2 BL, 3 BR
-    float lh, lw;
-    bool valid;           // false: the reference drops the sample (ms_deform_im2col_cuda.cuh:285-291)
-};
-__device__ __forceinline__ RpsTarget rps_targets(float x, float y, const RpsLevel &v, int slab)
+__device__ __forceinline__ unsigned rps_lut_col(const RpsLevel &v, int c)
 {
-    RpsTarget t;
-    t.bin[0] = t.bin[1] = t.bin[2] = t.bin[3] = -1;
-    t.pbase[0] = t.pbase[1] = t.pbase[2] = t.pbase[3] = 0u;
-    t.inmap = 0u;
-    const RpsPos p = rps_position(x, y, v.H, v.W);
-    t.valid = p.valid;
-    t.lh = p.h_im - (float)p.h_low;
-    t.lw = p.w_im - (float)p.w_low;
-    if (p.valid) {
-        const int br = max(p.h_low, 0), bc = max(p.w_low, 0);
-        const int ty = (int)(((float)br + 0.5f) * v.inv_TH), tx = (int)(((float)bc + 0.5f) * v.inv_TW);
-        const int R0 = ty * v.TH, C0 = tx * v.TW;
-        const int R1 = min(v.H, R0 + v.TH), C1 = min(v.W, C0 + v.TW);
-        const int gr = p.h_low - R0 + 1, gc = p.w_low - C0 + 1;   // base-grid position in the owner tile
-        const int ns = v.nslab;
-        t.bin[0] = v.bin0 + (ty * v.ntx + tx) * ns + slab;
-        t.inmap = (p.h_low >= 0 && p.w_low >= 0 ? 1u : 0u) | (p.h_low >= 0 && p.w_low + 1 < v.W ? 2u : 0u) |
-                  (p.h_low + 1 < v.H && p.w_low >= 0 ? 4u : 0u) | (p.h_low + 1 < v.H && p.w_low + 1 < v.W ? 8u : 0u);
-        t.pbase[0] = (unsigned)(gr * (C1 - C0 + 1) + gc);
-        // lower / right corners beyond the tile's edge belong to the next tile: there the point sits in row / column 0
-        const bool down = p.h_low == R1 - 1 && R1 < v.H, right = p.w_low == C1 - 1 && C1 < v.W;
-        if (down) {
-            t.bin[1] = t.bin[0] + v.ntx * ns;
-            t.pbase[1] = (unsigned)gc;   // row 0 of a tile with the same columns
-        }
-        if (right) {
-            const int gw2 = min(v.W, C1 + v.TW) - C1 + 1;
-            t.bin[2] = t.bin[0] + ns;
-            t.pbase[2] = (unsigned)(gr * gw2);
-        }
-        if (down && right) t.bin[3] = t.bin[0] + (v.ntx + 1) * ns;
-    }
-    return t;
+    const int w_low = c - 1, bc = max(w_low, 0);
+    const int tx = (int)(((float)bc + 0.5f) * v.inv_TW);
+    const int C0 = tx * v.TW, C1 = min(v.W, C0 + v.TW);
+    const unsigned gc = (unsigned)(w_low - C0 + 1), right = w_low == C1 - 1 && C1 < v.W ? 1u : 0u;
+    const unsigned inc = (w_low >= 0 ? 1u : 0u) | (w_low + 1 < v.W ? 2u : 0u);
+    const unsigned gw = (unsigned)(C1 - C0 + 1), gw2 = (unsigned)(min(v.W, C1 + v.TW) - C1 + 1);
+    return gc | right << 5 | inc << 6 | (unsigned)(tx * v.nslab) << 8 | gw << 17 | gw2 << 22;
 }
 
 // Route pass (ONE pass: no counting pass, no prefix pass).  A workgroup takes a block of consecutive queries of one (image, head);
@@ -229,19 +197,25 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
                                                                      float *__restrict__ grad_value, float *__restrict__ grad_loc,
                                                                      float *__restrict__ grad_aw, const RpsGeom g)
 {
-    __shared__ unsigned hist[kRpsMaxUnits], base[kRpsMaxUnits];
+    __shared__ unsigned hist[kRpsMaxUnits], base[512];
     __shared__ unsigned wtot[kRpsRouteThreads / kWave];
+    __shared__ unsigned sink[kWave];           // where the lanes that have nothing to count send their (zero) LDS atomics: see stage A
+    extern __shared__ unsigned rps_lut[];      // [g.lut_n]: row tables, then column tables, of the levels (offsets g.lut_r / g.lut_c)
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int B = g.bins_per_pair;
     {
         const int gtid = blockIdx.x * blockDim.x + tid, gsz = gridDim.x * blockDim.x;
         if (gtid < 8) g.ctr[gtid] = 0u;
+        if (tid < kWave) sink[tid] = 0u;
         const int row4 = g.M * kRpsD / 4;   // float4 per pixel
         for (int l = 0; l < g.L; ++l) {
-            if (!g.lv[l].atomic) continue;
-            const int n4 = g.lv[l].H * g.lv[l].W * row4;
+            const RpsLevel &v = g.lv[l];
+            for (int i = tid; i <= v.H; i += kRpsRouteThreads) rps_lut[g.lut_r[l] + i] = rps_lut_row(v, i);
+            for (int i = tid; i <= v.W; i += kRpsRouteThreads) rps_lut[g.lut_c[l] + i] = rps_lut_col(v, i);
+            if (!v.atomic) continue;
+            const int n4 = v.H * v.W * row4;
             for (int b = 0; b < g.N; ++b) {
-                float4 *dst = reinterpret_cast<float4 *>(grad_value) + (size_t)(b * g.S + g.lv[l].start) * row4;
+                float4 *dst = reinterpret_cast<float4 *>(grad_value) + (size_t)(b * g.S + v.start) * row4;
                 for (int i = gtid; i < n4; i += gsz) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -254,71 +228,136 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
     const int pairs = g.N * g.M;
     const int n_items = pairs * qblocks;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // (diagnostic, msda_debug_stamps: shader cycles of thread 0 per stage, rows 1024 + blockIdx.x of the stamp buffer)
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = g.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+#define RPS_RSTAMP(i)                                                  \
+    if (g.stamps) {                                                    \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+        st_acc[i] += now_ - st_last;                                   \
+        st_last = now_;                                                \
+    }
+    // The pass is a chain of round trips -- memory for the operands, LDS for the tables, the ballots' shuffles and the ranking atomics --
+    // with a few hundred instructions between them (round 4, tools/rps_stamps.py: waiting for the operands was a third of a work item,
+    // the per-level chains of stage A a quarter).  So the locations of the NEXT item are requested as soon as this item's are consumed
+    // (their registers are free then), and every stage issues the LDS operations of all four levels before it waits for any of them:
+    // lanes that have nothing to count add zero to a word of their own (`sink`) instead of branching around the atomic.
+    float2 xy[kRpsMaxL];
+    auto item_point = [&](int item_, bool &live_, int &q_) {      // -> index of the lane's point at level 0
+        const int it_ = min(item_, n_items - 1);
+        const int pair_ = it_ % pairs, qb_ = it_ / pairs;
+        const int b_ = pair_ / g.M, m_ = pair_ - b_ * g.M;
+        q_ = qb_ * qpb + wave * qpw + ql;
+        live_ = item_ < n_items && ql < qpw && pp < P && q_ < g.Lq;
+        return (unsigned)(((b_ * g.Lq + (live_ ? q_ : 0)) * g.M + m_) * LP + min(pp, P - 1));      // (a valid index whatever the lane)
+    };
+    // (loads are unconditional, from clamped addresses: hipcc waits for a conditional load right behind it; `live` masks the result)
+    auto request_xy = [&](int item_) {
+        bool live_;
+        int q_;
+        const unsigned pt0_ = item_point(item_, live_, q_);
+#pragma unroll
+        for (int l = 0; l < kRpsMaxL; ++l) xy[l] = *reinterpret_cast<const float2 *>(loc + 2u * (pt0_ + (unsigned)(min(l, g.L - 1) * P)));
+    };
+    request_xy(blockIdx.x);
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {   // (uniform)
         const int pair = item % pairs, qb = item / pairs;               // neighbouring workgroups: different pairs (different bins)
-        const int b = pair / g.M, m = pair - b * g.M;
         for (int i = tid; i < B; i += kRpsRouteThreads) hist[i] = 0u;
-        const int q = qb * qpb + wave * qpw + ql;
-        const bool live = ql < qpw && pp < P && q < g.Lq;
-        const unsigned pt0 = (unsigned)(((b * g.Lq + (live ? q : 0)) * g.M + m) * LP + pp);
-        // all levels' locations first: one round trip to memory per item, not one per level
-        float2 xy[kRpsMaxL];
-        float at[kRpsMaxL];
-#pragma unroll
-        for (int l = 0; l < kRpsMaxL; ++l) {
-            xy[l] = live && l < g.L ? *reinterpret_cast<const float2 *>(loc + 2u * (pt0 + (unsigned)(l * P))) : make_float2(-4.f, -4.f);
-            at[l] = live && l < g.L ? aw[pt0 + (unsigned)(l * P)] : 0.f;
-        }
-        __syncthreads();
+        bool live;
+        int q;
+        const unsigned pt0 = item_point(item, live, q);
+        __syncthreads();      // (the first item: the tables as well)
+        RPS_RSTAMP(1)
         // ---- A: ranks inside the workgroup ---------------------------------------------------------------------------------------
-        unsigned word[kRpsMaxL][4];   // bin | rank << 9 | pbase << 23; ~0u = no entry
-        unsigned own_rank[kRpsMaxL], inmap[kRpsMaxL];
-        int lead[kRpsMaxL];           // (uniform) lane whose LDS atomic served the matched lanes; -1 = none
-        bool matched[kRpsMaxL];
+        // word[l][k] = bin | rank << 9 | pbase << 23 of the point's entry in [0] its owner tile, [1] the tile below, [2] the tile to the
+        // right, [3] below-right (the few points on a tile's last row / column); ~0u = no entry
+        unsigned word[kRpsMaxL][4];
+        unsigned inmap[kRpsMaxL];
         float lh[kRpsMaxL], lw[kRpsMaxL];
+        unsigned re[kRpsMaxL], ce[kRpsMaxL];
+        unsigned valid_m = 0u, asked_m = 0u, matched_m = 0u;      // per-lane flags, bit l (kept in vector registers: a bool per level and flag costs a pair of scalar registers, and the kernel spills those)
+        unsigned dropped = 0u;      // levels at which the reference drops this point (their zero gradients are stored at the end of the item)
+        // A.1: the sampling positions (reference ms_deform_im2col_cuda.cuh:276-285: dropped unless -1 < h_im < H and -1 < w_im < W) and
+        //      their table entries
 #pragma unroll
         for (int l = 0; l < kRpsMaxL; ++l) {
-            word[l][0] = word[l][1] = word[l][2] = word[l][3] = ~0u;
-            own_rank[l] = 0u;
-            inmap[l] = 0u;
-            lead[l] = -1;
-            matched[l] = false;
             lh[l] = lw[l] = 0.f;
+            re[l] = ce[l] = 0u;
             if (l >= g.L) continue;   // (uniform)
             const RpsLevel &v = g.lv[l];
-            RpsTarget t;
-            t.bin[0] = t.bin[1] = t.bin[2] = t.bin[3] = -1;
-            t.valid = true;
-            if (live) t = rps_targets(xy[l].x, xy[l].y, v, rps_uni(qb % v.nslab));
-            if (live && !t.valid) {   // dropped sample: zero gradients
-                const unsigned pt = pt0 + (unsigned)(l * P);
-                grad_aw[pt] = 0.f;
-                *reinterpret_cast<float2 *>(grad_loc + 2u * pt) = make_float2(0.f, 0.f);
-            }
-            lh[l] = t.lh;
-            lw[l] = t.lw;
-            inmap[l] = t.inmap;
-            const int ob = t.bin[0];
-            const unsigned long long vote = __ballot(ob >= 0);
-            if (vote) {   // (uniform)
-                const int ld = __ffsll((long long)vote) - 1;
-                const int lb = __shfl(ob, ld, kWave);
-                const unsigned long long match = __ballot(ob == lb);
-                lead[l] = ld;
-                matched[l] = ob == lb;
-                if (lane == ld) own_rank[l] = atomicAdd(&hist[lb], (unsigned)__popcll(match));
-                else if (ob >= 0 && ob != lb) own_rank[l] = atomicAdd(&hist[ob], 1u);
-                else own_rank[l] = (unsigned)__popcll(match & lt_mask);   // + the leader's result, below
-                if (ob >= 0) word[l][0] = (unsigned)ob | t.pbase[0] << 23;
-            }
-#pragma unroll
-            for (int k = 1; k < 4; ++k)
-                if (t.bin[k] >= 0) {   // the few points on a tile's last row / column
-                    const unsigned r = atomicAdd(&hist[t.bin[k]], 1u);
-                    word[l][k] = (unsigned)t.bin[k] | r << 9 | t.pbase[k] << 23;
-                }
+            const float Hf = (float)v.H, Wf = (float)v.W;
+            const float h_im = xy[l].y * Hf - 0.5f, w_im = xy[l].x * Wf - 0.5f;
+            const bool valid = live && h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
+            valid_m |= valid ? 1u << l : 0u;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            lh[l] = h_im - hf;
+            lw[l] = w_im - wf;
+            dropped |= live && !valid ? 1u << l : 0u;
+            re[l] = rps_lut[g.lut_r[l] + (valid ? (int)hf + 1 : 0)];
+            ce[l] = rps_lut[g.lut_c[l] + (valid ? (int)wf + 1 : 0)];
         }
+        // (xy is consumed: the weights of this item -- needed by the record stores of stage C only -- and the next item's locations
+        // travel under the rest of this one; no other memory operation sits in a branch between here and stage C, so that the waits
+        // for them are counted and never drain the queue)
+        request_xy(item + (int)gridDim.x);
+        float at[kRpsMaxL];
+#pragma unroll
+        for (int l = 0; l < kRpsMaxL; ++l) at[l] = aw[pt0 + (unsigned)(min(l, g.L - 1) * P)];
+        // A.2: owner bins.  Lanes of a wave usually share the owner bin (neighbouring queries, neighbouring points): they are matched
+        //      with one ballot and served by the atomic of one of them; the others take one each.
+        int ob[kRpsMaxL], lead[kRpsMaxL], lb[kRpsMaxL];
+        unsigned own_rank[kRpsMaxL], lt_cnt[kRpsMaxL], n_match[kRpsMaxL];
+#pragma unroll
+        for (int l = 0; l < kRpsMaxL; ++l) {
+            ob[l] = -1;
+            lead[l] = 0;
+            lb[l] = -1;
+            own_rank[l] = lt_cnt[l] = n_match[l] = 0u;
+            inmap[l] = 0u;
+            word[l][0] = word[l][1] = word[l][2] = word[l][3] = ~0u;
+            if (l >= g.L) continue;   // (uniform)
+            const RpsLevel &v = g.lv[l];
+            const int ns = v.nslab;
+            const int slab = ns > 1 ? rps_uni(qb % ns) : 0;
+            ob[l] = (valid_m >> l & 1u) ? v.bin0 + slab + (int)(re[l] >> 8) + (int)((ce[l] >> 8) & 511u) : -1;
+            const unsigned inr = (re[l] >> 6) & 3u, inc = (ce[l] >> 6) & 3u;
+            inmap[l] = ((inr & 1u) ? inc : 0u) | ((inr & 2u) ? inc << 2 : 0u);      // bit 0 TL, 1 TR, 2 BL, 3 BR inside the map
+            const unsigned long long vote = __ballot(ob[l] >= 0);
+            const int ld = vote ? __ffsll((long long)vote) - 1 : 0;      // (uniform)
+            lb[l] = __builtin_amdgcn_readlane(ob[l], ld);               // (-1: no lane of the wave has a point at this level)
+            const unsigned long long match = __ballot(ob[l] == lb[l]);
+            lead[l] = ld;
+            matched_m |= ob[l] == lb[l] && lb[l] >= 0 ? 1u << l : 0u;
+            lt_cnt[l] = (unsigned)__popcll(match & lt_mask);
+            n_match[l] = (unsigned)__popcll(match);
+        }
+#pragma unroll
+        for (int l = 0; l < kRpsMaxL; ++l) {      // (the four atomics back to back: one wait)
+            const bool is_lead = lane == lead[l] && lb[l] >= 0, other = ob[l] >= 0 && ob[l] != lb[l];
+            const bool asked = is_lead || other;
+            asked_m |= asked ? 1u << l : 0u;
+            own_rank[l] = atomicAdd(asked ? &hist[is_lead ? lb[l] : ob[l]] : &sink[lane], is_lead ? n_match[l] : (other ? 1u : 0u));
+        }
+        // A.3: lower / right corners beyond the tile's edge belong to the next tile: there the point sits in row / column 0
+#pragma unroll
+        for (int l = 0; l < kRpsMaxL; ++l) {
+            if (l >= g.L) continue;   // (uniform)
+            const RpsLevel &v = g.lv[l];
+            const int ns = v.nslab;
+            const unsigned gr = re[l] & 31u, gc = ce[l] & 31u;
+            const bool down = (valid_m >> l & 1u) && (re[l] & 32u), right = (valid_m >> l & 1u) && (ce[l] & 32u);
+            const int b1 = ob[l] + v.ntx * ns, b2 = ob[l] + ns, b3 = ob[l] + (v.ntx + 1) * ns;
+            const unsigned r1 = atomicAdd(down ? &hist[b1] : &sink[lane], down ? 1u : 0u);
+            const unsigned r2 = atomicAdd(right ? &hist[b2] : &sink[lane], right ? 1u : 0u);
+            const unsigned r3 = atomicAdd(down && right ? &hist[b3] : &sink[lane], down && right ? 1u : 0u);
+            if (!(asked_m >> l & 1u)) own_rank[l] = lt_cnt[l];      // + the leader's result, below
+            if (ob[l] >= 0) word[l][0] = (unsigned)ob[l] | (gr * ((ce[l] >> 17) & 31u) + gc) << 23;
+            if (down) word[l][1] = (unsigned)b1 | r1 << 9 | gc << 23;                               // row 0 of a tile with the same columns
+            if (right) word[l][2] = (unsigned)b2 | r2 << 9 | (gr * ((ce[l] >> 22) & 31u)) << 23;   // column 0 of the right neighbour's grid
+            if (down && right) word[l][3] = (unsigned)b3 | r3 << 9;
+        }
+        RPS_RSTAMP(2)
         __syncthreads();
+        RPS_RSTAMP(3)
         // ---- B: the workgroup's runs: exclusive prefix over its bins' counts (one bin per thread), room in the pool, one 64-bit
         //      atomic per (workgroup, bin) ---------------------------------------------------------------------------------------------
         const unsigned cnt = tid < B ? hist[tid] : 0u;
@@ -337,36 +376,66 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         for (int l = 0; l < kRpsMaxL; ++l) {
             if (l >= g.L) continue;
             unsigned r = own_rank[l];
-            if (lead[l] >= 0) {
-                const unsigned rl = (unsigned)__shfl((int)r, lead[l], kWave);
-                if (matched[l] && lane != lead[l]) r += rl;
-            }
+            const unsigned rl = (unsigned)__builtin_amdgcn_readlane((int)r, lead[l]);
+            if ((matched_m >> l & 1u) && lane != lead[l]) r += rl;
             if (word[l][0] != ~0u) word[l][0] |= r << 9;
         }
         __syncthreads();
+        RPS_RSTAMP(4)
+        // ---- D (first half): the runs are announced to their bins -- one 64-bit atomic per (workgroup, bin) -- BEFORE the records are
+        //      stored: what the atomic returns (1-2 us later) is needed only for the run-table entry, written behind the record stores
+        //      (unconditional -- threads without a run add zero to a scratch word of their own --: behind a branch the wait for the
+        //      weights below could not be counted and would wait for the atomic as well)
+        const size_t gb = (size_t)pair * B + min(tid, B - 1);
+        unsigned long long *const scratch64 = reinterpret_cast<unsigned long long *>(g.dummy + (size_t)(blockIdx.x & (kRpsDummyWgs - 1)) * 256) + lane;
+        const unsigned long long old = atomicAdd(cnt ? g.bin_state + gb * (kRpsPad / 2) : scratch64, cnt ? (1ull << 32) | (unsigned long long)cnt : 0ull);
         const unsigned qp = (unsigned)((live ? q : 0) * P + pp);
+        unsigned slot0[kRpsMaxL][4];
+#pragma unroll
+        for (int l = 0; l < kRpsMaxL; ++l)      // (all the run starts are read before any of them is waited for; ~0u reads base[511])
+#pragma unroll
+            for (int k = 0; k < 4; ++k) slot0[l][k] = base[word[l][k] & 511u];
+        // (the weights are in their registers from here on: the conditional stores below then carry no wait of their own -- behind a
+        // branch the compiler cannot count what is outstanding and would wait for EVERY earlier store to be acknowledged)
+        asm volatile("" : "+v"(at[0]), "+v"(at[1]), "+v"(at[2]), "+v"(at[3]));
 #pragma unroll
         for (int l = 0; l < kRpsMaxL; ++l)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const unsigned w = word[l][k];
                 if (w != ~0u) {
-                    const unsigned slot = min(base[w & 511u] + ((w >> 9) & 16383u), g.entries_cap - 1u);
+                    const unsigned slot = min(slot0[l][k] + ((w >> 9) & 16383u), g.entries_cap - 1u);
                     const unsigned code = qp | (w >> 23) << kRpsQpBits | (k == 0 ? inmap[l] << 27 | 0x80000000u : 0u);
+#ifdef RPS_ROUTE_ABLATION      // (diagnostic build, profiles/r04_route_ablation.md: what the record stores cost)
+                    if (g.dbg & 512) reinterpret_cast<unsigned *>(g.entries)[slot] = code;
+                    else if (!(g.dbg & 256))
+#endif
                     g.entries[slot] = RpsRec{code, lh[l], lw[l], at[l]};
                 }
             }
-        // ---- D: the runs are announced to their bins; nothing in this work item waits for what the atomics return but the table entry
-        if (cnt) {
-            const size_t gb = (size_t)pair * B + tid;
-            const unsigned long long old = atomicAdd(g.bin_state + gb * (kRpsPad / 2), (1ull << 32) | (unsigned long long)cnt);
-            g.runs[gb * (size_t)g.max_runs + (size_t)min((unsigned)(old >> 32), (unsigned)g.max_runs - 1u)] = make_uint2(first, (unsigned)old);
+        if (__ballot(dropped != 0u)) {      // (uniform; rare) dropped samples: zero gradients
+#pragma unroll
+            for (int l = 0; l < kRpsMaxL; ++l)
+                if (dropped >> l & 1u) {
+                    const unsigned pt = pt0 + (unsigned)(l * P);
+                    grad_aw[pt] = 0.f;
+                    *reinterpret_cast<float2 *>(grad_loc + 2u * pt) = make_float2(0.f, 0.f);
+                }
         }
+        RPS_RSTAMP(5)
+        // ---- D (second half): the run's slot in the bin's run table and its position inside the bin
+        if (cnt) g.runs[gb * (size_t)g.max_runs + (size_t)min((unsigned)(old >> 32), (unsigned)g.max_runs - 1u)] = make_uint2(first, (unsigned)old);
+        RPS_RSTAMP(6)
         __syncthreads();   // hist / base are reused by the next item
+        RPS_RSTAMP(7)
     }
+    if (g.stamps && tid == 0)
+        for (int i = 0; i < 8; ++i) g.stamps[(size_t)(1024 + blockIdx.x) * 16 + i] = st_acc[i];
+#undef RPS_RSTAMP
 }
 
 typedef float rps_v2f __attribute__((ext_vector_type(2)));
+typedef float rps_v4f __attribute__((ext_vector_type(4)));
 
 // Lane j of a quad ends up with the quad's sum of d[j] (j = 0..3): two exchange steps in which every lane keeps the half
 // of the values it is responsible for and hands the other half to its partner (9 instructions instead of 4 x 2 + selects).
@@ -487,21 +556,39 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
         return it;
     };
     // bin of a work item: its index, number of records and number of runs (0 records for ids past the table or pairs past the batch)
+    // (bin_range_raw requests the counter; bin_counts turns it into numbers WHERE THEY ARE FIRST NEEDED -- behind an opaque asm, or the
+    // compiler forms them, and waits for the load, at the top of the work item)
+    auto bin_range_raw = [&](int id, unsigned &bin_, unsigned &okm_, unsigned long long &st_) {
+        const int idc = min(id, n_items - 1);
+        const unsigned unit = g.units[idc / g.ppx];
+        const int pair = xq + kXcds * (idc % g.ppx);
+        const bool ok = id < n_items && pair < pairs;
+        const int l = unit & 3, ty = (unit >> 2) & 63, tx = (unit >> 8) & 63, slab = (unit >> 14) & 255, nslab = (unit >> 22) & 255;
+        const unsigned bin_c = ok ? (unsigned)(pair * g.bins_per_pair + g.lv[l].bin0 + (ty * g.lv[l].ntx + tx) * nslab + slab) : 0u;
+        st_ = g.bin_state[(size_t)bin_c * (kRpsPad / 2)];
+        okm_ = ok ? 0xFFFFFFFFu : 0u;
+        bin_ = bin_c | ~okm_;                             // (0xFFFFFFFF: no bin)
+    };
+    auto bin_counts = [&](unsigned long long st_, unsigned okm_, int &n, int &nr) {
+        unsigned lo = (unsigned)st_, hi = (unsigned)(st_ >> 32);
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        n = (int)(min(lo, 0x7FFFFFFFu) & okm_);
+        nr = (int)(min(hi, (unsigned)min(g.max_runs, kRpsMaxRuns)) & okm_);
+    };
     auto bin_range = [&](int id, unsigned &bin_, int &n, int &nr) {
-        bin_ = 0xFFFFFFFFu;      // (no bin)
-        n = 0;
-        nr = 0;
-        if (id < n_items) {
-            const unsigned unit = g.units[id / g.ppx];
-            const int pair = xq + kXcds * (id % g.ppx);
-            if (pair < pairs) {
-                const int l = unit & 3, ty = (unit >> 2) & 63, tx = (unit >> 8) & 63, slab = (unit >> 14) & 255, nslab = (unit >> 22) & 255;
-                bin_ = (unsigned)(pair * g.bins_per_pair + g.lv[l].bin0 + (ty * g.lv[l].ntx + tx) * nslab + slab);
-                const unsigned long long st = g.bin_state[(size_t)bin_ * (kRpsPad / 2)];
-                n = (int)min((unsigned)st, 0x7FFFFFFFu);
-                nr = (int)min((unsigned)(st >> 32), (unsigned)min(g.max_runs, kRpsMaxRuns));
-            }
-        }
+        // (the counter is read unconditionally -- bin 0's for an id past the table or a pair past the batch, masked afterwards --: hipcc
+        // waits for a load that sits in a branch right behind it, and this one is needed a whole work item later)
+        const int idc = min(id, n_items - 1);
+        const unsigned unit = g.units[idc / g.ppx];
+        const int pair = xq + kXcds * (idc % g.ppx);
+        const bool ok = id < n_items && pair < pairs;
+        const int l = unit & 3, ty = (unit >> 2) & 63, tx = (unit >> 8) & 63, slab = (unit >> 14) & 255, nslab = (unit >> 22) & 255;
+        const unsigned bin_c = ok ? (unsigned)(pair * g.bins_per_pair + g.lv[l].bin0 + (ty * g.lv[l].ntx + tx) * nslab + slab) : 0u;
+        const unsigned long long st = g.bin_state[(size_t)bin_c * (kRpsPad / 2)];
+        const unsigned okm = ok ? 0xFFFFFFFFu : 0u;      // (masks, not selects: a select lets the compiler move the load under `ok`)
+        bin_ = bin_c | ~okm;                             // (0xFFFFFFFF: no bin)
+        n = (int)(min((unsigned)st, 0x7FFFFFFFu) & okm);
+        nr = (int)(min((unsigned)(st >> 32), (unsigned)min(g.max_runs, kRpsMaxRuns)) & okm);
     };
     // a bin's run table: global -> registers (one run per lane) -> LDS
     uint2 run_reg = make_uint2(0u, 0u);
@@ -555,11 +642,14 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
         }
     };
 
-    unsigned draw = 0;   // (thread 0) the queue draw in flight
-    if (tid == 0) {
-        S->item_slot[0] = (int)atomicAdd(g.ctr + xq, 1u);
-        draw = atomicAdd(g.ctr + xq, 1u);
-    }
+    // The work queue is drawn by EVERY thread (round 4): thread 0 adds one to its XCD's queue head, the others add zero to a scratch word.
+    // Inside `if (tid == 0)` the compiler waits for the returning atomic right behind it -- 1-2 us per work item during which wave 0 kept
+    // the whole workgroup at the next barrier, with the value rows and first records of the item it had requested early drained as well.
+    unsigned *const draw_at = tid == 0 ? g.ctr + xq : reinterpret_cast<unsigned *>(dummy_w) + (tid & 255);
+    const unsigned draw_by = tid == 0 ? 1u : 0u;
+    unsigned draw = atomicAdd(draw_at, draw_by);   // (thread 0) the queue draw in flight
+    if (tid == 0) S->item_slot[0] = (int)draw;
+    draw = atomicAdd(draw_at, draw_by);
     __syncthreads();
     int item_id = rps_uni(S->item_slot[0]);
     unsigned e_bin;
@@ -578,10 +668,7 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
     for (int i = tid; i < kRpsMaxPx * kRpsSumStride / 2; i += kRpsThreads) reinterpret_cast<double2 *>(S->sum)[i] = make_double2(0.0, 0.0);
 
     while (item_id < n_items) {
-        if (tid == 0) {
-            S->item_slot[par ^ 1] = (int)draw;   // issued one item ago
-            draw = atomicAdd(g.ctr + xq, 1u);
-        }
+        if (tid == 0) S->item_slot[par ^ 1] = (int)draw;   // issued one item ago
         const int l = it.l, b = it.b, m = it.m, H = it.H, W = it.W, R0 = it.R0, R1 = it.R1, C0 = it.C0, C1 = it.C1, gw = it.gw;
         const int npx = it.npx;
         const int n_chunks = it.live ? (n_ent + kRpsChunk - 1) / kRpsChunk : 0;
@@ -591,9 +678,10 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
         // the f64 sums are zero: cleared before the loop, and by the lanes that read them out at the end of every item)
         __syncthreads();
         const int next_id = rps_uni(S->item_slot[par ^ 1]);
-        unsigned next_bin;
-        int next_n, next_runs;
-        bin_range(next_id, next_bin, next_n, next_runs);   // (made uniform where first used: that waits for the loads)
+        unsigned next_bin, next_ok;
+        unsigned long long next_st;
+        int next_n = 0, next_runs = 0;
+        bin_range_raw(next_id, next_bin, next_ok, next_st);   // (turned into counts where first used: that waits for the load)
         const Item nit = item_geom(next_id);
         store_rows();   // (read only behind the barriers of the first chunk's sort; an empty bin reads nothing)
         RPS_STAMP(0)
@@ -610,6 +698,9 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                 // gradient stores of stage (5) -- taken in this order -- fall into 16 / 32 contiguous bytes per (query, level)
                 S->meta[u * kRpsThreads + tid] = n_rec[u];
             }
+            // (the next queue draw goes out here, in the item's first chunk: returning atomics and loads come back in order, and the three
+            // sort stages that follow touch LDS only -- at the top of the item it delayed the value rows, behind the walk the next records)
+            if (ch == 0) draw = atomicAdd(draw_at, draw_by);
             __syncthreads();
             RPS_STAMP(1)
 #pragma unroll
@@ -720,21 +811,26 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                         v[k][0] = (rps_v2f){a0.x, a0.y}; v[k][1] = (rps_v2f){a0.z, a0.w};
                         v[k][2] = (rps_v2f){a1.x, a1.y}; v[k][3] = (rps_v2f){a1.z, a1.w};
                     }
-                    rps_v2f acc[4][4];
+                    // partial sums: macc[m][k] = corner k, this lane's channel m (of its 8).  They are formed on the MATRIX pipe (round 4):
+                    // v_mfma_f32_4x4x1 is sixteen 4 x 4 outer products, one per quad -- A = the four corner weights (lane k of the quad
+                    // supplies corner k's), B = the four lanes' m-th channels, D[k][j] in register k of lane j -- so a point costs 8 MFMAs
+                    // and ONE weight per lane instead of 16 packed FMAs and four weights, and the vector pipe keeps the dots.
+                    rps_v4f macc[8];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) acc[k][c] = (rps_v2f){0.f, 0.f};
+                    for (int m_ = 0; m_ < 8; ++m_) macc[m_] = (rps_v4f){0.f, 0.f, 0.f, 0.f};
 #define RPS_POINT(EN, ROW, E)                                                                                                    \
     {                                                                                                                            \
-        const float hh = 1.f - EN.lh, hw = 1.f - EN.lw, ha = hh * EN.a, la = EN.lh * EN.a;                                       \
-        const float w[4] = {ha * hw, ha * EN.lw, la * hw, la * EN.lw};                                                           \
+        const float wj = ((j4 & 2) ? EN.lh : 1.f - EN.lh) * ((j4 & 1) ? EN.lw : 1.f - EN.lw) * EN.a;                             \
         rps_v2f gq[4];                                                                                                           \
         ROW.unpack(gq);                                                                                                          \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                            \
+        {                                                                                                                        \
+            macc[2 * c] = __builtin_amdgcn_mfma_f32_4x4x1f32(wj, gq[c].x, macc[2 * c], 0, 0, 0);                                 \
+            macc[2 * c + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wj, gq[c].y, macc[2 * c + 1], 0, 0, 0);                         \
+        }                                                                                                                        \
         float d[4];                                                                                                              \
         _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                            \
         {                                                                                                                        \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) acc[k][c] += w[k] * gq[c];                                             \
             rps_v2f t = gq[0] * v[k][0];                                                                                         \
             t += gq[1] * v[k][1];                                                                                                \
             t += gq[2] * v[k][2];                                                                                                \
@@ -781,24 +877,22 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                         const bool ok = (k >= 2 || lr >= 1) && ((k & 1) || lc >= 1);
                         if (ok) {
                             double *dst = S->sum + (my_p - (k < 2 ? gw : 0) - ((k & 1) ? 0 : 1)) * kRpsSumStride + j4;
-                            atomicAdd(dst, (double)acc[k][0].x);
-                            atomicAdd(dst + 4, (double)acc[k][0].y);
-                            atomicAdd(dst + 8, (double)acc[k][1].x);
-                            atomicAdd(dst + 12, (double)acc[k][1].y);
-                            atomicAdd(dst + 16, (double)acc[k][2].x);
-                            atomicAdd(dst + 20, (double)acc[k][2].y);
-                            atomicAdd(dst + 24, (double)acc[k][3].x);
-                            atomicAdd(dst + 28, (double)acc[k][3].y);
+#pragma unroll
+                            for (int m_ = 0; m_ < 8; ++m_) atomicAdd(dst + 4 * m_, (double)macc[m_][k]);
                         }
                     }
                 }
             }
             // the next chunk -- or the first chunk of the next work item -- is requested now, behind the walk (held across it,
             // the eight registers would spill) and AHEAD of this chunk's gradient stores
+            // (both requests are issued whatever the chunk -- the run table of the NEXT item is parked in LDS only behind the last chunk's
+            // barrier, the records are those of the next chunk, or a harmless re-read of this one behind the last --: inside
+            // `if (last_chunk) ... else ...` the compiler waited for them on the spot, 1-2 us per chunk that were meant to pass under
+            // the gradient stage below)
             const bool last_chunk = ch + 1 == n_chunks;
-            if (!last_chunk) fetch_recs(n_ent, n_runs, ch + 1);
-            else load_runs(next_bin, next_runs);      // (the next item's run table: parked in LDS behind the barrier, its records
-                                                      // requested where the sums are stored)
+            bin_counts(next_st, next_ok, next_n, next_runs);
+            load_runs(next_bin, next_runs);
+            fetch_recs(n_ent, n_runs, min(ch + 1, n_chunks - 1));
             __syncthreads();
             if (last_chunk) park_runs();
             RPS_STAMP(5)
@@ -840,6 +934,8 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
             RPS_STAMP(6)
         }
         if (n_chunks == 0) {   // (an empty bin: nothing was requested ahead)
+            draw = atomicAdd(draw_at, draw_by);
+            bin_counts(next_st, next_ok, next_n, next_runs);
             load_runs(next_bin, next_runs);
             __syncthreads();
             park_runs();
@@ -915,7 +1011,7 @@ __global__ __launch_bounds__(256) void rps_round_kernel(const float *__restrict_
 struct RpsOptions {
     std::atomic<int> tile{16};         // largest tile side + 1 (tile + one row / column <= kRpsMaxPx = 256 pixels)
     std::atomic<int> max_chunks{12};   // expected chunks of one workgroup before a tile is split into slabs (MI355X, call E: 6 -> 12 = 463 -> 447 us on uniform locations, equal at the init pattern)
-    std::atomic<int> route_wgs{4};     // route passes: workgroups per CU (persistent over the query blocks)
+    std::atomic<int> route_wgs{2};     // route pass: workgroups per CU (persistent over the query blocks): two are resident at its 102 registers (MI355X, call E: 2 -> 55.9 us, 3 -> 61.7, 4 -> 58.1, 6 -> 63.1)
     std::atomic<int> seg_shift{4};     // units of the list walk: at most 1 << seg_shift points of a pixel's list (3..11; MI355X,
                                        // call E, list walk: 8 -> 315 k cycles per workgroup, 16 -> 301 k, 32 -> 330 k, whole lists -> 347 k)
 };
@@ -980,6 +1076,13 @@ inline RpsPlan plan_rps(int N, int S, int M, int D, int L, int Lq, int P, const 
                                       (int64_t)(nchunks + v.nslab - 1) / v.nslab * 16 + 8});
     }
     if (units.size() > (size_t)kRpsMaxUnits) return pl;
+    g.lut_n = 0;
+    for (int l = 0; l < L; ++l) {      // (H, W <= 64 tiles of <= 15 pixels: at most 4 x 2 x 962 words = 30 KB of LDS)
+        g.lut_r[l] = g.lut_n;
+        g.lut_n += g.lv[l].H + 1;
+        g.lut_c[l] = g.lut_n;
+        g.lut_n += g.lv[l].W + 1;
+    }
     std::stable_sort(units.begin(), units.end(), [](const U &a, const U &b) { return a.cost > b.cost; });
     g.nunits = (int)units.size();
     for (int i = 0; i < g.nunits; ++i) g.units[i] = units[i].code;

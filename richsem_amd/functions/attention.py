@@ -18,10 +18,14 @@ _MASK_CACHE = {}
 
 def mask_bits(mask):
     """(nq, nq) bool, True = masked -> (bits (nq, nkb) int32: bit j of word (q, kb) = mask[q, 32 kb + j]; the same of the transposed
-    mask), kept for as long as the mask tensor is unchanged (the six layers of the decoder pass the same tensor)"""
+    mask), kept for as long as the mask tensor is unchanged (the six layers of the decoder pass the same tensor).
+    The cache entry HOLDS the mask tensor: while it does, the caching allocator cannot hand the mask's address to the next step's mask
+    (``dn.prepare_dn_layout`` fills a fresh ``torch.empty`` buffer with a raw kernel, so ``_version`` is 0 for every mask it makes:
+    with the address recycled, a different layout of equal shape would hit the stale bits).  A raw kernel that rewrites the SAME live
+    buffer without going through torch is the one change this key cannot see."""
     key = (mask.data_ptr(), mask._version, tuple(mask.shape), mask.device)
     hit = _MASK_CACHE.get("last")
-    if hit is not None and hit[0] == key:
+    if hit is not None and hit[0] == key and hit[2].untyped_storage().data_ptr() == mask.untyped_storage().data_ptr():
         return hit[1]
     assert mask.dtype == torch.bool and mask.dim() == 2 and mask.shape[0] == mask.shape[1]
     nq = mask.shape[0]
@@ -36,7 +40,7 @@ def mask_bits(mask):
         return s.to(torch.int32).contiguous()
 
     val = (to_i32(mask), to_i32(mask.t()))
-    _MASK_CACHE["last"] = (key, val)
+    _MASK_CACHE["last"] = (key, val, mask)      # (the tensor itself: keeps its storage, and so its address, taken)
     return val
 
 

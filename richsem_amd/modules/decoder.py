@@ -214,7 +214,12 @@ class TransformerDecoder(nn.Module):
                 refpoints_unsigmoid=None, level_start_index=None, spatial_shapes=None, valid_ratios=None):
         """tgt (nq, bs, C); memory (S, bs, C); refpoints_unsigmoid (nq, bs, 4); valid_ratios (bs, L, 2).  Returns the reference's
         ``[[norm(layer output) (bs, nq, C) per layer], [reference boxes (bs, nq, 4): initial + one per layer]]``."""
-        fast = all(layer._fast(tgt) for layer in self.layers) and memory.dtype == torch.bfloat16 and self.norm is not None
+        # (the library-kernel path takes what the shipped configuration passes: a square boolean self-attention mask or none, no
+        # cross-attention mask, no per-token padding of the queries (the reference ignores tgt_key_padding_mask too, :974-978), no memory
+        # positions; anything else -- a float / additive mask as nn.MultiheadAttention accepts -- takes the reference's op sequence)
+        mask_ok = tgt_mask is None or (tgt_mask.dtype == torch.bool and tgt_mask.dim() == 2 and tgt_mask.shape[0] == tgt_mask.shape[1])
+        fast = (all(layer._fast(tgt) for layer in self.layers) and memory.dtype == torch.bfloat16 and self.norm is not None and mask_ok
+                and memory_mask is None and tgt_key_padding_mask is None and pos is None)
         if fast:
             return self._forward_fast(tgt, memory, tgt_mask, memory_key_padding_mask, refpoints_unsigmoid, level_start_index,
                                       spatial_shapes, valid_ratios)

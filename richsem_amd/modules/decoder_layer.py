@@ -138,7 +138,9 @@ class DeformableTransformerDecoderLayer(nn.Module):
                 memory=None, memory_key_padding_mask=None, memory_level_start_index=None, memory_spatial_shapes=None,
                 memory_pos=None, self_attn_mask=None, cross_attn_mask=None, value=None):
         """the reference's signature (:1026-1043) plus ``value``: the cross-attention's projected memory when the caller has it"""
-        if self._fast(tgt):
+        mask_ok = self_attn_mask is None or (self_attn_mask.dtype == torch.bool and self_attn_mask.dim() == 2
+                                             and self_attn_mask.shape[0] == self_attn_mask.shape[1])
+        if self._fast(tgt) and mask_ok:      # (a float / additive mask takes the reference's op sequence: nn.MultiheadAttention accepts it)
             return self._forward_fast(tgt, tgt_query_pos, tgt_reference_points, memory, memory_key_padding_mask, memory_level_start_index,
                                       memory_spatial_shapes, self_attn_mask, value)
         tgt = self.forward_sa(tgt, tgt_query_pos, self_attn_mask)

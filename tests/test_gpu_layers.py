@@ -131,6 +131,37 @@ def test_attention_kernels_against_the_definition(nq, bs, heads, masked, batch_f
     assert float((a.grad.float() - ar.grad).abs().mean()) < 4e-3 * scale(ar.grad)
 
 
+def test_mask_bits_of_a_recycled_address_are_not_stale():
+    """Two denoising layouts of equal shape and different group_pad, one after the other with the first mask freed in between (round-3
+    advisor finding): ``prepare_dn_layout`` fills ``torch.empty`` buffers with a raw kernel (``_version`` 0) and the caching allocator
+    would hand the second mask the first one's address -- the bit cache must not answer with the first mask's bits."""
+    from richsem_amd import dn
+    from richsem_amd.functions.attention import mask_bits, masked_self_attention
+    heads, bs = 2, 1
+    outs, masks = [], []
+    g = torch.Generator(device="cuda").manual_seed(11)
+    C = heads * 32
+    lay = dn.prepare_dn_layout([4], dn_number=100, num_queries=40)        # pad_size 200, group_pad 8
+    nq = lay["attn_mask"].shape[0]
+    qk = (torch.randn(nq, bs, 2 * C, device="cuda", generator=g) * 1.5).to(torch.bfloat16)
+    v = torch.randn(nq, bs, C, device="cuda", generator=g).to(torch.bfloat16)
+    del lay
+    for max_gt in (4, 5):          # both give pad_size 200 (dn_components.py:27-39, 65-67): 25 groups of 2 x 4, 20 groups of 2 x 5
+        lay = dn.prepare_dn_layout([max_gt], dn_number=100, num_queries=40)
+        mask = lay["attn_mask"]
+        assert mask.shape == (nq, nq)
+        bits = mask_bits(mask)[0]
+        want_bits = mask_bits(mask.clone())[0]          # (a different address: always rebuilt)
+        assert torch.equal(bits, want_bits)
+        mask_bits(mask)                                   # the cache entry is this mask's again, as in a training step
+        outs.append(masked_self_attention(qk, v, mask, heads).float())
+        want = _attention_reference(qk, v, mask, heads)
+        assert float((outs[-1] - want).abs().max()) < 2e-2 * float(want.abs().max())
+        masks.append(mask.clone())
+        del lay, mask, bits                               # the cache holds the tensor: its address must not be handed out again
+    assert not torch.equal(masks[0], masks[1]) and float((outs[0] - outs[1]).abs().max()) > 1e-3
+
+
 def test_lin256_row_mask_and_stacked_projection():
     from richsem_amd.functions.linear import StackedValueProjFunction, Lin256Function, pack_linear256
     torch.manual_seed(3)

@@ -1,0 +1,98 @@
+"""The composed step of bench_step.py at a small size (round-3 verdict items 4d and 6):
+
+  * the bf16 step (the library's kernels) against the SAME parameters through the reference's op sequence in fp32 from the input
+    projections on -- loss and a sample of gradients, with the two-stage selection and the Hungarian assignment held equal;
+  * capture of the step into a HIP graph on the stream it was warmed up on, with the last eager step's loss (and so its autograd graph)
+    still referenced: what crashed round 3's harness when the eager steps had run on ANOTHER stream (tools/capture_crash_probe.py).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H, W_IMG, BOXES = 256, 320, 5      # pyramid 32 x 40, 16 x 20, 8 x 10, 4 x 5: S = 2100 tokens
+
+
+def _small_step(seed=0):
+    import bench_step
+    model = bench_step.Step(n_img=2, height=H, width=W_IMG, boxes_per_image=BOXES, seed=seed, dev=torch.device("cuda", 0))
+    model.timing = False
+    images, mask, targets = model.batch()
+    model.prepare(mask, targets)
+    return model, images, mask, targets
+
+
+def _run(model, images, mask, targets, indices=None, topk=None, seed=7):
+    for p in model.parameters():
+        p.grad = None
+    torch.manual_seed(seed)          # the denoising noise is drawn inside the step: the same draws in both precisions
+    loss = model(images, mask, targets, indices, topk)
+    loss.backward()
+    return loss
+
+
+def test_bf16_step_agrees_with_the_fp32_op_sequence():
+    model, images, mask, targets = _small_step()
+    loss16 = _run(model, images, mask, targets)
+    idx = [[(i.clone(), j.clone()) for i, j in per] for per in model.last_indices]
+    topk = model.last_topk.clone()
+    g16 = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+    # the same parameters through the reference's op sequence in fp32 (PyTorch ops around the operator's fp32 entry points)
+    model.act_dtype = torch.float32
+    for m in model.modules():
+        if hasattr(m, "fused"):
+            m.fused = False
+        if hasattr(m, "fused_ffn"):
+            m.fused_ffn = False
+    loss32 = _run(model, images, mask, targets, idx, topk)
+    g32 = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert torch.isfinite(loss16) and torch.isfinite(loss32)
+    rel = abs(float(loss16) - float(loss32)) / abs(float(loss32))
+    assert rel < 2e-2, (float(loss16), float(loss32))          # measured on MI355X: see DESIGN.md section 11
+    # a sample of gradients across the step: heads, last decoder layer, first decoder layer, last / first encoder layer, input projection
+    names = ["dino_visual_proj.weight", "proj_dino_hs.weight", "decoder.layers.5.linear2.weight", "decoder.layers.5.cross_attn.value_proj.weight",
+             "decoder.layers.0.self_attn.in_proj_weight", "decoder.bbox_embed.5.layers.2.weight", "decoder.ref_point_head.layers.0.weight",
+             "encoder.5.linear1.weight", "encoder.5.self_attn.sampling_offsets.weight", "encoder.0.self_attn.value_proj.weight",
+             "encoder.0.norm1.weight", "enc_output.weight", "level_embed", "tgt_embed.weight", "input_proj.0.0.weight"]
+    errs = {}
+    for n in names:
+        assert n in g16 and n in g32, (n, sorted(g16)[:40])
+        a, b = g16[n], g32[n]
+        assert torch.isfinite(a).all() and torch.isfinite(b).all()
+        # cosine of the two gradients and the ratio of their norms: a bf16 step is a noisy copy of the fp32 one, not a different direction
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        errs[n] = (cos, float(a.norm() / (b.norm() + 1e-30)))
+    bad = {n: e for n, e in errs.items() if e[0] < 0.90 or not 0.8 < e[1] < 1.25}
+    assert not bad, (bad, errs)
+
+
+def test_step_captures_on_the_stream_it_ran_on_with_its_loss_alive():
+    model, images, mask, targets = _small_step(seed=1)
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def step(indices=None):
+        for p in params:
+            p.grad = None
+        loss = model(images, mask, targets, indices)
+        loss.backward()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        kept = step()                                       # stays referenced (with its autograd graph) across the capture
+        torch.cuda.synchronize()
+        indices = [[(i.cuda(), j.cuda()) for i, j in per] for per in model.last_indices]
+        for _ in range(2):
+            step(indices)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        loss = step(indices)
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(kept) and torch.isfinite(loss)
+    assert all(torch.isfinite(p.grad).all() for p in params if p.grad is not None)
+    # the captured step is the step: equal parameters, equal assignment -> a loss next to the eager one (the denoising noise differs)
+    assert abs(float(loss) - float(kept)) < 0.2 * abs(float(kept))

@@ -47,7 +47,7 @@ for name in sys.argv[1:] or ["backbone", "input_proj", "encoder", "two_stage", "
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with (torch.autograd.detect_anomaly(check_nan=False) if anomaly else contextlib.nullcontext()), torch.cuda.graph(g):
+        with (torch.autograd.detect_anomaly(check_nan=False) if anomaly else contextlib.nullcontext()), torch.cuda.graph(g, stream=s):
             step()
         torch.cuda.synchronize()
         g.replay()

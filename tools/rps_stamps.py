@@ -39,6 +39,13 @@ def main():
     lib.msda_debug_stamps(None)
     s = buf.view(-1, 16)[:256].cpu().double()
     tot = s[:, :10].sum(1)
+    r = buf.view(-1, 16)[1024:2048].cpu().double()
+    r = r[r[:, :8].sum(1) > 0]
+    if len(r):
+        rt = r[:, :8].sum(1)
+        print(f"route pass: {len(r)} workgroups, per workgroup {rt.mean():.0f} cycles (min {rt.min():.0f}, max {rt.max():.0f})")
+        for i, n in enumerate(["prologue (tables, zero-fill)", "operands + barrier", "A ranks", "barrier", "B scan", "C record stores", "D announce", "barrier"]):
+            print(f"  {n:34s} {r[:, i].mean():10.0f} cycles  {100 * r[:, i].mean() / rt.mean():5.1f} %")
     print(f"{args.call} loc-{args.loc}: per workgroup {tot.mean():.0f} cycles (min {tot.min():.0f}, max {tot.max():.0f})")
     for i, n in enumerate(NAMES):
         print(f"  {n:34s} {s[:, i].mean():10.0f} cycles  {100 * s[:, i].mean() / tot.mean():5.1f} %")

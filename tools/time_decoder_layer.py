@@ -39,7 +39,7 @@ def timeit_graph(fn, reps):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=side):      # (the warmed stream: the library's workspaces are per stream)
         fn()
     g.replay()
     torch.cuda.synchronize()
