@@ -584,6 +584,15 @@ def main(argv=None):
         elapsed, records = timed(modes[0], collective, True, bf16=True)
         results["bf16"] = {"elapsed": elapsed, "records": records}
 
+    # N > 1: the composed step as a data-parallel TRAINING step (DistributedDataParallel over RCCL + AdamW), by every rank; beside
+    # `value`, never it (what the scaling curve of `value` hides behind 3 ms of operator kernels has 27 ms of step to hide in here)
+    full_step_ddp = None
+    if world > 1 and not args.no_full_step:
+        try:
+            import bench_step
+            full_step_ddp = bench_step.run_ddp(n_img, dev, dist, steps=5, warmup=3)
+        except Exception as e:      # noqa: BLE001
+            full_step_ddp = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     if rank == 0:
         n_total = total_images(n_img, world)
 
@@ -654,6 +663,8 @@ def main(argv=None):
                 line["full_step"] = bench_step.run(n_img, dev, steps=5, warmup=3)
             except Exception as e:      # noqa: BLE001
                 line["full_step"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        if full_step_ddp is not None:
+            line["full_step_ddp"] = full_step_ddp
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(calls, n_img)
         else:

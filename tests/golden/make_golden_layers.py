@@ -197,6 +197,103 @@ def decoder_stack(dt, ut):
                                    grad_tgt=tgt.grad, grad_memory=memory.grad, grad_refpoints=refu.grad), dec)
 
 
+# ---- d_model = 256, 8 heads (round 4): the shapes the bf16 kernels are built for (K = 256 projections, 8 x 32-channel attention heads,
+#      the fused feed-forward block), so that they meet reference-class outputs directly.  Parameters come from tests/layer_params.py (a
+#      pure function of seed and key, rebuilt by the test); stored: inputs, outputs, input gradients, parameter gradients as float16
+#      mantissas + scale.
+def _np(t):
+    """float64 activations are stored as float32 (the inputs are float32 values to begin with: `_rand32`): these fixtures are compared at
+    bf16 tolerance"""
+    if not torch.is_tensor(t):
+        return t
+    t = t.detach()
+    return (t.float() if t.dtype == torch.float64 else t).numpy()
+
+
+def _rand32(fn, *shape, gen, requires_grad=False):
+    """float32 values, held in float64: what the fixture stores is exactly what the reference ran on"""
+    return fn(*shape, generator=gen, dtype=torch.float32).double().requires_grad_(requires_grad)
+
+
+def layers_256(dt, ut):
+    sys.path.insert(0, os.path.dirname(OUT))
+    import layer_params as LP
+    shapes = torch.as_tensor(LP.SHAPES, dtype=torch.long)
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    N, C, H, L, P, F = 2, LP.D_MODEL, LP.HEADS, LP.LEVELS, LP.POINTS, LP.D_FFN
+    # -- encoder layer
+    gen = torch.Generator().manual_seed(401)
+    layer = LP.fill(dt.DeformableTransformerEncoderLayer(d_model=C, d_ffn=F, dropout=0.0, activation="relu", n_levels=L, n_heads=H,
+                                                         n_points=P).double(), 400)
+    src = _rand32(torch.randn, N, S, C, gen=gen, requires_grad=True)
+    pos = _rand32(torch.randn, N, S, C, gen=gen, requires_grad=True)
+    valid_ratios = _rand32(torch.rand, N, L, 2, gen=gen) * 0.3 + 0.7
+    ref = dt.TransformerEncoder.get_reference_points(shapes, valid_ratios, device="cpu").double()
+    mask = torch.zeros(N, S, dtype=torch.bool)
+    mask[1, lsi[0] + 8:lsi[0] + 12] = True
+    mask[1, -2:] = True
+    out = layer(src, pos, ref, shapes, lsi, mask)
+    go = _rand32(torch.randn, out.shape, gen=gen)
+    out.backward(go)
+    arrays = dict(src=src, pos=pos, valid_ratios=valid_ratios, reference_points=ref, shapes=shapes, lsi=lsi, mask=mask, out=out, grad_out=go,
+                  grad_src=src.grad, grad_pos=pos.grad)
+    np.savez_compressed(os.path.join(OUT, "layer256_encoder_f64.npz"), **{k: _np(v) for k, v in arrays.items()}, **LP.pack_grads(layer))
+    print("layer256_encoder_f64", tuple(out.shape))
+    # -- decoder layer
+    nq = 40
+    gen = torch.Generator().manual_seed(411)
+    layer = LP.fill(dt.DeformableTransformerDecoderLayer(d_model=C, d_ffn=F, dropout=0.0, activation="relu", n_levels=L, n_heads=H, n_points=P,
+                                                         decoder_sa_type="sa", module_seq=["sa", "ca", "ffn"]).double(), 410)
+    tgt = _rand32(torch.randn, nq, N, C, gen=gen, requires_grad=True)
+    qpos = _rand32(torch.randn, nq, N, C, gen=gen, requires_grad=True)
+    memory = _rand32(torch.randn, S, N, C, gen=gen, requires_grad=True)
+    cxcy = _rand32(torch.rand, nq, N, 1, 2, gen=gen) * 0.8 + 0.1
+    wh = _rand32(torch.rand, nq, N, 1, 2, gen=gen) * 0.4 + 0.05
+    ref = torch.cat((cxcy, wh), -1).expand(nq, N, L, 4).contiguous()
+    mmask = torch.zeros(N, S, dtype=torch.bool)
+    mmask[0, lsi[1]:lsi[1] + 6] = True
+    amask = torch.zeros(nq, nq, dtype=torch.bool)       # denoising-style: two groups of 6 that do not see each other, the matching part sees neither
+    amask[12:, :12] = True
+    amask[:6, 6:12] = True
+    amask[6:12, :6] = True
+    out = layer(tgt=tgt, tgt_query_pos=qpos, tgt_reference_points=ref, memory=memory, memory_key_padding_mask=mmask,
+                memory_level_start_index=lsi, memory_spatial_shapes=shapes, self_attn_mask=amask)
+    go = _rand32(torch.randn, out.shape, gen=gen)
+    out.backward(go)
+    arrays = dict(tgt=tgt, query_pos=qpos, memory=memory, reference_points=ref, shapes=shapes, lsi=lsi, memory_mask=mmask, attn_mask=amask,
+                  out=out, grad_out=go, grad_tgt=tgt.grad, grad_query_pos=qpos.grad, grad_memory=memory.grad)
+    np.savez_compressed(os.path.join(OUT, "layer256_decoder_f64.npz"), **{k: _np(v) for k, v in arrays.items()}, **LP.pack_grads(layer))
+    print("layer256_decoder_f64", tuple(out.shape))
+    # -- two-layer decoder with box refinement
+    nl = 2
+    gen = torch.Generator().manual_seed(421)
+    layer = dt.DeformableTransformerDecoderLayer(d_model=C, d_ffn=F, dropout=0.0, activation="relu", n_levels=L, n_heads=H, n_points=P,
+                                                 decoder_sa_type="sa", module_seq=["sa", "ca", "ffn"])
+    dec = dt.TransformerDecoder(layer, nl, torch.nn.LayerNorm(C), return_intermediate=True, d_model=C, query_dim=4,
+                                num_feature_levels=L, deformable_decoder=True, rm_dec_query_scale=True)
+    dec.bbox_embed = torch.nn.ModuleList([ut.MLP(C, C, 4, 3) for _ in range(nl)])
+    dec = LP.fill(dec.double(), 420)
+    tgt = _rand32(torch.randn, nq, N, C, gen=gen, requires_grad=True)
+    memory = _rand32(torch.randn, S, N, C, gen=gen, requires_grad=True)
+    refu = _rand32(torch.randn, nq, N, 4, gen=gen, requires_grad=True)
+    valid_ratios = _rand32(torch.rand, N, L, 2, gen=gen) * 0.3 + 0.7
+    mmask = torch.zeros(N, S, dtype=torch.bool)
+    mmask[1, lsi[2]:lsi[2] + 2] = True
+    hs, refs = dec(tgt=tgt, memory=memory, tgt_mask=amask, memory_key_padding_mask=mmask, pos=None, refpoints_unsigmoid=refu,
+                   level_start_index=lsi, spatial_shapes=shapes, valid_ratios=valid_ratios)
+    hs, refs = torch.stack(hs), torch.stack(refs)
+    g_hs = _rand32(torch.randn, hs.shape, gen=gen)
+    g_refs = _rand32(torch.randn, refs.shape, gen=gen)
+    ((hs * g_hs).sum() + (refs * g_refs).sum()).backward()
+    arrays = dict(tgt=tgt, memory=memory, refpoints_unsigmoid=refu, valid_ratios=valid_ratios, shapes=shapes, lsi=lsi, memory_mask=mmask,
+                  attn_mask=amask, hs=hs, refs=refs, grad_hs=g_hs, grad_refs=g_refs, grad_tgt=tgt.grad, grad_memory=memory.grad,
+                  grad_refpoints=refu.grad)
+    keep = lambda n: n.startswith(("layers.0.", "norm.", "ref_point_head.", "bbox_embed.1."))      # (a 0.9 M-parameter sample of 1.7 M)
+    np.savez_compressed(os.path.join(OUT, "decoder256_stack_f64.npz"), **{k: _np(v) for k, v in arrays.items()}, **LP.pack_grads(dec, keep))
+    print("decoder256_stack_f64", tuple(hs.shape))
+
+
 def denoising(dn):
     """prepare_for_cdn (dn_components.py:11-193): the integer / boolean part -- known_bid and map_known_indice are not returned by
     the function, so they are recovered from what it returns: the rows of ``input_query_bbox`` it scatters the boxes into."""
@@ -243,3 +340,4 @@ if __name__ == "__main__":
     decoder_layer(dt)
     decoder_stack(dt, ut)
     denoising(dn)
+    layers_256(dt, ut)

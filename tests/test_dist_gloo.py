@@ -144,3 +144,52 @@ def test_self_launch_builds_a_torchrun_command(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+# ---- the data-parallel training-step protocol of bench.py's `full_step_ddp` (bench_step.run_ddp) on two gloo ranks -----------------------
+class _TinyStep(torch.nn.Module):
+    """stand-in for bench_step.Step on the CPU (the Step's rows have no CPU path): what run_ddp needs of a module -- ``batch()`` -> forward
+    arguments, a scalar loss out of ``forward`` -- with rank-dependent data, so that equal parameters after the steps prove the all-reduce"""
+
+    def __init__(self, rank):
+        super().__init__()
+        torch.manual_seed(5)                      # equal initial weights on both ranks
+        self.net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
+        self.rank = rank
+
+    def batch(self):
+        g = torch.Generator().manual_seed(100 + self.rank)
+        return (torch.randn(8, 16, generator=g), torch.randn(8, 4, generator=g))
+
+    def forward(self, x, y):
+        return ((self.net(x) - y) ** 2).mean()
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench_step
+    holder = {}
+
+    def make():
+        holder["m"] = _TinyStep(rank)
+        return holder["m"]
+
+    res = bench_step.run_ddp(8, "cpu", dist, steps=3, warmup=1, optimizer=True, make_model=make)
+    assert res["world"] == world and res["ms"] > 0 and res["ms_no_collective"] > 0 and res["parameters_without_gradient"] == []
+    assert abs(res["img_per_s"] - world * 8 / (res["ms"] * 1e-3)) < 0.05 * res["img_per_s"]      # (`ms` is rounded to 10 us)
+    torch.save({"res": res, "w": holder["m"].net[0].weight.detach().clone()}, os.path.join(out_dir, f"ddp{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ddp_step_protocol_on_two_gloo_ranks(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_ddp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = (torch.load(os.path.join(str(tmp_path), f"ddp{r}.pt"), weights_only=False) for r in range(world))
+    assert a["res"]["ms"] == b["res"]["ms"] and a["res"]["ms_no_collective"] == b["res"]["ms_no_collective"]      # MAX over ranks, on every rank
+    # the timed DDP steps (with all-reduce) moved both ranks' weights together; the no_sync steps that follow let them drift by their own
+    # data -- so the weights differ now, but only by those last (1 + 3) un-synchronised AdamW steps of lr 1e-4
+    assert float((a["w"] - b["w"]).abs().max()) < 4 * 1e-4 * 1.5

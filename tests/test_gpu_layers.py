@@ -26,6 +26,14 @@ def _rel(a, b):
     return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-300)
 
 
+def _ratio(x, y, tag=None):
+    """mean |x - y| / mean |y|; RICHSEM_REPORT=1 prints it (the bounds below are 2 x what MI355X measures: profiles/r04_bf16_bounds.txt)"""
+    r = float((x.double() - y.double()).abs().mean()) / (float(y.double().abs().mean()) + 1e-12)
+    if tag and os.environ.get("RICHSEM_REPORT"):
+        print(f"[measured] {tag} {r:.4g}", flush=True)
+    return r
+
+
 def _check_params(mod, gr, tol):
     got = dict(mod.named_parameters())
     assert set(got) == set(gr), set(got) ^ set(gr)
@@ -85,6 +93,106 @@ def test_decoder_stack_against_the_reference_class():
     ((hs * t["grad_hs"]).sum() + (refs * t["grad_refs"]).sum()).backward()
     assert _rel(tgt.grad, t["grad_tgt"]) < 1e-7 and _rel(mem.grad, t["grad_memory"]) < 1e-7 and _rel(refu.grad, t["grad_refpoints"]) < 1e-7
     _check_params(dec, gr, 1e-7)
+
+
+# ---- d_model = 256, 8 heads: the bf16 kernels (K = 256 projections, 8 x 32-channel heads, fused feed-forward block) against fixtures of the
+#      REFERENCE's classes at that width (tests/golden/make_golden_layers.py: layers_256; parameters rebuilt by tests/layer_params.py) ------
+def _fix256(name):
+    import layer_params as LP
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    t = {k: torch.from_numpy(z[k]).cuda() for k in z.files if not k.startswith(("pgrad.", "pscale."))}
+    t = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in t.items()}
+    return t, {k: v.cuda() for k, v in LP.unpack_grads(z).items()}
+
+
+def _mean_rel(a, b):
+    return float((a.double() - b.double()).abs().mean()) / (float(b.double().abs().mean()) + 1e-300)
+
+
+def _errs_params(mod, gr):
+    got = dict(mod.named_parameters())
+    assert set(gr) <= set(got)
+    return {k: (_rel(got[k].grad.double(), want), _mean_rel(got[k].grad, want)) for k, want in gr.items()}
+
+
+def _build256(kind, dtype):
+    import layer_params as LP
+    from richsem_amd.modules import MLP, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, TransformerDecoder
+    C, F, L, H, P = LP.D_MODEL, LP.D_FFN, LP.LEVELS, LP.HEADS, LP.POINTS
+    if kind == "encoder":
+        m, seed = DeformableTransformerEncoderLayer(C, F, dropout=0.0, activation="relu", n_levels=L, n_heads=H, n_points=P), 400
+    elif kind == "decoder":
+        m, seed = DeformableTransformerDecoderLayer(C, F, dropout=0.0, activation="relu", n_levels=L, n_heads=H, n_points=P), 410
+    else:
+        layer = DeformableTransformerDecoderLayer(C, F, dropout=0.0, activation="relu", n_levels=L, n_heads=H, n_points=P)
+        m, seed = TransformerDecoder(layer, 2, torch.nn.LayerNorm(C), d_model=C, query_dim=4, num_feature_levels=L), 420
+        m.bbox_embed = torch.nn.ModuleList([MLP(C, C, 4, 3) for _ in range(2)])
+    return LP.fill(m.double(), seed).to(dtype).cuda()
+
+
+def _run256(kind, dtype, act):
+    """the mirror of `kind` with parameters in `dtype` on activations cast to `act` -> (outputs, input gradients, module)"""
+    t, gr = _fix256({"encoder": "layer256_encoder_f64", "decoder": "layer256_decoder_f64", "stack": "decoder256_stack_f64"}[kind])
+    m = _build256(kind, dtype)
+    if kind == "encoder":
+        m.fused_min_tokens = 0                       # (256 tokens: the fused feed-forward kernel is exercised, whatever its speed here)
+    leaf = lambda k: t[k].to(act).clone().requires_grad_(True)
+    if kind == "encoder":
+        src, pos = leaf("src"), leaf("pos")
+        out = m(src, pos, t["reference_points"].to(torch.float32 if act == torch.bfloat16 else act), t["shapes"], t["lsi"], t["mask"])
+        out.backward(t["grad_out"].to(out.dtype))
+        return {"out": (out, t["out"]), "grad_src": (src.grad, t["grad_src"]), "grad_pos": (pos.grad, t["grad_pos"])}, m, gr
+    if kind == "decoder":
+        tgt, qpos, mem = leaf("tgt"), leaf("query_pos"), leaf("memory")
+        out = m(tgt=tgt, tgt_query_pos=qpos, tgt_reference_points=t["reference_points"].to(torch.float32 if act == torch.bfloat16 else act),
+                memory=mem, memory_key_padding_mask=t["memory_mask"], memory_level_start_index=t["lsi"], memory_spatial_shapes=t["shapes"],
+                self_attn_mask=t["attn_mask"])
+        out.backward(t["grad_out"].to(out.dtype))
+        return {"out": (out, t["out"]), "grad_tgt": (tgt.grad, t["grad_tgt"]), "grad_query_pos": (qpos.grad, t["grad_query_pos"]),
+                "grad_memory": (mem.grad, t["grad_memory"])}, m, gr
+    tgt, mem = leaf("tgt"), leaf("memory")
+    refu = t["refpoints_unsigmoid"].to(torch.float32 if act == torch.bfloat16 else act).clone().requires_grad_(True)
+    hs, refs = m(tgt=tgt, memory=mem, tgt_mask=t["attn_mask"], memory_key_padding_mask=t["memory_mask"], refpoints_unsigmoid=refu,
+                 level_start_index=t["lsi"], spatial_shapes=t["shapes"], valid_ratios=t["valid_ratios"].to(refu.dtype))
+    hs, refs = torch.stack(hs), torch.stack(refs)
+    ((hs.double() * t["grad_hs"]).sum() + (refs.double() * t["grad_refs"]).sum()).backward()
+    return {"hs": (hs, t["hs"]), "refs": (refs, t["refs"]), "grad_tgt": (tgt.grad, t["grad_tgt"]), "grad_memory": (mem.grad, t["grad_memory"]),
+            "grad_refpoints": (refu.grad, t["grad_refpoints"])}, m, gr
+
+
+@pytest.mark.parametrize("kind", ["encoder", "decoder", "stack"])
+def test_layers256_fp64_mirrors_equal_the_reference_classes(kind):
+    """the fixture and the rebuilt parameters belong together: the fp64 mirrors reproduce the reference's outputs to what the fixture's
+    storage keeps (float32 activations: 6e-8; float16 gradient mantissas: 5e-4)"""
+    res, m, gr = _run256(kind, torch.float64, torch.float64)
+    for k, (got, want) in res.items():
+        assert _rel(got.double(), want) < 5e-7, (k, _rel(got.double(), want))
+    for k, (mx, _) in _errs_params(m, gr).items():
+        assert mx < 1e-3, (k, mx)
+
+
+# bf16 activations / fp32 master parameters on the library's kernels against the reference's fp64 outputs: (max error / max |want|,
+# mean error / mean |want|) per tensor.  The bounds are 2 x what MI355X measures (tools/measure_layer256.py, profiles/r04_layer256.txt);
+# PyTorch's own bf16 ops on the same fixtures measure the same or worse on every tensor (same file: e.g. linear1.weight 0.21 for both --
+# a hidden unit whose sign flips under bf16 rounding moves its whole row of the gradient -- sampling_offsets.weight 0.10 here, 0.30 there)
+BF16_BOUNDS = {
+    "encoder": {"out": (1.1e-2, 7e-3), "grad_src": (0.14, 3.6e-2), "grad_pos": (0.13, 4.5e-2), "params": (0.43, 6.2e-2)},
+    "decoder": {"out": (1.5e-2, 1e-2), "grad_tgt": (0.16, 5.7e-2), "grad_query_pos": (0.1, 5.9e-2), "grad_memory": (7e-2, 6e-2), "params": (0.42, 8e-2)},
+    "stack": {"hs": (1.5e-2, 1.1e-2), "refs": (6.3e-3, 1.6e-3), "grad_tgt": (0.11, 6.4e-2), "grad_memory": (6e-2, 7e-2), "grad_refpoints": (0.17, 6.5e-2),
+              "params": (0.41, 0.137)},
+}
+
+
+@pytest.mark.parametrize("kind", ["encoder", "decoder", "stack"])
+def test_layers256_bf16_kernels_against_the_reference_classes(kind):
+    res, m, gr = _run256(kind, torch.float32, torch.bfloat16)
+    bounds = BF16_BOUNDS[kind]
+    for k, (got, want) in res.items():
+        assert got.dtype in (torch.bfloat16, torch.float32)
+        e = (_rel(got.double(), want), _mean_rel(got, want))
+        assert e[0] < bounds[k][0] and e[1] < bounds[k][1], (k, e)
+    worst = {k: e for k, e in _errs_params(m, gr).items() if e[0] > bounds["params"][0] or e[1] > bounds["params"][1]}
+    assert not worst, worst
 
 
 # ---- the attention kernels (csrc/attn_mfma.hip) against the definition -------------------------------------------------------------
@@ -205,6 +313,13 @@ def _decoder_pair(layers=2):
     return dec
 
 
+# mean |bf16 - fp32| / mean |fp32| of the bf16 layer paths against their own fp32 path: at most 2 x what MI355X measures
+# (profiles/r04_bf16_bounds.txt: decoder hs 4.7e-3, refs 1.7e-4, input gradients 7.6e-2 / 5.4e-2, worst parameter gradient 0.139 --
+# sampling_offsets of the second layer --; encoder out 3.6e-3, grad_src 1.4e-2, grad_pos 3.6e-2, worst parameter gradient 0.105)
+HS_TOL, REFS_TOL, GRAD_IN_TOL, GRAD_PARAM_TOL = 1e-2, 5e-4, 0.12, 0.25
+ENC_OUT_TOL, ENC_GRAD_SRC_TOL, ENC_GRAD_POS_TOL, ENC_PARAM_TOL = 8e-3, 3e-2, 7.5e-2, 0.21
+
+
 def test_bf16_decoder_on_the_library_kernels_is_close_to_its_fp32_path():
     """the bf16 decoder (lin256 projections, attention kernels, stacked value projection, fused add + LayerNorm, small-token FFN) against the
     same module's fp32 path -- the op sequence the reference-generated fixtures above pin -- on a shrunk decoder-shaped call"""
@@ -235,11 +350,52 @@ def test_bf16_decoder_on_the_library_kernels_is_close_to_its_fp32_path():
         res[dt] = (hs.detach(), refs.detach(), a.grad.float(), m.grad.float(), {k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None})
         dec.zero_grad()
     (h32, r32, ga32, gm32, gp32), (h16, r16, ga16, gm16, gp16) = res[torch.float32], res[torch.bfloat16]
-    close = lambda x, y, tol: float((x - y).abs().mean()) <= tol * (float(y.abs().mean()) + 1e-12)
-    assert close(h16, h32, 3e-2) and close(r16, r32, 2e-2)
-    assert close(ga16, ga32, 0.12) and close(gm16, gm32, 0.12)
-    bad = [k for k in gp32 if gp32[k].abs().mean() > 0 and not close(gp16[k].float(), gp32[k], 0.25)]
-    assert not bad, bad
+    assert _ratio(h16, h32, "decoder hs") < HS_TOL and _ratio(r16, r32, "decoder refs") < REFS_TOL
+    assert _ratio(ga16, ga32, "decoder grad_tgt") < GRAD_IN_TOL and _ratio(gm16, gm32, "decoder grad_memory") < GRAD_IN_TOL
+    worst = max((_ratio(gp16[k].float(), gp32[k]), k) for k in gp32 if gp32[k].abs().mean() > 0)
+    _ratio(gp16[worst[1]].float(), gp32[worst[1]], "decoder worst parameter gradient " + worst[1])
+    assert worst[0] < GRAD_PARAM_TOL, worst
+
+
+def test_bf16_encoder_layer_close_to_fp32_path():
+    """the bf16 ENCODER layer at the shipped width (d_model 256, d_ffn 2048, 8 heads) with the DEFAULT thresholds -- 16800 tokens: lin256
+    projections with the padding mask in the epilogue, the operator's bf16 entry points (routed backward), add + LayerNorm kernel, the
+    fused feed-forward kernel and its backward -- against the same layer's fp32 op sequence, which the reference-class fixtures pin
+    (round-3 verdict: the largest row of the composed step had no numeric layer-level test)"""
+    from richsem_amd import workload as W
+    from richsem_amd.modules import DeformableTransformerEncoderLayer, get_reference_points
+    from richsem_amd.functions.ffn import FUSED_FFN_MIN_TOKENS
+    call = W.shrunk(W.call_E(3), 2)                       # 3 images of the half-size pyramid: 3 x 5600 tokens
+    assert call.N * call.S >= FUSED_FFN_MIN_TOKENS
+    shapes, lsi = W.level_tensors(call, "cuda")
+    torch.manual_seed(21)
+    layer = DeformableTransformerEncoderLayer(256, 2048, dropout=0.0, activation="relu", n_levels=4, n_heads=8, n_points=4).cuda()
+    with torch.no_grad():
+        layer.self_attn.sampling_offsets.weight.normal_(0, 0.01)
+        layer.self_attn.attention_weights.weight.normal_(0, 0.05)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    src = torch.randn(call.N, call.S, 256, device="cuda", generator=g)
+    pos = torch.randn(call.N, call.S, 256, device="cuda", generator=g)
+    vr = torch.rand(call.N, 4, 2, device="cuda", generator=g) * 0.2 + 0.8
+    ref = get_reference_points(shapes.tolist(), vr, "cuda")
+    mask = torch.zeros(call.N, call.S, dtype=torch.bool, device="cuda")
+    mask[1, 80:84] = True
+    mask[2, -5:] = True
+    go = torch.randn(call.N, call.S, 256, device="cuda", generator=g)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        a, p = src.clone().to(dt).requires_grad_(True), pos.clone().to(dt).requires_grad_(True)
+        out = layer(a, p, ref, shapes, lsi, mask)
+        assert out.dtype == dt
+        out.backward(go.to(dt))
+        res[dt] = (out.detach().float(), a.grad.float(), p.grad.float(), {k: q.grad.clone() for k, q in layer.named_parameters()})
+        layer.zero_grad()
+    (o32, a32, p32, g32), (o16, a16, p16, g16) = res[torch.float32], res[torch.bfloat16]
+    assert _ratio(o16, o32, "encoder out") < ENC_OUT_TOL
+    assert _ratio(a16, a32, "encoder grad_src") < ENC_GRAD_SRC_TOL and _ratio(p16, p32, "encoder grad_pos") < ENC_GRAD_POS_TOL
+    worst = max((_ratio(g16[k].float(), g32[k]), k) for k in g32)
+    _ratio(g16[worst[1]].float(), g32[worst[1]], "encoder worst parameter gradient " + worst[1])
+    assert worst[0] < ENC_PARAM_TOL, worst
 
 
 def test_bf16_layer_follows_an_optimizer_step():

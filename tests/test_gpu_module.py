@@ -121,6 +121,11 @@ def test_fused_path_float32_full_size_encoder_call():
         assert float((x - y).abs().max()) <= 2e-4 * float(y.abs().max()) + 1e-7
 
 
+# (2 x what MI355X measures for the encoder-shaped call, profiles/r04_bf16_bounds.txt: out 1.0e-2, grad_query 2.2e-2, grad_src 1.1e-2,
+# grad_ref 2.1e-2, worst parameter gradient 7.2e-2 -- the small sampling_offsets bias)
+MOD_TOL = {"out": 2e-2, "grad_query": 4.5e-2, "grad_src": 2.2e-2, "grad_ref": 4.2e-2, "params": 0.145}
+
+
 @pytest.mark.parametrize("ref_dim", [2, 4])
 def test_module_bf16_path_close_to_fp32(ref_dim):
     """bf16 activations through the fused path (bf16 GEMMs, msda_prep_*_bf16, the operator's bf16 entry points) against the
@@ -155,7 +160,13 @@ def test_module_bf16_path_close_to_fp32(ref_dim):
 
     o32, q32, s32, r32, g32 = run(torch.float32)
     o16, q16, s16, r16, g16 = run(torch.bfloat16)
-    close = lambda a, b, tol: float((a - b).abs().mean()) <= tol * (float(b.abs().mean()) + 1e-12)
-    assert close(o16, o32, 2e-2) and close(q16, q32, 5e-2) and close(s16, s32, 3e-2) and close(r16, r32, 8e-2)
-    for n in g32:
-        assert close(g16[n].float(), g32[n], 0.15), n   # (measured: up to 0.07 for the small sampling_offsets gradient)
+    def ratio(a, b, tag):
+        r = float((a - b).abs().mean()) / (float(b.abs().mean()) + 1e-12)
+        if os.environ.get("RICHSEM_REPORT"):
+            print(f"[measured] module ref_dim={ref_dim} {tag} {r:.4g}", flush=True)
+        return r
+    # (bounds: 2 x what MI355X measures, profiles/r04_bf16_bounds.txt)
+    assert ratio(o16, o32, "out") < MOD_TOL["out"] and ratio(q16, q32, "grad_query") < MOD_TOL["grad_query"]
+    assert ratio(s16, s32, "grad_src") < MOD_TOL["grad_src"] and ratio(r16, r32, "grad_ref") < MOD_TOL["grad_ref"]
+    worst = max((ratio(g16[n].float(), g32[n], "param " + n), n) for n in g32)
+    assert worst[0] < MOD_TOL["params"], worst
