@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RICHSEM_MSDA_ABI_VERSION 5
+#define RICHSEM_MSDA_ABI_VERSION 6
 
 /* Return codes: 0 = success; negative = argument error detected on the host (nothing was
  * launched); positive = hipError_t reported by the runtime. */
@@ -246,6 +246,27 @@ int msda_prep_backward_bf16(const float *grad_loc, const float *grad_aw, const f
                             const int64_t *shapes_host, int N, int Lq, int M, int L, int P,
                             uint16_t *grad_offsets, int64_t goff_stride, uint16_t *grad_logits, int64_t glog_stride,
                             float *grad_ref, msda_stream_t stream);
+/* msda_forward_prep_*: what msda_prep_forward_* followed by msda_forward_* compute, behind ONE entry point (SURVEY.md section 8f rank 1:
+ * "softmax + location math fused into the gather kernel"; reference ops/modules/ms_deform_attn.py:97-114).  Arguments as those two;
+ * sampling_loc / attn_weight are OUTPUTS (the module's backward needs them) and must not be NULL.  Decoder-shaped calls (Lq != S,
+ * L*P <= 32) run as one kernel that resolves the sampling points from the raw projection and never re-reads sampling_loc; other calls
+ * run the two kernels one after the other (the encoder-shaped forward keeps its LDS-window kernel and locality monitor).
+ * msda_set_option("fwd_prep_fused", 0) forces the two-kernel form everywhere. */
+int msda_forward_prep_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                          const float *offsets, int64_t off_stride, const float *logits, int64_t log_stride,
+                          const float *ref, int ref_dim, int N, int S, int M, int D, int L, int Lq, int P, int im2col_step,
+                          float *out, float *sampling_loc, float *attn_weight,
+                          const int64_t *shapes_host, const int64_t *level_start_host, msda_stream_t stream);
+int msda_forward_prep_f64(const double *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                          const double *offsets, int64_t off_stride, const double *logits, int64_t log_stride,
+                          const double *ref, int ref_dim, int N, int S, int M, int D, int L, int Lq, int P, int im2col_step,
+                          double *out, double *sampling_loc, double *attn_weight,
+                          const int64_t *shapes_host, const int64_t *level_start_host, msda_stream_t stream);
+int msda_forward_prep_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                           const uint16_t *offsets, int64_t off_stride, const uint16_t *logits, int64_t log_stride,
+                           const float *ref, int ref_dim, int N, int S, int M, int D, int L, int Lq, int P, int im2col_step,
+                           uint16_t *out, float *sampling_loc, float *attn_weight,
+                           const int64_t *shapes_host, const int64_t *level_start_host, msda_stream_t stream);
 int msda_mask_rows_f32(float *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);
 int msda_mask_rows_f64(double *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);
 int msda_mask_rows_bf16(uint16_t *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);

@@ -16,7 +16,7 @@ ERR_NAMES = {
     -4: "MSDA_ERR_TOO_LARGE", -5: "MSDA_ERR_MISALIGNED", -6: "MSDA_ERR_NO_DEVICE", -7: "MSDA_ERR_BAD_OPTION",
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/richsem_msda.h declares
 SYMBOLS = [
@@ -25,7 +25,7 @@ SYMBOLS = [
     "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64",
     "msda_forward_bf16", "msda_backward_bf16",
     "msda_prep_forward_f32", "msda_prep_forward_f64", "msda_prep_backward_f32", "msda_prep_backward_f64",
-    "msda_prep_forward_bf16", "msda_prep_backward_bf16",
+    "msda_prep_forward_bf16", "msda_prep_backward_bf16", "msda_forward_prep_f32", "msda_forward_prep_f64", "msda_forward_prep_bf16",
     "msda_mask_rows_f32", "msda_mask_rows_f64", "msda_mask_rows_bf16",
     "msda_dn_indices_i64", "msda_dn_attn_mask_u8", "msda_topk_f32", "msda_sine_embed_bf16", "msda_narrow_linear_backward_bf16", "msda_box_refine_forward", "msda_box_refine_backward", "msda_roi_align_forward_f32", "msda_roi_align_forward_f64",
     "msda_ffn_pack_w2_bf16", "msda_ffn_forward_bf16", "msda_ffn_debug_stamps", "msda_ffn_forward_train_bf16", "msda_ffn_ln_backward_bf16", "msda_add_layernorm_forward_bf16", "msda_lin256_pack_bf16", "msda_lin256_forward_bf16", "msda_lin256_pack_f32", "msda_lin256_forward_f32", "msda_lin256_forward_stacked_bf16",
@@ -182,6 +182,10 @@ def load():
         g = getattr(L, "msda_prep_backward_" + sfx)
         g.argtypes = [vp, vp, vp, vp, i64, vp, ci, vp] + [ci] * 5 + [vp, i64, vp, i64, vp, vp]
         g.restype = ci
+    for sfx in ("f32", "f64", "bf16"):
+        f = getattr(L, "msda_forward_prep_" + sfx)
+        f.argtypes = [vp, vp, vp, vp, i64, vp, i64, vp, ci] + [ci] * 8 + [vp, vp, vp, vp, vp, vp]
+        f.restype = ci
     for sfx in ("f32", "f64", "bf16"):
         f = getattr(L, "msda_mask_rows_" + sfx)
         f.argtypes = [vp, vp, i64, ci, vp]

@@ -59,7 +59,7 @@ int hip_fail(hipError_t e, const char *what)
     return (int)e;
 }
 
-std::atomic<int> g_fwd_variant{0}, g_bwd_variant{0}, g_bwd_cpl{0}, g_levelsum{1};
+std::atomic<int> g_fwd_variant{0}, g_bwd_variant{0}, g_bwd_cpl{0}, g_levelsum{1}, g_fwd_prep_fused{1};
 
 // ---- launch profiler: pre-created event pairs, one per logged call -----------------------------
 struct ProfileSlot {
@@ -576,7 +576,8 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
     }
 
     const int C = pick_channels_per_lane<T>(D, {value, out});
-    const msda::DirectGeom g = direct_geom(pb, C);
+    msda::DirectGeom g = direct_geom(pb, C);
+    g.head_major = (msda::tiled_options().dbg & 128) ? 1 : 0;      // (measured experiment: value read as (N, M, S, D))
     const size_t lds = msda::direct_lds_bytes<T>(g);
     if (lds > 64 * 1024) return fail(MSDA_ERR_BAD_DIMS, "too many levels (L=%d) for the level table in LDS", L);
     const dim3 grid(direct_grid(g)), block(msda::kDirectThreads);
@@ -954,6 +955,60 @@ int mask_rows_impl(T *x, const uint8_t *mask, int64_t rows, int row_elems, msda_
 
 }  // namespace
 
+// ---- msda_forward_prep_*: the module's softmax + location arithmetic and the operator's forward behind ONE entry point ----------------
+// Decoder-shaped calls (Lq != S) with L * P <= 32 run fwd_direct_prep_kernel -- one launch, sampling_loc / attn_weight written as a
+// by-product --; everything else (the encoder-shaped calls keep their LDS-window kernel and its locality monitor, which read
+// sampling_loc) runs the location / softmax kernel and then the forward of the same library, as two launches.  Results are those of
+// msda_prep_forward_* followed by msda_forward_* (the softmax sums in a different order: last-ulp differences).
+template <typename T, typename TV, typename TP>
+int forward_prep_impl(const TV *value, const int64_t *shapes, const int64_t *lsi, const TP *offsets, int64_t off_stride, const TP *logits,
+                      int64_t log_stride, const T *ref, int ref_dim, int N, int S, int M, int D, int L, int Lq, int P, int im2col_step,
+                      TV *out, T *loc, T *aw, const int64_t *shapes_host, const int64_t *lsi_host, msda_stream_t stream_)
+{
+    g_err[0] = 0;
+    if (!value || !shapes || !lsi || !offsets || !logits || !ref || !out || !loc || !aw) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+    if (ref_dim != 2 && ref_dim != 4) return fail(MSDA_ERR_BAD_DIMS, "reference points must have 2 or 4 components, got %d", ref_dim);
+    if (off_stride < (int64_t)M * L * P * 2 || log_stride < (int64_t)M * L * P)
+        return fail(MSDA_ERR_BAD_DIMS, "row stride smaller than a row (offsets %lld, logits %lld)", (long long)off_stride, (long long)log_stride);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const bool fused = g_fwd_prep_fused.load() && Lq != S && L * P <= msda::kPointBatch;
+    if (!fused) {
+        if (int rc = prep_forward_impl<T, TP>(offsets, off_stride, logits, log_stride, ref, ref_dim, shapes_host, N, Lq, M, L, P, loc, aw, stream_))
+            return rc;
+        if constexpr (std::is_same<TV, msda::bf16_t>::value)
+            return forward_bf16_impl(value, shapes, lsi, loc, aw, N, S, M, D, L, Lq, P, im2col_step, out, shapes_host, lsi_host, stream_);
+        else
+            return forward_impl<T>(value, shapes, lsi, loc, aw, N, S, M, D, L, Lq, P, im2col_step, out, shapes_host, lsi_host, stream_);
+    }
+    Problem pb{N, S, M, D, L, Lq, P, {}, {}};
+    if (int rc = check_problem(pb, shapes, lsi, shapes_host, lsi_host, im2col_step, stream)) return rc;
+    if (!is_aligned(value, sizeof(TV)) || !is_aligned(out, sizeof(TV)) || !is_aligned(aw, sizeof(T)) || !is_aligned(loc, 2 * sizeof(T)) ||
+        !is_aligned(ref, sizeof(T)) || !is_aligned(offsets, sizeof(TP)) || !is_aligned(logits, sizeof(TP)) || !is_aligned(shapes, 8) || !is_aligned(lsi, 8))
+        return fail(MSDA_ERR_MISALIGNED, "misaligned pointer (sampling_loc needs 2*sizeof(T))");
+    int C;
+    if constexpr (std::is_same<TV, msda::bf16_t>::value) C = pick_channels_bf16(D, {value, out});
+    else C = pick_channels_per_lane<T>(D, {value, out});
+    const msda::DirectGeom g = direct_geom(pb, C);
+    const size_t lds = msda::direct_lds_bytes<T>(g);
+    if (lds > 64 * 1024) return fail(MSDA_ERR_BAD_DIMS, "too many levels (L=%d) for the level table in LDS", L);
+    const dim3 grid(direct_grid(g)), block(msda::kDirectThreads);
+    const msda::PrepSrc<TP> src{offsets, logits, off_stride, log_stride, ref_dim};
+    ProfileScope prof(0, 5, (int)sizeof(TV), N, S, M, D, L, Lq, P, stream);
+    const bool many = (int64_t)N * Lq * M >= 65536;
+#define MSDA_LAUNCH_FWDP(CC)                                                                                                                    \
+    if (many) hipLaunchKernelGGL((msda::fwd_direct_prep_kernel<T, CC, 6, TV, TP>), grid, block, lds, stream, value, shapes, lsi, src, ref, loc, aw, out, g); \
+    else hipLaunchKernelGGL((msda::fwd_direct_prep_kernel<T, CC, 4, TV, TP>), grid, block, lds, stream, value, shapes, lsi, src, ref, loc, aw, out, g)
+    switch (C) {
+        case 4: MSDA_LAUNCH_FWDP((sizeof(T) == 4 ? 4 : 2)); break;
+        case 2: MSDA_LAUNCH_FWDP(2); break;
+        default: MSDA_LAUNCH_FWDP(1); break;
+    }
+#undef MSDA_LAUNCH_FWDP
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch of the fused location / softmax / gather kernel");
+    return MSDA_OK;
+}
+
 extern "C" {
 
 int msda_abi_version(void) { return RICHSEM_MSDA_ABI_VERSION; }
@@ -963,6 +1018,7 @@ const char *msda_last_error(void) { return g_err; }
 int msda_set_option(const char *key, int value)
 {
     if (key && !strcmp(key, "fwd_variant") && value >= 0 && value <= 2) { g_fwd_variant = value; return MSDA_OK; }
+    if (key && !strcmp(key, "fwd_prep_fused") && value >= 0 && value <= 1) { g_fwd_prep_fused = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_variant") && (value == 0 || value == 1 || value == 4)) { g_bwd_variant = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_tile") && value >= 4 && value <= 16) { msda::rps_options().tile = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_max_chunks") && value >= 1 && value <= 4096) { msda::rps_options().max_chunks = value; return MSDA_OK; }
@@ -993,6 +1049,7 @@ int msda_get_option(const char *key, int *value)
 {
     if (!value) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
     if (key && !strcmp(key, "fwd_variant")) { *value = g_fwd_variant; return MSDA_OK; }
+    if (key && !strcmp(key, "fwd_prep_fused")) { *value = g_fwd_prep_fused; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_variant")) { *value = g_bwd_variant; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_direct_cpl")) { *value = g_bwd_cpl; return MSDA_OK; }
     if (key && !strcmp(key, "rps_tile")) { *value = msda::rps_options().tile; return MSDA_OK; }
@@ -1168,6 +1225,34 @@ int msda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes, con
                               attn_weight, reinterpret_cast<const msda::bf16_t *>(grad_out), N, S, M, D, L, Lq, P, im2col_step,
                               reinterpret_cast<msda::bf16_t *>(grad_value), grad_sampling_loc, grad_attn_weight, shapes_host,
                               level_start_host, stream);
+}
+
+int msda_forward_prep_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start, const float *offsets,
+                          int64_t off_stride, const float *logits, int64_t log_stride, const float *ref, int ref_dim, int N, int S, int M, int D,
+                          int L, int Lq, int P, int im2col_step, float *out, float *sampling_loc, float *attn_weight,
+                          const int64_t *shapes_host, const int64_t *level_start_host, msda_stream_t stream)
+{
+    return forward_prep_impl<float, float, float>(value, spatial_shapes, level_start, offsets, off_stride, logits, log_stride, ref, ref_dim, N, S, M,
+                                                  D, L, Lq, P, im2col_step, out, sampling_loc, attn_weight, shapes_host, level_start_host, stream);
+}
+int msda_forward_prep_f64(const double *value, const int64_t *spatial_shapes, const int64_t *level_start, const double *offsets,
+                          int64_t off_stride, const double *logits, int64_t log_stride, const double *ref, int ref_dim, int N, int S, int M, int D,
+                          int L, int Lq, int P, int im2col_step, double *out, double *sampling_loc, double *attn_weight,
+                          const int64_t *shapes_host, const int64_t *level_start_host, msda_stream_t stream)
+{
+    return forward_prep_impl<double, double, double>(value, spatial_shapes, level_start, offsets, off_stride, logits, log_stride, ref, ref_dim, N, S,
+                                                     M, D, L, Lq, P, im2col_step, out, sampling_loc, attn_weight, shapes_host, level_start_host,
+                                                     stream);
+}
+int msda_forward_prep_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start, const uint16_t *offsets,
+                           int64_t off_stride, const uint16_t *logits, int64_t log_stride, const float *ref, int ref_dim, int N, int S, int M,
+                           int D, int L, int Lq, int P, int im2col_step, uint16_t *out, float *sampling_loc, float *attn_weight,
+                           const int64_t *shapes_host, const int64_t *level_start_host, msda_stream_t stream)
+{
+    return forward_prep_impl<float, msda::bf16_t, msda::bf16_t>(
+        reinterpret_cast<const msda::bf16_t *>(value), spatial_shapes, level_start, reinterpret_cast<const msda::bf16_t *>(offsets), off_stride,
+        reinterpret_cast<const msda::bf16_t *>(logits), log_stride, ref, ref_dim, N, S, M, D, L, Lq, P, im2col_step,
+        reinterpret_cast<msda::bf16_t *>(out), sampling_loc, attn_weight, shapes_host, level_start_host, stream);
 }
 
 #define MSDA_PREP_EXPORTS(SFX, T)                                                                                                  \

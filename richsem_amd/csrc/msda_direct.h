@@ -22,6 +22,7 @@
 #pragma once
 
 #include "msda_common.h"
+#include "msda_prep.h"      // prep_ld: element loads of the raw projection (fwd_direct_prep_kernel)
 
 namespace msda {
 
@@ -31,6 +32,7 @@ struct DirectGeom {
     int qtile, ntiles;     // queries per block, tiles per (b,m) pair
     int pbatch;            // sampling points staged in LDS per pass: min(L*P, kPointBatch)
     unsigned gv_skip;      // backward: bit l set = grad_value of level l is produced elsewhere (msda_levelsum.h)
+    int head_major;        // forward, measured experiment (round 4): value is (N, M, S, D) instead of the reference's (N, S, M, D)
 };
 
 constexpr int kDirectThreads = 256;
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(kDirectThreads, OCC) void fwd_direct_kernel(
     const int j = lane & (g.G - 1);               // lane within the group
     const int slot = wave * ipw + (lane >> g.logG);
     const int LP = g.L * g.P;
-    const int row_elems = g.M * g.D;
+    const int row_elems = g.head_major ? g.D : g.M * g.D;
     PointRec<T> *my = recs + slot * (g.pbatch + 1);
 
     const int q_end = min((tile + 1) * g.qtile, g.Lq);
@@ -105,7 +107,8 @@ __global__ __launch_bounds__(kDirectThreads, OCC) void fwd_direct_kernel(
                         const LevelGeom G_ = lv[l];
                         PointRec<T> r;
                         T lh, lw;
-                        resolve_point<T>(xy.v[0], xy.v[1], G_.H, G_.W, (b * g.S + G_.start) * row_elems + m * g.D,
+                        resolve_point<T>(xy.v[0], xy.v[1], G_.H, G_.W,
+                                         g.head_major ? ((b * g.M + m) * g.S + G_.start) * g.D : (b * g.S + G_.start) * row_elems + m * g.D,
                                          row_elems, r.o, lh, lw);
                         const T hh = (T)1 - lh, hw = (T)1 - lw;
                         r.f[0] = hh * hw * a;
@@ -147,6 +150,145 @@ __global__ __launch_bounds__(kDirectThreads, OCC) void fwd_direct_kernel(
                 *reinterpret_cast<Pack<TV, C> *>(out + (int64_t)item * g.D + c0) = o;
             }
         }
+    }
+}
+
+// ---- the module's element-wise work FUSED into the gather -----------------------------------------
+// fwd_direct_prep_kernel = fwd_direct_kernel whose point resolution reads the RAW projection of the module -- sampling offsets and
+// attention logits (reference ops/modules/ms_deform_attn.py:97-99), addressed with a row stride so that both come out of one GEMM -- and
+// the reference points, and does what the reference module does between the projections and the operator (:100 softmax over the L*P
+// logits of a (query, head); :102-109 location = reference + offset / (W_l, H_l), or reference_xy + offset / P * reference_wh * 0.5):
+// lane j of an item's group holds the logits of points j, j + G, ..., the softmax's maximum and sum are two butterfly reductions over the
+// group.  sampling_loc / attn_weight are written as a by-product when the caller wants them (training: the backward needs them);
+// the gather never re-reads them.  One launch instead of two for decoder-shaped calls (prep 19.5 us + gather 29 us at 1092 queries).
+// Needs all L*P points of an item in one pass (L*P <= kPointBatch).
+template <typename TP>
+struct PrepSrc {
+    const TP *offsets, *logits;            // raw projection: offsets[(n, q) * off_stride + (m * LP + pt) * 2 + {0, 1}], logits[(n, q) * log_stride + m * LP + pt]
+    long long off_stride, log_stride;
+    int ref_dim;                            // 2: reference points (x, y); 4: reference boxes (x, y, w, h)
+};
+
+template <typename T, int C, int OCC, typename TV, typename TP>
+__global__ __launch_bounds__(kDirectThreads, OCC) void fwd_direct_prep_kernel(
+    const TV *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi, const PrepSrc<TP> src,
+    const T *__restrict__ ref, T *__restrict__ loc_out, T *__restrict__ aw_out, TV *__restrict__ out, const DirectGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LevelGeom *lv = reinterpret_cast<LevelGeom *>(smem);
+    PointRec<T> *recs = reinterpret_cast<PointRec<T> *>(smem + sizeof(LevelGeom) * g.L);
+
+    int pair, tile;
+    if (!decode_block(blockIdx.x, g.N * g.M, g.ntiles, pair, tile)) return;  // block-uniform
+    load_levels(lv, shapes, lsi, g.L);
+
+    const int b = pair / g.M, m = pair - b * g.M;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int ipw = kWave >> g.logG;              // items per wave
+    const int j = lane & (g.G - 1);               // lane within the group
+    const int slot = wave * ipw + (lane >> g.logG);
+    const int LP = g.L * g.P;                     // (<= pbatch: the host launches this kernel only then)
+    const int row_elems = g.M * g.D;
+    PointRec<T> *my = recs + slot * (g.pbatch + 1);
+    constexpr int kPerLane = kPointBatch / kMinGroup;   // points a lane resolves at most
+
+    const int q_end = min((tile + 1) * g.qtile, g.Lq);
+    for (int q0 = tile * g.qtile; q0 < q_end; q0 += kDirectWaves * ipw) {   // block-uniform trip count
+        const int q = q0 + slot;
+        const bool live = q < q_end;
+        const long long nq = (long long)b * g.Lq + (live ? q : q_end - 1);
+        const long long item = nq * g.M + m;
+        // (1) this lane's points: logits -> softmax over the item's group -> locations -> corner records in the item's LDS slot.
+        //     (the group's lanes all belong to one item: the butterflies stay inside it, and `live` is uniform over the group)
+        T lg[kPerLane];
+        T mx = (T)-3.0e38;
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) {
+            const int pt = j + i * g.G;
+            lg[i] = pt < LP ? prep_ld<T>(src.logits + nq * src.log_stride + (long long)m * LP + pt) : (T)-3.0e38;
+            mx = lg[i] > mx ? lg[i] : mx;
+        }
+        for (int s_ = 1; s_ < g.G; s_ <<= 1) {
+            const T o = __shfl_xor(mx, s_, kWave);
+            mx = o > mx ? o : mx;
+        }
+        T sum = (T)0;
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) {
+            lg[i] = j + i * g.G < LP ? exp(lg[i] - mx) : (T)0;
+            sum += lg[i];
+        }
+        for (int s_ = 1; s_ < g.G; s_ <<= 1) sum += __shfl_xor(sum, s_, kWave);
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) {
+            const int pt = j + i * g.G;
+            if (live && pt < LP) {
+                const int l = pt / g.P;
+                const T a = lg[i] / sum;
+                const TP *o = src.offsets + nq * src.off_stride + ((long long)m * LP + pt) * 2;
+                const T ox = prep_ld<T>(o), oy = prep_ld<T>(o + 1);
+                const T *r = ref + (nq * g.L + l) * src.ref_dim;
+                const LevelGeom G_ = lv[l];
+                T lx, ly;
+                if (src.ref_dim == 2) {
+                    lx = r[0] + ox / (T)G_.W;
+                    ly = r[1] + oy / (T)G_.H;
+                } else {   // same operation order as the reference: offsets / n_points * wh * 0.5
+                    lx = r[0] + ox / (T)g.P * r[2] * (T)0.5;
+                    ly = r[1] + oy / (T)g.P * r[3] * (T)0.5;
+                }
+                if (loc_out) {
+                    Pack<T, 2> xy;
+                    xy.v[0] = lx;
+                    xy.v[1] = ly;
+                    *reinterpret_cast<Pack<T, 2> *>(loc_out + (item * LP + pt) * 2) = xy;
+                    aw_out[item * LP + pt] = a;
+                }
+                PointRec<T> rec;
+                T lh, lw;
+                resolve_point<T>(lx, ly, G_.H, G_.W, (b * g.S + G_.start) * row_elems + m * g.D, row_elems, rec.o, lh, lw);
+                const T hh = (T)1 - lh, hw = (T)1 - lw;
+                rec.f[0] = hh * hw * a;
+                rec.f[1] = hh * lw * a;
+                rec.f[2] = lh * hw * a;
+                rec.f[3] = lh * lw * a;
+                my[pt] = rec;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is in order; stop compiler motion
+        // (2) gather: every lane walks the item's points, C channels each, once per channel chunk
+        for (int ch = 0; ch < g.nchunks; ++ch) {
+            const int c0 = (ch * g.G + j) * C;
+            if (live && c0 < g.D) {
+                T acc[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] = (T)0;
+#pragma unroll(OCC >= 6 ? 2 : 4)
+                for (int pt = 0; pt < LP; ++pt) {
+                    const PointRec<T> r = my[pt];
+                    Pack<T, C> v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (r.o[k] >= 0) {
+                            const Pack<TV, C> raw = *reinterpret_cast<const Pack<TV, C> *>(value + r.o[k] + c0);
+#pragma unroll
+                            for (int c = 0; c < C; ++c) v[k].v[c] = to_compute<T, TV>(raw.v[c]);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < C; ++c) v[k].v[c] = (T)0;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        acc[c] += r.f[0] * v[0].v[c] + r.f[1] * v[1].v[c] + r.f[2] * v[2].v[c] + r.f[3] * v[3].v[c];
+                }
+                Pack<TV, C> o;
+#pragma unroll
+                for (int c = 0; c < C; ++c) o.v[c] = to_storage<TV, T>(acc[c]);
+                *reinterpret_cast<Pack<TV, C> *>(out + item * g.D + c0) = o;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

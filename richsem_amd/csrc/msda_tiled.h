@@ -575,7 +575,10 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
     const int tid = threadIdx.x;
     const int j = tid & (GL - 1), grp = tid / GL;
     const int fj = tid & (FL - 1), fgrp = tid / FL;
-    const int row_elems = g.M * kTD;
+    // value layout: the reference's (N, S, M, D) -- a pixel's row of one head every M * D elements -- or, as a measured experiment
+    // (round 4, dbg bit 7; SURVEY.md section 8f rank 1 "head-major value layout"), (N, M, S, D): rows of a head contiguous
+    const bool head_major = g.dbg & 128;
+    const int row_elems = head_major ? kTD : g.M * kTD;
     const int LP = g.L * g.P;
 
     bool live[kGatherQPG];
@@ -609,7 +612,8 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
             for (int l = lb; l < le; ++l) {
                 const int wr0 = uni(hdr->r[l].wr0), wc0 = uni(hdr->r[l].wc0), nwc = uni(hdr->r[l].nwc);
                 const int npx = uni(hdr->r[l].nwr) * nwc, Wl = uni(hdr->W[l]), Hl = uni(hdr->H[l]);
-                const TV *src = value + ((int64_t)(b * g.S + uni(hdr->start[l])) * g.M + m) * kTD + half * GC + 4 * fj;
+                const TV *src = value + (head_major ? ((int64_t)(b * g.M + m) * g.S + uni(hdr->start[l])) * kTD
+                                                    : ((int64_t)(b * g.S + uni(hdr->start[l])) * g.M + m) * kTD) + half * GC + 4 * fj;
                 float *dst = win + (int64_t)uni(hdr->lds_px[l]) * GC + 4 * fj;
                 // kFillBatch independent loads in flight per lane before the first LDS store
                 for (int px0 = fgrp; px0 < npx; px0 += kFillBatch * kFillGroups) {
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                 lc.nwr = uni(hdr->r[l].nwr);
                 lc.nwc = uni(hdr->r[l].nwc);
                 lc.lds_base = uni(hdr->lds_px[l]) * GC;
-                lc.base_row = (b * g.S + uni(hdr->start[l])) * row_elems + m * kTD;
+                lc.base_row = head_major ? ((b * g.M + m) * g.S + uni(hdr->start[l])) * kTD : (b * g.S + uni(hdr->start[l])) * row_elems + m * kTD;
                 unsigned pt0[kGatherQPG];
 #pragma unroll
                 for (int k = 0; k < kGatherQPG; ++k) pt0[k] = item[k] * (unsigned)LP + (unsigned)(l * g.P);
@@ -701,7 +705,9 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                     const float a = aw[pt];
                     int o[4];
                     float lh, lw;
-                    resolve_point<float>(xy.x, xy.y, hdr->H[lv], hdr->W[lv], (b * g.S + hdr->start[lv]) * row_elems + m * kTD, row_elems, o, lh, lw);
+                    resolve_point<float>(xy.x, xy.y, hdr->H[lv], hdr->W[lv],
+                                         head_major ? ((b * g.M + m) * g.S + hdr->start[lv]) * kTD : (b * g.S + hdr->start[lv]) * row_elems + m * kTD,
+                                         row_elems, o, lh, lw);
                     const float hh = 1.f - lh, hw = 1.f - lw;
                     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                     const float4 v1 = o[0] >= 0 ? ld4(value + o[0] + chan) : z, v2 = o[1] >= 0 ? ld4(value + o[1] + chan) : z;

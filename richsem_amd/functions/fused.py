@@ -72,16 +72,25 @@ class MSDeformAttnFusedFunction(Function):
         ref = reference_points.contiguous()
         if ref.shape[:3] != (N, Lq, L) or ref.shape[-1] not in (2, 4):
             raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {ref.shape[-1]} instead.")
-        sh, _ = MSDA._host_mirror(spatial_shapes, level_start_index)
+        sh, ls = MSDA._host_mirror(spatial_shapes, level_start_index)
         lib = _lib.load()
         loc = torch.empty((N, Lq, M, L, P, 2), dtype=work, device=qproj.device)
         aw = torch.empty((N, Lq, M, L, P), dtype=work, device=qproj.device)
         stride, esz = qproj.shape[-1], qproj.element_size()
+        # ONE entry point for softmax + location arithmetic + gather (msda_forward_prep_*): a single kernel for decoder-shaped calls, the
+        # location / softmax kernel followed by the forward for the others; loc / aw come back as by-products for the backward
+        value = value.contiguous()
+        if (value.dtype != qproj.dtype or value.dim() != 4 or value.shape[0] != N or value.shape[2] != M
+                or spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64):
+            raise RuntimeError("fused MSDeformAttn path: value must be a (N, S, M, D) tensor of the projection's dtype, shapes int64")
+        S, D = value.shape[1], value.shape[3]
+        out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
         with torch.cuda.device(qproj.device):
-            _lib.check(getattr(lib, "msda_prep_forward_" + _SFX[qproj.dtype])(
+            _lib.check(getattr(lib, "msda_forward_prep_" + _SFX[qproj.dtype])(
+                value.data_ptr(), spatial_shapes.contiguous().data_ptr(), level_start_index.contiguous().data_ptr(),
                 qproj.data_ptr(), stride, qproj.data_ptr() + n_off * esz, stride, ref.data_ptr(), ref.shape[-1],
-                sh.ctypes.data, N, Lq, M, L, P, loc.data_ptr(), aw.data_ptr(), _stream(qproj)))
-        out = MSDA.ms_deform_attn_forward(value, spatial_shapes, level_start_index, loc, aw, im2col_step)
+                N, S, M, D, L, Lq, P, im2col_step, out.data_ptr(), loc.data_ptr(), aw.data_ptr(), sh.ctypes.data, ls.ctypes.data,
+                _stream(qproj)))
         ctx.save_for_backward(value, spatial_shapes, level_start_index, loc, aw, ref, qproj)
         ctx.dims = (M, L, P, im2col_step)
         return out

@@ -115,3 +115,30 @@ def test_two_ranks_run_the_hip_kernels_on_their_shards(tmp_path):
         ref = ref.cpu().numpy()
         # images are independent; the kernels chosen for a batch of 2 and of 4 may differ, so sums agree at rounding level
         assert np.abs(got - ref).max() <= 1e-4 * (np.abs(ref).max() + 1e-12), name
+
+
+def test_composed_step_under_ddp_with_optimizer(nccl_world1):
+    """bench.py's `full_step_ddp` protocol (bench_step.run_ddp) on the small composed step: DistributedDataParallel over RCCL (world 1 here: a
+    self-all-reduce on RCCL's stream beside the step's kernels), AdamW on every trained parameter -- every trained parameter must get a
+    gradient (DDP is built without find_unused_parameters), and the bf16 caches of the layers must follow the optimizer's updates"""
+    import bench_step
+    dev = torch.device("cuda", 0)
+    holder = {}
+
+    def make():
+        m = bench_step.Step(n_img=2, height=256, width=320, boxes_per_image=5, seed=3, dev=dev)
+        holder["m"] = m
+        holder["w0"] = m.encoder[0].linear1.weight.detach().clone()
+
+        def batch():
+            b = bench_step.Step.batch(m, seed=0)
+            m.prepare(b[1], b[2])
+            return b
+        m.batch = batch
+        return m
+
+    res = bench_step.run_ddp(2, dev, dist, steps=2, warmup=1, optimizer=True, make_model=make)
+    assert res["world"] == 1 and res["ms"] > 0 and res["ms_no_collective"] > 0
+    assert res["parameters_without_gradient"] == [], res["parameters_without_gradient"]
+    assert np.isfinite(res["loss"])
+    assert not torch.equal(holder["m"].encoder[0].linear1.weight.detach(), holder["w0"])      # AdamW moved the weights

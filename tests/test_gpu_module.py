@@ -170,3 +170,36 @@ def test_module_bf16_path_close_to_fp32(ref_dim):
     assert ratio(s16, s32, "grad_src") < MOD_TOL["grad_src"] and ratio(r16, r32, "grad_ref") < MOD_TOL["grad_ref"]
     worst = max((ratio(g16[n].float(), g32[n], "param " + n), n) for n in g32)
     assert worst[0] < MOD_TOL["params"], worst
+
+
+# ---- msda_forward_prep_*: softmax + location arithmetic + gather as ONE kernel (decoder-shaped calls) against the two-kernel form ------
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ref_dim,L,P,Lq", [(4, 4, 4, 1092 // 4), (2, 4, 4, 37), (4, 3, 3, 50), (2, 4, 8, 64), (4, 1, 1, 9), (2, 2, 5, 33)])
+def test_fused_prep_gather_equals_the_two_kernel_form(dtype, ref_dim, L, P, Lq):
+    from richsem_amd import _lib
+    from richsem_amd.functions import MSDeformAttnFusedFunction
+    g = torch.Generator(device="cuda").manual_seed(100 * L + 10 * P + ref_dim)
+    N, M, D = 2, 8, 32
+    shapes_l = [(13, 21), (7, 11), (4, 6), (2, 3)][:L]
+    shapes = torch.tensor(shapes_l, dtype=torch.int64, device="cuda")
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    work = torch.float32 if dtype == torch.bfloat16 else dtype
+    value = torch.randn(N, S, M, D, device="cuda", generator=g).to(dtype)
+    qproj = (torch.randn(N, Lq, M * L * P * 3, device="cuda", generator=g) * 1.5).to(dtype)
+    ref = torch.rand(N, Lq, L, ref_dim, device="cuda", generator=g).to(work) * 0.8 + 0.1
+    go = torch.randn(N, Lq, M * D, device="cuda", generator=g).to(dtype)
+    res = {}
+    try:
+        for fused in (1, 0):
+            _lib.set_option("fwd_prep_fused", fused)
+            v, q, r = value.clone().requires_grad_(True), qproj.clone().requires_grad_(True), ref.clone().requires_grad_(True)
+            out = MSDeformAttnFusedFunction.apply(v, shapes, lsi, q, r, M, L, P, 64)
+            out.backward(go)
+            res[fused] = (out.detach().double(), v.grad.double(), q.grad.double(), r.grad.double())
+    finally:
+        _lib.set_option("fwd_prep_fused", 1)
+    # the softmax sums in a different order in the two forms: last-ulp differences of the compute type, then one rounding of the output
+    tol = {torch.float64: 1e-13, torch.float32: 2e-6, torch.bfloat16: 1e-2}[dtype]
+    for a, b in zip(res[1], res[0]):
+        assert float((a - b).abs().max()) <= tol * (float(b.abs().max()) + 1e-30), float((a - b).abs().max()) / float(b.abs().max())

@@ -5,6 +5,8 @@
   * capture of the step into a HIP graph on the stream it was warmed up on, with the last eager step's loss (and so its autograd graph)
     still referenced: what crashed round 3's harness when the eager steps had run on ANOTHER stream (tools/capture_crash_probe.py).
 """
+import os
+
 import pytest
 import torch
 
@@ -48,7 +50,10 @@ def test_bf16_step_agrees_with_the_fp32_op_sequence():
     g32 = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
     assert torch.isfinite(loss16) and torch.isfinite(loss32)
     rel = abs(float(loss16) - float(loss32)) / abs(float(loss32))
-    assert rel < 2e-2, (float(loss16), float(loss32))          # measured on MI355X: see DESIGN.md section 11
+    report = bool(os.environ.get("RICHSEM_REPORT"))
+    if report:
+        print(f"[measured] step loss bf16 {float(loss16):.6g} fp32 {float(loss32):.6g} rel {rel:.3g}", flush=True)
+    assert rel < 2e-2, (float(loss16), float(loss32))          # (measured on MI355X: profiles/r04_bf16_bounds.txt)
     # a sample of gradients across the step: heads, last decoder layer, first decoder layer, last / first encoder layer, input projection
     names = ["dino_visual_proj.weight", "proj_dino_hs.weight", "decoder.layers.5.linear2.weight", "decoder.layers.5.cross_attn.value_proj.weight",
              "decoder.layers.0.self_attn.in_proj_weight", "decoder.bbox_embed.5.layers.2.weight", "decoder.ref_point_head.layers.0.weight",
@@ -62,6 +67,8 @@ def test_bf16_step_agrees_with_the_fp32_op_sequence():
         # cosine of the two gradients and the ratio of their norms: a bf16 step is a noisy copy of the fp32 one, not a different direction
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
         errs[n] = (cos, float(a.norm() / (b.norm() + 1e-30)))
+        if report:
+            print(f"[measured] step gradient {n}: cosine {errs[n][0]:.4f} norm ratio {errs[n][1]:.4f}", flush=True)
     bad = {n: e for n, e in errs.items() if e[0] < 0.90 or not 0.8 < e[1] < 1.25}
     assert not bad, (bad, errs)
 
