@@ -192,6 +192,7 @@ class Step(nn.Module):
         st["scale"] = self.logit_scale.detach().clone()
         self.scorer.prepare(self.dino_visual_proj.weight, self.text_embed, self.logit_scale)      # (once per weight update)
         self.static = st
+        self._targets = targets
         return st
 
     def forward(self, images, mask, targets, indices=None, topk=None):
@@ -288,25 +289,64 @@ class Step(nn.Module):
             _, fmap = self.teacher(images, ret_sp=True)
             _, t_logits = clip_box_targets(fmap, targets, self.teacher.attnpool, self.text_embed, st["scale"])
         self._mark("teacher")
+        if self._model_only:      # (model_part: the step up to the matcher, as tensors)
+            return logits, coords, interm["pred_logits"], interm["pred_boxes"], clip_logits, torch.cat(t_logits).float()
         # ---- matcher (matcher.py:30-78, one host copy for the 7 outputs) -------------------------------------------------------------------
-        outs = [{"pred_logits": logits[l][:, pad:], "pred_boxes": coords[l][:, pad:]} for l in range(6)] + [interm]
         if indices is None:
-            indices = self.matcher.match_many(outs, targets)
-        self.last_indices = indices
+            indices = self.match(logits, coords, interm["pred_logits"], interm["pred_boxes"], targets)
+        packed = indices if (isinstance(indices, tuple) and torch.is_tensor(indices[0])) else self.pack_indices(indices, targets)
+        if packed is not indices:
+            self.last_indices = indices
         self._mark("matcher")
-        # ---- criterion (richsem.py:1124-1306, compact): the same per-output sums as the reference's loop over the 6 + 1 outputs, formed
-        #      over the STACKED decoder outputs in one pass (a loop of ~40 small launches per output is what an eager trainer pays) --------
-        num_boxes = float(max(sum(known_num), 1))
-        tgt_boxes_all = [t["boxes"] for t in targets]
-        nl = logits.shape[0]
+        loss = self.loss_part(logits, coords, interm["pred_logits"], interm["pred_boxes"], clip_logits, torch.cat(t_logits).float(), *packed)
+        self._mark("criterion")
+        return loss
 
-        def matched(idx_list):       # per output: (batch index, query index, target label, target box) of its matched pairs
-            bi = torch.cat([torch.full_like(s, b) for idx in idx_list for b, (s, _) in enumerate(idx)]).to(dev)
-            si = torch.cat([s for idx in idx_list for s, _ in idx]).to(dev)
-            tl = torch.cat([t["labels"][j.to(dev)] for idx in idx_list for t, (_, j) in zip(targets, idx)])
-            tb = torch.cat([tbx[j.to(dev)] for idx in idx_list for tbx, (_, j) in zip(tgt_boxes_all, idx)])
-            li = torch.cat([torch.full((sum(len(s) for s, _ in idx),), k, dtype=torch.int64, device=dev) for k, idx in enumerate(idx_list)])
-            return li, bi, si, tl, tb
+    _model_only = False
+
+    def model_part(self, images, mask=None, targets=None):
+        """the step up to the matcher: -> (logits (6, N, Q, C), boxes (6, N, Q, 4), two-stage logits, two-stage boxes, distillation logits,
+        the teacher's box logits): tensors in, tensors out, nothing read back to the host -- the part ``run_graphed`` captures"""
+        self._model_only = True
+        try:
+            return self.forward(images, mask, self._targets if targets is None else targets)
+        finally:
+            self._model_only = False
+
+    def match(self, logits, coords, il, ib, targets):
+        pad = self.static["lay"]["pad_size"]
+        outs = [{"pred_logits": logits[l][:, pad:], "pred_boxes": coords[l][:, pad:]} for l in range(logits.shape[0])]
+        return self.matcher.match_many(outs + [{"pred_logits": il, "pred_boxes": ib}], targets)
+
+    def pack_indices(self, indices, targets):
+        """the Hungarian assignment of the 6 + 1 outputs as flat device tensors of a size the batch fixes (every target is matched once per
+        output): (labels, boxes) of all targets, (layer, image, query, target) of the decoder outputs' pairs, (image, query, target) of the
+        two-stage output's and of the last layer's (the distillation pairs)"""
+        dev = self.level_embed.device
+        off = [0]
+        for t in targets:
+            off.append(off[-1] + len(t["labels"]))
+        labels, boxes = torch.cat([t["labels"] for t in targets]), torch.cat([t["boxes"] for t in targets])
+
+        def flat(idx_list):
+            li = torch.cat([torch.full((len(s),), k, dtype=torch.int64) for k, idx in enumerate(idx_list) for s, _ in idx])
+            bi = torch.cat([torch.full((len(s),), b, dtype=torch.int64) for idx in idx_list for b, (s, _) in enumerate(idx)])
+            si = torch.cat([s.cpu() for idx in idx_list for s, _ in idx])
+            tj = torch.cat([j.cpu() + off[b] for idx in idx_list for b, (_, j) in enumerate(idx)])
+            return torch.stack((li, bi, si, tj)).to(dev, non_blocking=True)
+        nl = len(indices) - 1
+        return labels, boxes, flat(indices[:nl]), flat(indices[nl:]), flat(indices[nl - 1:nl])
+
+    def loss_part(self, logits, coords, il, ib, clip_logits, t_logits, labels, boxes, m_dec, m_int, m_dis):
+        """criterion (richsem.py:1124-1306, compact): the same per-output sums as the reference's loop over the 6 + 1 outputs, formed over
+        the STACKED decoder outputs in one pass (a loop of ~40 small launches per output is what an eager trainer pays); tensors in, the
+        loss out"""
+        st = self.static
+        dev = logits.device
+        known_num, lay = st["known_num"], st["lay"]
+        pad, groups = lay["pad_size"], lay["num_dn_group"]
+        num_boxes = float(max(sum(known_num), 1))
+        nl = logits.shape[0]
 
         def box_losses(pb, tb, norm):
             return (5.0 * (pb - tb).abs().sum() + 2.0 * (1 - giou_pairs(box_cxcywh_to_xyxy(pb), box_cxcywh_to_xyxy(tb))).sum()) / norm
@@ -319,33 +359,30 @@ class Step(nn.Module):
             return (alpha * (1 - q) ** 2 * F.softplus(-x) - (1 - alpha) * q * q * F.softplus(x)).sum()
 
         # matched part of the six decoder outputs
-        li, bi, si, tl, tb = matched(indices[:nl])
-        sel = (li, bi, si + pad, tl)
+        li, bi, si, tj = m_dec
+        sel = (li, bi, si + pad, labels[tj])
         loss = (neg_all[:, :, pad:].sum() + focal_pos(logits[sel], p_all[sel])) / num_boxes
-        loss = loss + box_losses(coords[li, bi, si + pad], tb, num_boxes)
+        loss = loss + box_losses(coords[li, bi, si + pad], boxes[tj], num_boxes)
         # the intermediate (two-stage) output
-        _, bi, si, tl, tb = matched(indices[nl:])
-        il = interm["pred_logits"]
+        _, bi, si, tj = m_int
         ip = il.sigmoid()
+        tl = labels[tj]
         loss = loss + (((1 - alpha) * ip * ip * F.softplus(il)).sum() + focal_pos(il[bi, si, tl], ip[bi, si, tl])) / num_boxes
-        loss = loss + box_losses(interm["pred_boxes"][bi, si], tb, num_boxes)
+        loss = loss + box_losses(ib[bi, si], boxes[tj], num_boxes)
         # denoising part: the positive slots reconstruct their boxes and labels (dn_components.py / richsem.py:1163-1193)
         single = lay["single_pad"]
         pos_slots = (torch.arange(groups, device=dev)[:, None] * 2 * single + torch.arange(single, device=dev)[None]).flatten()
-        tlab = torch.stack([t["labels"] for t in targets]).repeat(1, groups)                            # (N, groups * single)
-        tbx = torch.stack(tgt_boxes_all).repeat(1, groups, 1)
+        N = logits.shape[1]
+        tlab = labels.view(N, -1).repeat(1, groups)                            # (N, groups * single): every image has `single` boxes here
+        tbx = boxes.view(N, -1, 4).repeat(1, groups, 1)
         nbx = num_boxes * groups
-        dl, dp, db = logits[:, :, pos_slots], p_all[:, :, pos_slots], coords[:, :, pos_slots]          # every image has `single` boxes here
+        dl, dp, db = logits[:, :, pos_slots], p_all[:, :, pos_slots], coords[:, :, pos_slots]
         hot = tlab[None, :, :, None].expand(nl, -1, -1, 1)
         loss = loss + (neg_all[:, :, pos_slots].sum() + focal_pos(dl.gather(3, hot), dp.gather(3, hot))) / nbx
         loss = loss + box_losses(db.reshape(-1, 4), tbx[None].expand(nl, -1, -1, -1).reshape(-1, 4), nbx)
         # distillation: KL of the matched queries' CLIP logits against the teacher's box logits (richsem.py:1255-1300)
-        idx = indices[5]
-        bi = torch.cat([torch.full_like(s, b) for b, (s, _) in enumerate(idx)]).to(dev)
-        si = torch.cat([s for s, _ in idx]).to(dev) + pad
-        tgt_l = torch.cat([tl[j.to(dev)] for tl, (_, j) in zip(t_logits, idx)]).float()
-        loss = loss + 0.5 * F.kl_div(F.log_softmax(clip_logits[bi, si], -1), F.softmax(tgt_l, -1), reduction="batchmean")
-        self._mark("criterion")
+        _, bi, si, tj = m_dis
+        loss = loss + 0.5 * F.kl_div(F.log_softmax(clip_logits[bi, si + pad], -1), F.softmax(t_logits[tj], -1), reduction="batchmean")
         return loss
 
     def section_ms(self):
@@ -413,7 +450,8 @@ def run(n_img, dev, steps=5, warmup=2, graph=True, stop_at=None):
     if not graph:
         return out
     # the device part as a captured graph: the assignment of the last eager step held fixed (the matcher's host round trip cannot be captured)
-    indices = [[(i.to(dev), j.to(dev)) for i, j in idx] for idx in model.last_indices]      # (no host -> device copies in the capture)
+    indices = model.pack_indices(model.last_indices, targets)      # (device tensors: no host <-> device copies in the capture)
+    torch.cuda.synchronize()
     model.timing = False
 
     def replay_ms(stop_at):
@@ -454,7 +492,95 @@ def run(n_img, dev, steps=5, warmup=2, graph=True, stop_at=None):
         out.setdefault("graph_replay", {})["error"] = f"{type(e).__name__}: {str(e)[:300]}"
     finally:
         model.stop_at = None
+    try:
+        del model
+        torch.cuda.empty_cache()
+        out["graphed_sections"] = run_graphed(n_img, dev, steps=steps, warmup=warmup)
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        out["graphed_sections"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     return out
+
+
+class _ModelPart(nn.Module):
+    """the step up to the matcher as a module of tensors (what torch.cuda.make_graphed_callables captures, forward and backward)"""
+
+    def __init__(self, step):
+        super().__init__()
+        self.step = step
+
+    def forward(self, images):
+        return self.step.model_part(images, self.step._mask)
+
+
+class _LossPart(nn.Module):
+    def __init__(self, step):
+        super().__init__()
+        self.step = [step]      # (not a sub-module: the criterion has no parameters of its own)
+
+    def forward(self, *tensors):
+        return self.step[0].loss_part(*tensors)
+
+
+def run_graphed(n_img, dev, steps=5, warmup=2, **step_kwargs):
+    """The composed step as a trainer can run it WITHOUT freezing the matcher: the two device-only parts -- everything up to the matcher,
+    and the criterion -- each captured once, forward and backward, with ``torch.cuda.make_graphed_callables`` (HIP graphs replayed by
+    autograd), the Hungarian assignment between them live on the host every step.  Eagerly the step is bound by ~2900 kernel launches
+    (ms above); this is the same work with three launches' worth of host time.  Returns the dict bench.py attaches as
+    ``full_step.graphed_sections`` (``step_kwargs``: a smaller Step for the tests)."""
+    model = Step(n_img=n_img, dev=dev, **step_kwargs)
+    model.timing = False
+    images, mask, targets = model.batch()
+    model.prepare(mask, targets)
+    model._mask = mask
+    part_a, part_b = _ModelPart(model), _LossPart(model)
+    # ONE side stream for the eager warm-up, the captures and the training steps: torch captures on its class-wide capture stream, which is
+    # set to that stream here -- the library's workspaces are per (device, stream) and are not allocated during capture (on a cold stream
+    # the capture records the fallback kernels), and an autograd graph built on another stream pins the parameters' AccumulateGrad nodes
+    # there (the capture then synchronises with that stream from inside: wrong results at best, see run())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    saved_capture_stream = torch.cuda.graph.default_capture_stream
+    torch.cuda.graph.default_capture_stream = side
+    try:
+        with torch.cuda.stream(side):
+            with torch.no_grad():
+                outs = model.model_part(images, mask)
+            idx = model.pack_indices(model.match(*outs[:4], targets), targets)
+            model.loss_part(*model.model_part(images, mask), *idx).backward()      # (eager once: workspaces of this stream, caches)
+            for p in model.parameters():
+                p.grad = None
+            sample_b = tuple(o.detach().clone().requires_grad_(i < 5) for i, o in enumerate(outs)) + tuple(idx)
+            torch.cuda.synchronize()
+            ga, gb = torch.cuda.make_graphed_callables((part_a, part_b), ((images,), sample_b), num_warmup_iters=3, allow_unused_input=True)
+            params = [p for p in model.parameters() if p.requires_grad]
+
+            def step():
+                for p in params:
+                    p.grad = None
+                outs = ga(images)
+                with torch.no_grad():
+                    assign = model.match(*outs[:4], targets)                  # device cost blocks -> one host copy -> scipy (matcher.py)
+                loss = gb(*outs, *model.pack_indices(assign, targets))
+                loss.backward()
+                return loss
+
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        torch.cuda.graph.default_capture_stream = saved_capture_stream
+    torch.cuda.current_stream().wait_stream(side)
+    return {"what": "the same step with its two device-only parts (model up to the matcher; criterion) captured forward + backward by "
+                    "torch.cuda.make_graphed_callables and the Hungarian assignment live on the host between them every step",
+            "ms": round(ms, 2), "img_per_s": round(n_img / (ms * 1e-3), 2), "loss": float(loss.detach()),
+            "grad_norm": float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in params if p.grad is not None)))}
 
 
 def run_ddp(n_img, dev, dist, steps=5, warmup=2, optimizer=True, make_model=None, backend_device=None):

@@ -80,9 +80,12 @@ const char *msda_last_error(void);
 /* Tuning / test hooks.  Keys:
  *   "fwd_variant"     0 = auto, 1 = direct gather kernel, 2 = LDS-window kernel (when applicable)
  *   "bwd_variant"     0 = auto, 1 = direct kernel (level-sum windows / row atomics), 4 = routed pixel-stationary kernels
- *                     (sampling points routed to output tiles in two exact passes, every pixel of grad_value written once with
- *                     plain stores; cost independent of where the points fall; fp32 / bf16 storage, D = 32, L <= 4, any Lq;
- *                     otherwise the call falls back to 1).  auto = routed for encoder-shaped calls (Lq == S), direct for the rest
+ *                     (sampling points routed to output tiles in ONE pass -- every query block lays its records out in a stretch of
+ *                     its own and announces them to the tiles' bins --, then one workgroup per tile: every pixel of grad_value
+ *                     written once with plain stores; cost independent of where the points fall; fp32 / bf16 storage, D = 32,
+ *                     L <= 4, Lq <= 256 x 128 per (image, head); otherwise the call falls back to 1).  auto = routed for
+ *                     encoder-shaped calls (Lq == S), direct for the rest
+ *   "fwd_prep_fused"  1 (default) = msda_forward_prep_* runs decoder-shaped calls as one kernel, 0 = always two
  *   "locality_monitor"  1 (default) = in auto mode the window forward kernel counts the points that miss their window on the
  *                     first 2 calls of a (problem shape, sampling_loc buffer) and on every 64th after; the count comes back
  *                     by an asynchronous copy and is read on a later call (no call waits, nothing is probed during graph

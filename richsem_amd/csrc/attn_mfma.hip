@@ -410,7 +410,8 @@ int msda_attn_backward_bf16(const uint16_t *q, int ldq, const uint16_t *k, int l
     const int nkb = (nq + 31) / 32, nqp = nkb * 32;
     const size_t tsz = (size_t)bs * heads * kHd * nqp;
     uint16_t *qt = static_cast<uint16_t *>(workspace), *kt = qt + tsz, *dot = kt + tsz;
-    float *delta = reinterpret_cast<float *>(dot + 2 * tsz);      // (the fourth slot is the forward's V^T)
+    float *delta = reinterpret_cast<float *>(dot + 2 * tsz);      // (the workspace has four transposed-tensor slots; the forward uses slot 0 for V^T, the backward -- a call of its own, with its own
+                                                                  // workspace -- slots 0..2 for Q^T, K^T, dO^T; the row sums follow the fourth)
     const dim3 tgrid((nqp + 63) / 64, bs * heads), grid(nqp / kQW, bs * heads);
     hipLaunchKernelGGL(attn_transpose_kernel, tgrid, dim3(256), 0, st, q, ldq, nq, nqp, tk.si, tk.sb, heads, qt);
     hipLaunchKernelGGL(attn_transpose_kernel, tgrid, dim3(256), 0, st, k, ldk, nq, nqp, tk.si, tk.sb, heads, kt);

@@ -2,8 +2,9 @@
 //
 // The reference's backward (ms_deform_im2col_cuda.cuh:87-159, 301-403) is query-stationary: every bilinear corner of every
 // sampling point is ADDED to grad_value with a global float atomic -- 2.9 GB of atomics per encoder call, ~2.3 ms at the
-// chip's atomic rate.  Here the OUTPUT owns the work: grad_value is cut into tiles of <= 18x19 pixels per (image, head,
-// level), and a tile's workgroup pulls in exactly the sampling points that land on it.
+// chip's atomic rate.  Here the OUTPUT owns the work: grad_value is cut into tiles of <= 15x15 pixels per (image, head,
+// level) -- the tile plus one apron row / column is a grid of at most kRpsMaxPx = 256 pixels --, and a tile's workgroup pulls in
+// exactly the sampling points that land on it.
 //
 //   route   (rps_route_kernel, ONE pass)  one lane per sampling point: where does its corner (h_low, w_low) fall?  The point is
 //           appended -- a 16-byte record: position code, bilinear fractions, attention weight -- to the bin of that tile, and to
@@ -42,7 +43,7 @@ constexpr int kRpsPpq = (kRpsMaxPx + kRpsThreads / 4 - 1) / (kRpsThreads / 4);  
 constexpr int kRpsRpl = 2;                      // records per lane and chunk
 constexpr int kRpsChunk = kRpsRpl * kRpsThreads;   // sampling points per chunk
 constexpr int kRpsSumStride = 36;               // doubles per pixel of the f64 sums (see RpsLds)
-constexpr int kRpsSegShift = 3;                 // a pixel's list is walked in segments ("units") of at most 8 points
+constexpr int kRpsSegShift = 3;                 // SMALLEST unit of the list walk: 1 << 3 = 8 points (the units' length is RpsOptions::seg_shift, default 4: <= 16 points)
 constexpr int kRpsMaxSegs = kRpsMaxPx + (kRpsChunk >> kRpsSegShift);   // units of a chunk: <= lists + points / 8
 constexpr int kRpsMaxL = 4;
 constexpr int kRpsMaxUnits = 448;
@@ -51,6 +52,7 @@ constexpr int kRpsPad = 32;                     // atomically updated counters s
 constexpr int kRpsDummyWgs = 2048, kRpsDummyBytes = kRpsDummyWgs * 1024;   // 1 KB per workgroup: 16 B per lane of a wave
 constexpr int kRpsMaxRuns = 256;               // runs per bin the tile kernel can index (2 KB of LDS): Lq <= 256 x 128 queries
 constexpr int kRpsQpBits = 19;                  // entry code: query * P + point below this bit (plan: Lq * P < 2^19)
+static_assert(kRpsMaxPx <= 256, "record code: the base-grid index has 8 bits (bits 19..26), the tile kernel masks it with 0xFF");
 
 struct RpsLevel {
     int H, W, start;
@@ -63,7 +65,7 @@ struct RpsLevel {
 };
 
 // Routed sampling point, as the route pass writes it and the tile kernel streams it.
-//   code = (query * P + point)  |  base-grid index in the tile << 19  |  corners inside the map << 27  |  owner << 31
+//   code = (query * P + point)  |  base-grid index in the tile << 19 (8 bits: < kRpsMaxPx)  |  corners inside the map << 27 (4 bits)  |  owner << 31
 // (owner: this tile also forms the point's gradients).  The bin fixes (image, head, level).
 struct alignas(16) RpsRec {
     unsigned code;

@@ -23,8 +23,8 @@ from conftest import GOLDEN, OP_CASES
 pytestmark = pytest.mark.gpu
 
 CASES = OP_CASES
-# 1 = direct kernels, 2 = LDS-window kernels, 3 = pixel-stationary backward (candidates by geometry), 4 = routed
-# pixel-stationary backward -- each where applicable, else the direct kernels
+# 1 = direct kernels, 2 = LDS-window forward kernel, 4 = routed pixel-stationary backward -- each where applicable, else the direct
+# kernels (variant 3, the pixel-stationary backward with candidates by geometry, was deleted in round 3)
 VARIANTS = [0, 1, 2, 4]   # 0 automatic; forward: 1 direct, 2 LDS windows; backward: 1 direct (+ level-sum), 4 routed
 
 

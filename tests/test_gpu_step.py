@@ -89,7 +89,8 @@ def test_step_captures_on_the_stream_it_ran_on_with_its_loss_alive():
     with torch.cuda.stream(side):
         kept = step()                                       # stays referenced (with its autograd graph) across the capture
         torch.cuda.synchronize()
-        indices = [[(i.cuda(), j.cuda()) for i, j in per] for per in model.last_indices]
+        indices = model.pack_indices(model.last_indices, targets)      # (device tensors: nothing is copied inside the capture)
+        torch.cuda.synchronize()
         for _ in range(2):
             step(indices)
     torch.cuda.synchronize()
@@ -103,3 +104,16 @@ def test_step_captures_on_the_stream_it_ran_on_with_its_loss_alive():
     assert all(torch.isfinite(p.grad).all() for p in params if p.grad is not None)
     # the captured step is the step: equal parameters, equal assignment -> a loss next to the eager one (the denoising noise differs)
     assert abs(float(loss) - float(kept)) < 0.2 * abs(float(kept))
+
+
+def test_graphed_sections_train_like_the_eager_step():
+    """bench_step.run_graphed: the model part and the criterion captured forward + backward by torch.cuda.make_graphed_callables, the
+    matcher live between them -- the loss and the size of the gradient are the eager step's (the denoising noise differs per step)"""
+    import bench_step
+    model, images, mask, targets = _small_step(seed=0)
+    loss = _run(model, images, mask, targets)
+    gnorm = float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+    del model
+    res = bench_step.run_graphed(2, torch.device("cuda", 0), steps=2, warmup=1, height=H, width=W_IMG, boxes_per_image=BOXES, seed=0)
+    assert abs(res["loss"] - float(loss)) < 0.1 * abs(float(loss)), (res["loss"], float(loss))
+    assert 0.7 < res["grad_norm"] / gnorm < 1.4, (res["grad_norm"], gnorm)

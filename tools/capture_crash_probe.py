@@ -56,7 +56,8 @@ def child(variant):
         if keep != "events_norecord":
             b.record()
     torch.cuda.synchronize()
-    indices = [[(i.to(dev), j.to(dev)) for i, j in idx] for idx in model.last_indices]
+    indices = model.pack_indices(model.last_indices, targets)
+    torch.cuda.synchronize()
     held = {"none": [], "loss": [loss], "fwd": [fwd], "ab": [a, b], "all": [loss, fwd, a, b], "loss_detached": [loss.detach()],
             "events_norecord": [a, b]}[keep]
     del loss, fwd, a, b

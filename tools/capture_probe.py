@@ -25,7 +25,8 @@ for _ in range(int(os.environ.get("PROBE_EAGER", "0"))):
     if model.timing:
         model.section_ms()
 model.timing = False
-indices = [[(a.to(dev), b.to(dev)) for a, b in idx] for idx in model.last_indices]
+indices = model.pack_indices(model.last_indices, targets)
+torch.cuda.synchronize()
 
 
 def step():
