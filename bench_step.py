@@ -29,7 +29,7 @@ from richsem_amd.backbone import InputProjection, ResNet50
 from richsem_amd.clip_resnet import ModifiedResNetTeacher
 from richsem_amd.dn import prepare_dn_layout
 from richsem_amd.functions.linear import Lin256Function, VersionCache, pack_linear256
-from richsem_amd.matcher import HungarianMatcher
+from richsem_amd.matcher import FocalNegativeSum, HungarianMatcher
 from richsem_amd.modules import (MLP, refine_boxes, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, TransformerDecoder,
                                  clip_box_targets, get_reference_points, inverse_sigmoid)
 from richsem_amd.two_stage import ClassScorer
@@ -338,49 +338,49 @@ class Step(nn.Module):
         return labels, boxes, flat(indices[:nl]), flat(indices[nl:]), flat(indices[nl - 1:nl])
 
     def loss_part(self, logits, coords, il, ib, clip_logits, t_logits, labels, boxes, m_dec, m_int, m_dis):
-        """criterion (richsem.py:1124-1306, compact): the same per-output sums as the reference's loop over the 6 + 1 outputs, formed over
-        the STACKED decoder outputs in one pass (a loop of ~40 small launches per output is what an eager trainer pays); tensors in, the
-        loss out"""
+        """criterion (richsem.py:1124-1306, compact): the same per-output sums as the reference's loop over the 6 + 1 outputs -- sigmoid focal
+        loss, L1 + GIoU on the matched pairs and on the denoising queries' positive slots, KL distillation -- formed in ONE pass per kind over
+        the stacked outputs: the all-negative focal term of a whole logit tensor is one kernel each way (matcher.FocalNegativeSum), and the
+        positive entries / box pairs of the matched, two-stage and denoising parts are concatenated with a weight each (1 / num_boxes, or
+        1 / (num_boxes x groups)) so that every loss formula runs once (a loop over the outputs is ~40 small launches per output and kind).
+        Tensors in, the loss out."""
         st = self.static
         dev = logits.device
-        known_num, lay = st["known_num"], st["lay"]
-        pad, groups = lay["pad_size"], lay["num_dn_group"]
-        num_boxes = float(max(sum(known_num), 1))
-        nl = logits.shape[0]
-
-        def box_losses(pb, tb, norm):
-            return (5.0 * (pb - tb).abs().sum() + 2.0 * (1 - giou_pairs(box_cxcywh_to_xyxy(pb), box_cxcywh_to_xyxy(tb))).sum()) / norm
-
-        alpha = 0.25
-        p_all = logits.sigmoid()
-        neg_all = (1 - alpha) * p_all * p_all * F.softplus(logits)                                    # the all-negative focal term
-
-        def focal_pos(x, q):         # what a positive entry contributes instead of its negative term
-            return (alpha * (1 - q) ** 2 * F.softplus(-x) - (1 - alpha) * q * q * F.softplus(x)).sum()
-
-        # matched part of the six decoder outputs
-        li, bi, si, tj = m_dec
-        sel = (li, bi, si + pad, labels[tj])
-        loss = (neg_all[:, :, pad:].sum() + focal_pos(logits[sel], p_all[sel])) / num_boxes
-        loss = loss + box_losses(coords[li, bi, si + pad], boxes[tj], num_boxes)
-        # the intermediate (two-stage) output
-        _, bi, si, tj = m_int
-        ip = il.sigmoid()
-        tl = labels[tj]
-        loss = loss + (((1 - alpha) * ip * ip * F.softplus(il)).sum() + focal_pos(il[bi, si, tl], ip[bi, si, tl])) / num_boxes
-        loss = loss + box_losses(ib[bi, si], boxes[tj], num_boxes)
-        # denoising part: the positive slots reconstruct their boxes and labels (dn_components.py / richsem.py:1163-1193)
-        single = lay["single_pad"]
-        pos_slots = (torch.arange(groups, device=dev)[:, None] * 2 * single + torch.arange(single, device=dev)[None]).flatten()
-        N = logits.shape[1]
-        tlab = labels.view(N, -1).repeat(1, groups)                            # (N, groups * single): every image has `single` boxes here
-        tbx = boxes.view(N, -1, 4).repeat(1, groups, 1)
+        lay = st["lay"]
+        pad, groups, single = lay["pad_size"], lay["num_dn_group"], lay["single_pad"]
+        num_boxes = float(max(sum(st["known_num"]), 1))
         nbx = num_boxes * groups
-        dl, dp, db = logits[:, :, pos_slots], p_all[:, :, pos_slots], coords[:, :, pos_slots]
-        hot = tlab[None, :, :, None].expand(nl, -1, -1, 1)
-        loss = loss + (neg_all[:, :, pos_slots].sum() + focal_pos(dl.gather(3, hot), dp.gather(3, hot))) / nbx
-        loss = loss + box_losses(db.reshape(-1, 4), tbx[None].expand(nl, -1, -1, -1).reshape(-1, 4), nbx)
-        # distillation: KL of the matched queries' CLIP logits against the teacher's box logits (richsem.py:1255-1300)
+        nl, N, Q = logits.shape[0], logits.shape[1], logits.shape[2]
+        alpha = 0.25
+        cst = st.get("loss_static")
+        if cst is None or cst["key"] != (nl, N, Q, pad, groups, single):      # index / weight tensors the batch's geometry fixes
+            pos_slots = (torch.arange(groups, device=dev)[:, None] * 2 * single + torch.arange(single, device=dev)[None]).flatten()
+            w_q = torch.zeros(Q, dtype=torch.float32, device=dev)
+            w_q[pad:] = 1.0 / num_boxes
+            w_q[pos_slots] = 1.0 / nbx
+            n_dn = nl * N * pos_slots.numel()
+            cst = {"key": (nl, N, Q, pad, groups, single), "pos_slots": pos_slots,
+                   "w_rows": w_q[None, None, :].expand(nl, N, Q).contiguous(),
+                   "w_int": torch.full(il.shape[:2], 1.0 / num_boxes, dtype=torch.float32, device=dev),
+                   "dn_l": torch.arange(nl, device=dev)[:, None, None].expand(nl, N, pos_slots.numel()).reshape(-1),
+                   "dn_n": torch.arange(N, device=dev)[None, :, None].expand(nl, N, pos_slots.numel()).reshape(-1),
+                   "dn_q": pos_slots[None, None, :].expand(nl, N, -1).reshape(-1),
+                   "w_dn": torch.full((n_dn,), 1.0 / nbx, dtype=torch.float32, device=dev)}
+            st["loss_static"] = cst
+        # ---- classification: all-negative term of every entry, then what the positive entries contribute instead ------------------------
+        loss = FocalNegativeSum.apply(logits, cst["w_rows"], alpha) + FocalNegativeSum.apply(il, cst["w_int"], alpha)
+        li, bi, si, tj = m_dec
+        _, ibi, isi, itj = m_int
+        dn_lab = labels.view(N, -1).repeat(1, groups)[None].expand(nl, -1, -1).reshape(-1)      # every image has `single` boxes here
+        x_pos = torch.cat((logits[li, bi, si + pad, labels[tj]], il[ibi, isi, labels[itj]], logits[cst["dn_l"], cst["dn_n"], cst["dn_q"], dn_lab]))
+        w_pair = torch.cat((torch.full((li.numel() + ibi.numel(),), 1.0 / num_boxes, dtype=torch.float32, device=dev), cst["w_dn"]))
+        q = x_pos.sigmoid()
+        loss = loss + ((alpha * (1 - q) ** 2 * F.softplus(-x_pos) - (1 - alpha) * q * q * F.softplus(x_pos)) * w_pair).sum()
+        # ---- boxes: L1 + GIoU of all pairs at once -------------------------------------------------------------------------------------------
+        pb = torch.cat((coords[li, bi, si + pad], ib[ibi, isi], coords[cst["dn_l"], cst["dn_n"], cst["dn_q"]]))
+        tb = torch.cat((boxes[tj], boxes[itj], boxes.view(N, -1, 4).repeat(1, groups, 1)[None].expand(nl, -1, -1, -1).reshape(-1, 4)))
+        loss = loss + ((5.0 * (pb - tb).abs().sum(-1) + 2.0 * (1 - giou_pairs(box_cxcywh_to_xyxy(pb), box_cxcywh_to_xyxy(tb)))) * w_pair).sum()
+        # ---- distillation: KL of the matched queries' CLIP logits against the teacher's box logits (richsem.py:1255-1300) -------------------
         _, bi, si, tj = m_dis
         loss = loss + 0.5 * F.kl_div(F.log_softmax(clip_logits[bi, si + pad], -1), F.softmax(t_logits[tj], -1), reduction="batchmean")
         return loss

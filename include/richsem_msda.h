@@ -274,6 +274,17 @@ int msda_mask_rows_f32(float *x, const uint8_t *mask, int64_t rows, int row_elem
 int msda_mask_rows_f64(double *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);
 int msda_mask_rows_bf16(uint16_t *x, const uint8_t *mask, int64_t rows, int row_elems, msda_stream_t stream);
 
+/* ---- criterion plumbing: the all-negative term of the sigmoid focal loss, one pass each way -----------------
+ * sigmoid_focal_loss at a negative entry is (1 - alpha) p^2 softplus(x) (reference models/richsem/richsem.py:1124-1160 through
+ * sigmoid_focal_loss); the criterion sums it over whole logit tensors with one weight per row (query), and corrects the positive entries
+ * separately.  logits (rows, C) float32 contiguous; row_weight (rows) float32 (0 = the row carries no loss).
+ * msda_focal_neg_sum_f32 writes *n_partial <= max_partial fp64 partial sums (add them up); msda_focal_neg_grad_f32 writes
+ * grad_logits = gscale[0] * d(sum)/d(logits) for every element (gscale: a device scalar, the upstream gradient). */
+int msda_focal_neg_sum_f32(const float *logits, const float *row_weight, int64_t rows, int C, float alpha, double *partial, int max_partial,
+                           int *n_partial, msda_stream_t stream);
+int msda_focal_neg_grad_f32(const float *logits, const float *row_weight, int64_t rows, int C, float alpha, const float *gscale,
+                            float *grad_logits, msda_stream_t stream);
+
 /* ---- integer part of the contrastive-denoising set-up (reference
  * models/richsem/dn_components.py:42-71, 131-179): bit-exact int64 / bool results ---------------------------------
  * msda_dn_indices_i64: cum = exclusive prefix of the per-image box counts (batch + 1 int64 on the device), total = cum[batch],

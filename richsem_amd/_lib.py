@@ -30,7 +30,7 @@ SYMBOLS = [
     "msda_dn_indices_i64", "msda_dn_attn_mask_u8", "msda_topk_f32", "msda_sine_embed_bf16", "msda_narrow_linear_backward_bf16", "msda_box_refine_forward", "msda_box_refine_backward", "msda_roi_align_forward_f32", "msda_roi_align_forward_f64",
     "msda_ffn_pack_w2_bf16", "msda_ffn_forward_bf16", "msda_ffn_debug_stamps", "msda_ffn_forward_train_bf16", "msda_ffn_ln_backward_bf16", "msda_add_layernorm_forward_bf16", "msda_lin256_pack_bf16", "msda_lin256_forward_bf16", "msda_lin256_pack_f32", "msda_lin256_forward_f32", "msda_lin256_forward_stacked_bf16",
     "msda_attn_workspace_bytes", "msda_attn_forward_bf16", "msda_attn_backward_bf16",
-    "msda_matcher_cost_f32", "msda_matcher_cost_f64", "msda_attnpool_core_f32", "msda_attnpool_core_f64",
+    "msda_matcher_cost_f32", "msda_matcher_cost_f64", "msda_focal_neg_sum_f32", "msda_focal_neg_grad_f32", "msda_attnpool_core_f32", "msda_attnpool_core_f64",
     "msda_cls_packed_elems", "msda_cls_pack", "msda_cls_max_scores",
     "msda_conv_set_tiling", "msda_conv_packed_elems", "msda_conv_pack_weight", "msda_conv_forward_bf16", "msda_conv_dgrad_bf16", "msda_conv_forward_workspace_bytes", "msda_conv_forward_ws_bf16", "msda_conv_dgrad_workspace_bytes", "msda_conv_dgrad_ws_bf16", "msda_pool_nhwc_bf16", "msda_groupnorm8_nhwc_bf16", "msda_groupnorm8_backward_nhwc_bf16", "msda_conv_wgrad_workspace_bytes", "msda_conv_wgrad_bf16",
 ]
@@ -101,6 +101,10 @@ def load():
         f = getattr(L, "msda_matcher_cost_" + sfx)
         f.argtypes = [vp] * 5 + [ci] * 3 + [i64] + [ctypes.c_double] * 4 + [vp, vp]
         f.restype = ci
+    L.msda_focal_neg_sum_f32.argtypes = [vp, vp, i64, ci, ctypes.c_float, vp, ci, ctypes.POINTER(ci), vp]
+    L.msda_focal_neg_sum_f32.restype = ci
+    L.msda_focal_neg_grad_f32.argtypes = [vp, vp, i64, ci, ctypes.c_float, vp, vp, vp]
+    L.msda_focal_neg_grad_f32.restype = ci
     for sfx in ("f32", "f64"):
         f = getattr(L, "msda_attnpool_core_" + sfx)
         f.argtypes = [vp] * 4 + [ci] * 5 + [vp, vp]

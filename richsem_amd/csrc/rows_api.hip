@@ -146,7 +146,88 @@ __global__ __launch_bounds__(256) void narrow_linear_dw_kernel(const uint16_t *_
 
 }  // namespace
 
+
+// ---- the all-negative term of the sigmoid focal loss over a whole logit tensor (criterion plumbing) ------------
+// sigmoid_focal_loss (reference models/richsem/utils.py / richsem.py:1124-1160) at a NEGATIVE entry is (1 - alpha) p^2 softplus(x), p = sigmoid(x);
+// the criterion sums it over every (output, image, query, class) with a weight per ROW (1 / num_boxes for the matching queries, 1 / (num_boxes
+// x groups) for the denoising queries' positive slots, 0 for the slots that carry no loss) and corrects the few positive entries separately.
+// As PyTorch ops that is sigmoid, softplus, three products, a slice and a sum forward and as many kernels backward over 63 MB of logits; here one
+// pass each way.   forward: partial[block] = sum_rows w[row] sum_c (1 - alpha) p^2 softplus(x)   (fp64 partials, summed by the caller)
+//                  backward: grad_x = g w[row] (1 - alpha) p^2 (2 (1 - p) softplus(x) + p)
+__device__ __forceinline__ float focal_neg(float x, float &dfdx)
+{
+    const float p = 1.f / (1.f + __expf(-x));
+    const float sp = x > 20.f ? x : log1pf(__expf(x));      // softplus, as torch (threshold 20)
+    const float pp = p * p;
+    dfdx = pp * (2.f * (1.f - p) * sp + p);
+    return pp * sp;
+}
+
+__global__ __launch_bounds__(256) void focal_neg_sum_kernel(const float *__restrict__ x, const float *__restrict__ w, long long rows, int C, float one_m_alpha,
+                                                            double *__restrict__ partial)
+{
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float wr = w[r];
+        if (wr == 0.f) continue;      // (block-uniform)
+        float s = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float d;
+            s += focal_neg(x[r * C + c], d);
+        }
+        acc += (double)(s * wr);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] * (double)one_m_alpha;
+}
+
+__global__ __launch_bounds__(256) void focal_neg_grad_kernel(const float *__restrict__ x, const float *__restrict__ w, long long rows, int C, float one_m_alpha,
+                                                             const float *__restrict__ gscale, float *__restrict__ gx)
+{
+    const float g = gscale[0] * one_m_alpha;
+    for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float wr = w[r] * g;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float d = 0.f;
+            if (wr != 0.f) focal_neg(x[r * C + c], d);
+            gx[r * C + c] = d * wr;
+        }
+    }
+}
+
 extern "C" {
+
+/* msda_focal_neg_sum_f32: partial (grid doubles, grid = the value returned through n_partial) <- weighted all-negative focal sums; the caller adds
+ * them up.  msda_focal_neg_grad_f32: grad_logits <- gscale[0] * d/dx of that sum (every element written). */
+int msda_focal_neg_sum_f32(const float *logits, const float *row_weight, int64_t rows, int C, float alpha, double *partial, int max_partial,
+                           int *n_partial, msda_stream_t stream)
+{
+    if (!logits || !row_weight || !partial || !n_partial) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (rows < 1 || C < 1 || max_partial < 1) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    const int grid = (int)std::min<int64_t>(std::min<int64_t>(rows, 4096), max_partial);
+    *n_partial = grid;
+    hipLaunchKernelGGL(focal_neg_sum_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), logits, row_weight, (long long)rows, C,
+                       1.f - alpha, partial);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
+int msda_focal_neg_grad_f32(const float *logits, const float *row_weight, int64_t rows, int C, float alpha, const float *gscale,
+                            float *grad_logits, msda_stream_t stream)
+{
+    if (!logits || !row_weight || !gscale || !grad_logits) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (rows < 1 || C < 1) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    const int grid = (int)std::min<int64_t>(rows, 8192);
+    hipLaunchKernelGGL(focal_neg_grad_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), logits, row_weight, (long long)rows, C,
+                       1.f - alpha, gscale, grad_logits);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
 
 /* Backward of y = x W^T + b for a 256 -> n layer, n <= 8: dy (T, n) bf16 contiguous, x (T, 256) bf16, w (n, 256) f32 -> dx (T, 256) bf16
  * (or NULL), dw (n, 256) f32 and db (n) f32 (or NULL), both overwritten */

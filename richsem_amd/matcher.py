@@ -13,6 +13,8 @@ asynchronous copy and ONE event wait.  The assignment itself stays scipy's ``lin
 engine (richsem.py:1143-1147, engine.py:84-91): the box count is known on the host and reduced there, the reduced loss dictionary
 for the log is read one step late.
 """
+import ctypes
+
 import torch
 from scipy.optimize import linear_sum_assignment
 from torch import nn
@@ -176,3 +178,38 @@ class AsyncLossLog:
 
     def flush(self):
         return self._finish()
+
+
+class FocalNegativeSum(torch.autograd.Function):
+    """``sum_rows w[row] * sum_c (1 - alpha) * sigmoid(x)^2 * softplus(x)``: the sigmoid focal loss (reference richsem.py:1124-1160 through
+    ``sigmoid_focal_loss``) of a logit tensor as if every entry were negative, with one weight per row (query) -- the criterion adds what
+    the few positive entries contribute instead.  One kernel forward, one backward (``msda_focal_neg_sum_f32 / msda_focal_neg_grad_f32``,
+    csrc/rows_api.hip) where PyTorch's ops make a dozen passes over the (6, N, queries, classes) logits.
+    ``apply(logits (..., C) float32, row_weight (...) float32, alpha)`` -> 0-dim float32."""
+
+    @staticmethod
+    def forward(ctx, logits, row_weight, alpha):
+        if not logits.is_cuda:
+            raise RuntimeError("Not implemented on the CPU")
+        assert logits.dtype == torch.float32 and row_weight.dtype == torch.float32 and row_weight.numel() * logits.shape[-1] == logits.numel()
+        x, w = logits.contiguous(), row_weight.contiguous()
+        rows, C = w.numel(), x.shape[-1]
+        partial = torch.empty(4096, dtype=torch.float64, device=x.device)
+        n = ctypes.c_int(0)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().msda_focal_neg_sum_f32(x.data_ptr(), w.data_ptr(), rows, C, float(alpha), partial.data_ptr(), 4096,
+                                                          ctypes.byref(n), torch.cuda.current_stream(x.device).cuda_stream))
+        ctx.save_for_backward(x, w)
+        ctx.alpha = float(alpha)
+        return partial[:n.value].sum().float()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        gs = g.reshape(1).float().contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().msda_focal_neg_grad_f32(x.data_ptr(), w.data_ptr(), w.numel(), x.shape[-1], ctx.alpha, gs.data_ptr(),
+                                                           gx.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream))
+        return gx, None, None

@@ -117,3 +117,84 @@ def test_graphed_sections_train_like_the_eager_step():
     res = bench_step.run_graphed(2, torch.device("cuda", 0), steps=2, warmup=1, height=H, width=W_IMG, boxes_per_image=BOXES, seed=0)
     assert abs(res["loss"] - float(loss)) < 0.1 * abs(float(loss)), (res["loss"], float(loss))
     assert 0.7 < res["grad_norm"] / gnorm < 1.4, (res["grad_norm"], gnorm)
+
+
+def _criterion_op_by_op(model, logits, coords, il, ib, clip_logits, t_logits, labels, boxes, m_dec, m_int, m_dis):
+    """the criterion as the plain op sequence round 3 ran (one focal / box-loss evaluation per part): the yardstick of the batched form"""
+    import torch.nn.functional as F
+    from bench_step import box_cxcywh_to_xyxy, giou_pairs
+    st = model.static
+    dev = logits.device
+    lay = st["lay"]
+    pad, groups, single = lay["pad_size"], lay["num_dn_group"], lay["single_pad"]
+    num_boxes = float(max(sum(st["known_num"]), 1))
+    nl, N = logits.shape[0], logits.shape[1]
+    alpha = 0.25
+
+    def box_losses(pb, tb, norm):
+        return (5.0 * (pb - tb).abs().sum() + 2.0 * (1 - giou_pairs(box_cxcywh_to_xyxy(pb), box_cxcywh_to_xyxy(tb))).sum()) / norm
+
+    p_all = logits.sigmoid()
+    neg_all = (1 - alpha) * p_all * p_all * F.softplus(logits)
+
+    def focal_pos(x, q):
+        return (alpha * (1 - q) ** 2 * F.softplus(-x) - (1 - alpha) * q * q * F.softplus(x)).sum()
+
+    li, bi, si, tj = m_dec
+    sel = (li, bi, si + pad, labels[tj])
+    loss = (neg_all[:, :, pad:].sum() + focal_pos(logits[sel], p_all[sel])) / num_boxes
+    loss = loss + box_losses(coords[li, bi, si + pad], boxes[tj], num_boxes)
+    _, bi, si, tj = m_int
+    ip = il.sigmoid()
+    tl = labels[tj]
+    loss = loss + (((1 - alpha) * ip * ip * F.softplus(il)).sum() + focal_pos(il[bi, si, tl], ip[bi, si, tl])) / num_boxes
+    loss = loss + box_losses(ib[bi, si], boxes[tj], num_boxes)
+    pos_slots = (torch.arange(groups, device=dev)[:, None] * 2 * single + torch.arange(single, device=dev)[None]).flatten()
+    tlab = labels.view(N, -1).repeat(1, groups)
+    tbx = boxes.view(N, -1, 4).repeat(1, groups, 1)
+    nbx = num_boxes * groups
+    dl, dp, db = logits[:, :, pos_slots], p_all[:, :, pos_slots], coords[:, :, pos_slots]
+    hot = tlab[None, :, :, None].expand(nl, -1, -1, 1)
+    loss = loss + (neg_all[:, :, pos_slots].sum() + focal_pos(dl.gather(3, hot), dp.gather(3, hot))) / nbx
+    loss = loss + box_losses(db.reshape(-1, 4), tbx[None].expand(nl, -1, -1, -1).reshape(-1, 4), nbx)
+    _, bi, si, tj = m_dis
+    return loss + 0.5 * F.kl_div(F.log_softmax(clip_logits[bi, si + pad], -1), F.softmax(t_logits[tj], -1), reduction="batchmean")
+
+
+def test_batched_criterion_equals_the_op_sequence():
+    """loss_part (fused all-negative focal kernel, every pair formula once over the concatenated parts) against the per-part op sequence:
+    loss and its gradients with respect to every input"""
+    model, images, mask, targets = _small_step(seed=2)
+    with torch.no_grad():
+        outs = model.model_part(images, mask)
+    idx = model.pack_indices(model.match(*outs[:4], targets), targets)
+    res = []
+    for fn in (model.loss_part, lambda *a: _criterion_op_by_op(model, *a)):
+        leaves = [o.detach().clone().requires_grad_(i < 5) for i, o in enumerate(outs)]
+        loss = fn(*leaves, *idx)
+        loss.backward()
+        res.append((loss.detach(), [t.grad for t in leaves[:5]]))
+    (la, ga), (lb, gb) = res
+    assert abs(float(la) - float(lb)) < 2e-5 * abs(float(lb)), (float(la), float(lb))
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) < 2e-5 * float(b.abs().max()) + 1e-12, float((a - b).abs().max()) / float(b.abs().max())
+
+
+def test_focal_negative_sum_kernel():
+    from richsem_amd.matcher import FocalNegativeSum
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = (torch.randn(3, 2, 57, 1204, device="cuda", generator=g) * 6).requires_grad_(True)       # (incl. |x| > 20: softplus's linear branch)
+    w = torch.rand(3, 2, 57, device="cuda", generator=g)
+    w[:, :, :5] = 0.0
+    got = FocalNegativeSum.apply(x, w, 0.25)
+    got.backward(torch.tensor(1.7, device="cuda"))
+    gx = x.grad.clone()
+    x.grad = None
+    xd = x.detach().double().requires_grad_(True)
+    p = xd.sigmoid()
+    want = ((0.75 * p * p * F.softplus(xd)).sum(-1) * w.double()).sum()
+    want.backward(torch.tensor(1.7, device="cuda", dtype=torch.float64))
+    assert abs(float(got) - float(want)) < 1e-5 * abs(float(want))
+    assert float((gx.double() - xd.grad).abs().max()) < 1e-5 * float(xd.grad.abs().max())
+    assert float(gx[:, :, :5].abs().max()) == 0.0
