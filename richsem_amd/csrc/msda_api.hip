@@ -1024,6 +1024,7 @@ int msda_set_option(const char *key, int value)
     if (key && !strcmp(key, "rps_max_chunks") && value >= 1 && value <= 4096) { msda::rps_options().max_chunks = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_route_wgs") && value >= 1 && value <= 64) { msda::rps_options().route_wgs = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_seg_shift") && value >= 3 && value <= 11) { msda::rps_options().seg_shift = value; return MSDA_OK; }
+    if (key && !strcmp(key, "rps_order") && value >= 0 && value <= 1) { msda::rps_options().order = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_direct_cpl") && (value == 0 || value == 1 || value == 2 || value == 4)) { g_bwd_cpl = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_region") && value >= 4 && value <= 64) { msda::tiled_options().region_px = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_margin") && value >= 0 && value <= 32) { msda::tiled_options().margin = value; return MSDA_OK; }
@@ -1056,6 +1057,7 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "rps_max_chunks")) { *value = msda::rps_options().max_chunks; return MSDA_OK; }
     if (key && !strcmp(key, "rps_route_wgs")) { *value = msda::rps_options().route_wgs; return MSDA_OK; }
     if (key && !strcmp(key, "rps_seg_shift")) { *value = msda::rps_options().seg_shift; return MSDA_OK; }
+    if (key && !strcmp(key, "rps_order")) { *value = msda::rps_options().order; return MSDA_OK; }
     if (key && !strcmp(key, "tile_region")) { *value = msda::tiled_options().region_px; return MSDA_OK; }
     if (key && !strcmp(key, "tile_margin")) { *value = msda::tiled_options().margin; return MSDA_OK; }
     if (key && !strcmp(key, "tile_persist")) { *value = msda::tiled_options().persist; return MSDA_OK; }

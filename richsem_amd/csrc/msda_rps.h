@@ -1014,6 +1014,7 @@ struct RpsOptions {
     std::atomic<int> tile{16};         // largest tile side + 1 (tile + one row / column <= kRpsMaxPx = 256 pixels)
     std::atomic<int> max_chunks{12};   // expected chunks of one workgroup before a tile is split into slabs (MI355X, call E: 6 -> 12 = 463 -> 447 us on uniform locations, equal at the init pattern)
     std::atomic<int> route_wgs{2};     // route pass: workgroups per CU (persistent over the query blocks): two are resident at its 102 registers (MI355X, call E: 2 -> 55.9 us, 3 -> 61.7, 4 -> 58.1, 6 -> 63.1)
+    std::atomic<int> order{0};         // work-queue order of the tile kernel: 0 = heaviest tile first, 1 = region-major (see plan_rps)
     std::atomic<int> seg_shift{4};     // units of the list walk: at most 1 << seg_shift points of a pixel's list (3..11; MI355X,
                                        // call E, list walk: 8 -> 315 k cycles per workgroup, 16 -> 301 k, 32 -> 330 k, whole lists -> 347 k)
 };
@@ -1085,7 +1086,44 @@ inline RpsPlan plan_rps(int N, int S, int M, int D, int L, int Lq, int P, const 
         g.lut_c[l] = g.lut_n;
         g.lut_n += g.lv[l].W + 1;
     }
-    std::stable_sort(units.begin(), units.end(), [](const U &a, const U &b) { return a.cost > b.cost; });
+    if (rps_options().order.load() == 0) {
+        std::stable_sort(units.begin(), units.end(), [](const U &a, const U &b) { return a.cost > b.cost; });      // heaviest first
+    } else {
+        // Region-major order (round 4): the slabbed (heaviest) tiles first, heaviest first as before; then every other tile in the order
+        // of a coarse-to-fine walk over the image -- a tile of the coarsest level, then the tiles of the next finer level whose centres
+        // lie in it, each followed by ITS finer tiles, ... -- so that the tiles the points of one group of queries land on at the
+        // different levels are drawn from the queue one after the other and run at about the same time on the same XCD: the four
+        // 32-byte pieces of a (query, head)'s 128-byte grad_loc line (one per level, written by four workgroups) then meet in that
+        // XCD's L2 instead of going out to memory one by one.
+        std::vector<int> order;      // the levels without slabs, coarsest tile grid first
+        for (int l = 0; l < L; ++l)
+            if (g.lv[l].nslab == 1) order.push_back(l);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return g.lv[a].nty * g.lv[a].ntx < g.lv[b].nty * g.lv[b].ntx; });
+        auto key_of = [&](unsigned code) {
+            const int l = code & 3, ty = (code >> 2) & 63, tx = (code >> 8) & 63, nslab = (code >> 22) & 255;
+            if (nslab > 1) return (unsigned long long)0;      // (kept in front, by cost)
+            const RpsLevel &v = g.lv[l];
+            const double cy = (std::min(v.H, ty * v.TH + v.TH) + ty * v.TH) * 0.5 / v.H, cx = (std::min(v.W, tx * v.TW + v.TW) + tx * v.TW) * 0.5 / v.W;
+            unsigned long long key = 1ull << 60;
+            int shift = 42;
+            for (int k : order) {
+                const RpsLevel &u = g.lv[k];
+                unsigned long long part = 0;      // (0: this unit is coarser than level k -- it sorts before the tiles inside it)
+                if (u.nty * u.ntx <= v.nty * v.ntx || k == l) {
+                    const int uy = k == l ? ty : std::min(u.nty - 1, (int)(cy * u.H / u.TH)), ux = k == l ? tx : std::min(u.ntx - 1, (int)(cx * u.W / u.TW));
+                    part = (unsigned long long)((uy + 1) << 7 | (ux + 1));
+                }
+                key |= part << shift;
+                shift -= 14;
+                if (k == l) break;
+            }
+            return key;
+        };
+        std::stable_sort(units.begin(), units.end(), [&](const U &a, const U &b) {
+            const unsigned long long ka = key_of(a.code), kb = key_of(b.code);
+            return ka != kb ? ka < kb : a.cost > b.cost;
+        });
+    }
     g.nunits = (int)units.size();
     for (int i = 0; i < g.nunits; ++i) g.units[i] = units[i].code;
     g.bins_per_pair = bins;
