@@ -615,24 +615,29 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                 const TV *src = value + (head_major ? ((int64_t)(b * g.M + m) * g.S + uni(hdr->start[l])) * kTD
                                                     : ((int64_t)(b * g.S + uni(hdr->start[l])) * g.M + m) * kTD) + half * GC + 4 * fj;
                 float *dst = win + (int64_t)uni(hdr->lds_px[l]) * GC + 4 * fj;
-                // kFillBatch independent loads in flight per lane before the first LDS store
+                // kFillBatch independent loads in flight per lane before the first LDS store.  Straight-line code (round 4): the pixel index
+                // is clamped for the load AND for the store -- lanes past the window's end re-store its last pixel, the same value to the
+                // same place -- so that no branch surrounds a store: with `if (px < npx)` around it hipcc moved the LOAD under the branch
+                // too and waited for it there (one or two loads in flight instead of four); the pixel's row comes from a reciprocal
+                // (exact: (px + 0.5) / nwc is at least 0.5 / nwc away from an integer), not from a 20-instruction integer division.
+                const float inv_nwc = 1.0f / (float)nwc;
                 for (int px0 = fgrp; px0 < npx; px0 += kFillBatch * kFillGroups) {
                     float4 v[kFillBatch];
+                    int pxs[kFillBatch];
+                    bool inm[kFillBatch];
 #pragma unroll
                     for (int u = 0; u < kFillBatch; ++u) {
-                        const int px = min(px0 + u * kFillGroups, npx - 1);   // clamped; stored only if in range
-                        const int rr = px / nwc, cc = px - rr * nwc;
+                        const int px = min(px0 + u * kFillGroups, npx - 1);
+                        const int rr = (int)(((float)px + 0.5f) * inv_nwc), cc = px - rr * nwc;
                         const int row = wr0 + rr, col = wc0 + cc;
-                        const bool in_map = row >= 0 && row < Hl && col >= 0 && col < Wl;   // else: the zero apron
+                        inm[u] = row >= 0 && row < Hl && col >= 0 && col < Wl;   // else: the zero apron
                         const int rowc = min(max(row, 0), Hl - 1), colc = min(max(col, 0), Wl - 1);
-                        const float4 t = ld4(src + (int64_t)(rowc * Wl + colc) * row_elems);
-                        v[u] = in_map ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                        pxs[u] = px;
+                        v[u] = ld4(src + (int64_t)(rowc * Wl + colc) * row_elems);
                     }
 #pragma unroll
-                    for (int u = 0; u < kFillBatch; ++u) {
-                        const int px = px0 + u * kFillGroups;
-                        if (px < npx) *reinterpret_cast<float4 *>(dst + px * GC) = v[u];
-                    }
+                    for (int u = 0; u < kFillBatch; ++u)
+                        *reinterpret_cast<float4 *>(dst + pxs[u] * GC) = inm[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             __syncthreads();
