@@ -794,6 +794,8 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
             //      point, grad_out rows straight from global memory, software-pipelined; then the sums go to the tile's f64 sums ----
             const int n_segs = rps_uni(S->n_segs);
             for (int u0 = wave * 16; u0 < n_segs; u0 += kRpsWaves * 16) {   // (uniform)
+                unsigned long long wt0 = 0, wt1 = 0, wt2 = 0;      // (diagnostic: wave 0's time in a group's set-up / point loop / epilogue)
+                if (g.stamps && tid == 0) wt0 = __builtin_amdgcn_s_memtime();
                 const int un = u0 + (lane >> 2);
                 if (un < n_segs) {
                     const unsigned sc = S->seg[un];
@@ -851,6 +853,7 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                     int itA = S->ent[e].item, itB = S->ent[min(e + 1, e_last)].item;
                     RpsRow<TV> gA, gB;
                     RPS_ROW(itA, gA)
+                    if (g.stamps && tid == 0) wt1 = __builtin_amdgcn_s_memtime();
                     for (; e + 1 < e1; e += 2) {
                         RPS_ROW(itB, gB)
                         itA = S->ent[min(e + 2, e_last)].item;
@@ -872,6 +875,7 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
 #undef RPS_COEF
 #undef RPS_ROW
 #undef RPS_POINT
+                    if (g.stamps && tid == 0) wt2 = __builtin_amdgcn_s_memtime();
                     // the unit's partial sums to the tile's f64 sums: corner k of base pixel p is pixel p-gw-1 / p-gw / p-1 / p of
                     // the pixel grid, where that pixel exists (else it lies outside the map or in the tile above / to the left)
 #pragma unroll
@@ -883,6 +887,13 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                             for (int m_ = 0; m_ < 8; ++m_) atomicAdd(dst + 4 * m_, (double)macc[m_][k]);
                         }
                     }
+                }
+                if (g.stamps && tid == 0 && wt1) {
+                    const unsigned long long wt3 = __builtin_amdgcn_s_memtime();
+                    S->stamp_acc[9] += wt1 - wt0;
+                    S->stamp_acc[10] += wt2 - wt1;
+                    S->stamp_acc[11] += wt3 - wt2;
+                    S->stamp_acc[12] += 1;
                 }
             }
             // the next chunk -- or the first chunk of the next work item -- is requested now, behind the walk (held across it,

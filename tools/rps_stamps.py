@@ -49,6 +49,10 @@ def main():
     print(f"{args.call} loc-{args.loc}: per workgroup {tot.mean():.0f} cycles (min {tot.min():.0f}, max {tot.max():.0f})")
     for i, n in enumerate(NAMES):
         print(f"  {n:34s} {s[:, i].mean():10.0f} cycles  {100 * s[:, i].mean() / tot.mean():5.1f} %")
+    ng = s[:, 12].mean()
+    if ng > 0:
+        print(f"  wave 0 inside the walk: {ng:.0f} groups per workgroup; per group: set-up (unit, value rows, first row request) {s[:, 9].mean() / ng:.0f}, "
+              f"point loop {s[:, 10].mean() / ng:.0f}, f64 epilogue {s[:, 11].mean() / ng:.0f} cycles")
 
 
 if __name__ == "__main__":
