@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RICHSEM_MSDA_ABI_VERSION 6
+#define RICHSEM_MSDA_ABI_VERSION 7
 
 /* Return codes: 0 = success; negative = argument error detected on the host (nothing was
  * launched); positive = hipError_t reported by the runtime. */
@@ -343,6 +343,9 @@ int msda_roi_align_forward_f64(const double *input, const double *rois, int K, i
  * (repack when the weight changes).  msda_conv_set_tiling forces the per-wave tile (channel tiles in {1, 2, 4, 8, 16}, pixel tiles in
  * {1, 2, 3}; 0 = chosen per call so that the grid fills the chip) -- results do not depend on it beyond summation order. */
 int msda_conv_set_tiling(int co_tiles, int pixel_tiles);
+/* ... and msda_conv_set_ring the operand prefetch of the C_in % 64 == 0 kernels: both operands through LDS rings of `slots` iterations
+ * (LDS DMA; csrc/conv_mfma.hip, conv_ring_kernel): -1 never, 0 chosen per call, 3 / 4 / 6 wherever that kernel applies.  Same results. */
+int msda_conv_set_ring(int slots);
 int msda_conv_packed_elems(int Cout, int Cin, int KH, int KW, int64_t *elems);
 int msda_conv_pack_weight(const float *weight, int Cout, int Cin, int KH, int KW, uint16_t *packed, msda_stream_t stream);
 int msda_conv_forward_bf16(const uint16_t *x, const uint16_t *packed_weight, const float *scale, const float *shift,
@@ -388,6 +391,13 @@ int msda_conv_dgrad_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, in
 int msda_conv_dgrad_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride, int pad, int H, int W, int64_t *bytes);
 int msda_conv_dgrad_ws_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW,
                             int stride, int pad, int H, int W, uint16_t *dx, void *workspace, msda_stream_t stream);
+/* ... with the element-wise work that follows an input gradient in a residual network in its epilogue: dx = mask(conv_dgrad(dy) + add).
+ * add (N, H, W, Cin) bf16 or NULL: a second gradient of the same tensor (the identity branch of a bottleneck); relu_out (N, H, W, Cin)
+ * bf16 or NULL: the tensor whose gradient this is, when it is the output of a ReLU -- dx is zeroed where it is not positive, i.e. dx is
+ * the gradient at that ReLU's INPUT (what aten::threshold_backward would make of it in a pass of its own). */
+int msda_conv_dgrad_fused_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW,
+                               int stride, int pad, int H, int W, const uint16_t *add, const uint16_t *relu_out, uint16_t *dx,
+                               void *workspace, msda_stream_t stream);
 
 /* Gradient of msda_conv_forward_bf16 w.r.t. its weight (csrc/conv_wgrad.hip): dw[co][kh][kw][ci] = sum over output pixels of
  * dz[n, ho, wo, co] * x[n, ho stride + kh - pad, wo stride + kw - pad, ci].  dz (N, Ho, Wo, Cout) bf16 = gradient at the CONVOLUTION's

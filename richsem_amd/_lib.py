@@ -16,7 +16,7 @@ ERR_NAMES = {
     -4: "MSDA_ERR_TOO_LARGE", -5: "MSDA_ERR_MISALIGNED", -6: "MSDA_ERR_NO_DEVICE", -7: "MSDA_ERR_BAD_OPTION",
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/richsem_msda.h declares
 SYMBOLS = [
@@ -32,7 +32,7 @@ SYMBOLS = [
     "msda_attn_workspace_bytes", "msda_attn_forward_bf16", "msda_attn_backward_bf16",
     "msda_matcher_cost_f32", "msda_matcher_cost_f64", "msda_focal_neg_sum_f32", "msda_focal_neg_grad_f32", "msda_attnpool_core_f32", "msda_attnpool_core_f64",
     "msda_cls_packed_elems", "msda_cls_pack", "msda_cls_max_scores",
-    "msda_conv_set_tiling", "msda_conv_packed_elems", "msda_conv_pack_weight", "msda_conv_forward_bf16", "msda_conv_dgrad_bf16", "msda_conv_forward_workspace_bytes", "msda_conv_forward_ws_bf16", "msda_conv_dgrad_workspace_bytes", "msda_conv_dgrad_ws_bf16", "msda_pool_nhwc_bf16", "msda_groupnorm8_nhwc_bf16", "msda_groupnorm8_backward_nhwc_bf16", "msda_conv_wgrad_workspace_bytes", "msda_conv_wgrad_bf16",
+    "msda_conv_set_tiling", "msda_conv_set_ring", "msda_conv_dgrad_fused_bf16", "msda_conv_packed_elems", "msda_conv_pack_weight", "msda_conv_forward_bf16", "msda_conv_dgrad_bf16", "msda_conv_forward_workspace_bytes", "msda_conv_forward_ws_bf16", "msda_conv_dgrad_workspace_bytes", "msda_conv_dgrad_ws_bf16", "msda_pool_nhwc_bf16", "msda_groupnorm8_nhwc_bf16", "msda_groupnorm8_backward_nhwc_bf16", "msda_conv_wgrad_workspace_bytes", "msda_conv_wgrad_bf16",
 ]
 
 
@@ -119,6 +119,10 @@ def load():
     L.msda_conv_pack_weight.restype = ci
     L.msda_conv_set_tiling.argtypes = [ci, ci]
     L.msda_conv_set_tiling.restype = ci
+    L.msda_conv_set_ring.argtypes = [ci]
+    L.msda_conv_set_ring.restype = ci
+    L.msda_conv_dgrad_fused_bf16.argtypes = [vp, vp] + [ci] * 11 + [vp, vp, vp, vp, vp]
+    L.msda_conv_dgrad_fused_bf16.restype = ci
     L.msda_conv_packed_elems.argtypes = [ci] * 4 + [ctypes.POINTER(i64)]
     L.msda_conv_packed_elems.restype = ci
     L.msda_conv_forward_bf16.argtypes = [vp] * 5 + [ci] * 10 + [vp, vp]

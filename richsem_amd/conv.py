@@ -95,6 +95,27 @@ def set_tiling(co_tiles=0, pixel_tiles=0):
     _lib.check(_lib.load().msda_conv_set_tiling(int(co_tiles), int(pixel_tiles)))
 
 
+def set_ring(slots=0):
+    """Tuning / tests: the operand rings of the C_in % 64 == 0 convolution kernel: -1 never, 0 automatic, 3 / 4 / 6 slots wherever it applies."""
+    _lib.check(_lib.load().msda_conv_set_ring(int(slots)))
+
+
+def conv_dgrad(dz, packed_t, x_shape, Cout, KH, KW, stride, padding, add=None, relu_out=None):
+    """Input gradient of a convolution (``msda_conv_dgrad_fused_bf16``): dz (N, Ho, Wo, Cout) bf16 NHWC, ``packed_t`` the packed flipped /
+    transposed weight -> dx of shape ``x_shape`` (N, H, W, Cin); ``add``: a second gradient of the same tensor, summed in the epilogue;
+    ``relu_out``: the tensor itself when it is the output of a ReLU -- dx is then the gradient at that ReLU's input"""
+    N, H, W, Cin = x_shape
+    dx = torch.empty(x_shape, dtype=torch.bfloat16, device=dz.device)
+    L = _lib.load()
+    with torch.cuda.device(dz.device):
+        ws = _ksplit_workspace(L.msda_conv_dgrad_workspace_bytes, (N, dz.shape[1], dz.shape[2], Cout, Cin, KH, KW, stride, padding, H, W), dz.device)
+        _lib.check(L.msda_conv_dgrad_fused_bf16(dz.data_ptr(), packed_t.data_ptr(), N, dz.shape[1], dz.shape[2], Cout, Cin, KH, KW, stride, padding,
+                                                H, W, add.data_ptr() if add is not None else None,
+                                                relu_out.data_ptr() if relu_out is not None else None, dx.data_ptr(),
+                                                ws.data_ptr() if ws is not None else None, _stream(dz.device)))
+    return dx
+
+
 def _pool(x, k, stride, pad, is_max):
     assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[3] % 8 == 0
     x = x.contiguous()

@@ -27,6 +27,7 @@
 
 #include <atomic>
 #include <initializer_list>
+#include <type_traits>
 
 #include "../../include/richsem_msda.h"
 
@@ -92,13 +93,80 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, uint16_t *__restri
     }
 }
 
+// epilogue: lane (c, q) holds, for every group of G tiles, the 4 G consecutive channels co0 + 16 G grp + 4 G q + (4 u + i) of pixel c
+// (tile u of the group, register i): affine, residual, relu (or the mask of an input gradient taken THROUGH a ReLU: zero where the
+// forward's activation `mask` was not positive), one 8 G-byte store
+template <int CO_TILES, int PT>
+__device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[PT][CO_TILES], long long pix0, int c, int q, int co0, long long P, int Cout,
+                                              const float *__restrict__ scale, const float *__restrict__ shift,
+                                              const uint16_t *__restrict__ residual, int relu, const uint16_t *__restrict__ mask,
+                                              uint16_t *__restrict__ out)
+{
+    constexpr int G = CO_TILES >= 4 ? 4 : CO_TILES;
+#pragma unroll
+    for (int t3 = 0; t3 < PT; ++t3) {
+        const long long p = pix0 + 16 * t3 + c;
+        if (p >= P) continue;
+#pragma unroll
+        for (int grp = 0; grp < CO_TILES / G; ++grp) {
+            const int co = co0 + 16 * G * grp + 4 * G * q;
+            float y[4 * G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const float4 sc = scale ? *reinterpret_cast<const float4 *>(scale + co + 4 * u) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float4 sh = shift ? *reinterpret_cast<const float4 *>(shift + co + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+                y[4 * u + 0] = fmaf(acc[t3][grp * G + u][0], sc.x, sh.x);
+                y[4 * u + 1] = fmaf(acc[t3][grp * G + u][1], sc.y, sh.y);
+                y[4 * u + 2] = fmaf(acc[t3][grp * G + u][2], sc.z, sh.z);
+                y[4 * u + 3] = fmaf(acc[t3][grp * G + u][3], sc.w, sh.w);
+            }
+            if (residual) {
+                const uint2 *rp = reinterpret_cast<const uint2 *>(residual + p * Cout + co);
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const uint2 r = rp[u];
+                    y[4 * u + 0] += bf16_lo(r.x); y[4 * u + 1] += bf16_hi(r.x); y[4 * u + 2] += bf16_lo(r.y); y[4 * u + 3] += bf16_hi(r.y);
+                }
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4 * G; ++e) y[e] = fmaxf(y[e], 0.f);
+            }
+            if (mask) {      // (bf16 > 0  <=>  its bits, read as a signed 16-bit integer, are > 0)
+                const uint2 *mp = reinterpret_cast<const uint2 *>(mask + p * Cout + co);
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const uint2 m = mp[u];
+                    if ((short)(m.x & 0xFFFFu) <= 0) y[4 * u + 0] = 0.f;
+                    if ((short)(m.x >> 16) <= 0) y[4 * u + 1] = 0.f;
+                    if ((short)(m.y & 0xFFFFu) <= 0) y[4 * u + 2] = 0.f;
+                    if ((short)(m.y >> 16) <= 0) y[4 * u + 3] = 0.f;
+                }
+            }
+            unsigned o[2 * G];
+#pragma unroll
+            for (int e = 0; e < 2 * G; ++e) o[e] = pack_bf16(y[2 * e], y[2 * e + 1]);
+            uint16_t *dst = out + p * Cout + co;
+            if (G == 4) {
+                reinterpret_cast<u32x4 *>(dst)[0] = (u32x4){o[0], o[1], o[2], o[3]};
+                reinterpret_cast<u32x4 *>(dst)[1] = (u32x4){o[4 % (2 * G)], o[5 % (2 * G)], o[6 % (2 * G)], o[7 % (2 * G)]};
+            } else if (G == 2) {
+                reinterpret_cast<u32x4 *>(dst)[0] = (u32x4){o[0], o[1], o[2 % (2 * G)], o[3 % (2 * G)]};
+            } else {
+                reinterpret_cast<uint2 *>(dst)[0] = make_uint2(o[0], o[1]);
+            }
+        }
+    }
+}
+
+
 // MODE 0: few-channel input (fragments gathered element by element through a table); 1: C_in % 32 == 0, one k-step per barrier;
 // 2: C_in % 64 == 0, two k-steps (one 32-byte load per lane and pixel) per barrier.
 template <int CO_TILES, int PT, int MODE, bool KSPLIT = false>
 __global__ __launch_bounds__(kWaves * 64)
 void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wpk, const float *__restrict__ scale,
                      const float *__restrict__ shift, const uint16_t *__restrict__ residual, uint16_t *__restrict__ out, ConvGeom g,
-                     int relu, float *__restrict__ ksum)
+                     int relu, float *__restrict__ ksum, const uint16_t *__restrict__ mask)
 {
     constexpr bool SMALLC = MODE == 0;
     constexpr int KT = MODE == 2 ? 2 : 1;
@@ -267,52 +335,190 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
         return;
     }
 
-    // epilogue: lane (c, q) holds, for every group of G tiles, the 4 G consecutive channels co0 + 16 G grp + 4 G q + (4 u + i) of pixel c
-    // (tile u of the group, register i): affine, residual, relu, one 8 G-byte store
+    conv_epilogue<CO_TILES, PT>(acc, pix0, c, q, co0, P, g.Cout, scale, shift, residual, relu, mask, out);
+}
+
+// ---- the same convolution with BOTH operands prefetched several iterations ahead through LDS rings (round 4) -------------------------
+// conv_fwd_kernel asks for an iteration's operands one iteration (KT x CO_TILES MFMAs = 256-512 cycles) before it uses them and leaves
+// the rest of the 1-2 k cycles of memory latency to the other waves of its SIMD.  The deep layers of a two-image batch (2100-8400
+// pixels: 33-132 pixel tiles) give a SIMD ONE wave, so every iteration waits out a memory round trip (layer3's 1 x 1 over 1024 channels:
+// 16 iterations, 19.8 us).  Here nothing is staged in registers:
+//   * weights: the iteration's KT x CO_TILES fragments go by LDS DMA (global_load_lds_dwordx4, 1 KB per wave instruction, already in
+//     fragment order) into slot it % R of a ring shared by the workgroup, each wave bringing a quarter;
+//   * activations: the lane's 16 bytes of an im2col fragment ARE its global_load_lds_dwordx4 element -- the fragment lands in the wave's
+//     own ring in the order ds_read_b128 hands it back; lanes outside the image (padding, the zero-upsampled gradient of a strided
+//     convolution) fetch a zero line instead of branching;
+//   * R - 1 iterations are in flight; an iteration begins with s_waitcnt vmcnt((R - 2) x requests per iteration) and ONE bare s_barrier
+//     (everybody's share of the weights has landed; everybody has left the slot that is requested next).  Past the last iteration the
+//     requests repeat the last one into a free slot, so the count is the same in every iteration.
+//   * the operand reads are inline ds_read_b128 (the compiler would wait for every DMA in flight before an LDS read it can see),
+//     eight fragments ahead of their MFMAs, released by partial lgkmcnt waits (csrc/ffn_mfma.hip's scheme).
+// C_in % 64 == 0 (two k-steps per iteration), CO_TILES >= 2.  Geometry, packing and epilogue are conv_fwd_kernel's.
+__device__ __attribute__((aligned(16))) unsigned g_conv_zero_line[4];      // (device globals are zero-initialised)
+
+#define CONV_LDS_READ(dst, addr, byte_off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(byte_off))
+#define CONV_LDS_WAIT(n, a) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(n))
+
+// fragments I .. N - 1 of a slot (1 KB apart) -> dst[I .. N - 1]   (compile-time recursion: the offsets and counts are instruction immediates)
+template <int I, int N>
+__device__ __forceinline__ void ring_read(u32x4 *dst, unsigned addr)
+{
+    if constexpr (I < N) {
+        CONV_LDS_READ(dst[I], addr, I * 1024);
+        ring_read<I + 1, N>(dst, addr);
+    }
+}
+
+// weight fragments p .. WFR - 1 of an iteration against its activation fragments: fragment p lives in fr[p & 7], is waited for with "at
+// most min(7, WFR - 1 - p) newer reads in flight", feeds PT MFMAs and is at once replaced by the read of fragment p + 8
+template <int P_, int CO_TILES, int PT>
+__device__ __forceinline__ void ring_products(f32x4 (&acc)[PT][CO_TILES], u32x4 *fr, const u32x4 *bfr, unsigned wa)
+{
+    constexpr int WFR = 2 * CO_TILES;
+    if constexpr (P_ < WFR) {
+        constexpr int h = P_ / CO_TILES, t = P_ % CO_TILES;
+        constexpr int newer = (WFR - 1 - P_) < 7 ? (WFR - 1 - P_) : 7;
+        CONV_LDS_WAIT(newer, fr[P_ & 7]);      // (the activation fragments were asked for before fragment 0)
+        const bf16x8 a = __builtin_bit_cast(bf16x8, fr[P_ & 7]);
 #pragma unroll
-    for (int t3 = 0; t3 < PT; ++t3) {
-        const long long p = pix0 + 16 * t3 + c;
-        if (p >= P) continue;
+        for (int t3 = 0; t3 < PT; ++t3)
+            acc[t3][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, bfr[h * PT + t3]), acc[t3][t], 0, 0, 0);
+        if constexpr (P_ + 8 < WFR) CONV_LDS_READ(fr[P_ & 7], wa, (P_ + 8) * 1024);
+        ring_products<P_ + 1, CO_TILES, PT>(acc, fr, bfr, wa);
+    }
+}
+
+// the request side of conv_ring_kernel: which iteration is asked for next (tap kh, kw; channel block cb) and this lane's sources for it.
+// (A __device__ member, not a lambda of the kernel: the LDS-DMA builtin inside a lambda keeps hipcc from emitting the kernel's host stub.)
+template <int CO_TILES, int PT>
+struct RingRequest {
+    static constexpr int KT = 2, WFR = KT * CO_TILES, WPW = WFR / kWaves, AFR = KT * PT;
+    const unsigned char *wsrc[WPW];      // this wave's weight fragments of the iteration (the lane's 16 bytes of each)
+    const uint16_t *asrc[PT];            // the lane's pixel row at the iteration's tap (+ 16 q channels), or null outside the image
+    size_t step_bytes;
+    int it, cb, kh, kw;
+
+    __device__ __forceinline__ void tap_sources(const uint16_t *x, const ConvGeom &g, const long long (&img)[PT], const int (&hi0)[PT],
+                                                const int (&wi0)[PT], int q)
+    {
 #pragma unroll
-        for (int grp = 0; grp < CO_TILES / G; ++grp) {
-            const int co = co0 + 16 * G * grp + 4 * G * q;
-            float y[4 * G];
-#pragma unroll
-            for (int u = 0; u < G; ++u) {
-                const float4 sc = scale ? *reinterpret_cast<const float4 *>(scale + co + 4 * u) : make_float4(1.f, 1.f, 1.f, 1.f);
-                const float4 sh = shift ? *reinterpret_cast<const float4 *>(shift + co + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
-                y[4 * u + 0] = fmaf(acc[t3][grp * G + u][0], sc.x, sh.x);
-                y[4 * u + 1] = fmaf(acc[t3][grp * G + u][1], sc.y, sh.y);
-                y[4 * u + 2] = fmaf(acc[t3][grp * G + u][2], sc.z, sh.z);
-                y[4 * u + 3] = fmaf(acc[t3][grp * G + u][3], sc.w, sh.w);
+        for (int t3 = 0; t3 < PT; ++t3) {
+            int hi = hi0[t3] + kh, wi = wi0[t3] + kw;
+            bool in = hi >= 0 && wi >= 0;
+            if (g.up > 1) {      // virtual (zero-upsampled) coordinates: only multiples of `up` hold data
+                in = in && hi % g.up == 0 && wi % g.up == 0;
+                hi /= g.up;
+                wi /= g.up;
             }
-            if (residual) {
-                const uint2 *rp = reinterpret_cast<const uint2 *>(residual + p * g.Cout + co);
+            in = in && hi < g.H && wi < g.W;
+            asrc[t3] = in ? x + (img[t3] + (long long)hi * g.W + wi) * g.Cin + 16 * q : nullptr;
+        }
+    }
+
+    template <int R>
+    __device__ __forceinline__ void request(int slot, int wave, int S, int cpb, const uint16_t *x, const ConvGeom &g, const long long (&img)[PT],
+                                            const int (&hi0)[PT], const int (&wi0)[PT], int q, unsigned char *wring, unsigned char *aring,
+                                            const uint16_t *zero)
+    {
+        unsigned char *wdst = wring + (slot * WFR + wave * WPW) * 1024;
 #pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    const uint2 r = rp[u];
-                    y[4 * u + 0] += bf16_lo(r.x); y[4 * u + 1] += bf16_hi(r.x); y[4 * u + 2] += bf16_lo(r.y); y[4 * u + 3] += bf16_hi(r.y);
-                }
-            }
-            if (relu) {
+        for (int i = 0; i < WPW; ++i)
+            __builtin_amdgcn_global_load_lds(wsrc[i], reinterpret_cast<__attribute__((address_space(3))) void *>(reinterpret_cast<uintptr_t>(wdst + i * 1024)),
+                                             16, 0, 0);
+        unsigned char *adst = aring + ((wave * R + slot) * AFR) * 1024;
 #pragma unroll
-                for (int e = 0; e < 4 * G; ++e) y[e] = fmaxf(y[e], 0.f);
-            }
-            unsigned o[2 * G];
+        for (int h = 0; h < KT; ++h)
 #pragma unroll
-            for (int e = 0; e < 2 * G; ++e) o[e] = pack_bf16(y[2 * e], y[2 * e + 1]);
-            uint16_t *dst = out + p * g.Cout + co;
-            if (G == 4) {
-                reinterpret_cast<u32x4 *>(dst)[0] = (u32x4){o[0], o[1], o[2], o[3]};
-                reinterpret_cast<u32x4 *>(dst)[1] = (u32x4){o[4 % (2 * G)], o[5 % (2 * G)], o[6 % (2 * G)], o[7 % (2 * G)]};
-            } else if (G == 2) {
-                reinterpret_cast<u32x4 *>(dst)[0] = (u32x4){o[0], o[1], o[2 % (2 * G)], o[3 % (2 * G)]};
-            } else {
-                reinterpret_cast<uint2 *>(dst)[0] = make_uint2(o[0], o[1]);
+            for (int t3 = 0; t3 < PT; ++t3)
+                __builtin_amdgcn_global_load_lds(asrc[t3] ? asrc[t3] + 64 * cb + 8 * h : zero,
+                                                 reinterpret_cast<__attribute__((address_space(3))) void *>(reinterpret_cast<uintptr_t>(adst + (h * PT + t3) * 1024)),
+                                                 16, 0, 0);
+        if (it + 1 < S) {      // (uniform) the next one; past the end the last one is repeated into a free slot
+            ++it;
+#pragma unroll
+            for (int i = 0; i < WPW; ++i) wsrc[i] += KT * step_bytes;
+            if (++cb == cpb) {
+                cb = 0;
+                if (++kw == g.KW) { kw = 0; ++kh; }
+                tap_sources(x, g, img, hi0, wi0, q);
             }
         }
     }
+};
+
+template <int CO_TILES, int PT, int R>
+__global__ __launch_bounds__(kWaves * 64)
+void conv_ring_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wpk, const float *__restrict__ scale,
+                      const float *__restrict__ shift, const uint16_t *__restrict__ residual, uint16_t *__restrict__ out, ConvGeom g,
+                      int relu, const uint16_t *__restrict__ mask)
+{
+    constexpr int KT = 2;
+    constexpr int WFR = KT * CO_TILES;            // weight fragments (1 KB each) per iteration
+    constexpr int WPW = WFR / kWaves;             // ... requested by each wave
+    constexpr int AFR = KT * PT;                  // activation fragments per wave and iteration
+    constexpr int NPI = WPW + AFR;                // LDS-DMA requests per wave and iteration
+    static_assert(WFR % kWaves == 0 && R >= 2 && (R - 2) * NPI < 64, "ring shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];      // [R][WFR] KB of weights, then [kWaves][R][AFR] KB of activations
+    unsigned char *wring = ring, *aring = ring + R * WFR * 1024;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const long long P = (long long)g.N * g.Ho * g.Wo;
+    const long long pix0 = (long long)blockIdx.x * (kWaves * 16 * PT) + wave * (16 * PT);
+    const int cpb = g.Cin / 64;                   // iterations per tap
+    const int S = g.KH * g.KW * cpb;
+    const int tiles_all = g.Cout / 16;
+    const int co0 = blockIdx.y * (16 * CO_TILES);
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(g_conv_zero_line);
+
+    long long img[PT];
+    int hi0[PT], wi0[PT];
+#pragma unroll
+    for (int t3 = 0; t3 < PT; ++t3) {
+        long long p = pix0 + 16 * t3 + c;
+        if (p > P - 1) p = P - 1;
+        const int wo = (int)(p % g.Wo), ho = (int)((p / g.Wo) % g.Ho);
+        img[t3] = (p / ((long long)g.Wo * g.Ho)) * g.H * g.W;
+        hi0[t3] = ho * g.stride - g.pad;
+        wi0[t3] = wo * g.stride - g.pad;
+    }
+
+    f32x4 acc[PT][CO_TILES];
+#pragma unroll
+    for (int t3 = 0; t3 < PT; ++t3)
+#pragma unroll
+        for (int t = 0; t < CO_TILES; ++t) acc[t3][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // request side: the iteration that is asked for next -- its tap, its channel block, this lane's sources
+    RingRequest<CO_TILES, PT> rq;
+    rq.step_bytes = (size_t)tiles_all * 1024;                                            // one k-step of the packed weight
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int f = wave * WPW + i, h = f / CO_TILES, t = f % CO_TILES;
+        rq.wsrc[i] = reinterpret_cast<const unsigned char *>(wpk) + ((size_t)blockIdx.y * CO_TILES + t) * 1024 + h * rq.step_bytes + lane * 16;
+    }
+    rq.it = rq.cb = rq.kh = rq.kw = 0;
+    rq.tap_sources(x, g, img, hi0, wi0, q);
+#pragma unroll
+    for (int r = 0; r < R - 1; ++r) rq.template request<R>(r, wave, S, cpb, x, g, img, hi0, wi0, q, wring, aring, zero);
+
+    const unsigned wbase = (unsigned)(uintptr_t)wring + lane * 16, abase = (unsigned)(uintptr_t)aring + (wave * R * AFR) * 1024 + lane * 16;
+    int slot = 0;
+    for (int s = 0; s < S; ++s) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * NPI) : "memory");      // iteration s has landed (this wave's requests)
+        __builtin_amdgcn_s_barrier();                                              // ... everybody's; and slot (s - 1) % R is free
+        rq.template request<R>(slot == 0 ? R - 1 : slot - 1, wave, S, cpb, x, g, img, hi0, wi0, q, wring, aring, zero);
+        const unsigned wa = wbase + slot * (WFR * 1024), ba = abase + slot * (AFR * 1024);
+        u32x4 bfr[AFR], fr[8];
+        ring_read<0, AFR>(bfr, ba);
+        ring_read<0, (WFR < 8 ? WFR : 8)>(fr, wa);
+        ring_products<0, CO_TILES, PT>(acc, fr, bfr, wa);
+        slot = slot + 1 == R ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the repeated requests of the last iterations)
+    conv_epilogue<CO_TILES, PT>(acc, pix0, c, q, co0, P, g.Cout, scale, shift, residual, relu, mask, out);
 }
+
 
 // k x k pooling (stride s, padding p) on NHWC bf16: a thread owns 8 channels (16 bytes) of one output pixel.  MAX: maximum over the taps
 // inside the image (torch's MaxPool2d with implicit -inf padding); else the mean over all k * k taps, which must lie inside the image
@@ -514,7 +720,8 @@ __global__ __launch_bounds__(256) void gn8_bwd_apply_kernel(const uint16_t *__re
 // epilogue of a k-split convolution: out = act(scale * ksum + shift (+ residual)), 8 channels per thread
 __global__ __launch_bounds__(256) void conv_ksum_finish_kernel(const float *__restrict__ ksum, const float *__restrict__ scale,
                                                                const float *__restrict__ shift, const uint16_t *__restrict__ residual,
-                                                               uint16_t *__restrict__ out, long long P, int Cout, int relu)
+                                                               uint16_t *__restrict__ out, long long P, int Cout, int relu,
+                                                               const uint16_t *__restrict__ mask)
 {
     const int cv = Cout / 8;
     const long long n = P * cv;
@@ -537,6 +744,14 @@ __global__ __launch_bounds__(256) void conv_ksum_finish_kernel(const float *__re
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] = fmaxf(y[e], 0.f);
         }
+        if (mask) {
+            const u32x4 m = *reinterpret_cast<const u32x4 *>(mask + at);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if ((short)(m[e] & 0xFFFFu) <= 0) y[2 * e] = 0.f;
+                if ((short)(m[e] >> 16) <= 0) y[2 * e + 1] = 0.f;
+            }
+        }
         *reinterpret_cast<u32x4 *>(out + at) = (u32x4){pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7])};
     }
 }
@@ -551,7 +766,30 @@ struct ConvArgs {
     hipStream_t stream;
     float *ksum = nullptr;      // zeroed (P, C_out) fp32 image for a k split, or nullptr
     int nz = 1;                 // k slices
+    const uint16_t *mask = nullptr;      // input gradient through a ReLU: the forward's activation (result zeroed where it is not positive)
+    int ring = 0;               // > 0: conv_ring_kernel with this many slots (C_in % 64 == 0, CO_TILES >= 2, PT <= 2, no k split)
 };
+
+template <int CO_TILES, int PT, int R>
+int launch_ring(const ConvArgs &a, const dim3 &grid)
+{
+    constexpr int bytes = R * (2 * CO_TILES + kWaves * 2 * PT) * 1024;
+    if constexpr (bytes <= 160 * 1024) {
+        static std::atomic<int> prepared{0};
+        if (bytes > 64 * 1024 && !prepared.load()) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_ring_kernel<CO_TILES, PT, R>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return (int)e;
+            prepared = 1;
+        }
+        hipLaunchKernelGGL((conv_ring_kernel<CO_TILES, PT, R>), grid, dim3(kWaves * 64), bytes, a.stream, a.x, a.wpk, a.scale, a.shift,
+                           a.residual, a.out, a.g, a.relu, a.mask);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? MSDA_OK : (int)e;
+    } else {
+        return MSDA_ERR_BAD_OPTION;
+    }
+}
 
 template <int CO_TILES, int PT, int MODE>
 int launch_conv(const ConvArgs &a)
@@ -559,18 +797,29 @@ int launch_conv(const ConvArgs &a)
     const long long P = (long long)a.g.N * a.g.Ho * a.g.Wo;
     const bool split = a.ksum != nullptr && a.nz > 1 && MODE == 2 && PT == 1;
     const dim3 grid((unsigned)((P + kWaves * 16 * PT - 1) / (kWaves * 16 * PT)), (unsigned)(a.g.Cout / (16 * CO_TILES)), split ? a.nz : 1);
+    if constexpr (MODE == 2 && PT <= 2 && CO_TILES >= 2) {
+        if (!split && a.ring > 0) {
+            int ring = a.ring;
+            while (ring > 3 && ring * (2 * CO_TILES + kWaves * 2 * PT) > 160) ring = ring > 4 ? 4 : 3;      // (what fits the CU's 160 KB)
+            switch (ring) {
+            case 3: return launch_ring<CO_TILES, PT, 3>(a, grid);
+            case 4: return launch_ring<CO_TILES, PT, 4>(a, grid);
+            default: return launch_ring<CO_TILES, PT, 6>(a, grid);
+            }
+        }
+    }
     if constexpr (MODE == 2 && PT == 1) {
         if (split)
             hipLaunchKernelGGL((conv_fwd_kernel<CO_TILES, PT, MODE, true>), grid, dim3(kWaves * 64), 0, a.stream, a.x, a.wpk, a.scale, a.shift,
-                               a.residual, a.out, a.g, a.relu, a.ksum);
+                               a.residual, a.out, a.g, a.relu, a.ksum, nullptr);
     }
     if (!split)
         hipLaunchKernelGGL((conv_fwd_kernel<CO_TILES, PT, MODE>), grid, dim3(kWaves * 64), 0, a.stream, a.x, a.wpk, a.scale, a.shift,
-                           a.residual, a.out, a.g, a.relu, nullptr);
+                           a.residual, a.out, a.g, a.relu, nullptr, a.mask);
     if (split) {
         const long long n = P * (a.g.Cout / 8);
         hipLaunchKernelGGL(conv_ksum_finish_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, a.stream,
-                           a.ksum, a.scale, a.shift, a.residual, a.out, P, a.g.Cout, a.relu);
+                           a.ksum, a.scale, a.shift, a.residual, a.out, P, a.g.Cout, a.relu, a.mask);
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
@@ -599,6 +848,7 @@ int launch_ct(const ConvArgs &a, int ct, int pt)
 }
 
 std::atomic<int> g_force_ct{0}, g_force_pt{0};   // tuning: msda_conv_set_tiling
+std::atomic<int> g_ring{0};                       // msda_conv_set_ring: -1 never, 0 automatic (choose_ring), 3 / 4 / 6 slots wherever the kernel applies
 
 // Tile choice (tools/time_conv.py --sweep on MI355X, ResNet-50 shapes at 2 x 800 x 1344): the kernel is bound by latency, not by operand
 // re-use -- small tiles (more waves per SIMD, more workgroups) win almost everywhere: 16 pixels per wave, 128 output channels per wave
@@ -629,9 +879,26 @@ int choose_ksplit(long long P, int Cout, int Cin, int KH, int KW, int ct, int pt
     return nz < 2 ? 1 : (int)nz;
 }
 
+// ring slots for a problem at the chosen tiling (0: conv_fwd_kernel).  Measured (tools/time_conv.py --ring, MI355X): see DESIGN.md section 10.
+int choose_ring(long long P, int Cout, int Cin, int KH, int KW, int ct, int pt)
+{
+    const int r = g_ring.load();
+    if (r < 0 || Cin % 64 != 0 || ct < 2 || pt > 2) return 0;
+    if (r > 0) return r;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+/* Tuning / tests: the operand rings of conv_ring_kernel: -1 never, 0 automatic, 3 / 4 / 6 slots wherever the kernel applies. */
+int msda_conv_set_ring(int slots)
+{
+    if (slots != -1 && slots != 0 && slots != 3 && slots != 4 && slots != 6) return msda_note_error(MSDA_ERR_BAD_OPTION, __func__);
+    g_ring = slots;
+    return MSDA_OK;
+}
 
 /* Tuning / tests: force the tile shape (channel tiles per wave in {1, 2, 4, 8, 16}, pixel tiles per wave in {1, 2, 3}); 0 = automatic. */
 int msda_conv_set_tiling(int co_tiles, int pixel_tiles)
@@ -720,6 +987,7 @@ int msda_conv_forward_ws_bf16(const uint16_t *x, const uint16_t *packed_weight, 
         a.nz = choose_ksplit((long long)N * Ho * Wo, Cout, Cin, KH, KW, ct, pt);
         a.ksum = a.nz > 1 ? static_cast<float *>(workspace) : nullptr;
     }
+    a.ring = choose_ring((long long)N * Ho * Wo, Cout, Cin, KH, KW, ct, pt);
     if (small_c) return launch_ct<0>(a, ct, pt);
     return Cin % 64 == 0 ? launch_ct<2>(a, ct, pt) : launch_ct<1>(a, ct, pt);
 }
@@ -822,26 +1090,42 @@ int msda_conv_dgrad_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, in
 int msda_conv_dgrad_ws_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW,
                             int stride, int pad, int H, int W, uint16_t *dx, void *workspace, msda_stream_t stream)
 {
+    return msda_conv_dgrad_fused_bf16(dy, packed_weight_t, N, Ho, Wo, Cout, Cin, KH, KW, stride, pad, H, W, nullptr, nullptr, dx, workspace,
+                                      stream);
+}
+
+/* msda_conv_dgrad_ws_bf16 with the element-wise work that follows an input gradient in a residual network done in its epilogue:
+ *   dx = mask(conv_dgrad(dy) + add)
+ * `add` (N, H, W, Cin) bf16 or NULL: a second gradient of the same tensor (the identity branch of a bottleneck, torchvision's
+ * Bottleneck.forward `out += identity`); `relu_out` (N, H, W, Cin) bf16 or NULL: the tensor whose gradient this is, when it is the OUTPUT
+ * OF A RELU -- dx is zeroed where it is not positive, i.e. dx is the gradient at the ReLU's input (aten::threshold_backward). */
+int msda_conv_dgrad_fused_bf16(const uint16_t *dy, const uint16_t *packed_weight_t, int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW,
+                               int stride, int pad, int H, int W, const uint16_t *add, const uint16_t *relu_out, uint16_t *dx,
+                               void *workspace, msda_stream_t stream)
+{
     if (!dy || !packed_weight_t || !dx) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     if (N < 1 || Ho < 1 || Wo < 1 || H < 1 || W < 1 || Cout < 32 || Cout % 32 != 0 || Cin < 16 || Cin % 16 != 0 || KH < 1 || KW < 1 ||
         KH > 16 || KW > 16 || stride < 1 || pad < 0 || pad > KH - 1 || pad > KW - 1)
         return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     if ((H + 2 * pad - KH) / stride + 1 != Ho || (W + 2 * pad - KW) / stride + 1 != Wo) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     if ((long long)N * H * W * Cin >= (1ll << 40) || (long long)N * Ho * Wo * Cout >= (1ll << 40)) return msda_note_error(MSDA_ERR_TOO_LARGE, __func__);
-    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(packed_weight_t) | reinterpret_cast<uintptr_t>(dx)) & 15)
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(packed_weight_t) | reinterpret_cast<uintptr_t>(dx) |
+         reinterpret_cast<uintptr_t>(add) | reinterpret_cast<uintptr_t>(relu_out)) & 15)
         return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
     // as a forward call: input dy with Cout channels, output dx with Cin channels and H x W pixels, padding KH - 1 - pad
     // (KH == KW is not required: the column padding is KW - 1 - pad, see below), virtual input upsampled by `stride`
     if (KH - 1 - pad != KW - 1 - pad) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);      // one padding value in the kernel's geometry: square kernels
     int ct, pt;
     choose_tiling((long long)N * H * W, Cin, KH * KW * Cout, ct, pt);
-    ConvArgs a{dy, packed_weight_t, nullptr, nullptr, nullptr, dx, ConvGeom{N, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, KH - 1 - pad, stride},
+    ConvArgs a{dy, packed_weight_t, nullptr, nullptr, add, dx, ConvGeom{N, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, KH - 1 - pad, stride},
                0, static_cast<hipStream_t>(stream)};
+    a.mask = relu_out;
     if (workspace) {
         if (reinterpret_cast<uintptr_t>(workspace) & 15) return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
         a.nz = choose_ksplit((long long)N * H * W, Cin, Cout, KH, KW, ct, pt);
         a.ksum = a.nz > 1 ? static_cast<float *>(workspace) : nullptr;
     }
+    a.ring = choose_ring((long long)N * H * W, Cin, Cout, KH, KW, ct, pt);
     return Cout % 64 == 0 ? launch_ct<2>(a, ct, pt) : launch_ct<1>(a, ct, pt);
 }
 

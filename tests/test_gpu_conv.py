@@ -80,6 +80,84 @@ def test_every_tile_shape_gives_the_same_result(co_tiles, pixel_tiles):
     assert float(((got - ref).abs() / (ref.abs() + 1.0)).max()) < 2 ** -7
 
 
+RING_CASES = [  # N, H, W, Cin, Cout, k, stride, pad: C_in % 64 == 0 (the ring kernel's domain)
+    (2, 13, 17, 64, 64, 1, 1, 0),        # one iteration: fewer than the ring's slots
+    (2, 13, 17, 128, 32, 1, 1, 0),       # two row tiles
+    (2, 13, 17, 64, 64, 3, 1, 1),
+    (2, 9, 11, 128, 512, 1, 1, 0),
+    (2, 15, 14, 256, 128, 3, 2, 1),
+    (1, 7, 9, 512, 256, 1, 2, 0),
+    (1, 50, 84, 1024, 256, 1, 1, 0),
+    (1, 13, 21, 512, 512, 3, 1, 1),
+    (1, 5, 7, 2048, 512, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", RING_CASES, ids=[str(c) for c in RING_CASES])
+@pytest.mark.parametrize("slots", [3, 4, 6])
+def test_ring_kernel_is_bit_identical_to_the_register_staged_kernel(case, slots):
+    """conv_ring_kernel (both operands prefetched through LDS rings by LDS DMA) takes the products in conv_fwd_kernel's order: the same bits"""
+    from richsem_amd.conv import ConvAffine, set_ring, set_tiling, to_nhwc_bf16
+    N, H, W, Cin, Cout, k, stride, pad = case
+    torch.manual_seed(hash(case) % 1000)
+    x = to_nhwc_bf16(torch.randn(N, Cin, H, W).cuda())
+    w = (torch.randn(Cout, Cin, k, k) * (Cin * k * k) ** -0.5).cuda()
+    conv = ConvAffine(w, (1 + 0.3 * torch.randn(Cout)).cuda(), torch.randn(Cout).cuda(), stride, pad, relu=True)
+    Ho, Wo = conv.out_hw(H, W)
+    res = torch.randn(N, Ho, Wo, Cout, device="cuda").to(torch.bfloat16)
+    for ct, pt in ((0, 0), (2, 1), (4, 2), (8, 1), (16, 2)):
+        if ct and (Cout // 16) % ct:
+            continue
+        try:
+            set_tiling(ct, pt)
+            set_ring(-1)
+            want = conv(x, res)
+            set_ring(slots)
+            got = conv(x, res)
+        finally:
+            set_ring(0)
+            set_tiling(0, 0)
+        if ct:
+            assert torch.equal(got, want), (ct, pt, float((got.float() - want.float()).abs().max()))
+        else:      # (the automatic choice may split k over workgroups that add their sums with atomics: the order of that sum is not fixed)
+            assert float(((got.float() - want.float()).abs() / (want.float().abs() + 1.0)).max()) < 2 ** -7
+
+
+@pytest.mark.parametrize("case", [(2, 15, 14, 256, 128, 3, 2, 1), (2, 13, 17, 64, 64, 3, 1, 1), (1, 7, 9, 512, 256, 1, 2, 0), (2, 9, 11, 128, 512, 1, 1, 0),
+                                  (1, 13, 21, 512, 512, 3, 1, 1)], ids=str)
+@pytest.mark.parametrize("slots", [-1, 4])
+def test_fused_input_gradient_epilogue(case, slots):
+    """msda_conv_dgrad_fused_bf16: dx = mask(dgrad(dz) + add) against the unfused call followed by the two PyTorch ops"""
+    from richsem_amd.conv import _pack_form, conv_dgrad, set_ring
+    N, H, W, Cin, Cout, k, stride, pad = case
+    torch.manual_seed(3)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    w = (torch.randn(Cout, Cin, k, k) * (Cout * k * k) ** -0.5).cuda()
+    packed_t = _pack_form(w, torch.ones(Cout, device="cuda"), True)
+    dz = torch.randn(N, Ho, Wo, Cout, device="cuda").to(torch.bfloat16)
+    add = torch.randn(N, H, W, Cin, device="cuda").to(torch.bfloat16)
+    act = torch.relu(torch.randn(N, H, W, Cin, device="cuda")).to(torch.bfloat16)        # a ReLU's output: about half zeros
+    act.view(-1)[:7] = torch.tensor([0.0, -0.0, 1e-30, 1.0, 0.0, 3.0, -0.0], dtype=torch.bfloat16)
+    try:
+        set_ring(slots)
+        plain = conv_dgrad(dz, packed_t, (N, H, W, Cin), Cout, k, k, stride, pad)
+        fused = conv_dgrad(dz, packed_t, (N, H, W, Cin), Cout, k, k, stride, pad, add=add, relu_out=act)
+        only_mask = conv_dgrad(dz, packed_t, (N, H, W, Cin), Cout, k, k, stride, pad, relu_out=act)
+    finally:
+        set_ring(0)
+    masked = torch.ops.aten.threshold_backward(plain, act, 0)
+    if Cin * k * k < 4096:
+        assert torch.equal(only_mask, masked)
+    else:      # (a long k loop on few pixels is split over workgroups that add their sums with atomics: the order of that sum is not fixed)
+        assert float(((only_mask.float() - masked.float()).abs() / (masked.float().abs() + 1e-2)).max()) < 2 ** -7
+        assert bool((only_mask[act <= 0] == 0).all())
+    # the fused sum is rounded once (fp32 accumulator + add), the two-op form twice: one bf16 ulp apart at most
+    want = torch.ops.aten.threshold_backward((plain.float() + add.float()), act.float(), 0)
+    err = (fused.float() - want).abs()
+    assert float((err / (plain.float().abs() + add.float().abs() + 1e-2)).max()) < 2 ** -7
+    assert bool((fused[act <= 0] == 0).all())
+
+
 def test_errors():
     from richsem_amd.conv import ConvAffine
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):

@@ -68,13 +68,51 @@ def sweep(args):
         print(f"{name:18s} auto {auto:7.1f} us | " + "  ".join(f"({ct:2d},{pt}) {t:6.1f}" for t, ct, pt in res[:6]), flush=True)
 
 
+def ring_sweep(args):
+    """conv_ring_kernel (operands prefetched through LDS rings) against conv_fwd_kernel per shape: ring slots x tile shapes"""
+    from richsem_amd.conv import set_ring, set_tiling
+    torch.manual_seed(0)
+    N = 2
+    tot = {}
+    for name, H, W, Cin, Cout, k, stride, pad in SHAPES:
+        if Cin % 64:
+            continue
+        x = torch.randn(N, H, W, Cin, device="cuda").to(torch.bfloat16)
+        w = torch.randn(Cout, Cin, k, k, device="cuda") * (Cin * k * k) ** -0.5
+        conv = ConvAffine(w, None, None, stride, pad, relu=True)
+        set_tiling(0, 0)
+        set_ring(-1)
+        auto = timeit(lambda: conv(x), args.reps)
+        line = []
+        for slots in (-1, 3, 4, 6):
+            res = []
+            for ct in (16, 8, 4, 2):
+                if (Cout // 16) % ct or (ct < 4 and (Cout // 16) % 4 == 0):
+                    continue
+                for pt in (2, 1):
+                    set_tiling(ct, pt)
+                    set_ring(slots)
+                    res.append((timeit(lambda: conv(x), args.reps), ct, pt))
+            res.sort()
+            tot[slots] = tot.get(slots, 0.0) + res[0][0]
+            line.append(f"ring {slots:2d}: " + " ".join(f"({ct:2d},{pt}) {t:5.1f}" for t, ct, pt in res[:3]))
+        set_tiling(0, 0)
+        set_ring(0)
+        tot["auto"] = tot.get("auto", 0.0) + auto
+        print(f"{name:18s} auto {auto:6.1f} us | " + " | ".join(line), flush=True)
+    print("sums of the best per shape:", {k: round(v, 1) for k, v in tot.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--ring", action="store_true", help="conv_ring_kernel against conv_fwd_kernel: ring slots x tile shapes per convolution")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--sweep", action="store_true", help="time every tile shape per convolution (msda_conv_set_tiling)")
     args = ap.parse_args()
     if args.sweep:
         return sweep(args)
+    if args.ring:
+        return ring_sweep(args)
     torch.manual_seed(0)
     N = 2
     print(f"{'shape':18s} {'GFLOP':>7s} {'mfma us':>8s} {'TFLOP/s':>8s} {'of peak':>8s} {'MIOpen bf16 us':>15s} {'(+bn+relu)':>11s}")
