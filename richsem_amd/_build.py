@@ -17,7 +17,8 @@ def _headers():
     forgotten by the staleness check)"""
     import glob
     return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(_PKG, "..", "include", "*.h")))
-HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function"]
+HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function"] + \
+    os.environ.get("RICHSEM_HIPCC_EXTRA", "").split()      # (diagnostic builds: -DRPS_ROUTE_ABLATION, -DCONV_RING_ABLATE=...)
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 
 

@@ -97,7 +97,7 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, uint16_t *__restri
 // (tile u of the group, register i): affine, residual, relu (or the mask of an input gradient taken THROUGH a ReLU: zero where the
 // forward's activation `mask` was not positive), one 8 G-byte store
 template <int CO_TILES, int PT>
-__device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[PT][CO_TILES], long long pix0, int c, int q, int co0, long long P, int Cout,
+__device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[PT][CO_TILES], const long long (&pout)[PT], int q, int co0, int Cout,
                                               const float *__restrict__ scale, const float *__restrict__ shift,
                                               const uint16_t *__restrict__ residual, int relu, const uint16_t *__restrict__ mask,
                                               uint16_t *__restrict__ out)
@@ -105,8 +105,8 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[PT][CO_TILES], long l
     constexpr int G = CO_TILES >= 4 ? 4 : CO_TILES;
 #pragma unroll
     for (int t3 = 0; t3 < PT; ++t3) {
-        const long long p = pix0 + 16 * t3 + c;
-        if (p >= P) continue;
+        const long long p = pout[t3];      // the lane's output pixel of column tile t3 (-1: none)
+        if (p < 0) continue;
 #pragma unroll
         for (int grp = 0; grp < CO_TILES / G; ++grp) {
             const int co = co0 + 16 * G * grp + 4 * G * q;
@@ -335,7 +335,10 @@ void conv_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
         return;
     }
 
-    conv_epilogue<CO_TILES, PT>(acc, pix0, c, q, co0, P, g.Cout, scale, shift, residual, relu, mask, out);
+    long long pout[PT];
+#pragma unroll
+    for (int t3 = 0; t3 < PT; ++t3) pout[t3] = pix0 + 16 * t3 + c < P ? pix0 + 16 * t3 + c : -1;
+    conv_epilogue<CO_TILES, PT>(acc, pout, q, co0, g.Cout, scale, shift, residual, relu, mask, out);
 }
 
 // ---- the same convolution with BOTH operands prefetched several iterations ahead through LDS rings (round 4) -------------------------
@@ -393,12 +396,14 @@ __device__ __forceinline__ void ring_products(f32x4 (&acc)[PT][CO_TILES], u32x4 
 template <int CO_TILES, int PT>
 struct RingRequest {
     static constexpr int KT = 2, WFR = KT * CO_TILES, WPW = WFR / kWaves, AFR = KT * PT;
-    const unsigned char *wsrc[WPW];      // this wave's weight fragments of the iteration (the lane's 16 bytes of each)
+    const unsigned char *wtap[WPW];      // this wave's weight fragments of tap (0, 0), channel block 0 (the lane's 16 bytes of each)
+    const unsigned char *wsrc[WPW];      // ... of the iteration that is requested next
     const uint16_t *asrc[PT];            // the lane's pixel row at the iteration's tap (+ 16 q channels), or null outside the image
-    size_t step_bytes;
+    size_t step_bytes;                   // one k-step of the packed weight
     int it, cb, kh, kw;
+    int kh0, kw0, kstep;                 // the taps walked: kh0, kh0 + kstep, .. x kw0, kw0 + kstep, ..  (all of them: 0, 0, 1)
 
-    __device__ __forceinline__ void tap_sources(const uint16_t *x, const ConvGeom &g, const long long (&img)[PT], const int (&hi0)[PT],
+    __device__ __forceinline__ void tap_sources(const uint16_t *x, const ConvGeom &g, int cpb, const long long (&img)[PT], const int (&hi0)[PT],
                                                 const int (&wi0)[PT], int q)
     {
 #pragma unroll
@@ -413,6 +418,8 @@ struct RingRequest {
             in = in && hi < g.H && wi < g.W;
             asrc[t3] = in ? x + (img[t3] + (long long)hi * g.W + wi) * g.Cin + 16 * q : nullptr;
         }
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) wsrc[i] = wtap[i] + (size_t)(kh * g.KW + kw) * cpb * KT * step_bytes;
     }
 
     template <int R>
@@ -421,13 +428,16 @@ struct RingRequest {
                                             const uint16_t *zero)
     {
         unsigned char *wdst = wring + (slot * WFR + wave * WPW) * 1024;
+#ifndef CONV_RING_ABLATE      // diagnostic builds (wrong results): 1 = no weight requests, 2 = no activation requests, 3 = neither
+#define CONV_RING_ABLATE 0
+#endif
 #pragma unroll
-        for (int i = 0; i < WPW; ++i)
+        for (int i = 0; i < ((CONV_RING_ABLATE & 1) ? 0 : WPW); ++i)
             __builtin_amdgcn_global_load_lds(wsrc[i], reinterpret_cast<__attribute__((address_space(3))) void *>(reinterpret_cast<uintptr_t>(wdst + i * 1024)),
                                              16, 0, 0);
         unsigned char *adst = aring + ((wave * R + slot) * AFR) * 1024;
 #pragma unroll
-        for (int h = 0; h < KT; ++h)
+        for (int h = 0; h < ((CONV_RING_ABLATE & 2) ? 0 : KT); ++h)
 #pragma unroll
             for (int t3 = 0; t3 < PT; ++t3)
                 __builtin_amdgcn_global_load_lds(asrc[t3] ? asrc[t3] + 64 * cb + 8 * h : zero,
@@ -435,12 +445,14 @@ struct RingRequest {
                                                  16, 0, 0);
         if (it + 1 < S) {      // (uniform) the next one; past the end the last one is repeated into a free slot
             ++it;
-#pragma unroll
-            for (int i = 0; i < WPW; ++i) wsrc[i] += KT * step_bytes;
             if (++cb == cpb) {
                 cb = 0;
-                if (++kw == g.KW) { kw = 0; ++kh; }
-                tap_sources(x, g, img, hi0, wi0, q);
+                kw += kstep;
+                if (kw >= g.KW) { kw = kw0; kh += kstep; }
+                tap_sources(x, g, cpb, img, hi0, wi0, q);
+            } else {
+#pragma unroll
+                for (int i = 0; i < WPW; ++i) wsrc[i] += KT * step_bytes;
             }
         }
     }
@@ -463,24 +475,37 @@ void conv_ring_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, q = lane >> 4;
-    const long long P = (long long)g.N * g.Ho * g.Wo;
+    // A zero-upsampled input (g.up > 1: the gradient of a strided convolution) is taken by PARITY CLASS: output pixels with
+    // (ho % up, wo % up) = (ph, pw) = blockIdx.z see data only under the taps kh = kh0, kh0 + up, .. (kh0 = (pad - ph) mod up), kw likewise
+    // -- 1, 2, 2 and 4 of a 3 x 3 kernel's 9 taps at up = 2, none for three of a 1 x 1 kernel's four classes (zeros, + add, masked).  A
+    // class is a convolution of its own over its pixels; walking all taps with three quarters of the lanes on the zero line cost 4 x the
+    // products (conv_fwd_kernel still does that for the shapes this kernel does not take).
+    const int up = g.up, ph = (int)blockIdx.z / up, pw = (int)blockIdx.z % up;
+    const int Hc = (g.Ho - ph + up - 1) / up, Wc = (g.Wo - pw + up - 1) / up;      // the class's pixels: ho = ph + up hc, wo = pw + up wc
+    const long long P = (long long)g.N * Hc * Wc;
     const long long pix0 = (long long)blockIdx.x * (kWaves * 16 * PT) + wave * (16 * PT);
+    if ((long long)blockIdx.x * (kWaves * 16 * PT) >= P) return;      // (whole workgroup; the grid is sized for class (0, 0), the largest)
     const int cpb = g.Cin / 64;                   // iterations per tap
-    const int S = g.KH * g.KW * cpb;
+    const int kh0 = ((g.pad - ph) % up + up) % up, kw0 = ((g.pad - pw) % up + up) % up;
+    const int nkh = kh0 < g.KH ? (g.KH - kh0 + up - 1) / up : 0, nkw = kw0 < g.KW ? (g.KW - kw0 + up - 1) / up : 0;
+    const int S = nkh * nkw * cpb;
     const int tiles_all = g.Cout / 16;
     const int co0 = blockIdx.y * (16 * CO_TILES);
     const uint16_t *zero = reinterpret_cast<const uint16_t *>(g_conv_zero_line);
 
-    long long img[PT];
+    long long img[PT], pout[PT];
     int hi0[PT], wi0[PT];
 #pragma unroll
     for (int t3 = 0; t3 < PT; ++t3) {
         long long p = pix0 + 16 * t3 + c;
-        if (p > P - 1) p = P - 1;
-        const int wo = (int)(p % g.Wo), ho = (int)((p / g.Wo) % g.Ho);
-        img[t3] = (p / ((long long)g.Wo * g.Ho)) * g.H * g.W;
+        const bool valid = p < P;
+        if (!valid) p = P - 1;
+        const int wo = (int)(p % Wc) * up + pw, ho = (int)((p / Wc) % Hc) * up + ph;
+        const long long n = p / ((long long)Wc * Hc);
+        img[t3] = n * g.H * g.W;
         hi0[t3] = ho * g.stride - g.pad;
         wi0[t3] = wo * g.stride - g.pad;
+        pout[t3] = valid ? (n * g.Ho + ho) * g.Wo + wo : -1;
     }
 
     f32x4 acc[PT][CO_TILES];
@@ -491,21 +516,26 @@ void conv_ring_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict
 
     // request side: the iteration that is asked for next -- its tap, its channel block, this lane's sources
     RingRequest<CO_TILES, PT> rq;
-    rq.step_bytes = (size_t)tiles_all * 1024;                                            // one k-step of the packed weight
+    rq.step_bytes = (size_t)tiles_all * 1024;
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
         const int f = wave * WPW + i, h = f / CO_TILES, t = f % CO_TILES;
-        rq.wsrc[i] = reinterpret_cast<const unsigned char *>(wpk) + ((size_t)blockIdx.y * CO_TILES + t) * 1024 + h * rq.step_bytes + lane * 16;
+        rq.wtap[i] = reinterpret_cast<const unsigned char *>(wpk) + ((size_t)blockIdx.y * CO_TILES + t) * 1024 + h * rq.step_bytes + lane * 16;
     }
-    rq.it = rq.cb = rq.kh = rq.kw = 0;
-    rq.tap_sources(x, g, img, hi0, wi0, q);
+    rq.it = rq.cb = 0;
+    rq.kh = rq.kh0 = kh0;
+    rq.kw = rq.kw0 = kw0;
+    rq.kstep = up;
+    if (S > 0) {      // (uniform; a class without taps: zeros through the epilogue)
+        rq.tap_sources(x, g, cpb, img, hi0, wi0, q);
 #pragma unroll
-    for (int r = 0; r < R - 1; ++r) rq.template request<R>(r, wave, S, cpb, x, g, img, hi0, wi0, q, wring, aring, zero);
+        for (int r = 0; r < R - 1; ++r) rq.template request<R>(r, wave, S, cpb, x, g, img, hi0, wi0, q, wring, aring, zero);
+    }
 
     const unsigned wbase = (unsigned)(uintptr_t)wring + lane * 16, abase = (unsigned)(uintptr_t)aring + (wave * R * AFR) * 1024 + lane * 16;
     int slot = 0;
     for (int s = 0; s < S; ++s) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * NPI) : "memory");      // iteration s has landed (this wave's requests)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CONV_RING_ABLATE ? 0 : (R - 2) * NPI) : "memory");      // iteration s has landed (this wave's requests)
         __builtin_amdgcn_s_barrier();                                              // ... everybody's; and slot (s - 1) % R is free
         rq.template request<R>(slot == 0 ? R - 1 : slot - 1, wave, S, cpb, x, g, img, hi0, wi0, q, wring, aring, zero);
         const unsigned wa = wbase + slot * (WFR * 1024), ba = abase + slot * (AFR * 1024);
@@ -516,7 +546,7 @@ void conv_ring_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict
         slot = slot + 1 == R ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the repeated requests of the last iterations)
-    conv_epilogue<CO_TILES, PT>(acc, pix0, c, q, co0, P, g.Cout, scale, shift, residual, relu, mask, out);
+    conv_epilogue<CO_TILES, PT>(acc, pout, q, co0, g.Cout, scale, shift, residual, relu, mask, out);
 }
 
 
@@ -799,6 +829,9 @@ int launch_conv(const ConvArgs &a)
     const dim3 grid((unsigned)((P + kWaves * 16 * PT - 1) / (kWaves * 16 * PT)), (unsigned)(a.g.Cout / (16 * CO_TILES)), split ? a.nz : 1);
     if constexpr (MODE == 2 && PT <= 2 && CO_TILES >= 2) {
         if (!split && a.ring > 0) {
+            const int up = a.g.up;
+            const long long Pc = (long long)a.g.N * ((a.g.Ho + up - 1) / up) * ((a.g.Wo + up - 1) / up);      // class (0, 0)'s pixels
+            const dim3 grid((unsigned)((Pc + kWaves * 16 * PT - 1) / (kWaves * 16 * PT)), (unsigned)(a.g.Cout / (16 * CO_TILES)), (unsigned)(up * up));
             int ring = a.ring;
             while (ring > 3 && ring * (2 * CO_TILES + kWaves * 2 * PT) > 160) ring = ring > 4 ? 4 : 3;      // (what fits the CU's 160 KB)
             switch (ring) {
@@ -879,13 +912,25 @@ int choose_ksplit(long long P, int Cout, int Cin, int KH, int KW, int ct, int pt
     return nz < 2 ? 1 : (int)nz;
 }
 
-// ring slots for a problem at the chosen tiling (0: conv_fwd_kernel).  Measured (tools/time_conv.py --ring, MI355X): see DESIGN.md section 10.
-int choose_ring(long long P, int Cout, int Cin, int KH, int KW, int ct, int pt)
+// Operand rings for a problem (0: conv_fwd_kernel), and the tile that goes with them.  Measured per shape (tools/time_conv.py --ring,
+// MI355X, 2 x 800 x 1344): the ring wins where a SIMD gets one or two waves and the k loop is long -- layer3's / layer4's 3 x 3 and
+// channel-reducing 1 x 1 convolutions (26.6 against 34.4, 15.7 / 18.6, 32.6 / 54.0, 16.7 / 31.8 us) and every strided input gradient
+// (three quarters of whose lanes fetch the zero line) -- and loses where thousands of workgroups hide the latency by themselves (layer1,
+// layer2) or the loop is 4-8 iterations (256 -> 1024, 512 -> 2048).  Three slots: deeper rings cost occupancy and gain nothing.
+int choose_ring(long long P, int Cout, int Cin, int KH, int KW, int up, bool forced_tile, int &ct, int &pt)
 {
     const int r = g_ring.load();
-    if (r < 0 || Cin % 64 != 0 || ct < 2 || pt > 2) return 0;
-    if (r > 0) return r;
-    return 0;
+    if (r < 0 || Cin % 64 != 0) return 0;
+    const int tiles = Cout / 16;
+    if (r == 0) {
+        if ((long long)KH * KW * Cin < 1024 || (P > 16384 && up == 1)) return 0;
+        if (!forced_tile) {
+            ct = tiles % 8 == 0 ? 8 : (tiles % 4 == 0 ? 4 : conv_group(Cout));
+            pt = (P >= 4096 && up == 1) ? 2 : 1;
+        }
+    }
+    if (ct < 2 || pt > 2) return 0;
+    return r > 0 ? r : 3;
 }
 
 }  // namespace
@@ -987,7 +1032,7 @@ int msda_conv_forward_ws_bf16(const uint16_t *x, const uint16_t *packed_weight, 
         a.nz = choose_ksplit((long long)N * Ho * Wo, Cout, Cin, KH, KW, ct, pt);
         a.ksum = a.nz > 1 ? static_cast<float *>(workspace) : nullptr;
     }
-    a.ring = choose_ring((long long)N * Ho * Wo, Cout, Cin, KH, KW, ct, pt);
+    if (!a.ksum) a.ring = choose_ring((long long)N * Ho * Wo, Cout, Cin, KH, KW, 1, fct || fpt, ct, pt);      // (a k split where the grid is tiny)
     if (small_c) return launch_ct<0>(a, ct, pt);
     return Cin % 64 == 0 ? launch_ct<2>(a, ct, pt) : launch_ct<1>(a, ct, pt);
 }
@@ -1117,6 +1162,9 @@ int msda_conv_dgrad_fused_bf16(const uint16_t *dy, const uint16_t *packed_weight
     if (KH - 1 - pad != KW - 1 - pad) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);      // one padding value in the kernel's geometry: square kernels
     int ct, pt;
     choose_tiling((long long)N * H * W, Cin, KH * KW * Cout, ct, pt);
+    const int fct = g_force_ct.load(), fpt = g_force_pt.load();
+    if (fct && (Cin / 16) % fct == 0 && fct % conv_group(Cin) == 0) ct = fct;
+    if (fpt) pt = fpt;
     ConvArgs a{dy, packed_weight_t, nullptr, nullptr, add, dx, ConvGeom{N, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, KH - 1 - pad, stride},
                0, static_cast<hipStream_t>(stream)};
     a.mask = relu_out;
@@ -1125,7 +1173,7 @@ int msda_conv_dgrad_fused_bf16(const uint16_t *dy, const uint16_t *packed_weight
         a.nz = choose_ksplit((long long)N * H * W, Cin, Cout, KH, KW, ct, pt);
         a.ksum = a.nz > 1 ? static_cast<float *>(workspace) : nullptr;
     }
-    a.ring = choose_ring((long long)N * H * W, Cin, Cout, KH, KW, ct, pt);
+    if (!a.ksum) a.ring = choose_ring((long long)N * H * W, Cin, Cout, KH, KW, stride, fct || fpt, ct, pt);
     return Cout % 64 == 0 ? launch_ct<2>(a, ct, pt) : launch_ct<1>(a, ct, pt);
 }
 

@@ -124,7 +124,8 @@ def test_ring_kernel_is_bit_identical_to_the_register_staged_kernel(case, slots)
 
 
 @pytest.mark.parametrize("case", [(2, 15, 14, 256, 128, 3, 2, 1), (2, 13, 17, 64, 64, 3, 1, 1), (1, 7, 9, 512, 256, 1, 2, 0), (2, 9, 11, 128, 512, 1, 1, 0),
-                                  (1, 13, 21, 512, 512, 3, 1, 1)], ids=str)
+                                  (1, 13, 21, 512, 512, 3, 1, 1), (2, 16, 18, 128, 128, 3, 2, 1), (1, 9, 12, 64, 128, 1, 2, 0), (1, 11, 11, 64, 64, 3, 3, 1)],
+                         ids=str)
 @pytest.mark.parametrize("slots", [-1, 4])
 def test_fused_input_gradient_epilogue(case, slots):
     """msda_conv_dgrad_fused_bf16: dx = mask(dgrad(dz) + add) against the unfused call followed by the two PyTorch ops"""
@@ -146,6 +147,12 @@ def test_fused_input_gradient_epilogue(case, slots):
     finally:
         set_ring(0)
     masked = torch.ops.aten.threshold_backward(plain, act, 0)
+    if slots > 0 and Cout * k * k < 4096:      # the ring kernel takes a strided gradient by parity class (only the taps that meet data): the same sums
+        try:
+            set_ring(-1)
+            assert torch.equal(plain, conv_dgrad(dz, packed_t, (N, H, W, Cin), Cout, k, k, stride, pad))
+        finally:
+            set_ring(0)
     if Cin * k * k < 4096:
         assert torch.equal(only_mask, masked)
     else:      # (a long k loop on few pixels is split over workgroups that add their sums with atomics: the order of that sum is not fixed)

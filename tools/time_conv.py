@@ -69,30 +69,52 @@ def sweep(args):
 
 
 def ring_sweep(args):
-    """conv_ring_kernel (operands prefetched through LDS rings) against conv_fwd_kernel per shape: ring slots x tile shapes"""
-    from richsem_amd.conv import set_ring, set_tiling
+    """conv_ring_kernel (operands prefetched through LDS rings) against conv_fwd_kernel per shape: ring slots x tile shapes.  The library
+    entry is called directly on preallocated buffers (no workspace: no k split), 3 + reps launches between two events."""
+    import ctypes
+    from richsem_amd import _lib
+    from richsem_amd.conv import set_ring, set_tiling, _pack_form
+    L = _lib.load()
     torch.manual_seed(0)
     N = 2
+    st = torch.cuda.current_stream().cuda_stream
     tot = {}
-    for name, H, W, Cin, Cout, k, stride, pad in SHAPES:
-        if Cin % 64:
+    shapes = [(n, H, W, ci, co, k, s_, p_, False) for n, H, W, ci, co, k, s_, p_ in SHAPES if ci % 64 == 0]
+    shapes += [("dgrad l3 3x3 s2", 100, 168, 256, 256, 3, 2, 1, True), ("dgrad l4 3x3 s2", 50, 84, 512, 512, 3, 2, 1, True),
+               ("dgrad l3 down s2", 100, 168, 512, 1024, 1, 2, 0, True), ("dgrad l4 down s2", 50, 84, 1024, 2048, 1, 2, 0, True)]
+    only = [n.strip() for n in args.only.split(",") if n.strip()]
+    for name, H, W, Cin, Cout, k, stride, pad, dgrad in shapes:
+        if only and name not in only:
             continue
-        x = torch.randn(N, H, W, Cin, device="cuda").to(torch.bfloat16)
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         w = torch.randn(Cout, Cin, k, k, device="cuda") * (Cin * k * k) ** -0.5
-        conv = ConvAffine(w, None, None, stride, pad, relu=True)
+        one = torch.ones(Cout, device="cuda")
+        zero = torch.zeros(Cout, device="cuda")
+        packed = _pack_form(w, one, dgrad)
+        if dgrad:
+            src = torch.randn(N, Ho, Wo, Cout, device="cuda").to(torch.bfloat16)
+            dst = torch.empty(N, H, W, Cin, device="cuda", dtype=torch.bfloat16)
+            call = lambda: L.msda_conv_dgrad_ws_bf16(src.data_ptr(), packed.data_ptr(), N, Ho, Wo, Cout, Cin, k, k, stride, pad, H, W, dst.data_ptr(), None, st)
+            couts = Cin
+        else:
+            src = torch.randn(N, H, W, Cin, device="cuda").to(torch.bfloat16)
+            dst = torch.empty(N, Ho, Wo, Cout, device="cuda", dtype=torch.bfloat16)
+            call = lambda: L.msda_conv_forward_ws_bf16(src.data_ptr(), packed.data_ptr(), one.data_ptr(), zero.data_ptr(), None, N, H, W, Cin, Cout, k, k,
+                                                        stride, pad, 1, dst.data_ptr(), None, st)
+            couts = Cout
         set_tiling(0, 0)
         set_ring(-1)
-        auto = timeit(lambda: conv(x), args.reps)
+        auto = timeit(call, args.reps)
         line = []
         for slots in (-1, 3, 4, 6):
             res = []
             for ct in (16, 8, 4, 2):
-                if (Cout // 16) % ct or (ct < 4 and (Cout // 16) % 4 == 0):
+                if (couts // 16) % ct or (ct < 4 and (couts // 16) % 4 == 0):
                     continue
                 for pt in (2, 1):
                     set_tiling(ct, pt)
                     set_ring(slots)
-                    res.append((timeit(lambda: conv(x), args.reps), ct, pt))
+                    res.append((timeit(call, args.reps), ct, pt))
             res.sort()
             tot[slots] = tot.get(slots, 0.0) + res[0][0]
             line.append(f"ring {slots:2d}: " + " ".join(f"({ct:2d},{pt}) {t:5.1f}" for t, ct, pt in res[:3]))
@@ -105,6 +127,7 @@ def ring_sweep(args):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="with --ring: comma-separated shape names")
     ap.add_argument("--ring", action="store_true", help="conv_ring_kernel against conv_fwd_kernel: ring slots x tile shapes per convolution")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--sweep", action="store_true", help="time every tile shape per convolution (msda_conv_set_tiling)")
