@@ -115,7 +115,7 @@ class InputProj:
 # ---- trainable form (forward + backward on the library's kernels) -----------------------------------------------------------------
 from torch import nn                                         # noqa: E402
 
-from .conv import ConvAffineFunction, GroupNorm8Function, PackCache              # noqa: E402
+from .conv import ConvAffineFunction, GroupNorm8Function, PackCache, conv_dgrad, conv_forward, conv_wgrad              # noqa: E402
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -158,8 +158,63 @@ def _conv_bn_act(x, conv, bn, relu, residual=None):
     return ConvAffineFunction.apply(x, conv.weight, scale, shift, residual, conv.stride, conv.padding, relu, conv.pack_cache)
 
 
+class BottleneckFunction(torch.autograd.Function):
+    """One bottleneck block (torchvision's Bottleneck.forward with the frozen norms folded: conv1 -> relu -> conv2 -> relu -> conv3 (+ identity
+    or downsample(x)) -> relu) as ONE autograd node, so that the element-wise work of its backward runs in the convolutions' epilogues
+    (``msda_conv_dgrad_fused_bf16``): the ReLU masks of conv1 / conv2 are applied by the input gradient that produces their gradient, the
+    two branches' gradients of x are summed by conv1's input gradient.  Per block that removes three ``threshold_backward`` passes and one or
+    two adds over the block's largest tensors.  ``mask_input``: x is itself the output of a ReLU whose node does NOT mask (the previous
+    block, told so by ``masked_by_consumer``): dx comes back as the gradient at that ReLU's input."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3, wd, blk, mask_input, masked_by_consumer):
+        c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
+        (s1, b1), (s2, b2), (s3, b3) = blk.bn1.scale_shift(), blk.bn2.scale_shift(), blk.bn3.scale_shift()
+        x = x.contiguous()
+        planes = w1.shape[0]
+        o1 = conv_forward(x, c1.pack_cache.get(w1, s1, False), s1, b1, None, planes, 1, 1, 1, 0, True)
+        o2 = conv_forward(o1, c2.pack_cache.get(w2, s2, False), s2, b2, None, planes, 3, 3, c2.stride, 1, True)
+        if wd is not None:
+            cd = blk.downsample[0]
+            sd_, bd_ = blk.downsample[1].scale_shift()
+            idt = conv_forward(x, cd.pack_cache.get(wd, sd_, False), sd_, bd_, None, 4 * planes, 1, 1, cd.stride, 0, False)
+        else:
+            idt, sd_ = x, None
+        y = conv_forward(o2, c3.pack_cache.get(w3, s3, False), s3, b3, idt, 4 * planes, 1, 1, 1, 0, True)
+        ctx.save_for_backward(x, o1, o2, y, w1, w2, w3, wd, s1, s2, s3, sd_)
+        ctx.cfg = (blk, mask_input, masked_by_consumer)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, o1, o2, y, w1, w2, w3, wd, s1, s2, s3, sd_ = ctx.saved_tensors
+        blk, mask_input, masked_by_consumer = ctx.cfg
+        c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
+        planes = w1.shape[0]
+        # gradient at the last ReLU's input (= the identity branch's gradient): masked by this node unless every consumer of y did it
+        dz3 = dy.contiguous() if masked_by_consumer else torch.ops.aten.threshold_backward(dy.contiguous(), y, 0)
+        need = ctx.needs_input_grad
+        dz2 = conv_dgrad(dz3, c3.pack_cache.get(w3, s3, True), o2.shape, 4 * planes, 1, 1, 1, 0, relu_out=o2)
+        dw3 = conv_wgrad(dz3, o2, 4 * planes, 1, 1, 1, 0, s3) if need[3] else None
+        dz1 = conv_dgrad(dz2, c2.pack_cache.get(w2, s2, True), o1.shape, planes, 3, 3, c2.stride, 1, relu_out=o1)
+        dw2 = conv_wgrad(dz2, o1, planes, 3, 3, c2.stride, 1, s2) if need[2] else None
+        dx = dwd = None
+        if wd is not None:
+            cd = blk.downsample[0]
+            dwd = conv_wgrad(dz3, x, 4 * planes, 1, 1, cd.stride, 0, sd_) if need[4] else None
+            if need[0]:
+                dxd = conv_dgrad(dz3, cd.pack_cache.get(wd, sd_, True), x.shape, 4 * planes, 1, 1, cd.stride, 0)
+                dx = conv_dgrad(dz1, c1.pack_cache.get(w1, s1, True), x.shape, planes, 1, 1, 1, 0, add=dxd, relu_out=x if mask_input else None)
+        elif need[0]:
+            dx = conv_dgrad(dz1, c1.pack_cache.get(w1, s1, True), x.shape, planes, 1, 1, 1, 0, add=dz3, relu_out=x if mask_input else None)
+        dw1 = conv_wgrad(dz1, x, planes, 1, 1, 1, 0, s1) if need[1] else None
+        return dx, dw1, dw2, dw3, dwd, None, None, None
+
+
 class Bottleneck(nn.Module):
     expansion = 4
+    fused = True          # forward + backward as one autograd node (BottleneckFunction) where the channel counts allow it
 
     def __init__(self, inplanes, planes, stride=1, downsample=False):
         super().__init__()
@@ -168,7 +223,14 @@ class Bottleneck(nn.Module):
         self.conv3, self.bn3 = _ConvWeight(planes, planes * 4, 1), FrozenBatchNorm2d(planes * 4)
         self.downsample = nn.Sequential(_ConvWeight(inplanes, planes * 4, 1, stride), FrozenBatchNorm2d(planes * 4)) if downsample else None
 
-    def forward(self, x):
+    def forward(self, x, mask_input=False, masked_by_consumer=False):
+        """``mask_input`` / ``masked_by_consumer``: see BottleneckFunction (set by ResNet50.forward for blocks inside a stage; both False is
+        always correct)"""
+        planes, inplanes = self.conv1.weight.shape[:2]
+        if Bottleneck.fused and torch.is_grad_enabled() and self.conv3.weight.requires_grad and planes % 128 == 0 and inplanes % 128 == 0:
+            return BottleneckFunction.apply(x, self.conv1.weight, self.conv2.weight, self.conv3.weight,
+                                            self.downsample[0].weight if self.downsample is not None else None, self, mask_input,
+                                            masked_by_consumer)
         identity = x if self.downsample is None else _conv_bn_act(x, self.downsample[0], self.downsample[1], False)
         out = _conv_bn_act(x, self.conv1, self.bn1, True)
         out = _conv_bn_act(out, self.conv2, self.bn2, True)
@@ -203,9 +265,20 @@ class ResNet50(nn.Module):
             x = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
         else:                    # the default: stem and layer1 frozen (backbone.py:65-67), no gradient flows through the pool
             x = max_pool_nhwc(x, 3, 2, 1)
-        outs = []
+        outs, prev_fused = [], False
         for li in range(1, 5):
-            x = getattr(self, f"layer{li}")(x)
+            blocks = getattr(self, f"layer{li}")
+            for b, blk in enumerate(blocks):
+                # inside a stage a block's output feeds the next block alone: that block's node masks the gradient it returns with this
+                # block's ReLU (in conv1's input-gradient epilogue), and this block's node then skips its own mask pass.  Both blocks must
+                # run as BottleneckFunction nodes for the pair of flags to be set.
+                fused_here = Bottleneck.fused and torch.is_grad_enabled() and blk.conv3.weight.requires_grad and blk.conv1.weight.shape[0] % 128 == 0 \
+                    and blk.conv1.weight.shape[1] % 128 == 0
+                nxt = blocks[b + 1] if b + 1 < len(blocks) else None
+                fused_next = nxt is not None and Bottleneck.fused and torch.is_grad_enabled() and nxt.conv3.weight.requires_grad \
+                    and nxt.conv1.weight.shape[0] % 128 == 0 and nxt.conv1.weight.shape[1] % 128 == 0
+                x = blk(x, mask_input=b > 0 and fused_here and prev_fused, masked_by_consumer=fused_here and fused_next)
+                prev_fused = fused_here
             if li in self.return_layers:
                 outs.append(x)
         return outs

@@ -116,6 +116,37 @@ def conv_dgrad(dz, packed_t, x_shape, Cout, KH, KW, stride, padding, add=None, r
     return dx
 
 
+def conv_forward(x, packed, scale, shift, residual, Cout, KH, KW, stride, padding, relu):
+    """``msda_conv_forward_ws_bf16`` on an NHWC bf16 tensor with an already packed weight -> (N, Ho, Wo, Cout) bf16"""
+    N, H, W, Cin = x.shape
+    Ho, Wo = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
+    out = torch.empty((N, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        L = _lib.load()
+        ws = _ksplit_workspace(L.msda_conv_forward_workspace_bytes, (N, H, W, Cin, Cout, KH, KW, stride, padding), x.device)
+        _lib.check(L.msda_conv_forward_ws_bf16(
+            x.data_ptr(), packed.data_ptr(), scale.data_ptr(), shift.data_ptr(), residual.data_ptr() if residual is not None else None,
+            N, H, W, Cin, Cout, KH, KW, stride, padding, int(relu), out.data_ptr(), ws.data_ptr() if ws is not None else None,
+            _stream(x.device)))
+    return out
+
+
+def conv_wgrad(dz, x, Cout, KH, KW, stride, padding, scale=None):
+    """Weight gradient (``msda_conv_wgrad_bf16``): dz (N, Ho, Wo, Cout), x (N, H, W, Cin) bf16 NHWC -> (Cout, Cin, KH, KW) fp32 (nn.Conv2d's
+    layout), times ``scale[co]`` when given.  Cout % 128 == 0 and Cin % 128 == 0."""
+    N, H, W, Cin = x.shape
+    dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=x.device)
+    L = _lib.load()
+    nb = ctypes.c_int64(0)
+    _lib.check(L.msda_conv_wgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, padding, ctypes.byref(nb)))
+    ws = torch.empty(nb.value // 4, dtype=torch.float32, device=x.device) if nb.value else None
+    with torch.cuda.device(x.device):
+        _lib.check(L.msda_conv_wgrad_bf16(dz.data_ptr(), x.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, padding, dw.data_ptr(), None,
+                                          scale.data_ptr() if scale is not None else None, 1, ws.data_ptr() if ws is not None else None,
+                                          _stream(x.device)))
+    return dw
+
+
 def _pool(x, k, stride, pad, is_max):
     assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[3] % 8 == 0
     x = x.contiguous()

@@ -132,6 +132,39 @@ def test_trainable_resnet_names_forward_and_gradients():
     print("worst mean weight-gradient error (of the tensor's maximum):", worst)
 
 
+def test_fused_bottleneck_node_equals_the_per_convolution_nodes():
+    """BottleneckFunction (ReLU masks and the branch sum in the input gradients' epilogues, the block's own mask left to the next block's node
+    inside a stage) against the same network as one autograd node per convolution: equal outputs, gradients equal up to the roundings the
+    fusion removes (a sum rounded once instead of twice)"""
+    from richsem_amd.backbone import Bottleneck, ResNet50
+    layers = (1, 3, 2, 2)
+    sd = resnet_state_dict(layers=layers, seed=9)
+    net = ResNet50(layers=layers).cuda()
+    net.load_state_dict(sd)
+    x = torch.from_numpy(np.random.default_rng(2).normal(0, 1, (2, 3, 96, 128)).astype(np.float32)).cuda()
+    res = {}
+    for fused in (True, False):
+        Bottleneck.fused = fused
+        try:
+            for p in net.parameters():
+                p.grad = None
+            outs = net(x)
+            gs = [torch.from_numpy(np.random.default_rng(7 + i).normal(0, 1, tuple(o.shape)).astype(np.float32)).to(torch.bfloat16).cuda()
+                  for i, o in enumerate(outs)]
+            torch.autograd.backward(outs, gs)
+            res[fused] = ([o.detach().clone() for o in outs], {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+        finally:
+            Bottleneck.fused = True
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    assert sorted(res[True][1]) == sorted(res[False][1]) and len(res[True][1]) == sum(3 * n + 1 for n in layers[1:])
+    for n, g in res[True][1].items():
+        ref = res[False][1][n]
+        cos = float((g * ref).sum() / (g.norm() * ref.norm() + 1e-30))
+        rel = float((g - ref).abs().mean() / (ref.abs().mean() + 1e-30))
+        assert cos > 0.9995 and rel < 2e-2, (n, cos, rel)
+
+
 def test_trainable_input_projection_forward_and_gradients():
     """InputProjection (nn.Module, the reference's parameter names) against the inference form and fp32 autograd through the oracle's
     op sequence: convolution weight, bias and GroupNorm parameters."""
