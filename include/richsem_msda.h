@@ -411,6 +411,19 @@ int msda_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int 
 int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                          int pad, float *dw, float *dbias, const float *scale, int torch_layout, void *workspace, msda_stream_t stream);
 
+/* Several weight gradients in ONE launch of the product kernel and one of the reduction (a bottleneck block's three or four,
+ * models/richsem/backbone.py:59-92 trains layer2-4): each problem is msda_conv_wgrad_bf16's, its result in nn.Conv2d's layout
+ * (Cout, Cin, KH, KW), multiplied by scale[co] when scale is not NULL; no bias gradients.  The problems share the chip in proportion to
+ * their work instead of each being cut into ~512 short workgroups.  n <= 8. */
+typedef struct {
+    const uint16_t *dz, *x;
+    float *dw;
+    const float *scale;
+    int N, H, W, Cin, Cout, KH, KW, stride, pad;
+} msda_wgrad_problem;
+int msda_conv_wgrad_group_workspace_bytes(const msda_wgrad_problem *problems, int n, int64_t *bytes);
+int msda_conv_wgrad_group_bf16(const msda_wgrad_problem *problems, int n, void *workspace, msda_stream_t stream);
+
 /* ---- two-stage query selection: row maxima of the class logits without the logits (reference
  * models/richsem/deformable_transformer.py:368-372 with the CLIP-text classifier models/richsem/richsem.py:176-184 in its shipped
  * configuration: bias-free linear projection Wp (proj x 256), text embeddings t_c) ------------------------------------------------

@@ -18,6 +18,12 @@ ERR_NAMES = {
 
 ABI_VERSION = 7
 
+
+class WgradProblem(ctypes.Structure):
+    """``msda_wgrad_problem`` (include/richsem_msda.h): one weight gradient of a grouped launch"""
+    _fields_ = [("dz", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("scale", ctypes.c_void_p)] + \
+        [(k, ctypes.c_int) for k in ("N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad")]
+
 # every symbol include/richsem_msda.h declares
 SYMBOLS = [
     "msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option",
@@ -32,7 +38,7 @@ SYMBOLS = [
     "msda_attn_workspace_bytes", "msda_attn_forward_bf16", "msda_attn_backward_bf16",
     "msda_matcher_cost_f32", "msda_matcher_cost_f64", "msda_focal_neg_sum_f32", "msda_focal_neg_grad_f32", "msda_attnpool_core_f32", "msda_attnpool_core_f64",
     "msda_cls_packed_elems", "msda_cls_pack", "msda_cls_max_scores",
-    "msda_conv_set_tiling", "msda_conv_set_ring", "msda_conv_dgrad_fused_bf16", "msda_conv_packed_elems", "msda_conv_pack_weight", "msda_conv_forward_bf16", "msda_conv_dgrad_bf16", "msda_conv_forward_workspace_bytes", "msda_conv_forward_ws_bf16", "msda_conv_dgrad_workspace_bytes", "msda_conv_dgrad_ws_bf16", "msda_pool_nhwc_bf16", "msda_groupnorm8_nhwc_bf16", "msda_groupnorm8_backward_nhwc_bf16", "msda_conv_wgrad_workspace_bytes", "msda_conv_wgrad_bf16",
+    "msda_conv_set_tiling", "msda_conv_set_ring", "msda_conv_dgrad_fused_bf16", "msda_conv_packed_elems", "msda_conv_pack_weight", "msda_conv_forward_bf16", "msda_conv_dgrad_bf16", "msda_conv_forward_workspace_bytes", "msda_conv_forward_ws_bf16", "msda_conv_dgrad_workspace_bytes", "msda_conv_dgrad_ws_bf16", "msda_pool_nhwc_bf16", "msda_groupnorm8_nhwc_bf16", "msda_groupnorm8_backward_nhwc_bf16", "msda_conv_wgrad_workspace_bytes", "msda_conv_wgrad_bf16", "msda_conv_wgrad_group_workspace_bytes", "msda_conv_wgrad_group_bf16",
 ]
 
 
@@ -147,6 +153,10 @@ def load():
     L.msda_conv_wgrad_bf16.restype = ci
     L.msda_conv_wgrad_workspace_bytes.argtypes = [ci] * 9 + [ctypes.POINTER(i64)]
     L.msda_conv_wgrad_workspace_bytes.restype = ci
+    L.msda_conv_wgrad_group_workspace_bytes.argtypes = [ctypes.POINTER(WgradProblem), ci, ctypes.POINTER(i64)]
+    L.msda_conv_wgrad_group_workspace_bytes.restype = ci
+    L.msda_conv_wgrad_group_bf16.argtypes = [ctypes.POINTER(WgradProblem), ci, vp, vp]
+    L.msda_conv_wgrad_group_bf16.restype = ci
     L.msda_ffn_debug_stamps.argtypes = [vp]
     L.msda_ffn_debug_stamps.restype = ci
     L.msda_ffn_pack_w2_bf16.argtypes = [vp, ci, ci, vp, vp]

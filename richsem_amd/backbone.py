@@ -115,7 +115,7 @@ class InputProj:
 # ---- trainable form (forward + backward on the library's kernels) -----------------------------------------------------------------
 from torch import nn                                         # noqa: E402
 
-from .conv import ConvAffineFunction, GroupNorm8Function, PackCache, conv_dgrad, conv_forward, conv_wgrad              # noqa: E402
+from .conv import ConvAffineFunction, GroupNorm8Function, PackCache, conv_dgrad, conv_forward, conv_wgrad_group              # noqa: E402
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -196,19 +196,28 @@ class BottleneckFunction(torch.autograd.Function):
         dz3 = dy.contiguous() if masked_by_consumer else torch.ops.aten.threshold_backward(dy.contiguous(), y, 0)
         need = ctx.needs_input_grad
         dz2 = conv_dgrad(dz3, c3.pack_cache.get(w3, s3, True), o2.shape, 4 * planes, 1, 1, 1, 0, relu_out=o2)
-        dw3 = conv_wgrad(dz3, o2, 4 * planes, 1, 1, 1, 0, s3) if need[3] else None
         dz1 = conv_dgrad(dz2, c2.pack_cache.get(w2, s2, True), o1.shape, planes, 3, 3, c2.stride, 1, relu_out=o1)
-        dw2 = conv_wgrad(dz2, o1, planes, 3, 3, c2.stride, 1, s2) if need[2] else None
-        dx = dwd = None
+        dx = None
         if wd is not None:
             cd = blk.downsample[0]
-            dwd = conv_wgrad(dz3, x, 4 * planes, 1, 1, cd.stride, 0, sd_) if need[4] else None
             if need[0]:
                 dxd = conv_dgrad(dz3, cd.pack_cache.get(wd, sd_, True), x.shape, 4 * planes, 1, 1, cd.stride, 0)
                 dx = conv_dgrad(dz1, c1.pack_cache.get(w1, s1, True), x.shape, planes, 1, 1, 1, 0, add=dxd, relu_out=x if mask_input else None)
         elif need[0]:
             dx = conv_dgrad(dz1, c1.pack_cache.get(w1, s1, True), x.shape, planes, 1, 1, 1, 0, add=dz3, relu_out=x if mask_input else None)
-        dw1 = conv_wgrad(dz1, x, planes, 1, 1, 1, 0, s1) if need[1] else None
+        # the block's weight gradients: one launch of the product kernel and one of the reduction for all of them
+        probs, slots = [], []
+        for i, (dz, inp, cout, k, stride, pad, sc) in enumerate(((dz1, x, planes, 1, 1, 0, s1), (dz2, o1, planes, 3, c2.stride, 1, s2),
+                                                                  (dz3, o2, 4 * planes, 1, 1, 0, s3),
+                                                                  (dz3, x, 4 * planes, 1, blk.downsample[0].stride if wd is not None else 1, 0, sd_))):
+            if need[1 + i] and (i < 3 or wd is not None):
+                probs.append((dz, inp, cout, k, k, stride, pad, sc))
+                slots.append(i)
+        grads = [None] * 4
+        if probs:
+            for i, dw in zip(slots, conv_wgrad_group(probs)):
+                grads[i] = dw
+        dw1, dw2, dw3, dwd = grads
         return dx, dw1, dw2, dw3, dwd, None, None, None
 
 

@@ -147,6 +147,28 @@ def conv_wgrad(dz, x, Cout, KH, KW, stride, padding, scale=None):
     return dw
 
 
+def conv_wgrad_group(problems):
+    """Several weight gradients in one launch (``msda_conv_wgrad_group_bf16``): ``problems`` = [(dz, x, Cout, KH, KW, stride, padding, scale)]
+    as :func:`conv_wgrad` takes them (at most 8) -> the list of (Cout, Cin, KH, KW) fp32 results"""
+    L = _lib.load()
+    n = len(problems)
+    arr = (_lib.WgradProblem * n)()
+    outs = []
+    dev = problems[0][0].device
+    for j, (dz, x, Cout, KH, KW, stride, padding, scale) in enumerate(problems):
+        N, H, W, Cin = x.shape
+        dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=dev)
+        outs.append(dw)
+        arr[j] = _lib.WgradProblem(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                   N, H, W, Cin, Cout, KH, KW, stride, padding)
+    nb = ctypes.c_int64(0)
+    _lib.check(L.msda_conv_wgrad_group_workspace_bytes(arr, n, ctypes.byref(nb)))
+    ws = torch.empty(nb.value // 4, dtype=torch.float32, device=dev) if nb.value else None
+    with torch.cuda.device(dev):
+        _lib.check(L.msda_conv_wgrad_group_bf16(arr, n, ws.data_ptr() if ws is not None else None, _stream(dev)))
+    return outs
+
+
 def _pool(x, k, stride, pad, is_max):
     assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[3] % 8 == 0
     x = x.contiguous()

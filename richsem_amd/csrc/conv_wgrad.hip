@@ -45,20 +45,19 @@ struct WgradGeom {
 
 __device__ __forceinline__ int lds_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__restrict__ dz, const uint16_t *__restrict__ x,
-                                                              float *__restrict__ dw, float *__restrict__ dbias,
-                                                              const float *__restrict__ scale, int direct, WgradGeom g)
+// one workgroup's work: pixel chunk `bx`, (tap, channel blocks) `by_` of problem g
+__device__ __forceinline__ void wgrad_block(const uint16_t *__restrict__ dz, const uint16_t *__restrict__ x, float *__restrict__ dw,
+                                            float *__restrict__ dbias, const float *__restrict__ scale, int direct, const WgradGeom &g,
+                                            int bx, int by_, unsigned char (*lds)[2 * kImageBytes])
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * kImageBytes];   // [buffer][A image | B image]
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb_ci = g.Cin / kBN, nb_co = g.Cout / kBM;
-    int by = blockIdx.y;
+    int by = by_;
     const int cib = by % nb_ci;
     by /= nb_ci;
     const int cob = by % nb_co, tap = by / nb_co;
     const int kh = tap / g.KW, kw = tap - kh * g.KW;
-    const long long p0 = (long long)blockIdx.x * g.chunk;
+    const long long p0 = (long long)bx * g.chunk;
     const long long p1 = p0 + g.chunk < g.P ? p0 + g.chunk : g.P;
     const int n_stage = (int)((p1 - p0 + kStagePx - 1) / kStagePx);
 
@@ -171,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
     // accumulator tile: lane (c = lane & 15, gI) holds rows (output channels) 4 gI + i, column (input channel) c; pixel chunk
     // blockIdx.x writes its own slice of the output (the result itself when there is one chunk, else the workspace)
     const int taps = g.KH * g.KW;
-    float *out = dw + (size_t)blockIdx.x * g.Cout * taps * g.Cin;
+    float *out = dw + (size_t)bx * g.Cout * taps * g.Cin;
     if (want_bias) {      // fold the 16 row groups (threads with equal ch) through LDS; chunk blockIdx.x writes its slice of dbias
         float *red = reinterpret_cast<float *>(lds[0]);     // (the last barrier of the loop has passed: the images are free)
 #pragma unroll
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
         if (tid < kBM) {
             float v = 0.f;
             for (int r = 0; r < 16; ++r) v += red[(r * 16 + (tid >> 3)) * 8 + (tid & 7)];
-            dbias[(size_t)blockIdx.x * g.Cout + cob * kBM + tid] = v;
+            dbias[(size_t)bx * g.Cout + cob * kBM + tid] = v;
         }
     }
 #pragma unroll
@@ -198,6 +197,98 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__
                     out[((long long)co * taps + tap) * g.Cin + ci] = acc[a][b][i];
             }
         }
+}
+
+__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__restrict__ dz, const uint16_t *__restrict__ x,
+                                                              float *__restrict__ dw, float *__restrict__ dbias,
+                                                              const float *__restrict__ scale, int direct, WgradGeom g)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * kImageBytes];   // [buffer][A image | B image]
+    wgrad_block(dz, x, dw, dbias, scale, direct, g, blockIdx.x, blockIdx.y, lds);
+}
+
+// Several weight gradients in ONE launch (a bottleneck block's three or four: msda_conv_wgrad_group_bf16).  Each problem alone would be
+// split into ~512 workgroups of 4-8 stages; together they share the chip: a seventh of the partial sums, loops of 15-30 stages, one launch
+// (and one reduction launch) instead of three or four of each.  Workgroup b belongs to the problem j with first[j] <= b < first[j + 1].
+constexpr int kMaxGroup = 8;
+struct WgradGroup {
+    const uint16_t *dz[kMaxGroup], *x[kMaxGroup];
+    float *part[kMaxGroup];          // where the chunks' slices go: the workspace, or the result itself for a problem of one chunk
+    float *dw[kMaxGroup];
+    const float *scale[kMaxGroup];
+    WgradGeom g[kMaxGroup];
+    int split[kMaxGroup], first[kMaxGroup + 1];
+    long long red_first[kMaxGroup + 1];      // reduction: float4 elements of the problems with more than one chunk, concatenated
+    int n;
+};
+
+__global__ __launch_bounds__(kThreads) void conv_wgrad_group_kernel(WgradGroup grp)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * kImageBytes];
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxGroup; ++i)
+        if (i < grp.n && (int)blockIdx.x >= grp.first[i]) j = i;      // (uniform)
+    const int local = (int)blockIdx.x - grp.first[j], split = grp.split[j];
+    wgrad_block(grp.dz[j], grp.x[j], grp.part[j], nullptr, grp.scale[j], split > 1 ? 0 : 1, grp.g[j], local % split, local / split, lds);
+}
+
+// the reduction of a group's split problems: 64 float4 elements per workgroup-iteration as in conv_wgrad_reduce_kernel
+__global__ __launch_bounds__(256) void conv_wgrad_group_reduce_kernel(WgradGroup grp)
+{
+    __shared__ float4 red[4][64];
+    const int col = threadIdx.x & 63, phase = threadIdx.x >> 6;
+    const long long total = grp.red_first[grp.n];
+    for (long long i0 = (long long)blockIdx.x * 64; i0 < total; i0 += (long long)gridDim.x * 64) {
+        const long long ig = i0 + col;
+        int j = 0;
+#pragma unroll
+        for (int k = 1; k < kMaxGroup; ++k)
+            if (k < grp.n && ig >= grp.red_first[k]) j = k;
+        const bool live = ig < total;
+        const long long i = ig - grp.red_first[j], n4 = grp.red_first[j + 1] - grp.red_first[j];
+        const int split = grp.split[j];
+        const float4 *ws = reinterpret_cast<const float4 *>(grp.part[j]);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (live) {
+            int s = phase;
+            for (; s + 4 < split; s += 8) {
+                const float4 u = ws[(long long)s * n4 + i], v = ws[(long long)(s + 4) * n4 + i];
+                a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+                b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+            }
+            if (s < split) {
+                const float4 u = ws[(long long)s * n4 + i];
+                a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            }
+        }
+        red[phase][col] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        __syncthreads();
+        if (phase == 0 && live) {
+            float4 r = red[0][col];
+#pragma unroll
+            for (int p = 1; p < 4; ++p) {
+                r.x += red[p][col].x; r.y += red[p][col].y; r.z += red[p][col].z; r.w += red[p][col].w;
+            }
+            const WgradGeom &g = grp.g[j];
+            const int taps = g.KH * g.KW, cin = g.Cin;
+            const long long e0 = 4 * i;
+            const int co = (int)(e0 / ((long long)taps * cin));
+            if (grp.scale[j]) {
+                const float sc = grp.scale[j][co];
+                r.x *= sc; r.y *= sc; r.z *= sc; r.w *= sc;
+            }
+            float *dw = grp.dw[j];
+            if (g.torch_layout && taps > 1) {
+                const int rem = (int)(e0 - (long long)co * taps * cin), tap = rem / cin, ci = rem - tap * cin;
+                float *d = dw + ((long long)co * cin + ci) * taps + tap;
+                d[0] = r.x; d[taps] = r.y; d[2 * taps] = r.z; d[3 * taps] = r.w;
+            } else {
+                reinterpret_cast<float4 *>(dw)[i] = r;
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // dw[i] = sum over the chunks' slices.  64 float4 elements per workgroup, four phases of threads per element (phase p sums slices
@@ -277,9 +368,97 @@ void wgrad_split(const WgradGeom &g, long long &split, long long &chunk)
     split = (g.P + chunk - 1) / chunk;
 }
 
+// a group's plan: the problems share ~512 workgroups in proportion to their work (pixels x taps x channel blocks), each chunk at least
+// 256 pixels (4 stages)
+int plan_group(const msda_wgrad_problem *probs, int n, WgradGroup &grp, int64_t &ws_floats)
+{
+    if (!probs || n < 1 || n > kMaxGroup) return MSDA_ERR_BAD_DIMS;
+    double work[kMaxGroup], total = 0;
+    for (int j = 0; j < n; ++j) {
+        const msda_wgrad_problem &p = probs[j];
+        if (p.N < 1 || p.H < 1 || p.W < 1 || p.Cin < kBN || p.Cin % kBN != 0 || p.Cout < kBM || p.Cout % kBM != 0 || p.KH < 1 || p.KW < 1 ||
+            p.KH > 16 || p.KW > 16 || p.stride < 1 || p.pad < 0)
+            return MSDA_ERR_BAD_DIMS;
+        const int Ho = (p.H + 2 * p.pad - p.KH) / p.stride + 1, Wo = (p.W + 2 * p.pad - p.KW) / p.stride + 1;
+        if (Ho < 1 || Wo < 1) return MSDA_ERR_BAD_DIMS;
+        grp.g[j] = WgradGeom{p.N, p.H, p.W, p.Cin, Ho, Wo, p.Cout, p.KH, p.KW, p.stride, p.pad, (long long)p.N * Ho * Wo, 0, 1};
+        if (grp.g[j].P >= (1ll << 31) - (1 << 20) || (long long)p.N * p.H * p.W >= (1ll << 31)) return MSDA_ERR_TOO_LARGE;
+        work[j] = (double)grp.g[j].P * p.KH * p.KW * (p.Cout / kBM) * (p.Cin / kBN);
+        total += work[j];
+    }
+    grp.n = n;
+    grp.first[0] = 0;
+    grp.red_first[0] = 0;
+    ws_floats = 0;
+    for (int j = 0; j < n; ++j) {
+        const WgradGeom &g = grp.g[j];
+        const long long blocks_y = (long long)g.KH * g.KW * (g.Cout / kBM) * (g.Cin / kBN);
+        long long split = (long long)(512.0 * work[j] / total / (double)blocks_y + 0.5);
+        const long long max_split = (g.P + 255) / 256;
+        if (split > max_split) split = max_split;
+        if (split < 1) split = 1;
+        long long chunk = ((g.P + split - 1) / split + kStagePx - 1) / kStagePx * kStagePx;
+        split = (g.P + chunk - 1) / chunk;
+        grp.g[j].chunk = chunk;
+        grp.split[j] = (int)split;
+        grp.first[j + 1] = grp.first[j] + (int)(split * blocks_y);
+        const long long n_dw = (long long)g.Cout * g.KH * g.KW * g.Cin;
+        grp.red_first[j + 1] = grp.red_first[j] + (split > 1 ? n_dw / 4 : 0);
+        if (split > 1) ws_floats += split * n_dw;
+    }
+    return MSDA_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+/* Several weight gradients (msda_conv_wgrad_bf16 problems with the result in nn.Conv2d's layout, scaled; no bias gradients) in one launch
+ * of the product kernel and one of the reduction: the problems share the chip instead of each being cut into ~512 short workgroups.
+ * n <= 8; workspace: msda_conv_wgrad_group_workspace_bytes() bytes (may be NULL when that is 0). */
+int msda_conv_wgrad_group_workspace_bytes(const msda_wgrad_problem *problems, int n, int64_t *bytes)
+{
+    if (!bytes) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    WgradGroup grp;
+    int64_t fl = 0;
+    const int rc = plan_group(problems, n, grp, fl);
+    if (rc != MSDA_OK) return msda_note_error(rc, __func__);
+    *bytes = fl * (int64_t)sizeof(float);
+    return MSDA_OK;
+}
+
+int msda_conv_wgrad_group_bf16(const msda_wgrad_problem *problems, int n, void *workspace, msda_stream_t stream)
+{
+    WgradGroup grp;
+    int64_t fl = 0;
+    const int rc = plan_group(problems, n, grp, fl);
+    if (rc != MSDA_OK) return msda_note_error(rc, __func__);
+    if (fl > 0 && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15))) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    float *ws = static_cast<float *>(workspace);
+    for (int j = 0; j < n; ++j) {
+        const msda_wgrad_problem &p = problems[j];
+        if (!p.dz || !p.x || !p.dw) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+        if ((reinterpret_cast<uintptr_t>(p.dz) | reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.dw)) & 15)
+            return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
+        grp.dz[j] = p.dz;
+        grp.x[j] = p.x;
+        grp.dw[j] = p.dw;
+        grp.scale[j] = p.scale;
+        grp.part[j] = grp.split[j] > 1 ? ws : p.dw;
+        if (grp.split[j] > 1) ws += (int64_t)grp.split[j] * p.Cout * p.KH * p.KW * p.Cin;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(conv_wgrad_group_kernel, dim3((unsigned)grp.first[n]), dim3(kThreads), 0, st, grp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const long long total = grp.red_first[n];
+    if (total > 0) {
+        const int grid = (int)((total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192);
+        hipLaunchKernelGGL(conv_wgrad_group_reduce_kernel, dim3(grid), dim3(256), 0, st, grp);
+        e = hipGetLastError();
+    }
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
 
 /* bytes of workspace msda_conv_wgrad_bf16 needs for a problem (0: none) */
 int msda_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t *bytes)

@@ -165,6 +165,28 @@ def test_fused_input_gradient_epilogue(case, slots):
     assert bool((fused[act <= 0] == 0).all())
 
 
+def test_grouped_weight_gradients_equal_the_single_launches():
+    """msda_conv_wgrad_group_bf16 (a bottleneck block's weight gradients sharing one launch) against msda_conv_wgrad_bf16 per problem: the
+    pixel chunks differ, so the sums differ in order only"""
+    from richsem_amd.conv import conv_wgrad, conv_wgrad_group
+    torch.manual_seed(11)
+    N, H, W = 2, 26, 30
+    probs = []
+    for cin, cout, k, stride, pad in ((512, 128, 1, 1, 0), (128, 128, 3, 2, 1), (128, 512, 1, 1, 0), (512, 512, 1, 2, 0), (256, 128, 3, 1, 1)):
+        h, w = (H, W) if (cin, k) != (128, 1) else (H // 2, W // 2)
+        Ho, Wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        x = torch.randn(N, h, w, cin, device="cuda").to(torch.bfloat16)
+        dz = torch.randn(N, Ho, Wo, cout, device="cuda").to(torch.bfloat16)
+        scale = (1 + 0.3 * torch.randn(cout, device="cuda")) if k == 1 else None
+        probs.append((dz, x, cout, k, k, stride, pad, scale))
+    for sub in (probs, probs[:1], probs[1:4]):
+        got = conv_wgrad_group(sub)
+        for g, (dz, x, cout, k, _, stride, pad, scale) in zip(got, sub):
+            want = conv_wgrad(dz, x, cout, k, k, stride, pad, scale)
+            assert g.shape == want.shape
+            assert float((g - want).abs().max()) <= 2e-5 * float(want.abs().max()), float((g - want).abs().max()) / float(want.abs().max())
+
+
 def test_errors():
     from richsem_amd.conv import ConvAffine
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
