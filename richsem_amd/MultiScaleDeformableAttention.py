@@ -104,8 +104,8 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     if value.dtype == torch.bfloat16:
         sampling_loc, attn_weight = sampling_loc.float(), attn_weight.float()   # no-ops for float32 inputs
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
-    with torch.cuda.device(value.device):
-        stream = torch.cuda.current_stream().cuda_stream
+    with _lib.on_device(value.device):
+        stream = _lib.raw_stream()
         rc = getattr(lib, "msda_forward_" + _SUFFIX[value.dtype])(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
             attn_weight.data_ptr(), N, S, M, D, L, Lq, P, int(im2col_step), out.data_ptr(),
@@ -130,8 +130,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_value = torch.empty_like(value)            # zero-filled by the library, on the same stream
     grad_loc = torch.empty_like(sampling_loc)       # written exactly once per element by the kernel
     grad_aw = torch.empty_like(attn_weight)
-    with torch.cuda.device(value.device):
-        stream = torch.cuda.current_stream().cuda_stream
+    with _lib.on_device(value.device):
+        stream = _lib.raw_stream()
         rc = getattr(lib, "msda_backward_" + _SUFFIX[value.dtype])(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
             attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L, Lq, P, int(im2col_step),

@@ -13,7 +13,7 @@ from . import _lib
 
 
 def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+    return _lib.raw_stream(dev)
 
 
 def fold_bn(weight, bias, running_mean, running_var, eps=1e-5):
@@ -30,11 +30,18 @@ def to_nchw(x_nhwc, dtype=torch.float32):
     return x_nhwc.permute(0, 3, 1, 2).to(dtype).contiguous()
 
 
+_WS_BYTES = {}      # (entry point, problem dimensions) -> bytes: the library's answer depends on nothing else
+
+
 def _ksplit_workspace(fn, dims, device):
     """zeroed fp32 workspace for a k-split convolution call, or None where the library does not split the problem"""
-    nb = ctypes.c_int64(0)
-    _lib.check(fn(*dims, ctypes.byref(nb)))
-    return torch.zeros(nb.value // 4, dtype=torch.float32, device=device) if nb.value else None
+    key = (fn.__name__, dims)
+    n = _WS_BYTES.get(key)
+    if n is None:
+        nb = ctypes.c_int64(0)
+        _lib.check(fn(*dims, ctypes.byref(nb)))
+        n = _WS_BYTES[key] = nb.value
+    return torch.zeros(n // 4, dtype=torch.float32, device=device) if n else None
 
 
 class ConvAffine:
@@ -58,7 +65,7 @@ class ConvAffine:
         n = ctypes.c_int64(0)
         _lib.check(L.msda_conv_packed_elems(self.Cout, self.Cin, self.KH, self.KW, ctypes.byref(n)))
         self.packed = torch.empty(n.value, dtype=torch.int16, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.msda_conv_pack_weight(w.data_ptr(), self.Cout, self.Cin, self.KH, self.KW, self.packed.data_ptr(), _stream(dev)))
 
     def out_hw(self, H, W):
@@ -79,7 +86,7 @@ class ConvAffine:
         if residual is not None:
             assert residual.shape == out.shape and residual.dtype == torch.bfloat16
             residual = residual.contiguous()
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             L = _lib.load()
             ws = _ksplit_workspace(L.msda_conv_forward_workspace_bytes, (N, H, W, self.Cin, self.Cout, self.KH, self.KW, self.stride, self.pad),
                                    x.device)
@@ -107,7 +114,7 @@ def conv_dgrad(dz, packed_t, x_shape, Cout, KH, KW, stride, padding, add=None, r
     N, H, W, Cin = x_shape
     dx = torch.empty(x_shape, dtype=torch.bfloat16, device=dz.device)
     L = _lib.load()
-    with torch.cuda.device(dz.device):
+    with _lib.on_device(dz.device):
         ws = _ksplit_workspace(L.msda_conv_dgrad_workspace_bytes, (N, dz.shape[1], dz.shape[2], Cout, Cin, KH, KW, stride, padding, H, W), dz.device)
         _lib.check(L.msda_conv_dgrad_fused_bf16(dz.data_ptr(), packed_t.data_ptr(), N, dz.shape[1], dz.shape[2], Cout, Cin, KH, KW, stride, padding,
                                                 H, W, add.data_ptr() if add is not None else None,
@@ -121,7 +128,7 @@ def conv_forward(x, packed, scale, shift, residual, Cout, KH, KW, stride, paddin
     N, H, W, Cin = x.shape
     Ho, Wo = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
     out = torch.empty((N, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         L = _lib.load()
         ws = _ksplit_workspace(L.msda_conv_forward_workspace_bytes, (N, H, W, Cin, Cout, KH, KW, stride, padding), x.device)
         _lib.check(L.msda_conv_forward_ws_bf16(
@@ -140,7 +147,7 @@ def conv_wgrad(dz, x, Cout, KH, KW, stride, padding, scale=None):
     nb = ctypes.c_int64(0)
     _lib.check(L.msda_conv_wgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, padding, ctypes.byref(nb)))
     ws = torch.empty(nb.value // 4, dtype=torch.float32, device=x.device) if nb.value else None
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(L.msda_conv_wgrad_bf16(dz.data_ptr(), x.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, padding, dw.data_ptr(), None,
                                           scale.data_ptr() if scale is not None else None, 1, ws.data_ptr() if ws is not None else None,
                                           _stream(x.device)))
@@ -164,7 +171,7 @@ def conv_wgrad_group(problems):
     nb = ctypes.c_int64(0)
     _lib.check(L.msda_conv_wgrad_group_workspace_bytes(arr, n, ctypes.byref(nb)))
     ws = torch.empty(nb.value // 4, dtype=torch.float32, device=dev) if nb.value else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(L.msda_conv_wgrad_group_bf16(arr, n, ws.data_ptr() if ws is not None else None, _stream(dev)))
     return outs
 
@@ -175,7 +182,7 @@ def _pool(x, k, stride, pad, is_max):
     N, H, W, C = x.shape
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     out = torch.empty((N, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(_lib.load().msda_pool_nhwc_bf16(x.data_ptr(), N, H, W, C, k, stride, pad, int(is_max), out.data_ptr(), _stream(x.device)))
     return out
 
@@ -199,7 +206,7 @@ def group_norm8_nhwc(x, gamma, beta, eps=1e-5, want_f32=True, want_bf16=True):
     o32 = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device) if want_f32 else None
     o16 = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(_lib.load().msda_groupnorm8_nhwc_bf16(x.data_ptr(), g.data_ptr(), b.data_ptr(), float(eps), N, H * W, C, stats.data_ptr(),
                                                          o32.data_ptr() if o32 is not None else None,
                                                          o16.data_ptr() if o16 is not None else None, _stream(x.device)))
@@ -218,7 +225,7 @@ class GroupNorm8Function(torch.autograd.Function):
         stats = torch.empty(N * (C // 8) * 2, dtype=torch.float64, device=x.device)
         out = torch.empty_like(x)
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.load().msda_groupnorm8_nhwc_bf16(x.data_ptr(), g.data_ptr(), b.data_ptr(), float(eps), N, H * W, C, stats.data_ptr(),
                                                              None, out.data_ptr(), _stream(x.device)))
         ctx.save_for_backward(x, g, stats)
@@ -234,7 +241,7 @@ class GroupNorm8Function(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgb = torch.empty(2, C, dtype=torch.float32, device=x.device)
         bstats = torch.empty(N * (C // 8) * 16, dtype=torch.float64, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.load().msda_groupnorm8_backward_nhwc_bf16(x.data_ptr(), dy.data_ptr(), g.data_ptr(), ctx.eps, N, H * W, C,
                                                                       stats.data_ptr(), bstats.data_ptr(), dx.data_ptr(), dgb[0].data_ptr(),
                                                                       dgb[1].data_ptr(), _stream(x.device)))
@@ -248,7 +255,7 @@ def _pack(w):
     n = ctypes.c_int64(0)
     _lib.check(L.msda_conv_packed_elems(Cout, Cin, KH, KW, ctypes.byref(n)))
     packed = torch.empty(n.value, dtype=torch.int16, device=w.device)
-    with torch.cuda.device(w.device):
+    with _lib.on_device(w.device):
         _lib.check(L.msda_conv_pack_weight(w.data_ptr(), Cout, Cin, KH, KW, packed.data_ptr(), _stream(w.device)))
     return packed
 
@@ -308,7 +315,7 @@ class ConvAffineFunction(torch.autograd.Function):
         out = torch.empty((N, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
         res = residual.contiguous() if residual is not None else None
         packed = _packed_for(weight, scale, False, cache)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             L = _lib.load()
             ws = _ksplit_workspace(L.msda_conv_forward_workspace_bytes, (N, H, W, Cin, Cout, KH, KW, stride, padding), x.device)
             _lib.check(L.msda_conv_forward_ws_bf16(
@@ -335,7 +342,7 @@ class ConvAffineFunction(torch.autograd.Function):
                 raise RuntimeError("ConvAffineFunction: the input gradient needs C_out % 32 == 0, C_in % 16 == 0 and a square kernel")
             packed_t = _packed_for(weight, scale, True, cache)
             dx = torch.empty_like(x)
-            with torch.cuda.device(x.device):
+            with _lib.on_device(x.device):
                 L = _lib.load()
                 ws = _ksplit_workspace(L.msda_conv_dgrad_workspace_bytes, (N, dz.shape[1], dz.shape[2], Cout, Cin, KH, KW, stride, padding, H, W),
                                        x.device)
@@ -349,7 +356,7 @@ class ConvAffineFunction(torch.autograd.Function):
                 nb = ctypes.c_int64(0)
                 _lib.check(L.msda_conv_wgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, padding, ctypes.byref(nb)))
                 ws = torch.empty(nb.value // 4, dtype=torch.float32, device=x.device) if nb.value else None
-                with torch.cuda.device(x.device):
+                with _lib.on_device(x.device):
                     _lib.check(L.msda_conv_wgrad_bf16(dz.data_ptr(), x.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, padding,
                                                       dw.data_ptr(), None, scale.data_ptr(), 1, ws.data_ptr() if ws is not None else None,
                                                       _stream(x.device)))

@@ -40,13 +40,13 @@ def prepare_dn_layout(known_num, dn_number, num_queries, use_cdn=True, add_gt=Fa
     single_pad = int(max(known_num)) if batch else 0
     pad_size = single_pad * 2 * groups
     lib = _lib.load()
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    stream = _lib.raw_stream(dev)
     cum = torch.tensor([0] + list(torch.tensor(known_num, dtype=torch.int64).cumsum(0).tolist()) if batch else [0], dtype=torch.int64,
                        device=dev)
     n = total * 2 * groups
     known_bid = torch.empty(n, dtype=torch.int64, device=dev)
     map_known_indice = torch.empty(n, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         if batch and n:
             _lib.check(lib.msda_dn_indices_i64(cum.data_ptr(), batch, total, 2 * groups, single_pad, known_bid.data_ptr(),
                                                map_known_indice.data_ptr(), stream))
@@ -83,7 +83,7 @@ def topk_indices(scores, k, return_values=False):
     s = scores.contiguous()
     idx = torch.empty((rows, k), dtype=torch.int64, device=s.device)
     val = torch.empty((rows, k), dtype=torch.float32, device=s.device) if return_values else None
-    with torch.cuda.device(s.device):
+    with _lib.on_device(s.device):
         _lib.check(_lib.load().msda_topk_f32(s.data_ptr(), rows, n, k, idx.data_ptr(), val.data_ptr() if val is not None else None,
-                                             torch.cuda.current_stream(s.device).cuda_stream))
+                                             _lib.raw_stream(s.device)))
     return (idx, val) if return_values else idx

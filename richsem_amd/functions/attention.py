@@ -68,10 +68,10 @@ class MaskedSelfAttentionFunction(Function):
         lse = torch.empty((bs * n_heads, nqp), dtype=torch.float32, device=qk.device)
         ws = _ws(nq, bs, n_heads, qk.device)
         esz = 2
-        with torch.cuda.device(qk.device):
+        with _lib.on_device(qk.device):
             _lib.check(_lib.load().msda_attn_forward_bf16(
                 qk.data_ptr(), c2, qk.data_ptr() + C * esz, c2, v.data_ptr(), C, bits[0].data_ptr() if bits[0] is not None else None,
-                nq, bs, int(batch_first), n_heads, out.data_ptr(), lse.data_ptr(), ws.data_ptr(), torch.cuda.current_stream(qk.device).cuda_stream))
+                nq, bs, int(batch_first), n_heads, out.data_ptr(), lse.data_ptr(), ws.data_ptr(), _lib.raw_stream(qk.device)))
         ctx.save_for_backward(qk, v, out, lse, *(b for b in bits if b is not None))
         ctx.meta = (n_heads, mask is not None, batch_first, nq, bs)
         return out
@@ -88,12 +88,12 @@ class MaskedSelfAttentionFunction(Function):
         dout = dout.contiguous()
         dqk, dv = torch.empty_like(qk), torch.empty_like(v)
         ws = _ws(nq, bs, n_heads, qk.device)
-        with torch.cuda.device(qk.device):
+        with _lib.on_device(qk.device):
             _lib.check(_lib.load().msda_attn_backward_bf16(
                 qk.data_ptr(), c2, qk.data_ptr() + C * 2, c2, v.data_ptr(), C, out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
                 bits[0].data_ptr() if has_mask else None, bits[1].data_ptr() if has_mask else None, nq, bs, int(batch_first), n_heads,
                 dqk.data_ptr(), c2, dqk.data_ptr() + C * 2, c2, dv.data_ptr(), C, ws.data_ptr(),
-                torch.cuda.current_stream(qk.device).cuda_stream))
+                _lib.raw_stream(qk.device)))
         return dqk, dv, None, None, None
 
 

@@ -34,7 +34,7 @@ def _wgrad(dy, x, with_bias=False):
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _lib.raw_stream(t.device)
 
 
 def pack_w2_bf16(w2):
@@ -43,7 +43,7 @@ def pack_w2_bf16(w2):
         raise RuntimeError("Not implemented on the CPU")
     assert w2.dtype == torch.bfloat16 and w2.is_contiguous()
     out = torch.empty_like(w2)
-    with torch.cuda.device(w2.device):
+    with _lib.on_device(w2.device):
         _lib.check(_lib.load().msda_ffn_pack_w2_bf16(w2.data_ptr(), w2.shape[0], w2.shape[1], out.data_ptr(), _stream(w2)))
     return out
 
@@ -61,7 +61,7 @@ def ffn_forward_bf16(x, w1, b1, w2_packed, b2, ln_weight, ln_bias, eps=1e-5, ret
     out = torch.empty_like(x2)
     rstd = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device) if return_rstd else None
     yhat = torch.empty_like(x2) if return_rstd else None
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(_lib.load().msda_ffn_forward_train_bf16(
             x2.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2_packed.data_ptr(), b2.data_ptr(), ln_weight.data_ptr(),
             ln_bias.data_ptr(), float(eps), x2.shape[0], x2.shape[1], w1.shape[0], out.data_ptr(),
@@ -74,7 +74,7 @@ def ffn_ln_backward_bf16(grad_out, yhat, rstd, ln_weight):
     g2, o2 = grad_out.contiguous().view(-1, 256), yhat.contiguous().view(-1, 256)
     dz = torch.empty_like(o2)
     sums = torch.empty(3, 256, dtype=torch.float32, device=o2.device)
-    with torch.cuda.device(o2.device):
+    with _lib.on_device(o2.device):
         _lib.check(_lib.load().msda_ffn_ln_backward_bf16(g2.data_ptr(), o2.data_ptr(), rstd.data_ptr(), ln_weight.data_ptr(),
                                                          o2.shape[0], 256, dz.data_ptr(), sums[0].data_ptr(),
                                                          sums[1].data_ptr(), sums[2].data_ptr(), _stream(o2)))
@@ -119,7 +119,7 @@ def add_layernorm_forward_bf16(a2, b2, ln_weight32, ln_bias32, eps, need_backwar
     out = torch.empty_like(a2)
     rstd = torch.empty(a2.shape[0], dtype=torch.float32, device=a2.device) if need_backward else None
     yhat = torch.empty_like(a2) if need_backward else None
-    with torch.cuda.device(a2.device):
+    with _lib.on_device(a2.device):
         _lib.check(_lib.load().msda_add_layernorm_forward_bf16(
             a2.data_ptr(), b2.data_ptr(), ln_weight32.data_ptr(), ln_bias32.data_ptr(), float(eps), a2.shape[0], 256, out.data_ptr(),
             rstd.data_ptr() if need_backward else None, yhat.data_ptr() if need_backward else None, _stream(a2)))
@@ -178,7 +178,7 @@ class AddLayerNormFunction(Function):
         rstd = torch.empty(a2.shape[0], dtype=torch.float32, device=a.device) if need else None
         yhat = torch.empty_like(a2) if need else None
         w, bi = ln_weight.detach().float().contiguous(), ln_bias.detach().float().contiguous()
-        with torch.cuda.device(a.device):
+        with _lib.on_device(a.device):
             _lib.check(_lib.load().msda_add_layernorm_forward_bf16(
                 a2.data_ptr(), b2.data_ptr(), w.data_ptr(), bi.data_ptr(), float(eps), a2.shape[0], 256, out.data_ptr(),
                 rstd.data_ptr() if need else None, yhat.data_ptr() if need else None, _stream(a)))

@@ -20,7 +20,7 @@ _SFX = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _lib.raw_stream(t.device)
 
 
 class MaskRows(Function):
@@ -32,7 +32,7 @@ class MaskRows(Function):
         mask = mask.contiguous()
         sfx = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}[value.dtype]
         rows = mask.numel()
-        with torch.cuda.device(value.device):
+        with _lib.on_device(value.device):
             _lib.check(getattr(_lib.load(), "msda_mask_rows_" + sfx)(
                 value.data_ptr(), mask.view(torch.uint8).data_ptr(), rows, value.numel() // rows, _stream(value)))
         ctx.mark_dirty(value)
@@ -46,7 +46,7 @@ class MaskRows(Function):
         grad = grad.contiguous().clone()
         sfx = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}[grad.dtype]
         rows = mask.numel()
-        with torch.cuda.device(grad.device):
+        with _lib.on_device(grad.device):
             _lib.check(getattr(_lib.load(), "msda_mask_rows_" + sfx)(
                 grad.data_ptr(), mask.view(torch.uint8).data_ptr(), rows, grad.numel() // rows, _stream(grad)))
         return grad, None
@@ -85,7 +85,7 @@ class MSDeformAttnFusedFunction(Function):
             raise RuntimeError("fused MSDeformAttn path: value must be a (N, S, M, D) tensor of the projection's dtype, shapes int64")
         S, D = value.shape[1], value.shape[3]
         out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
-        with torch.cuda.device(qproj.device):
+        with _lib.on_device(qproj.device):
             _lib.check(getattr(lib, "msda_forward_prep_" + _SFX[qproj.dtype])(
                 value.data_ptr(), spatial_shapes.contiguous().data_ptr(), level_start_index.contiguous().data_ptr(),
                 qproj.data_ptr(), stride, qproj.data_ptr() + n_off * esz, stride, ref.data_ptr(), ref.shape[-1],
@@ -108,7 +108,7 @@ class MSDeformAttnFusedFunction(Function):
         grad_qproj = torch.empty_like(qproj)
         grad_ref = torch.empty_like(ref) if ctx.needs_input_grad[4] else None
         stride, esz = qproj.shape[-1], qproj.element_size()
-        with torch.cuda.device(qproj.device):
+        with _lib.on_device(qproj.device):
             _lib.check(getattr(_lib.load(), "msda_prep_backward_" + _SFX[qproj.dtype])(
                 grad_loc.data_ptr(), grad_aw.data_ptr(), aw.data_ptr(), qproj.data_ptr(), stride, ref.data_ptr(),
                 ref.shape[-1], sh.ctypes.data, N, Lq, M, L, P, grad_qproj.data_ptr(), stride,

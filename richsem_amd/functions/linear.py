@@ -30,10 +30,10 @@ def linear_wgrad_bf16(dy, x, with_bias=False):
     nb = ctypes.c_int64(0)
     _lib.check(L.msda_conv_wgrad_workspace_bytes(1, 1, T, cin, cout, 1, 1, 1, 0, ctypes.byref(nb)))
     ws = torch.empty(nb.value // 4, dtype=torch.float32, device=x.device) if nb.value else None
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(L.msda_conv_wgrad_bf16(dy.data_ptr(), x.data_ptr(), 1, 1, T, cin, cout, 1, 1, 1, 0, dw.data_ptr(),
                                           db.data_ptr() if db is not None else None, None, 0, ws.data_ptr() if ws is not None else None,
-                                          torch.cuda.current_stream(x.device).cuda_stream))
+                                          _lib.raw_stream(x.device)))
     return (dw, db) if with_bias else dw
 
 
@@ -93,9 +93,9 @@ def lin256_pack(weight):
     w = weight.detach().to(torch.bfloat16).contiguous()
     assert w.is_cuda and w.dim() == 2 and w.shape[1] == 256 and w.shape[0] % 64 == 0
     packed = torch.empty_like(w)
-    with torch.cuda.device(w.device):
+    with _lib.on_device(w.device):
         _lib.check(_lib.load().msda_lin256_pack_bf16(w.data_ptr(), w.shape[0], 256, packed.data_ptr(),
-                                                     torch.cuda.current_stream(w.device).cuda_stream))
+                                                     _lib.raw_stream(w.device)))
     return packed
 
 
@@ -117,10 +117,10 @@ def lin256(x, packed_w, bias=None, relu=False, relu_mask=None, row_mask=None):
         aux, epi = row_mask.contiguous().view(torch.uint8), 3
     b = bias if bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and not bias.requires_grad) \
         else bias.detach().float().contiguous()
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(_lib.load().msda_lin256_forward_bf16(x.data_ptr(), packed_w.data_ptr(), b.data_ptr() if b is not None else None,
                                                         aux.data_ptr() if aux is not None else None, epi, x.shape[0], 256, N,
-                                                        out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream))
+                                                        out.data_ptr(), _lib.raw_stream(x.device)))
     return out
 
 
@@ -129,9 +129,9 @@ def lin256_f32_pack(weight):
     w = weight.detach().float().contiguous()
     assert w.is_cuda and w.dim() == 2 and w.shape[1] == 256 and w.shape[0] % 32 == 0
     packed = torch.empty(2 * w.numel(), dtype=torch.int16, device=w.device)
-    with torch.cuda.device(w.device):
+    with _lib.on_device(w.device):
         _lib.check(_lib.load().msda_lin256_pack_f32(w.data_ptr(), w.shape[0], 256, packed.data_ptr(),
-                                                    torch.cuda.current_stream(w.device).cuda_stream))
+                                                    _lib.raw_stream(w.device)))
     return packed
 
 
@@ -141,10 +141,10 @@ def lin256_f32(x, packed_w, out_features, bias=None):
     x = x.contiguous()
     out = torch.empty((x.shape[0], out_features), dtype=torch.float32, device=x.device)
     b = bias.detach().float().contiguous() if bias is not None else None
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(_lib.load().msda_lin256_forward_f32(x.data_ptr(), packed_w.data_ptr(), b.data_ptr() if b is not None else None,
                                                        x.shape[0], 256, out_features, out.data_ptr(),
-                                                       torch.cuda.current_stream(x.device).cuda_stream))
+                                                       _lib.raw_stream(x.device)))
     return out
 
 
@@ -262,10 +262,10 @@ class Lin256NarrowFunction(torch.autograd.Function):
         w32 = weight.detach().float().contiguous()
         dx = torch.empty((T, 256), dtype=torch.bfloat16, device=x2.device) if ctx.needs_input_grad[0] else None
         dwb = torch.empty(n * 256 + 8, dtype=torch.float32, device=x2.device)
-        with torch.cuda.device(x2.device):
+        with _lib.on_device(x2.device):
             _lib.check(_lib.load().msda_narrow_linear_backward_bf16(
                 dy2.data_ptr(), x2.data_ptr(), w32.data_ptr(), T, n, dx.data_ptr() if dx is not None else None, dwb.data_ptr(),
-                dwb[n * 256:].data_ptr(), torch.cuda.current_stream(x2.device).cuda_stream))
+                dwb[n * 256:].data_ptr(), _lib.raw_stream(x2.device)))
         dw, db = dwb[:n * 256].view(n, 256), dwb[n * 256:n * 256 + n]
         return (dx.view(ctx.shape) if dx is not None else None, None, dw.to(ctx.dts[0]) if ctx.needs_input_grad[2] else None,
                 db.to(ctx.dts[1]) if ctx.needs_input_grad[3] else None)
@@ -273,9 +273,9 @@ class Lin256NarrowFunction(torch.autograd.Function):
 
 def _mask_rows_(t, mask):
     """zero the rows of ``t`` (T, C) bf16 where ``mask`` (T,) bool is set, in place (only those rows are touched)"""
-    with torch.cuda.device(t.device):
+    with _lib.on_device(t.device):
         _lib.check(_lib.load().msda_mask_rows_bf16(t.data_ptr(), mask.view(torch.uint8).data_ptr(), mask.numel(), t.numel() // mask.numel(),
-                                                   torch.cuda.current_stream(t.device).cuda_stream))
+                                                   _lib.raw_stream(t.device)))
     return t
 
 
@@ -349,10 +349,10 @@ class StackedValueProjFunction(torch.autograd.Function):
         nl = len(pk["rows"])
         out = torch.empty((nl,) + x.shape[:-1] + (256,), dtype=torch.bfloat16, device=x.device)
         m8 = row_mask.reshape(-1).contiguous().view(torch.uint8) if row_mask is not None else None
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.load().msda_lin256_forward_stacked_bf16(
                 x2.data_ptr(), pk["packed"].data_ptr(), pk["b32"].data_ptr(), m8.data_ptr() if m8 is not None else None, x2.shape[0], 256,
-                256 * nl, out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream))
+                256 * nl, out.data_ptr(), _lib.raw_stream(x.device)))
         ctx.save_for_backward(x2, row_mask)
         ctx.pk, ctx.dts, ctx.shape = pk, tuple(p.dtype for p in params), x.shape
         return tuple(out.unbind(0))

@@ -23,7 +23,7 @@ from . import _lib
 
 
 def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+    return _lib.raw_stream(dev)
 
 
 class CostPlan:
@@ -62,7 +62,7 @@ def cost_blocks(pred_logits, pred_boxes, plan, cost_class, cost_bbox, cost_giou,
     assert out.numel() == n and out.dtype == dt and out.is_contiguous()
     if n:
         fn = getattr(_lib.load(), "msda_matcher_cost_" + ("f32" if dt == torch.float32 else "f64"))
-        with torch.cuda.device(logits.device):
+        with _lib.on_device(logits.device):
             _lib.check(fn(logits.data_ptr(), boxes.data_ptr(), plan.tgt_ids.data_ptr(), plan.tgt_boxes.data_ptr(),
                           plan.offsets_dev.data_ptr(), bs, nq, C, plan.total, float(cost_class), float(cost_bbox), float(cost_giou),
                           float(focal_alpha), out.data_ptr(), _stream(logits.device)))
@@ -196,9 +196,9 @@ class FocalNegativeSum(torch.autograd.Function):
         rows, C = w.numel(), x.shape[-1]
         partial = torch.empty(4096, dtype=torch.float64, device=x.device)
         n = ctypes.c_int(0)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.load().msda_focal_neg_sum_f32(x.data_ptr(), w.data_ptr(), rows, C, float(alpha), partial.data_ptr(), 4096,
-                                                          ctypes.byref(n), torch.cuda.current_stream(x.device).cuda_stream))
+                                                          ctypes.byref(n), _lib.raw_stream(x.device)))
         ctx.save_for_backward(x, w)
         ctx.alpha = float(alpha)
         return partial[:n.value].sum().float()
@@ -209,7 +209,7 @@ class FocalNegativeSum(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gx = torch.empty_like(x)
         gs = g.reshape(1).float().contiguous()
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.load().msda_focal_neg_grad_f32(x.data_ptr(), w.data_ptr(), w.numel(), x.shape[-1], ctx.alpha, gs.data_ptr(),
-                                                           gx.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream))
+                                                           gx.data_ptr(), _lib.raw_stream(x.device)))
         return gx, None, None

@@ -50,9 +50,9 @@ class AttentionPool2d(nn.Module):
         z = torch.empty_like(u)
         spos = torch.mm(u.view(H * K, C), d["pos_t"])                                          # u . pos_t for every (head, ROI): (H K, T + 1)
         fn = getattr(_lib.load(), "msda_attnpool_core_" + ("f32" if dt == torch.float32 else "f64"))
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(fn(u.data_ptr(), feat.data_ptr(), d["pos"].data_ptr(), spos.data_ptr(), K, H, C, T, 1, z.data_ptr(),
-                          torch.cuda.current_stream(x.device).cuda_stream))
+                          _lib.raw_stream(x.device)))
         # o[k, h] = Wv_h z[h, k] (+ bv_h, folded into the output bias: the attention weights sum to one), then the output projection
         o = torch.bmm(z, d["wv_ht"]).transpose(0, 1).reshape(K, C)
         return torch.addmm(d["bc"], o, d["wc_t"])

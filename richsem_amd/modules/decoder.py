@@ -107,9 +107,9 @@ class BoxRefineFunction(torch.autograd.Function):
         from .. import _lib
         d, r = delta.contiguous(), ref.detach().float().contiguous()
         y = torch.empty(d.shape, dtype=torch.float32, device=d.device)
-        with torch.cuda.device(d.device):
+        with _lib.on_device(d.device):
             _lib.check(_lib.load().msda_box_refine_forward(d.data_ptr(), int(d.dtype == torch.bfloat16), r.data_ptr(), float(eps), d.numel(),
-                                                          y.data_ptr(), torch.cuda.current_stream(d.device).cuda_stream))
+                                                          y.data_ptr(), _lib.raw_stream(d.device)))
         ctx.save_for_backward(y)
         ctx.dt = d.dtype
         return y
@@ -121,9 +121,9 @@ class BoxRefineFunction(torch.autograd.Function):
         y, = ctx.saved_tensors
         gy = gy.float().contiguous()
         gd = torch.empty(y.shape, dtype=ctx.dt, device=y.device)
-        with torch.cuda.device(y.device):
+        with _lib.on_device(y.device):
             _lib.check(_lib.load().msda_box_refine_backward(gy.data_ptr(), y.data_ptr(), y.numel(), gd.data_ptr(), int(ctx.dt == torch.bfloat16),
-                                                           torch.cuda.current_stream(y.device).cuda_stream))
+                                                           _lib.raw_stream(y.device)))
         return gd, None, None
 
 
@@ -149,9 +149,9 @@ def sine_embed_bf16(boxes, pe_dim=128):
         b = b.float().contiguous()
     ld, rows = (b.stride(-2), b.numel() // dims) if b.dim() >= 2 else (dims, 1)
     out = torch.empty(b.shape[:-1] + (dims * pe_dim,), dtype=torch.bfloat16, device=b.device)
-    with torch.cuda.device(b.device):
+    with _lib.on_device(b.device):
         _lib.check(_lib.load().msda_sine_embed_bf16(b.data_ptr(), ld, rows, dims, pe_dim, 10000.0, out.data_ptr(),
-                                                   torch.cuda.current_stream(b.device).cuda_stream))
+                                                   _lib.raw_stream(b.device)))
     return out
 
 

@@ -27,9 +27,9 @@ class ROIAlign:
         if r.shape[0] == 0:
             return out
         fn = getattr(_lib.load(), "msda_roi_align_forward_" + ("f32" if dt == torch.float32 else "f64"))
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(fn(x.data_ptr(), r.data_ptr(), r.shape[0], N, C, H, W, ph, pw, self.spatial_scale, self.sampling_ratio,
-                          int(self.aligned), out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream))
+                          int(self.aligned), out.data_ptr(), _lib.raw_stream(x.device)))
         return out
 
     __call__ = forward

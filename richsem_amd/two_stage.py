@@ -16,7 +16,7 @@ from .dn import topk_indices
 
 
 def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+    return _lib.raw_stream(dev)
 
 
 class ClassScorer:
@@ -52,7 +52,7 @@ class ClassScorer:
         n = ctypes.c_int64(0)
         _lib.check(L.msda_cls_packed_elems(self.classes, ctypes.byref(n)))
         self.packed = torch.empty(n.value, dtype=torch.int16, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.msda_cls_pack(G.data_ptr(), self.classes, A.data_ptr(), 256, self.packed.data_ptr(), _stream(dev)))
         return self
 
@@ -71,7 +71,7 @@ class ClassScorer:
         scores = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
         if tokens == 0:
             return scores
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.load().msda_cls_max_scores(x.data_ptr(), int(x.dtype == torch.bfloat16), self.packed.data_ptr(), tokens, 256,
                                                        self.classes, self.scale, self.parts, scores.data_ptr(), _stream(x.device)))
         return scores
