@@ -132,13 +132,17 @@ def train(args):
     if args.ours_only:
         print(f"forward + backward {t:.2f} ms")
         return
-    ConvAffineFunction.library_wgrad = True
+    from richsem_amd.backbone import Bottleneck
+    Bottleneck.fused = False                      # one autograd node per convolution (the form before round 4) ...
+    t_nodes = timeit(step, args.reps)
+    ConvAffineFunction.library_wgrad = True       # ... and that form with MIOpen's weight gradients
     t_lib = timeit(step, args.reps)
     ConvAffineFunction.library_wgrad = False
+    Bottleneck.fused = True
     t_t = timeit(step_t, args.reps)
     t_f = timeit(lambda: net(x), args.reps)
     print(f"ResNet-50 at 2 x 800 x 1344, layer2-4 trained: forward + backward on the library's kernels {t:.2f} ms (forward alone {t_f:.2f}; "
-          f"with MIOpen weight gradients {t_lib:.2f});  PyTorch bf16 channels-last autograd {t_t:.2f} ms")
+          f"one autograd node per convolution {t_nodes:.2f}, that with MIOpen weight gradients {t_lib:.2f});  PyTorch bf16 channels-last autograd {t_t:.2f} ms")
 
 
 def main():
