@@ -408,6 +408,8 @@ int msda_conv_dgrad_fused_bf16(const uint16_t *dy, const uint16_t *packed_weight
  * that follows the convolution commutes with the pixel sum).  torch_layout != 0: dw is written as (Cout, Cin, KH, KW), nn.Conv2d's layout.
  * Cout % 128 == 0, Cin % 128 == 0. */
 int msda_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t *bytes);
+/* Tuning / tests: 1 (default) = operand stages prefetched three ahead through an LDS ring (LDS DMA), 0 = register-staged; same results */
+int msda_conv_set_wgrad_ring(int on);
 int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                          int pad, float *dw, float *dbias, const float *scale, int torch_layout, void *workspace, msda_stream_t stream);
 

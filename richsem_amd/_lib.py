@@ -67,7 +67,7 @@ SYMBOLS = [
     "msda_attn_workspace_bytes", "msda_attn_forward_bf16", "msda_attn_backward_bf16",
     "msda_matcher_cost_f32", "msda_matcher_cost_f64", "msda_focal_neg_sum_f32", "msda_focal_neg_grad_f32", "msda_attnpool_core_f32", "msda_attnpool_core_f64",
     "msda_cls_packed_elems", "msda_cls_pack", "msda_cls_max_scores",
-    "msda_conv_set_tiling", "msda_conv_set_ring", "msda_conv_dgrad_fused_bf16", "msda_conv_packed_elems", "msda_conv_pack_weight", "msda_conv_forward_bf16", "msda_conv_dgrad_bf16", "msda_conv_forward_workspace_bytes", "msda_conv_forward_ws_bf16", "msda_conv_dgrad_workspace_bytes", "msda_conv_dgrad_ws_bf16", "msda_pool_nhwc_bf16", "msda_groupnorm8_nhwc_bf16", "msda_groupnorm8_backward_nhwc_bf16", "msda_conv_wgrad_workspace_bytes", "msda_conv_wgrad_bf16", "msda_conv_wgrad_group_workspace_bytes", "msda_conv_wgrad_group_bf16",
+    "msda_conv_set_tiling", "msda_conv_set_ring", "msda_conv_dgrad_fused_bf16", "msda_conv_packed_elems", "msda_conv_pack_weight", "msda_conv_forward_bf16", "msda_conv_dgrad_bf16", "msda_conv_forward_workspace_bytes", "msda_conv_forward_ws_bf16", "msda_conv_dgrad_workspace_bytes", "msda_conv_dgrad_ws_bf16", "msda_pool_nhwc_bf16", "msda_groupnorm8_nhwc_bf16", "msda_groupnorm8_backward_nhwc_bf16", "msda_conv_wgrad_workspace_bytes", "msda_conv_wgrad_bf16", "msda_conv_set_wgrad_ring", "msda_conv_wgrad_group_workspace_bytes", "msda_conv_wgrad_group_bf16",
 ]
 
 
@@ -182,6 +182,8 @@ def load():
     L.msda_conv_wgrad_bf16.restype = ci
     L.msda_conv_wgrad_workspace_bytes.argtypes = [ci] * 9 + [ctypes.POINTER(i64)]
     L.msda_conv_wgrad_workspace_bytes.restype = ci
+    L.msda_conv_set_wgrad_ring.argtypes = [ci]
+    L.msda_conv_set_wgrad_ring.restype = ci
     L.msda_conv_wgrad_group_workspace_bytes.argtypes = [ctypes.POINTER(WgradProblem), ci, ctypes.POINTER(i64)]
     L.msda_conv_wgrad_group_workspace_bytes.restype = ci
     L.msda_conv_wgrad_group_bf16.argtypes = [ctypes.POINTER(WgradProblem), ci, vp, vp]

@@ -21,6 +21,8 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/richsem_msda.h"
 
 extern "C" int msda_note_error(int code, const char *entry);      // msda_api.hip: sets msda_last_error()
@@ -199,12 +201,229 @@ __device__ __forceinline__ void wgrad_block(const uint16_t *__restrict__ dz, con
         }
 }
 
-__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const uint16_t *__restrict__ dz, const uint16_t *__restrict__ x,
+// ---- the same workgroup with its operand stages prefetched THREE stages ahead through an LDS ring filled by LDS DMA (round 4) ---------
+// wgrad_block asks for a stage one stage ahead (registers: a second set spills) and a stage is 512 MFMA cycles per wave: a workgroup's stage
+// takes what a memory round trip takes (2.07 us per stage at the feed-forward block's 44646 tokens: the matrix pipe 20 % busy at two
+// workgroups per CU).  Here a stage is 32 pixels (one k-step: 8 KB of each operand, the same swizzled 256-byte-row image), the ring four
+// stages (the same 64 KB), and the rows go from memory to LDS without passing through registers: global_load_lds_dwordx4 writes lane l's
+// 16 bytes at (base + 16 l), i.e. row (l / 16) and chunk SLOT (l % 16) of four consecutive rows -- so the lane fetches the chunk that
+// BELONGS in that slot, ch = slot ^ swizzle(row) (the swizzle is applied on the memory side; rows beyond the chunk's pixels or in the
+// padding come from a zero line).  A wave brings rows 8 w .. 8 w + 7 of both images: four requests per stage.  A stage begins with
+// s_waitcnt vmcnt(8) (two younger stages may be in flight) and one bare s_barrier; the transposed operand reads are inline
+// ds_read_b64_tr_b16 (the compiler would wait for every DMA in flight before an LDS read it can see), released in four steps by lgkmcnt.
+// The bias gradient, which wgrad_block sums from its staging registers, is a fifth column of products here: A fragments x a fragment of ones.
+__device__ __attribute__((aligned(16))) unsigned g_wgrad_zero_line[4];      // (device globals are zero-initialised)
+
+constexpr int kRingStagePx = 32, kRingSlots = 4, kRingImage = kRingStagePx * 256, kRingSlotBytes = 2 * kRingImage;
+static_assert(kRingSlots * kRingSlotBytes == 2 * 2 * kImageBytes, "the ring is the old double buffer's LDS");
+
+#ifndef WGRAD_RING_ABLATE      // diagnostic builds (wrong results): 1 = no requests inside the loop, 2 = no products, 4 = no barrier, 8 = plain 8-byte reads, 16 = no MFMAs
+#define WGRAD_RING_ABLATE 0
+#endif
+#if WGRAD_RING_ABLATE & 8
+#define WG_TR_READ(dst, addr, byte_off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(byte_off))
+#else
+#define WG_TR_READ(dst, addr, byte_off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(byte_off))
+#endif
+#define WG_LDS_WAIT(n, a, b) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(n))
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct WgradRing {      // a workgroup's request side: the two rows (of four consecutive image rows each) a lane requests per stage and operand
+    int rp[2], rn[2], rho[2], rwo[2];
+    const uint16_t *acol[2], *bcol[2];      // the lane's chunk of a dz row / an x row (channel block and swizzled chunk folded in)
+    unsigned char *ring;
+    const uint16_t *zero;
+    int wave, P1, kh, kw;
+
+    // requests of one stage into ring slot `slot`; advances the rows by a stage (past the chunk's last pixel: zero lines)
+    __device__ __forceinline__ void request(int slot, const WgradGeom &g)
+    {
+        request_row(0, slot, g);
+        request_row(1, slot, g);
+    }
+
+    // ... one of its two halves (a dz row and an x row of the lane: two requests), so that the loop can place them between its MFMA groups
+    __device__ __forceinline__ void request_row(int j, int slot, const WgradGeom &g)
+    {
+        {
+            const bool live = rp[j] < P1;
+            const int hi = rho[j] * g.stride + kh - g.pad, wi = rwo[j] * g.stride + kw - g.pad;
+            const bool in = live && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+            const uint16_t *pa = live ? acol[j] + (size_t)rp[j] * g.Cout : zero;
+            const uint16_t *pb = in ? bcol[j] + ((size_t)(rn[j] * g.H + hi) * g.W + wi) * g.Cin : zero;
+            unsigned char *dst = ring + slot * kRingSlotBytes + (8 * wave + 4 * j) * 256;
+            __builtin_amdgcn_global_load_lds(pa, reinterpret_cast<__attribute__((address_space(3))) void *>(reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(pb, reinterpret_cast<__attribute__((address_space(3))) void *>(reinterpret_cast<uintptr_t>(dst + kRingImage)), 16,
+                                             0, 0);
+            rp[j] += kRingStagePx;
+            rwo[j] += kRingStagePx;
+            while (rwo[j] >= g.Wo) {
+                rwo[j] -= g.Wo;
+                if (++rho[j] == g.Ho) {
+                    rho[j] = 0;
+                    ++rn[j];
+                }
+            }
+        }
+    }
+};
+
+// the products of the stage in the ring slot at byte offset `so` (a run-time slot: unrolling the loop over the four slots for immediate
+// offsets gave every slot its own set of accumulators, 64 register moves per trip and spills whose reloads drained the DMA queue)
+template <bool BIAS>
+__device__ __forceinline__ void wgrad_ring_products(f32x4 (&acc)[4][4], f32x4 (&bacc)[4], const unsigned (&aa)[2][4], const unsigned (&ab)[2][4], unsigned so,
+                                                    bool want_bias, WgradRing &rq, int req_slot, const WgradGeom &g)
+{
+    constexpr int oa = 0, ob = kRingImage;
+    u32x2 fa[4][2], fb[4][2];
+    // order of the reads = order of the waits: A tile 0, the four B tiles, then A tiles 1-3
+    WG_TR_READ(fa[0][0], aa[0][0] + so, oa); WG_TR_READ(fa[0][1], aa[1][0] + so, oa);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { WG_TR_READ(fb[t][0], ab[0][t] + so, ob); WG_TR_READ(fb[t][1], ab[1][t] + so, ob); }
+#pragma unroll
+    for (int t = 1; t < 4; ++t) { WG_TR_READ(fa[t][0], aa[0][t] + so, oa); WG_TR_READ(fa[t][1], aa[1][t] + so, oa); }
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+#define WG_FRAG(f) __builtin_bit_cast(bf16x8, (u32x4){(f)[0][0], (f)[0][1], (f)[1][0], (f)[1][1]})
+#define WG_ROW(A_, NEWER)                                                                                                      \
+    WG_LDS_WAIT(NEWER, fa[A_][0], fa[A_][1]);                                                                                  \
+    {                                                                                                                          \
+        const bf16x8 a = WG_FRAG(fa[A_]);                                                                                      \
+        _Pragma("unroll") for (int b = 0; b < ((WGRAD_RING_ABLATE & 16) ? 1 : 4); ++b)                                         \
+            acc[A_][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, WG_FRAG(fb[b]), acc[A_][b], 0, 0, 0);                      \
+        if (BIAS && want_bias) bacc[A_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, bacc[A_], 0, 0, 0);                 \
+    }
+    asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]));      // (the B fragments are read by the MFMAs only behind ...
+    asm volatile("" : "+v"(fb[2][0]), "+v"(fb[2][1]), "+v"(fb[3][0]), "+v"(fb[3][1]));
+    // the next-but-two stage's requests go between the MFMA groups (an LDS-DMA instruction holds its wave for ~100 cycles of issue: under
+    // the matrix pipe's work instead of in front of it); the scheduling barriers keep the groups where they are written
+    WG_ROW(0, 6)      // ... this wait: at most A tiles 1-3 (six reads) still in flight)
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(WGRAD_RING_ABLATE & 1)) rq.request_row(0, req_slot, g);
+    __builtin_amdgcn_sched_barrier(0);
+    WG_ROW(1, 4)
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(WGRAD_RING_ABLATE & 1)) rq.request_row(1, req_slot, g);
+    __builtin_amdgcn_sched_barrier(0);
+    WG_ROW(2, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    WG_ROW(3, 0)
+#undef WG_ROW
+#undef WG_FRAG
+}
+
+template <bool BIAS>
+__device__ __forceinline__ void wgrad_block_ring(const uint16_t *__restrict__ dz, const uint16_t *__restrict__ x, float *__restrict__ dw,
+                                                 float *__restrict__ dbias, const float *__restrict__ scale, int direct, const WgradGeom &g, int bx,
+                                                 int by_, unsigned char *ring)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb_ci = g.Cin / kBN, nb_co = g.Cout / kBM;
+    int by = by_;
+    const int cib = by % nb_ci;
+    by /= nb_ci;
+    const int cob = by % nb_co, tap = by / nb_co;
+    const long long p0 = (long long)bx * g.chunk;
+    const long long p1 = p0 + g.chunk < g.P ? p0 + g.chunk : g.P;
+    const int n_stage = (int)((p1 - p0 + kRingStagePx - 1) / kRingStagePx);
+
+    // request side: rows 8 wave + 4 j + lane / 16 of a stage, chunk slot lane % 16 -> chunk (slot ^ swizzle(row)) of the pixel's 256-byte row
+    WgradRing rq;
+    rq.ring = ring;
+    rq.zero = reinterpret_cast<const uint16_t *>(g_wgrad_zero_line);
+    rq.wave = wave;
+    rq.P1 = (int)p1;
+    rq.kh = tap / g.KW;
+    rq.kw = tap - rq.kh * g.KW;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 8 * wave + 4 * j + (lane >> 4);
+        const int chunk = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
+        rq.acol[j] = dz + cob * kBM + chunk * 8;
+        rq.bcol[j] = x + cib * kBN + chunk * 8;
+        rq.rp[j] = (int)p0 + r;
+        const int pc = rq.rp[j] < (int)g.P ? rq.rp[j] : 0;
+        rq.rwo[j] = pc % g.Wo;
+        rq.rho[j] = (pc / g.Wo) % g.Ho;
+        rq.rn[j] = pc / (g.Wo * g.Ho);
+    }
+
+    f32x4 acc[4][4], bacc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        bacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // read side: lane = (group gI = lane / 16, i = lane % 16 = 4 q + p): rows r = 8 gI + q and r + 4 of the stage, chunk 2 tile + (p >> 1),
+    // half p & 1 (wgrad_block's frag)
+    const int gI = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int wm = wave & 1, wn = wave >> 1;
+    unsigned aa[2][4], ab[2][4];
+    const unsigned base = (unsigned)(uintptr_t)ring;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int r = 8 * gI + q + 4 * v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            aa[v][t] = base + lds_off(r, 2 * (4 * wm + t) + (pp >> 1)) + 8 * (pp & 1);
+            ab[v][t] = base + lds_off(r, 2 * (4 * wn + t) + (pp >> 1)) + 8 * (pp & 1);
+        }
+    }
+
+    // three stages ahead (stages past the chunk's end are zero lines: the request count per stage is a constant)
+#pragma unroll
+    for (int r = 0; r < kRingSlots - 1; ++r) rq.request(r, g);
+    const bool want_bias = BIAS && dbias != nullptr && tap == 0 && cib == 0 && wn == 0;
+    int slot = 0;
+    for (int st = 0; st < n_stage; ++st) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this stage has landed (this wave's requests; two younger stages may be in flight)
+        if (!(WGRAD_RING_ABLATE & 4)) __builtin_amdgcn_s_barrier();      // ... everybody's; and the slot of stage st - 1 is free
+        if (WGRAD_RING_ABLATE & 2) { rq.request((slot + kRingSlots - 1) % kRingSlots, g); slot = (slot + 1) % kRingSlots; continue; }
+        wgrad_ring_products<BIAS>(acc, bacc, aa, ab, (unsigned)slot * kRingSlotBytes, want_bias, rq, (slot + kRingSlots - 1) % kRingSlots, g);      // (+ stage st + 3's requests)
+        slot = (slot + 1) % kRingSlots;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the zero-line requests past the end)
+
+    const int taps = g.KH * g.KW;
+    float *out = dw + (size_t)bx * g.Cout * taps * g.Cin;
+    if (want_bias) {      // every column of the ones product is the row sum: column 0's lanes write it (rows 16 (4 wm + a) + 4 gI + i)
+        if (li == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dbias[(size_t)bx * g.Cout + cob * kBM + 16 * (4 * wm + a) + 4 * gI + i] = bacc[a][i];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int ci = cib * kBN + 16 * (4 * wn + b) + li;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = cob * kBM + 16 * (4 * wm + a) + 4 * gI + i;
+                if (direct)
+                    out[g.torch_layout ? ((long long)co * g.Cin + ci) * taps + tap : ((long long)co * taps + tap) * g.Cin + ci] =
+                        acc[a][b][i] * (scale ? scale[co] : 1.f);
+                else
+                    out[((long long)co * taps + tap) * g.Cin + ci] = acc[a][b][i];
+            }
+        }
+}
+
+template <bool RING, bool BIAS>
+__global__ __launch_bounds__(kThreads, 2)      // (two workgroups per CU: without the hint the unrolled ring loop is given a fresh set of accumulators per slot)
+void conv_wgrad_kernel(const uint16_t *__restrict__ dz, const uint16_t *__restrict__ x,
                                                               float *__restrict__ dw, float *__restrict__ dbias,
                                                               const float *__restrict__ scale, int direct, WgradGeom g)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * kImageBytes];   // [buffer][A image | B image]
-    wgrad_block(dz, x, dw, dbias, scale, direct, g, blockIdx.x, blockIdx.y, lds);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * kImageBytes];   // [buffer][A image | B image], or the ring's four slots
+    if constexpr (RING)
+        wgrad_block_ring<BIAS>(dz, x, dw, dbias, scale, direct, g, blockIdx.x, blockIdx.y, &lds[0][0]);
+    else
+        wgrad_block(dz, x, dw, dbias, scale, direct, g, blockIdx.x, blockIdx.y, lds);
 }
 
 // Several weight gradients in ONE launch (a bottleneck block's three or four: msda_conv_wgrad_group_bf16).  Each problem alone would be
@@ -222,7 +441,8 @@ struct WgradGroup {
     int n;
 };
 
-__global__ __launch_bounds__(kThreads) void conv_wgrad_group_kernel(WgradGroup grp)
+template <bool RING>
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_group_kernel(WgradGroup grp)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * kImageBytes];
     int j = 0;
@@ -230,7 +450,11 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_group_kernel(WgradGroup g
     for (int i = 1; i < kMaxGroup; ++i)
         if (i < grp.n && (int)blockIdx.x >= grp.first[i]) j = i;      // (uniform)
     const int local = (int)blockIdx.x - grp.first[j], split = grp.split[j];
-    wgrad_block(grp.dz[j], grp.x[j], grp.part[j], nullptr, grp.scale[j], split > 1 ? 0 : 1, grp.g[j], local % split, local / split, lds);
+    if constexpr (RING)
+        wgrad_block_ring<false>(grp.dz[j], grp.x[j], grp.part[j], nullptr, grp.scale[j], split > 1 ? 0 : 1, grp.g[j], local % split, local / split,
+                                &lds[0][0]);
+    else
+        wgrad_block(grp.dz[j], grp.x[j], grp.part[j], nullptr, grp.scale[j], split > 1 ? 0 : 1, grp.g[j], local % split, local / split, lds);
 }
 
 // the reduction of a group's split problems: 64 float4 elements per workgroup-iteration as in conv_wgrad_reduce_kernel
@@ -368,6 +592,8 @@ void wgrad_split(const WgradGeom &g, long long &split, long long &chunk)
     split = (g.P + chunk - 1) / chunk;
 }
 
+std::atomic<int> g_wgrad_ring{1};      // msda_conv_set_wgrad_ring: 1 = operand stages through the LDS ring (wgrad_block_ring), 0 = register-staged
+
 // a group's plan: the problems share ~512 workgroups in proportion to their work (pixels x taps x channel blocks), each chunk at least
 // 256 pixels (4 stages)
 int plan_group(const msda_wgrad_problem *probs, int n, WgradGroup &grp, int64_t &ws_floats)
@@ -448,7 +674,10 @@ int msda_conv_wgrad_group_bf16(const msda_wgrad_problem *problems, int n, void *
         if (grp.split[j] > 1) ws += (int64_t)grp.split[j] * p.Cout * p.KH * p.KW * p.Cin;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(conv_wgrad_group_kernel, dim3((unsigned)grp.first[n]), dim3(kThreads), 0, st, grp);
+    if (g_wgrad_ring.load())
+        hipLaunchKernelGGL(conv_wgrad_group_kernel<true>, dim3((unsigned)grp.first[n]), dim3(kThreads), 0, st, grp);
+    else
+        hipLaunchKernelGGL(conv_wgrad_group_kernel<false>, dim3((unsigned)grp.first[n]), dim3(kThreads), 0, st, grp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const long long total = grp.red_first[n];
@@ -458,6 +687,15 @@ int msda_conv_wgrad_group_bf16(const msda_wgrad_problem *problems, int n, void *
         e = hipGetLastError();
     }
     return e == hipSuccess ? MSDA_OK : (int)e;
+}
+
+/* Tuning / tests: 1 (default) = the weight-gradient kernels prefetch their operand stages three ahead through an LDS ring (LDS DMA);
+ * 0 = the register-staged form (one stage ahead).  Same products, same order: same results. */
+int msda_conv_set_wgrad_ring(int on)
+{
+    if (on != 0 && on != 1) return msda_note_error(MSDA_ERR_BAD_OPTION, __func__);
+    g_wgrad_ring = on;
+    return MSDA_OK;
 }
 
 /* bytes of workspace msda_conv_wgrad_bf16 needs for a problem (0: none) */
@@ -497,9 +735,14 @@ int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, in
     if (split > 1 && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15))) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     if (blocks_y > 65535) return msda_note_error(MSDA_ERR_TOO_LARGE, __func__);
     float *ws_bias = split > 1 ? static_cast<float *>(workspace) + split * n_dw : nullptr;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)split, (unsigned)blocks_y), dim3(kThreads), 0, st, dz, x,
-                       split > 1 ? static_cast<float *>(workspace) : dw, dbias ? (split > 1 ? ws_bias : dbias) : nullptr, scale, split > 1 ? 0 : 1,
-                       g);
+    const dim3 grid((unsigned)split, (unsigned)blocks_y);
+    float *part = split > 1 ? static_cast<float *>(workspace) : dw, *bpart = dbias ? (split > 1 ? ws_bias : dbias) : nullptr;
+    if (!g_wgrad_ring.load())
+        hipLaunchKernelGGL((conv_wgrad_kernel<false, true>), grid, dim3(kThreads), 0, st, dz, x, part, bpart, scale, split > 1 ? 0 : 1, g);
+    else if (dbias)
+        hipLaunchKernelGGL((conv_wgrad_kernel<true, true>), grid, dim3(kThreads), 0, st, dz, x, part, bpart, scale, split > 1 ? 0 : 1, g);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<true, false>), grid, dim3(kThreads), 0, st, dz, x, part, bpart, scale, split > 1 ? 0 : 1, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (split > 1) {

@@ -165,6 +165,43 @@ def test_fused_input_gradient_epilogue(case, slots):
     assert bool((fused[act <= 0] == 0).all())
 
 
+@pytest.mark.parametrize("case", [(2, 26, 30, 128, 128, 1, 1, 0), (2, 26, 30, 256, 128, 3, 1, 1), (1, 31, 17, 128, 256, 3, 2, 1), (3, 9, 7, 512, 128, 1, 2, 0),
+                                  (1, 1, 5000, 256, 384, 1, 1, 0), (1, 1, 37, 128, 128, 1, 1, 0), (1, 40, 40, 128, 128, 5, 1, 2)], ids=str)
+def test_weight_gradient_ring_is_bit_identical_to_the_register_staged_kernel(case):
+    """wgrad_block_ring (stages of 32 pixels three ahead through an LDS ring by LDS DMA, bias gradient as a product with ones) against
+    wgrad_block: the same MFMAs over the same k-steps in the same order -- equal bits for dw; the bias sums are formed in a different order"""
+    import ctypes
+    from richsem_amd import _lib
+    N, H, W, Cin, Cout, k, stride, pad = case
+    L = _lib.load()
+    torch.manual_seed(hash(case) % 997)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    x = torch.randn(N, H, W, Cin, device="cuda").to(torch.bfloat16)
+    dz = torch.randn(N, Ho, Wo, Cout, device="cuda").to(torch.bfloat16)
+    nb = ctypes.c_int64(0)
+    _lib.check(L.msda_conv_wgrad_workspace_bytes(N, H, W, Cin, Cout, k, k, stride, pad, ctypes.byref(nb)))
+    res = {}
+    for ring in (1, 0):
+        try:
+            _lib.check(L.msda_conv_set_wgrad_ring(ring))
+            dw = torch.full((Cout, k, k, Cin), float("nan"), device="cuda")
+            db = torch.full((Cout,), float("nan"), device="cuda")
+            ws = torch.full((max(nb.value // 4, 1),), float("nan"), device="cuda")
+            _lib.check(L.msda_conv_wgrad_bf16(dz.data_ptr(), x.data_ptr(), N, H, W, Cin, Cout, k, k, stride, pad, dw.data_ptr(), db.data_ptr(), None, 0,
+                                              ws.data_ptr(), _lib.raw_stream(x.device)))
+            res[ring] = (dw, db)
+        finally:
+            _lib.check(L.msda_conv_set_wgrad_ring(1))
+    assert torch.equal(res[1][0], res[0][0]), float((res[1][0] - res[0][0]).abs().max())
+    want_b = dz.float().sum(dim=(0, 1, 2))
+    for ring in (1, 0):
+        assert float((res[ring][1] - want_b).abs().max()) <= 1e-4 * float(want_b.abs().max()) + 1e-4, ring
+    # and against the definition (fp32 products of the bf16 operands, on the GPU)
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).float(), (Cout, Cin, k, k), dz.permute(0, 3, 1, 2).float(), stride=stride, padding=pad)
+    got = res[1][0].permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
 def test_grouped_weight_gradients_equal_the_single_launches():
     """msda_conv_wgrad_group_bf16 (a bottleneck block's weight gradients sharing one launch) against msda_conv_wgrad_bf16 per problem: the
     pixel chunks differ, so the sums differ in order only"""
