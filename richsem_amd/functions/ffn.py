@@ -114,6 +114,52 @@ class FusedFFNFunction(Function):
         return grad_x, grad_w1, grad_b1, grad_w2, grad_b2, grad_ln_w, grad_ln_b, None
 
 
+def pack_ffn(linear1_weight, linear1_bias, linear2_weight):
+    """The derived forms :class:`FusedFFNCachedFunction` runs the feed-forward block from (kept by the layer in a ``VersionCache``: rebuilt
+    when a parameter changes, not per call and not again in the backward): linear1.weight as bf16 and in lin256's fragment order,
+    linear2.weight in the fused kernel's hidden-column order and its transpose in lin256's order, linear1.bias as float32."""
+    from .linear import lin256_pack
+    w1_16 = linear1_weight.detach().to(torch.bfloat16).contiguous()
+    w2_16 = linear2_weight.detach().to(torch.bfloat16).contiguous()
+    return {"w1_16": w1_16, "w1_packed": lin256_pack(w1_16), "w2_ffn": pack_w2_bf16(w2_16), "w2t_packed": lin256_pack(w2_16.t().contiguous()),
+            "b1_32": linear1_bias.detach().float().contiguous()}
+
+
+class FusedFFNCachedFunction(Function):
+    """:class:`FusedFFNFunction` for a caller that keeps the packed parameters (``pk`` from :func:`pack_ffn`) across calls and hands over the
+    float32 master parameters themselves: ``apply(x, pk, eps, linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm.weight,
+    norm.bias)``.  No cast / pack / transpose kernels per call (the uncached form runs three in the forward and four in the backward), and
+    the weight gradients reach the parameters in float32 as the kernel sums them -- not rounded to bf16 on the way through a cast node."""
+
+    @staticmethod
+    def forward(ctx, x, pk, eps, w1, b1, w2, b2, ln_weight, ln_bias):
+        lw, lb = ln_weight.detach().float().contiguous(), ln_bias.detach().float().contiguous()
+        out, rstd, yhat = ffn_forward_bf16(x, pk["w1_16"], pk["b1_32"], pk["w2_ffn"], b2.detach().float().contiguous(), lw, lb, eps,
+                                           return_rstd=True)
+        ctx.save_for_backward(x, lw, yhat, rstd)
+        ctx.pk, ctx.dts = pk, tuple(p.dtype for p in (w1, b1, w2, b2, ln_weight, ln_bias))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        from .linear import lin256, linear_wgrad_bf16
+        x, lw, yhat, rstd = ctx.saved_tensors
+        pk, dts = ctx.pk, ctx.dts
+        x2 = x.reshape(-1, x.shape[-1])
+        dz, g_lnw, g_lnb, g_b2 = ffn_ln_backward_bf16(grad_out.to(torch.bfloat16), yhat, rstd, lw)
+        h = lin256(x2, pk["w1_packed"], pk["b1_32"], relu=True)                 # the hidden activation, recomputed
+        need = ctx.needs_input_grad
+        g_w2 = linear_wgrad_bf16(dz, h).to(dts[2]) if need[5] else None
+        gh = lin256(dz, pk["w2t_packed"], relu_mask=h)                           # gradient at the ReLU's input
+        g_w1 = g_b1 = None
+        if need[3] or need[4]:
+            g_w1, g_b1 = linear_wgrad_bf16(gh, x2.contiguous(), with_bias=True)
+            g_w1, g_b1 = g_w1.to(dts[0]), g_b1.to(dts[1])
+        dx = torch.addmm(dz, gh, pk["w1_16"]).view(x.shape) if need[0] else None
+        return dx, None, None, g_w1, g_b1, g_w2, g_b2.to(dts[3]), g_lnw.to(dts[4]), g_lnb.to(dts[5])
+
+
 def add_layernorm_forward_bf16(a2, b2, ln_weight32, ln_bias32, eps, need_backward=True):
     """LayerNorm(a2 + b2) over 256 channels, (tokens, 256) bf16 -> out, and (for the backward) rstd (tokens) f32, yhat (tokens, 256) bf16"""
     out = torch.empty_like(a2)

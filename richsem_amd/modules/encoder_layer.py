@@ -14,7 +14,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions.ffn import FUSED_FFN_MIN_TOKENS, AddLayerNormFunction, FusedFFNFunction
+from ..functions.ffn import FUSED_FFN_MIN_TOKENS, AddLayerNormFunction, FusedFFNCachedFunction, FusedFFNFunction, pack_ffn
+from ..functions.linear import VersionCache, linear_wgrad_supported
 from .ms_deform_attn import MSDeformAttn
 
 
@@ -47,6 +48,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.fused_ffn = True
         self.fused_min_tokens = FUSED_FFN_MIN_TOKENS   # below it the op sequence is faster (functions/ffn.py)
+        self._ffn_pack = VersionCache()                 # packed forms of linear1 / linear2 (rebuilt when a parameter changes)
 
     @staticmethod
     def with_pos_embed(tensor, pos):
@@ -59,7 +61,12 @@ class DeformableTransformerEncoderLayer(nn.Module):
                 and src.numel() // src.shape[-1] >= self.fused_min_tokens)
 
     def forward_ffn(self, src):
-        if self._ffn_fusable(src):
+        if self._ffn_fusable(src) and self.linear1.out_features % 128 == 0 and linear_wgrad_supported(256, self.linear1.out_features):
+            pk = self._ffn_pack.get((self.linear1.weight, self.linear1.bias, self.linear2.weight),
+                                    lambda: pack_ffn(self.linear1.weight, self.linear1.bias, self.linear2.weight))
+            return FusedFFNCachedFunction.apply(src, pk, self.norm2.eps, self.linear1.weight, self.linear1.bias, self.linear2.weight,
+                                                self.linear2.bias, self.norm2.weight, self.norm2.bias)
+        if self._ffn_fusable(src):      # (hidden widths the weight-gradient kernel does not take: parameters cast / packed per call)
             return FusedFFNFunction.apply(src, self.linear1.weight.to(torch.bfloat16), self.linear1.bias.float(),
                                           self.linear2.weight.to(torch.bfloat16), self.linear2.bias.float(),
                                           self.norm2.weight.float(), self.norm2.bias.float(), self.norm2.eps)

@@ -97,6 +97,35 @@ def test_function_gradients_match_fp32_autograd():
         assert float(err.mean()) / (float(b.grad.abs().mean()) + 1e-12) < 2e-2, name
 
 
+def test_cached_function_equals_the_uncached_one_and_keeps_fp32_weight_gradients():
+    """FusedFFNCachedFunction (packed parameters kept by the caller, float32 master parameters handed over) against FusedFFNFunction on
+    the bf16 casts: the same kernels -> equal output and equal input gradient; weight gradients equal before the uncached form's bf16
+    rounding, and closer to fp32 autograd than it"""
+    from richsem_amd.functions.ffn import FusedFFNCachedFunction, pack_ffn
+    x, w1, b1, w2, b2, gw, gb = make(4608, 256, seed=5)
+    go = torch.randn(4608, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9)).to(torch.bfloat16)
+    masters = [t.float().clone().requires_grad_(True) for t in (w1, b1, w2, b2, gw, gb)]
+    xa = x.clone().requires_grad_(True)
+    pk = pack_ffn(masters[0], masters[1], masters[2])
+    out_c = FusedFFNCachedFunction.apply(xa, pk, 1e-5, *masters)
+    out_c.backward(go)
+    leaves = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2, gw, gb)]
+    out_u = FusedFFNFunction.apply(*leaves, 1e-5)
+    out_u.backward(go)
+    assert torch.equal(out_c, out_u) and torch.equal(xa.grad, leaves[0].grad)
+    refl = [t.float().clone().requires_grad_(True) for t in (x, w1, b1, w2, b2, gw, gb)]
+    ref_fp32(*refl).backward(go.float())
+    for i, name in ((0, "w1"), (2, "w2")):
+        gc, gu, gr = masters[i].grad, leaves[1 + i].grad, refl[1 + i].grad
+        assert gc.dtype == torch.float32 and gu.dtype == torch.bfloat16
+        assert torch.equal(gc.to(torch.bfloat16), gu), name                                  # the uncached form = this one, rounded
+        ec, eu = float((gc - gr).abs().mean()), float((gu.float() - gr).abs().mean())
+        assert ec <= eu * 1.001, (name, ec, eu)
+    for i in (1, 3, 4, 5):      # (bias / LayerNorm gradients: token sums whose order of accumulation is not fixed)
+        a, b = masters[i].grad, leaves[1 + i].grad.float()
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()), i
+
+
 def test_module_fused_path_equals_op_by_op_path_within_bf16():
     torch.manual_seed(0)
     m = FFN(256, 2048, dropout=0.0).cuda()
