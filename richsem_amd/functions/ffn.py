@@ -20,15 +20,17 @@ from .. import _lib
 FUSED_FFN_MIN_TOKENS = 16384
 
 
-def _wgrad(dy, x, with_bias=False):
-    """dW = dy^T x in bf16 (contraction over the tokens): the library's own MFMA kernel where it applies (functions/linear.py: 131 vs
-    208 us at the encoder shape), else the library's transposed GEMM"""
+def _wgrad(dy, x, with_bias=False, fp32=False):
+    """dW = dy^T x (contraction over the tokens): the library's own MFMA kernel where it applies (functions/linear.py: 131 vs
+    208 us at the encoder shape), else the library's transposed GEMM.  bf16 result unless ``fp32`` (the kernel's own sums, for a caller
+    that hands them to float32 master parameters: no cast to bf16 and back)"""
     from .linear import LinearBf16Function, linear_wgrad_bf16, linear_wgrad_supported
     if linear_wgrad_supported(dy.shape[1], x.shape[1]) and dy.shape[0] >= LinearBf16Function.MIN_TOKENS:
         if with_bias:
             dw, db = linear_wgrad_bf16(dy, x.contiguous(), with_bias=True)
-            return dw.to(torch.bfloat16), db
-        return linear_wgrad_bf16(dy, x.contiguous()).to(torch.bfloat16)
+            return (dw if fp32 else dw.to(torch.bfloat16)), db
+        dw = linear_wgrad_bf16(dy, x.contiguous())
+        return dw if fp32 else dw.to(torch.bfloat16)
     dw = dy.t() @ x
     return (dw, dy.sum(0, dtype=torch.float32)) if with_bias else dw
 
@@ -201,11 +203,11 @@ class FFNSmallFunction(Function):
         shape, dts = ctx.meta
         dz, g_lnw, g_lnb, g_b2 = ffn_ln_backward_bf16(grad_out.to(torch.bfloat16), yhat, rstd, lw)
         need = ctx.needs_input_grad
-        g_w2 = _wgrad(dz, h).to(dts[2]) if need[7] else None
+        g_w2 = _wgrad(dz, h, fp32=dts[2] == torch.float32).to(dts[2]) if need[7] else None
         gh = lin256(dz, w2t_packed, relu_mask=h)
         g_w1 = g_b1 = None
         if need[5] or need[6]:
-            g_w1, g_b1 = _wgrad(gh, x2, with_bias=True)
+            g_w1, g_b1 = _wgrad(gh, x2, with_bias=True, fp32=dts[0] == torch.float32)
             g_w1, g_b1 = g_w1.to(dts[0]), g_b1.to(dts[1])
         dx = torch.addmm(dz, gh, w1_16).view(shape) if need[0] else None
         return dx, None, None, None, None, g_w1, g_b1, g_w2, g_b2.to(dts[3]), g_lnw.to(dts[4]), g_lnb.to(dts[5])
