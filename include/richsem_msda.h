@@ -317,6 +317,10 @@ int msda_narrow_linear_backward_bf16(const uint16_t *dy, const uint16_t *x, cons
  * reference detaches it between layers). */
 int msda_box_refine_forward(const void *delta, int delta_is_bf16, const float *ref, float eps, int64_t n, float *y, msda_stream_t stream);
 int msda_box_refine_backward(const float *grad_y, const float *y, int64_t n, void *grad_delta, int delta_is_bf16, msda_stream_t stream);
+/* ... with the gradient w.r.t. ref as well (ref, grad_ref (n) f32; the heads' boxes of decoder layers 1..5, whose reference is not detached:
+ * models/richsem/richsem.py:705-715): grad_ref = grad_delta * d inverse_sigmoid(ref) / d ref, the clamps' gradients as torch takes them */
+int msda_box_refine_backward_ref(const float *grad_y, const float *y, int64_t n, void *grad_delta, int delta_is_bf16, const float *ref, float eps,
+                                 float *grad_ref, msda_stream_t stream);
 
 int msda_sine_embed_bf16(const float *boxes, int ld, int tokens, int dims, int pe_dim, float temperature, uint16_t *out, msda_stream_t stream);
 

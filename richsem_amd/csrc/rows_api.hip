@@ -88,14 +88,23 @@ __global__ __launch_bounds__(256) void box_refine_kernel(const void *__restrict_
     }
 }
 
+// ... and, when `ref` carries a gradient too (the heads' boxes of decoder layers 1..5, richsem.py:705-715: the "look forward twice"
+// reference is not detached there), w.r.t. ref: d inverse_sigmoid / d r = [r_c >= eps] / max(r_c, eps) + [1 - r_c >= eps] / max(1 - r_c, eps)
+// inside [0, 1] (torch's clamp passes the gradient where the bound is not active, bounds included), 0 outside
 template <bool BF16>
 __global__ __launch_bounds__(256) void box_refine_grad_kernel(const float *__restrict__ gy, const float *__restrict__ y, long long n,
-                                                              void *__restrict__ gdelta)
+                                                              void *__restrict__ gdelta, const float *__restrict__ ref, float eps,
+                                                              float *__restrict__ gref)
 {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
         const float v = gy[i] * y[i] * (1.f - y[i]);
         if (BF16) static_cast<__hip_bfloat16 *>(gdelta)[i] = __float2bfloat16(v);
         else static_cast<float *>(gdelta)[i] = v;
+        if (gref) {
+            const float r0 = ref[i], r = fminf(fmaxf(r0, 0.f), 1.f);
+            const float dr = (r >= eps ? 1.f / fmaxf(r, eps) : 0.f) + (1.f - r >= eps ? 1.f / fmaxf(1.f - r, eps) : 0.f);
+            gref[i] = (r0 >= 0.f && r0 <= 1.f) ? v * dr : 0.f;
+        }
     }
 }
 
@@ -269,13 +278,22 @@ int msda_box_refine_forward(const void *delta, int delta_is_bf16, const float *r
 /* grad_delta = grad_y * y * (1 - y), written in delta's type */
 int msda_box_refine_backward(const float *grad_y, const float *y, int64_t n, void *grad_delta, int delta_is_bf16, msda_stream_t stream)
 {
-    if (!grad_y || !y || !grad_delta) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    return msda_box_refine_backward_ref(grad_y, y, n, grad_delta, delta_is_bf16, nullptr, 0.f, nullptr, stream);
+}
+
+/* ... and grad_ref (n) f32 = grad_delta * d inverse_sigmoid(ref) / d ref (the clamps' gradients as torch takes them); ref, grad_ref may be NULL */
+int msda_box_refine_backward_ref(const float *grad_y, const float *y, int64_t n, void *grad_delta, int delta_is_bf16, const float *ref, float eps,
+                                 float *grad_ref, msda_stream_t stream)
+{
+    if (!grad_y || !y || !grad_delta || (grad_ref && !ref)) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     if (n < 1) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     if (delta_is_bf16)
-        hipLaunchKernelGGL(box_refine_grad_kernel<true>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), grad_y, y, (long long)n, grad_delta);
+        hipLaunchKernelGGL(box_refine_grad_kernel<true>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), grad_y, y, (long long)n, grad_delta,
+                           ref, eps, grad_ref);
     else
-        hipLaunchKernelGGL(box_refine_grad_kernel<false>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), grad_y, y, (long long)n, grad_delta);
+        hipLaunchKernelGGL(box_refine_grad_kernel<false>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), grad_y, y, (long long)n, grad_delta,
+                           ref, eps, grad_ref);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
 }

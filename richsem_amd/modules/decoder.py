@@ -99,8 +99,10 @@ def gen_sineembed_for_position(pos_tensor, pe_dim=128):
 
 
 class BoxRefineFunction(torch.autograd.Function):
-    """``(delta + inverse_sigmoid(ref)).sigmoid()`` (deformable_transformer.py:779-804, richsem.py:705-715) for a constant ``ref`` as
-    one launch each way (``msda_box_refine_forward / _backward``): delta bf16 or fp32 on the GPU, ref fp32 -> fp32 boxes"""
+    """``(delta + inverse_sigmoid(ref)).sigmoid()`` (deformable_transformer.py:779-804, richsem.py:705-715) as one launch each way
+    (``msda_box_refine_forward`` / ``msda_box_refine_backward_ref``): delta bf16 or fp32 on the GPU, ref fp32 -> fp32 boxes; gradients for
+    delta and -- where it carries one: the heads' boxes of decoder layers 1..5, whose reference is the previous layer's un-detached box --
+    for ref (inverse_sigmoid's clamps differentiated as torch does)"""
 
     @staticmethod
     def forward(ctx, delta, ref, eps):
@@ -110,28 +112,29 @@ class BoxRefineFunction(torch.autograd.Function):
         with _lib.on_device(d.device):
             _lib.check(_lib.load().msda_box_refine_forward(d.data_ptr(), int(d.dtype == torch.bfloat16), r.data_ptr(), float(eps), d.numel(),
                                                           y.data_ptr(), _lib.raw_stream(d.device)))
-        ctx.save_for_backward(y)
-        ctx.dt = d.dtype
+        ctx.save_for_backward(y, r)
+        ctx.dt, ctx.eps, ctx.ref_dt = d.dtype, float(eps), ref.dtype
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
         from .. import _lib
-        y, = ctx.saved_tensors
+        y, r = ctx.saved_tensors
         gy = gy.float().contiguous()
         gd = torch.empty(y.shape, dtype=ctx.dt, device=y.device)
+        gr = torch.empty(y.shape, dtype=torch.float32, device=y.device) if ctx.needs_input_grad[1] else None
         with _lib.on_device(y.device):
-            _lib.check(_lib.load().msda_box_refine_backward(gy.data_ptr(), y.data_ptr(), y.numel(), gd.data_ptr(), int(ctx.dt == torch.bfloat16),
-                                                           _lib.raw_stream(y.device)))
-        return gd, None, None
+            _lib.check(_lib.load().msda_box_refine_backward_ref(gy.data_ptr(), y.data_ptr(), y.numel(), gd.data_ptr(), int(ctx.dt == torch.bfloat16),
+                                                               r.data_ptr(), ctx.eps, gr.data_ptr() if gr is not None else None,
+                                                               _lib.raw_stream(y.device)))
+        return gd, (gr.to(ctx.ref_dt) if gr is not None else None), None
 
 
 def refine_boxes(delta, ref, eps=1e-3):
-    """``(delta + inverse_sigmoid(ref)).sigmoid()``: on the library's kernel where ``ref`` carries no gradient (the decoder detaches it),
-    the reference's op sequence otherwise"""
-    if delta.is_cuda and delta.dtype in (torch.bfloat16, torch.float32) and not (ref.requires_grad and torch.is_grad_enabled()) \
-            and delta.shape == ref.shape:
+    """``(delta + inverse_sigmoid(ref)).sigmoid()``: on the library's kernels (float32 result) for bf16 / fp32 operands of equal shape on
+    the GPU, the reference's op sequence otherwise"""
+    if delta.is_cuda and delta.dtype in (torch.bfloat16, torch.float32) and ref.dtype == torch.float32 and delta.shape == ref.shape:
         return BoxRefineFunction.apply(delta, ref, eps)
     return (delta.to(ref.dtype) + inverse_sigmoid(ref, eps)).sigmoid()
 

@@ -461,6 +461,16 @@ def test_refine_boxes_kernel_matches_the_op_sequence(dt):
     assert y.dtype == torch.float32 and (y - y2).abs().max() < 2e-6
     tol = 2e-6 if dt == torch.float32 else 2 ** -8
     assert (delta.grad.float() - d2.grad.float()).abs().max() <= tol * max(1.0, float(d2.grad.float().abs().max()))
+    # a reference that carries a gradient (the heads' boxes of decoder layers 1..5): inverse_sigmoid's clamps differentiated as torch does,
+    # incl. the values on and beyond the bounds
+    r1, r2 = ref.clone().requires_grad_(True), ref.clone().requires_grad_(True)
+    d1, d3 = delta.detach().clone().requires_grad_(True), delta.detach().clone().requires_grad_(True)
+    refine_boxes(d1, r1).backward(gy)
+    (d3.float() + inverse_sigmoid(r2)).sigmoid().backward(gy)
+    assert torch.isfinite(r1.grad).all()
+    scale = float(r2.grad.abs().max())
+    assert float((r1.grad - r2.grad).abs().max()) <= 2e-5 * scale, float((r1.grad - r2.grad).abs().max()) / scale
+    assert (d1.grad.float() - d3.grad.float()).abs().max() <= tol * max(1.0, float(d3.grad.float().abs().max()))
 
 
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
