@@ -29,7 +29,7 @@ from richsem_amd.backbone import InputProjection, ResNet50
 from richsem_amd.clip_resnet import ModifiedResNetTeacher
 from richsem_amd.dn import prepare_dn_layout
 from richsem_amd.functions.linear import Lin256Function, VersionCache, pack_linear256
-from richsem_amd.matcher import FocalNegativeSum, HungarianMatcher
+from richsem_amd.matcher import BoxPairLoss, FocalNegativeSum, FocalPositiveSum, HungarianMatcher
 from richsem_amd.modules import (MLP, refine_boxes, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, TransformerDecoder,
                                  clip_box_targets, get_reference_points, inverse_sigmoid)
 from richsem_amd.two_stage import ClassScorer
@@ -342,7 +342,8 @@ class Step(nn.Module):
         loss, L1 + GIoU on the matched pairs and on the denoising queries' positive slots, KL distillation -- formed in ONE pass per kind over
         the stacked outputs: the all-negative focal term of a whole logit tensor is one kernel each way (matcher.FocalNegativeSum), and the
         positive entries / box pairs of the matched, two-stage and denoising parts are concatenated with a weight each (1 / num_boxes, or
-        1 / (num_boxes x groups)) so that every loss formula runs once (a loop over the outputs is ~40 small launches per output and kind).
+        1 / (num_boxes x groups)) so that every loss formula runs once -- as one kernel each (matcher.FocalPositiveSum, matcher.BoxPairLoss:
+        value and gradient in one launch; a loop over the outputs is ~40 small launches per output and kind).
         Tensors in, the loss out."""
         st = self.static
         dev = logits.device
@@ -374,12 +375,11 @@ class Step(nn.Module):
         dn_lab = labels.view(N, -1).repeat(1, groups)[None].expand(nl, -1, -1).reshape(-1)      # every image has `single` boxes here
         x_pos = torch.cat((logits[li, bi, si + pad, labels[tj]], il[ibi, isi, labels[itj]], logits[cst["dn_l"], cst["dn_n"], cst["dn_q"], dn_lab]))
         w_pair = torch.cat((torch.full((li.numel() + ibi.numel(),), 1.0 / num_boxes, dtype=torch.float32, device=dev), cst["w_dn"]))
-        q = x_pos.sigmoid()
-        loss = loss + ((alpha * (1 - q) ** 2 * F.softplus(-x_pos) - (1 - alpha) * q * q * F.softplus(x_pos)) * w_pair).sum()
+        loss = loss + FocalPositiveSum.apply(x_pos, w_pair, alpha)
         # ---- boxes: L1 + GIoU of all pairs at once -------------------------------------------------------------------------------------------
         pb = torch.cat((coords[li, bi, si + pad], ib[ibi, isi], coords[cst["dn_l"], cst["dn_n"], cst["dn_q"]]))
         tb = torch.cat((boxes[tj], boxes[itj], boxes.view(N, -1, 4).repeat(1, groups, 1)[None].expand(nl, -1, -1, -1).reshape(-1, 4)))
-        loss = loss + ((5.0 * (pb - tb).abs().sum(-1) + 2.0 * (1 - giou_pairs(box_cxcywh_to_xyxy(pb), box_cxcywh_to_xyxy(tb)))) * w_pair).sum()
+        loss = loss + BoxPairLoss.apply(pb, tb, w_pair, 5.0, 2.0)
         # ---- distillation: KL of the matched queries' CLIP logits against the teacher's box logits (richsem.py:1255-1300) -------------------
         _, bi, si, tj = m_dis
         loss = loss + 0.5 * F.kl_div(F.log_softmax(clip_logits[bi, si + pad], -1), F.softmax(t_logits[tj], -1), reduction="batchmean")

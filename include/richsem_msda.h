@@ -285,6 +285,16 @@ int msda_focal_neg_sum_f32(const float *logits, const float *row_weight, int64_t
 int msda_focal_neg_grad_f32(const float *logits, const float *row_weight, int64_t rows, int C, float alpha, const float *gscale,
                             float *grad_logits, msda_stream_t stream);
 
+/* The criterion's per-pair tails, one launch each (K pairs, float32): loss[0] <- the weighted sum, grad <- its gradient w.r.t. the
+ * predictions (multiply by the incoming scalar gradient).  msda_box_pair_loss_f32: sum_k w[k] (c_l1 |p_k - t_k|_1 + c_giou (1 - GIoU(p_k,
+ * t_k))) for boxes (cx, cy, w, h) (SetCriterion.loss_boxes, models/richsem/richsem.py:1162-1188; util/box_ops.py:9-64 on the diagonal;
+ * gradients with torch's conventions for |x|, max / min and clamp); msda_focal_pos_sum_f32: sum_k w[k] (alpha (1 - q)^2 softplus(-x_k) -
+ * (1 - alpha) q^2 softplus(x_k)), q = sigmoid(x_k) -- a positive entry's share of the sigmoid focal loss (richsem.py:1124-1160) minus the
+ * all-negative term that msda_focal_neg_sum_f32 counted for it. */
+int msda_box_pair_loss_f32(const float *pred, const float *target, const float *weight, int K, float c_l1, float c_giou, float *loss, float *grad_pred,
+                           msda_stream_t stream);
+int msda_focal_pos_sum_f32(const float *x, const float *weight, int K, float alpha, float *loss, float *grad_x, msda_stream_t stream);
+
 /* ---- integer part of the contrastive-denoising set-up (reference
  * models/richsem/dn_components.py:42-71, 131-179): bit-exact int64 / bool results ---------------------------------
  * msda_dn_indices_i64: cum = exclusive prefix of the per-image box counts (batch + 1 int64 on the device), total = cum[batch],

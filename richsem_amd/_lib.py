@@ -62,7 +62,7 @@ SYMBOLS = [
     "msda_prep_forward_f32", "msda_prep_forward_f64", "msda_prep_backward_f32", "msda_prep_backward_f64",
     "msda_prep_forward_bf16", "msda_prep_backward_bf16", "msda_forward_prep_f32", "msda_forward_prep_f64", "msda_forward_prep_bf16",
     "msda_mask_rows_f32", "msda_mask_rows_f64", "msda_mask_rows_bf16",
-    "msda_dn_indices_i64", "msda_dn_attn_mask_u8", "msda_topk_f32", "msda_sine_embed_bf16", "msda_narrow_linear_backward_bf16", "msda_box_refine_forward", "msda_box_refine_backward", "msda_box_refine_backward_ref", "msda_roi_align_forward_f32", "msda_roi_align_forward_f64",
+    "msda_dn_indices_i64", "msda_dn_attn_mask_u8", "msda_topk_f32", "msda_sine_embed_bf16", "msda_narrow_linear_backward_bf16", "msda_box_refine_forward", "msda_box_refine_backward", "msda_box_refine_backward_ref", "msda_box_pair_loss_f32", "msda_focal_pos_sum_f32", "msda_roi_align_forward_f32", "msda_roi_align_forward_f64",
     "msda_ffn_pack_w2_bf16", "msda_ffn_forward_bf16", "msda_ffn_debug_stamps", "msda_ffn_forward_train_bf16", "msda_ffn_ln_backward_bf16", "msda_add_layernorm_forward_bf16", "msda_lin256_pack_bf16", "msda_lin256_forward_bf16", "msda_lin256_pack_f32", "msda_lin256_forward_f32", "msda_lin256_forward_stacked_bf16",
     "msda_attn_workspace_bytes", "msda_attn_forward_bf16", "msda_attn_backward_bf16",
     "msda_matcher_cost_f32", "msda_matcher_cost_f64", "msda_focal_neg_sum_f32", "msda_focal_neg_grad_f32", "msda_attnpool_core_f32", "msda_attnpool_core_f64",
@@ -130,6 +130,10 @@ def load():
     L.msda_box_refine_backward.restype = ci
     L.msda_box_refine_backward_ref.argtypes = [vp, vp, ctypes.c_int64, vp, ci, vp, ctypes.c_float, vp, vp]
     L.msda_box_refine_backward_ref.restype = ci
+    L.msda_box_pair_loss_f32.argtypes = [vp, vp, vp, ci, ctypes.c_float, ctypes.c_float, vp, vp, vp]
+    L.msda_box_pair_loss_f32.restype = ci
+    L.msda_focal_pos_sum_f32.argtypes = [vp, vp, ci, ctypes.c_float, vp, vp, vp]
+    L.msda_focal_pos_sum_f32.restype = ci
     for sfx in ("f32", "f64"):
         f = getattr(L, "msda_roi_align_forward_" + sfx)
         f.argtypes = [vp, vp] + [ci] * 7 + [ctypes.c_double, ci, ci, vp, vp]

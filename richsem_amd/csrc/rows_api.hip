@@ -210,6 +210,98 @@ __global__ __launch_bounds__(256) void focal_neg_grad_kernel(const float *__rest
     }
 }
 
+// ---- the criterion's per-pair tails as one kernel each (verdict item 3: "one kernel for the stacked focal + L1 + GIoU tails") -------------
+// Box loss of K matched pairs (reference SetCriterion.loss_boxes, models/richsem/richsem.py:1162-1188 with util/box_ops.py:9-64 on the
+// diagonal):   sum_k w[k] * ( c_l1 * |p_k - t_k|_1 + c_giou * (1 - GIoU(xyxy(p_k), xyxy(t_k))) ),   p, t = (cx, cy, w, h)
+// and its gradient w.r.t. p, by forward-mode differentiation with four tangents per value (torch's conventions: |x|' = sign x, a maximum /
+// minimum passes the gradient to the larger / smaller operand and halves it on a tie, clamp(min = 0) passes it where x >= 0).
+struct Dual4 {
+    float v, d[4];
+};
+__device__ __forceinline__ Dual4 d4_const(float v) { return Dual4{v, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ Dual4 d4_var(float v, int i) { Dual4 r = d4_const(v); r.d[i] = 1.f; return r; }
+__device__ __forceinline__ Dual4 operator+(Dual4 a, Dual4 b) { return Dual4{a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2], a.d[3] + b.d[3]}}; }
+__device__ __forceinline__ Dual4 operator-(Dual4 a, Dual4 b) { return Dual4{a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2], a.d[3] - b.d[3]}}; }
+__device__ __forceinline__ Dual4 operator*(Dual4 a, Dual4 b)
+{
+    return Dual4{a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2], a.d[3] * b.v + a.v * b.d[3]}};
+}
+__device__ __forceinline__ Dual4 operator/(Dual4 a, Dual4 b)
+{
+    const float q = a.v / b.v, ib = 1.f / b.v;
+    return Dual4{q, {(a.d[0] - q * b.d[0]) * ib, (a.d[1] - q * b.d[1]) * ib, (a.d[2] - q * b.d[2]) * ib, (a.d[3] - q * b.d[3]) * ib}};
+}
+__device__ __forceinline__ Dual4 d4_scale(Dual4 a, float s) { return Dual4{a.v * s, {a.d[0] * s, a.d[1] * s, a.d[2] * s, a.d[3] * s}}; }
+__device__ __forceinline__ Dual4 d4_max(Dual4 a, Dual4 b) { return a.v > b.v ? a : (b.v > a.v ? b : d4_scale(a + b, 0.5f)); }
+__device__ __forceinline__ Dual4 d4_min(Dual4 a, Dual4 b) { return a.v < b.v ? a : (b.v < a.v ? b : d4_scale(a + b, 0.5f)); }
+__device__ __forceinline__ Dual4 d4_relu(Dual4 a) { return a.v >= 0.f ? a : d4_const(0.f); }
+__device__ __forceinline__ Dual4 d4_abs(Dual4 a) { return a.v > 0.f ? a : (a.v < 0.f ? d4_scale(a, -1.f) : d4_const(0.f)); }
+
+__device__ __forceinline__ float block_sum_1024(float v, float *red)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    if (threadIdx.x < 64) {
+        s = threadIdx.x < blockDim.x / 64 ? red[threadIdx.x] : 0.f;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    }
+    return s;      // (valid in thread 0)
+}
+
+// one workgroup (K is thousands: the matched, two-stage and denoising pairs of a step): loss[0] and grad_p (K, 4) = d loss / d p
+__global__ __launch_bounds__(1024) void box_pair_loss_kernel(const float *__restrict__ p, const float *__restrict__ t, const float *__restrict__ w, int K,
+                                                             float c_l1, float c_giou, float *__restrict__ loss, float *__restrict__ grad_p)
+{
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float4 pv = reinterpret_cast<const float4 *>(p)[k], tv = reinterpret_cast<const float4 *>(t)[k];
+        const Dual4 cx = d4_var(pv.x, 0), cy = d4_var(pv.y, 1), pw = d4_var(pv.z, 2), ph = d4_var(pv.w, 3);
+        const Dual4 l1 = d4_abs(cx - d4_const(tv.x)) + d4_abs(cy - d4_const(tv.y)) + d4_abs(pw - d4_const(tv.z)) + d4_abs(ph - d4_const(tv.w));
+        const Dual4 half = d4_const(0.5f);
+        const Dual4 ax0 = cx - half * pw, ay0 = cy - half * ph, ax1 = cx + half * pw, ay1 = cy + half * ph;
+        const Dual4 bx0 = d4_const(tv.x - 0.5f * tv.z), by0 = d4_const(tv.y - 0.5f * tv.w), bx1 = d4_const(tv.x + 0.5f * tv.z), by1 = d4_const(tv.y + 0.5f * tv.w);
+        const Dual4 area_a = (ax1 - ax0) * (ay1 - ay0), area_b = (bx1 - bx0) * (by1 - by0);
+        const Dual4 iw = d4_relu(d4_min(ax1, bx1) - d4_max(ax0, bx0)), ih = d4_relu(d4_min(ay1, by1) - d4_max(ay0, by0));
+        const Dual4 inter = iw * ih, uni = area_a + area_b - inter;
+        const Dual4 iou = inter / (uni + d4_const(1e-6f));
+        const Dual4 hw = d4_relu(d4_max(ax1, bx1) - d4_min(ax0, bx0)), hh = d4_relu(d4_max(ay1, by1) - d4_min(ay0, by0));
+        const Dual4 hull = hw * hh;
+        const Dual4 giou = iou - (hull - uni) / (hull + d4_const(1e-6f));
+        const Dual4 l = d4_scale(l1, c_l1) + d4_scale(d4_const(1.f) - giou, c_giou);
+        const float wk = w[k];
+        acc += l.v * wk;
+        reinterpret_cast<float4 *>(grad_p)[k] = make_float4(l.d[0] * wk, l.d[1] * wk, l.d[2] * wk, l.d[3] * wk);
+    }
+    const float s = block_sum_1024(acc, red);
+    if (threadIdx.x == 0) loss[0] = s;
+}
+
+// What the positive entries of a sigmoid focal loss contribute INSTEAD of the all-negative term FocalNegativeSum has counted for them
+// (sigmoid_focal_loss, models/richsem/richsem.py:1124-1160 with util: alpha (1 - q)^2 softplus(-x) for a positive, (1 - alpha) q^2
+// softplus(x) for a negative, q = sigmoid(x)):   sum_k w[k] * ( alpha (1 - q_k)^2 softplus(-x_k) - (1 - alpha) q_k^2 softplus(x_k) )
+__global__ __launch_bounds__(1024) void focal_pos_sum_kernel(const float *__restrict__ x, const float *__restrict__ w, int K, float alpha,
+                                                             float *__restrict__ loss, float *__restrict__ grad_x)
+{
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float v = x[k], q = 1.f / (1.f + expf(-v));
+        const float sp_pos = v > 20.f ? v : log1pf(expf(v)), sp_neg = -v > 20.f ? -v : log1pf(expf(-v));      // softplus(x), softplus(-x) (torch's threshold 20)
+        const float omq = 1.f - q;
+        const float l = alpha * omq * omq * sp_neg - (1.f - alpha) * q * q * sp_pos;
+        // d/dx: q' = q (1 - q); softplus(x)' = q; softplus(-x)' = -(1 - q)
+        const float dl = alpha * (-2.f * omq * q * omq * sp_neg - omq * omq * omq) - (1.f - alpha) * (2.f * q * q * omq * sp_pos + q * q * q);
+        const float wk = w[k];
+        acc += l * wk;
+        grad_x[k] = dl * wk;
+    }
+    const float s = block_sum_1024(acc, red);
+    if (threadIdx.x == 0) loss[0] = s;
+}
+
 extern "C" {
 
 /* msda_focal_neg_sum_f32: partial (grid doubles, grid = the value returned through n_partial) <- weighted all-negative focal sums; the caller adds
@@ -234,6 +326,31 @@ int msda_focal_neg_grad_f32(const float *logits, const float *row_weight, int64_
     const int grid = (int)std::min<int64_t>(rows, 8192);
     hipLaunchKernelGGL(focal_neg_grad_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), logits, row_weight, (long long)rows, C,
                        1.f - alpha, gscale, grad_logits);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
+
+/* The criterion's per-pair tails, one launch each (K pairs, float32, one workgroup): loss[0] <- the weighted sum, grad (K, 4) / (K) <- its
+ * gradient w.r.t. the predictions (the caller multiplies by the incoming scalar gradient).
+ * msda_box_pair_loss_f32: sum_k w[k] (c_l1 |p_k - t_k|_1 + c_giou (1 - GIoU(p_k, t_k))), boxes (cx, cy, w, h) (SetCriterion.loss_boxes);
+ * msda_focal_pos_sum_f32: sum_k w[k] (alpha (1 - q)^2 softplus(-x_k) - (1 - alpha) q^2 softplus(x_k)), q = sigmoid(x_k): what a positive entry
+ * contributes to the sigmoid focal loss instead of the all-negative term msda_focal_neg_sum_f32 counted for it. */
+int msda_box_pair_loss_f32(const float *pred, const float *target, const float *weight, int K, float c_l1, float c_giou, float *loss, float *grad_pred,
+                           msda_stream_t stream)
+{
+    if (!pred || !target || !weight || !loss || !grad_pred) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (K < 1) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    if ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(grad_pred)) & 15)
+        return msda_note_error(MSDA_ERR_MISALIGNED, __func__);
+    hipLaunchKernelGGL(box_pair_loss_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), pred, target, weight, K, c_l1, c_giou, loss, grad_pred);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MSDA_OK : (int)e;
+}
+int msda_focal_pos_sum_f32(const float *x, const float *weight, int K, float alpha, float *loss, float *grad_x, msda_stream_t stream)
+{
+    if (!x || !weight || !loss || !grad_x) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
+    if (K < 1) return msda_note_error(MSDA_ERR_BAD_DIMS, __func__);
+    hipLaunchKernelGGL(focal_pos_sum_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), x, weight, K, alpha, loss, grad_x);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MSDA_OK : (int)e;
 }

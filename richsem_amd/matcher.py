@@ -213,3 +213,58 @@ class FocalNegativeSum(torch.autograd.Function):
             _lib.check(_lib.load().msda_focal_neg_grad_f32(x.data_ptr(), w.data_ptr(), w.numel(), x.shape[-1], ctx.alpha, gs.data_ptr(),
                                                            gx.data_ptr(), _lib.raw_stream(x.device)))
         return gx, None, None
+
+
+class _PairSum(torch.autograd.Function):
+    """a weighted per-pair loss as one kernel: the forward computes the sum AND its gradient w.r.t. the predictions; the backward scales"""
+
+    @staticmethod
+    def _launch(ctx, fn, pred, *args):
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        grad = torch.empty_like(pred)
+        with _lib.on_device(pred.device):
+            _lib.check(fn(pred.data_ptr(), *args, loss.data_ptr(), grad.data_ptr(), _lib.raw_stream(pred.device)))
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        grad, = ctx.saved_tensors
+        return (grad * g,) + (None,) * (ctx.n_inputs - 1)
+
+
+class BoxPairLoss(_PairSum):
+    """``sum_k w[k] * (c_l1 * |p_k - t_k|_1 + c_giou * (1 - GIoU(p_k, t_k)))`` over K matched (cx, cy, w, h) pairs (SetCriterion.loss_boxes,
+    richsem.py:1162-1188) as one kernel (``msda_box_pair_loss_f32``): ``apply(pred (K, 4), target (K, 4), weight (K), c_l1, c_giou)`` -> 0-dim;
+    gradient for ``pred``.  PyTorch's op sequence is ~35 launches forward and ~70 backward on a few thousand pairs."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight, c_l1, c_giou):
+        if not pred.is_cuda:
+            raise RuntimeError("Not implemented on the CPU")
+        assert pred.dtype == torch.float32 and pred.dim() == 2 and pred.shape[1] == 4 and target.shape == pred.shape and weight.numel() == pred.shape[0]
+        p, t, w = pred.contiguous(), target.detach().float().contiguous(), weight.detach().float().contiguous()
+        ctx.n_inputs = 5
+        if p.shape[0] == 0:
+            ctx.save_for_backward(torch.zeros_like(p))
+            return p.sum()
+        return _PairSum._launch(ctx, _lib.load().msda_box_pair_loss_f32, p, t.data_ptr(), w.data_ptr(), p.shape[0], float(c_l1), float(c_giou))
+
+
+class FocalPositiveSum(_PairSum):
+    """``sum_k w[k] * (alpha (1 - q_k)^2 softplus(-x_k) - (1 - alpha) q_k^2 softplus(x_k))``, q = sigmoid(x): what the positive entries of a
+    sigmoid focal loss contribute instead of the all-negative term :class:`FocalNegativeSum` counted for them, as one kernel
+    (``msda_focal_pos_sum_f32``): ``apply(x (K), weight (K), alpha)`` -> 0-dim; gradient for ``x``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, alpha):
+        if not x.is_cuda:
+            raise RuntimeError("Not implemented on the CPU")
+        assert x.dtype == torch.float32 and x.dim() == 1 and weight.numel() == x.numel()
+        xc, w = x.contiguous(), weight.detach().float().contiguous()
+        ctx.n_inputs = 3
+        if xc.numel() == 0:
+            ctx.save_for_backward(torch.zeros_like(xc))
+            return xc.sum()
+        return _PairSum._launch(ctx, _lib.load().msda_focal_pos_sum_f32, xc, w.data_ptr(), xc.numel(), float(alpha))

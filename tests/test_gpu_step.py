@@ -180,6 +180,41 @@ def test_batched_criterion_equals_the_op_sequence():
         assert float((a - b).abs().max()) < 2e-5 * float(b.abs().max()) + 1e-12, float((a - b).abs().max()) / float(b.abs().max())
 
 
+def test_pair_loss_kernels_against_the_op_sequence():
+    """matcher.BoxPairLoss / matcher.FocalPositiveSum (value + gradient in one launch) against PyTorch's op sequence and its autograd,
+    incl. identical boxes (a tie in every maximum / minimum), disjoint and nested boxes, weights of zero, |logits| beyond softplus's threshold"""
+    import torch.nn.functional as F
+    from bench_step import box_cxcywh_to_xyxy, giou_pairs
+    from richsem_amd.matcher import BoxPairLoss, FocalPositiveSum
+    g = torch.Generator(device="cuda").manual_seed(11)
+    K = 3001
+    tb = torch.rand(K, 4, device="cuda", generator=g) * 0.5 + 0.2
+    pb = (tb + 0.15 * torch.randn(K, 4, device="cuda", generator=g)).clamp(0.01, 0.99)
+    pb[:7] = tb[:7]                                                            # identical
+    pb[7:14, :2] = tb[7:14, :2] + 0.6                                          # disjoint
+    pb[14:21, 2:] = tb[14:21, 2:] * 0.3; pb[14:21, :2] = tb[14:21, :2]         # nested
+    w = torch.rand(K, device="cuda", generator=g)
+    w[::13] = 0.0
+    a, b = pb.clone().requires_grad_(True), pb.clone().requires_grad_(True)
+    la = BoxPairLoss.apply(a, tb, w, 5.0, 2.0)
+    lb = ((5.0 * (b - tb).abs().sum(-1) + 2.0 * (1 - giou_pairs(box_cxcywh_to_xyxy(b), box_cxcywh_to_xyxy(tb)))) * w).sum()
+    (la * 1.7).backward()
+    (lb * 1.7).backward()
+    assert abs(float(la) - float(lb)) <= 2e-5 * abs(float(lb))
+    assert float((a.grad - b.grad).abs().max()) <= 2e-4 * float(b.grad.abs().max()), float((a.grad - b.grad).abs().max()) / float(b.grad.abs().max())
+    x = torch.randn(K, device="cuda", generator=g) * 8
+    x[:4] = torch.tensor([25.0, -25.0, 0.0, 19.999], device="cuda")
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    fa = FocalPositiveSum.apply(xa, w, 0.25)
+    q = xb.sigmoid()
+    fb = ((0.25 * (1 - q) ** 2 * F.softplus(-xb) - 0.75 * q * q * F.softplus(xb)) * w).sum()
+    (fa * 0.3).backward()
+    (fb * 0.3).backward()
+    assert abs(float(fa) - float(fb)) <= 2e-5 * abs(float(fb)) + 1e-6
+    assert float((xa.grad - xb.grad).abs().max()) <= 2e-5 * float(xb.grad.abs().max())
+    assert float(BoxPairLoss.apply(pb[:0], tb[:0], w[:0], 5.0, 2.0)) == 0.0 and float(FocalPositiveSum.apply(x[:0], w[:0], 0.25)) == 0.0
+
+
 def test_focal_negative_sum_kernel():
     from richsem_amd.matcher import FocalNegativeSum
     import torch.nn.functional as F
