@@ -121,3 +121,48 @@ def test_error_notes_of_the_other_translation_units_name_the_call():
     rc = L.msda_sine_embed_bf16(None, 4, 1, 4, 128, 10000.0, None, None)
     with pytest.raises(RuntimeError, match="msda_sine_embed_bf16.*null pointer"):
         _lib.check(rc)
+
+
+def test_round4_entry_points_check_their_arguments_on_the_host():
+    """ABI v7's additions (convolution rings / fused input gradient / grouped weight gradients, box refinement with the reference's gradient,
+    the criterion's pair kernels): null pointers, bad dimensions, misalignment and bad option values are refused before any launch"""
+    L = _lib.load()
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.addressof(buf)
+    p16 = (p + 15) & ~15
+    for bad in (2, 5, 7, -2):
+        assert L.msda_conv_set_ring(bad) != 0
+    with pytest.raises(RuntimeError, match="msda_conv_set_ring.*BAD_OPTION"):
+        _lib.check(L.msda_conv_set_ring(5))
+    for ok in (-1, 3, 4, 6, 0):
+        assert L.msda_conv_set_ring(ok) == 0
+    assert L.msda_conv_set_wgrad_ring(2) != 0 and L.msda_conv_set_wgrad_ring(1) == 0
+    # fused input gradient: nulls, C_out not a multiple of 32, an output size that does not match, a misaligned `add`
+    args = lambda dy, w, dx, add=None, mask=None, Cout=64, Ho=4: (dy, w, 1, Ho, 4, Cout, 64, 1, 1, 1, 0, 4, 4, add, mask, dx, None, None)
+    assert L.msda_conv_dgrad_fused_bf16(*args(None, p16, p16)) == -1
+    assert L.msda_conv_dgrad_fused_bf16(*args(p16, p16, p16, Cout=48)) == -2
+    assert L.msda_conv_dgrad_fused_bf16(*args(p16, p16, p16, Ho=5)) == -2
+    with pytest.raises(RuntimeError, match="msda_conv_dgrad_fused_bf16.*align"):
+        _lib.check(L.msda_conv_dgrad_fused_bf16(*args(p16, p16, p16, add=p16 + 2)))
+    # grouped weight gradients: no problems, too many, a channel count the kernel does not take, a missing workspace
+    n = ctypes.c_int64(0)
+    arr = (_lib.WgradProblem * 9)()
+    for j in range(9):
+        arr[j] = _lib.WgradProblem(p16, p16, p16, None, 1, 64, 64, 128, 128, 1, 1, 1, 0)
+    assert L.msda_conv_wgrad_group_workspace_bytes(arr, 0, ctypes.byref(n)) == -2
+    assert L.msda_conv_wgrad_group_workspace_bytes(arr, 9, ctypes.byref(n)) == -2
+    assert L.msda_conv_wgrad_group_workspace_bytes(arr, 3, None) == -1
+    assert L.msda_conv_wgrad_group_workspace_bytes(arr, 3, ctypes.byref(n)) == 0 and n.value > 0 and n.value % 4 == 0
+    assert L.msda_conv_wgrad_group_bf16(arr, 3, None, None) == -1                     # the split needs its workspace
+    arr[1].Cin = 100
+    with pytest.raises(RuntimeError, match="msda_conv_wgrad_group_workspace_bytes.*dimension"):
+        _lib.check(L.msda_conv_wgrad_group_workspace_bytes(arr, 3, ctypes.byref(n)))
+    # box refinement / pair losses
+    assert L.msda_box_refine_backward_ref(p, p, 8, p, 0, None, 1e-3, p, None) == -1        # grad_ref without ref
+    assert L.msda_box_refine_backward_ref(p, p, 0, p, 0, p, 1e-3, p, None) == -2
+    assert L.msda_box_pair_loss_f32(p16, p16, p, 0, 5.0, 2.0, p, p16, None) == -2
+    assert L.msda_box_pair_loss_f32(p16, None, p, 4, 5.0, 2.0, p, p16, None) == -1
+    with pytest.raises(RuntimeError, match="msda_box_pair_loss_f32.*align"):
+        _lib.check(L.msda_box_pair_loss_f32(p16 + 4, p16, p, 4, 5.0, 2.0, p, p16, None))
+    assert L.msda_focal_pos_sum_f32(p, p, 0, 0.25, p, p, None) == -2
+    assert L.msda_focal_pos_sum_f32(None, p, 4, 0.25, p, p, None) == -1
