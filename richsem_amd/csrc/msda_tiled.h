@@ -115,6 +115,8 @@ struct TileHeader {
 };
 static_assert(sizeof(TileHeader) % 16 == 0, "windows must stay 16-byte aligned behind the header");
 
+static __device__ __attribute__((aligned(16))) unsigned g_tiled_zero_line[4];      // (zero-initialised: the source of apron pixels in the DMA fill)
+
 // Set by msda_set_option (any thread), read by every launch (any thread): plain atomics, like the other options.
 struct TiledOptions {
     std::atomic<int> region_px{20};   // finest-level pixels per region side (swept on MI355X: 20 beats 16 by ~15 %; larger does not fit LDS)
@@ -621,6 +623,30 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                 // too and waited for it there (one or two loads in flight instead of four); the pixel's row comes from a reciprocal
                 // (exact: (px + 0.5) / nwc is at least 0.5 / nwc away from an integer), not from a 20-instruction integer division.
                 const float inv_nwc = 1.0f / (float)nwc;
+                if constexpr (sizeof(TV) == 4 && FL == 4) {
+                    if (!(g.dbg & 256)) {
+                        // fp32 value (round 4): the window rows by LDS DMA: lane l of a wave writes 16 B at (base + 16 l) = pixel l / 4, quarter
+                        // l % 4 of the wave's 16 consecutive window pixels -- no staging registers, no LDS store instructions; lanes past
+                        // the window's end are masked off, pixels of the zero apron fetch a zero line.  114.2 -> 108.5 us at the init pattern,
+                        // 145.5 -> 140.5 us at sigma = 4 (tools/r04_dma_fill.py, same box; tile_debug bit 8 = the register-staged fill below,
+                        // which bf16 storage keeps: its rows are converted on the way)
+                        const int wave_px = (tid >> 6) * 16;
+                        for (int px0 = 0; px0 < npx; px0 += kFillGroups) {
+                            const int px = px0 + fgrp;
+                            if (px < npx) {
+                                const int rr = (int)(((float)px + 0.5f) * inv_nwc), cc = px - rr * nwc;
+                                const int row = wr0 + rr, col = wc0 + cc;
+                                const bool in = row >= 0 && row < Hl && col >= 0 && col < Wl;
+                                const float *sp = in ? reinterpret_cast<const float *>(src) + (int64_t)(row * Wl + col) * row_elems
+                                                     : reinterpret_cast<const float *>(g_tiled_zero_line);
+                                float *dp = win + (int64_t)(uni(hdr->lds_px[l]) + px0 + wave_px) * GC;
+                                __builtin_amdgcn_global_load_lds(sp, reinterpret_cast<__attribute__((address_space(3))) void *>(reinterpret_cast<uintptr_t>(dp)),
+                                                                 16, 0, 0);
+                            }
+                        }
+                        continue;
+                    }
+                }
                 for (int px0 = fgrp; px0 < npx; px0 += kFillBatch * kFillGroups) {
                     float4 v[kFillBatch];
                     int pxs[kFillBatch];
@@ -640,6 +666,7 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                         *reinterpret_cast<float4 *>(dst + pxs[u] * GC) = inm[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
+            if (sizeof(TV) == 4 && FL == 4 && !(g.dbg & 256)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the DMA fill's requests have landed)
             __syncthreads();
             stamp<2>(g, st++);
 
