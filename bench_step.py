@@ -285,12 +285,12 @@ class Step(nn.Module):
         if self.stop_at == "heads":
             return coords.sum() + logits.sum() + clip_logits.sum() + interm['pred_logits'].sum() + interm['pred_boxes'].sum()
         # ---- frozen teacher -> ROIAlign -> attention pool -> text logits (richsem.py:614-629, :741-768) ----------------------------------
-        with torch.no_grad():
-            _, fmap = self.teacher(images, ret_sp=True)
-            _, t_logits = clip_box_targets(fmap, targets, self.teacher.attnpool, self.text_embed, st["scale"])
+        if self._model_only == "student":      # (model_part without the frozen teacher: run_graphed launches it beside the host's matching)
+            return logits, coords, interm["pred_logits"], interm["pred_boxes"], clip_logits
+        t_logits = self.teacher_part(images, targets)
         self._mark("teacher")
         if self._model_only:      # (model_part: the step up to the matcher, as tensors)
-            return logits, coords, interm["pred_logits"], interm["pred_boxes"], clip_logits, torch.cat(t_logits).float()
+            return logits, coords, interm["pred_logits"], interm["pred_boxes"], clip_logits, t_logits
         # ---- matcher (matcher.py:30-78, one host copy for the 7 outputs) -------------------------------------------------------------------
         if indices is None:
             indices = self.match(logits, coords, interm["pred_logits"], interm["pred_boxes"], targets)
@@ -298,25 +298,45 @@ class Step(nn.Module):
         if packed is not indices:
             self.last_indices = indices
         self._mark("matcher")
-        loss = self.loss_part(logits, coords, interm["pred_logits"], interm["pred_boxes"], clip_logits, torch.cat(t_logits).float(), *packed)
+        loss = self.loss_part(logits, coords, interm["pred_logits"], interm["pred_boxes"], clip_logits, t_logits, *packed)
         self._mark("criterion")
         return loss
 
     _model_only = False
 
-    def model_part(self, images, mask=None, targets=None):
+    def model_part(self, images, mask=None, targets=None, teacher=True):
         """the step up to the matcher: -> (logits (6, N, Q, C), boxes (6, N, Q, 4), two-stage logits, two-stage boxes, distillation logits,
-        the teacher's box logits): tensors in, tensors out, nothing read back to the host -- the part ``run_graphed`` captures"""
-        self._model_only = True
+        the teacher's box logits -- unless ``teacher`` is False): tensors in, tensors out, nothing read back to the host -- the part
+        ``run_graphed`` captures"""
+        self._model_only = True if teacher else "student"
         try:
             return self.forward(images, mask, self._targets if targets is None else targets)
         finally:
             self._model_only = False
 
-    def match(self, logits, coords, il, ib, targets):
+    @torch.no_grad()
+    def teacher_part(self, images, targets=None):
+        """frozen CLIP-RN50 teacher -> ROIAlign -> attention pool -> text logits of the target boxes (richsem.py:614-629, :741-768): no
+        gradient, no dependence on the student"""
+        targets = self._targets if targets is None else targets
+        _, fmap = self.teacher(images, ret_sp=True)
+        _, t_logits = clip_box_targets(fmap, targets, self.teacher.attnpool, self.text_embed, self.static["scale"])
+        return torch.cat(t_logits).float()
+
+    def _match_outputs(self, logits, coords, il, ib):
         pad = self.static["lay"]["pad_size"]
-        outs = [{"pred_logits": logits[l][:, pad:], "pred_boxes": coords[l][:, pad:]} for l in range(logits.shape[0])]
-        return self.matcher.match_many(outs + [{"pred_logits": il, "pred_boxes": ib}], targets)
+        return [{"pred_logits": logits[l][:, pad:], "pred_boxes": coords[l][:, pad:]} for l in range(logits.shape[0])] + \
+            [{"pred_logits": il, "pred_boxes": ib}]
+
+    def match(self, logits, coords, il, ib, targets):
+        return self.matcher.match_many(self._match_outputs(logits, coords, il, ib), targets)
+
+    def match_begin(self, logits, coords, il, ib, targets):
+        """the device half of :meth:`match` (cost blocks + copy to the host enqueued, nothing waits); :meth:`match_end` the host half"""
+        return self.matcher.match_many_begin(self._match_outputs(logits, coords, il, ib), targets)
+
+    def match_end(self, pending):
+        return self.matcher.match_many_end(pending)
 
     def pack_indices(self, indices, targets):
         """the Hungarian assignment of the 6 + 1 outputs as flat device tensors of a size the batch fixes (every target is matched once per
@@ -511,7 +531,7 @@ class _ModelPart(nn.Module):
         self.step = step
 
     def forward(self, images):
-        return self.step.model_part(images, self.step._mask)
+        return self.step.model_part(images, self.step._mask, teacher=False)
 
 
 class _LossPart(nn.Module):
@@ -554,6 +574,15 @@ def run_graphed(n_img, dev, steps=5, warmup=2, **step_kwargs):
             sample_b = tuple(o.detach().clone().requires_grad_(i < 5) for i, o in enumerate(outs)) + tuple(idx)
             torch.cuda.synchronize()
             ga, gb = torch.cuda.make_graphed_callables((part_a, part_b), ((images,), sample_b), num_warmup_iters=3, allow_unused_input=True)
+            # the frozen teacher (no gradient, independent of the student) is a HIP graph of its own, replayed BETWEEN the two halves of the
+            # matching: the cost blocks and their copy to the host are enqueued first, the teacher's ~2 ms of GPU work run while the host
+            # waits for that copy and solves the seven assignments (scipy) -- the round trip costs the step nothing
+            for _ in range(2):
+                model.teacher_part(images)
+            torch.cuda.synchronize()
+            teacher_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(teacher_graph, stream=side):
+                t_static = model.teacher_part(images)
             params = [p for p in model.parameters() if p.requires_grad]
 
             def step():
@@ -561,8 +590,10 @@ def run_graphed(n_img, dev, steps=5, warmup=2, **step_kwargs):
                     p.grad = None
                 outs = ga(images)
                 with torch.no_grad():
-                    assign = model.match(*outs[:4], targets)                  # device cost blocks -> one host copy -> scipy (matcher.py)
-                loss = gb(*outs, *model.pack_indices(assign, targets))
+                    pending = model.match_begin(*outs[:4], targets)           # device cost blocks -> one host copy, enqueued
+                    teacher_graph.replay()
+                    assign = model.match_end(pending)                         # wait for the copy, scipy (matcher.py) -- under the teacher
+                loss = gb(*outs, t_static, *model.pack_indices(assign, targets))
                 loss.backward()
                 return loss
 
@@ -578,7 +609,8 @@ def run_graphed(n_img, dev, steps=5, warmup=2, **step_kwargs):
         torch.cuda.graph.default_capture_stream = saved_capture_stream
     torch.cuda.current_stream().wait_stream(side)
     return {"what": "the same step with its two device-only parts (model up to the matcher; criterion) captured forward + backward by "
-                    "torch.cuda.make_graphed_callables and the Hungarian assignment live on the host between them every step",
+                    "torch.cuda.make_graphed_callables and the Hungarian assignment live on the host between them every step, under the frozen "
+                    "teacher's forward (a HIP graph of its own, replayed while the host waits for the cost blocks and solves the assignments)",
             "ms": round(ms, 2), "img_per_s": round(n_img / (ms * 1e-3), 2), "loss": float(loss.detach()),
             "grad_norm": float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in params if p.grad is not None)))}
 

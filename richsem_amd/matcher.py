@@ -98,6 +98,13 @@ class HungarianMatcher(nn.Module):
         """Match several decoder outputs (each a dict with "pred_logits" (bs, nq_o, C) and "pred_boxes" (bs, nq_o, 4)) against the
         same targets: one cost kernel per output into one device buffer, one copy to the host, one wait.  Returns a list (per
         output) of the reference's per-image index pairs."""
+        return self.match_many_end(self.match_many_begin(outputs_list, targets))
+
+    @torch.no_grad()
+    def match_many_begin(self, outputs_list, targets):
+        """the device half of :meth:`match_many`: cost kernels, the copy to pinned host memory and an event behind it are ENQUEUED; nothing
+        waits.  Work enqueued after this call (a frozen teacher's forward, say) runs on the GPU while :meth:`match_many_end` waits for the
+        copy and solves the assignments on the host."""
         first = outputs_list[0]["pred_logits"]
         plan = CostPlan(targets, first.device, first.dtype)
         nqs = [o["pred_logits"].shape[1] for o in outputs_list]
@@ -112,6 +119,11 @@ class HungarianMatcher(nn.Module):
         host.copy_(dev_buf, non_blocking=True)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(first.device))
+        return plan, nqs, host, done, dev_buf
+
+    @torch.no_grad()
+    def match_many_end(self, pending):
+        plan, nqs, host, done, _keep = pending
         done.synchronize()          # the one wait of the step's matching (the reference: one .cpu() per output)
         res, at = [], 0
         for nq in nqs:
