@@ -429,12 +429,13 @@ int msda_conv_wgrad_bf16(const uint16_t *dz, const uint16_t *x, int N, int H, in
 
 /* Several weight gradients in ONE launch of the product kernel and one of the reduction (a bottleneck block's three or four,
  * models/richsem/backbone.py:59-92 trains layer2-4): each problem is msda_conv_wgrad_bf16's, its result in nn.Conv2d's layout
- * (Cout, Cin, KH, KW), multiplied by scale[co] when scale is not NULL; no bias gradients.  The problems share the chip in proportion to
+ * (Cout, Cin, KH, KW), multiplied by scale[co] when scale is not NULL; dbias as msda_conv_wgrad_bf16's (optional).  The problems share the chip in proportion to
  * their work instead of each being cut into ~512 short workgroups.  n <= 8. */
 typedef struct {
     const uint16_t *dz, *x;
     float *dw;
     const float *scale;
+    float *dbias;      /* (Cout) fp32: sum over the pixels of dz, or NULL */
     int N, H, W, Cin, Cout, KH, KW, stride, pad;
 } msda_wgrad_problem;
 int msda_conv_wgrad_group_workspace_bytes(const msda_wgrad_problem *problems, int n, int64_t *bytes);

@@ -50,7 +50,7 @@ def on_device(dev):
 
 class WgradProblem(ctypes.Structure):
     """``msda_wgrad_problem`` (include/richsem_msda.h): one weight gradient of a grouped launch"""
-    _fields_ = [("dz", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("scale", ctypes.c_void_p)] + \
+    _fields_ = [("dz", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("dbias", ctypes.c_void_p)] + \
         [(k, ctypes.c_int) for k in ("N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad")]
 
 # every symbol include/richsem_msda.h declares

@@ -166,7 +166,7 @@ def conv_wgrad_group(problems):
         N, H, W, Cin = x.shape
         dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=dev)
         outs.append(dw)
-        arr[j] = _lib.WgradProblem(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), scale.data_ptr() if scale is not None else None,
+        arr[j] = _lib.WgradProblem(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), scale.data_ptr() if scale is not None else None, None,
                                    N, H, W, Cin, Cout, KH, KW, stride, padding)
     nb = ctypes.c_int64(0)
     _lib.check(L.msda_conv_wgrad_group_workspace_bytes(arr, n, ctypes.byref(nb)))

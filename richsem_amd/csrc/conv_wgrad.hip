@@ -434,6 +434,7 @@ struct WgradGroup {
     const uint16_t *dz[kMaxGroup], *x[kMaxGroup];
     float *part[kMaxGroup];          // where the chunks' slices go: the workspace, or the result itself for a problem of one chunk
     float *dw[kMaxGroup];
+    float *bpart[kMaxGroup], *dbias[kMaxGroup];      // bias gradient (or null): where the chunks' slices go, and the result
     const float *scale[kMaxGroup];
     WgradGeom g[kMaxGroup];
     int split[kMaxGroup], first[kMaxGroup + 1];
@@ -441,7 +442,7 @@ struct WgradGroup {
     int n;
 };
 
-template <bool RING>
+template <bool RING, bool BIAS>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_group_kernel(WgradGroup grp)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * kImageBytes];
@@ -451,10 +452,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_group_kernel(WgradGrou
         if (i < grp.n && (int)blockIdx.x >= grp.first[i]) j = i;      // (uniform)
     const int local = (int)blockIdx.x - grp.first[j], split = grp.split[j];
     if constexpr (RING)
-        wgrad_block_ring<false>(grp.dz[j], grp.x[j], grp.part[j], nullptr, grp.scale[j], split > 1 ? 0 : 1, grp.g[j], local % split, local / split,
-                                &lds[0][0]);
+        wgrad_block_ring<BIAS>(grp.dz[j], grp.x[j], grp.part[j], BIAS ? grp.bpart[j] : nullptr, grp.scale[j], split > 1 ? 0 : 1, grp.g[j], local % split,
+                               local / split, &lds[0][0]);
     else
-        wgrad_block(grp.dz[j], grp.x[j], grp.part[j], nullptr, grp.scale[j], split > 1 ? 0 : 1, grp.g[j], local % split, local / split, lds);
+        wgrad_block(grp.dz[j], grp.x[j], grp.part[j], grp.bpart[j], grp.scale[j], split > 1 ? 0 : 1, grp.g[j], local % split, local / split, lds);
 }
 
 // the reduction of a group's split problems: 64 float4 elements per workgroup-iteration as in conv_wgrad_reduce_kernel
@@ -462,6 +463,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_group_reduce_kernel(WgradGroup
 {
     __shared__ float4 red[4][64];
     const int col = threadIdx.x & 63, phase = threadIdx.x >> 6;
+    // the bias partials of the split problems: 64 channels per workgroup, the same four phases (as conv_wgrad_reduce_kernel)
+    for (int j = 0; j < grp.n; ++j) {
+        const int cout = grp.g[j].Cout, split = grp.split[j];
+        if (!grp.dbias[j] || split < 2 || (int)blockIdx.x * 64 >= cout) continue;      // (uniform)
+        __shared__ float bred[4][64];
+        const int c = blockIdx.x * 64 + col;
+        float v = 0.f;
+        if (c < cout)
+            for (int s = phase; s < split; s += 4) v += grp.bpart[j][(size_t)s * cout + c];
+        bred[phase][col] = v;
+        __syncthreads();
+        if (phase == 0 && c < cout) grp.dbias[j][c] = bred[0][col] + bred[1][col] + bred[2][col] + bred[3][col];
+        __syncthreads();
+    }
     const long long total = grp.red_first[grp.n];
     for (long long i0 = (long long)blockIdx.x * 64; i0 < total; i0 += (long long)gridDim.x * 64) {
         const long long ig = i0 + col;
@@ -630,7 +645,7 @@ int plan_group(const msda_wgrad_problem *probs, int n, WgradGroup &grp, int64_t 
         grp.first[j + 1] = grp.first[j] + (int)(split * blocks_y);
         const long long n_dw = (long long)g.Cout * g.KH * g.KW * g.Cin;
         grp.red_first[j + 1] = grp.red_first[j] + (split > 1 ? n_dw / 4 : 0);
-        if (split > 1) ws_floats += split * n_dw;
+        if (split > 1) ws_floats += split * n_dw + (probs[j].dbias ? split * (long long)g.Cout : 0);
     }
     return MSDA_OK;
 }
@@ -661,6 +676,8 @@ int msda_conv_wgrad_group_bf16(const msda_wgrad_problem *problems, int n, void *
     if (rc != MSDA_OK) return msda_note_error(rc, __func__);
     if (fl > 0 && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15))) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
     float *ws = static_cast<float *>(workspace);
+    bool any_bias = false;
+    int max_cout = 0;
     for (int j = 0; j < n; ++j) {
         const msda_wgrad_problem &p = problems[j];
         if (!p.dz || !p.x || !p.dw) return msda_note_error(MSDA_ERR_NULL_POINTER, __func__);
@@ -672,17 +689,27 @@ int msda_conv_wgrad_group_bf16(const msda_wgrad_problem *problems, int n, void *
         grp.scale[j] = p.scale;
         grp.part[j] = grp.split[j] > 1 ? ws : p.dw;
         if (grp.split[j] > 1) ws += (int64_t)grp.split[j] * p.Cout * p.KH * p.KW * p.Cin;
+        grp.dbias[j] = p.dbias;
+        grp.bpart[j] = !p.dbias ? nullptr : (grp.split[j] > 1 ? ws : p.dbias);
+        if (p.dbias && grp.split[j] > 1) ws += (int64_t)grp.split[j] * p.Cout;
+        any_bias = any_bias || p.dbias != nullptr;
+        max_cout = p.dbias && grp.split[j] > 1 && p.Cout > max_cout ? p.Cout : max_cout;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (g_wgrad_ring.load())
-        hipLaunchKernelGGL(conv_wgrad_group_kernel<true>, dim3((unsigned)grp.first[n]), dim3(kThreads), 0, st, grp);
+    const dim3 ggrid((unsigned)grp.first[n]);
+    if (!g_wgrad_ring.load())
+        hipLaunchKernelGGL((conv_wgrad_group_kernel<false, true>), ggrid, dim3(kThreads), 0, st, grp);
+    else if (any_bias)
+        hipLaunchKernelGGL((conv_wgrad_group_kernel<true, true>), ggrid, dim3(kThreads), 0, st, grp);
     else
-        hipLaunchKernelGGL(conv_wgrad_group_kernel<false>, dim3((unsigned)grp.first[n]), dim3(kThreads), 0, st, grp);
+        hipLaunchKernelGGL((conv_wgrad_group_kernel<true, false>), ggrid, dim3(kThreads), 0, st, grp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const long long total = grp.red_first[n];
-    if (total > 0) {
-        const int grid = (int)((total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192);
+    if (total > 0 || max_cout > 0) {
+        long long blocks = (total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192;
+        if (blocks < (max_cout + 63) / 64) blocks = (max_cout + 63) / 64;      // (the bias partials: 64 channels per workgroup)
+        const int grid = (int)blocks;
         hipLaunchKernelGGL(conv_wgrad_group_reduce_kernel, dim3(grid), dim3(256), 0, st, grp);
         e = hipGetLastError();
     }

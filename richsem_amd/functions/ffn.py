@@ -193,6 +193,8 @@ class FFNSmallFunction(Function):
         out, rstd, yhat = add_layernorm_forward_bf16(x2, y, lw, lb, eps)
         ctx.save_for_backward(x2, h, yhat, rstd, lw, w2t_packed, pk1["w16"])
         ctx.meta = (x.shape, tuple(p.dtype for p in (w1, b1, w2, b2, ln_weight, ln_bias)))
+        from .linear import WgradGroup
+        ctx.group = WgradGroup.active()
         return out.view(x.shape)
 
     @staticmethod
@@ -203,12 +205,21 @@ class FFNSmallFunction(Function):
         shape, dts = ctx.meta
         dz, g_lnw, g_lnb, g_b2 = ffn_ln_backward_bf16(grad_out.to(torch.bfloat16), yhat, rstd, lw)
         need = ctx.needs_input_grad
-        g_w2 = _wgrad(dz, h, fp32=dts[2] == torch.float32).to(dts[2]) if need[7] else None
+        from .linear import deferrable
+        grp2 = deferrable(ctx.group, dz, h, (dts[2],))      # (the layer's deferred weight gradients: functions/linear.py, WgradGroup)
+        if need[7]:
+            g_w2 = grp2.add(dz, h, False)[0] if grp2 is not None else _wgrad(dz, h, fp32=dts[2] == torch.float32).to(dts[2])
+        else:
+            g_w2 = None
         gh = lin256(dz, w2t_packed, relu_mask=h)
         g_w1 = g_b1 = None
         if need[5] or need[6]:
-            g_w1, g_b1 = _wgrad(gh, x2, with_bias=True, fp32=dts[0] == torch.float32)
-            g_w1, g_b1 = g_w1.to(dts[0]), g_b1.to(dts[1])
+            grp1 = deferrable(ctx.group, gh, x2, (dts[0], dts[1]))
+            if grp1 is not None:
+                g_w1, g_b1 = grp1.add(gh, x2, True)
+            else:
+                g_w1, g_b1 = _wgrad(gh, x2, with_bias=True, fp32=dts[0] == torch.float32)
+                g_w1, g_b1 = g_w1.to(dts[0]), g_b1.to(dts[1])
         dx = torch.addmm(dz, gh, w1_16).view(shape) if need[0] else None
         return dx, None, None, None, None, g_w1, g_b1, g_w2, g_b2.to(dts[3]), g_lnw.to(dts[4]), g_lnb.to(dts[5])
 

@@ -279,6 +279,82 @@ def _mask_rows_(t, mask):
     return t
 
 
+# ---- a layer's weight gradients in ONE launch ----------------------------------------------------------------------------------------
+class WgradGroup:
+    """The weight (+ bias) gradients of one layer call, deferred and launched together (``msda_conv_wgrad_group_bf16``): at the decoder's
+    ~2 k tokens every such product is a launch of 11-18 us plus a 6 us reduction that keep the matrix pipe 1-4 % busy; seven of them per
+    decoder layer in one launch share the chip.  Protocol (modules/decoder_layer.py): the layer routes its parameters through
+    :class:`WgradBoundary` -- an identity whose backward runs AFTER every function that consumed one of its outputs -- and runs its body
+    ``with group:``; :class:`Lin256Function` / ``FFNSmallFunction`` then hand autograd EMPTY gradient tensors and register the products here;
+    the boundary's backward launches them and passes the (now filled) tensors on to the parameters.  Every parameter alias must feed exactly
+    one function (a gradient sum would read a tensor that is not written yet): the layers that use this satisfy it by construction."""
+
+    enabled = True
+    _active = None
+
+    def __init__(self):
+        self.pending = []
+
+    def __enter__(self):
+        self._prev, WgradGroup._active = WgradGroup._active, self
+        return self
+
+    def __exit__(self, *exc):
+        WgradGroup._active = self._prev
+        return False
+
+    @staticmethod
+    def active():
+        return WgradGroup._active
+
+    def add(self, dy2, x2, with_bias):
+        """register dW = dy2^T x2 (+ db = column sums of dy2): -> (dw (out, in) float32, db (out) float32 or None), written by flush()"""
+        dw = torch.empty((dy2.shape[1], x2.shape[1]), dtype=torch.float32, device=x2.device)
+        db = torch.empty(dy2.shape[1], dtype=torch.float32, device=x2.device) if with_bias else None
+        self.pending.append((dy2, x2, dw, db))
+        return dw, db
+
+    def flush(self):
+        pend, self.pending = self.pending, []
+        L = _lib.load()
+        for i0 in range(0, len(pend), 8):
+            part = pend[i0:i0 + 8]
+            arr = (_lib.WgradProblem * len(part))()
+            for j, (dy2, x2, dw, db) in enumerate(part):
+                arr[j] = _lib.WgradProblem(dy2.data_ptr(), x2.data_ptr(), dw.data_ptr(), None, db.data_ptr() if db is not None else None,
+                                           1, 1, x2.shape[0], x2.shape[1], dy2.shape[1], 1, 1, 1, 0)
+            nb = ctypes.c_int64(0)
+            _lib.check(L.msda_conv_wgrad_group_workspace_bytes(arr, len(part), ctypes.byref(nb)))
+            dev = part[0][1].device
+            ws = torch.empty(nb.value // 4, dtype=torch.float32, device=dev) if nb.value else None
+            with _lib.on_device(dev):
+                _lib.check(L.msda_conv_wgrad_group_bf16(arr, len(part), ws.data_ptr() if ws is not None else None, _lib.raw_stream(dev)))
+
+
+class WgradBoundary(torch.autograd.Function):
+    """``apply(group, *params)`` -> aliases of ``params``; the backward first launches ``group``'s deferred weight gradients (every
+    function downstream of the aliases has run its backward by then), then passes the aliases' gradients through to the parameters"""
+
+    @staticmethod
+    def forward(ctx, group, *params):
+        ctx.group = group
+        ctx.set_materialize_grads(False)      # (an alias that fed nothing comes back as None, not as a zero tensor)
+        return tuple(p.view_as(p) for p in params)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.group.flush()
+        return (None,) + grads
+
+
+def deferrable(group, dy2, x2, dts):
+    """``group`` (the :class:`WgradGroup` that was active in the forward, or None) if the product dy2^T x2 can be deferred to it: the
+    weight-gradient kernel's shapes, enough tokens, float32 parameters"""
+    if group is None or not linear_wgrad_supported(dy2.shape[1], x2.shape[1]) or dy2.shape[0] < LinearBf16Function.MIN_TOKENS:
+        return None
+    return group if all(dt == torch.float32 for dt in dts) else None
+
+
 class Lin256Function(torch.autograd.Function):
     """``x W^T + b`` for a 256-wide bf16 input on the library's own MFMA kernel (csrc/lin256_mfma.hip): forward, and the input gradient
     too when the layer is 256 -> 256 (else the library's bf16 GEMM); the weight / bias gradients on the weight-gradient kernel where
@@ -293,6 +369,7 @@ class Lin256Function(torch.autograd.Function):
         out = lin256(x2, pk["packed"], pk["b32"], relu=bool(relu), row_mask=row_mask.reshape(-1) if row_mask is not None else None)
         ctx.save_for_backward(x, row_mask, out if relu else None)
         ctx.pk, ctx.dts = pk, tuple(p.dtype for p in params)
+        ctx.group = WgradGroup.active()
         return out.view(x.shape[:-1] + (out.shape[-1],))
 
     @staticmethod
@@ -318,7 +395,10 @@ class Lin256Function(torch.autograd.Function):
         if any(need):
             want_w, want_b = any(need[:nl]), any(need[nl:])
             dw = db = None
-            if want_w and linear_wgrad_supported(n, 256) and dy2.shape[0] >= LinearBf16Function.MIN_TOKENS:
+            grp = deferrable(ctx.group, dy2, x2, dts) if want_w else None
+            if grp is not None:      # registered with the layer's group: written when its WgradBoundary runs
+                dw, db = grp.add(dy2, x2.contiguous(), want_b)
+            elif want_w and linear_wgrad_supported(n, 256) and dy2.shape[0] >= LinearBf16Function.MIN_TOKENS:
                 if want_b:
                     dw, db = linear_wgrad_bf16(dy2, x2.contiguous(), with_bias=True)
                 else:

@@ -18,13 +18,15 @@ Two paths:
     (``csrc/attn_mfma.hip``); residual + LayerNorm fused (``AddLayerNormFunction``); the cross-attention's value can be handed in by
     the decoder, which projects the memory for all its layers at once (modules/decoder.py).
 """
+import contextlib
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from ..functions.attention import masked_self_attention
 from ..functions.ffn import AddLayerNormFunction, FFNSmallFunction
-from ..functions.linear import Lin256Function, VersionCache, lin256_pack, pack_linear256
+from ..functions.linear import Lin256Function, VersionCache, WgradBoundary, WgradGroup, lin256_pack, pack_linear256
 from .ms_deform_attn import MSDeformAttn
 
 
@@ -45,6 +47,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.norm3 = nn.LayerNorm(d_model)
         self.n_heads = n_heads
         self.fused = True                 # False: bfloat16 input takes the op-by-op sequence too (parameters cast per call)
+        self.group_wgrad = True           # the fast path's seven weight gradients in one launch (functions/linear.py: WgradGroup)
         self._packs = VersionCache()
 
     @staticmethod
@@ -80,22 +83,33 @@ class DeformableTransformerDecoderLayer(nn.Module):
         """the bf16 library-kernel path on BATCH-first tensors (no transposes between its blocks): x, query_pos (bs, nq, 256) bf16,
         reference_points (bs, nq, L, 4) float32, value = the cross-attention's projected memory (bs, S, 256) bf16 -> (bs, nq, 256)"""
         pk = self._lin_packs()
-        a = self.self_attn
-        w, b = a.in_proj_weight, a.in_proj_bias
-        # self-attention (:974-978)
-        q_in = x if query_pos is None else x + query_pos
-        qk = Lin256Function.apply(q_in, pk["qk"], None, False, w[:512], b[:512])
-        v = Lin256Function.apply(x, pk["v"], None, False, w[512:], b[512:])
-        att = masked_self_attention(qk, v, attn_mask, self.n_heads, batch_first=True)
-        x2 = Lin256Function.apply(att, pk["o"], None, False, a.out_proj.weight, a.out_proj.bias)
-        x = AddLayerNormFunction.apply(x, x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        # cross-attention (:1017-1022)
-        q_in = x if query_pos is None else x + query_pos
-        x2 = self.cross_attn.forward_from_value(q_in, reference_points, value, shapes, lsi)
-        x = AddLayerNormFunction.apply(x, x2, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        # feed-forward block (:940-944)
-        return FFNSmallFunction.apply(x, pk["w1"], pk["w2_16"], pk["w2t"], self.norm3.eps, self.linear1.weight, self.linear1.bias,
-                                      self.linear2.weight, self.linear2.bias, self.norm3.weight, self.norm3.bias)
+        a, ca = self.self_attn, self.cross_attn
+        w, b, ow, ob = a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias
+        l1w, l1b, l2w = self.linear1.weight, self.linear1.bias, self.linear2.weight
+        cross = (ca.sampling_offsets.weight, ca.attention_weights.weight, ca.sampling_offsets.bias, ca.attention_weights.bias, ca.output_proj.weight,
+                 ca.output_proj.bias)
+        # the layer's seven weight gradients in ONE launch (functions/linear.py: WgradGroup): the parameters go through a boundary whose
+        # backward runs behind every function below; each alias feeds exactly one of them (in_proj's two slices are one alias each)
+        group = WgradGroup() if (self.group_wgrad and WgradGroup.enabled and torch.is_grad_enabled() and w.requires_grad) else None
+        if group is not None:
+            wqk, wv, bqk, bv, ow, ob, l1w, l1b, l2w, *cross = WgradBoundary.apply(group, w[:512], w[512:], b[:512], b[512:], ow, ob, l1w, l1b, l2w, *cross)
+        else:
+            wqk, wv, bqk, bv = w[:512], w[512:], b[:512], b[512:]
+        with (group if group is not None else contextlib.nullcontext()):
+            # self-attention (:974-978)
+            q_in = x if query_pos is None else x + query_pos
+            qk = Lin256Function.apply(q_in, pk["qk"], None, False, wqk, bqk)
+            v = Lin256Function.apply(x, pk["v"], None, False, wv, bv)
+            att = masked_self_attention(qk, v, attn_mask, self.n_heads, batch_first=True)
+            x2 = Lin256Function.apply(att, pk["o"], None, False, ow, ob)
+            x = AddLayerNormFunction.apply(x, x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            # cross-attention (:1017-1022)
+            q_in = x if query_pos is None else x + query_pos
+            x2 = self.cross_attn.forward_from_value(q_in, reference_points, value, shapes, lsi, params=tuple(cross))
+            x = AddLayerNormFunction.apply(x, x2, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            # feed-forward block (:940-944)
+            return FFNSmallFunction.apply(x, pk["w1"], pk["w2_16"], pk["w2t"], self.norm3.eps, l1w, l1b, l2w, self.linear2.bias, self.norm3.weight,
+                                          self.norm3.bias)
 
     def _forward_fast(self, tgt, query_pos, reference_points, memory, memory_mask, lsi, shapes, attn_mask, value):
         """sequence-first in and out (the reference's layout) around :meth:`forward_batch_first`"""

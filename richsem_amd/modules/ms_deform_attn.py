@@ -108,17 +108,21 @@ class MSDeformAttn(nn.Module):
         mask = input_padding_mask.contiguous() if input_padding_mask is not None else None
         return Lin256Function.apply(input_flatten.to(torch.bfloat16), pk["v"], mask, False, self.value_proj.weight, self.value_proj.bias)
 
-    def forward_from_value(self, query, reference_points, value, input_spatial_shapes, input_level_start_index):
+    def forward_from_value(self, query, reference_points, value, input_spatial_shapes, input_level_start_index, params=None):
         """bf16, d_model = 256: the module's forward behind the value projection (reference :97-114) -- for callers that project the
-        memory for several layers at once (richsem_amd/modules/decoder.py)"""
+        memory for several layers at once (richsem_amd/modules/decoder.py).  ``params``: stand-ins for (sampling_offsets.weight,
+        attention_weights.weight, sampling_offsets.bias, attention_weights.bias, output_proj.weight, output_proj.bias) to route the
+        gradients to (a layer's WgradBoundary aliases: functions/linear.py)"""
         N, S = value.shape[0], value.shape[1]
         H, L, P = self.n_heads, self.n_levels, self.n_points
         pk = self._lin256_packs()
-        qproj = Lin256Function.apply(query.to(torch.bfloat16), pk["q"], None, False, self.sampling_offsets.weight, self.attention_weights.weight,
-                                     self.sampling_offsets.bias, self.attention_weights.bias)
+        if params is None:
+            params = (self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias, self.attention_weights.bias,
+                      self.output_proj.weight, self.output_proj.bias)
+        qproj = Lin256Function.apply(query.to(torch.bfloat16), pk["q"], None, False, *params[:4])
         out = MSDeformAttnFusedFunction.apply(value.reshape(N, S, H, self.d_model // H), input_spatial_shapes, input_level_start_index,
                                               qproj, reference_points.float(), H, L, P, self.im2col_step)
-        return Lin256Function.apply(out, pk["o"], None, False, self.output_proj.weight, self.output_proj.bias)
+        return Lin256Function.apply(out, pk["o"], None, False, *params[4:])
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):

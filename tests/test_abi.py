@@ -148,7 +148,7 @@ def test_round4_entry_points_check_their_arguments_on_the_host():
     n = ctypes.c_int64(0)
     arr = (_lib.WgradProblem * 9)()
     for j in range(9):
-        arr[j] = _lib.WgradProblem(p16, p16, p16, None, 1, 64, 64, 128, 128, 1, 1, 1, 0)
+        arr[j] = _lib.WgradProblem(p16, p16, p16, None, None, 1, 64, 64, 128, 128, 1, 1, 1, 0)
     assert L.msda_conv_wgrad_group_workspace_bytes(arr, 0, ctypes.byref(n)) == -2
     assert L.msda_conv_wgrad_group_workspace_bytes(arr, 9, ctypes.byref(n)) == -2
     assert L.msda_conv_wgrad_group_workspace_bytes(arr, 3, None) == -1

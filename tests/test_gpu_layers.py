@@ -357,6 +357,44 @@ def test_bf16_decoder_on_the_library_kernels_is_close_to_its_fp32_path():
     assert worst[0] < GRAD_PARAM_TOL, worst
 
 
+def test_grouped_layer_weight_gradients_equal_the_separate_launches():
+    """functions/linear.py: WgradGroup / WgradBoundary -- a decoder layer's seven weight (+ bias) gradients deferred to ONE launch behind
+    the layer's backward -- against one launch per linear layer: equal outputs and input gradients (nothing else changes), parameter
+    gradients equal up to the order of the pixel-chunk sums"""
+    from richsem_amd import workload as W
+    from richsem_amd.functions.linear import WgradGroup
+    call = W.shrunk(W.call_Dd(2), 4)
+    shapes, lsi = W.level_tensors(call, "cuda")
+    dec = _decoder_pair()
+    nq, bs, S = 640, call.N, call.S                     # 1280 tokens: above the weight-gradient kernel's threshold
+    g = torch.Generator(device="cuda").manual_seed(6)
+    tgt = torch.randn(nq, bs, 256, device="cuda", generator=g).to(torch.bfloat16)
+    mem = torch.randn(S, bs, 256, device="cuda", generator=g).to(torch.bfloat16)
+    refu = torch.randn(nq, bs, 4, device="cuda", generator=g)
+    vr = torch.rand(bs, 4, 2, device="cuda", generator=g) * 0.2 + 0.8
+    amask = torch.zeros(nq, nq, dtype=torch.bool, device="cuda")
+    amask[40:, :40] = True
+    res = {}
+    for grouped in (True, False):
+        WgradGroup.enabled = grouped
+        try:
+            a, m, r = tgt.clone().requires_grad_(True), mem.clone().requires_grad_(True), refu.clone().requires_grad_(True)
+            hs, refs = dec(tgt=a, memory=m, tgt_mask=amask, memory_key_padding_mask=None, refpoints_unsigmoid=r, level_start_index=lsi,
+                           spatial_shapes=shapes, valid_ratios=vr)
+            hs, refs = torch.stack(hs).float(), torch.stack(refs).float()
+            (hs.square().mean() + refs.square().mean()).backward()
+            res[grouped] = (hs.detach(), a.grad.float(), m.grad.float(), {k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None})
+        finally:
+            WgradGroup.enabled = True
+            dec.zero_grad()
+    (h1, ga1, gm1, gp1), (h0, ga0, gm0, gp0) = res[True], res[False]
+    assert torch.equal(h1, h0) and torch.equal(ga1, ga0) and torch.equal(gm1, gm0)
+    assert sorted(gp1) == sorted(gp0)
+    for k in gp0:
+        assert torch.isfinite(gp1[k]).all(), k
+        assert float((gp1[k].float() - gp0[k].float()).abs().max()) <= 1e-4 * float(gp0[k].float().abs().max()) + 1e-12, k
+
+
 def test_bf16_encoder_layer_close_to_fp32_path():
     """the bf16 ENCODER layer at the shipped width (d_model 256, d_ffn 2048, 8 heads) with the DEFAULT thresholds -- 16800 tokens: lin256
     projections with the padding mask in the epilogue, the operator's bf16 entry points (routed backward), add + LayerNorm kernel, the
