@@ -15,6 +15,7 @@ bfloat16 memory (new capability): the cross-attentions' value projections of ALL
 256 -> 256 x num_layers on ``csrc/lin256_mfma.hip`` with the padding mask in its epilogue -- and the memory's gradient is one product
 too; each layer takes its slice.  (The reference projects the 22 k memory tokens separately in each of its six layers.)
 """
+import contextlib
 import copy
 import math
 
@@ -22,7 +23,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions.linear import (Lin256Function, Lin256NarrowFunction, LinearBf16CachedFunction, StackedValueProjFunction, VersionCache, pack_linear256,
+from ..functions.linear import (WgradBoundary, WgradGroup, Lin256Function, Lin256NarrowFunction, LinearBf16CachedFunction, StackedValueProjFunction, VersionCache, pack_linear256,
                                 pack_linear256_padded)
 
 
@@ -66,17 +67,28 @@ class MLP(nn.Module):
                     forms.append(("gemm", (w.detach().to(torch.bfloat16).contiguous(), b.detach().to(torch.bfloat16).contiguous())))
             return forms
         forms = self._packs.get(ps, build)
-        for i, (layer, (kind, f)) in enumerate(zip(self.layers, forms)):
-            relu = i < self.num_layers - 1
-            if kind == "lin256":
-                x = Lin256Function.apply(x, f, None, relu, layer.weight, layer.bias)
-            elif kind == "lin256pad" and layer.weight.shape[0] <= 8 and not relu:
-                x = Lin256NarrowFunction.apply(x, f, layer.weight, layer.bias)
-            elif kind == "lin256pad":
-                x = Lin256Function.apply(x, f, None, relu, layer.weight, layer.bias)[..., :layer.weight.shape[0]]
-            else:
-                x = LinearBf16CachedFunction.apply(x, f[0], f[1], None, layer.weight, layer.bias)
-                x = F.relu(x) if relu else x
+        # the 256-wide layers' weight gradients in one launch (functions/linear.py: WgradGroup) unless a caller's group is active
+        wb = [(layer.weight, layer.bias) for layer in self.layers]
+        lin = [i for i, (kind, _) in enumerate(forms) if kind == "lin256"]
+        group = None
+        if len(lin) > 1 and WgradGroup.active() is None and WgradGroup.enabled and torch.is_grad_enabled() and wb[lin[0]][0].requires_grad:
+            group = WgradGroup()
+            al = WgradBoundary.apply(group, *[t for i in lin for t in wb[i]])
+            for k, i in enumerate(lin):
+                wb[i] = (al[2 * k], al[2 * k + 1])
+        with (group if group is not None else contextlib.nullcontext()):
+            for i, (layer, (kind, f)) in enumerate(zip(self.layers, forms)):
+                relu = i < self.num_layers - 1
+                w, b = wb[i]
+                if kind == "lin256":
+                    x = Lin256Function.apply(x, f, None, relu, w, b)
+                elif kind == "lin256pad" and w.shape[0] <= 8 and not relu:
+                    x = Lin256NarrowFunction.apply(x, f, w, b)
+                elif kind == "lin256pad":
+                    x = Lin256Function.apply(x, f, None, relu, w, b)[..., :w.shape[0]]
+                else:
+                    x = LinearBf16CachedFunction.apply(x, f[0], f[1], None, w, b)
+                    x = F.relu(x) if relu else x
         return x
 
 

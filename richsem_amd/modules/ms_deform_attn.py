@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions import MaskRows, MSDeformAttnFunction, MSDeformAttnFusedFunction
-from ..functions.linear import Lin256Function, LinearBf16CachedFunction, VersionCache, pack_linear256
+from ..functions.linear import WgradBoundary, WgradGroup, Lin256Function, LinearBf16CachedFunction, VersionCache, pack_linear256
 
 
 def _is_power_of_2(n):
@@ -102,11 +102,13 @@ class MSDeformAttn(nn.Module):
         return self._packs.get(ps, lambda: {"v": pack_linear256([ps[0]], [ps[1]]), "q": pack_linear256([ps[2], ps[4]], [ps[3], ps[5]]),
                                             "o": pack_linear256([ps[6]], [ps[7]])})
 
-    def project_value(self, input_flatten, input_padding_mask=None):
-        """bf16, d_model = 256: ``value_proj(input_flatten)`` with the rows of padded pixels zeroed (reference :94-96), (N, S, C)"""
+    def project_value(self, input_flatten, input_padding_mask=None, params=None):
+        """bf16, d_model = 256: ``value_proj(input_flatten)`` with the rows of padded pixels zeroed (reference :94-96), (N, S, C);
+        ``params``: stand-ins for (value_proj.weight, value_proj.bias) to route the gradients to"""
         pk = self._lin256_packs()
         mask = input_padding_mask.contiguous() if input_padding_mask is not None else None
-        return Lin256Function.apply(input_flatten.to(torch.bfloat16), pk["v"], mask, False, self.value_proj.weight, self.value_proj.bias)
+        vw, vb = params if params is not None else (self.value_proj.weight, self.value_proj.bias)
+        return Lin256Function.apply(input_flatten.to(torch.bfloat16), pk["v"], mask, False, vw, vb)
 
     def forward_from_value(self, query, reference_points, value, input_spatial_shapes, input_level_start_index, params=None):
         """bf16, d_model = 256: the module's forward behind the value projection (reference :97-114) -- for callers that project the
@@ -152,6 +154,16 @@ class MSDeformAttn(nn.Module):
                 # bf16, d_model = 256 (RichSem): the four projections on the library's own MFMA kernel (csrc/lin256_mfma.hip: K = 256) --
                 # value_proj with the padding mask in its epilogue, offsets + logits as ONE 256 -> 384 projection, output_proj; their
                 # input gradients on the same kernel where the layer is 256 -> 256, the weight gradients on the weight-gradient kernel
+                # (the three weight gradients in one launch -- functions/linear.py: WgradGroup -- unless a caller's group is active)
+                group = None
+                if WgradGroup.active() is None and WgradGroup.enabled and torch.is_grad_enabled() and self.value_proj.weight.requires_grad:
+                    group = WgradGroup()
+                    al = WgradBoundary.apply(group, self.value_proj.weight, self.value_proj.bias, self.sampling_offsets.weight,
+                                             self.attention_weights.weight, self.sampling_offsets.bias, self.attention_weights.bias,
+                                             self.output_proj.weight, self.output_proj.bias)
+                    with group:
+                        return self.forward_from_value(query, reference_points, self.project_value(input_flatten, input_padding_mask, al[:2]),
+                                                       input_spatial_shapes, input_level_start_index, params=al[2:])
                 return self.forward_from_value(query, reference_points, self.project_value(input_flatten, input_padding_mask),
                                                input_spatial_shapes, input_level_start_index)
             if dt == torch.bfloat16:
