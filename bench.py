@@ -74,6 +74,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-collective", action="store_true", help="N > 1: leave the gradient all-reduce out")
     ap.add_argument("--no-bf16", action="store_true", help="skip the extra bf16 pass")
+    ap.add_argument("--no-em", action="store_true", help="skip the second encoder shape (1280 x 1280 mosaic batches, S = 34000)")
     ap.add_argument("--no-ffn", action="store_true", help="skip the feed-forward (MFMA) row beside the path")
     ap.add_argument("--no-graph", action="store_true", help="skip the graph-replay variant of the step")
     ap.add_argument("--no-full-step", action="store_true", help="skip the composed training step (bench_step.py) beside the path")
@@ -504,12 +505,13 @@ def main(argv=None):
         buckets = grad_buckets(W.GRAD_ALLREDUCE_ELEMS, W.DDP_BUCKET_BYTES)
         fire_after = bucket_schedule(len(buckets), len(layers))
 
-    def step(mode, with_collective, bf16=False):
+    def step(mode, with_collective, bf16=False, layers_=None):
         vk, gk = ("value_bf16", "grad_out_bf16") if bf16 else ("value", "grad_out")
-        for c, t, locs in layers:
+        layers_ = layers if layers_ is None else layers_
+        for c, t, locs in layers_:
             MSDA.ms_deform_attn_forward(t[vk], t["shapes"], t["lsi"], locs[mode], t["aw"], 64)
         nb = 0
-        for k, (c, t, locs) in enumerate(reversed(layers), 1):
+        for k, (c, t, locs) in enumerate(reversed(layers_), 1):
             MSDA.ms_deform_attn_backward(t[vk], t["shapes"], t["lsi"], locs[mode], t["aw"], t[gk], 64)
             while with_collective and nb < len(buckets) and fire_after[nb] <= k:
                 s, e = buckets[nb]
@@ -524,17 +526,17 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(mode, with_collective, profile, bf16=False):
+    def timed(mode, with_collective, profile, bf16=False, layers_=None):
         _lib.set_option("locality_monitor", _lib.get_option("locality_monitor"))   # forget the previous distribution
         for _ in range(max(args.warmup, 3)):   # (the locality monitor settles within the first two steps)
-            step(mode, with_collective, bf16)
+            step(mode, with_collective, bf16, layers_)
         fence()
         if profile:
-            _lib.profile_enable(calls_per_step * args.steps)
+            _lib.profile_enable((calls_per_step if layers_ is None else 2 * len(layers_)) * args.steps)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step(mode, with_collective, bf16)
+            step(mode, with_collective, bf16, layers_)
         fence()
         elapsed = time.perf_counter() - t0
         records = []
@@ -578,6 +580,22 @@ def main(argv=None):
             res["elapsed_nc"], _ = timed(mode, False, False)
         results[mode] = res
     graph_ms = graph_replay(modes[0]) if (world == 1 and not args.no_graph) else None
+    # The second encoder shape of BASELINE.json's configs[2] / [3]: every other step there is a 1280 x 1280 ImageNet-LVIS mosaic batch
+    # (reference main.py:53-71, datasets/transforms.py:356-357,437-445) -> S = Lq = 34000 (SURVEY.md section 8d "Em").  Its six encoder
+    # forward + backward calls, each layer on its own tensors, timed like the headline step; beside `value`, never it (rank 0's GPU only:
+    # it is a per-kernel measurement, no collective).
+    if world == 1 and not args.no_em:
+        em = W.call_Em(n_img)
+        em_layers = []
+        for layer in range(6):
+            t = W.make_inputs(em, "init", seed=7000 + layer, device=dev)
+            em_layers.append((em, t, {m: (t["loc"] if m == "init" else W.make_loc(em, m, seed=7000 + layer, device=dev))
+                                      for m in ("init", "uniform")}))
+        for m in ("init", "uniform"):
+            elapsed, records = timed(m, False, True, layers_=em_layers)
+            results["Em/" + m] = {"elapsed": elapsed, "records": records}
+        del em_layers
+        torch.cuda.empty_cache()
     if not args.no_bf16:   # the same step with bf16 value / out / grad tensors (library entry points msda_*_bf16), headline distribution
         for c, t, locs in layers:
             t["value_bf16"], t["grad_out_bf16"] = t["value"].to(torch.bfloat16), t["grad_out"].to(torch.bfloat16)
@@ -603,7 +621,7 @@ def main(argv=None):
                 by.setdefault((r["kind"], r["Lq"], r["variant"]), []).append(r["kernel_ms"])
             kernels = []
             for (kind, Lq, variant), ms in sorted(by.items()):
-                call = next(c for c, _ in calls if c.Lq == Lq)
+                call = next(c for c in [c for c, _ in calls] + [W.call_Em(n_img)] if c.Lq == Lq)
                 e_v = 2 if mode == "bf16" else 4   # bytes per value / out / grad element
                 nbytes = call.bytes_bwd(e_v) if kind == "bwd" else call.bytes_fwd(e_v)
                 avg = sum(ms) / len(ms)
@@ -649,6 +667,17 @@ def main(argv=None):
             line["bf16"] = {"dtype": "bf16 value/out/grad, f32 locations/weights and accumulation", "loc": modes[0],
                             "value": b["value"], "ms_per_step": b["ms_per_step"], "roofline": b["roofline"],
                             "kernels": b["kernels"]}
+        if "Em/init" in results:
+            wl = {}
+            for m in ("init", "uniform"):
+                e = summarise("Em/" + m)
+                wl[m] = {"ms_per_6_layers_fwd_bwd": e["ms_per_step"], "kernels": e["kernels"], "roofline": e["roofline"]}
+            line["workloads"] = {"Em": {
+                "what": "the second encoder shape: 1280 x 1280 ImageNet-LVIS mosaic batches of configs[2] / [3] (every other step there), "
+                        f"bs={n_img}/GPU, S = Lq = 34000 (160^2, 80^2, 40^2, 20^2), M=8 D=32 L=P=4, fp32; six encoder forward + backward "
+                        "calls on six tensor sets; algorithmic bytes per call 243.7 MB forward / 417.8 MB backward (SURVEY.md section 8d); "
+                        "beside `value`, never it",
+                "loc": wl}}
         if graph_ms is not None:
             line["graph_replay"] = {"what": "the same step (no collective) captured into one HIP graph and replayed; not `value`",
                                     "ms_per_step": round(graph_ms, 4), "img_per_s": round(n_total / (graph_ms * 1e-3), 3)}

@@ -359,7 +359,9 @@ class Step(nn.Module):
 
     def loss_part(self, logits, coords, il, ib, clip_logits, t_logits, labels, boxes, m_dec, m_int, m_dis):
         """criterion (richsem.py:1124-1306, compact): the same per-output sums as the reference's loop over the 6 + 1 outputs -- sigmoid focal
-        loss, L1 + GIoU on the matched pairs and on the denoising queries' positive slots, KL distillation -- formed in ONE pass per kind over
+        loss (over every query incl. the denoising part's negative slots, whose target is no-object; the federated-loss class sampling of
+        use_fed_loss is not restated: all classes count), L1 + GIoU on the matched pairs and on the denoising queries' positive slots, KL
+        distillation -- formed in ONE pass per kind over
         the stacked outputs: the all-negative focal term of a whole logit tensor is one kernel each way (matcher.FocalNegativeSum), and the
         positive entries / box pairs of the matched, two-stage and denoising parts are concatenated with a weight each (1 / num_boxes, or
         1 / (num_boxes x groups)) so that every loss formula runs once -- as one kernel each (matcher.FocalPositiveSum, matcher.BoxPairLoss:
@@ -376,9 +378,11 @@ class Step(nn.Module):
         cst = st.get("loss_static")
         if cst is None or cst["key"] != (nl, N, Q, pad, groups, single):      # index / weight tensors the batch's geometry fixes
             pos_slots = (torch.arange(groups, device=dev)[:, None] * 2 * single + torch.arange(single, device=dev)[None]).flatten()
-            w_q = torch.zeros(Q, dtype=torch.float32, device=dev)
+            # (reference richsem.py:938-964: loss_labels of the denoising part runs the focal loss over ALL pad_size denoising queries --
+            # the negative slots with the no-object target -- normalised by num_boxes x groups, :1180 / :1227; the matching part by num_boxes)
+            w_q = torch.empty(Q, dtype=torch.float32, device=dev)
+            w_q[:pad] = 1.0 / nbx
             w_q[pad:] = 1.0 / num_boxes
-            w_q[pos_slots] = 1.0 / nbx
             n_dn = nl * N * pos_slots.numel()
             cst = {"key": (nl, N, Q, pad, groups, single), "pos_slots": pos_slots,
                    "w_rows": w_q[None, None, :].expand(nl, N, Q).contiguous(),

@@ -501,13 +501,18 @@ hipError_t launch_bwd_rps(const Problem &pb, const TV *value, const float *loc, 
     auto kern = pb.P == 4 ? &msda::rps_tile_kernel<true, TV> : &msda::rps_tile_kernel<false, TV>;
     hipError_t e = msda::set_lds_limit(reinterpret_cast<const void *>(kern), sizeof(msda::RpsLds));
     if (e != hipSuccess) return e;
-    // route passes: a workgroup (8 waves) per block of queries of an (image, head)
+    // route passes: a workgroup (8 waves; 16 where the plan asks for them) per block of queries of an (image, head)
     const int qpw = pb.P <= 4 ? 16 : (pb.P <= 8 ? 8 : (pb.P <= 16 ? 4 : (pb.P <= 32 ? 2 : 1)));
-    const int qpb = qpw * (msda::kRpsRouteThreads / msda::kWave);
+    const int qpb = qpw * (pl.g.route_threads / msda::kWave);
     const int64_t r_items = (int64_t)pb.N * pb.M * ((pb.Lq + qpb - 1) / qpb);
-    const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(r_items, (int64_t)msda::rps_options().route_wgs.load() * cu_count()));
-    hipLaunchKernelGGL(msda::rps_route_kernel, dim3(rgrid), dim3(msda::kRpsRouteThreads), (size_t)pl.g.lut_n * sizeof(unsigned), stream, loc, aw,
-                       grad_acc, grad_loc, grad_aw, pl.g);
+    const int route_wgs = pl.g.route_threads > 512 ? 1 : msda::rps_options().route_wgs.load();      // (16 waves at 102 registers: one workgroup per CU)
+    const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(r_items, (int64_t)route_wgs * cu_count()));
+    if (pl.g.route_threads > 512)
+        hipLaunchKernelGGL(msda::rps_route_kernel<msda::kRpsRouteThreadsMax>, dim3(rgrid), dim3(msda::kRpsRouteThreadsMax),
+                           (size_t)pl.g.lut_n * sizeof(unsigned), stream, loc, aw, grad_acc, grad_loc, grad_aw, pl.g);
+    else
+        hipLaunchKernelGGL(msda::rps_route_kernel<512>, dim3(rgrid), dim3(512), (size_t)pl.g.lut_n * sizeof(unsigned), stream, loc, aw,
+                           grad_acc, grad_loc, grad_aw, pl.g);
     const int grid = (cu_count() / msda::kXcds) * msda::kXcds;   // persistent: one workgroup per CU (its LDS is most of a CU's)
 #ifdef RPS_ROUTE_ABLATION
     if (pl.g.dbg & 0x300) {      // diagnostic: route-pass ablations -- the records are not what the tile kernel expects; wrong results

@@ -82,6 +82,7 @@ struct RpsGeom {
     unsigned long long *bin_state;   // [nbins], one per 128-B line (stride kRpsPad / 2): records of the bin (low word) | runs (high word); zero between calls
     uint2 *runs;            // [nbins * max_runs] a bin's runs in the record pool: {first record, position of the run inside the bin}
     int max_runs;           // runs a bin can get = query blocks of a pair (every route work item adds at most one run to a bin)
+    int route_threads;      // threads of a route workgroup (512, or 1024 where 512 would give a bin more than kRpsMaxRuns runs)
     unsigned entries_cap;   // records the pool holds (4 x points: exact worst case); indices are clamped to it, so that counters left
                             // dirty by an aborted call can give wrong results but never an access outside the pool
     struct RpsRec *entries;         // one 16-byte record per (point, bin it was routed to)
@@ -192,9 +193,13 @@ __device__ __forceinline__ unsigned rps_lut_col(const RpsLevel &v, int c)
 // kernel's queue heads are reset.
 // Lanes of a wave usually share the owner bin (neighbouring queries, neighbouring points): they are matched with one ballot and
 // served by a single LDS atomic; the others take one each.
-constexpr int kRpsRouteThreads = 512;
-static_assert(kRpsMaxUnits <= kRpsRouteThreads, "route pass: one thread per bin of a pair");
+// kRpsRouteThreads: 512 (8 waves: 128 queries per work item at P <= 4) is the form every shape up to Lq = 256 x 128 takes; longer query
+// sets (the 1280 x 1280 mosaic batches: Lq = 34000) run the same kernel with 1024 threads -- 256 queries per work item, so that a bin
+// still gets at most kRpsMaxRuns runs (the tile kernel keeps a bin's run table in LDS).
+constexpr int kRpsRouteThreadsMax = 1024;
+static_assert(kRpsMaxUnits <= 512, "route pass: one thread per bin of a pair");
 
+template <int kRpsRouteThreads>
 __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float *__restrict__ loc, const float *__restrict__ aw,
                                                                      float *__restrict__ grad_value, float *__restrict__ grad_loc,
                                                                      float *__restrict__ grad_aw, const RpsGeom g)
@@ -1139,12 +1144,21 @@ inline RpsPlan plan_rps(int N, int S, int M, int D, int L, int Lq, int P, const 
     for (int i = 0; i < g.nunits; ++i) g.units[i] = units[i].code;
     g.bins_per_pair = bins;
     g.nbins = bins * N * M;
-    // runs a bin can get: one per route work item of its pair (the route pass's block of queries: 16 queries per wave at P <= 4)
+    // runs a bin can get: one per route work item of its pair (the route pass's block of queries: 16 queries per wave at P <= 4).  The
+    // tile kernel keeps a bin's run table in LDS (kRpsMaxRuns entries): where 8-wave route workgroups would write more runs than that
+    // (Lq > 32768 at P <= 4: the 1280 x 1280 mosaic batches of ImageNet-LVIS, reference datasets/transforms.py:356-357,437-445, have
+    // Lq = 34000) the route pass runs with 16 waves per workgroup -- half the runs.
     const int qpw = P <= 4 ? 16 : (P <= 8 ? 8 : (P <= 16 ? 4 : (P <= 32 ? 2 : 1)));
+    g.route_threads = 512;
     g.max_runs = (Lq + qpw * 8 - 1) / (qpw * 8);
-    if (g.max_runs > kRpsMaxRuns) return pl;      // (the tile kernel keeps a bin's run table in LDS)
-    // the record pool: a stretch per route work item (pair, block of qpw x 8 queries), each for the worst case of 4 bins per point
-    pl.max_entries = (size_t)N * M * g.max_runs * (size_t)(qpw * 8) * L * P * 4;
+    if (g.max_runs > kRpsMaxRuns) {
+        g.route_threads = kRpsRouteThreadsMax;
+        g.max_runs = (Lq + qpw * 16 - 1) / (qpw * 16);
+    }
+    if (g.max_runs > kRpsMaxRuns) return pl;
+    const int qpb = qpw * (g.route_threads / kWave);
+    // the record pool: a stretch per route work item (pair, block of qpb queries), each for the worst case of 4 bins per point
+    pl.max_entries = (size_t)N * M * g.max_runs * (size_t)qpb * L * P * 4;
     if (pl.max_entries >= ((size_t)1 << 32)) return pl;
     pl.ok = true;
     return pl;

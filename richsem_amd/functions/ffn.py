@@ -194,7 +194,7 @@ class FFNSmallFunction(Function):
         ctx.save_for_backward(x2, h, yhat, rstd, lw, w2t_packed, pk1["w16"])
         ctx.meta = (x.shape, tuple(p.dtype for p in (w1, b1, w2, b2, ln_weight, ln_bias)))
         from .linear import WgradGroup
-        ctx.group = WgradGroup.active()
+        ctx.group = WgradGroup.active_for((w1, b1, w2))      # (only a boundary's aliases are deferred: functions/linear.py)
         return out.view(x.shape)
 
     @staticmethod
@@ -214,7 +214,7 @@ class FFNSmallFunction(Function):
         gh = lin256(dz, w2t_packed, relu_mask=h)
         g_w1 = g_b1 = None
         if need[5] or need[6]:
-            grp1 = deferrable(ctx.group, gh, x2, (dts[0], dts[1]))
+            grp1 = deferrable(ctx.group, gh, x2, (dts[0], dts[1])) if (need[5] and need[6]) else None
             if grp1 is not None:
                 g_w1, g_b1 = grp1.add(gh, x2, True)
             else:

@@ -23,7 +23,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions.linear import (WgradBoundary, WgradGroup, Lin256Function, Lin256NarrowFunction, LinearBf16CachedFunction, StackedValueProjFunction, VersionCache, pack_linear256,
+from ..functions.linear import (wgrad_boundary, WgradGroup, Lin256Function, Lin256NarrowFunction, LinearBf16CachedFunction, StackedValueProjFunction, VersionCache, pack_linear256,
                                 pack_linear256_padded)
 
 
@@ -73,7 +73,7 @@ class MLP(nn.Module):
         group = None
         if len(lin) > 1 and WgradGroup.active() is None and WgradGroup.enabled and torch.is_grad_enabled() and wb[lin[0]][0].requires_grad:
             group = WgradGroup()
-            al = WgradBoundary.apply(group, *[t for i in lin for t in wb[i]])
+            al = wgrad_boundary(group, *[t for i in lin for t in wb[i]])
             for k, i in enumerate(lin):
                 wb[i] = (al[2 * k], al[2 * k + 1])
         with (group if group is not None else contextlib.nullcontext()):

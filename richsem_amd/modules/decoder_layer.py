@@ -26,7 +26,7 @@ from torch import nn
 
 from ..functions.attention import masked_self_attention
 from ..functions.ffn import AddLayerNormFunction, FFNSmallFunction
-from ..functions.linear import Lin256Function, VersionCache, WgradBoundary, WgradGroup, lin256_pack, pack_linear256
+from ..functions.linear import Lin256Function, VersionCache, wgrad_boundary, WgradGroup, lin256_pack, pack_linear256
 from .ms_deform_attn import MSDeformAttn
 
 
@@ -92,7 +92,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         # backward runs behind every function below; each alias feeds exactly one of them (in_proj's two slices are one alias each)
         group = WgradGroup() if (self.group_wgrad and WgradGroup.enabled and torch.is_grad_enabled() and w.requires_grad) else None
         if group is not None:
-            wqk, wv, bqk, bv, ow, ob, l1w, l1b, l2w, *cross = WgradBoundary.apply(group, w[:512], w[512:], b[:512], b[512:], ow, ob, l1w, l1b, l2w, *cross)
+            wqk, wv, bqk, bv, ow, ob, l1w, l1b, l2w, *cross = wgrad_boundary(group, w[:512], w[512:], b[:512], b[512:], ow, ob, l1w, l1b, l2w, *cross)
         else:
             wqk, wv, bqk, bv = w[:512], w[512:], b[:512], b[512:]
         with (group if group is not None else contextlib.nullcontext()):

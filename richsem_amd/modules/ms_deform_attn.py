@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions import MaskRows, MSDeformAttnFunction, MSDeformAttnFusedFunction
-from ..functions.linear import WgradBoundary, WgradGroup, Lin256Function, LinearBf16CachedFunction, VersionCache, pack_linear256
+from ..functions.linear import wgrad_boundary, WgradGroup, Lin256Function, LinearBf16CachedFunction, VersionCache, pack_linear256
 
 
 def _is_power_of_2(n):
@@ -158,7 +158,7 @@ class MSDeformAttn(nn.Module):
                 group = None
                 if WgradGroup.active() is None and WgradGroup.enabled and torch.is_grad_enabled() and self.value_proj.weight.requires_grad:
                     group = WgradGroup()
-                    al = WgradBoundary.apply(group, self.value_proj.weight, self.value_proj.bias, self.sampling_offsets.weight,
+                    al = wgrad_boundary(group, self.value_proj.weight, self.value_proj.bias, self.sampling_offsets.weight,
                                              self.attention_weights.weight, self.sampling_offsets.bias, self.attention_weights.bias,
                                              self.output_proj.weight, self.output_proj.bias)
                     with group:

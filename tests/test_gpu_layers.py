@@ -395,6 +395,26 @@ def test_grouped_layer_weight_gradients_equal_the_separate_launches():
         assert float((gp1[k].float() - gp0[k].float()).abs().max()) <= 1e-4 * float(gp0[k].float().abs().max()) + 1e-12, k
 
 
+def test_lin256_on_raw_parameters_inside_an_active_group_is_not_deferred():
+    """round-4 advice: `Lin256Function` called on RAW module parameters while some layer's WgradGroup is active must not hand autograd an
+    unwritten gradient (AccumulateGrad could run before the group's flush): only the group's own boundary aliases are deferred.  Same
+    weight gradient as without any group, and nothing left pending."""
+    from richsem_amd.functions.linear import Lin256Function, WgradGroup, pack_linear256
+    torch.manual_seed(4)
+    lin = torch.nn.Linear(256, 256).cuda()
+    x = torch.randn(2048, 256, device="cuda").to(torch.bfloat16)
+    pk = pack_linear256([lin.weight], [lin.bias])
+    Lin256Function.apply(x, pk, None, False, lin.weight, lin.bias).float().square().mean().backward()
+    want_w, want_b = lin.weight.grad.clone(), lin.bias.grad.clone()
+    lin.zero_grad()
+    group = WgradGroup()
+    with group:
+        y = Lin256Function.apply(x, pk, None, False, lin.weight, lin.bias)
+    y.float().square().mean().backward()
+    assert not group.pending
+    assert torch.equal(lin.weight.grad, want_w) and torch.equal(lin.bias.grad, want_b)
+
+
 def test_bf16_encoder_layer_close_to_fp32_path():
     """the bf16 ENCODER layer at the shipped width (d_model 256, d_ffn 2048, 8 heads) with the DEFAULT thresholds -- 16800 tokens: lin256
     projections with the padding mask in the epilogue, the operator's bf16 entry points (routed backward), add + LayerNorm kernel, the

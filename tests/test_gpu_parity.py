@@ -272,6 +272,48 @@ def test_full_size_properties(which, n_images):
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("loc_mode", ["init", "uniform"])
+@pytest.mark.parametrize("which", ["E", "Em"])
+def test_full_size_encoder_calls_against_oracle(which, loc_mode):
+    """The two encoder-shaped calls of BASELINE.json's configurations AT FULL SIZE -- E (800 x 1344: S = Lq = 22323) and the 1280 x 1280
+    mosaic step Em of the ImageNet-LVIS batches (S = Lq = 34000; reference main.py:53-71, datasets/transforms.py:356-357,437-445) --
+    forward and backward against the oracle (all host threads: ~0.1-0.3 s per call), in automatic mode, AND which kernels ran: the
+    routed backward is THE encoder-shaped backward at both shapes (round 4's planner refused Em -- 266 runs per bin for a 256-entry
+    table -- and the call silently took the direct path), the window forward at the init pattern once the locality monitor has
+    its verdict."""
+    call = {"E": W.call_E, "Em": W.call_Em}[which](2)
+    t = W.make_inputs(call, loc_mode, seed=5)
+    z = {k: v.numpy() for k, v in t.items()}
+    g = {k: v.cuda() for k, v in t.items()}
+    # (a verdict is kept per (shape, sampling_loc ADDRESS) and refreshed every 64th call: the allocator may hand this test the address an
+    # earlier test's tensor had -- start from an empty table, as a new training run does)
+    _lib.set_option("locality_monitor", _lib.get_option("locality_monitor"))
+    fwd = lambda: MSDA.ms_deform_attn_forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["aw"], 64)
+    res = {}
+
+    def bwd():
+        res["g"] = MSDA.ms_deform_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["aw"], g["grad_out"], 64)
+
+    assert _profiled_variants(bwd) == [("bwd", 4)], "the routed kernels must be the ones that ran"
+    outs = []
+    for _ in range(6):      # (the monitor probes on the first two calls and reads the counts on a later one)
+        outs.append(fwd())
+        torch.cuda.synchronize()
+    ran_fwd = _profiled_variants(lambda: outs.append(fwd()))
+    assert ran_fwd == [("fwd", 2 if loc_mode == "init" else 1)], ran_fwd
+    O.set_threads(O.max_threads())
+    try:
+        oo = O.forward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"])
+        ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
+    finally:
+        O.set_threads(1)
+    tf, tg = tols(np.float32)
+    for o in (outs[0], outs[-1]):      # the probing call (window kernel or direct) and the settled choice
+        assert rel_err(o, oo) < tf
+    gv, gl, ga = res["g"]
+    assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg
+
+
 @pytest.mark.parametrize("opts", [
     {"tile_persist": 0},                     # one workgroup per work item instead of persistent workgroups
     {"tile_region": 12, "tile_margin": 3},   # small windows: many samples take the general (global) path

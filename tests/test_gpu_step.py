@@ -119,8 +119,23 @@ def test_graphed_sections_train_like_the_eager_step():
     assert 0.7 < res["grad_norm"] / gnorm < 1.4, (res["grad_norm"], gnorm)
 
 
+def _sigmoid_focal_loss(inputs, targets, num_boxes, alpha=0.25, gamma=2):
+    """the reference's formula (models/richsem/utils.py:82-108), which tests/golden/criterion_reference.npz pins"""
+    import torch.nn.functional as F
+    prob = inputs.sigmoid()
+    ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = prob * targets + (1 - prob) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    return loss.mean(1).sum() / num_boxes
+
+
 def _criterion_op_by_op(model, logits, coords, il, ib, clip_logits, t_logits, labels, boxes, m_dec, m_int, m_dis):
-    """the criterion as the plain op sequence round 3 ran (one focal / box-loss evaluation per part): the yardstick of the batched form"""
+    """the criterion as the REFERENCE's loop over the 6 + 1 outputs and the denoising parts (richsem.py:1124-1306, use_fed_loss off):
+    per output ``loss_labels`` = sigmoid_focal_loss on one-hot targets x queries (:938-964), ``loss_boxes`` = L1 / num_boxes + (1 - GIoU)
+    / num_boxes on the matched pairs; the denoising part of every decoder output with ALL pad_size queries in the focal loss (negative
+    slots: no-object target), the positive slots' boxes, normalised by num_boxes x groups (:1166-1180, :1220-1227) -- the yardstick of
+    the batched form (bench_step.Step.loss_part)"""
     import torch.nn.functional as F
     from bench_step import box_cxcywh_to_xyxy, giou_pairs
     st = model.static
@@ -128,37 +143,76 @@ def _criterion_op_by_op(model, logits, coords, il, ib, clip_logits, t_logits, la
     lay = st["lay"]
     pad, groups, single = lay["pad_size"], lay["num_dn_group"], lay["single_pad"]
     num_boxes = float(max(sum(st["known_num"]), 1))
-    nl, N = logits.shape[0], logits.shape[1]
-    alpha = 0.25
+    nl, N, C = logits.shape[0], logits.shape[1], logits.shape[-1]
 
-    def box_losses(pb, tb, norm):
+    def loss_labels(src_logits, bi, si, tl, norm):
+        target_classes = torch.full(src_logits.shape[:2], C, dtype=torch.int64, device=dev)
+        target_classes[bi, si] = tl
+        onehot = torch.zeros(src_logits.shape[:2] + (C + 1,), dtype=src_logits.dtype, device=dev)
+        onehot.scatter_(2, target_classes.unsqueeze(-1), 1)
+        return _sigmoid_focal_loss(src_logits, onehot[:, :, :-1], norm) * src_logits.shape[1]
+
+    def loss_boxes(pb, tb, norm):
         return (5.0 * (pb - tb).abs().sum() + 2.0 * (1 - giou_pairs(box_cxcywh_to_xyxy(pb), box_cxcywh_to_xyxy(tb))).sum()) / norm
 
-    p_all = logits.sigmoid()
-    neg_all = (1 - alpha) * p_all * p_all * F.softplus(logits)
-
-    def focal_pos(x, q):
-        return (alpha * (1 - q) ** 2 * F.softplus(-x) - (1 - alpha) * q * q * F.softplus(x)).sum()
-
     li, bi, si, tj = m_dec
-    sel = (li, bi, si + pad, labels[tj])
-    loss = (neg_all[:, :, pad:].sum() + focal_pos(logits[sel], p_all[sel])) / num_boxes
-    loss = loss + box_losses(coords[li, bi, si + pad], boxes[tj], num_boxes)
-    _, bi, si, tj = m_int
-    ip = il.sigmoid()
-    tl = labels[tj]
-    loss = loss + (((1 - alpha) * ip * ip * F.softplus(il)).sum() + focal_pos(il[bi, si, tl], ip[bi, si, tl])) / num_boxes
-    loss = loss + box_losses(ib[bi, si], boxes[tj], num_boxes)
     pos_slots = (torch.arange(groups, device=dev)[:, None] * 2 * single + torch.arange(single, device=dev)[None]).flatten()
-    tlab = labels.view(N, -1).repeat(1, groups)
-    tbx = boxes.view(N, -1, 4).repeat(1, groups, 1)
+    dn_b = torch.arange(N, device=dev)[:, None].expand(N, pos_slots.numel()).reshape(-1)
+    dn_q = pos_slots[None].expand(N, -1).reshape(-1)
+    dn_lab = labels.view(N, -1).repeat(1, groups).reshape(-1)
+    dn_box = boxes.view(N, -1, 4).repeat(1, groups, 1).reshape(-1, 4)
     nbx = num_boxes * groups
-    dl, dp, db = logits[:, :, pos_slots], p_all[:, :, pos_slots], coords[:, :, pos_slots]
-    hot = tlab[None, :, :, None].expand(nl, -1, -1, 1)
-    loss = loss + (neg_all[:, :, pos_slots].sum() + focal_pos(dl.gather(3, hot), dp.gather(3, hot))) / nbx
-    loss = loss + box_losses(db.reshape(-1, 4), tbx[None].expand(nl, -1, -1, -1).reshape(-1, 4), nbx)
+    loss = 0.0
+    for l in range(nl):
+        k = li == l
+        loss = loss + loss_labels(logits[l][:, pad:], bi[k], si[k], labels[tj[k]], num_boxes)
+        loss = loss + loss_boxes(coords[l][bi[k], si[k] + pad], boxes[tj[k]], num_boxes)
+        loss = loss + loss_labels(logits[l][:, :pad], dn_b, dn_q, dn_lab, nbx)
+        loss = loss + loss_boxes(coords[l][dn_b, dn_q], dn_box, nbx)
+    _, bi, si, tj = m_int
+    loss = loss + loss_labels(il, bi, si, labels[tj], num_boxes) + loss_boxes(ib[bi, si], boxes[tj], num_boxes)
     _, bi, si, tj = m_dis
     return loss + 0.5 * F.kl_div(F.log_softmax(clip_logits[bi, si + pad], -1), F.softmax(t_logits[tj], -1), reduction="batchmean")
+
+
+def test_criterion_kernels_against_the_reference_loss_functions():
+    """tests/golden/criterion_reference.npz (made by tests/golden/make_golden_criterion.py from the reference's OWN ``sigmoid_focal_loss``,
+    models/richsem/utils.py:82-108, called as ``loss_labels`` calls it, and ``generalized_box_iou`` / ``box_cxcywh_to_xyxy``,
+    util/box_ops.py:9-64, called as ``loss_boxes`` calls them; float64 on float32-exact inputs): the focal loss as the library forms it --
+    all-negative kernel + positive-entry kernel -- and the box-pair kernel, values and gradients.  Also the op-sequence yardstick above."""
+    import os
+    import numpy as np
+    from richsem_amd.matcher import BoxPairLoss, FocalNegativeSum, FocalPositiveSum
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "criterion_reference.npz"))
+    for tag in ("match", "dn"):
+        x = torch.from_numpy(z[f"focal_{tag}.logits"]).cuda().requires_grad_(True)
+        tc = torch.from_numpy(z[f"focal_{tag}.target_classes"]).cuda()
+        nb, want, want_g = float(z[f"focal_{tag}.num_boxes"]), float(z[f"focal_{tag}.loss"]), torch.from_numpy(z[f"focal_{tag}.grad"]).cuda()
+        N, Q, C = x.shape
+        w_rows = torch.full((N, Q), 1.0 / nb, dtype=torch.float32, device="cuda")
+        b, q = (tc < C).nonzero(as_tuple=True)
+        loss = FocalNegativeSum.apply(x, w_rows, 0.25) + FocalPositiveSum.apply(x[b, q, tc[b, q]], torch.full((b.numel(),), 1.0 / nb, device="cuda"), 0.25)
+        loss.backward()
+        assert abs(float(loss) - want) < 1e-5 * abs(want), (tag, float(loss), want)
+        assert float((x.grad.double() - want_g).abs().max()) < 1e-5 * float(want_g.abs().max()), tag
+        # the yardstick restates the same formula: hold it to the fixture as well (fp64)
+        xd = torch.from_numpy(z[f"focal_{tag}.logits"]).cuda().double()
+        onehot = torch.zeros((N, Q, C + 1), dtype=torch.float64, device="cuda").scatter_(2, tc.unsqueeze(-1), 1)[:, :, :-1]
+        assert abs(float(_sigmoid_focal_loss(xd, onehot, nb) * Q) - want) < 1e-12 * abs(want)
+    pb = torch.from_numpy(z["box.pred"]).cuda().requires_grad_(True)
+    tb, w = torch.from_numpy(z["box.tgt"]).cuda(), torch.from_numpy(z["box.w"]).cuda()
+    loss = BoxPairLoss.apply(pb, tb, w, 5.0, 2.0)
+    loss.backward()
+    want, want_g = float(z["box.loss"]), torch.from_numpy(z["box.grad"]).cuda()
+    assert abs(float(loss) - want) < 1e-5 * abs(want), (float(loss), want)
+    # (identical boxes sit on the kink of |x| and of every max / min: the subgradient chosen there is the implementation's own)
+    rows = torch.ones(pb.shape[0], dtype=torch.bool, device="cuda")
+    rows[:5] = False
+    assert float((pb.grad.double() - want_g)[rows].abs().max()) < 2e-4 * float(want_g.abs().max())
+    from bench_step import box_cxcywh_to_xyxy, giou_pairs
+    pd, td = pb.detach().double(), tb.double()
+    assert float((giou_pairs(box_cxcywh_to_xyxy(pd), box_cxcywh_to_xyxy(td)) - torch.from_numpy(z["box.giou"]).cuda()).abs().max()) < 1e-12
+    assert float(((pd - td).abs().sum(-1) - torch.from_numpy(z["box.l1"]).cuda()).abs().max()) < 1e-12
 
 
 def test_batched_criterion_equals_the_op_sequence():

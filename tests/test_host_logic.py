@@ -220,3 +220,54 @@ def test_fold_bn_matches_the_reference_frozen_batchnorm():
     scale, shift = fold_bn(t["weight"], t["bias"], t["running_mean"], t["running_var"])
     y = t["x"] * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     assert torch.allclose(y, t["y"], rtol=1e-6, atol=1e-6)
+
+
+def test_wgrad_group_protocol_is_enforced(monkeypatch):
+    """functions/linear.py: a deferring function hands autograd an EMPTY weight gradient that the group's boundary fills later.  That is
+    only correct for aliases made by that group's boundary, each feeding exactly one function -- both are checked, not assumed: raw
+    parameters inside an active group are not deferred, and an alias that feeds two functions raises at the boundary (autograd has summed
+    the unwritten tensors by then) instead of training on garbage.  (The launch itself is replaced by a fill: no GPU here.)"""
+    from richsem_amd.functions.linear import WgradGroup, wgrad_boundary
+    monkeypatch.setattr(WgradGroup, "_launch", staticmethod(lambda pend: [t[2].fill_(7.0) for t in pend]))
+    seen = {}
+
+    class Deferring(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.group = seen["group"] = WgradGroup.active_for((w,))
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, dy):
+            dw = torch.empty(3)
+            if ctx.group is not None:
+                ctx.group.pending.append((None, None, dw, None))
+            else:
+                dw.fill_(7.0)
+            return dy * 2, dw
+
+    w, x = torch.zeros(3, requires_grad=True), torch.ones(3, requires_grad=True)
+    group = WgradGroup()
+    (alias,) = wgrad_boundary(group, w)
+    with group:
+        y = Deferring.apply(x, alias)
+        assert seen["group"] is group                     # the boundary's alias: deferred
+        y_raw = Deferring.apply(x, w)
+        assert seen["group"] is None                      # the raw parameter inside the active group: computed on the spot
+    (y.sum() + y_raw.sum()).backward()
+    assert torch.equal(w.grad, torch.full((3,), 14.0))
+    other = WgradGroup()
+    wgrad_boundary(other, w)
+    with group:
+        Deferring.apply(x, alias)
+        assert seen["group"] is group
+    with other:
+        Deferring.apply(x, alias)
+        assert seen["group"] is None                      # another group's alias
+    w.grad = None
+    group = WgradGroup()
+    (alias,) = wgrad_boundary(group, w)
+    with group:
+        y = Deferring.apply(x, alias) + Deferring.apply(x, alias)
+    with pytest.raises(RuntimeError, match="fed more than one function"):
+        y.sum().backward()
