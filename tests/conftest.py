@@ -9,7 +9,7 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # fixtures of the OPERATOR (value, shapes, lsi, loc, aw, grad_out -> out, grads): every .npz that is not a fixture of another row
-_OTHER_ROWS = ("module_", "attnpool_", "clip_resnet_", "layer_", "layer256_", "decoder_stack", "decoder256_", "dn_", "matcher_", "cls_", "frozenbn_")
+_OTHER_ROWS = ("module_", "attnpool_", "clip_resnet_", "layer_", "layer256_", "decoder_stack", "decoder256_", "dn_", "matcher_", "cls_", "frozenbn_", "criterion_")
 OP_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith(_OTHER_ROWS))
 
 
