@@ -247,12 +247,14 @@ class Step(nn.Module):
         pad, groups = lay["pad_size"], lay["num_dn_group"]
         labels, boxes = torch.cat([t["labels"] for t in targets]), torch.cat([t["boxes"] for t in targets])
         known_labels, known_boxes = labels.repeat(2 * groups), boxes.repeat(2 * groups, 1)
-        p = torch.rand(known_labels.shape, device=dev)
-        noised = torch.where(p < 0.25, torch.randint(0, NUM_CLASSES, known_labels.shape, device=dev), known_labels)
+        fz = self.frozen_noise      # (tests: the same draws in every step and in every form of the step -- see freeze_noise)
+        p = torch.rand(known_labels.shape, device=dev) if fz is None else fz["p"]
+        rnd_lab = torch.randint(0, NUM_CLASSES, known_labels.shape, device=dev) if fz is None else fz["labels"]
+        noised = torch.where(p < 0.25, rnd_lab, known_labels)
         xyxy = box_cxcywh_to_xyxy(known_boxes)
         diff = torch.cat((known_boxes[:, 2:] / 2, known_boxes[:, 2:] / 2), 1)
-        sign = torch.randint(0, 2, xyxy.shape, device=dev).float() * 2 - 1
-        rand_part = torch.rand(xyxy.shape, device=dev)
+        sign = (torch.randint(0, 2, xyxy.shape, device=dev).float() * 2 - 1) if fz is None else fz["sign"]
+        rand_part = torch.rand(xyxy.shape, device=dev) if fz is None else fz["rand"]
         neg = (torch.arange(known_labels.numel(), device=dev) // labels.numel()) % 2 == 1
         rand_part = torch.where(neg[:, None], rand_part + 1.0, rand_part) * sign
         xyxy = (xyxy + rand_part * diff).clamp(0.0, 1.0)
@@ -303,6 +305,18 @@ class Step(nn.Module):
         return loss
 
     _model_only = False
+    frozen_noise = None
+
+    def freeze_noise(self, seed):
+        """draw the denoising noise ONCE from ``seed`` and use it in every later step (a training step draws it anew each time,
+        dn_components.py:72-110): eager, captured and graphed forms of the step can then be compared parameter by parameter"""
+        st = self.static
+        n = 2 * st["lay"]["num_dn_group"] * sum(st["known_num"])
+        g = torch.Generator(device=self.level_embed.device).manual_seed(seed)
+        dev = self.level_embed.device
+        self.frozen_noise = {"p": torch.rand(n, device=dev, generator=g), "labels": torch.randint(0, NUM_CLASSES, (n,), device=dev, generator=g),
+                             "sign": torch.randint(0, 2, (n, 4), device=dev, generator=g).float() * 2 - 1,
+                             "rand": torch.rand((n, 4), device=dev, generator=g)}
 
     def model_part(self, images, mask=None, targets=None, teacher=True):
         """the step up to the matcher: -> (logits (6, N, Q, C), boxes (6, N, Q, 4), two-stage logits, two-stage boxes, distillation logits,
@@ -419,6 +433,31 @@ class Step(nn.Module):
         return out
 
 
+def pin_grad_accumulators(params):
+    """Create every parameter's AccumulateGrad node NOW -- on the current stream -- and return the nodes; the caller keeps them alive.
+    The autograd engine runs an AccumulateGrad node on the stream that was current when the node was CREATED, and a node lives as long as
+    some graph (or this list) references it.  Round 4's harness let the first forward that happened to touch a parameter decide -- for
+    torch.cuda.make_graphed_callables that is its private warm-up stream -- and a later backward on the capture stream then synchronised
+    with that foreign stream on every step ("AccumulateGrad node's stream does not match ..."), the precondition of the
+    hipStreamEndCapture crash of profiles/r04_capture_probe.txt.  Pinned here, every later graph reuses these nodes."""
+    return [p.view_as(p).grad_fn.next_functions[0][0] for p in params if p.requires_grad]
+
+
+CLIP_MAX_NORM = 0.1      # reference config/RichSem/baseline_4scale.py:19 (clip_max_norm), engine.py:110-112
+
+
+def make_optimizer(params):
+    """AdamW as the reference builds it (main.py:213-214; lr / weight_decay of config/RichSem/baseline_4scale.py:7,14), one fused launch per step"""
+    return torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True)
+
+
+def optimizer_step(opt, params):
+    """what follows ``losses.backward()`` in the reference's training loop (engine.py:109-113): gradient clipping to clip_max_norm, AdamW step.
+    No host synchronisation: the norm stays on the device (``error_if_nonfinite`` is off as in the reference's call)."""
+    torch.nn.utils.clip_grad_norm_(params, CLIP_MAX_NORM, foreach=True)
+    opt.step()
+
+
 def run(n_img, dev, steps=5, warmup=2, graph=True, stop_at=None):
     """time `steps` composed steps (forward + loss + backward); returns the dict bench.py attaches as ``full_step``"""
     model = Step(n_img=n_img, dev=dev)
@@ -426,8 +465,9 @@ def run(n_img, dev, steps=5, warmup=2, graph=True, stop_at=None):
     images, mask, targets = model.batch()
     model.prepare(mask, targets)
     params = [p for p in model.parameters() if p.requires_grad]
+    opt = make_optimizer(params)
 
-    def step(indices=None):
+    def step(indices=None, optimize=True):
         for p in params:
             p.grad = None
         loss = model(images, mask, targets, indices)
@@ -436,6 +476,8 @@ def run(n_img, dev, steps=5, warmup=2, graph=True, stop_at=None):
             fwd = torch.cuda.Event(enable_timing=True)
             fwd.record()
         loss.backward()
+        if optimize:
+            optimizer_step(opt, params)
         return loss, fwd
 
     # Everything -- warm-up, the timed eager steps, the capture -- runs on ONE side stream (round 4).  An autograd graph pins every
@@ -449,6 +491,7 @@ def run(n_img, dev, steps=5, warmup=2, graph=True, stop_at=None):
     side.wait_stream(torch.cuda.current_stream())
     rows, totals, bwds = {}, [], []
     with torch.cuda.stream(side):
+        pinned = pin_grad_accumulators(params)      # (kept alive to the end of run(): every graph below reuses these nodes)
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
@@ -466,8 +509,9 @@ def run(n_img, dev, steps=5, warmup=2, graph=True, stop_at=None):
     ms = sum(totals) / len(totals)
     out = {"what": "ONE composed training step on the library's rows at configs[1] sizes: ResNet-50 (layer2-4 trained) -> input projections "
                    "-> 6 encoder layers -> two-stage score + top-900 -> denoising layout -> 6 decoder layers -> heads -> frozen CLIP-RN50 "
-                   "teacher -> ROIAlign -> attention pool -> matcher -> losses, forward + backward, bf16 activations / fp32 parameters; "
-                   "synthetic weights and batch; no optimizer step, no data pipeline (bench_step.py)",
+                   "teacher -> ROIAlign -> attention pool -> matcher -> losses, forward + backward, gradient clipping (0.1) + fused AdamW step "
+                   "(reference engine.py:105-113), bf16 activations / fp32 parameters; synthetic weights and batch; no data pipeline "
+                   "(bench_step.py)",
            "ms": round(ms, 2), "img_per_s": round(n_img / (ms * 1e-3), 2), "loss": float(loss.detach()),
            "forward_rows_ms": {k: round(sum(v) / len(v), 3) for k, v in rows.items()},
            "backward_ms": round(sum(bwds) / len(bwds), 2)}
@@ -483,11 +527,11 @@ def run(n_img, dev, steps=5, warmup=2, graph=True, stop_at=None):
         model.stop_at = stop_at
         with torch.cuda.stream(side):
             for _ in range(2):
-                step(indices)
+                step(indices, optimize=False)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):      # the stream that was warmed up
-            step(indices)
+            step(indices, optimize=False)
         g.replay()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -499,8 +543,9 @@ def run(n_img, dev, steps=5, warmup=2, graph=True, stop_at=None):
     try:
         rep = replay_ms(None)
         out["graph_replay"] = {"ms": round(rep, 2), "img_per_s": round(n_img / (rep * 1e-3), 2),
-                               "note": "forward + backward captured once into a HIP graph and replayed, the Hungarian assignment of the last "
-                                       "eager step held fixed (its host round trip cannot be captured)"}
+                               "note": "forward + backward (no optimizer step: a diagnostic of the device work per row) captured once into a HIP "
+                                       "graph and replayed, the Hungarian assignment of the last eager step held fixed (its host round trip "
+                                       "cannot be captured)"}
         # GPU time per row, forward + backward: replay time of the step cut off after each section (a surrogate loss = the sum of the
         # section's outputs), differenced; "criterion" = the rest (teacher + matcher-less losses and their backward into the heads)
         prev, table = 0.0, {}
@@ -547,7 +592,7 @@ class _LossPart(nn.Module):
         return self.step[0].loss_part(*tensors)
 
 
-def run_graphed(n_img, dev, steps=5, warmup=2, **step_kwargs):
+def run_graphed(n_img, dev, steps=5, warmup=2, optimizer=True, noise_seed=None, return_grads=False, **step_kwargs):
     """The composed step as a trainer can run it WITHOUT freezing the matcher: the two device-only parts -- everything up to the matcher,
     and the criterion -- each captured once, forward and backward, with ``torch.cuda.make_graphed_callables`` (HIP graphs replayed by
     autograd), the Hungarian assignment between them live on the host every step.  Eagerly the step is bound by ~2900 kernel launches
@@ -558,6 +603,8 @@ def run_graphed(n_img, dev, steps=5, warmup=2, **step_kwargs):
     images, mask, targets = model.batch()
     model.prepare(mask, targets)
     model._mask = mask
+    if noise_seed is not None:
+        model.freeze_noise(noise_seed)
     part_a, part_b = _ModelPart(model), _LossPart(model)
     # ONE side stream for the eager warm-up, the captures and the training steps: torch captures on its class-wide capture stream, which is
     # set to that stream here -- the library's workspaces are per (device, stream) and are not allocated during capture (on a cold stream
@@ -569,6 +616,7 @@ def run_graphed(n_img, dev, steps=5, warmup=2, **step_kwargs):
     torch.cuda.graph.default_capture_stream = side
     try:
         with torch.cuda.stream(side):
+            pinned = pin_grad_accumulators(model.parameters())      # on `side`, before anything touches a parameter; alive to the end
             with torch.no_grad():
                 outs = model.model_part(images, mask)
             idx = model.pack_indices(model.match(*outs[:4], targets), targets)
@@ -588,6 +636,7 @@ def run_graphed(n_img, dev, steps=5, warmup=2, **step_kwargs):
             with torch.cuda.graph(teacher_graph, stream=side):
                 t_static = model.teacher_part(images)
             params = [p for p in model.parameters() if p.requires_grad]
+            opt = make_optimizer(params) if optimizer else None
 
             def step():
                 for p in params:
@@ -599,6 +648,8 @@ def run_graphed(n_img, dev, steps=5, warmup=2, **step_kwargs):
                     assign = model.match_end(pending)                         # wait for the copy, scipy (matcher.py) -- under the teacher
                 loss = gb(*outs, t_static, *model.pack_indices(assign, targets))
                 loss.backward()
+                if opt is not None:
+                    optimizer_step(opt, params)
                 return loss
 
             for _ in range(warmup):
@@ -614,9 +665,13 @@ def run_graphed(n_img, dev, steps=5, warmup=2, **step_kwargs):
     torch.cuda.current_stream().wait_stream(side)
     return {"what": "the same step with its two device-only parts (model up to the matcher; criterion) captured forward + backward by "
                     "torch.cuda.make_graphed_callables and the Hungarian assignment live on the host between them every step, under the frozen "
-                    "teacher's forward (a HIP graph of its own, replayed while the host waits for the cost blocks and solves the assignments)",
+                    "teacher's forward (a HIP graph of its own, replayed while the host waits for the cost blocks and solves the assignments)"
+                    + ("; then gradient clipping (0.1) + fused AdamW step (reference engine.py:105-113): a TRAINING step, the same thing "
+                       "full_step_ddp measures at N > 1" if optimizer else "; no optimizer step"),
+            "optimizer": "AdamW(fused) + clip_grad_norm_(0.1)" if optimizer else None,
             "ms": round(ms, 2), "img_per_s": round(n_img / (ms * 1e-3), 2), "loss": float(loss.detach()),
-            "grad_norm": float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in params if p.grad is not None)))}
+            "grad_norm": float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in params if p.grad is not None))),
+            **({"grads": {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}} if return_grads else {})}
 
 
 def run_ddp(n_img, dev, dist, steps=5, warmup=2, optimizer=True, make_model=None, backend_device=None):
@@ -643,7 +698,8 @@ def run_ddp(n_img, dev, dist, steps=5, warmup=2, optimizer=True, make_model=None
     else:
         ddp = model
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4) if optimizer else None      # main.py:238-239
+    opt = (torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True) if is_cuda else
+           torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)) if optimizer else None      # main.py:213-214
 
     def step(sync=True):
         if opt is not None:
@@ -656,6 +712,7 @@ def run_ddp(n_img, dev, dist, steps=5, warmup=2, optimizer=True, make_model=None
             loss = ddp(*batch)
             loss.backward()
         if opt is not None:
+            torch.nn.utils.clip_grad_norm_(params, CLIP_MAX_NORM)      # engine.py:110-112
             opt.step()
         return loss
 
@@ -684,7 +741,8 @@ def run_ddp(n_img, dev, dist, steps=5, warmup=2, optimizer=True, make_model=None
     ms_nc, _ = timed(False)
     unused = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
     return {"what": "the composed step as a data-parallel training step: the module in DistributedDataParallel (RCCL, gradient_as_bucket_view, "
-                    "25 MB buckets overlapped with the backward), AdamW step included, every rank on its own images; ms = max over ranks",
+                    "25 MB buckets overlapped with the backward), gradient clipping (0.1) + AdamW step included, every rank on its own images; "
+                    "ms = max over ranks",
             "world": world, "ms": round(ms, 2), "ms_no_collective": round(ms_nc, 2), "img_per_s": round(world * n_img / (ms * 1e-3), 2),
             "img_per_s_per_rank": round(n_img / (ms * 1e-3), 2), "optimizer": "AdamW" if optimizer else None, "loss": loss,
             "trained_parameters": sum(p.numel() for p in params), "parameters_without_gradient": unused}

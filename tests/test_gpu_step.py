@@ -108,15 +108,49 @@ def test_step_captures_on_the_stream_it_ran_on_with_its_loss_alive():
 
 def test_graphed_sections_train_like_the_eager_step():
     """bench_step.run_graphed: the model part and the criterion captured forward + backward by torch.cuda.make_graphed_callables, the
-    matcher live between them -- the loss and the size of the gradient are the eager step's (the denoising noise differs per step)"""
+    matcher live between them -- with the denoising noise frozen to the same draws the loss and EVERY parameter's gradient are the eager
+    step's (same kernels; sums of atomics and the bf16 rounding of re-packed parameters are what differs), and no parameter's
+    AccumulateGrad node sits on a foreign stream (round 4: torch's stream-mismatch warning fired here -- the precondition of the
+    hipStreamEndCapture crash of profiles/r04_capture_probe.txt)."""
+    import warnings
     import bench_step
     model, images, mask, targets = _small_step(seed=0)
+    model.freeze_noise(3)
     loss = _run(model, images, mask, targets)
-    gnorm = float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+    want = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
     del model
-    res = bench_step.run_graphed(2, torch.device("cuda", 0), steps=2, warmup=1, height=H, width=W_IMG, boxes_per_image=BOXES, seed=0)
-    assert abs(res["loss"] - float(loss)) < 0.1 * abs(float(loss)), (res["loss"], float(loss))
-    assert 0.7 < res["grad_norm"] / gnorm < 1.4, (res["grad_norm"], gnorm)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        res = bench_step.run_graphed(2, torch.device("cuda", 0), steps=2, warmup=1, optimizer=False, noise_seed=3, return_grads=True,
+                                     height=H, width=W_IMG, boxes_per_image=BOXES, seed=0)
+    stream_warnings = [str(w.message)[:120] for w in caught if "AccumulateGrad" in str(w.message)]
+    assert not stream_warnings, stream_warnings
+    assert abs(res["loss"] - float(loss)) < 2e-3 * abs(float(loss)), (res["loss"], float(loss))
+    got = res["grads"]
+    assert sorted(got) == sorted(want)
+    bad = {}
+    for n, b in want.items():
+        a = got[n]
+        if float(b.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, n
+            continue
+        cos, ratio = float((a * b).sum() / (a.norm() * b.norm())), float(a.norm() / b.norm())
+        if cos < 0.999 or not 0.98 < ratio < 1.02:
+            bad[n] = (cos, ratio)
+    assert not bad, bad
+
+
+def test_training_step_with_optimizer_moves_the_loss_down():
+    """the graphed sections as a TRAINING step (gradient clipping 0.1 + fused AdamW, reference engine.py:105-113) on one frozen batch:
+    finite, and the loss after a few updates is below the first one"""
+    import bench_step
+    first = bench_step.run_graphed(2, torch.device("cuda", 0), steps=1, warmup=0, optimizer=True, noise_seed=3, height=H, width=W_IMG,
+                                   boxes_per_image=BOXES, seed=0)
+    later = bench_step.run_graphed(2, torch.device("cuda", 0), steps=2, warmup=10, optimizer=True, noise_seed=3, height=H, width=W_IMG,
+                                   boxes_per_image=BOXES, seed=0)
+    assert first["loss"] == first["loss"] and later["loss"] == later["loss"]      # not NaN
+    assert later["loss"] < first["loss"], (first["loss"], later["loss"])
+    assert later["grad_norm"] <= bench_step.CLIP_MAX_NORM * 1.01      # what the optimizer saw was clipped
 
 
 def _sigmoid_focal_loss(inputs, targets, num_boxes, alpha=0.25, gamma=2):
