@@ -629,11 +629,10 @@ def main(argv=None):
     # `value`, never it (what the scaling curve of `value` hides behind 3 ms of operator kernels has 27 ms of step to hide in here)
     full_step_ddp = None
     if world > 1 and not args.no_full_step:
-        try:
-            import bench_step
-            full_step_ddp = bench_step.run_ddp(n_img, dev, dist, steps=5, warmup=3)
-        except Exception as e:      # noqa: BLE001
-            full_step_ddp = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        # (no try / except here: a rank that swallowed its own failure would leave the others inside DDP's all-reduces until the driver's
+        # timeout; an exception ends this rank, and torch.distributed.run tears the job down with a non-zero exit)
+        import bench_step
+        full_step_ddp = bench_step.run_ddp(n_img, dev, dist, steps=5, warmup=3)
     if rank == 0:
         n_total = total_images(n_img, world)
 

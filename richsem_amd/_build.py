@@ -20,6 +20,7 @@ def _headers():
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function"] + \
     os.environ.get("RICHSEM_HIPCC_EXTRA", "").split()      # (diagnostic builds: -DRPS_ROUTE_ABLATION, -DCONV_RING_ABLATE=...)
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
+STAMP = os.path.join(LIB_DIR, "build_flags.txt")      # the hipcc flags the library on disk was built with (part of the staleness key)
 
 
 def find_hipcc():
@@ -31,6 +32,11 @@ def find_hipcc():
 
 def is_stale():
     if not os.path.exists(LIB_PATH):
+        return True
+    try:
+        if open(STAMP).read() != " ".join(HIPCC_FLAGS):      # (a diagnostic build left behind, or RICHSEM_HIPCC_EXTRA changed)
+            return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, f) for f in SOURCES] + _headers() + [os.path.abspath(__file__)]
@@ -44,6 +50,11 @@ def build(force=False, verbose=False):
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ_DIR, exist_ok=True)
+    try:
+        flags_changed = open(STAMP).read() != " ".join(HIPCC_FLAGS)
+    except OSError:
+        flags_changed = True
+    force = force or flags_changed      # (objects built with other flags are not reused)
     hipcc = find_hipcc()
     newest_header = max(os.path.getmtime(h) for h in _headers() + [os.path.abspath(__file__)])
 
@@ -64,6 +75,8 @@ def build(force=False, verbose=False):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(STAMP, "w") as f:
+        f.write(" ".join(HIPCC_FLAGS))
     return LIB_PATH
 
 

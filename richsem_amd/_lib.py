@@ -79,7 +79,9 @@ class ProfileRecord(ctypes.Structure):
 
 
 def lib_path():
-    return _build.LIB_PATH
+    """the product library -- or, for diagnostic runs only, the library RICHSEM_MSDA_LIB names (ablation builds are loaded from where they
+    were built: nothing ever overwrites the product .so)"""
+    return os.environ.get("RICHSEM_MSDA_LIB") or _build.LIB_PATH
 
 
 def load():

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Diagnostic builds of the library for tools/r04_ring_ablate.sh and tools/r04_wgrad_ablate.sh (results WRONG by construction), made in the
 # container (hipcc cross-compiles gfx950; the libraries travel to the GPU box with the snapshot: build_ablate/ is git-ignored, not
-# gpurun-ignored).  The product library is rebuilt at the end.
+# gpurun-ignored); the GPU-side scripts load them through RICHSEM_MSDA_LIB.  The product library is rebuilt at the end (the flag stamp of
+# richsem_amd/_build.py would rebuild it anyway: a library built with other flags counts as stale).
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_ablate
