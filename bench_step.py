@@ -625,7 +625,15 @@ def run_graphed(n_img, dev, steps=5, warmup=2, optimizer=True, noise_seed=None, 
                 p.grad = None
             sample_b = tuple(o.detach().clone().requires_grad_(i < 5) for i, o in enumerate(outs)) + tuple(idx)
             torch.cuda.synchronize()
-            ga, gb = torch.cuda.make_graphed_callables((part_a, part_b), ((images,), sample_b), num_warmup_iters=3, allow_unused_input=True)
+            # (make_graphed_callables warms its callables up on a PRIVATE stream of its own making -- torch/cuda/graphs.py -- before it
+            # captures them on `side`: during those three iterations the gradients arrive at the pinned nodes from that other stream, by
+            # construction.  The engine's warning about it is switched off for this one call only; every training step below runs with it
+            # on, and tests/test_gpu_step.py fails on it)
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+            try:
+                ga, gb = torch.cuda.make_graphed_callables((part_a, part_b), ((images,), sample_b), num_warmup_iters=3, allow_unused_input=True)
+            finally:
+                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(True)
             # the frozen teacher (no gradient, independent of the student) is a HIP graph of its own, replayed BETWEEN the two halves of the
             # matching: the cost blocks and their copy to the host are enqueued first, the teacher's ~2 ms of GPU work run while the host
             # waits for that copy and solves the seven assignments (scipy) -- the round trip costs the step nothing

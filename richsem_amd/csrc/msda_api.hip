@@ -60,6 +60,7 @@ int hip_fail(hipError_t e, const char *what)
 }
 
 std::atomic<int> g_fwd_variant{0}, g_bwd_variant{0}, g_bwd_cpl{0}, g_levelsum{1}, g_fwd_prep_fused{1};
+thread_local int g_tl_fwd_variant = -1;      // >= 0: the forward variant of THIS call (set by a caller inside the library that has already chosen)
 
 // ---- launch profiler: pre-created event pairs, one per logged call -----------------------------
 struct ProfileSlot {
@@ -558,7 +559,7 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
         !is_aligned(loc, 2 * sizeof(T)) || !is_aligned(shapes, 8) || !is_aligned(lsi, 8))
         return fail(MSDA_ERR_MISALIGNED, "misaligned pointer (sampling_loc needs 2*sizeof(T))");
 
-    int variant = g_fwd_variant.load();
+    int variant = g_tl_fwd_variant >= 0 ? g_tl_fwd_variant : g_fwd_variant.load();
     if (variant != 1 && msda::tiled_fwd_applicable<T>(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(),
                                                      pb.lsi.data(), value, out)) {
         unsigned *probe = nullptr;
@@ -732,7 +733,7 @@ int forward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const in
         !is_aligned(lsi, 8))
         return fail(MSDA_ERR_MISALIGNED, "misaligned pointer (sampling_loc needs 8 bytes)");
 
-    int variant = g_fwd_variant.load();
+    int variant = g_tl_fwd_variant >= 0 ? g_tl_fwd_variant : g_fwd_variant.load();
     if (variant != 1 && is_aligned(value, 8) && is_aligned(out, 8) &&
         msda::plan_gather(N, S, M, D, L, Lq, P, pb.shapes.data(), pb.lsi.data()).ok) {
         unsigned *probe = nullptr;
@@ -977,6 +978,50 @@ int forward_prep_impl(const TV *value, const int64_t *shapes, const int64_t *lsi
         return fail(MSDA_ERR_BAD_DIMS, "row stride smaller than a row (offsets %lld, logits %lld)", (long long)off_stride, (long long)log_stride);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const bool fused = g_fwd_prep_fused.load() && Lq != S && L * P <= msda::kPointBatch;
+    // Encoder-shaped calls (round 5): the LDS-window kernel reads the raw projection itself -- softmax by the
+    // quad that owns the query, location arithmetic by the lane that resolves the point -- and writes sampling_loc / attn_weight as
+    // by-products: no prep_forward_kernel launch, no re-read of the two tensors.  While the locality monitor sends the call to the direct
+    // kernel (spread sampling points) the two-kernel form below runs, with that choice held.
+    if constexpr (std::is_same<T, float>::value) {
+        if (g_fwd_prep_fused.load() >= 2 && !fused && P == 4 && g_fwd_variant.load() != 1) {
+            Problem pb{N, S, M, D, L, Lq, P, {}, {}};
+            if (int rc = check_problem(pb, shapes, lsi, shapes_host, lsi_host, im2col_step, stream)) return rc;
+            constexpr size_t row_align = sizeof(TV) * 4;
+            const bool aligned = is_aligned(value, row_align) && is_aligned(out, row_align) && is_aligned(offsets, 2 * sizeof(TP)) && off_stride % 2 == 0 &&
+                                 is_aligned(logits, sizeof(TP)) && is_aligned(ref, 8) && is_aligned(loc, 8) && is_aligned(aw, 4);
+            if (aligned && msda::plan_gather(N, S, M, D, L, Lq, P, pb.shapes.data(), pb.lsi.data()).ok) {
+                int variant = g_fwd_variant.load();
+                unsigned *probe = nullptr;
+                Monitor *mo = nullptr;
+                if (variant == 0) {
+                    mo = monitor_for_current_device();
+                    variant = monitor_choose_fwd(mo, problem_key(N, S, M, L, P, pb.shapes.data(), loc), stream, &probe);
+                }
+                if (variant == 2) {
+                    const msda::TiledPrepSrc src{offsets, logits, (long long)off_stride, (long long)log_stride, ref, ref_dim, loc, aw};
+                    hipError_t e;
+                    {
+                        ProfileScope prof(0, 6, (int)sizeof(TV), N, S, M, D, L, Lq, P, stream);
+                        e = msda::launch_fwd_tiled_prep<TV, TP>(value, src, out, N, S, M, D, L, Lq, P, pb.shapes.data(), pb.lsi.data(), probe, stream);
+                    }
+                    if (probe) monitor_finish_probe(mo, 2.0 * N * Lq * M * L * P, stream, e == hipSuccess);
+                    if (e != hipSuccess) return hip_fail(e, "launch of the fused location / softmax / window-gather kernel");
+                    return MSDA_OK;
+                }
+                // the monitor chose the direct kernel: location / softmax kernel, then the direct forward (the choice is not asked for again)
+                if (int rc = prep_forward_impl<T, TP>(offsets, off_stride, logits, log_stride, ref, ref_dim, shapes_host, N, Lq, M, L, P, loc, aw, stream_))
+                    return rc;
+                g_tl_fwd_variant = 1;
+                int rc;
+                if constexpr (std::is_same<TV, msda::bf16_t>::value)
+                    rc = forward_bf16_impl(value, shapes, lsi, loc, aw, N, S, M, D, L, Lq, P, im2col_step, out, shapes_host, lsi_host, stream_);
+                else
+                    rc = forward_impl<T>(value, shapes, lsi, loc, aw, N, S, M, D, L, Lq, P, im2col_step, out, shapes_host, lsi_host, stream_);
+                g_tl_fwd_variant = -1;
+                return rc;
+            }
+        }
+    }
     if (!fused) {
         if (int rc = prep_forward_impl<T, TP>(offsets, off_stride, logits, log_stride, ref, ref_dim, shapes_host, N, Lq, M, L, P, loc, aw, stream_))
             return rc;
@@ -1023,7 +1068,7 @@ const char *msda_last_error(void) { return g_err; }
 int msda_set_option(const char *key, int value)
 {
     if (key && !strcmp(key, "fwd_variant") && value >= 0 && value <= 2) { g_fwd_variant = value; return MSDA_OK; }
-    if (key && !strcmp(key, "fwd_prep_fused") && value >= 0 && value <= 1) { g_fwd_prep_fused = value; return MSDA_OK; }
+    if (key && !strcmp(key, "fwd_prep_fused") && value >= 0 && value <= 2) { g_fwd_prep_fused = value; return MSDA_OK; }      // 1: decoder-shaped calls; 2: + encoder-shaped
     if (key && !strcmp(key, "bwd_variant") && (value == 0 || value == 1 || value == 4)) { g_bwd_variant = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_tile") && value >= 4 && value <= 16) { msda::rps_options().tile = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_max_chunks") && value >= 1 && value <= 4096) { msda::rps_options().max_chunks = value; return MSDA_OK; }

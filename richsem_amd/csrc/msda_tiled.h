@@ -22,6 +22,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 
 #include "msda_common.h"
@@ -437,6 +438,67 @@ __device__ __forceinline__ void load_level_ops(const float *__restrict__ loc, co
     }
 }
 
+// ---- fused module path: the kernel reads the RAW projection of the query -- offsets and attention logits,
+// one row of M * L * P * 3 values per (image, query) -- and the reference points instead of sampling_loc / attn_weight: the softmax over a
+// (query, head)'s L * P logits (reference ops/modules/ms_deform_attn.py:100) is formed by the quad that owns the query -- lane i holds
+// point i of every level: a maximum and a sum over its own L values, then two DPP steps over the quad --, the location arithmetic
+// (:102-109) by the lane that resolves the point.  sampling_loc / attn_weight are written as BY-PRODUCTS (what the backward needs) by
+// the first channel half's workgroup only, or not at all (loc_out == nullptr: inference).  P = 4 only (a quad = the points of a level).
+struct TiledPrepSrc {
+    const void *offsets, *logits;      // TP = float or bf16_t: offsets[(n, q) * off_stride + (m * LP + pt) * 2 + {0, 1}], logits[(n, q) * log_stride + m * LP + pt]
+    long long off_stride, log_stride;
+    const float *ref;                  // (N, Lq, L, ref_dim)
+    int ref_dim;                       // 2: reference points (x, y); 4: reference boxes (x, y, w, h)
+    float *loc_out, *aw_out;           // by-products, or null
+};
+
+__device__ __forceinline__ float quad_max(float v)
+{
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+}
+
+template <typename TP>
+__device__ __forceinline__ float tp_ld(const TP *p);
+template <>
+__device__ __forceinline__ float tp_ld<float>(const float *p) { return *p; }
+template <>
+__device__ __forceinline__ float tp_ld<bf16_t>(const bf16_t *p) { return __uint_as_float((unsigned)*reinterpret_cast<const unsigned short *>(p) << 16); }
+template <typename TP>
+__device__ __forceinline__ float2 tp_ld2(const TP *p);      // two consecutive elements (an offset pair): aligned to the pair
+template <>
+__device__ __forceinline__ float2 tp_ld2<float>(const float *p) { return *reinterpret_cast<const float2 *>(p); }
+template <>
+__device__ __forceinline__ float2 tp_ld2<bf16_t>(const bf16_t *p)
+{
+    const unsigned u = *reinterpret_cast<const unsigned *>(p);
+    return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u));
+}
+
+// The raw operands of one level for the quad's queries: requested a level ahead (like LevelOps), turned into locations / weights where used.
+template <int QPG, bool REF4>
+struct LevelRaw {
+    float2 off[QPG];                 // this lane's offset pair (point j & 3 of the level)
+    float2 rxy[QPG];                 // the level's reference point
+    float2 rwh[REF4 ? QPG : 1];      // ... and box size (reference boxes only)
+    float lg[QPG];                   // this lane's logit
+};
+
+template <int QPG, typename TP, bool REF4>
+__device__ __forceinline__ void load_level_raw(const TiledPrepSrc &src, const unsigned (&nq)[QPG], int m, int L, int LP, int lvl, int j,
+                                               LevelRaw<QPG, REF4> &o)
+{
+    const int pt = m * LP + lvl * 4 + (j & 3);
+#pragma unroll
+    for (int k = 0; k < QPG; ++k) {
+        o.off[k] = tp_ld2<TP>(reinterpret_cast<const TP *>(src.offsets) + (long long)nq[k] * src.off_stride + 2 * pt);
+        o.lg[k] = tp_ld<TP>(reinterpret_cast<const TP *>(src.logits) + (long long)nq[k] * src.log_stride + pt);
+        const float *r = src.ref + ((long long)nq[k] * L + lvl) * (REF4 ? 4 : 2);
+        o.rxy[k] = *reinterpret_cast<const float2 *>(r);
+        if constexpr (REF4) o.rwh[k] = *reinterpret_cast<const float2 *>(r + 2);
+    }
+}
+
 // One sampled level for the kGatherQPG queries of a quad.  P4 = the level has exactly 4 points (RichSem): no
 // point-count checks in the unrolled body.  Hot path = in-window points: one wave-divergent branch per point and
 // straight-line LDS reads + packed FMAs.  Points with a corner outside the window are rare; they are handled
@@ -537,11 +599,15 @@ __device__ __forceinline__ void gather_level(
 // Workgroup = (image, head, region, channel half); accumulates over the LDS phases in registers.
 // TV = storage type of value / out (float, or bf16_t: converted at the loads / the store; the LDS windows and all arithmetic
 // are fp32 either way)
-template <bool P4, int GC, int CPL, typename TV = float>
+// TPREP = void: sampling_loc / attn_weight are inputs (the operator's entry points); float / bf16_t: the fused module path -- the raw
+// projection of that type in `prep`, `loc` / `aw` unused (see TiledPrepSrc).
+template <bool P4, int GC, int CPL, typename TV = float, typename TPREP = void, bool REF4 = false>
 __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled_gather_kernel(
     const TV *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ aw, TV *__restrict__ out,
-    const TiledGeom g)
+    const TiledGeom g, const TiledPrepSrc prep)
 {
+    constexpr bool PREP = !std::is_same<TPREP, void>::value;
+    static_assert(!PREP || (P4 && GC / CPL == 4), "fused prep: a quad owns a query and a level has four points");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TileHeader *hdr = reinterpret_cast<TileHeader *>(smem);
     float *win = reinterpret_cast<float *>(smem + sizeof(TileHeader));
@@ -594,6 +660,27 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
         acc_lo[k] = acc_hi[k] = (v2f){0.f, 0.f};
     }
 
+    // fused module path: (image, query) row of the quad's queries in the raw projection, and the softmax statistics of their L * P logits
+    // (maximum, sum of exponentials: lane i of the quad holds point i of every level)
+    unsigned nqv[kGatherQPG];
+    float smax[kGatherQPG], ssum[kGatherQPG];
+    if constexpr (PREP) {
+#pragma unroll
+        for (int k = 0; k < kGatherQPG; ++k) {
+            nqv[k] = (unsigned)(b * g.Lq + hdr->qid[live[k] ? grp + k * kGroups : 0]);
+            float x[kTL];
+#pragma unroll
+            for (int l = 0; l < kTL; ++l)
+                x[l] = l < g.L ? tp_ld<TPREP>(reinterpret_cast<const TPREP *>(prep.logits) + (long long)nqv[k] * prep.log_stride + m * LP + l * 4 + (j & 3))
+                               : -3.0e38f;
+            const float mx = quad_max(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+            float e = 0.f;
+#pragma unroll
+            for (int l = 0; l < kTL; ++l) e += l < g.L ? expf(x[l] - mx) : 0.f;
+            smax[k] = mx;
+            ssum[k] = quad_sum(e);
+        }
+    }
     unsigned miss[kGatherQPG];   // bit (level*4 + point) = that point of query k missed its window (this lane's point only)
 #pragma unroll
     for (int k = 0; k < kGatherQPG; ++k) miss[k] = 0u;
@@ -609,7 +696,9 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
             for (int l = 0; l < g.L; ++l)
                 if (uni(hdr->phase[l]) == ph) { lb = l < lb ? l : lb; le = l + 1; }
             LevelOps<kGatherQPG> nxt;
-            load_level_ops(loc, aw, item, (unsigned)LP, (unsigned)(lb * g.P), g.P, j, nxt);   // in flight during the fill
+            LevelRaw<PREP ? kGatherQPG : 1, REF4> rnxt;
+            if constexpr (PREP) load_level_raw<kGatherQPG, TPREP, REF4>(prep, nqv, m, g.L, LP, lb, j, rnxt);   // in flight during the fill
+            else load_level_ops(loc, aw, item, (unsigned)LP, (unsigned)(lb * g.P), g.P, j, nxt);
             // ---- stage this phase's windows: 64-B pixel half-rows, 16 B per lane -------------------------------------
             for (int l = lb; l < le; ++l) {
                 const int wr0 = uni(hdr->r[l].wr0), wc0 = uni(hdr->r[l].wc0), nwc = uni(hdr->r[l].nwc);
@@ -672,8 +761,36 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
 
             // ---- gather -------------------------------------------------------------------------------------
             for (int l = lb; l < le; ++l) {
-                const LevelOps<kGatherQPG> cur = nxt;
-                if (l + 1 < le) load_level_ops(loc, aw, item, (unsigned)LP, (unsigned)((l + 1) * g.P), g.P, j, nxt);
+                LevelOps<kGatherQPG> cur = nxt;
+                [[maybe_unused]] const LevelRaw<PREP ? kGatherQPG : 1, REF4> rcur = rnxt;
+                if (l + 1 < le) {
+                    if constexpr (PREP) load_level_raw<kGatherQPG, TPREP, REF4>(prep, nqv, m, g.L, LP, l + 1, j, rnxt);
+                    else load_level_ops(loc, aw, item, (unsigned)LP, (unsigned)((l + 1) * g.P), g.P, j, nxt);
+                }
+                if constexpr (PREP) {
+                    // softmax weight and sampling location of this lane's point (reference ms_deform_attn.py:100, :102-109; the operation
+                    // order of msda_prep.h's prep_forward_kernel), written out once -- by the first channel half -- for the backward
+                    const float Wl = (float)uni(hdr->W[l]), Hl = (float)uni(hdr->H[l]);
+#pragma unroll
+                    for (int k = 0; k < kGatherQPG; ++k) {
+                        const float a = expf(rcur.lg[k] - smax[k]) / ssum[k];
+                        float lx, ly;
+                        if constexpr (!REF4) {
+                            lx = rcur.rxy[k].x + rcur.off[k].x / Wl;
+                            ly = rcur.rxy[k].y + rcur.off[k].y / Hl;
+                        } else {
+                            lx = rcur.rxy[k].x + rcur.off[k].x / 4.0f * rcur.rwh[k].x * 0.5f;
+                            ly = rcur.rxy[k].y + rcur.off[k].y / 4.0f * rcur.rwh[k].y * 0.5f;
+                        }
+                        cur.xy[k] = make_float2(lx, ly);
+                        cur.a[k] = a;
+                        if (prep.loc_out && sub == 0 && live[k]) {
+                            const unsigned pt = item[k] * (unsigned)LP + (unsigned)(l * 4 + (j & 3));
+                            *reinterpret_cast<float2 *>(prep.loc_out + 2u * pt) = make_float2(lx, ly);
+                            prep.aw_out[pt] = a;
+                        }
+                    }
+                }
                 LevelCtx lc;
                 lc.H = uni(hdr->H[l]);
                 lc.W = uni(hdr->W[l]);
@@ -728,13 +845,38 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
                 unsigned mk = (unsigned)fx_list[2 * e + 1];
                 const unsigned itm = (unsigned)((b * g.Lq + hdr->qid[slot]) * g.M + m);
                 v2f lo = (v2f){0.f, 0.f}, hi = (v2f){0.f, 0.f};
+                // (fused module path: the query's softmax statistics once more -- any lane group may be handed any query)
+                [[maybe_unused]] float fmx = 0.f, fsum = 1.f;
+                [[maybe_unused]] const long long fnq = (long long)b * g.Lq + hdr->qid[slot];
+                if constexpr (PREP) {
+                    float x[kTL];
+#pragma unroll
+                    for (int l = 0; l < kTL; ++l)
+                        x[l] = l < g.L ? tp_ld<TPREP>(reinterpret_cast<const TPREP *>(prep.logits) + fnq * prep.log_stride + m * LP + l * 4 + (j & 3)) : -3.0e38f;
+                    fmx = quad_max(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+                    float e = 0.f;
+#pragma unroll
+                    for (int l = 0; l < kTL; ++l) e += l < g.L ? expf(x[l] - fmx) : 0.f;
+                    fsum = quad_sum(e);
+                }
                 while (mk) {
                     const int bit = __ffs((int)mk) - 1;
                     mk &= mk - 1u;
                     const int lv = bit >> 2, pp = bit & 3;
                     const unsigned pt = itm * (unsigned)LP + (unsigned)(lv * g.P + pp);
-                    const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
-                    const float a = aw[pt];
+                    float2 xy;
+                    float a;
+                    if constexpr (PREP) {
+                        const int rp = m * LP + lv * 4 + pp;
+                        const float2 of = tp_ld2<TPREP>(reinterpret_cast<const TPREP *>(prep.offsets) + fnq * prep.off_stride + 2 * rp);
+                        a = expf(tp_ld<TPREP>(reinterpret_cast<const TPREP *>(prep.logits) + fnq * prep.log_stride + rp) - fmx) / fsum;
+                        const float *r = prep.ref + (fnq * g.L + lv) * (REF4 ? 4 : 2);
+                        if constexpr (!REF4) xy = make_float2(r[0] + of.x / (float)hdr->W[lv], r[1] + of.y / (float)hdr->H[lv]);
+                        else xy = make_float2(r[0] + of.x / 4.0f * r[2] * 0.5f, r[1] + of.y / 4.0f * r[3] * 0.5f);
+                    } else {
+                        xy = *reinterpret_cast<const float2 *>(loc + 2u * pt);
+                        a = aw[pt];
+                    }
                     int o[4];
                     float lh, lw;
                     resolve_point<float>(xy.x, xy.y, hdr->H[lv], hdr->W[lv],
@@ -844,7 +986,24 @@ inline hipError_t launch_fwd_tiled_tv(const TV *value, const float *loc, const f
     hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pl.lds_bytes);
     if (e != hipSuccess) return e;
     const int grid = persistent_grid(pl.grid * (kTD / kFwdGC), tiled_options().persist, kTD / kFwdGC);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdGC == 16 ? 512 : 1024), pl.lds_bytes, stream, value, loc, aw, out, pl.g);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdGC == 16 ? 512 : 1024), pl.lds_bytes, stream, value, loc, aw, out, pl.g, TiledPrepSrc{});
+    return hipGetLastError();
+}
+
+// Fused module path (P = 4): raw projection + reference points in, out (+ sampling_loc / attn_weight as by-products) out.
+template <typename TV, typename TP>
+inline hipError_t launch_fwd_tiled_prep(const TV *value, const TiledPrepSrc &src, TV *out, int N, int S, int M, int D, int L, int Lq, int P,
+                                        const int64_t *shapes_h, const int64_t *lsi_h, unsigned *general_points, hipStream_t stream)
+{
+    if (P != 4) return hipErrorNotSupported;
+    TiledPlan pl = plan_gather(N, S, M, D, L, Lq, P, shapes_h, lsi_h);
+    if (!pl.ok) return hipErrorNotSupported;
+    if (general_points) pl.g.stats = general_points;
+    auto kern = src.ref_dim == 4 ? &tiled_gather_kernel<true, kFwdGC, 4, TV, TP, true> : &tiled_gather_kernel<true, kFwdGC, 4, TV, TP, false>;
+    hipError_t e = set_lds_limit(reinterpret_cast<const void *>(kern), pl.lds_bytes);
+    if (e != hipSuccess) return e;
+    const int grid = persistent_grid(pl.grid * (kTD / kFwdGC), tiled_options().persist, kTD / kFwdGC);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pl.lds_bytes, stream, value, (const float *)nullptr, (const float *)nullptr, out, pl.g, src);
     return hipGetLastError();
 }
 

@@ -203,3 +203,51 @@ def test_fused_prep_gather_equals_the_two_kernel_form(dtype, ref_dim, L, P, Lq):
     tol = {torch.float64: 1e-13, torch.float32: 2e-6, torch.bfloat16: 1e-2}[dtype]
     for a, b in zip(res[1], res[0]):
         assert float((a - b).abs().max()) <= tol * (float(b.abs().max()) + 1e-30), float((a - b).abs().max()) / float(b.abs().max())
+
+
+# ---- the same entry point for ENCODER-shaped calls: the LDS-window kernel reads the raw projection itself (fwd_prep_fused = 2) ------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ref_dim,spread", [(2, 1.5), (2, 40.0), (4, 1.5)])
+def test_fused_prep_window_gather_equals_the_two_kernel_form(dtype, ref_dim, spread):
+    """msda_forward_prep_* with fwd_prep_fused = 2 on an encoder-shaped call (Lq == S, P = 4): softmax + location arithmetic inside
+    tiled_gather_kernel, sampling_loc / attn_weight as by-products -- against prep_forward_kernel + the same gather (fwd_variant 2 forces
+    the window kernel in both forms).  ``spread`` = the offsets' size in pixels: 1.5 keeps every point in its window, 40 sends most of
+    them through the per-point fix-up, which recomputes the softmax from the raw row."""
+    from richsem_amd import _lib, workload as W
+    from richsem_amd.functions import MSDeformAttnFusedFunction
+    from richsem_amd.modules import get_reference_points
+    call = W.shrunk(W.call_E(2), 4)
+    shapes, lsi = W.level_tensors(call, "cuda")
+    N, S, M, D, L, P = call.N, call.S, call.M, call.D, call.L, call.P
+    g = torch.Generator(device="cuda").manual_seed(31 + ref_dim)
+    work = torch.float32
+    value = torch.randn(N, S, M, D, device="cuda", generator=g).to(dtype)
+    qproj = torch.randn(N, S, M * L * P * 3, device="cuda", generator=g)
+    qproj[..., :M * L * P * 2] *= spread
+    qproj[..., M * L * P * 2:] *= 2.0
+    qproj = qproj.to(dtype)
+    vr = torch.rand(N, L, 2, device="cuda", generator=g) * 0.2 + 0.8
+    ref = get_reference_points(shapes.tolist(), vr, "cuda").to(work)                     # (N, S, L, 2)
+    if ref_dim == 4:
+        ref = torch.cat((ref, torch.rand(N, S, L, 2, device="cuda", generator=g) * 0.2 + 0.02), -1).contiguous()
+    go = torch.randn(N, S, M * D, device="cuda", generator=g).to(dtype)
+    res = {}
+    try:
+        _lib.set_option("fwd_variant", 2)
+        for fused in (2, 0):
+            _lib.set_option("fwd_prep_fused", fused)
+            v, q, r = value.clone().requires_grad_(True), qproj.clone().requires_grad_(True), ref.clone().requires_grad_(True)
+            _lib.profile_enable(8)
+            out = MSDeformAttnFusedFunction.apply(v, shapes, lsi, q, r, M, L, P, 64)
+            torch.cuda.synchronize()
+            ran = [(rec["kind"], rec["variant"]) for rec in _lib.profile_collect()]
+            _lib.profile_enable(0)
+            assert ran == [("fwd", 6 if fused else 2)], ran
+            out.backward(go)
+            res[fused] = (out.detach().double(), v.grad.double(), q.grad.double(), r.grad.double())
+    finally:
+        _lib.set_option("fwd_prep_fused", 1)
+        _lib.set_option("fwd_variant", 0)
+    tol = {torch.float32: 2e-6, torch.bfloat16: 1e-2}[dtype]
+    for a, b in zip(res[2], res[0]):
+        assert float((a - b).abs().max()) <= tol * (float(b.abs().max()) + 1e-30), float((a - b).abs().max()) / float(b.abs().max())

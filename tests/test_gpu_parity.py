@@ -538,10 +538,12 @@ def test_routed_backward_overwrites_poisoned_outputs():
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
 
 
-def test_routed_backward_falls_back_beyond_its_run_table():
-    """more query blocks per (image, head) than a bin's run table holds (Lq > 256 x 128): the routed plan does not apply and the call
-    takes the direct kernels -- same results, no error"""
-    N, M, D, L, P, Lq = 1, 1, 32, 1, 4, 256 * 128 + 300
+@pytest.mark.parametrize("Lq,want", [(256 * 128 + 300, 4), (256 * 256 + 300, 1)])
+def test_routed_backward_beyond_the_8_wave_route_blocks(Lq, want):
+    """more query blocks per (image, head) than a bin's run table holds with 8-wave route workgroups (Lq > 256 x 128): the route pass runs
+    with 16 waves per workgroup -- 256 queries per block, what the 1280 x 1280 mosaic shape (Lq = 34000) takes at full size --; beyond
+    256 x 256 queries the routed plan does not apply and the call takes the direct kernels.  Same results either way, no error."""
+    N, M, D, L, P = 1, 1, 32, 1, 4
     shapes = torch.as_tensor([(24, 30)], dtype=torch.long)
     lsi = torch.as_tensor([0])
     gen = torch.Generator().manual_seed(77)
@@ -554,7 +556,7 @@ def test_routed_backward_falls_back_beyond_its_run_table():
     def bwd():
         res["g"] = MSDA.ms_deform_attn_backward(v, sh, ls, lc, a, g, 64)
     ran = _profiled_variants(bwd)
-    assert ran == [("bwd", 1)], ran
+    assert ran == [("bwd", want)], ran
     ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
     tf, tg = tols(np.float32)
     gv, gl, ga = res["g"]
