@@ -59,8 +59,11 @@ HIP_KERNELS = {
     ("bwd", 1): "bwd_levelsum_kernel + bwd_direct_kernel",
     ("fwd", 2): "tiled_gather_kernel",
     ("bwd", 4): "rps_route_kernel + rps_tile_kernel",
+    ("bwd", 5): "bwd_band_kernel",
+    ("fwd", 5): "fwd_direct_prep_kernel",
+    ("fwd", 6): "tiled_gather_kernel (raw projection in)",
 }
-VARIANT_NAMES = {1: "direct", 2: "tiled", 4: "routed"}
+VARIANT_NAMES = {1: "direct", 2: "tiled", 4: "routed", 5: "band", 6: "tiled_prep"}
 
 
 def parse_args(argv=None):

@@ -21,6 +21,7 @@
 #include "msda_dn.h"
 #include "msda_topk.h"
 #include "msda_roi.h"
+#include "msda_band.h"
 #include "msda_rps.h"
 #include "msda_tiled.h"
 
@@ -533,6 +534,48 @@ hipError_t launch_bwd_rps(const Problem &pb, const TV *value, const float *loc, 
     return e;
 }
 
+// ---- row-band backward (msda_band.h): decoder-shaped calls, D = 32, one launch ------------------------------------------------------
+// returns hipErrorNotSupported when the plan does not apply.  TV = bf16_t: grad_acc is an fp32 image of grad_value for the slabbed levels.
+template <typename TV>
+hipError_t launch_bwd_band(const Problem &pb, const TV *value, const float *loc, const float *aw, const TV *grad_out, TV *grad_value,
+                           float *grad_acc, float *grad_loc, float *grad_aw, hipStream_t stream)
+{
+    msda::BandPlan pl = msda::plan_band(pb.N, pb.S, pb.M, pb.D, pb.L, pb.Lq, pb.P, pb.shapes.data(), pb.lsi.data());
+    if (!pl.ok) return hipErrorNotSupported;
+    pl.g.dbg = msda::tiled_options().dbg & 63;
+    pl.g.stamps = msda::tiled_options().stamps;
+    if ((reinterpret_cast<uintptr_t>(grad_loc) | reinterpret_cast<uintptr_t>(loc)) & 7) return hipErrorNotSupported;
+    constexpr uintptr_t row_align = sizeof(TV) * 4 - 1;   // 16 B (fp32) / 8 B (bf16) per lane access
+    if ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_value)) & row_align)
+        return hipErrorNotSupported;
+    if (pl.atomic_levels && !grad_acc) return hipErrorNotSupported;
+    if (reinterpret_cast<uintptr_t>(grad_acc) & 15) return hipErrorNotSupported;
+    hipError_t e;
+    if (pl.atomic_levels)      // the levels several workgroups add to: zero in every image
+        hipLaunchKernelGGL(msda::band_zero_kernel, dim3(128), dim3(256), 0, stream, grad_acc, pl.g, pl.atomic_levels);
+    auto kern = &msda::bwd_band_kernel<TV>;
+    e = msda::set_lds_limit(reinterpret_cast<const void *>(kern), pl.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(msda::band_grid(pl.g)), dim3(msda::kBandThreads), pl.lds_bytes, stream, value, loc, aw, grad_out, grad_value,
+                       grad_acc, grad_loc, grad_aw, pl.g);
+    if constexpr (!std::is_same<TV, float>::value) {
+        if (pl.atomic_levels) hipLaunchKernelGGL(msda::band_round_kernel, dim3(256), dim3(256), 0, stream, grad_acc, grad_value, pl.g, pl.atomic_levels);
+    }
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t try_bwd_band(const Problem &, const T *, const T *, const T *, const T *, T *, T *, T *, hipStream_t)
+{
+    return hipErrorNotSupported;
+}
+template <>
+hipError_t try_bwd_band<float>(const Problem &pb, const float *value, const float *loc, const float *aw, const float *grad_out,
+                               float *grad_value, float *grad_loc, float *grad_aw, hipStream_t stream)
+{
+    return launch_bwd_band<float>(pb, value, loc, aw, grad_out, grad_value, grad_value, grad_loc, grad_aw, stream);
+}
+
 template <typename T>
 hipError_t try_bwd_rps(const Problem &, const T *, const T *, const T *, const T *, T *, T *, T *, hipStream_t)
 {
@@ -634,6 +677,18 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         if (e == hipSuccess) return MSDA_OK;
         prof.cancel();
         if (e != hipErrorNotSupported) return hip_fail(e, "launch of the routed backward kernels");
+        e = hipSuccess;
+    }
+
+    // bwd_variant 5: the row-band kernel (msda_band.h) -- grad_value, grad_sampling_loc and grad_attn_weight in ONE launch, no zero-fill of
+    // grad_value.  A measured option, not the automatic choice: 101-123 us on the decoder call Dd against 88 us for the level-sum + direct
+    // kernels below (profiles/r05_dd_backward.md).
+    if (variant == 5) {
+        ProfileScope prof(1, 5, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
+        e = try_bwd_band<T>(pb, value, loc, aw, grad_out, grad_value, grad_loc, grad_aw, stream);
+        if (e == hipSuccess) return MSDA_OK;
+        prof.cancel();
+        if (e != hipErrorNotSupported) return hip_fail(e, "launch of the row-band backward kernel");
         e = hipSuccess;
     }
 
@@ -799,9 +854,23 @@ int backward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const i
 
     int variant = g_bwd_variant.load();
     if (variant != 1 && is_aligned(value, 8) && is_aligned(grad_out, 8) && is_aligned(grad_value, 8)) {
-        // automatic: encoder-shaped calls take the routed kernels (as in fp32; the rows they request per point are half as wide)
+        // automatic: encoder-shaped calls take the routed kernels (as in fp32; the rows they request per point are half as wide);
+        // (5: the row-band kernel, a measured option -- see backward_impl)
         if (variant == 0) variant = Lq == S ? 4 : 1;
         float *gv32 = nullptr;
+        if (variant == 5 && D == msda::kBandD) {
+            const msda::BandPlan bp = msda::plan_band(N, S, M, D, L, Lq, P, pb.shapes.data(), pb.lsi.data());
+            if (bp.ok && (!bp.atomic_levels || bf16_scratch(stream, n_value, &gv32))) {
+                {
+                    ProfileScope prof(1, 5, 2, N, S, M, D, L, Lq, P, stream);
+                    e = launch_bwd_band<msda::bf16_t>(pb, value, loc, aw, grad_out, grad_value, gv32, grad_loc, grad_aw, stream);
+                    if (e == hipErrorNotSupported) prof.cancel();
+                }
+                if (e == hipSuccess) return MSDA_OK;
+                if (e != hipErrorNotSupported) return hip_fail(e, "launch of the row-band backward kernel (bf16)");
+            }
+            gv32 = nullptr;
+        }
         if (variant == 4 && D == msda::kRpsD && bf16_scratch(stream, n_value, &gv32)) {
             // routed kernels: plain bf16 stores for the levels a workgroup owns alone; the levels shared by several workgroups are
             // accumulated in the fp32 scratch (zeroed by the route pass) and rounded once
@@ -1069,7 +1138,9 @@ int msda_set_option(const char *key, int value)
 {
     if (key && !strcmp(key, "fwd_variant") && value >= 0 && value <= 2) { g_fwd_variant = value; return MSDA_OK; }
     if (key && !strcmp(key, "fwd_prep_fused") && value >= 0 && value <= 2) { g_fwd_prep_fused = value; return MSDA_OK; }      // 1: decoder-shaped calls; 2: + encoder-shaped
-    if (key && !strcmp(key, "bwd_variant") && (value == 0 || value == 1 || value == 4)) { g_bwd_variant = value; return MSDA_OK; }
+    if (key && !strcmp(key, "bwd_variant") && (value == 0 || value == 1 || value == 4 || value == 5)) { g_bwd_variant = value; return MSDA_OK; }
+    if (key && !strcmp(key, "band_lds_kb") && value >= 16 && value <= 150) { msda::band_options().lds_kb = value; return MSDA_OK; }
+    if (key && !strcmp(key, "band_hits") && value >= 32 && value <= 65536) { msda::band_options().hits = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_tile") && value >= 4 && value <= 16) { msda::rps_options().tile = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_max_chunks") && value >= 1 && value <= 4096) { msda::rps_options().max_chunks = value; return MSDA_OK; }
     if (key && !strcmp(key, "rps_route_wgs") && value >= 1 && value <= 64) { msda::rps_options().route_wgs = value; return MSDA_OK; }
@@ -1102,6 +1173,8 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "fwd_variant")) { *value = g_fwd_variant; return MSDA_OK; }
     if (key && !strcmp(key, "fwd_prep_fused")) { *value = g_fwd_prep_fused; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_variant")) { *value = g_bwd_variant; return MSDA_OK; }
+    if (key && !strcmp(key, "band_lds_kb")) { *value = msda::band_options().lds_kb; return MSDA_OK; }
+    if (key && !strcmp(key, "band_hits")) { *value = msda::band_options().hits; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_direct_cpl")) { *value = g_bwd_cpl; return MSDA_OK; }
     if (key && !strcmp(key, "rps_tile")) { *value = msda::rps_options().tile; return MSDA_OK; }
     if (key && !strcmp(key, "rps_max_chunks")) { *value = msda::rps_options().max_chunks; return MSDA_OK; }

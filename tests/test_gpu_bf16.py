@@ -51,9 +51,9 @@ def ulp_share(a_bf16, ref64):
 
 
 def run_bf16(z, variant):
-    """variant: 1 direct kernels; 2 window forward + routed backward; 4 direct forward + routed backward"""
-    _lib.set_option("fwd_variant", {1: 1, 2: 2, 4: 1}[variant])
-    _lib.set_option("bwd_variant", {1: 1, 2: 4, 4: 4}[variant])
+    """variant: 1 direct kernels; 2 window forward + routed backward; 4 direct forward + routed backward; 5 direct forward + row-band backward"""
+    _lib.set_option("fwd_variant", {1: 1, 2: 2, 4: 1, 5: 1}[variant])
+    _lib.set_option("bwd_variant", {1: 1, 2: 4, 4: 4, 5: 5}[variant])
     v = torch.from_numpy(z["value"]).float().to(torch.bfloat16).cuda()
     go = torch.from_numpy(z["grad_out"]).float().to(torch.bfloat16).cuda().contiguous()
     sh, ls = torch.from_numpy(z["shapes"]).cuda(), torch.from_numpy(z["lsi"]).cuda()
@@ -92,7 +92,7 @@ def test_bf16_golden_inputs(case, variant):
     check(got, want)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4])   # direct; window forward + routed backward; direct forward + routed backward
+@pytest.mark.parametrize("variant", [1, 2, 4, 5])   # direct; window forward + routed backward; direct forward + routed backward; + row-band backward
 @pytest.mark.parametrize("loc_mode", ["init", "sigma4", "uniform"])
 @pytest.mark.parametrize("which", ["E", "Dd", "Em"])
 def test_bf16_shrunk_baseline_calls(which, loc_mode, variant):
@@ -113,6 +113,28 @@ def test_bf16_odd_shapes(dims):
     z = {k: v.numpy() for k, v in W.make_inputs(call, "uniform", seed=3).items()}
     got, want = run_bf16(z, 1)
     check(got, want)
+
+
+@pytest.mark.parametrize("opts", [{}, {"band_hits": 200}, {"band_lds_kb": 150}])
+def test_bf16_band_backward_full_size_decoder_call(opts):
+    """the decoder call Dd at full size in bf16 storage: the row-band kernel (bwd_variant 5); slabbed levels go through the fp32
+    scratch image and one rounding (band_hits = 200: levels 1-3)"""
+    from test_gpu_parity import _profiled_variants
+    call = W.call_Dd(2)
+    z = {k: v.numpy() for k, v in W.make_inputs(call, "init", seed=17).items()}
+    defaults = {k: _lib.get_option(k) for k in opts}
+    try:
+        for k, v in opts.items():
+            _lib.set_option(k, v)
+        got, want = run_bf16(z, 5)
+        check(got, want)
+        v = torch.from_numpy(z["value"]).to(torch.bfloat16).cuda()
+        go = torch.from_numpy(z["grad_out"]).to(torch.bfloat16).cuda()
+        args = [torch.from_numpy(z[k]).cuda() for k in ("shapes", "lsi", "loc", "aw")]
+        assert _profiled_variants(lambda: MSDA.ms_deform_attn_backward(v, *args, go, 64)) == [("bwd", 5)]
+    finally:
+        for k, v in defaults.items():
+            _lib.set_option(k, v)
 
 
 def test_bf16_autograd_function_and_full_size_adjoint():

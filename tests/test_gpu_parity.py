@@ -422,6 +422,71 @@ def test_levelsum_backward_matches_oracle_and_atomics(dims, loc_mode):
     assert torch.allclose(res[0], res[1], rtol=1e-3, atol=1e-3 * float(np.abs(ogv).max()))
 
 
+# ---- row-band backward (msda_band.h): decoder-shaped calls in one launch ----------------------------------------------------------------------
+@pytest.mark.parametrize("opts", [
+    {},                                              # defaults: 64-KB windows, two workgroups per CU
+    {"band_lds_kb": 16},                             # 64-pixel windows: many thin bands, most points touch two of them
+    {"band_lds_kb": 150},                            # one workgroup per CU, tall bands
+    {"band_hits": 32},                               # every band dealt over many slabs: the row-atomic flush everywhere
+])
+@pytest.mark.parametrize("loc_mode", ["init", "uniform", "far"])
+@pytest.mark.parametrize("dims", [
+    dict(call="Dd"),                                                              # BASELINE decoder call, full size
+    dict(call="Dd/4"),
+    dict(N=1, M=3, D=32, P=3, shapes=[(40, 50), (7, 9), (1, 1), (20, 20)], Lq=700),   # P = 3, a 1 x 1 level
+    dict(N=2, M=2, D=32, P=8, shapes=[(3, 2), (60, 64)], Lq=300),
+    dict(N=1, M=1, D=32, P=4, shapes=[(9, 9)], Lq=5),                             # fewer points than threads
+    dict(N=1, M=2, D=32, P=1, shapes=[(31, 17), (5, 5)], Lq=6000),                # more points than one scan round lists
+])
+def test_band_backward_matches_oracle(dims, loc_mode, opts):
+    """msda_band.h (bwd_variant 5: a measured option, profiles/r05_dd_backward.md): grad_value, grad_sampling_loc and
+    grad_attn_weight of ONE launch against the oracle -- incl. samples the reference drops (loc-far: a third of the points outside
+    [0, 1]^2, their gradients must be written as zeros), windows of every size, slabbed bands, poisoned outputs (every element is written)."""
+    if dims.get("call") == "Dd":
+        call = W.call_Dd(2)
+    elif dims.get("call") == "Dd/4":
+        call = W.shrunk(W.call_Dd(2), 4)
+    else:
+        call = W.Call("band", dims["N"], dims["M"], dims["D"], dims["P"], dims["shapes"], dims["Lq"], False)
+    if opts and dims.get("call") == "Dd" and loc_mode != "init":
+        pytest.skip("option sweeps at full size: init only")
+    if "band_hits" in opts and call.Lq * call.P > 4000:      # (32 would make more work items per (image, head) than the table holds: falls back)
+        opts = {"band_hits": 200 if dims.get("call") == "Dd" else 64}
+    if opts.get("band_lds_kb", 64) * 1024 < max(w for _, w in call.shapes) * 36 * 8:
+        pytest.skip("a row of the widest level does not fit this window: the plan does not apply (falls back, covered elsewhere)")
+    t = W.make_inputs(call, "uniform" if loc_mode == "far" else loc_mode, seed=9)
+    if loc_mode == "far":
+        t["loc"] = (t["loc"] * 1.6 - 0.3).contiguous()
+    z = {k: v.numpy() for k, v in t.items()}
+    g = {k: v.cuda() for k, v in t.items()}
+    defaults = {k: _lib.get_option(k) for k in opts}
+    res = {}
+
+    def bwd():
+        gv, gl, ga = (torch.full_like(g[k], float("nan")) for k in ("value", "loc", "aw"))
+        L_, P_ = g["shapes"].shape[0], g["loc"].shape[4]
+        N, S, M, D = g["value"].shape
+        _lib.check(_lib.load().msda_backward_f32(
+            g["value"].data_ptr(), g["shapes"].data_ptr(), g["lsi"].data_ptr(), g["loc"].data_ptr(), g["aw"].data_ptr(),
+            g["grad_out"].data_ptr(), N, S, M, D, L_, g["loc"].shape[1], P_, 64, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), None, None,
+            torch.cuda.current_stream().cuda_stream))
+        res["g"] = (gv, gl, ga)
+    try:
+        for k, v in opts.items():
+            _lib.set_option(k, v)
+        for variant in (5,):
+            _lib.set_option("bwd_variant", variant)
+            assert _profiled_variants(bwd) == [("bwd", 5)], "the row-band kernel must be the one that ran"
+            gv, gl, ga = res["g"]
+            ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
+            tf, tg = tols(np.float32)
+            assert torch.isfinite(gv).all() and torch.isfinite(gl).all() and torch.isfinite(ga).all()
+            assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg, (loc_mode, opts)
+    finally:
+        for k, v in defaults.items():
+            _lib.set_option(k, v)
+
+
 def _random_problem(rng):
     """A random small problem: any L / P / D / M, maps down to 1 x 1, encoder-shaped (Lq == S) half of the time, sampling
     locations partly outside [0, 1] (dropped points, border corners)."""
