@@ -645,6 +645,7 @@ def run_graphed(n_img, dev, steps=5, warmup=2, optimizer=True, noise_seed=None, 
                 t_static = model.teacher_part(images)
             params = [p for p in model.parameters() if p.requires_grad]
             opt = make_optimizer(params) if optimizer else None
+            last = {}
 
             def step():
                 for p in params:
@@ -654,6 +655,7 @@ def run_graphed(n_img, dev, steps=5, warmup=2, optimizer=True, noise_seed=None, 
                     pending = model.match_begin(*outs[:4], targets)           # device cost blocks -> one host copy, enqueued
                     teacher_graph.replay()
                     assign = model.match_end(pending)                         # wait for the copy, scipy (matcher.py) -- under the teacher
+                last["assign"] = assign
                 loss = gb(*outs, t_static, *model.pack_indices(assign, targets))
                 loss.backward()
                 if opt is not None:
@@ -679,7 +681,8 @@ def run_graphed(n_img, dev, steps=5, warmup=2, optimizer=True, noise_seed=None, 
             "optimizer": "AdamW(fused) + clip_grad_norm_(0.1)" if optimizer else None,
             "ms": round(ms, 2), "img_per_s": round(n_img / (ms * 1e-3), 2), "loss": float(loss.detach()),
             "grad_norm": float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in params if p.grad is not None))),
-            **({"grads": {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}} if return_grads else {})}
+            **({"grads": {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None},
+                "indices": last["assign"], "topk": model.last_topk.clone()} if return_grads else {})}
 
 
 def run_ddp(n_img, dev, dist, steps=5, warmup=2, optimizer=True, make_model=None, backend_device=None):

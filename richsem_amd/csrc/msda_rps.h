@@ -50,7 +50,10 @@ constexpr int kRpsMaxUnits = 448;
 constexpr int kRpsD = 32;
 constexpr int kRpsPad = 32;                     // atomically updated counters sit on lines of their own
 constexpr int kRpsDummyWgs = 2048, kRpsDummyBytes = kRpsDummyWgs * 1024;   // 1 KB per workgroup: 16 B per lane of a wave
-constexpr int kRpsMaxRuns = 256;               // runs per bin the tile kernel can index (2 KB of LDS): Lq <= 256 x 128 queries
+constexpr int kRpsMaxRuns = 320;               // runs per bin the tile kernel can index (2.5 KB of LDS: what the budget leaves): Lq <= 320 x 128 queries
+                                               // with 8-wave route workgroups (the 1280 x 1280 mosaic shape: 266), twice that with 16-wave ones
+constexpr int kRpsRunSearch = 256;             // first step of the binary search over a bin's runs: the largest power of two below kRpsMaxRuns
+static_assert(kRpsRunSearch < kRpsMaxRuns && 2 * kRpsRunSearch >= kRpsMaxRuns, "run search");
 constexpr int kRpsQpBits = 19;                  // entry code: query * P + point below this bit (plan: Lq * P < 2^19)
 static_assert(kRpsMaxPx <= 256, "record code: the base-grid index has 8 bits (bits 19..26), the tile kernel masks it with 0xFF");
 
@@ -193,9 +196,10 @@ __device__ __forceinline__ unsigned rps_lut_col(const RpsLevel &v, int c)
 // kernel's queue heads are reset.
 // Lanes of a wave usually share the owner bin (neighbouring queries, neighbouring points): they are matched with one ballot and
 // served by a single LDS atomic; the others take one each.
-// kRpsRouteThreads: 512 (8 waves: 128 queries per work item at P <= 4) is the form every shape up to Lq = 256 x 128 takes; longer query
-// sets (the 1280 x 1280 mosaic batches: Lq = 34000) run the same kernel with 1024 threads -- 256 queries per work item, so that a bin
-// still gets at most kRpsMaxRuns runs (the tile kernel keeps a bin's run table in LDS).
+// kRpsRouteThreads: 512 (8 waves: 128 queries per work item at P <= 4) is the form every shape up to Lq = kRpsMaxRuns x 128 = 40960 takes
+// (E: 22323, the 1280 x 1280 mosaic batches: 34000); longer query sets run the same kernel with 1024 threads -- 256 queries per work item,
+// so that a bin still gets at most kRpsMaxRuns runs (the tile kernel keeps a bin's run table in LDS) -- at ~12 % more time per query
+// (one workgroup of 16 waves per CU instead of two of 8: MI355X, Lq = 34000: 94.3 against 83.8 us).
 constexpr int kRpsRouteThreadsMax = 1024;
 static_assert(kRpsMaxUnits <= 512, "route pass: one thread per bin of a pair");
 
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
             const unsigned k = (unsigned)min(ch * kRpsChunk + u * kRpsThreads + tid, max(n - 1, 0));
             int r = 0;      // the last run that starts at or before record k of the bin (the runs' positions ascend with their slots)
 #pragma unroll
-            for (int step = kRpsMaxRuns / 2; step > 0; step >>= 1) {
+            for (int step = kRpsRunSearch; step > 0; step >>= 1) {
                 const int cand = r + step;
                 if (cand < nr && S->runs[cand].y <= k) r = cand;
             }
@@ -1146,8 +1150,8 @@ inline RpsPlan plan_rps(int N, int S, int M, int D, int L, int Lq, int P, const 
     g.nbins = bins * N * M;
     // runs a bin can get: one per route work item of its pair (the route pass's block of queries: 16 queries per wave at P <= 4).  The
     // tile kernel keeps a bin's run table in LDS (kRpsMaxRuns entries): where 8-wave route workgroups would write more runs than that
-    // (Lq > 32768 at P <= 4: the 1280 x 1280 mosaic batches of ImageNet-LVIS, reference datasets/transforms.py:356-357,437-445, have
-    // Lq = 34000) the route pass runs with 16 waves per workgroup -- half the runs.
+    // (Lq > 40960 at P <= 4; the 1280 x 1280 mosaic batches of ImageNet-LVIS, reference datasets/transforms.py:356-357,437-445, have
+    // Lq = 34000: 266 runs) the route pass runs with 16 waves per workgroup -- half the runs.
     const int qpw = P <= 4 ? 16 : (P <= 8 ? 8 : (P <= 16 ? 4 : (P <= 32 ? 2 : 1)));
     g.route_threads = 512;
     g.max_runs = (Lq + qpw * 8 - 1) / (qpw * 8);

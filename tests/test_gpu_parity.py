@@ -603,11 +603,11 @@ def test_routed_backward_overwrites_poisoned_outputs():
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("Lq,want", [(256 * 128 + 300, 4), (256 * 256 + 300, 1)])
+@pytest.mark.parametrize("Lq,want", [(256 * 128 + 300, 4), (320 * 128 + 300, 4), (320 * 256 + 300, 1)])
 def test_routed_backward_beyond_the_8_wave_route_blocks(Lq, want):
-    """more query blocks per (image, head) than a bin's run table holds with 8-wave route workgroups (Lq > 256 x 128): the route pass runs
-    with 16 waves per workgroup -- 256 queries per block, what the 1280 x 1280 mosaic shape (Lq = 34000) takes at full size --; beyond
-    256 x 256 queries the routed plan does not apply and the call takes the direct kernels.  Same results either way, no error."""
+    """the run table of a bin holds 320 runs: 8-wave route workgroups (128 queries per block) reach Lq = 40960 -- past round 4's 256 x 128,
+    where the 1280 x 1280 mosaic shape (Lq = 34000) fell off the routed path --, 16-wave ones (256 queries per block) twice that; beyond,
+    the routed plan does not apply and the call takes the direct kernels.  Same results every way, no error."""
     N, M, D, L, P = 1, 1, 32, 1, 4
     shapes = torch.as_tensor([(24, 30)], dtype=torch.long)
     lsi = torch.as_tensor([0])

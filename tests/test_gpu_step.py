@@ -114,17 +114,18 @@ def test_graphed_sections_train_like_the_eager_step():
     hipStreamEndCapture crash of profiles/r04_capture_probe.txt)."""
     import warnings
     import bench_step
-    model, images, mask, targets = _small_step(seed=0)
-    model.freeze_noise(3)
-    loss = _run(model, images, mask, targets)
-    want = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
-    del model
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
         res = bench_step.run_graphed(2, torch.device("cuda", 0), steps=2, warmup=1, optimizer=False, noise_seed=3, return_grads=True,
                                      height=H, width=W_IMG, boxes_per_image=BOXES, seed=0)
     stream_warnings = [str(w.message)[:120] for w in caught if "AccumulateGrad" in str(w.message)]
     assert not stream_warnings, stream_warnings
+    # the eager step on the same parameters, noise, two-stage selection and Hungarian assignment (both are discrete: a different top-k or
+    # assignment is a different, equally valid, step)
+    model, images, mask, targets = _small_step(seed=0)
+    model.freeze_noise(3)
+    loss = _run(model, images, mask, targets, res["indices"], res["topk"])
+    want = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
     assert abs(res["loss"] - float(loss)) < 2e-3 * abs(float(loss)), (res["loss"], float(loss))
     got = res["grads"]
     assert sorted(got) == sorted(want)
@@ -136,8 +137,8 @@ def test_graphed_sections_train_like_the_eager_step():
             continue
         cos, ratio = float((a * b).sum() / (a.norm() * b.norm())), float(a.norm() / b.norm())
         if cos < 0.999 or not 0.98 < ratio < 1.02:
-            bad[n] = (cos, ratio)
-    assert not bad, bad
+            bad[n] = (round(cos, 4), round(ratio, 4))
+    assert not bad, sorted(bad.items(), key=lambda kv: kv[1][0])[:12]
 
 
 def test_training_step_with_optimizer_moves_the_loss_down():
@@ -232,7 +233,7 @@ def test_criterion_kernels_against_the_reference_loss_functions():
         # the yardstick restates the same formula: hold it to the fixture as well (fp64)
         xd = torch.from_numpy(z[f"focal_{tag}.logits"]).cuda().double()
         onehot = torch.zeros((N, Q, C + 1), dtype=torch.float64, device="cuda").scatter_(2, tc.unsqueeze(-1), 1)[:, :, :-1]
-        assert abs(float(_sigmoid_focal_loss(xd, onehot, nb) * Q) - want) < 1e-12 * abs(want)
+        assert abs(float(_sigmoid_focal_loss(xd, onehot, nb) * Q) - want) < 1e-9 * abs(want)      # (the GPU's fp64 exp / log against the CPU's)
     pb = torch.from_numpy(z["box.pred"]).cuda().requires_grad_(True)
     tb, w = torch.from_numpy(z["box.tgt"]).cuda(), torch.from_numpy(z["box.w"]).cuda()
     loss = BoxPairLoss.apply(pb, tb, w, 5.0, 2.0)
@@ -245,8 +246,8 @@ def test_criterion_kernels_against_the_reference_loss_functions():
     assert float((pb.grad.double() - want_g)[rows].abs().max()) < 2e-4 * float(want_g.abs().max())
     from bench_step import box_cxcywh_to_xyxy, giou_pairs
     pd, td = pb.detach().double(), tb.double()
-    assert float((giou_pairs(box_cxcywh_to_xyxy(pd), box_cxcywh_to_xyxy(td)) - torch.from_numpy(z["box.giou"]).cuda()).abs().max()) < 1e-12
-    assert float(((pd - td).abs().sum(-1) - torch.from_numpy(z["box.l1"]).cuda()).abs().max()) < 1e-12
+    assert float((giou_pairs(box_cxcywh_to_xyxy(pd), box_cxcywh_to_xyxy(td)) - torch.from_numpy(z["box.giou"]).cuda()).abs().max()) < 1e-9
+    assert float(((pd - td).abs().sum(-1) - torch.from_numpy(z["box.l1"]).cuda()).abs().max()) < 1e-9
 
 
 def test_batched_criterion_equals_the_op_sequence():
