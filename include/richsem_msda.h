@@ -83,9 +83,17 @@ const char *msda_last_error(void);
  *                     (sampling points routed to output tiles in ONE pass -- every query block lays its records out in a stretch of
  *                     its own and announces them to the tiles' bins --, then one workgroup per tile: every pixel of grad_value
  *                     written once with plain stores; cost independent of where the points fall; fp32 / bf16 storage, D = 32,
- *                     L <= 4, Lq <= 256 x 128 per (image, head); otherwise the call falls back to 1).  auto = routed for
- *                     encoder-shaped calls (Lq == S), direct for the rest
- *   "fwd_prep_fused"  1 (default) = msda_forward_prep_* runs decoder-shaped calls as one kernel, 0 = always two
+ *                     L <= 4, Lq <= 320 x 256 per (image, head): up to 320 x 128 queries -- E: 22323, the 1280 x 1280 mosaic
+ *                     batches: 34000 -- with 8-wave route workgroups, beyond that with 16-wave ones; otherwise the call falls
+ *                     back to 1); 5 = row-band kernel (msda_band.h: grad_value, grad_sampling_loc and grad_attn_weight of a
+ *                     decoder-shaped call in ONE launch; a measured option -- 101 us against 88 us for 1 on the decoder call,
+ *                     profiles/r05_dd_backward.md -- D = 32 only, else falls back to 1).  auto = routed for encoder-shaped calls
+ *                     (Lq == S), direct for the rest
+ *   "band_lds_kb"     row-band backward: window budget in KB (16..150, default 64 = two workgroups per CU)
+ *   "band_hits"       row-band backward: expected listed points per workgroup above which a band is dealt over query slabs (default 400)
+ *   "fwd_prep_fused"  1 (default) = msda_forward_prep_* runs decoder-shaped calls as one kernel, 0 = always two, 2 = encoder-shaped
+ *                     calls too: the LDS-window kernel reads the raw projection itself (a measured option: 232 us against 139 us
+ *                     for the two-kernel form on the encoder call, profiles/r05_f1_ab.txt)
  *   "locality_monitor"  1 (default) = in auto mode the window forward kernel counts the points that miss their window on the
  *                     first 2 calls of a (problem shape, sampling_loc buffer) and on every 64th after; the count comes back
  *                     by an asynchronous copy and is read on a later call (no call waits, nothing is probed during graph
@@ -96,7 +104,7 @@ const char *msda_last_error(void);
  *   "rps_tile"        routed backward: largest tile side + 1 (4..16, default 16: tile + one row / column <= 256 pixels)
  *   "rps_max_chunks"  routed backward: chunks of 1536 points one workgroup takes before a tile's points are dealt over
  *                     several workgroups (default 12)
- *   "rps_route_wgs"   routed backward: workgroups per CU of the route passes (default 4)
+ *   "rps_route_wgs"   routed backward: workgroups per CU of the route pass (default 2: what is resident)
  *   "rps_seg_shift"   routed backward: a pixel's list is walked in units of at most 2^n sampling points (3..11, default 4)
  *   "levelsum_lds_kb" level-sum window size in KB (8..150, default 150 = one workgroup per CU)
  *   "bwd_direct_cpl"  channels per lane of the direct backward kernel (0 = auto, 1, 2, 4)
