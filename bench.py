@@ -148,26 +148,28 @@ def self_launch(args, argv):
     return proc.returncode
 
 
-def measured_traffic(hip_kernels, dtype):
+def measured_traffic(hip_kernels, dtype, table_key="kernels"):
     """HBM bytes per launch of the given HIP kernels IN THE GIVEN VALUE DTYPE ("f32" | "bf16") from the latest committed PMC summary
     (profiles/*_traffic.json, made by profiles/summarize.py from separate rocprofv3 --pmc passes), or None.  The counters cannot be
     read from inside this process; the number is attached so that it sits next to the algorithmic bytes it is compared with.  A
     kernel instantiated per value type carries the type as its last template argument ("..., float>" / "..., __hip_bfloat16>"); the
-    route kernels are not typed and match either."""
+    route kernels are not typed and match either.  ``table_key``: "kernels" (the headline shape E) or "kernels_Em" (the mosaic shape)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if not files:
         return None
     try:
-        table = json.load(open(files[-1]))["kernels"]
+        table = json.load(open(files[-1])).get(table_key) or {}
     except Exception:
         return None
     total, found = 0, 0
     for want in hip_kernels.split(" + "):
         want = want.strip().rstrip(">")   # "tiled_gather_kernel<false" matches "...tiled_gather_kernel<false, true, 16>"
-        mine, other = ("__hip_bfloat16>", "float>") if dtype == "bf16" else ("float>", "__hip_bfloat16>")
-        hits = [v for k, v in table.items() if want in k and v["hbm_bytes_est"] > 0
-                and (mine in k.split("|")[0] or other not in k.split("|")[0])]
+        # (a kernel instantiated for bf16 storage carries __hip_bfloat16 among its template arguments; kernels without a storage type -- the route
+        # pass -- match either)
+        def typed_ok(name):
+            return ("<" not in name or "rps_route" in name) or (("__hip_bfloat16" in name) == (dtype == "bf16"))
+        hits = [v for k, v in table.items() if want in k and v["hbm_bytes_est"] > 0 and typed_ok(k.split("|")[0])]
         if hits:
             total += max(h["hbm_bytes_est"] for h in hits)   # E-sized launch of that kernel
             found += 1
@@ -657,7 +659,8 @@ def main(argv=None):
             dom = max(kernels, key=lambda k: k["total_ms"])
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "hip_kernels": dom["hip_kernels"],
                         "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom["hip_kernels"], "bf16" if mode == "bf16" else "f32"),
+                        "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4),
+                        "traffic": measured_traffic(dom["hip_kernels"], "bf16" if mode == "bf16" else "f32", "kernels_Em" if mode.startswith("Em/") else "kernels"),
                         "alg_bytes_per_launch": dom["alg_bytes"], "avg_launch_us": dom["avg_us"]}
             out = {"value": round(n_total / (res["elapsed"] / args.steps), 3),
                    "ms_per_step": round(res["elapsed"] / args.steps * 1e3, 4), "roofline": roofline, "kernels": kernels}

@@ -92,8 +92,21 @@ def main():
         f = sum(fetch.get(key, [0])) / max(1, len(fetch.get(key, [0])))
         w = sum(write.get(key, [0])) / max(1, len(write.get(key, [0])))
         traffic[f"{key[0]}|{key[1]}"] = {"fetch_size_kib": f, "write_size_kib": w, "hbm_bytes_est": int((2 * f + w) * 1024)}
+    # the mosaic shape Em (S = Lq = 34000), counted in passes of its own (tools/time_calls.py --calls Em): the persistent kernels' grid does not tell the shape
+    fetch_em, write_em = pmc(d, "pmc_fetch_em", "FETCH_SIZE"), pmc(d, "pmc_write_em", "WRITE_SIZE")
+    traffic_em = {}
+    if fetch_em or write_em:
+        out += ["", "### the mosaic shape Em (1280 x 1280: S = Lq = 34000), `tools/time_calls.py --calls Em --fwd 2 --bwd 4` under the same two counters", "",
+                "| kernel | grid | FETCH_SIZE KiB | WRITE_SIZE KiB | est. HBM MB |", "|---|---|---|---|---|"]
+        for key in sorted(set(fetch_em) | set(write_em)):
+            if not ours(key[0]):
+                continue
+            f = sum(fetch_em.get(key, [0])) / max(1, len(fetch_em.get(key, [0])))
+            w = sum(write_em.get(key, [0])) / max(1, len(write_em.get(key, [0])))
+            out.append(f"| `{key[0][:60]}` | {key[1]} | {f:.0f} | {w:.0f} | {(2 * f + w) * 1024 / 1e6:.1f} |")
+            traffic_em[f"{key[0]}|{key[1]}"] = {"fetch_size_kib": f, "write_size_kib": w, "hbm_bytes_est": int((2 * f + w) * 1024)}
     json.dump({"tag": tag, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; read side doubled "
-               "(gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section)", "kernels": traffic},
+               "(gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section)", "kernels": traffic, "kernels_Em": traffic_em},
               open(os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{tag}_traffic.json"), "w"), indent=1)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{tag}_summary.md")
     open(path, "w").write("\n".join(out) + "\n")
