@@ -524,11 +524,8 @@ hipError_t launch_bwd_rps(const Problem &pb, const TV *value, const float *loc, 
 #endif
     hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 8), dim3(msda::kRpsThreads), sizeof(msda::RpsLds), stream, value, grad_out,
                        grad_value, grad_acc, grad_loc, grad_aw, pl.g);
-    if constexpr (!std::is_same<TV, float>::value) {
-        bool any_atomic = false;
-        for (int l = 0; l < pb.L; ++l) any_atomic = any_atomic || pl.g.lv[l].atomic;
-        if (any_atomic) hipLaunchKernelGGL(msda::rps_round_kernel, dim3(256), dim3(256), 0, stream, grad_acc, grad_value, pl.g);
-    }
+    if constexpr (!std::is_same<TV, float>::value)      // (every level has rows in the fp32 image: the tiles' shared first rows / columns at least)
+        hipLaunchKernelGGL(msda::rps_round_kernel, dim3(256), dim3(256), 0, stream, grad_acc, grad_value, pl.g);
     e = hipGetLastError();
     if (e != hipSuccess) rps_mark_dirty(stream);
     return e;

@@ -7,8 +7,11 @@
 // exactly the sampling points that land on it.
 //
 //   route   (rps_route_kernel, ONE pass)  one lane per sampling point: where does its corner (h_low, w_low) fall?  The point is
-//           appended -- a 16-byte record: position code, bilinear fractions, attention weight -- to the bin of that tile, and to
-//           the bin of the tile below / right of it when its lower / right corners cross the tile's edge.  A workgroup (128
+//           appended -- a 16-byte record: position code, bilinear fractions, attention weight -- to the bin of THAT tile only
+//           (round 5; rounds 2-4 sent a second / third / fourth record to the tiles below / right of it when its lower / right
+//           corners cross the tile's edge: 13 % more records and three quarters of the pass's ranking work -- now the owner tile
+//           keeps those corners' sums in the apron row / column of its window and ADDS them to the neighbours' first row /
+//           column, which every tile flushes with row atomics onto rows the route pass has zeroed).  A workgroup (128
 //           queries of one (image, head)) writes the records of each bin it touches as one RUN inside its own stretch of the
 //           record pool and announces the run to the bin with one 64-bit atomic (records | runs): a bin is the list of its runs.
 //           No counting pass, no prefix pass, no capacity guess, no overflow path.
@@ -21,11 +24,12 @@
 //           of gfx950), so units -- not pixels -- are what the waves share out: a chunk's walk takes as long as its
 //           points need, not as long as its longest list.
 //
-// grad_value is written with plain stores, once per pixel -- no float atomics, no zero-fill, fp32 sums as in the
+// grad_value is written with plain stores, once per pixel, inside the tiles -- no float atomics, no zero-fill there, fp32 sums as in the
 // reference -- and value is read once.  Nothing depends on WHERE the points fall: uniform-random locations cost the same
 // as local ones, so there is no margin, no "far" path and no locality monitor on this side.
 // Coarse levels whose tile is the whole map split their bin into slabs over several workgroups; those add their rows to
-// the (pre-zeroed) level with 128-B row atomics -- a few MB per call.
+// the (pre-zeroed) level with 128-B row atomics -- a few MB per call.  So do all tiles for their first row / column and their apron (the
+// pixels they share with their neighbours: 13 % of the rows).
 #pragma once
 
 #include <algorithm>
@@ -68,8 +72,9 @@ struct RpsLevel {
 };
 
 // Routed sampling point, as the route pass writes it and the tile kernel streams it.
-//   code = (query * P + point)  |  base-grid index in the tile << 19 (8 bits: < kRpsMaxPx)  |  corners inside the map << 27 (4 bits)  |  owner << 31
-// (owner: this tile also forms the point's gradients).  The bin fixes (image, head, level).
+//   code = (query * P + point)  |  base-grid index in the tile << 19 (8 bits: < kRpsMaxPx)  |  corners inside the map << 27 (4 bits)  |  1 << 31
+// (bit 31: this tile forms the point's gradients -- every record since round 5, when a point stopped being sent to the neighbouring tiles
+// as well).  The bin fixes (image, head, level).
 struct alignas(16) RpsRec {
     unsigned code;
     float lh, lw, a;   // bilinear fractions, attention weight
@@ -86,7 +91,7 @@ struct RpsGeom {
     uint2 *runs;            // [nbins * max_runs] a bin's runs in the record pool: {first record, position of the run inside the bin}
     int max_runs;           // runs a bin can get = query blocks of a pair (every route work item adds at most one run to a bin)
     int route_threads;      // threads of a route workgroup (512, or 1024 where 512 would give a bin more than kRpsMaxRuns runs)
-    unsigned entries_cap;   // records the pool holds (4 x points: exact worst case); indices are clamped to it, so that counters left
+    unsigned entries_cap;   // records the pool holds (one per point); indices are clamped to it, so that counters left
                             // dirty by an aborted call can give wrong results but never an access outside the pool
     struct RpsRec *entries;         // one 16-byte record per (point, bin it was routed to)
     int lut_r[kRpsMaxL], lut_c[kRpsMaxL], lut_n;      // route pass: where the levels' row / column tables start in LDS, their total length
@@ -160,29 +165,29 @@ __device__ __forceinline__ int rps_wave_scan(int v)
 // Where a sampling position falls, per level, comes from two small tables in LDS (round 4) -- one entry per base row r = h_low + 1 in
 // [0, H] and one per base column c = w_low + 1 in [0, W] -- instead of ~35 vector instructions of tile arithmetic per point and level
 // (the route pass is bound by instruction issue: ~2400 instructions per wave and work item before, profiles/r04_route_ablation.md):
-//   row entry     gr (bits 0..4) | down << 5 | inr << 6 | (ty * ntx * nslab) << 8
-//   column entry  gc (bits 0..4) | right << 5 | inc << 6 | (tx * nslab) << 8 | gw << 17 | gw2 << 22
-// gr / gc: base-grid row / column inside the owner tile; down / right: the point's lower / right corners belong to the next tile;
-// inr / inc: bit 0 = upper / left corner inside the map, bit 1 = lower / right corner inside the map; gw: width of the owner tile's
-// grid; gw2: width of the right neighbour's grid.  The tile grid is the one the host plans (RpsLevel) and the tile kernel's work items use.
+//   row entry     gr (bits 0..4) | inr << 6 | (ty * ntx * nslab) << 8
+//   column entry  gc (bits 0..4) | inc << 6 | (tx * nslab) << 8 | gw << 17
+// gr / gc: base-grid row / column inside the owner tile (the tile that holds the point's upper-left corner; row / column 0 of the grid is
+// the map's edge: a corner above / left of the map); inr / inc: bit 0 = upper / left corner inside the map, bit 1 = lower / right corner
+// inside the map; gw: width of the owner tile's grid.  The tile grid is the one the host plans (RpsLevel) and the tile kernel's work items use.
 __device__ __forceinline__ unsigned rps_lut_row(const RpsLevel &v, int r)
 {
     const int h_low = r - 1, br = max(h_low, 0);
     const int ty = (int)(((float)br + 0.5f) * v.inv_TH);
-    const int R0 = ty * v.TH, R1 = min(v.H, R0 + v.TH);
-    const unsigned gr = (unsigned)(h_low - R0 + 1), down = h_low == R1 - 1 && R1 < v.H ? 1u : 0u;
+    const int R0 = ty * v.TH;
+    const unsigned gr = (unsigned)(h_low - R0 + 1);
     const unsigned inr = (h_low >= 0 ? 1u : 0u) | (h_low + 1 < v.H ? 2u : 0u);
-    return gr | down << 5 | inr << 6 | (unsigned)(ty * v.ntx * v.nslab) << 8;
+    return gr | inr << 6 | (unsigned)(ty * v.ntx * v.nslab) << 8;
 }
 __device__ __forceinline__ unsigned rps_lut_col(const RpsLevel &v, int c)
 {
     const int w_low = c - 1, bc = max(w_low, 0);
     const int tx = (int)(((float)bc + 0.5f) * v.inv_TW);
     const int C0 = tx * v.TW, C1 = min(v.W, C0 + v.TW);
-    const unsigned gc = (unsigned)(w_low - C0 + 1), right = w_low == C1 - 1 && C1 < v.W ? 1u : 0u;
+    const unsigned gc = (unsigned)(w_low - C0 + 1);
     const unsigned inc = (w_low >= 0 ? 1u : 0u) | (w_low + 1 < v.W ? 2u : 0u);
-    const unsigned gw = (unsigned)(C1 - C0 + 1), gw2 = (unsigned)(min(v.W, C1 + v.TW) - C1 + 1);
-    return gc | right << 5 | inc << 6 | (unsigned)(tx * v.nslab) << 8 | gw << 17 | gw2 << 22;
+    const unsigned gw = (unsigned)(C1 - C0 + 1);
+    return gc | inc << 6 | (unsigned)(tx * v.nslab) << 8 | gw << 17;
 }
 
 // Route pass (ONE pass: no counting pass, no prefix pass).  A workgroup takes a block of consecutive queries of one (image, head);
@@ -192,8 +197,8 @@ __device__ __forceinline__ unsigned rps_lut_col(const RpsLevel &v, int c)
 // where its run is -- one 64-bit atomic per (workgroup, bin) adds the run's length to the bin's record count and one to its run count,
 // and what it returns is the run's slot in the bin's run table and the run's position inside the bin -- and writes its 16-byte entries
 // (position code, bilinear fractions, attention weight) at run start + rank.  The tile kernel reads a bin as the list of its runs.
-// Also here: dropped samples get their (zero) gradients; the levels flushed with atomics later are zeroed in grad_value; the tile
-// kernel's queue heads are reset.
+// Also here: dropped samples get their (zero) gradients; what the tile kernel flushes with atomics later -- the slabbed levels, and
+// the first row / column of every tile of the others -- is zeroed in grad_value; the tile kernel's queue heads are reset.
 // Lanes of a wave usually share the owner bin (neighbouring queries, neighbouring points): they are matched with one ballot and
 // served by a single LDS atomic; the others take one each.
 // kRpsRouteThreads: 512 (8 waves: 128 queries per work item at P <= 4) is the form every shape up to Lq = kRpsMaxRuns x 128 = 40960 takes
@@ -223,7 +228,27 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
             const RpsLevel &v = g.lv[l];
             for (int i = tid; i <= v.H; i += kRpsRouteThreads) rps_lut[g.lut_r[l] + i] = rps_lut_row(v, i);
             for (int i = tid; i <= v.W; i += kRpsRouteThreads) rps_lut[g.lut_c[l] + i] = rps_lut_col(v, i);
-            if (!v.atomic) continue;
+            if (!v.atomic) {
+                // the first row and the first column of every tile take their neighbours' apron sums by row atomics (rps_tile_kernel's
+                // flush): zero them in every image -- nty rows of W pixels, ntx columns of H pixels, all heads of a pixel at once
+                const int nb = v.nty * v.W + v.ntx * v.H;
+                for (int b = 0; b < g.N; ++b) {
+                    float4 *dst = reinterpret_cast<float4 *>(grad_value) + (size_t)(b * g.S + v.start) * row4;
+                    for (int i = gtid; i < nb * row4; i += gsz) {
+                        const int k = i / row4, c = i - k * row4;
+                        int px;
+                        if (k < v.nty * v.W) {
+                            const int ty = k / v.W;
+                            px = ty * v.TH * v.W + (k - ty * v.W);
+                        } else {
+                            const int k2 = k - v.nty * v.W, tx = k2 / v.H;
+                            px = (k2 - tx * v.H) * v.W + tx * v.TW;
+                        }
+                        dst[(size_t)px * row4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+                continue;
+            }
             const int n4 = v.H * v.W * row4;
             for (int b = 0; b < g.N; ++b) {
                 float4 *dst = reinterpret_cast<float4 *>(grad_value) + (size_t)(b * g.S + v.start) * row4;
@@ -279,9 +304,8 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         __syncthreads();      // (the first item: the tables as well)
         RPS_RSTAMP(1)
         // ---- A: ranks inside the workgroup ---------------------------------------------------------------------------------------
-        // word[l][k] = bin | rank << 9 | pbase << 23 of the point's entry in [0] its owner tile, [1] the tile below, [2] the tile to the
-        // right, [3] below-right (the few points on a tile's last row / column); ~0u = no entry
-        unsigned word[kRpsMaxL][4];
+        // word[l] = bin | rank << 9 | pbase << 23 of the point's entry in its owner tile; ~0u = no entry
+        unsigned word[kRpsMaxL];
         unsigned inmap[kRpsMaxL];
         float lh[kRpsMaxL], lw[kRpsMaxL];
         unsigned re[kRpsMaxL], ce[kRpsMaxL];
@@ -324,7 +348,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
             lb[l] = -1;
             own_rank[l] = lt_cnt[l] = n_match[l] = 0u;
             inmap[l] = 0u;
-            word[l][0] = word[l][1] = word[l][2] = word[l][3] = ~0u;
+            word[l] = ~0u;
             if (l >= g.L) continue;   // (uniform)
             const RpsLevel &v = g.lv[l];
             const int ns = v.nslab;
@@ -348,23 +372,14 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
             asked_m |= asked ? 1u << l : 0u;
             own_rank[l] = atomicAdd(asked ? &hist[is_lead ? lb[l] : ob[l]] : &sink[lane], is_lead ? n_match[l] : (other ? 1u : 0u));
         }
-        // A.3: lower / right corners beyond the tile's edge belong to the next tile: there the point sits in row / column 0
+        // A.3: the record's word: bin | rank << 9 (added in stage C) | base-grid index << 23.  (Lower / right corners beyond the tile's edge
+        //      stay with this tile: its window has an apron row / column for them, flushed with atomics -- no second record.)
 #pragma unroll
         for (int l = 0; l < kRpsMaxL; ++l) {
             if (l >= g.L) continue;   // (uniform)
-            const RpsLevel &v = g.lv[l];
-            const int ns = v.nslab;
             const unsigned gr = re[l] & 31u, gc = ce[l] & 31u;
-            const bool down = (valid_m >> l & 1u) && (re[l] & 32u), right = (valid_m >> l & 1u) && (ce[l] & 32u);
-            const int b1 = ob[l] + v.ntx * ns, b2 = ob[l] + ns, b3 = ob[l] + (v.ntx + 1) * ns;
-            const unsigned r1 = atomicAdd(down ? &hist[b1] : &sink[lane], down ? 1u : 0u);
-            const unsigned r2 = atomicAdd(right ? &hist[b2] : &sink[lane], right ? 1u : 0u);
-            const unsigned r3 = atomicAdd(down && right ? &hist[b3] : &sink[lane], down && right ? 1u : 0u);
             if (!(asked_m >> l & 1u)) own_rank[l] = lt_cnt[l];      // + the leader's result, below
-            if (ob[l] >= 0) word[l][0] = (unsigned)ob[l] | (gr * ((ce[l] >> 17) & 31u) + gc) << 23;
-            if (down) word[l][1] = (unsigned)b1 | r1 << 9 | gc << 23;                               // row 0 of a tile with the same columns
-            if (right) word[l][2] = (unsigned)b2 | r2 << 9 | (gr * ((ce[l] >> 22) & 31u)) << 23;   // column 0 of the right neighbour's grid
-            if (down && right) word[l][3] = (unsigned)b3 | r3 << 9;
+            if (ob[l] >= 0) word[l] = (unsigned)ob[l] | (gr * ((ce[l] >> 17) & 31u) + gc) << 23;
         }
         RPS_RSTAMP(2)
         __syncthreads();
@@ -378,9 +393,8 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         unsigned before = 0u;
 #pragma unroll
         for (int w = 0; w < kRpsRouteThreads / kWave; ++w) before += w < wave ? wtot[w] : 0u;
-        // (every work item has its own stretch of the record pool, sized for its worst case -- 4 bins per point --: no cursor to share,
-        // and the pool's capacity is the exact bound it always had: 4 x the points of all work items)
-        const unsigned first = (unsigned)item * (unsigned)(qpb * LP * 4) + before + incl - cnt;
+        // (every work item has its own stretch of the record pool, sized for its points -- one record each --: no cursor to share)
+        const unsigned first = (unsigned)item * (unsigned)(qpb * LP) + before + incl - cnt;
         if (cnt) base[tid] = first;      // (known without asking anybody: the entries below do not wait for the bins' counters)
         // ---- C: entries to their slots ------------------------------------------------------------------------------------------
 #pragma unroll
@@ -389,7 +403,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
             unsigned r = own_rank[l];
             const unsigned rl = (unsigned)__builtin_amdgcn_readlane((int)r, lead[l]);
             if ((matched_m >> l & 1u) && lane != lead[l]) r += rl;
-            if (word[l][0] != ~0u) word[l][0] |= r << 9;
+            if (word[l] != ~0u) word[l] |= r << 9;
         }
         __syncthreads();
         RPS_RSTAMP(4)
@@ -401,29 +415,25 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         unsigned long long *const scratch64 = reinterpret_cast<unsigned long long *>(g.dummy + (size_t)(blockIdx.x & (kRpsDummyWgs - 1)) * 256) + lane;
         const unsigned long long old = atomicAdd(cnt ? g.bin_state + gb * (kRpsPad / 2) : scratch64, cnt ? (1ull << 32) | (unsigned long long)cnt : 0ull);
         const unsigned qp = (unsigned)((live ? q : 0) * P + pp);
-        unsigned slot0[kRpsMaxL][4];
+        unsigned slot0[kRpsMaxL];
 #pragma unroll
-        for (int l = 0; l < kRpsMaxL; ++l)      // (all the run starts are read before any of them is waited for; ~0u reads base[511])
-#pragma unroll
-            for (int k = 0; k < 4; ++k) slot0[l][k] = base[word[l][k] & 511u];
+        for (int l = 0; l < kRpsMaxL; ++l) slot0[l] = base[word[l] & 511u];      // (all the run starts are read before any of them is waited for; ~0u reads base[511])
         // (the weights are in their registers from here on: the conditional stores below then carry no wait of their own -- behind a
         // branch the compiler cannot count what is outstanding and would wait for EVERY earlier store to be acknowledged)
         asm volatile("" : "+v"(at[0]), "+v"(at[1]), "+v"(at[2]), "+v"(at[3]));
 #pragma unroll
-        for (int l = 0; l < kRpsMaxL; ++l)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned w = word[l][k];
-                if (w != ~0u) {
-                    const unsigned slot = min(slot0[l][k] + ((w >> 9) & 16383u), g.entries_cap - 1u);
-                    const unsigned code = qp | (w >> 23) << kRpsQpBits | (k == 0 ? inmap[l] << 27 | 0x80000000u : 0u);
+        for (int l = 0; l < kRpsMaxL; ++l) {
+            const unsigned w = word[l];
+            if (w != ~0u) {
+                const unsigned slot = min(slot0[l] + ((w >> 9) & 16383u), g.entries_cap - 1u);
+                const unsigned code = qp | (w >> 23) << kRpsQpBits | inmap[l] << 27 | 0x80000000u;
 #ifdef RPS_ROUTE_ABLATION      // (diagnostic build, profiles/r04_route_ablation.md: what the record stores cost)
-                    if (g.dbg & 512) reinterpret_cast<unsigned *>(g.entries)[slot] = code;
-                    else if (!(g.dbg & 256))
+                if (g.dbg & 512) reinterpret_cast<unsigned *>(g.entries)[slot] = code;
+                else if (!(g.dbg & 256))
 #endif
-                    g.entries[slot] = RpsRec{code, lh[l], lw[l], at[l]};
-                }
+                g.entries[slot] = RpsRec{code, lh[l], lw[l], at[l]};
             }
+        }
         if (__ballot(dropped != 0u)) {      // (uniform; rare) dropped samples: zero gradients
 #pragma unroll
             for (int l = 0; l < kRpsMaxL; ++l)
@@ -970,24 +980,40 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
         fetch_recs(next_n, next_runs, 0);      // the next item's first chunk (its run table is in LDS now) travels under the stores below
         if (tid == 0 && e_bin != 0xFFFFFFFFu) g.bin_state[(size_t)e_bin * (kRpsPad / 2)] = 0ull;      // this bin is consumed: its counter is zero for the next call
         if (!g.lv[l].atomic) {   // (uniform)
+            // interior pixels of the tile -- everything but its first row / column -- belong to this workgroup alone: plain stores
 #pragma unroll
             for (int r = 0; r < kRpsPpq; ++r) {
                 const int px = quad + r * (kRpsThreads / 4);
                 const int pxc = min(px, kRpsMaxPx - 1);
                 const int gr = pxc / gw, gc = pxc - gr * gw;
                 const int prow = R0 + gr, pcol = C0 + gc;
-                const bool in_tile = px < npx && prow < R1 && pcol < C1;
+                const bool interior = px < npx && gr >= 1 && gc >= 1 && prow < R1 && pcol < C1;
                 double *src = S->sum + pxc * kRpsSumStride + j4;
                 const int64_t px_off = ((int64_t)(b * g.S + g.lv[l].start + prow * W + pcol) * g.M + m) * kRpsD;
-                TV *const dst = in_tile ? grad_value + px_off : reinterpret_cast<TV *>(dummy_w) + 4 * lane - c_lo;
+                TV *const dst = interior ? grad_value + px_off : reinterpret_cast<TV *>(dummy_w) + 4 * lane - c_lo;
                 st4(dst + c_lo, make_float4((float)src[0], (float)src[4], (float)src[8], (float)src[12]));
-                st4(in_tile ? dst + c_hi : dst + c_lo, make_float4((float)src[16], (float)src[20], (float)src[24], (float)src[28]));
+                st4(interior ? dst + c_hi : dst + c_lo, make_float4((float)src[16], (float)src[20], (float)src[24], (float)src[28]));
+                if (interior) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) src[4 * k] = 0.0;      // (read out: zero for the next work item)
+                    for (int k = 0; k < 8; ++k) src[4 * k] = 0.0;      // (read out: zero for the next work item)
+                }
+            }
+            // The tile's first row / column and its apron (the row below / the column right of it: the lower / right corners of the points
+            // on its last row / column) are shared with the neighbouring tiles: ADDED to rows the route pass has zeroed, one channel per lane,
+            // so that a wave instruction adds two whole 128-B rows.  (Rounds 2-4 routed a second record to the neighbour instead.)
+            const int c32 = tid & 31;
+            const int64_t tile_base = ((int64_t)(b * g.S + g.lv[l].start) * g.M + m) * kRpsD + c32;
+            for (int p = tid >> 5; p < npx; p += kRpsThreads / 32) {
+                const int pr = p / gw, pc = p - pr * gw, row = R0 + pr, col = C0 + pc;
+                if (pr >= 1 && pc >= 1 && row < R1 && col < C1) continue;      // (interior: done above)
+                double *const sp = S->sum + p * kRpsSumStride + (c32 & 16) + 4 * (c32 & 3) + ((c32 & 15) >> 2);
+                const float x = (float)*sp;
+                *sp = 0.0;
+                if (row < H && col < W && x != 0.f) atomicAdd(grad_acc + tile_base + (int64_t)(row * W + col) * row_elems, x);
             }
         } else if (n_chunks > 0) {
-            // several workgroups share the tile: its rows are ADDED to the (pre-zeroed) level, one channel per lane, so that a wave
-            // instruction adds two whole 128-B rows (32-B atomic segments run ~4x slower)
+            // several workgroups share the tile: its rows -- apron included -- are ADDED to the (pre-zeroed) level, one channel per lane, so
+            // that a wave instruction adds two whole 128-B rows (32-B atomic segments run ~4x slower)
             const int c32 = tid & 31;
             const int64_t tile_base = ((int64_t)(b * g.S + g.lv[l].start) * g.M + m) * kRpsD + c32;
             for (int p = tid >> 5; p < npx; p += kRpsThreads / 32) {
@@ -995,7 +1021,7 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                 double *const sp = S->sum + p * kRpsSumStride + (c32 & 16) + 4 * (c32 & 3) + ((c32 & 15) >> 2);
                 const float x = (float)*sp;
                 *sp = 0.0;
-                if (row < R1 && col < C1 && x != 0.f) atomicAdd(grad_acc + tile_base + (int64_t)(row * W + col) * row_elems, x);
+                if (row < H && col < W && x != 0.f) atomicAdd(grad_acc + tile_base + (int64_t)(row * W + col) * row_elems, x);
             }
         }
         __syncthreads();
@@ -1014,17 +1040,34 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
     }
 }
 
-// bf16 storage: the levels accumulated with atomics live in the fp32 image `acc`; round them into grad_value once.
+// bf16 storage: what is accumulated with atomics lives in the fp32 image `acc` -- the slabbed levels, and the first row / column of every
+// tile of the others --; round it into grad_value once.
 __global__ __launch_bounds__(256) void rps_round_kernel(const float *__restrict__ acc, bf16_t *__restrict__ grad_value, const RpsGeom g)
 {
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     const int row4 = g.M * kRpsD / 4;
     for (int l = 0; l < g.L; ++l) {
-        if (!g.lv[l].atomic) continue;
-        const int n4 = g.lv[l].H * g.lv[l].W * row4;
+        const RpsLevel &v = g.lv[l];
+        const int nb = v.nty * v.W + v.ntx * v.H;      // border pixels of the tile grid (see rps_route_kernel's prologue)
+        const int n4 = (v.atomic ? v.H * v.W : nb) * row4;
         for (int b = 0; b < g.N; ++b) {
-            const size_t base = (size_t)(b * g.S + g.lv[l].start) * row4 * 4;
-            for (int i = gtid; i < n4; i += gsz) st4(grad_value + base + 4 * (size_t)i, *reinterpret_cast<const float4 *>(acc + base + 4 * (size_t)i));
+            const size_t base = (size_t)(b * g.S + v.start) * row4 * 4;
+            for (int i = gtid; i < n4; i += gsz) {
+                size_t at = (size_t)i;
+                if (!v.atomic) {
+                    const int k = i / row4, c = i - k * row4;
+                    int px;
+                    if (k < v.nty * v.W) {
+                        const int ty = k / v.W;
+                        px = ty * v.TH * v.W + (k - ty * v.W);
+                    } else {
+                        const int k2 = k - v.nty * v.W, tx = k2 / v.H;
+                        px = (k2 - tx * v.H) * v.W + tx * v.TW;
+                    }
+                    at = (size_t)px * row4 + c;
+                }
+                st4(grad_value + base + 4 * at, *reinterpret_cast<const float4 *>(acc + base + 4 * at));
+            }
         }
     }
 }
@@ -1085,7 +1128,7 @@ inline RpsPlan plan_rps(int N, int S, int M, int D, int L, int Lq, int P, const 
         // slabs per tile, from the points a tile receives if they spread evenly over the level (they need not: a slab just
         // takes what lands in its bin)
         const double per_px = (double)Lq * P / ((double)v.H * v.W);
-        const int nchunks = (int)(per_px * v.TH * v.TW * 1.2 / kRpsChunk) + 1;
+        const int nchunks = (int)(per_px * v.TH * v.TW * 1.05 / kRpsChunk) + 1;
         v.nslab = std::min(255, std::max(1, (nchunks + max_chunks - 1) / max_chunks));
         v.atomic = v.nslab > 1 ? 1 : 0;
         v.inv_TH = 1.0f / (float)v.TH;
@@ -1161,8 +1204,8 @@ inline RpsPlan plan_rps(int N, int S, int M, int D, int L, int Lq, int P, const 
     }
     if (g.max_runs > kRpsMaxRuns) return pl;
     const int qpb = qpw * (g.route_threads / kWave);
-    // the record pool: a stretch per route work item (pair, block of qpb queries), each for the worst case of 4 bins per point
-    pl.max_entries = (size_t)N * M * g.max_runs * (size_t)qpb * L * P * 4;
+    // the record pool: a stretch per route work item (pair, block of qpb queries): one record per point
+    pl.max_entries = (size_t)N * M * g.max_runs * (size_t)qpb * L * P;
     if (pl.max_entries >= ((size_t)1 << 32)) return pl;
     pl.ok = true;
     return pl;
