@@ -1001,12 +1001,16 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
             // The tile's first row / column and its apron (the row below / the column right of it: the lower / right corners of the points
             // on its last row / column) are shared with the neighbouring tiles: ADDED to rows the route pass has zeroed, one channel per lane,
             // so that a wave instruction adds two whole 128-B rows.  (Rounds 2-4 routed a second record to the neighbour instead.)
+            // (the perimeter of the pixel grid, walked without divisions: its first and last row, then the two columns between them)
             const int c32 = tid & 31;
             const int64_t tile_base = ((int64_t)(b * g.S + g.lv[l].start) * g.M + m) * kRpsD + c32;
-            for (int p = tid >> 5; p < npx; p += kRpsThreads / 32) {
-                const int pr = p / gw, pc = p - pr * gw, row = R0 + pr, col = C0 + pc;
-                if (pr >= 1 && pc >= 1 && row < R1 && col < C1) continue;      // (interior: done above)
-                double *const sp = S->sum + p * kRpsSumStride + (c32 & 16) + 4 * (c32 & 3) + ((c32 & 15) >> 2);
+            const int gh = R1 - R0 + 1, n_border = npx ? 2 * (gw + gh) - 4 : 0;
+            for (int k = tid >> 5; k < n_border; k += kRpsThreads / 32) {
+                const int k2 = k - 2 * gw;
+                const int pr = k < gw ? 0 : (k2 < 0 ? gh - 1 : 1 + (k2 >> 1));
+                const int pc = k < gw ? k : (k2 < 0 ? k - gw : ((k2 & 1) ? gw - 1 : 0));
+                const int row = R0 + pr, col = C0 + pc;
+                double *const sp = S->sum + (pr * gw + pc) * kRpsSumStride + (c32 & 16) + 4 * (c32 & 3) + ((c32 & 15) >> 2);
                 const float x = (float)*sp;
                 *sp = 0.0;
                 if (row < H && col < W && x != 0.f) atomicAdd(grad_acc + tile_base + (int64_t)(row * W + col) * row_elems, x);
