@@ -1,5 +1,4 @@
 from .ms_deform_attn import MSDeformAttn  # noqa: F401
-from .ffn import FFN  # noqa: F401
 from .encoder_layer import DeformableTransformerEncoderLayer, get_reference_points  # noqa: F401
 from .decoder_layer import DeformableTransformerDecoderLayer  # noqa: F401
 from .attnpool import AttentionPool2d, clip_box_targets  # noqa: F401

@@ -1,4 +1,5 @@
-"""The feed-forward block of the deformable transformer layers, mirror of the reference's ``forward_ffn``
+"""Test helper (moved out of the product in round 5: only tests/test_gpu_ffn.py uses it -- the layers call the fused block directly).
+The feed-forward block of the deformable transformer layers, mirror of the reference's ``forward_ffn``
 (models/richsem/deformable_transformer.py:840-866 encoder layer, :907-944 decoder layer):
 
     src = norm(src + dropout(linear2(dropout(activation(linear1(src))))))
@@ -12,7 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions.ffn import FUSED_FFN_MIN_TOKENS, FusedFFNFunction
+from richsem_amd.functions.ffn import FUSED_FFN_MIN_TOKENS, FusedFFNFunction
 
 
 class FFN(nn.Module):

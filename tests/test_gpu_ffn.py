@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from richsem_amd import _lib
 from richsem_amd.functions import FusedFFNFunction, ffn_forward_bf16, pack_w2_bf16
-from richsem_amd.modules.ffn import FFN
+from ffn_module import FFN
 
 pytestmark = pytest.mark.gpu
 D = 256
