@@ -487,7 +487,7 @@ def test_band_backward_matches_oracle(dims, loc_mode, opts):
             _lib.set_option(k, v)
 
 
-def _random_problem(rng):
+def _random_problem(rng, D=None):
     """A random small problem: any L / P / D / M, maps down to 1 x 1, encoder-shaped (Lq == S) half of the time, sampling
     locations partly outside [0, 1] (dropped points, border corners)."""
     L = int(rng.integers(1, 6))
@@ -495,7 +495,7 @@ def _random_problem(rng):
     shapes = [(int(rng.integers(1, 41)), int(rng.integers(1, 41))) for _ in range(L)]
     S = sum(h * w for h, w in shapes)
     N, M = int(rng.integers(1, 4)), int(rng.choice([1, 2, 3, 8]))
-    D = int(rng.choice([8, 16, 32, 32, 32, 48, 64]))
+    D = int(rng.choice([8, 16, 32, 32, 32, 48, 64])) if D is None else D
     enc = bool(rng.integers(0, 2))
     Lq = S if enc else int(rng.integers(1, 400))
     g = torch.Generator().manual_seed(int(rng.integers(0, 2**31)))
@@ -529,6 +529,23 @@ def test_random_problems_against_oracle(seed):
         out, gv, gl, ga = run_gpu(z, variant)
         assert rel_err(out, oo) < tf, (variant, z["value"].shape, z["loc"].shape)
         assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg, (variant, z["value"].shape)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_d32_problems_on_the_routed_and_band_kernels(seed):
+    """Seeded random shapes at D = 32 -- maps down to 1 x 1, 1-5 levels, 1-8 points, dropped samples, encoder- and decoder-shaped -- FORCED onto
+    the routed backward (one record per point; tiles' shared rows by atomics) and the row-band backward, against the oracle; whichever of the
+    two does not apply to a shape (L > 4 for the routed kernels) falls back, which the result must survive too."""
+    rng = np.random.default_rng(5000 + seed)
+    t = _random_problem(rng, D=32)
+    z = {k: v.numpy() for k, v in t.items()}
+    ogv, ogl, oga = O.backward(z["value"], z["shapes"], z["lsi"], z["loc"], z["aw"], z["grad_out"])
+    tf, tg = tols(np.float32)
+    v, sh, ls, loc, aw, go = (dev(z[k]) for k in ("value", "shapes", "lsi", "loc", "aw", "grad_out"))
+    for variant in (4, 5):
+        _lib.set_option("bwd_variant", variant)
+        gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, ls, loc, aw, go, 64)
+        assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg, (variant, z["value"].shape, z["loc"].shape)
 
 
 def _profiled_variants(fn):
