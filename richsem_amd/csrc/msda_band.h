@@ -11,7 +11,7 @@
 //             lies in it)?  Queries with a hit are listed in LDS (4 B each: query, hit mask, owner mask).  The thread of a DROPPED sample
 //             (outside the reference's acceptance window, :276-285) writes its zero gradients on the spot (first band of the level only).
 //   reduce    a group of EIGHT lanes (4 channels each) takes a listed query: grad_out's row (128 B) once, the four corners' value rows of
-//             every point the band owns (the band that holds its upper row) -- up to 16 rows requested together --, w * a * grad_out added
+//             every point the band owns (the band that holds its upper row) -- two points, 8 rows, requested together --, w * a * grad_out added
 //             to the window's sums of the corners inside the band, the four corner dots <grad_out, value> reduced over the group (DPP) and
 //             turned into grad_sampling_loc / grad_attn_weight by one lane.
 //   flush     every pixel of the band once: a 128-B row per lane group, plain stores -- no zero-fill of grad_value, no global atomics.
@@ -122,7 +122,8 @@ __device__ __forceinline__ float band_group_sum(float v)
 // accumulated with fp32 row atomics -- grad_value itself for TV = float, an fp32 image of it for bf16 (rounded by band_round_kernel).
 // Work decomposition of scan and reduce: an ITEM is (query, chunk of four points of this level) -- RichSem's P = 4: one item per query --;
 // a thread scans an item (its points' locations are 32 contiguous bytes), a group of EIGHT lanes (4 channels each) reduces a listed item:
-// grad_out's row once, then the value rows of every point the band owns -- up to 16 rows of 128 B requested before the first is used.
+// grad_out's row once, then the value rows of the points the band owns, two points (8 rows of 128 B) at a time -- four at a time cost 64
+// registers: hipcc spilled, and a spill is a memory round trip in the middle of the loop (154 -> 103 us).
 template <typename TV>
 __global__ __launch_bounds__(kBandThreads, 4) void bwd_band_kernel(const TV *__restrict__ value, const float *__restrict__ loc,
                                                                    const float *__restrict__ aw, const TV *__restrict__ grad_out,
