@@ -622,16 +622,28 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
         if (tid < kRpsMaxRuns) S->runs[tid] = run_reg;
     };
     RpsRec n_rec[kRpsRpl];   // this lane's records of the chunk in flight (lanes past the end of the bin: a copy of its last record)
+    // The run of record k = the last run that starts at or before it (the runs' positions ascend with their slots).  A binary search over
+    // the table is nine DEPENDENT LDS reads per record -- 2.2 k cycles per call with every wave of the workgroup in the same chain, ~20 calls
+    // per workgroup: 9 % of the kernel (round 5, stage stamps).  A wave's 64 records are consecutive, so the wave searches together: every
+    // lane reads ONE sample of the table (every T-th run), two ballots bracket the wave's first and last record between samples, and a lane
+    // finishes inside that bracket -- a few runs -- with a short search of its own: 3-5 dependent reads instead of 10.
     auto fetch_recs = [&](int n_, int nr_, int ch) {      // (the bin's run table is in LDS)
         const int n = rps_uni(n_), nr = rps_uni(nr_);
+        const int T = max((nr + kWave - 1) / kWave, 1);      // sample stride (nr <= kRpsMaxRuns: T <= 5)
+        const bool s_ok = lane * T < nr;
+        const unsigned sy = S->runs[min(lane * T, max(nr - 1, 0))].y;
+        const int k_last = max(n - 1, 0);
 #pragma unroll
         for (int u = 0; u < kRpsRpl; ++u) {
-            const unsigned k = (unsigned)min(ch * kRpsChunk + u * kRpsThreads + tid, max(n - 1, 0));
-            int r = 0;      // the last run that starts at or before record k of the bin (the runs' positions ascend with their slots)
-#pragma unroll
-            for (int step = kRpsRunSearch; step > 0; step >>= 1) {
+            const int kb = ch * kRpsChunk + u * kRpsThreads + wave * kWave;      // (uniform) the wave's first record of this slot
+            const unsigned k = (unsigned)min(kb + lane, k_last);
+            const unsigned k_lo = (unsigned)min(kb, k_last), k_hi = (unsigned)min(kb + kWave - 1, k_last);
+            const int c_lo = __popcll(__ballot(s_ok && sy <= k_lo)) - 1, c_hi = __popcll(__ballot(s_ok && sy <= k_hi)) - 1;
+            const int ra = max(c_lo, 0) * T, rb = min((max(c_hi, 0) + 1) * T, nr);      // (uniform) the runs of all 64 records lie in [ra, rb)
+            int r = ra;
+            for (int step = rb - ra > 1 ? 1 << (31 - __builtin_clz(rb - ra - 1)) : 0; step > 0; step >>= 1) {      // (uniform trip count)
                 const int cand = r + step;
-                if (cand < nr && S->runs[cand].y <= k) r = cand;
+                if (cand < rb && S->runs[cand].y <= k) r = cand;
             }
             const uint2 run = S->runs[r];
             n_rec[u] = g.entries[n > 0 ? min(run.x + (k - run.y), g.entries_cap - 1u) : 0u];
