@@ -295,6 +295,9 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         for (int l = 0; l < kRpsMaxL; ++l) xy[l] = *reinterpret_cast<const float2 *>(loc + 2u * (pt0_ + (unsigned)(min(l, g.L - 1) * P)));
     };
     request_xy(blockIdx.x);
+    unsigned long long p_old = 0ull;      // the previous work item's announce (see stage D)
+    unsigned p_first = 0u, p_cnt = 0u;
+    size_t p_gb = 0;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {   // (uniform)
         const int pair = item % pairs, qb = item / pairs;               // neighbouring workgroups: different pairs (different bins)
         for (int i = tid; i < B; i += kRpsRouteThreads) hist[i] = 0u;
@@ -413,6 +416,9 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         //      weights below could not be counted and would wait for the atomic as well)
         const size_t gb = (size_t)pair * B + min(tid, B - 1);
         unsigned long long *const scratch64 = reinterpret_cast<unsigned long long *>(g.dummy + (size_t)(blockIdx.x & (kRpsDummyWgs - 1)) * 256) + lane;
+        // (the run-table entry of the PREVIOUS work item: its announce has had a whole item to come back -- round 5; written here, before this
+        // item's atomic is issued, so that the two results never live at the same time and no register copy waits for the new one)
+        if (p_cnt) g.runs[p_gb * (size_t)g.max_runs + (size_t)min((unsigned)(p_old >> 32), (unsigned)g.max_runs - 1u)] = make_uint2(p_first, (unsigned)p_old);
         const unsigned long long old = atomicAdd(cnt ? g.bin_state + gb * (kRpsPad / 2) : scratch64, cnt ? (1ull << 32) | (unsigned long long)cnt : 0ull);
         const unsigned qp = (unsigned)((live ? q : 0) * P + pp);
         unsigned slot0[kRpsMaxL];
@@ -444,12 +450,16 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
                 }
         }
         RPS_RSTAMP(5)
-        // ---- D (second half): the run's slot in the bin's run table and its position inside the bin
-        if (cnt) g.runs[gb * (size_t)g.max_runs + (size_t)min((unsigned)(old >> 32), (unsigned)g.max_runs - 1u)] = make_uint2(first, (unsigned)old);
+        // ---- D (second half): the run's slot in the bin's run table and its position inside the bin -- written one work item later (above)
+        p_old = old;
+        p_first = first;
+        p_cnt = cnt;
+        p_gb = gb;
         RPS_RSTAMP(6)
         __syncthreads();   // hist / base are reused by the next item
         RPS_RSTAMP(7)
     }
+    if (p_cnt) g.runs[p_gb * (size_t)g.max_runs + (size_t)min((unsigned)(p_old >> 32), (unsigned)g.max_runs - 1u)] = make_uint2(p_first, (unsigned)p_old);
     if (g.stamps && tid == 0)
         for (int i = 0; i < 8; ++i) g.stamps[(size_t)(1024 + blockIdx.x) * 16 + i] = st_acc[i];
 #undef RPS_RSTAMP
