@@ -561,8 +561,9 @@ def main(argv=None):
                 for _ in range(3):
                     step(mode, False)
             torch.cuda.synchronize()
+            from richsem_amd.capture import quiet_gc
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
+            with quiet_gc(), torch.cuda.graph(graph, stream=side):
                 step(mode, False)
             for _ in range(2):
                 graph.replay()

@@ -26,6 +26,7 @@ from torch import nn
 
 from richsem_amd import workload as W
 from richsem_amd.backbone import InputProjection, ResNet50
+from richsem_amd.capture import quiet_gc
 from richsem_amd.clip_resnet import ModifiedResNetTeacher
 from richsem_amd.dn import prepare_dn_layout
 from richsem_amd.functions.linear import Lin256Function, VersionCache, pack_linear256
@@ -530,7 +531,7 @@ def run(n_img, dev, steps=5, warmup=2, graph=True, stop_at=None):
                 step(indices, optimize=False)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):      # the stream that was warmed up
+        with quiet_gc(), torch.cuda.graph(g, stream=side):      # the stream that was warmed up
             step(indices, optimize=False)
         g.replay()
         torch.cuda.synchronize()
@@ -631,7 +632,8 @@ def run_graphed(n_img, dev, steps=5, warmup=2, optimizer=True, noise_seed=None, 
             # on, and tests/test_gpu_step.py fails on it)
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
             try:
-                ga, gb = torch.cuda.make_graphed_callables((part_a, part_b), ((images,), sample_b), num_warmup_iters=3, allow_unused_input=True)
+                with quiet_gc():      # (richsem_amd/capture.py: a collection inside a capture aborts the process)
+                    ga, gb = torch.cuda.make_graphed_callables((part_a, part_b), ((images,), sample_b), num_warmup_iters=3, allow_unused_input=True)
             finally:
                 torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(True)
             # the frozen teacher (no gradient, independent of the student) is a HIP graph of its own, replayed BETWEEN the two halves of the
@@ -641,7 +643,7 @@ def run_graphed(n_img, dev, steps=5, warmup=2, optimizer=True, noise_seed=None, 
                 model.teacher_part(images)
             torch.cuda.synchronize()
             teacher_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(teacher_graph, stream=side):
+            with quiet_gc(), torch.cuda.graph(teacher_graph, stream=side):
                 t_static = model.teacher_part(images)
             params = [p for p in model.parameters() if p.requires_grad]
             opt = make_optimizer(params) if optimizer else None

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from richsem_amd import _lib, workload as W
+from richsem_amd.capture import quiet_gc
 from richsem_amd import MultiScaleDeformableAttention as MSDA
 
 pytestmark = pytest.mark.gpu
@@ -36,7 +37,7 @@ def test_calls_can_be_captured_into_a_graph(which):
             _run(t)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with quiet_gc(), torch.cuda.graph(graph):
         out, grads = _run(t)
     out.zero_()
     for x in grads:
@@ -93,7 +94,7 @@ def test_routed_backward_replays_from_a_graph():
                 MSDA.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
+        with quiet_gc(), torch.cuda.graph(graph, stream=side):
             grads = MSDA.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64)
         for rep in range(3):
             for x in grads:

@@ -13,6 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from richsem_amd import workload as W   # noqa: E402
+from richsem_amd.capture import quiet_gc   # noqa: E402
 from richsem_amd.modules import MLP, DeformableTransformerDecoderLayer, TransformerDecoder   # noqa: E402
 
 
@@ -39,7 +40,7 @@ def timeit_graph(fn, reps):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):      # (the warmed stream: the library's workspaces are per stream)
+    with quiet_gc(), torch.cuda.graph(g, stream=side):      # (the warmed stream: the library's workspaces are per stream)
         fn()
     g.replay()
     torch.cuda.synchronize()
