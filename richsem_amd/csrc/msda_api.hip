@@ -488,6 +488,7 @@ hipError_t launch_bwd_rps(const Problem &pb, const TV *value, const float *loc, 
         return hipErrorNotSupported;
     if (reinterpret_cast<uintptr_t>(grad_acc) & 15) return hipErrorNotSupported;
     if ((reinterpret_cast<uintptr_t>(grad_loc) | reinterpret_cast<uintptr_t>(loc)) & 7) return hipErrorNotSupported;
+    if ((int64_t)pb.N * pb.Lq * pb.M * msda::kRpsD * (int64_t)sizeof(TV) > (int64_t)0xFFFFFFFF) return hipErrorNotSupported;      // (the tile kernel addresses grad_out rows by 32-bit byte offsets)
     Workspace ws;
     const size_t n_runs = (size_t)pl.g.nbins * (size_t)pl.g.max_runs;
     if (n_runs * sizeof(uint2) > ((size_t)256 << 20)) return hipErrorNotSupported;      // (run tables of a quarter GB: not a shape this path is for)
@@ -500,7 +501,8 @@ hipError_t launch_bwd_rps(const Problem &pb, const TV *value, const float *loc, 
     pl.g.dummy = reinterpret_cast<float *>(ws.rps_entries + ws.rps_entries_cap);
     pl.g.stamps = msda::tiled_options().stamps;
     pl.g.dbg = msda::tiled_options().dbg;
-    auto kern = pb.P == 4 ? &msda::rps_tile_kernel<true, TV> : &msda::rps_tile_kernel<false, TV>;
+    auto kern = pl.g.stamps ? (pb.P == 4 ? &msda::rps_tile_kernel<true, TV, true> : &msda::rps_tile_kernel<false, TV, true>)
+                            : (pb.P == 4 ? &msda::rps_tile_kernel<true, TV> : &msda::rps_tile_kernel<false, TV>);
     hipError_t e = msda::set_lds_limit(reinterpret_cast<const void *>(kern), sizeof(msda::RpsLds));
     if (e != hipSuccess) return e;
     // route passes: a workgroup (8 waves; 16 where the plan asks for them) per block of queries of an (image, head)
@@ -509,12 +511,22 @@ hipError_t launch_bwd_rps(const Problem &pb, const TV *value, const float *loc, 
     const int64_t r_items = (int64_t)pb.N * pb.M * ((pb.Lq + qpb - 1) / qpb);
     const int route_wgs = pl.g.route_threads > 512 ? 1 : msda::rps_options().route_wgs.load();      // (16 waves at 102 registers: one workgroup per CU)
     const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(r_items, (int64_t)route_wgs * cu_count()));
-    if (pl.g.route_threads > 512)
-        hipLaunchKernelGGL(msda::rps_route_kernel<msda::kRpsRouteThreadsMax>, dim3(rgrid), dim3(msda::kRpsRouteThreadsMax),
-                           (size_t)pl.g.lut_n * sizeof(unsigned), stream, loc, aw, grad_acc, grad_loc, grad_aw, pl.g);
-    else
-        hipLaunchKernelGGL(msda::rps_route_kernel<512>, dim3(rgrid), dim3(512), (size_t)pl.g.lut_n * sizeof(unsigned), stream, loc, aw,
-                           grad_acc, grad_loc, grad_aw, pl.g);
+    {
+        // (the reference's models all have L = P = 4: that instance has both as compile-time constants; the stage stamps live in an
+        // instance of their own)
+        using RouteFn = void (*)(const float *, const float *, float *, float *, float *, const msda::RpsGeom);
+        const bool big = pl.g.route_threads > 512, lp4 = pb.L == 4 && pb.P == 4;
+        RouteFn route;
+        if (pl.g.stamps)
+            route = big ? &msda::rps_route_kernel<msda::kRpsRouteThreadsMax, 0, 0, true>
+                        : (lp4 ? &msda::rps_route_kernel<512, 4, 4, true> : &msda::rps_route_kernel<512, 0, 0, true>);
+        else if (lp4)
+            route = big ? &msda::rps_route_kernel<msda::kRpsRouteThreadsMax, 4, 4> : &msda::rps_route_kernel<512, 4, 4>;
+        else
+            route = big ? &msda::rps_route_kernel<msda::kRpsRouteThreadsMax> : &msda::rps_route_kernel<512>;
+        hipLaunchKernelGGL(route, dim3(rgrid), dim3(pl.g.route_threads), (size_t)pl.g.lut_n * sizeof(unsigned), stream, loc, aw, grad_acc,
+                           grad_loc, grad_aw, pl.g);
+    }
     const int grid = (cu_count() / msda::kXcds) * msda::kXcds;   // persistent: one workgroup per CU (its LDS is most of a CU's)
 #ifdef RPS_ROUTE_ABLATION
     if (pl.g.dbg & 0x300) {      // diagnostic: route-pass ablations -- the records are not what the tile kernel expects; wrong results

@@ -40,11 +40,15 @@
 
 namespace msda {
 
-constexpr int kRpsThreads = 768;               // 12 waves = 3 per SIMD, 168 registers per lane (1024 threads at 128 registers spilled; 512 threads: same speed)
+#ifndef RPS_THREADS
+#define RPS_THREADS 768
+#define RPS_RPL 2
+#endif
+constexpr int kRpsThreads = RPS_THREADS;               // 12 waves = 3 per SIMD, 168 registers per lane (1024 threads at 128 registers spilled; 512 threads: same speed)
 constexpr int kRpsWaves = kRpsThreads / 64;
 constexpr int kRpsMaxPx = 256;                  // pixel grid of a tile (tile + one row / column): bound by LDS (f64 sums + value rows)
 constexpr int kRpsPpq = (kRpsMaxPx + kRpsThreads / 4 - 1) / (kRpsThreads / 4);   // pixels per quad where a quad stands for a pixel
-constexpr int kRpsRpl = 2;                      // records per lane and chunk
+constexpr int kRpsRpl = RPS_RPL;                      // records per lane and chunk
 constexpr int kRpsChunk = kRpsRpl * kRpsThreads;   // sampling points per chunk
 constexpr int kRpsSumStride = 36;               // doubles per pixel of the f64 sums (see RpsLds)
 constexpr int kRpsSegShift = 3;                 // SMALLEST unit of the list walk: 1 << 3 = 8 points (the units' length is RpsOptions::seg_shift, default 4: <= 16 points)
@@ -103,12 +107,15 @@ struct RpsGeom {
                                     // bits 8..9, builds with -DRPS_ROUTE_ABLATION only: route-pass ablations (the tile kernel is not launched): 256 no record stores, 512 4-byte records
 };
 
-struct alignas(16) RpsEnt {   // one sampling point in the list of its base pixel; overwritten by its four corner dots
-    float lh, lw, a;          // bilinear fractions, attention weight
-    int item;                 // (b*Lq + q)*M + m: row of grad_out -- read ahead of the rest (it is all a row request needs)
-};
-struct RpsCoef {
-    float lh, lw, a;
+// One sampling point in the list of its base pixel; overwritten by its four corner dots.  The walk is bound by instruction issue (round 5:
+// ~690 cycles per step of a wave with three waves per SIMD = 3 x ~57 instructions x 4 cycles), so the entry holds what costs a lane the
+// fewest instructions: corner j4 = 2*r + c of a quad's lane weighs the point with (r ? lh : 1 - lh) * (c ? lw : 1 - lw) * a -- one FMA on
+// lh (per-lane constants +-1, 0 / 1) times ONE word the lane picks by address (hwa or lwa) -- and the grad_out row is a 32-bit byte offset
+// added to a scalar base (6 + 3 instructions per point before).
+struct alignas(16) RpsEnt {
+    float lh;                 // fraction along the rows
+    float hwa, lwa;           // (1 - lw) * a, lw * a: the column fraction's two weights times the attention weight
+    unsigned row;             // ((b*Lq + q)*M + m) * D * sizeof(TV): byte offset of the grad_out row -- read ahead of the rest
 };
 
 struct RpsLds {
@@ -156,7 +163,7 @@ __device__ __forceinline__ int rps_wave_scan(int v)
 }
 
 #define RPS_STAMP(i)                                                                   \
-    if (g.stamps && threadIdx.x == 0) {                                                \
+    if (kStamps && g.stamps && threadIdx.x == 0) {                                     \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();                  \
         S->stamp_acc[i] += now_ - S->stamp_last;                                       \
         S->stamp_last = now_;                                                          \
@@ -208,8 +215,15 @@ __device__ __forceinline__ unsigned rps_lut_col(const RpsLevel &v, int c)
 constexpr int kRpsRouteThreadsMax = 1024;
 static_assert(kRpsMaxUnits <= 512, "route pass: one thread per bin of a pair");
 
-template <int kRpsRouteThreads>
-__global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float *__restrict__ loc, const float *__restrict__ aw,
+// kL / kP: the call's levels / points per level as compile-time constants (0: read from the geometry) -- the pass is bound by instruction
+// issue, and with L = P = 4 known the per-level branches, the zero-fills of skipped levels, the divisions by P and a good part of the
+// scalar registers the generic form spills go away (round 5: 1150 -> ~700 instructions per wave and work item).  kStamps: the diagnostic
+// stage stamps (msda_debug_stamps) are compiled into a second instance only.
+template <int kRpsRouteThreads, int kL = 0, int kP = 0, bool kStamps = false>
+#ifndef RPS_ROUTE_OCC
+#define RPS_ROUTE_OCC 4      // waves per SIMD the 8-wave form is compiled for (two workgroups per CU)
+#endif
+__global__ __launch_bounds__(kRpsRouteThreads, kRpsRouteThreads == 512 ? RPS_ROUTE_OCC : 4) void rps_route_kernel(const float *__restrict__ loc, const float *__restrict__ aw,
                                                                      float *__restrict__ grad_value, float *__restrict__ grad_loc,
                                                                      float *__restrict__ grad_aw, const RpsGeom g)
 {
@@ -219,12 +233,13 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
     extern __shared__ unsigned rps_lut[];      // [g.lut_n]: row tables, then column tables, of the levels (offsets g.lut_r / g.lut_c)
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int B = g.bins_per_pair;
+    const int L = kL ? kL : g.L;
     {
         const int gtid = blockIdx.x * blockDim.x + tid, gsz = gridDim.x * blockDim.x;
         if (gtid < 8) g.ctr[gtid] = 0u;
         if (tid < kWave) sink[tid] = 0u;
         const int row4 = g.M * kRpsD / 4;   // float4 per pixel
-        for (int l = 0; l < g.L; ++l) {
+        for (int l = 0; l < L; ++l) {
             const RpsLevel &v = g.lv[l];
             for (int i = tid; i <= v.H; i += kRpsRouteThreads) rps_lut[g.lut_r[l] + i] = rps_lut_row(v, i);
             for (int i = tid; i <= v.W; i += kRpsRouteThreads) rps_lut[g.lut_c[l] + i] = rps_lut_col(v, i);
@@ -256,7 +271,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
             }
         }
     }
-    const int P = g.P, LP = g.L * g.P;
+    const int P = kP ? kP : g.P, LP = L * P;
     const int qpw = P <= 4 ? 16 : (P <= 8 ? 8 : (P <= 16 ? 4 : (P <= 32 ? 2 : 1)));   // queries per wave: qpw * P <= 64 lanes
     const int ql = lane / P, pp = lane - ql * P;
     const int qpb = qpw * (kRpsRouteThreads / kWave);   // queries per workgroup item
@@ -265,9 +280,9 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
     const int n_items = pairs * qblocks;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // (diagnostic, msda_debug_stamps: shader cycles of thread 0 per stage, rows 1024 + blockIdx.x of the stamp buffer)
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = g.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = kStamps && g.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
 #define RPS_RSTAMP(i)                                                  \
-    if (g.stamps) {                                                    \
+    if (kStamps && g.stamps) {                                         \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
         st_acc[i] += now_ - st_last;                                   \
         st_last = now_;                                                \
@@ -278,32 +293,40 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
     // (their registers are free then), and every stage issues the LDS operations of all four levels before it waits for any of them:
     // lanes that have nothing to count add zero to a word of their own (`sink`) instead of branching around the atomic.
     float2 xy[kRpsMaxL];
-    auto item_point = [&](int item_, bool &live_, int &q_) {      // -> index of the lane's point at level 0
-        const int it_ = min(item_, n_items - 1);
-        const int pair_ = it_ % pairs, qb_ = it_ / pairs;
+    // (work item i = query block * pairs + pair; the items of a workgroup are gridDim.x apart: (pair, block) advance by a constant step,
+    // without a division per item.  A queue instead -- items drawn one ahead with an atomic, tried in round 5 because the slowest workgroups
+    // end 10-15 % after the median -- cost more than the tail: 47 -> 57 us, the wait for the returning draw sits in every item's first stage)
+    const int step_pair = (int)(gridDim.x % (unsigned)pairs), step_qb = (int)(gridDim.x / (unsigned)pairs);
+    auto item_point = [&](int item_, int pair_, int qb_, bool &live_, int &q_) {      // -> index of the lane's point at level 0
         const int b_ = pair_ / g.M, m_ = pair_ - b_ * g.M;
         q_ = qb_ * qpb + wave * qpw + ql;
         live_ = item_ < n_items && ql < qpw && pp < P && q_ < g.Lq;
         return (unsigned)(((b_ * g.Lq + (live_ ? q_ : 0)) * g.M + m_) * LP + min(pp, P - 1));      // (a valid index whatever the lane)
     };
     // (loads are unconditional, from clamped addresses: hipcc waits for a conditional load right behind it; `live` masks the result)
-    auto request_xy = [&](int item_) {
+    auto request_xy = [&](int item_, int pair_, int qb_) {
         bool live_;
         int q_;
-        const unsigned pt0_ = item_point(item_, live_, q_);
+        const unsigned pt0_ = item_point(item_, pair_, qb_, live_, q_);
 #pragma unroll
-        for (int l = 0; l < kRpsMaxL; ++l) xy[l] = *reinterpret_cast<const float2 *>(loc + 2u * (pt0_ + (unsigned)(min(l, g.L - 1) * P)));
+        for (int l = 0; l < kRpsMaxL; ++l) xy[l] = *reinterpret_cast<const float2 *>(loc + 2u * (pt0_ + (unsigned)(min(l, L - 1) * P)));
     };
-    request_xy(blockIdx.x);
+    int pair = (int)(blockIdx.x % (unsigned)pairs), qb = (int)(blockIdx.x / (unsigned)pairs);
+    request_xy(blockIdx.x, pair, qb);
     unsigned long long p_old = 0ull;      // the previous work item's announce (see stage D)
     unsigned p_first = 0u, p_cnt = 0u;
     size_t p_gb = 0;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {   // (uniform)
-        const int pair = item % pairs, qb = item / pairs;               // neighbouring workgroups: different pairs (different bins)
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {   // (uniform; neighbouring workgroups: different pairs = different bins)
         for (int i = tid; i < B; i += kRpsRouteThreads) hist[i] = 0u;
         bool live;
         int q;
-        const unsigned pt0 = item_point(item, live, q);
+        const unsigned pt0 = item_point(item, pair, qb, live, q);
+        int n_pair = pair + step_pair, n_qb = qb + step_qb;      // the next item of this workgroup
+        if (n_pair >= pairs) {
+            n_pair -= pairs;
+            ++n_qb;
+        }
+        n_qb = min(n_qb, qblocks - 1);      // (past the table: a valid address, the lanes are not live)
         __syncthreads();      // (the first item: the tables as well)
         RPS_RSTAMP(1)
         // ---- A: ranks inside the workgroup ---------------------------------------------------------------------------------------
@@ -320,7 +343,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         for (int l = 0; l < kRpsMaxL; ++l) {
             lh[l] = lw[l] = 0.f;
             re[l] = ce[l] = 0u;
-            if (l >= g.L) continue;   // (uniform)
+            if (l >= L) continue;   // (uniform)
             const RpsLevel &v = g.lv[l];
             const float Hf = (float)v.H, Wf = (float)v.W;
             const float h_im = xy[l].y * Hf - 0.5f, w_im = xy[l].x * Wf - 0.5f;
@@ -336,10 +359,10 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         // (xy is consumed: the weights of this item -- needed by the record stores of stage C only -- and the next item's locations
         // travel under the rest of this one; no other memory operation sits in a branch between here and stage C, so that the waits
         // for them are counted and never drain the queue)
-        request_xy(item + (int)gridDim.x);
+        request_xy(item + (int)gridDim.x, n_pair, n_qb);
         float at[kRpsMaxL];
 #pragma unroll
-        for (int l = 0; l < kRpsMaxL; ++l) at[l] = aw[pt0 + (unsigned)(min(l, g.L - 1) * P)];
+        for (int l = 0; l < kRpsMaxL; ++l) at[l] = aw[pt0 + (unsigned)(min(l, L - 1) * P)];
         // A.2: owner bins.  Lanes of a wave usually share the owner bin (neighbouring queries, neighbouring points): they are matched
         //      with one ballot and served by the atomic of one of them; the others take one each.
         int ob[kRpsMaxL], lead[kRpsMaxL], lb[kRpsMaxL];
@@ -352,7 +375,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
             own_rank[l] = lt_cnt[l] = n_match[l] = 0u;
             inmap[l] = 0u;
             word[l] = ~0u;
-            if (l >= g.L) continue;   // (uniform)
+            if (l >= L) continue;   // (uniform)
             const RpsLevel &v = g.lv[l];
             const int ns = v.nslab;
             const int slab = ns > 1 ? rps_uni(qb % ns) : 0;
@@ -379,7 +402,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         //      stay with this tile: its window has an apron row / column for them, flushed with atomics -- no second record.)
 #pragma unroll
         for (int l = 0; l < kRpsMaxL; ++l) {
-            if (l >= g.L) continue;   // (uniform)
+            if (l >= L) continue;   // (uniform)
             const unsigned gr = re[l] & 31u, gc = ce[l] & 31u;
             if (!(asked_m >> l & 1u)) own_rank[l] = lt_cnt[l];      // + the leader's result, below
             if (ob[l] >= 0) word[l] = (unsigned)ob[l] | (gr * ((ce[l] >> 17) & 31u) + gc) << 23;
@@ -402,7 +425,7 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         // ---- C: entries to their slots ------------------------------------------------------------------------------------------
 #pragma unroll
         for (int l = 0; l < kRpsMaxL; ++l) {
-            if (l >= g.L) continue;
+            if (l >= L) continue;
             unsigned r = own_rank[l];
             const unsigned rl = (unsigned)__builtin_amdgcn_readlane((int)r, lead[l]);
             if ((matched_m >> l & 1u) && lane != lead[l]) r += rl;
@@ -455,12 +478,14 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
         p_first = first;
         p_cnt = cnt;
         p_gb = gb;
+        pair = n_pair;
+        qb = n_qb;
         RPS_RSTAMP(6)
         __syncthreads();   // hist / base are reused by the next item
         RPS_RSTAMP(7)
     }
     if (p_cnt) g.runs[p_gb * (size_t)g.max_runs + (size_t)min((unsigned)(p_old >> 32), (unsigned)g.max_runs - 1u)] = make_uint2(p_first, (unsigned)p_old);
-    if (g.stamps && tid == 0)
+    if (kStamps && g.stamps && tid == 0)
         for (int i = 0; i < 8; ++i) g.stamps[(size_t)(1024 + blockIdx.x) * 16 + i] = st_acc[i];
 #undef RPS_RSTAMP
 }
@@ -468,16 +493,16 @@ __global__ __launch_bounds__(kRpsRouteThreads) void rps_route_kernel(const float
 typedef float rps_v2f __attribute__((ext_vector_type(2)));
 typedef float rps_v4f __attribute__((ext_vector_type(4)));
 
-// Lane j of a quad ends up with the quad's sum of d[j] (j = 0..3): two exchange steps in which every lane keeps the half
-// of the values it is responsible for and hands the other half to its partner (9 instructions instead of 4 x 2 + selects).
-__device__ __forceinline__ float rps_quad_transpose_sum(float d0, float d1, float d2, float d3, int j4)
+// Lane j of a quad ends up with the quad's sum over its four lanes of "corner j's value" (j = 0..3), where every lane passes ITS values
+// in the order x[r] = value of corner r ^ j: two exchange steps -- with lane ^ 1, then lane ^ 2 -- in which a lane keeps the half it is
+// responsible for and takes the matching half of its partner: with the rotated order those are the same REGISTERS in every lane, so the
+// steps are three DPP adds and no selects (rounds 3-4 kept corner r in register r: six selects per point on top, a fifth of the walk's
+// vector instructions once the rest had shrunk).  The caller arranges the rotation where it is free: which value row a register holds.
+__device__ __forceinline__ float rps_quad_rotated_sum(float x0, float x1, float x2, float x3)
 {
-    const bool b0 = j4 & 1, b1 = j4 & 2;
-    const float keep_a = b0 ? d1 : d0, keep_b = b0 ? d3 : d2, send_a = b0 ? d0 : d1, send_b = b0 ? d2 : d3;
-    const float ra = keep_a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send_a), 0xB1, 0xF, 0xF, true));   // lane ^ 1
-    const float rb = keep_b + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send_b), 0xB1, 0xF, 0xF, true));
-    const float keep = b1 ? rb : ra, send = b1 ? ra : rb;
-    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xF, 0xF, true));                  // lane ^ 2
+    const float ra = x0 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x1), 0xB1, 0xF, 0xF, true));   // lane ^ 1: its x1 is corner j
+    const float rb = x2 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x3), 0xB1, 0xF, 0xF, true));   //           its x3 is corner j ^ 2
+    return ra + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(rb), 0x4E, 0xF, 0xF, true));             // lane ^ 2: its rb is corner j
 }
 
 // A lane's 8 channels of a grad_out row as they travel from memory: fp32 as two float4, bf16 as two packed 8-byte words that are
@@ -487,10 +512,11 @@ struct RpsRow;
 template <>
 struct RpsRow<float> {
     float4 a, b;
-    __device__ __forceinline__ void load(const float *row, int c_lo, int c_hi)
+    // (the lane's two 16-B pieces of the row at byte offset `off` -- lane offset included -- from the uniform base: one 32-bit add per point)
+    __device__ __forceinline__ void load(const float *base, unsigned off)
     {
-        a = *reinterpret_cast<const float4 *>(row + c_lo);
-        b = *reinterpret_cast<const float4 *>(row + c_hi);
+        a = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + off);
+        b = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + off + 64u);
     }
     __device__ __forceinline__ void unpack(rps_v2f (&gq)[4]) const
     {
@@ -501,10 +527,10 @@ struct RpsRow<float> {
 template <>
 struct RpsRow<bf16_t> {
     uint2 a, b;
-    __device__ __forceinline__ void load(const bf16_t *row, int c_lo, int c_hi)
+    __device__ __forceinline__ void load(const bf16_t *base, unsigned off)
     {
-        a = *reinterpret_cast<const uint2 *>(row + c_lo);
-        b = *reinterpret_cast<const uint2 *>(row + c_hi);
+        a = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(base) + off);
+        b = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(base) + off + 32u);
     }
     __device__ __forceinline__ void unpack(rps_v2f (&gq)[4]) const
     {
@@ -532,7 +558,8 @@ struct RpsRow<bf16_t> {
 // TV: storage type of value / grad_out / grad_value (float, or bf16_t with fp32 arithmetic).  grad_acc: where the levels whose
 // tiles are shared by several workgroups are accumulated with fp32 atomics -- grad_value itself for TV = float, an fp32 scratch
 // image of it for bf16 (rounded by rps_round_kernel afterwards).
-template <bool P4, typename TV = float>
+// kStamps: the diagnostic stage stamps (msda_debug_stamps) are compiled into a second instance only
+template <bool P4, typename TV = float, bool kStamps = false>
 __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kernel(
     const TV *__restrict__ value, const TV *__restrict__ grad_out, TV *__restrict__ grad_value, float *__restrict__ grad_acc,
     float *__restrict__ grad_loc, float *__restrict__ grad_aw, const RpsGeom g)
@@ -545,6 +572,10 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
     // this lane's 8 channels: [c_lo, c_lo + 4) and [c_hi, c_hi + 4) -- so that each of a lane's two 16-B accesses to a 128-B
     // row forms, with the other three lanes of its quad, 64 contiguous bytes
     const int c_lo = 4 * j4, c_hi = 16 + 4 * j4;
+    // the walk's per-lane constants (see RpsEnt): corner j4 = 2 * r + c of the quad's lane
+    const float w_ys = (j4 & 2) ? 1.f : -1.f, w_yc = (j4 & 2) ? 0.f : 1.f;      // (r ? lh : 1 - lh) = w_ys * lh + w_yc
+    const unsigned w_xoff = (j4 & 1) ? 8u : 4u;                                  // lwa : hwa
+    const unsigned lane_row = (unsigned)(c_lo * sizeof(TV));
     const int P = P4 ? 4 : g.P;
     const int LP = g.L * P;
     const int row_elems = g.M * kRpsD;
@@ -552,7 +583,7 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
     const int xq = blockIdx.x & (kXcds - 1);   // blocks equal mod 8 share an XCD (observed; speed only)
     const int n_items = g.nunits * g.ppx;
     float *const dummy_w = g.dummy + (size_t)(blockIdx.x & (kRpsDummyWgs - 1)) * 256;   // this workgroup's 1 KB of scratch
-    if (g.stamps && tid == 0) {
+    if (kStamps && g.stamps && tid == 0) {
         for (int i = 0; i < 14; ++i) S->stamp_acc[i] = 0;
         S->stamp_last = __builtin_amdgcn_s_memtime();
     }
@@ -825,7 +856,8 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                     const int e = pos[u] + S->offs[pbase[u]];
                     const unsigned qp = n_rec[u].code & ((1u << kRpsQpBits) - 1u);
                     const int q = P4 ? (int)(qp >> 2) : (int)(qp / (unsigned)P);
-                    S->ent[e] = RpsEnt{n_rec[u].lh, n_rec[u].lw, n_rec[u].a, (bq0 + q) * g.M + m};
+                    const float lwa = n_rec[u].lw * n_rec[u].a;
+                    S->ent[e] = RpsEnt{n_rec[u].lh, (1.f - n_rec[u].lw) * n_rec[u].a, lwa, (unsigned)((bq0 + q) * g.M + m) * (unsigned)(kRpsD * sizeof(TV))};
                     S->slot[u * kRpsThreads + tid] = (unsigned short)e;
                 }
             __syncthreads();
@@ -836,7 +868,7 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
             const int n_segs = rps_uni(S->n_segs);
             for (int u0 = wave * 16; u0 < n_segs; u0 += kRpsWaves * 16) {   // (uniform)
                 unsigned long long wt0 = 0, wt1 = 0, wt2 = 0;      // (diagnostic: wave 0's time in a group's set-up / point loop / epilogue)
-                if (g.stamps && tid == 0) wt0 = __builtin_amdgcn_s_memtime();
+                if (kStamps && g.stamps && tid == 0) wt0 = __builtin_amdgcn_s_memtime();
                 const int un = u0 + (lane >> 2);
                 if (un < n_segs) {
                     const unsigned sc = S->seg[un];
@@ -847,14 +879,22 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                     // the grid lies outside the map or belongs to a point this tile does not form gradients for)
                     const int lr = my_p / gw, lc = my_p - lr * gw;
                     const int r0 = max(lr - 1, 0) * gw, c0 = max(lc - 1, 0);
+                    // (register set r of lane j4 holds corner r ^ j4 -- see rps_quad_rotated_sum --: the rotation is address arithmetic here,
+                    // a per-lane choice between "this row / column" and "the other one")
                     rps_v2f v[4][4];
+                    {
+                        const int row_hi = lr * gw - r0, col_hi = lc - c0;                    // corner bit set: lower row / right column
+                        const int row_same = (j4 & 2) ? row_hi : 0, row_flip = row_hi - row_same;   // bit 1 of r ^ j4 for r = 0, 1 / r = 2, 3
+                        const int col_same = (j4 & 1) ? col_hi : 0, col_flip = col_hi - col_same;   // bit 0 of r ^ j4 for r even / odd
+                        const float *const v00 = vt + (r0 + c0) * kRpsD;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int vp = (k < 2 ? r0 : lr * gw) + ((k & 1) ? lc : c0);
-                        const float4 a0 = *reinterpret_cast<const float4 *>(vt + vp * kRpsD + c_lo);
-                        const float4 a1 = *reinterpret_cast<const float4 *>(vt + vp * kRpsD + c_hi);
-                        v[k][0] = (rps_v2f){a0.x, a0.y}; v[k][1] = (rps_v2f){a0.z, a0.w};
-                        v[k][2] = (rps_v2f){a1.x, a1.y}; v[k][3] = (rps_v2f){a1.z, a1.w};
+                        for (int r = 0; r < 4; ++r) {
+                            const float *const src = v00 + (((r & 2) ? row_flip : row_same) + ((r & 1) ? col_flip : col_same)) * kRpsD;
+                            const float4 a0 = *reinterpret_cast<const float4 *>(src + c_lo);
+                            const float4 a1 = *reinterpret_cast<const float4 *>(src + c_hi);
+                            v[r][0] = (rps_v2f){a0.x, a0.y}; v[r][1] = (rps_v2f){a0.z, a0.w};
+                            v[r][2] = (rps_v2f){a1.x, a1.y}; v[r][3] = (rps_v2f){a1.z, a1.w};
+                        }
                     }
                     // partial sums: macc[m][k] = corner k, this lane's channel m (of its 8).  They are formed on the MATRIX pipe (round 4):
                     // v_mfma_f32_4x4x1 is sixteen 4 x 4 outer products, one per quad -- A = the four corner weights (lane k of the quad
@@ -863,9 +903,9 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                     rps_v4f macc[8];
 #pragma unroll
                     for (int m_ = 0; m_ < 8; ++m_) macc[m_] = (rps_v4f){0.f, 0.f, 0.f, 0.f};
-#define RPS_POINT(EN, ROW, E)                                                                                                    \
+#define RPS_POINT(ROW, CF, EP)                                                                                                   \
     {                                                                                                                            \
-        const float wj = ((j4 & 2) ? EN.lh : 1.f - EN.lh) * ((j4 & 1) ? EN.lw : 1.f - EN.lw) * EN.a;                             \
+        const float wj = __builtin_fmaf(w_ys, CF.x, w_yc) * CF.y;                                                                \
         rps_v2f gq[4];                                                                                                           \
         ROW.unpack(gq);                                                                                                          \
         _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                            \
@@ -880,43 +920,65 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
             t += gq[1] * v[k][1];                                                                                                \
             t += gq[2] * v[k][2];                                                                                                \
             t += gq[3] * v[k][3];                                                                                                \
-            d[k] = t.x + t.y;                                                                                                    \
+            d[k] = t.x + t.y;      /* this lane's part of corner k ^ j4's dot */                                               \
         }                                                                                                                        \
         /* lane k of the quad writes dot k over the entry (all four lanes have read it) */                                       \
-        reinterpret_cast<float *>(S->ent + (E))[j4] = rps_quad_transpose_sum(d[0], d[1], d[2], d[3], j4);                        \
+        *RPS_LDS(float, (EP) + 4u * (unsigned)j4) = rps_quad_rotated_sum(d[0], d[1], d[2], d[3]);                                \
     }
-                    // software pipeline: while point e is reduced, the grad_out row of point e + 1 is in flight and the row index
+                    // software pipeline: while point e is reduced, the grad_out row of point e + 1 is in flight and the row offset
                     // of point e + 2 is being read (the chain entry -> row address -> row is what a walk waits for).  Only the
-                    // row index is read ahead; fractions and weight are read when the point is reduced (registers).
-#define RPS_ROW(ITEM, ROW) ROW.load(grad_out + (int64_t)(ITEM) * kRpsD, c_lo, c_hi);
-#define RPS_COEF(E) (*reinterpret_cast<const RpsCoef *>(S->ent + (E)))
-                    const int e_last = e1 - 1;
-                    int itA = S->ent[e].item, itB = S->ent[min(e + 1, e_last)].item;
+                    // row offset is read ahead; the weight's two words are read when the point is reduced (registers).
+                    // (entries are addressed by BYTE offset into the chunk's entry array: one add per two points)
+#if defined(RPS_WALK_ABLATE) && RPS_WALK_ABLATE == 1      // (diagnostic: no row requests at all -- wrong results)
+#define RPS_ROW(OFF, ROW) asm volatile("" : "+v"(ROW.a.x), "+v"(ROW.a.y), "+v"(ROW.b.x), "+v"(ROW.b.y), "+v"(OFF));
+#elif defined(RPS_WALK_ABLATE) && RPS_WALK_ABLATE == 2    // (diagnostic: every request hits one of 64 rows -- wrong results)
+#define RPS_ROW(OFF, ROW) ROW.load(grad_out, ((OFF) & 0x1F80u) + lane_row);
+#else
+#define RPS_ROW(OFF, ROW) ROW.load(grad_out, (OFF) + lane_row);
+#endif
+#define RPS_OFF(EP) (*RPS_LDS(const unsigned, (EP) + 12u))
+                    // (ep = LDS ADDRESS of the entry: the array's base is added once, behind an opaque asm -- derived from the symbol inside
+                    // the loop, every address costs an extra add of the "+ 0" the LDS layout pass leaves behind)
+#define RPS_LDS(T, A) (reinterpret_cast<__attribute__((address_space(3))) T *>((size_t)(A)))
+                    unsigned ent_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)(S->ent);
+                    asm volatile("" : "+v"(ent_lds));
+                    unsigned ep = ent_lds + (unsigned)e * 16u;
+                    const unsigned ep_end = ent_lds + (unsigned)e1 * 16u, ep_last = ep_end - 16u;
+                    if (kStamps && g.stamps && wave == 0) {      // (diagnostic: the longest unit of wave 0's group = the steps its point loop takes)
+                        int len = e1 - e;
+                        for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o));
+                        if (tid == 0) S->stamp_acc[13] += (unsigned long long)len;
+                    }
+                    // (a point's two weight words -- RPS_CF -- are read one iteration ahead as well: with the loop no longer bound by instruction
+                    // issue, the two LDS round trips in front of a point's first MFMA were on its critical path.  A ring of THREE rows -- a
+                    // row requested two steps ahead -- was tried in round 5 and gained nothing, with or without scheduling barriers: the steps
+                    // do not wait for one row's latency but for the CU's vector-memory pipe, see profiles/r05_routed_experiments.md)
+#define RPS_CF(EP) make_float2(*RPS_LDS(const float, EP), *RPS_LDS(const float, (EP) + w_xoff))
+                    unsigned offA = RPS_OFF(ep), offB = RPS_OFF(min(ep + 16u, ep_last));
+                    float2 cA = RPS_CF(ep), cB = RPS_CF(min(ep + 16u, ep_last));
                     RpsRow<TV> gA, gB;
-                    RPS_ROW(itA, gA)
-                    if (g.stamps && tid == 0) wt1 = __builtin_amdgcn_s_memtime();
-                    for (; e + 1 < e1; e += 2) {
-                        RPS_ROW(itB, gB)
-                        itA = S->ent[min(e + 2, e_last)].item;
-                        {
-                            const RpsCoef en = RPS_COEF(e);
-                            RPS_POINT(en, gA, e)
-                        }
-                        RPS_ROW(itA, gA)
-                        itB = S->ent[min(e + 3, e_last)].item;
-                        {
-                            const RpsCoef en = RPS_COEF(e + 1);
-                            RPS_POINT(en, gB, e + 1)
-                        }
+                    RPS_ROW(offA, gA)
+                    if (kStamps && g.stamps && tid == 0) wt1 = __builtin_amdgcn_s_memtime();
+                    for (; ep + 16u < ep_end; ep += 32u) {
+                        RPS_ROW(offB, gB)
+                        const unsigned nA = min(ep + 32u, ep_last), nB = min(ep + 48u, ep_last);
+                        offA = RPS_OFF(nA);
+                        const float2 cA2 = RPS_CF(nA);
+                        RPS_POINT(gA, cA, ep)
+                        RPS_ROW(offA, gA)
+                        offB = RPS_OFF(nB);
+                        const float2 cB2 = RPS_CF(nB);
+                        RPS_POINT(gB, cB, ep + 16u)
+                        cA = cA2;
+                        cB = cB2;
                     }
-                    if (e < e1) {
-                        const RpsCoef en = RPS_COEF(e);
-                        RPS_POINT(en, gA, e)
-                    }
-#undef RPS_COEF
+                    if (ep < ep_end) RPS_POINT(gA, cA, ep)
+#undef RPS_CF
+#undef RPS_LDS
+#undef RPS_OFF
 #undef RPS_ROW
 #undef RPS_POINT
-                    if (g.stamps && tid == 0) wt2 = __builtin_amdgcn_s_memtime();
+                    if (kStamps && g.stamps && tid == 0) wt2 = __builtin_amdgcn_s_memtime();
                     // the unit's partial sums to the tile's f64 sums: corner k of base pixel p is pixel p-gw-1 / p-gw / p-1 / p of
                     // the pixel grid, where that pixel exists (else it lies outside the map or in the tile above / to the left)
 #pragma unroll
@@ -925,11 +987,17 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
                         if (ok) {
                             double *dst = S->sum + (my_p - (k < 2 ? gw : 0) - ((k & 1) ? 0 : 1)) * kRpsSumStride + j4;
 #pragma unroll
+#if defined(RPS_EPI_ABLATE) && RPS_EPI_ABLATE == 1      // (diagnostic: no f64 atomics -- wrong results; the sums are kept alive by one plain store)
+                            for (int m_ = 0; m_ < 1; ++m_) *reinterpret_cast<float *>(dst) = macc[0][k] + macc[1][k] + macc[2][k] + macc[3][k] + macc[4][k] + macc[5][k] + macc[6][k] + macc[7][k];
+#elif defined(RPS_EPI_ABLATE) && RPS_EPI_ABLATE == 2    // (diagnostic: plain f64 read-modify-write instead of atomics -- racy, wrong results)
+                            for (int m_ = 0; m_ < 8; ++m_) dst[4 * m_] += (double)macc[m_][k];
+#else
                             for (int m_ = 0; m_ < 8; ++m_) atomicAdd(dst + 4 * m_, (double)macc[m_][k]);
+#endif
                         }
                     }
                 }
-                if (g.stamps && tid == 0 && wt1) {
+                if (kStamps && g.stamps && tid == 0 && wt1) {
                     const unsigned long long wt3 = __builtin_amdgcn_s_memtime();
                     S->stamp_acc[9] += wt1 - wt0;
                     S->stamp_acc[10] += wt2 - wt1;
@@ -1059,7 +1127,7 @@ __global__ __launch_bounds__(kRpsThreads, kRpsThreads / 256) void rps_tile_kerne
         it = nit;
         par ^= 1;
     }
-    if (g.stamps && tid == 0) {
+    if (kStamps && g.stamps && tid == 0) {
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();
         S->stamp_acc[8] += now_ - S->stamp_last;   // waiting at the empty queue
         for (int i = 0; i < 14; ++i) g.stamps[(size_t)blockIdx.x * 16 + i] = S->stamp_acc[i];

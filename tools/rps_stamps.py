@@ -53,6 +53,9 @@ def main():
     if ng > 0:
         print(f"  wave 0 inside the walk: {ng:.0f} groups per workgroup; per group: set-up (unit, value rows, first row request) {s[:, 9].mean() / ng:.0f}, "
               f"point loop {s[:, 10].mean() / ng:.0f}, f64 epilogue {s[:, 11].mean() / ng:.0f} cycles")
+        steps = s[:, 13].mean()
+        if steps > 0:
+            print(f"  wave 0's groups: {steps / ng:.1f} points in the longest unit on average -> {s[:, 10].mean() / steps:.0f} cycles per step of the point loop")
 
 
 if __name__ == "__main__":
