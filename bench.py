@@ -56,14 +56,15 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 # what the library's profile records call "variant" -> the HIP kernels behind a call
 HIP_KERNELS = {
     ("fwd", 1): "fwd_direct_kernel",
-    ("bwd", 1): "bwd_levelsum_kernel + bwd_direct_kernel",
+    ("bwd", 1): "bwd_levelsum_kernel + bwd_split_kernel",      # (small calls; bwd_direct_kernel instead of the split kernel for large ones)
     ("fwd", 2): "tiled_gather_kernel",
+    ("fwd", 3): "fwd_split_kernel",
     ("bwd", 4): "rps_route_kernel + rps_tile_kernel",
     ("bwd", 5): "bwd_band_kernel",
     ("fwd", 5): "fwd_direct_prep_kernel",
     ("fwd", 6): "tiled_gather_kernel (raw projection in)",
 }
-VARIANT_NAMES = {1: "direct", 2: "tiled", 4: "routed", 5: "band", 6: "tiled_prep"}
+VARIANT_NAMES = {1: "direct", 2: "tiled", 3: "split", 4: "routed", 5: "band", 6: "tiled_prep"}
 
 
 def parse_args(argv=None):

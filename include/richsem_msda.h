@@ -78,7 +78,9 @@ int msda_abi_version(void);
 const char *msda_last_error(void);
 
 /* Tuning / test hooks.  Keys:
- *   "fwd_variant"     0 = auto, 1 = direct gather kernel, 2 = LDS-window kernel (when applicable)
+ *   "fwd_variant"     0 = auto, 1 = direct gather kernel, 2 = LDS-window kernel (when applicable), 3 = split kernel (32 lanes per
+ *                     (query, head), all gathers of a lane in flight at once: D = 32, L*P a multiple of 4 up to 32; automatic for
+ *                     fp32 calls of fewer than 65536 (query, head) items: decoder-shaped calls)
  *   "bwd_variant"     0 = auto, 1 = direct kernel (level-sum windows / row atomics), 4 = routed pixel-stationary kernels
  *                     (sampling points routed to output tiles in ONE pass -- every query block lays its records out in a stretch of
  *                     its own and announces them to the tiles' bins --, then one workgroup per tile: every pixel of grad_value

@@ -60,7 +60,7 @@ int hip_fail(hipError_t e, const char *what)
     return (int)e;
 }
 
-std::atomic<int> g_fwd_variant{0}, g_bwd_variant{0}, g_bwd_cpl{0}, g_levelsum{1}, g_fwd_prep_fused{1};
+std::atomic<int> g_fwd_variant{0}, g_bwd_variant{0}, g_bwd_cpl{0}, g_levelsum{1}, g_fwd_prep_fused{1}, g_bwd_split{1};
 thread_local int g_tl_fwd_variant = -1;      // >= 0: the forward variant of THIS call (set by a caller inside the library that has already chosen)
 
 // ---- launch profiler: pre-created event pairs, one per logged call -----------------------------
@@ -597,6 +597,38 @@ hipError_t try_bwd_rps<float>(const Problem &pb, const float *value, const float
     return launch_bwd_rps<float>(pb, value, loc, aw, grad_out, grad_value, grad_value, grad_loc, grad_aw, stream);
 }
 
+// The split kernels (msda_direct.h: fwd_split_kernel / bwd_split_kernel) apply at D = 32 with 16-byte (fp32) / 8-byte (bf16) rows, L*P a
+// multiple of 4 up to 32; they are the automatic choice for calls of fewer than 65536 (query, head) items.
+inline bool split_fits(const Problem &pb, int C) { return pb.D == 32 && C == 4 && (pb.L * pb.P) % msda::kSplitGroups == 0 && pb.L * pb.P / msda::kSplitGroups <= msda::kSplitMaxPts; }
+inline bool split_small(const Problem &pb) { return (int64_t)pb.N * pb.Lq * pb.M < 65536; }
+inline dim3 split_grid(const Problem &pb) { return dim3((unsigned)(((int64_t)pb.N * pb.Lq * pb.M * 32 + msda::kDirectThreads - 1) / msda::kDirectThreads)); }
+
+template <typename TV>
+hipError_t launch_fwd_split(const Problem &pb, const TV *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *aw,
+                            TV *out, const msda::DirectGeom &g, hipStream_t stream)
+{
+    const size_t lds = sizeof(msda::LevelGeom) * pb.L;
+    if (pb.L * pb.P == 16)
+        hipLaunchKernelGGL((msda::fwd_split_kernel<TV, 4>), split_grid(pb), dim3(msda::kDirectThreads), lds, stream, value, shapes, lsi, loc, aw, out, g);
+    else
+        hipLaunchKernelGGL((msda::fwd_split_kernel<TV, 0>), split_grid(pb), dim3(msda::kDirectThreads), lds, stream, value, shapes, lsi, loc, aw, out, g);
+    return hipGetLastError();
+}
+
+template <typename TV>
+hipError_t launch_bwd_split(const Problem &pb, const TV *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *aw,
+                            const TV *grad_out, float *grad_loc, float *grad_aw, const msda::DirectGeom &g, hipStream_t stream)
+{
+    const size_t lds = sizeof(msda::LevelGeom) * pb.L;
+    if (pb.L * pb.P == 16)
+        hipLaunchKernelGGL((msda::bwd_split_kernel<TV, 4>), split_grid(pb), dim3(msda::kDirectThreads), lds, stream, value, shapes, lsi, loc, aw,
+                           grad_out, grad_loc, grad_aw, g);
+    else
+        hipLaunchKernelGGL((msda::bwd_split_kernel<TV, 0>), split_grid(pb), dim3(msda::kDirectThreads), lds, stream, value, shapes, lsi, loc, aw,
+                           grad_out, grad_loc, grad_aw, g);
+    return hipGetLastError();
+}
+
 template <typename T>
 int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc, const T *aw, int N, int S,
                  int M, int D, int L, int Lq, int P, int im2col_step, T *out, const int64_t *shapes_host,
@@ -636,6 +668,16 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
     const int C = pick_channels_per_lane<T>(D, {value, out});
     msda::DirectGeom g = direct_geom(pb, C);
     g.head_major = (msda::tiled_options().dbg & 128) ? 1 : 0;      // (measured experiment: value read as (N, M, S, D))
+    // small fp32 calls at D = 32 (decoder-shaped): 32 lanes per item, all of a lane's gathers in flight at once (fwd_split_kernel);
+    // fwd_variant 3 forces it wherever it applies, 1 keeps the 8-lane kernel
+    if constexpr (std::is_same<T, float>::value) {
+        if (split_fits(pb, C) && !g.head_major && (variant == 3 || (variant != 1 && split_small(pb)))) {
+            ProfileScope prof(0, 3, (int)sizeof(T), N, S, M, D, L, Lq, P, stream);
+            const hipError_t e = launch_fwd_split<float>(pb, value, shapes, lsi, loc, aw, out, g, stream);
+            if (e != hipSuccess) return hip_fail(e, "launch of the split forward kernel");
+            return MSDA_OK;
+        }
+    }
     const size_t lds = msda::direct_lds_bytes<T>(g);
     if (lds > 64 * 1024) return fail(MSDA_ERR_BAD_DIMS, "too many levels (L=%d) for the level table in LDS", L);
     const dim3 grid(direct_grid(g)), block(msda::kDirectThreads);
@@ -728,6 +770,14 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         // more than the overlap gains on a 90 us call -- 113 vs 96 us)
         e = launch_levelsum<T>(pb, loc, aw, grad_out, grad_value, stream, g.gv_skip);
         if (e != hipSuccess) return hip_fail(e, "launch of the level-sum backward kernel");
+    }
+    if constexpr (std::is_same<T, float>::value) {
+        // grad_value is complete: the location / weight gradients of a small call come from the split kernel (bwd_split = 0 keeps the 8-lane one)
+        if (g.gv_skip == all_levels && g_bwd_split.load() && split_fits(pb, C) && split_small(pb)) {
+            e = launch_bwd_split<float>(pb, value, shapes, lsi, loc, aw, grad_out, grad_loc, grad_aw, g, stream);
+            if (e != hipSuccess) return hip_fail(e, "launch of the split backward kernel");
+            return MSDA_OK;
+        }
     }
     switch (C) {
         case 4: hipLaunchKernelGGL((msda::bwd_direct_kernel<T, (sizeof(T) == 4 ? 4 : 2)>), grid, block, lds, stream, value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw, g); break;
@@ -823,6 +873,12 @@ int forward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const in
     const size_t lds = msda::direct_lds_bytes<float>(g);
     if (lds > 64 * 1024) return fail(MSDA_ERR_BAD_DIMS, "too many levels (L=%d) for the level table in LDS", L);
     const dim3 grid(direct_grid(g)), block(msda::kDirectThreads);
+    if (split_fits(pb, C) && (variant == 3 || (variant != 1 && split_small(pb)))) {
+        ProfileScope prof(0, 3, 2, N, S, M, D, L, Lq, P, stream);
+        const hipError_t e = launch_fwd_split<msda::bf16_t>(pb, value, shapes, lsi, loc, aw, out, g, stream);
+        if (e != hipSuccess) return hip_fail(e, "launch of the split forward kernel (bf16)");
+        return MSDA_OK;
+    }
     ProfileScope prof(0, 1, 2, N, S, M, D, L, Lq, P, stream);
     const bool many = (int64_t)N * Lq * M >= 65536;
 #define MSDA_LAUNCH_FWD(CC)                                                                                                          \
@@ -928,6 +984,11 @@ int backward_bf16_impl(const msda::bf16_t *value, const int64_t *shapes, const i
         hipLaunchKernelGGL(kern, dim3(msda::levelsum_grid(lg)), dim3(msda::kLsThreads), ls_lds, stream, loc, aw, grad_out, grad_value, lg);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "launch of the level-sum backward kernel (bf16)");
         g.gv_skip = all_levels;
+        if (g_bwd_split.load() && split_fits(pb, C) && split_small(pb)) {
+            e = launch_bwd_split<msda::bf16_t>(pb, value, shapes, lsi, loc, aw, grad_out, grad_loc, grad_aw, g, stream);
+            if (e != hipSuccess) return hip_fail(e, "launch of the split backward kernel (bf16)");
+            return MSDA_OK;
+        }
     }
     switch (C) {
         case 4: hipLaunchKernelGGL((msda::bwd_direct_kernel<float, 4, msda::bf16_t>), grid, block, lds, stream, value, shapes, lsi, loc, aw, grad_out, gv32, grad_loc, grad_aw, g); break;
@@ -1145,7 +1206,7 @@ const char *msda_last_error(void) { return g_err; }
 
 int msda_set_option(const char *key, int value)
 {
-    if (key && !strcmp(key, "fwd_variant") && value >= 0 && value <= 2) { g_fwd_variant = value; return MSDA_OK; }
+    if (key && !strcmp(key, "fwd_variant") && value >= 0 && value <= 3) { g_fwd_variant = value; return MSDA_OK; }
     if (key && !strcmp(key, "fwd_prep_fused") && value >= 0 && value <= 2) { g_fwd_prep_fused = value; return MSDA_OK; }      // 1: decoder-shaped calls; 2: + encoder-shaped
     if (key && !strcmp(key, "bwd_variant") && (value == 0 || value == 1 || value == 4 || value == 5)) { g_bwd_variant = value; return MSDA_OK; }
     if (key && !strcmp(key, "band_lds_kb") && value >= 16 && value <= 150) { msda::band_options().lds_kb = value; return MSDA_OK; }
@@ -1161,6 +1222,7 @@ int msda_set_option(const char *key, int value)
     if (key && !strcmp(key, "tile_debug") && value >= 0 && value <= 65535) { msda::tiled_options().dbg = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_persist") && value >= 0 && value <= 65536) { msda::tiled_options().persist = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_levelsum") && (value == 0 || value == 1)) { g_levelsum = value; return MSDA_OK; }
+    if (key && !strcmp(key, "bwd_split") && (value == 0 || value == 1)) { g_bwd_split = value; return MSDA_OK; }
     if (key && !strcmp(key, "levelsum_lds_kb") && value >= 8 && value <= 150) { msda::levelsum_lds_kb() = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_grow") && (value == 0 || value == 1)) { msda::tiled_options().grow = value; return MSDA_OK; }
     if (key && !strcmp(key, "locality_monitor") && (value == 0 || value == 1)) {
@@ -1194,6 +1256,7 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "tile_margin")) { *value = msda::tiled_options().margin; return MSDA_OK; }
     if (key && !strcmp(key, "tile_persist")) { *value = msda::tiled_options().persist; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_levelsum")) { *value = g_levelsum; return MSDA_OK; }
+    if (key && !strcmp(key, "bwd_split")) { *value = g_bwd_split; return MSDA_OK; }
     if (key && !strcmp(key, "levelsum_lds_kb")) { *value = msda::levelsum_lds_kb(); return MSDA_OK; }
     if (key && !strcmp(key, "tile_grow")) { *value = msda::tiled_options().grow; return MSDA_OK; }
     if (key && !strcmp(key, "locality_monitor")) { *value = g_monitor_on; return MSDA_OK; }

@@ -153,6 +153,69 @@ __global__ __launch_bounds__(kDirectThreads, OCC) void fwd_direct_kernel(
     }
 }
 
+// ---- forward of SMALL calls (decoder-shaped: a thousand queries), D = 32, fp32 compute -------------------------------------------------
+// fwd_direct_kernel gives an item (query, head) to 8 lanes that walk its L*P points one after the other, four points' gathers in flight:
+// at 1092 queries x 2 images x 8 heads that is 2184 waves -- two per SIMD -- each of which sits through four rounds of memory latency:
+// 29 us for 51 MB.  Here an item takes 32 lanes: 8 channel lanes (4 channels each) x 4 point groups, every lane resolves ITS L*P/4 points
+// itself (the 8 lanes of a group read the same locations: one broadcast request) and has all their corner gathers in flight at once --
+// one round of latency instead of four, four times the waves --, then the four groups' partial sums meet in two exchange steps.
+// No LDS but the level table, no barrier after it.  Items in their natural order (image, query, head): a wave holds two heads of a query.
+constexpr int kSplitGroups = 4;           // point groups per item
+constexpr int kSplitMaxPts = 8;           // points a lane can take: L*P <= 32
+template <typename TV, int PPG>           // PPG: points per group (L*P / 4) as a compile-time constant; 0 = g.L * g.P / 4 at run time
+__global__ __launch_bounds__(kDirectThreads, 4) void fwd_split_kernel(
+    const TV *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
+    const float *__restrict__ loc, const float *__restrict__ aw, TV *__restrict__ out, const DirectGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LevelGeom *lv = reinterpret_cast<LevelGeom *>(smem);
+    load_levels(lv, shapes, lsi, g.L);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int j = lane & 7, pg = (lane >> 3) & (kSplitGroups - 1);
+    const long long n_items = (long long)g.N * g.Lq * g.M;
+    const long long item_raw = ((long long)blockIdx.x * kDirectThreads + threadIdx.x) >> 5;
+    const bool live = item_raw < n_items;
+    const long long item = live ? item_raw : n_items - 1;      // (a valid item whatever the lane: the exchange steps need every lane)
+    const int m = (int)(item % g.M);
+    const int b = (int)(item / ((long long)g.Lq * g.M));
+    const int LP = g.L * g.P, ppg = PPG ? PPG : LP / kSplitGroups;
+    const int row_elems = g.M * g.D, c0 = 4 * j;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < (PPG ? PPG : kSplitMaxPts); ++i) {
+        if (!PPG && i >= ppg) break;
+        const int gp = pg * ppg + i, l = gp / g.P;
+        const Pack<float, 2> xy = *reinterpret_cast<const Pack<float, 2> *>(loc + (item * LP + gp) * 2);
+        const float a = aw[item * LP + gp];
+        const LevelGeom G_ = lv[l];
+        int o[4];
+        float lh, lw;
+        resolve_point<float>(xy.v[0], xy.v[1], G_.H, G_.W, (b * g.S + G_.start) * row_elems + m * g.D, row_elems, o, lh, lw);
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const float f[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // (a corner outside the map reads the item's own first value row and masks it: no branch around the gather)
+            const Pack<TV, 4> raw = *reinterpret_cast<const Pack<TV, 4> *>(value + (o[k] >= 0 ? o[k] : (b * g.S) * row_elems + m * g.D) + c0);
+            // (the VALUE is masked, not the weight: 0 x inf would be NaN where the reference adds nothing)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += f[k] * (o[k] >= 0 ? to_compute<float, TV>(raw.v[c]) : 0.f);
+        }
+    }
+    // the four point groups of an item: lanes 8 and 16 apart
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        acc[c] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0x128, 0xF, 0xF, true));      // row_ror:8 = lane ^ 8 inside a row of 16
+        acc[c] += __shfl_xor(acc[c], 16, kWave);
+    }
+    if (live && pg == 0) {
+        Pack<TV, 4> o_;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o_.v[c] = to_storage<TV, float>(acc[c]);
+        *reinterpret_cast<Pack<TV, 4> *>(out + item * g.D + c0) = o_;
+    }
+}
+
 // ---- the module's element-wise work FUSED into the gather -----------------------------------------
 // fwd_direct_prep_kernel = fwd_direct_kernel whose point resolution reads the RAW projection of the module -- sampling offsets and
 // attention logits (reference ops/modules/ms_deform_attn.py:97-99), addressed with a row stride so that both come out of one GEMM -- and
@@ -289,6 +352,96 @@ __global__ __launch_bounds__(kDirectThreads, OCC) void fwd_direct_prep_kernel(
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- grad_sampling_loc / grad_attn_weight of SMALL calls whose grad_value is produced elsewhere (decoder-shaped: msda_levelsum.h takes
+// every level), D = 32, fp32 compute: the backward twin of fwd_split_kernel.  bwd_direct_kernel walks an item's L*P points one after the
+// other -- gathers, then three shuffle reductions, per point: sixteen rounds of memory latency per wave, 33 us at 1092 queries.  Here a
+// lane has its L*P/4 points' sixteen corner gathers in flight at once and the three sums of a point meet over the item's 8 channel lanes
+// in three DPP steps (no LDS crossbar).
+__device__ __forceinline__ float direct_group8_sum(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    return v;
+}
+
+template <typename TV, int PPG>
+__global__ __launch_bounds__(kDirectThreads, 4) void bwd_split_kernel(
+    const TV *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
+    const float *__restrict__ loc, const float *__restrict__ aw, const TV *__restrict__ grad_out,
+    float *__restrict__ grad_loc, float *__restrict__ grad_aw, const DirectGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LevelGeom *lv = reinterpret_cast<LevelGeom *>(smem);
+    load_levels(lv, shapes, lsi, g.L);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int j = lane & 7, pg = (lane >> 3) & (kSplitGroups - 1);
+    const long long n_items = (long long)g.N * g.Lq * g.M;
+    const long long item_raw = ((long long)blockIdx.x * kDirectThreads + threadIdx.x) >> 5;
+    const bool live = item_raw < n_items;
+    const long long item = live ? item_raw : n_items - 1;      // (a valid item whatever the lane: the reductions need every lane)
+    const int m = (int)(item % g.M);
+    const int b = (int)(item / ((long long)g.Lq * g.M));
+    const int LP = g.L * g.P, ppg = PPG ? PPG : LP / kSplitGroups;
+    const int row_elems = g.M * g.D, c0 = 4 * j;
+    float go[4];
+    {
+        const Pack<TV, 4> raw = *reinterpret_cast<const Pack<TV, 4> *>(grad_out + item * g.D + c0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) go[c] = to_compute<float, TV>(raw.v[c]);
+    }
+    float r_a[PPG ? PPG : kSplitMaxPts], r_w[PPG ? PPG : kSplitMaxPts], r_h[PPG ? PPG : kSplitMaxPts];
+#pragma unroll
+    for (int i = 0; i < (PPG ? PPG : kSplitMaxPts); ++i) {
+        if (!PPG && i >= ppg) break;      // (uniform)
+        const int gp = pg * ppg + i, l = gp / g.P;
+        const Pack<float, 2> xy = *reinterpret_cast<const Pack<float, 2> *>(loc + (item * LP + gp) * 2);
+        const float a = aw[item * LP + gp];
+        const LevelGeom G_ = lv[l];
+        int o[4];
+        float lh, lw;
+        resolve_point<float>(xy.v[0], xy.v[1], G_.H, G_.W, (b * g.S + G_.start) * row_elems + m * g.D, row_elems, o, lh, lw);
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        float v[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const Pack<TV, 4> raw = *reinterpret_cast<const Pack<TV, 4> *>(value + (o[k] >= 0 ? o[k] : (b * g.S) * row_elems + m * g.D) + c0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[k][c] = o[k] >= 0 ? to_compute<float, TV>(raw.v[c]) : 0.f;
+        }
+        float s_a = 0.f, s_w = 0.f, s_h = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float tgv = go[c] * a;
+            s_a += go[c] * (hh * hw * v[0][c] + hh * lw * v[1][c] + lh * hw * v[2][c] + lh * lw * v[3][c]);
+            s_w += (hh * (v[1][c] - v[0][c]) + lh * (v[3][c] - v[2][c])) * tgv;
+            s_h += (hw * (v[2][c] - v[0][c]) + lw * (v[3][c] - v[1][c])) * tgv;
+        }
+        // (with the point count known the three sums are kept and stored behind the loop: no store sits between the points' gathers)
+        r_a[i] = direct_group8_sum(s_a);
+        r_w[i] = (float)G_.W * direct_group8_sum(s_w);
+        r_h[i] = (float)G_.H * direct_group8_sum(s_h);
+        if (!PPG && live && j == 0) {
+            grad_aw[item * LP + gp] = r_a[i];
+            Pack<float, 2> gl;
+            gl.v[0] = r_w[i];
+            gl.v[1] = r_h[i];
+            *reinterpret_cast<Pack<float, 2> *>(grad_loc + (item * LP + gp) * 2) = gl;
+        }
+    }
+    if (PPG && live && j == 0) {
+#pragma unroll
+        for (int i = 0; i < PPG; ++i) {
+            const int gp = pg * PPG + i;
+            grad_aw[item * LP + gp] = r_a[i];
+            Pack<float, 2> gl;
+            gl.v[0] = r_w[i];
+            gl.v[1] = r_h[i];
+            *reinterpret_cast<Pack<float, 2> *>(grad_loc + (item * LP + gp) * 2) = gl;
+        }
     }
 }
 

@@ -548,6 +548,58 @@ def test_random_d32_problems_on_the_routed_and_band_kernels(seed):
         assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg, (variant, z["value"].shape, z["loc"].shape)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_split_kernels_against_oracle_and_the_eight_lane_kernels(seed):
+    """fwd_split_kernel / bwd_split_kernel (msda_direct.h: 32 lanes per (query, head), every gather of a lane in flight at once -- the
+    automatic choice for small calls at D = 32) on seeded random DECODER-shaped problems whose L * P is a multiple of four (the run-time
+    point count and the L = P = 4 instance), dropped samples and border corners included: against the oracle, against the 8-lane direct
+    kernels they replace, and with the profile records saying which forward kernel ran."""
+    rng = np.random.default_rng(9100 + seed)
+    L, P = [(4, 4), (4, 4), (2, 2), (1, 4), (3, 4), (4, 1), (2, 8), (4, 8), (2, 6), (4, 2), (1, 8), (4, 3), (5, 4), (4, 4), (3, 8), (2, 4)][seed]
+    shapes = [(int(rng.integers(1, 41)), int(rng.integers(1, 41))) for _ in range(L)]
+    N, M, D = int(rng.integers(1, 4)), int(rng.choice([1, 2, 3, 8])), 32
+    Lq = int(rng.integers(1, 400))
+    call = W.Call("split", N, M, D, P, shapes, Lq, False)
+    g = torch.Generator().manual_seed(seed)
+    S = call.S
+    z = dict(value=torch.randn(N, S, M, D, generator=g), aw=torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P).contiguous(),
+             grad_out=torch.randn(N, Lq, M * D, generator=g), loc=(torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.3 - 0.15).contiguous())
+    z["shapes"], z["lsi"] = W.level_tensors(call)
+    zn = {k: v.numpy() for k, v in z.items()}
+    oout = O.forward(zn["value"], zn["shapes"], zn["lsi"], zn["loc"], zn["aw"])
+    ogv, ogl, oga = O.backward(zn["value"], zn["shapes"], zn["lsi"], zn["loc"], zn["aw"], zn["grad_out"])
+    tf, tg = tols(np.float32)
+    v, sh, ls, loc, aw, go = (dev(zn[k]) for k in ("value", "shapes", "lsi", "loc", "aw", "grad_out"))
+    try:
+        res = {}
+        for split in (1, 0):
+            _lib.set_option("fwd_variant", 3 if split else 1)
+            _lib.set_option("bwd_split", split)
+            _lib.set_option("bwd_variant", 1)
+            outs = []
+            ran = _profiled_variants(lambda: outs.append(MSDA.ms_deform_attn_forward(v, sh, ls, loc, aw, 64)))
+            assert ran == [("fwd", 3 if split else 1)], ran
+            gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, ls, loc, aw, go, 64)
+            assert rel_err(outs[0], oout) < tf, (split, L, P)
+            assert rel_err(gv, ogv) < tg and rel_err(gl, ogl) < tg and rel_err(ga, oga) < tg, (split, L, P)
+            res[split] = (outs[0], gl, ga)
+        for a, b in zip(res[0], res[1]):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max() + 1e-30))
+        # bf16 storage: the split kernels against the 8-lane ones on the same rounded inputs
+        vb, gob = v.bfloat16(), go.bfloat16()
+        resb = {}
+        for split in (1, 0):
+            _lib.set_option("fwd_variant", 3 if split else 1)
+            _lib.set_option("bwd_split", split)
+            out = MSDA.ms_deform_attn_forward(vb, sh, ls, loc, aw, 64)
+            gv, gl, ga = MSDA.ms_deform_attn_backward(vb, sh, ls, loc, aw, gob, 64)
+            resb[split] = (out.float(), gl, ga)
+        for a, b in zip(resb[0], resb[1]):
+            assert torch.allclose(a, b, rtol=2e-2, atol=2e-2 * float(b.abs().max() + 1e-30))
+    finally:
+        _lib.set_option("bwd_split", 1)
+
+
 def _profiled_variants(fn):
     _lib.profile_enable(8)
     fn()
