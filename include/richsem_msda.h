@@ -118,6 +118,8 @@ const char *msda_last_error(void);
  *                     in an f64 LDS window by its own kernel and written once.  Calls with Lq*P <= 2^20 whose levels fit 16 windows
  *                     hand over ALL levels: no global atomics, no zero-fill, sums exact to fp32 rounding whatever the order.  Otherwise only
  *                     levels that fit LDS whole and receive >= 2 sampling points per pixel.  0 = off (row atomics only)
+ *   "bwd_split"       1 (default) = when the level-sum kernel has produced all of grad_value, small calls (as "fwd_variant" 3) take
+ *                     grad_sampling_loc / grad_attn_weight from the split kernel (32 lanes per (query, head)); 0 = the 8-lane kernel
  *   "tile_persist"    persistent workgroups walking the work items (default 512 = 2 per CU; 0 = one workgroup per item)
  *   "tile_debug"      diagnostic bits (stage-stamp kernel selection)
  * Unknown key or value out of range -> MSDA_ERR_BAD_OPTION.  Options change speed, never results. */
