@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 CASES = OP_CASES
 # 1 = direct kernels, 2 = LDS-window forward kernel, 4 = routed pixel-stationary backward -- each where applicable, else the direct
 # kernels (variant 3, the pixel-stationary backward with candidates by geometry, was deleted in round 3)
-VARIANTS = [0, 1, 2, 4]   # 0 automatic; forward: 1 direct, 2 LDS windows; backward: 1 direct (+ level-sum), 4 routed
+VARIANTS = [0, 1, 2, 3, 4]   # 0 automatic; forward: 1 direct, 2 LDS windows, 3 split (32 lanes per item); backward: 1 direct (+ level-sum), 4 routed
 
 
 def dev(a):
@@ -49,9 +49,10 @@ def _restore_variants():
 
 
 def run_gpu(z, variant=0):
-    """variant: 0 automatic; 1 direct kernels; 2 window forward + routed backward; 4 direct forward + routed backward"""
-    _lib.set_option("fwd_variant", {0: 0, 1: 1, 2: 2, 4: 1}[variant])
-    _lib.set_option("bwd_variant", {0: 0, 1: 1, 2: 4, 4: 4}[variant])
+    """variant: 0 automatic; 1 direct kernels; 2 window forward + routed backward; 3 split forward (where it applies) + direct
+    backward; 4 direct forward + routed backward"""
+    _lib.set_option("fwd_variant", {0: 0, 1: 1, 2: 2, 3: 3, 4: 1}[variant])
+    _lib.set_option("bwd_variant", {0: 0, 1: 1, 2: 4, 3: 1, 4: 4}[variant])
     v, sh, ls, loc, aw, go = (dev(z[k]) for k in ("value", "shapes", "lsi", "loc", "aw", "grad_out"))
     out = MSDA.ms_deform_attn_forward(v, sh, ls, loc, aw, 64)
     gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, ls, loc, aw, go.contiguous(), 64)
@@ -263,11 +264,11 @@ def test_full_size_properties(which, n_images):
     # kernel variants agree
     res = {}
     for variant in VARIANTS:
-        _lib.set_option("fwd_variant", {0: 0, 1: 1, 2: 2, 4: 1}[variant])
-        _lib.set_option("bwd_variant", {0: 0, 1: 1, 2: 4, 4: 4}[variant])
+        _lib.set_option("fwd_variant", {0: 0, 1: 1, 2: 2, 3: 3, 4: 1}[variant])
+        _lib.set_option("bwd_variant", {0: 0, 1: 1, 2: 4, 3: 1, 4: 4}[variant])
         res[variant] = (f(t["value"]),) + tuple(MSDA.ms_deform_attn_backward(
             t["value"], t["shapes"], t["lsi"], t["loc"], t["aw"], t["grad_out"], 64))
-    for other in (0, 2, 4):
+    for other in (0, 2, 3, 4):
         for a, b in zip(res[1], res[other]):
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-3)
 
