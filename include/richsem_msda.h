@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RICHSEM_MSDA_ABI_VERSION 7
+#define RICHSEM_MSDA_ABI_VERSION 8
 
 /* Return codes: 0 = success; negative = argument error detected on the host (nothing was
  * launched); positive = hipError_t reported by the runtime. */
@@ -67,7 +67,8 @@ enum {
                                  /* reference: ms_deform_im2col_cuda.cuh:255-263)           */
     MSDA_ERR_MISALIGNED = -5,    /* a data pointer is not aligned to its element size        */
     MSDA_ERR_NO_DEVICE = -6,     /* no gfx950 device / code object not loadable              */
-    MSDA_ERR_BAD_OPTION = -7
+    MSDA_ERR_BAD_OPTION = -7,
+    MSDA_ERR_NOT_ON_CPU = -8     /* the host ("_cpu") variants: declared, as in the reference, and not implemented */
 };
 
 typedef void *msda_stream_t; /* hipStream_t; NULL = the default stream */
@@ -194,6 +195,20 @@ int msda_backward_f64(const double *value, const int64_t *spatial_shapes, const 
                       double *grad_value, double *grad_sampling_loc, double *grad_attn_weight,
                       const int64_t *shapes_host, const int64_t *level_start_host,
                       msda_stream_t stream);
+
+/* ---- host ("_cpu") variants of both (ABI v8).  The reference declares ms_deform_attn_cpu_forward / _backward
+ * (src/cpu/ms_deform_attn_cpu.h:14-31) and implements neither: both bodies are AT_ERROR("Not implement on cpu")
+ * (src/cpu/ms_deform_attn_cpu.cpp:17-41), and the dispatcher never reaches them (src/ms_deform_attn.h:38,60 raise
+ * "Not implemented on the CPU" for a tensor that is not on the device).  These two do the same: they read no
+ * argument, launch nothing, set msda_last_error() to the reference's text and return MSDA_ERR_NOT_ON_CPU.  This
+ * library has no CPU implementation of the operator (the restatement under oracle/ is test infrastructure). */
+int msda_forward_cpu(const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                     const void *sampling_loc, const void *attn_weight,
+                     int N, int S, int M, int D, int L, int Lq, int P, int im2col_step, void *out);
+int msda_backward_cpu(const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                      const void *sampling_loc, const void *attn_weight, const void *grad_out,
+                      int N, int S, int M, int D, int L, int Lq, int P, int im2col_step,
+                      void *grad_value, void *grad_sampling_loc, void *grad_attn_weight);
 
 /* ---- bf16 storage, fp32 compute (new capability: the reference dispatches float / double only,
  * src/cuda/ms_deform_attn_cuda.cu:64,134) -------------------------------------------------------

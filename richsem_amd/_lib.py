@@ -14,9 +14,10 @@ _lib = None
 ERR_NAMES = {
     -1: "MSDA_ERR_NULL_POINTER", -2: "MSDA_ERR_BAD_DIMS", -3: "MSDA_ERR_IM2COL_STEP",
     -4: "MSDA_ERR_TOO_LARGE", -5: "MSDA_ERR_MISALIGNED", -6: "MSDA_ERR_NO_DEVICE", -7: "MSDA_ERR_BAD_OPTION",
+    -8: "MSDA_ERR_NOT_ON_CPU",
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def raw_stream(dev=None):
@@ -58,7 +59,7 @@ SYMBOLS = [
     "msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option",
     "msda_profile_enable", "msda_profile_collect", "msda_tiled_plan", "msda_levelsum_plan", "msda_debug_stamps", "msda_debug_stats",
     "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64",
-    "msda_forward_bf16", "msda_backward_bf16",
+    "msda_forward_bf16", "msda_backward_bf16", "msda_forward_cpu", "msda_backward_cpu",
     "msda_prep_forward_f32", "msda_prep_forward_f64", "msda_prep_backward_f32", "msda_prep_backward_f64",
     "msda_prep_forward_bf16", "msda_prep_backward_bf16", "msda_forward_prep_f32", "msda_forward_prep_f64", "msda_forward_prep_bf16",
     "msda_mask_rows_f32", "msda_mask_rows_f64", "msda_mask_rows_bf16",

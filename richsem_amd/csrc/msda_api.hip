@@ -1202,6 +1202,17 @@ extern "C" {
 
 int msda_abi_version(void) { return RICHSEM_MSDA_ABI_VERSION; }
 
+// the host variants the reference declares and does not implement (src/cpu/ms_deform_attn_cpu.cpp:17-41)
+int msda_forward_cpu(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int, int, int, int, int, int, void *)
+{
+    return fail(MSDA_ERR_NOT_ON_CPU, "Not implement on cpu");
+}
+int msda_backward_cpu(const void *, const int64_t *, const int64_t *, const void *, const void *, const void *, int, int, int, int, int, int, int,
+                      int, void *, void *, void *)
+{
+    return fail(MSDA_ERR_NOT_ON_CPU, "Not implement on cpu");
+}
+
 const char *msda_last_error(void) { return g_err; }
 
 int msda_set_option(const char *key, int value)

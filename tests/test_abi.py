@@ -100,6 +100,21 @@ def test_argument_errors_are_reported_not_printed(lib):
         _lib.check(-5)
 
 
+def test_host_variants_are_declared_and_not_implemented_as_in_the_reference(lib):
+    """msda_forward_cpu / msda_backward_cpu (SURVEY.md section 8b "host (_cpu) variants of both"): the reference's bodies are
+    AT_ERROR("Not implement on cpu") (src/cpu/ms_deform_attn_cpu.cpp:17-41); these return MSDA_ERR_NOT_ON_CPU with that text, touch no
+    argument and launch nothing (called here with null pointers, on a machine without a GPU)."""
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.msda_forward_cpu.argtypes = [vp] * 5 + [ci] * 8 + [vp]
+    lib.msda_forward_cpu.restype = ci
+    lib.msda_backward_cpu.argtypes = [vp] * 6 + [ci] * 8 + [vp] * 3
+    lib.msda_backward_cpu.restype = ci
+    assert lib.msda_forward_cpu(*([None] * 5), 1, 1, 1, 1, 1, 1, 1, 64, None) == -8
+    assert _lib.last_error() == "Not implement on cpu"
+    assert lib.msda_backward_cpu(*([None] * 6), 1, 1, 1, 1, 1, 1, 1, 64, None, None, None) == -8
+    assert _lib.last_error() == "Not implement on cpu"
+
+
 def test_im2col_step_contract_matches_reference(lib):
     """reference ms_deform_attn_cuda.cu:48-52: step' = min(N, step); N % step' must be 0."""
     shapes, lsi = [[6, 4], [3, 2]], [0, 24]
