@@ -701,6 +701,9 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
             else load_level_ops(loc, aw, item, (unsigned)LP, (unsigned)(lb * g.P), g.P, j, nxt);
             // ---- stage this phase's windows: 64-B pixel half-rows, 16 B per lane -------------------------------------
             for (int l = lb; l < le; ++l) {
+#if defined(FWD_ABLATE) && FWD_ABLATE == 1      // (diagnostic: no window fills -- wrong results)
+                continue;
+#endif
                 const int wr0 = uni(hdr->r[l].wr0), wc0 = uni(hdr->r[l].wc0), nwc = uni(hdr->r[l].nwc);
                 const int npx = uni(hdr->r[l].nwr) * nwc, Wl = uni(hdr->W[l]), Hl = uni(hdr->H[l]);
                 const TV *src = value + (head_major ? ((int64_t)(b * g.M + m) * g.S + uni(hdr->start[l])) * kTD
@@ -761,6 +764,9 @@ __global__ __launch_bounds__(GC == 16 ? 512 : 1024, GC == 16 ? 4 : 1) void tiled
 
             // ---- gather -------------------------------------------------------------------------------------
             for (int l = lb; l < le; ++l) {
+#if defined(FWD_ABLATE) && FWD_ABLATE == 2      // (diagnostic: no gather -- wrong results)
+                continue;
+#endif
                 LevelOps<kGatherQPG> cur = nxt;
                 [[maybe_unused]] const LevelRaw<PREP ? kGatherQPG : 1, REF4> rcur = rnxt;
                 if (l + 1 < le) {
