@@ -121,6 +121,8 @@ const char *msda_last_error(void);
  *                     levels that fit LDS whole and receive >= 2 sampling points per pixel.  0 = off (row atomics only)
  *   "bwd_split"       1 (default) = when the level-sum kernel has produced all of grad_value, small calls (as "fwd_variant" 3) take
  *                     grad_sampling_loc / grad_attn_weight from the split kernel (32 lanes per (query, head)); 0 = the 8-lane kernel
+ *   "profile_filter"  which calls msda_profile_enable brackets with its event pair: 0 (default) = every call; (kind + 1) * 16 + variant =
+ *                     only those (kind 0 forward / 1 backward, variant as in msda_profile_record) -- an event pair costs a call ~4 us
  *   "tile_persist"    persistent workgroups walking the work items (default 512 = 2 per CU; 0 = one workgroup per item)
  *   "tile_debug"      diagnostic bits (stage-stamp kernel selection)
  * Unknown key or value out of range -> MSDA_ERR_BAD_OPTION.  Options change speed, never results. */

@@ -72,6 +72,7 @@ std::mutex g_prof_mutex;
 std::vector<ProfileSlot> g_prof_slots;
 int g_prof_used = 0;
 std::atomic<bool> g_prof_on{false};
+std::atomic<int> g_prof_filter{0};      // 0: every call is bracketed; else only calls of (kind + 1) * 16 + variant (option "profile_filter")
 
 // RAII bracket around the main kernel launch of one call
 struct ProfileScope {
@@ -82,6 +83,10 @@ struct ProfileScope {
         : stream(st)
     {
         if (!g_prof_on.load(std::memory_order_relaxed)) return;
+        // (an event pair is two more packets on the stream -- ~4 us of a call's time on MI355X: a caller that times a whole step brackets
+        // only the kernel it wants the duration of)
+        const int f = g_prof_filter.load(std::memory_order_relaxed);
+        if (f && f != (kind + 1) * 16 + variant) return;
         std::lock_guard<std::mutex> lock(g_prof_mutex);
         if (g_prof_used >= (int)g_prof_slots.size()) return;
         slot = &g_prof_slots[g_prof_used++];
@@ -1234,6 +1239,7 @@ int msda_set_option(const char *key, int value)
     if (key && !strcmp(key, "tile_persist") && value >= 0 && value <= 65536) { msda::tiled_options().persist = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_levelsum") && (value == 0 || value == 1)) { g_levelsum = value; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_split") && (value == 0 || value == 1)) { g_bwd_split = value; return MSDA_OK; }
+    if (key && !strcmp(key, "profile_filter") && value >= 0 && value <= 47) { g_prof_filter = value; return MSDA_OK; }
     if (key && !strcmp(key, "levelsum_lds_kb") && value >= 8 && value <= 150) { msda::levelsum_lds_kb() = value; return MSDA_OK; }
     if (key && !strcmp(key, "tile_grow") && (value == 0 || value == 1)) { msda::tiled_options().grow = value; return MSDA_OK; }
     if (key && !strcmp(key, "locality_monitor") && (value == 0 || value == 1)) {
@@ -1268,6 +1274,7 @@ int msda_get_option(const char *key, int *value)
     if (key && !strcmp(key, "tile_persist")) { *value = msda::tiled_options().persist; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_levelsum")) { *value = g_levelsum; return MSDA_OK; }
     if (key && !strcmp(key, "bwd_split")) { *value = g_bwd_split; return MSDA_OK; }
+    if (key && !strcmp(key, "profile_filter")) { *value = g_prof_filter; return MSDA_OK; }
     if (key && !strcmp(key, "levelsum_lds_kb")) { *value = msda::levelsum_lds_kb(); return MSDA_OK; }
     if (key && !strcmp(key, "tile_grow")) { *value = msda::tiled_options().grow; return MSDA_OK; }
     if (key && !strcmp(key, "locality_monitor")) { *value = g_monitor_on; return MSDA_OK; }
