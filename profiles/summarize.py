@@ -51,6 +51,8 @@ def ours(name):
 
 def main():
     d, tag = sys.argv[1], sys.argv[2]
+    if not os.path.isfile(os.path.join(d, "bench.json")):      # (never overwrite the committed summaries with an empty one)
+        sys.exit(f"{d}: no bench.json -- was the collection run?")
     out = [f"# rocprofv3 summary {tag}", ""]
     try:
         line = json.loads(open(os.path.join(d, "bench.json")).read().strip().splitlines()[-1])
