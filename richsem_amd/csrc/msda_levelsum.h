@@ -103,7 +103,9 @@ __global__ __launch_bounds__(kLsThreads) void bwd_levelsum_kernel(const float *_
     int pair, t;
     if (!decode_block(blockIdx.x, g.N * g.M, g.nlev * g.nslices, pair, t)) return;
     // the slices of one level are neighbours in the XCD-local order: they read the same loc / attn lines
-    const int li = t / g.nslices, slice = t - li * g.nslices;
+    // (entries are taken LAST FIRST -- round 5: the coarse levels, whose single window takes every point of the call, are the long workgroups;
+    // launched behind the 512 short row-band workgroups of level 0 they ran as a half-empty last round)
+    const int li = g.nlev - 1 - t / g.nslices, slice = t - (t / g.nslices) * g.nslices;
     const int b = pair / g.M, m = pair - b * g.M;
     const int l = g.lev[li], H = g.H[li], W = g.W[li], r0 = g.r0[li], nr = g.nr[li];
     const int npx = nr * W;   // the window: rows [r0, r0 + nr) of the level
