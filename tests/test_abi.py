@@ -51,11 +51,15 @@ def test_abi_version(lib):
 
 
 def test_options_roundtrip(lib):
-    for key in ("fwd_variant", "bwd_variant"):
+    for key in ("fwd_variant", "bwd_variant", "bwd_split", "profile_filter"):
         old = _lib.get_option(key)
         _lib.set_option(key, 1)
         assert _lib.get_option(key) == 1
         _lib.set_option(key, old)
+    with pytest.raises(RuntimeError, match="MSDA_ERR_BAD_OPTION"):
+        _lib.set_option("profile_filter", 48)
+    with pytest.raises(RuntimeError, match="MSDA_ERR_BAD_OPTION"):
+        _lib.set_option("fwd_variant", 4)
     assert _lib.get_option("locality_monitor") == 1          # on by default
     _lib.set_option("locality_monitor", 0)
     assert _lib.get_option("locality_monitor") == 0

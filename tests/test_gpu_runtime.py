@@ -130,3 +130,36 @@ def test_routed_backward_state_survives_changing_shapes():
                     assert _close(a, torch.from_numpy(b).cuda(), 2e-4), rep
     finally:
         _lib.set_option("bwd_variant", 0)
+
+
+def test_profile_filter_brackets_only_the_calls_it_names():
+    """Library option ``profile_filter`` (bench.py: only the dominant kernel is bracketed with events inside the timed region): 0 = every call,
+    (kind + 1) * 16 + variant = only those; results do not depend on it."""
+    enc, dec = W.shrunk(W.call_E(2), 4), W.shrunk(W.call_Dd(2), 4)
+    te, td = (W.make_inputs(c, "init", seed=9, device="cuda") for c in (enc, dec))
+    ref = _run(te)
+    torch.cuda.synchronize()
+
+    def records(flt):
+        _lib.set_option("profile_filter", flt)
+        _lib.profile_enable(16)
+        out = _run(te)
+        _run(td)
+        torch.cuda.synchronize()
+        recs = [(r["kind"], r["variant"]) for r in _lib.profile_collect()]
+        _lib.profile_enable(0)
+        return out, recs
+    try:
+        _lib.set_option("locality_monitor", 0)
+        _lib.set_option("fwd_variant", 2)
+        out, everything = records(0)
+        assert sorted(everything) == sorted([("fwd", 2), ("bwd", 4), ("fwd", 3), ("bwd", 1)]), everything
+        out, only = records((1 + 1) * 16 + 4)
+        assert only == [("bwd", 4)], only
+        assert torch.equal(out[0], ref[0])
+        out, only = records((0 + 1) * 16 + 3)
+        assert only == [("fwd", 3)], only
+    finally:
+        _lib.set_option("profile_filter", 0)
+        _lib.set_option("fwd_variant", 0)
+        _lib.set_option("locality_monitor", 1)
