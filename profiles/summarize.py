@@ -11,8 +11,8 @@ import os
 import sys
 
 
-def kernel_stats(d):
-    f = glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv"))
+def kernel_stats(d, sub="trace"):
+    f = glob.glob(os.path.join(d, sub, "*", "*_kernel_stats.csv"))
     rows = list(csv.DictReader(open(f[0]))) if f else []
     return [(r["Name"], int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, float(r["Percentage"]))
             for r in rows]
@@ -68,6 +68,14 @@ def main():
         else:
             other_calls, other_ms, other_pct = other_calls + calls, other_ms + tot, other_pct + pct
     out.append(f"| (PyTorch / MIOpen / hipBLASLt / RCCL / memset kernels of the comparison rows and the harness) | {other_calls} | | {other_ms:.2f} | {other_pct:.1f} |")
+    init_rows = [r for r in kernel_stats(d, "trace_init") if ours(r[0])]
+    if init_rows:
+        out += ["", "### the headline distribution alone: `... bench.py --steps 10 --warmup 3 --loc init --no-bf16 --no-em --no-settle --no-cpu-baseline --no-full-step`", "",
+                "(the trace above mixes the init / sigma4 / uniform distributions, bf16 storage and the mosaic shape in one row per kernel; `roofline.avg_launch_us` of the",
+                "bench line is the routed backward at the init pattern: `rps_route_kernel` + `rps_tile_kernel` of THIS table, plus the 1-2 us of its event pair)", "",
+                "| kernel | calls | avg µs | total ms | % |", "|---|---|---|---|---|"]
+        for name, calls, avg, tot, pct in init_rows:
+            out.append(f"| `{name[:90]}` | {calls} | {avg:.1f} | {tot:.2f} | {pct:.1f} |")
     out += ["", "### per (kernel, grid): E and Dd launches of the same kernel separated", "",
             "| kernel | grid (threads) | launches | avg µs |", "|---|---|---|---|"]
     for (name, grid), v in sorted(per_grid(d).items()):

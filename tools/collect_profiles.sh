@@ -12,6 +12,8 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 python3 $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json; echo
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-full-step > $OUT/trace_bench.json 2> $OUT/trace.err
+# the headline distribution alone (no sigma4 / uniform / bf16 / mosaic passes): the rows of the routed kernels in THIS trace are what `roofline.avg_launch_us` is compared with
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_init -- python3 $ROOT/bench.py --steps 10 --warmup 3 --loc init --no-bf16 --no-em --no-settle --no-cpu-baseline --no-full-step > $OUT/trace_init_bench.json 2> $OUT/trace_init.err
 # (--no-em --no-settle: the persistent kernels have ONE grid size whatever the shape, so the headline shape E and the mosaic shape Em are counted in passes of their own)
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full-step --no-em --no-settle > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full-step --no-em --no-settle > $OUT/pmc_write.json 2> $OUT/pmc_write.err
